@@ -1,0 +1,160 @@
+/* statmc.h -- C ABI of libstatmc_hip.so: the MI355X (gfx950) implementation of StatMC's
+ * per-pixel statistics accumulation and statistics-gated cross-bilateral filter.
+ *
+ * This is the drop-in boundary.  Every entry point names the reference interface it replaces
+ * (paths relative to the StatMC repository).  Conventions:
+ *   - plain C types only; device memory is passed as raw pointers (hipMalloc'ed by the caller,
+ *     by statmc_malloc, or by any other HIP allocator in the same process, e.g. PyTorch-ROCm);
+ *   - `stream` is a hipStream_t cast to void* (NULL = the default stream); every call is
+ *     asynchronous on it, exactly like the reference enqueues on its one cv::cuda::Stream
+ *     (src/statistics/estimator.h:326); statmc_synchronize() closes an iteration;
+ *   - return value: 0 on success, a negative STATMC_ERR_* otherwise; statmc_last_error()
+ *     returns a thread-local message.  (The reference has no error convention at these call
+ *     sites -- OpenCV throws)
+ *   - images are row-major with interleaved channels, exactly the cv::Mat / GpuMat layout of
+ *     src/statistics/buffer.h:19-71: int32 x1 for "n", float32 x1 or x3 otherwise.  `step` is
+ *     the row pitch in bytes.  This build requires tightly packed rows
+ *     (step == cols * channels * 4) and returns STATMC_ERR_UNSUPPORTED otherwise.
+ */
+#ifndef STATMC_H
+#define STATMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STATMC_OK 0
+#define STATMC_ERR_INVALID (-1)     /* bad argument (null pointer, zero size, radius too large) */
+#define STATMC_ERR_UNSUPPORTED (-2) /* valid in the reference, not supported by this build */
+#define STATMC_ERR_HIP (-3)         /* a HIP runtime call failed; see statmc_last_error() */
+#define STATMC_ERR_NO_DEVICE (-4)   /* no gfx950 device / setup not called */
+
+#define STATMC_MAX_BUFFERS 16  /* nBuffers per filter call (reference passes a uchar) */
+#define STATMC_MAX_GBUFFERS 8
+
+const char *statmc_last_error(void);
+
+/* Replaces cv::cuda::stat_denoiser::setup()  (src/statistics/estimator.h:280).
+ * Selects the device, uploads the Student-t quantile tables. Idempotent per device. */
+int statmc_setup(int device);
+
+/* The reference picks the significance level at compile time by pointing `t_quantiles` at one
+ * of three tables (README.md:149,158): 0 -> 0.005 (default), 1 -> 0.002, 2 -> 0.05. */
+int statmc_set_significance(int alpha_index);
+int statmc_get_significance(void);
+
+/* Device memory + copies: the GpuMat role inside Buffer (src/statistics/buffer.h:25,57-63). */
+int statmc_malloc(void **dev_ptr, size_t bytes);
+int statmc_free(void *dev_ptr);
+int statmc_memset(void *dev_ptr, int value, size_t bytes, void *stream);
+int statmc_upload(void *dev_dst, const void *host_src, size_t bytes, void *stream);   /* Buffer::upload */
+int statmc_download(void *host_dst, const void *dev_src, size_t bytes, void *stream); /* Buffer::download */
+int statmc_stream_create(void **stream);
+int statmc_stream_destroy(void *stream);
+/* Replaces cv::cuda::stat_denoiser::synchronize(stream)  (src/statistics/estimator.cpp:571-573). */
+int statmc_synchronize(void *stream);
+
+/* Device image descriptor: what one cv::cuda::PtrStepSzb entry of the reference's pointer
+ * tables carries (src/statistics/estimator.cpp:35-84). */
+typedef struct statmc_image {
+    void *data;   /* device pointer */
+    size_t step;  /* bytes per row */
+    int32_t cols; /* width  */
+    int32_t rows; /* height */
+} statmc_image;
+
+/* Argument block of cv::cuda::stat_denoiser::filter<T>, in the reference's order
+ * (src/statistics/estimator.cpp:437-459 for T=float, 465-487 for T=float3).  The reference
+ * passes the per-buffer tables as device arrays of PtrStepSzb; here they are host arrays of
+ * n_buffers descriptors (they are copied into the kernel arguments). */
+typedef struct statmc_filter_args {
+    uint8_t n_buffers;        /* floatBufferCounts / rgbBufferCounts [DenoiseGroup] */
+    uint16_t width, height;
+    float filter_ds_factor;   /* -0.5 / filtersd^2   (estimator.h:259) */
+    uint8_t filter_radius;
+    uint8_t denoise_film;     /* bool denoiseFilm */
+    const statmc_image *n;    /* int32 x1 */
+    const statmc_image *mean; /* T */
+    const statmc_image *m2;   /* T */
+    const statmc_image *m3;   /* T */
+    const statmc_image *film; /* T: per-buffer untransformed means (tX-bY-film-mean) */
+    statmc_image film_buffer; /* float3 "film" image; colour input of buffer 0 iff denoise_film */
+    const statmc_image *g_buffers;     /* n_g_buffers feature-mean images */
+    const uint8_t *g_channel_counts;   /* 1 or 3 per G-buffer */
+    const float *g_dr_factors;         /* -0.5 / sd_g^2  (estimator.cpp:16) */
+    size_t n_g_buffers;
+    const statmc_image *mean_corr;     /* out, T */
+    const statmc_image *discriminator; /* out, T */
+    const statmc_image *film_filtered; /* out, T: tX-bY-film-mean-f */
+    statmc_image film_filtered_buffer; /* out, float3 "film-f"; output of buffer 0 iff denoise_film */
+    void *stream;
+    /* ---- extension (all-zero = reference behaviour: filter the whole image) --------------
+     * Output region of interest, used by the multi-GPU block decomposition: outputs are
+     * written for x in [roi_x0, roi_x1), y in [roi_y0, roi_y1) only; the window is still
+     * clipped to the full [0,width) x [0,height) local image. */
+    int32_t roi_x0, roi_y0, roi_x1, roi_y1;
+} statmc_filter_args;
+
+/* Replace cv::cuda::stat_denoiser::filter<float> / filter<float3>: pre-pass + window filter. */
+int statmc_filter_f32(const statmc_filter_args *args);
+int statmc_filter_f32x3(const statmc_filter_args *args);
+
+/* The two halves of filter<T>, separately callable (multi-GPU runs exchange halos between
+ * them; the bench times them separately).  channels = 1 or 3 selects T. */
+int statmc_prepass(const statmc_filter_args *args, int channels);     /* -> mean_corr, discriminator */
+int statmc_window_filter(const statmc_filter_args *args, int channels); /* mean_corr, discriminator -> filtered */
+
+/* Replaces cv::cuda::stat_denoiser::calculateMeanVars<T> (commented-out call,
+ * src/statistics/estimator.cpp:501-521) and its CPU stand-in (estimator.cpp:524-568):
+ * film_var = film_m2 / ((n-1)*n).  row_n_quirk != 0 reproduces the CPU loop reading n once
+ * per row (estimator.cpp:540,558). */
+int statmc_calculate_mean_vars(uint8_t n_buffers, uint16_t width, uint16_t height, int channels,
+                               const statmc_image *n, const statmc_image *film_m2,
+                               const statmc_image *film_var, int row_n_quirk, void *stream);
+
+/* ---- accumulation: the GPU form of StatTile<T>::Add[Transform]SampleM{1,2,3}
+ * (src/statistics/estimator.h:162-232) + Estimator::Merge[Transform]Tile
+ * (src/statistics/estimator.cpp:341-407) for a whole batch of samples per pixel. ---------- */
+typedef struct statmc_stat_type {
+    int32_t channels;    /* 1 or 3                      (StatTypeConfig::nChannels) */
+    int32_t transform;   /* Box-Cox(0.5) on the sample  (StatTypeConfig::transform) */
+    int32_t max_moment;  /* 1, 2 or 3                   (StatTypeConfig::maxMoment) */
+    int32_t n_samples;   /* samples per pixel in this batch */
+    const float *samples; /* device, [n_samples][height][width][channels] */
+    int32_t *n;          /* device state images, updated in place */
+    float *mean, *m2, *m3;
+    float *film_mean, *film_m2; /* transform types only; non-transform types alias mean/m2
+                                   (estimator.cpp:127-137) and may pass NULL here */
+} statmc_stat_type;
+
+int statmc_accumulate(uint16_t width, uint16_t height, const statmc_stat_type *types, int n_types,
+                      void *stream);
+
+/* Scatter of reference-layout AoS tiles (StatTilePixel<T>, estimator.h:104-124: 64 B for
+ * T=float, 128 B for T=Vec3) that were accumulated on the host into the planar device images:
+ * Estimator::MergeTile / MergeTransformTile.  tile_bounds = {x0,y0,x1,y1} per tile (device,
+ * int32 x4), tile_offsets = index of each tile's first pixel in tile_pixels (device). */
+int statmc_merge_tiles(uint16_t width, uint16_t height, int channels, int transform,
+                       const void *tile_pixels, const int32_t *tile_bounds,
+                       const int64_t *tile_offsets, int n_tiles, int max_tile_pixels,
+                       int32_t *n, float *mean, float *m2, float *m3, float *film_mean,
+                       float *film_m2, void *stream);
+
+/* Tile-local pooled moments of an image by wavefront-level Welford/Chan merges: for every
+ * tile_size x tile_size tile writes {count, mean, M2} per channel of `values`
+ * (out: [tiles_y][tiles_x][channels][3] fp32).  tile_size in {8, 16}. */
+int statmc_tile_moments(uint16_t width, uint16_t height, int channels, const float *values,
+                        int tile_size, float *out, void *stream);
+
+/* Introspection used by tests/bench: name of the window-filter kernel variant the last
+ * statmc_window_filter call dispatched ("lds_r20", "lds_rt", "generic", ...). */
+const char *statmc_last_filter_variant(void);
+int statmc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STATMC_H */

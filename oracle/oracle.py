@@ -1,0 +1,141 @@
+"""ctypes binding of the CPU oracle (oracle/libstatmc_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the cpu_baseline leg
+of bench.py.  The product package (statmc_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libstatmc_oracle.so")
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []),
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        f32p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        _lib.oracle_box_cox.restype = C.c_float
+        _lib.oracle_box_cox.argtypes = [C.c_float, C.c_float]
+        _lib.oracle_t_quantile.restype = C.c_float
+        _lib.oracle_t_quantile.argtypes = [C.c_int, C.c_int]
+        _lib.oracle_add_sample.argtypes = [C.c_void_p, C.c_int, f32p, C.c_int, C.c_int]
+        _lib.oracle_accumulate_image.argtypes = [C.c_int] * 6 + [f32p, i32p] + [f32p] * 5 + [C.c_int] * 2
+        _lib.oracle_merge_tile.argtypes = [C.c_void_p] + [C.c_int] * 6 + [i32p] + [f32p] * 5
+        _lib.oracle_mean_vars.argtypes = [C.c_int] * 3 + [i32p, f32p, f32p, C.c_int]
+        _lib.oracle_prepass.argtypes = [C.c_int] * 4 + [i32p] + [f32p] * 5
+        _lib.oracle_filter.argtypes = ([C.c_int] * 3 + [C.c_float, C.c_int] + [f32p] * 3 +
+                                       [C.c_int, C.POINTER(f32p), C.POINTER(C.c_int), f32p, f32p] +
+                                       [C.c_int] * 5)
+        _lib.oracle_num_threads.restype = C.c_int
+    return _lib
+
+
+def _f(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _i(a):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def num_threads():
+    return lib().oracle_num_threads()
+
+
+def box_cox(v, lam=0.5):
+    return lib().oracle_box_cox(float(v), float(lam))
+
+
+def t_quantile(alpha_index, dof):
+    return lib().oracle_t_quantile(int(alpha_index), int(dof))
+
+
+TILE_PIXEL_DTYPE = {
+    1: np.dtype({"names": ["n", "mean", "m2", "m3", "film_mean", "film_m2"],
+                 "formats": ["<u8"] + ["<f4"] * 5, "offsets": [0, 8, 12, 16, 20, 24], "itemsize": 64}),
+    3: np.dtype({"names": ["n", "mean", "m2", "m3", "film_mean", "film_m2"],
+                 "formats": ["<u8"] + [("<f4", (3,))] * 5, "offsets": [0, 8, 20, 32, 44, 56],
+                 "itemsize": 128}),
+}
+
+
+def add_samples_to_pixel(samples, channels, transform, max_moment):
+    """Run a 1-D sample sequence through one AoS StatTilePixel; returns the structured pixel."""
+    px = np.zeros(1, dtype=TILE_PIXEL_DTYPE[channels])
+    samples = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1, channels)
+    for s in samples:
+        lib().oracle_add_sample(px.ctypes.data, channels, _f(np.ascontiguousarray(s)),
+                                int(transform), int(max_moment))
+    return px[0]
+
+
+def new_state(h, w, channels):
+    z = lambda: np.zeros((h, w, channels), np.float32)
+    return dict(n=np.zeros((h, w), np.int32), mean=z(), m2=z(), m3=z(), film_mean=z(), film_m2=z())
+
+
+def accumulate(state, samples, transform, max_moment, tile_size=16, threads=0):
+    """samples: [S, H, W, C] float32.  Updates `state` (see new_state) in place."""
+    S, h, w, c = samples.shape
+    samples = np.ascontiguousarray(samples, dtype=np.float32)
+    lib().oracle_accumulate_image(w, h, c, int(transform), int(max_moment), S, _f(samples),
+                                  _i(state["n"]), _f(state["mean"]), _f(state["m2"]), _f(state["m3"]),
+                                  _f(state["film_mean"]), _f(state["film_m2"]), tile_size, threads)
+    return state
+
+
+def merge_tile(tile_pixels, channels, x0, y0, x1, y1, state, transform=True):
+    h, w = state["n"].shape
+    fm = _f(state["film_mean"]) if transform else None
+    f2 = _f(state["film_m2"]) if transform else None
+    lib().oracle_merge_tile(tile_pixels.ctypes.data, channels, x0, y0, x1, y1, w, _i(state["n"]),
+                            _f(state["mean"]), _f(state["m2"]), _f(state["m3"]), fm, f2)
+
+
+def mean_vars(n, film_m2, row_n_quirk=True):
+    h, w = n.shape
+    c = film_m2.shape[2] if film_m2.ndim == 3 else 1
+    out = np.empty_like(film_m2)
+    lib().oracle_mean_vars(w, h, c, _i(n), _f(film_m2), _f(out), int(row_n_quirk))
+    return out
+
+
+def prepass(n, mean, m2, m3, alpha_index=0):
+    h, w = n.shape
+    c = mean.shape[2] if mean.ndim == 3 else 1
+    mc, disc = np.empty_like(mean), np.empty_like(mean)
+    lib().oracle_prepass(w, h, c, alpha_index, _i(n), _f(mean), _f(m2), _f(m3), _f(mc), _f(disc))
+    return mc, disc
+
+
+def filter_image(mean_corr, disc, colour, g_buffers, g_dr, ds, radius, roi=None, threads=0):
+    """g_buffers: list of [H, W, Cg] (or [H, W]) float32 arrays; g_dr: list of -0.5/sd^2."""
+    h, w = mean_corr.shape[:2]
+    c = mean_corr.shape[2] if mean_corr.ndim == 3 else 1
+    gs = [np.ascontiguousarray(g, dtype=np.float32) for g in g_buffers]
+    ng = len(gs)
+    gptrs = (C.POINTER(C.c_float) * max(ng, 1))(*[_f(g) for g in gs])
+    gch = (C.c_int * max(ng, 1))(*[(g.shape[2] if g.ndim == 3 else 1) for g in gs])
+    gdr = np.asarray(list(g_dr) + ([] if ng else [0.0]), dtype=np.float32)
+    out = np.zeros_like(colour)
+    x0, y0, x1, y1 = roi if roi is not None else (0, 0, w, h)
+    lib().oracle_filter(w, h, c, float(ds), int(radius), _f(mean_corr), _f(disc), _f(colour),
+                        ng, gptrs, gch, _f(gdr), _f(out), x0, y0, x1, y1, threads)
+    return out

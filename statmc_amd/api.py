@@ -1,0 +1,258 @@
+"""ctypes binding of libstatmc_hip.so (include/statmc.h) + thin helpers that marshal torch
+tensors (device memory, streams) into the C structs.  Plumbing only: every number is produced
+by the HIP kernels behind the C ABI.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+STATMC_OK = 0
+ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = -1, -2, -3, -4
+MAX_BUFFERS, MAX_GBUFFERS = 16, 8
+
+
+class StatmcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("statmc error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Image(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("step", C.c_size_t), ("cols", C.c_int32), ("rows", C.c_int32)]
+
+
+class FilterArgs(C.Structure):
+    _fields_ = [
+        ("n_buffers", C.c_uint8), ("width", C.c_uint16), ("height", C.c_uint16),
+        ("filter_ds_factor", C.c_float), ("filter_radius", C.c_uint8), ("denoise_film", C.c_uint8),
+        ("n", C.POINTER(Image)), ("mean", C.POINTER(Image)), ("m2", C.POINTER(Image)),
+        ("m3", C.POINTER(Image)), ("film", C.POINTER(Image)), ("film_buffer", Image),
+        ("g_buffers", C.POINTER(Image)), ("g_channel_counts", C.POINTER(C.c_uint8)),
+        ("g_dr_factors", C.POINTER(C.c_float)), ("n_g_buffers", C.c_size_t),
+        ("mean_corr", C.POINTER(Image)), ("discriminator", C.POINTER(Image)),
+        ("film_filtered", C.POINTER(Image)), ("film_filtered_buffer", Image),
+        ("stream", C.c_void_p),
+        ("roi_x0", C.c_int32), ("roi_y0", C.c_int32), ("roi_x1", C.c_int32), ("roi_y1", C.c_int32),
+    ]
+
+
+class StatType(C.Structure):
+    _fields_ = [
+        ("channels", C.c_int32), ("transform", C.c_int32), ("max_moment", C.c_int32),
+        ("n_samples", C.c_int32), ("samples", C.c_void_p), ("n", C.c_void_p),
+        ("mean", C.c_void_p), ("m2", C.c_void_p), ("m3", C.c_void_p),
+        ("film_mean", C.c_void_p), ("film_m2", C.c_void_p),
+    ]
+
+
+EXPORTS = [
+    "statmc_last_error", "statmc_setup", "statmc_set_significance", "statmc_get_significance",
+    "statmc_malloc", "statmc_free", "statmc_memset", "statmc_upload", "statmc_download",
+    "statmc_stream_create", "statmc_stream_destroy", "statmc_synchronize",
+    "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter",
+    "statmc_calculate_mean_vars", "statmc_accumulate", "statmc_merge_tiles", "statmc_tile_moments",
+    "statmc_last_filter_variant", "statmc_version",
+]
+
+_lib = None
+
+
+def library_path():
+    return _build.SO
+
+
+def load():
+    """Load libstatmc_hip.so.  Raises if it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_build.SO):
+        raise RuntimeError(
+            "libstatmc_hip.so is missing (%s). Build it with `python -m statmc_amd.build` or "
+            "__graft_entry__.build(); statmc_amd has no CPU/PyTorch fallback." % _build.SO)
+    lib = C.CDLL(_build.SO)
+    lib.statmc_last_error.restype = C.c_char_p
+    lib.statmc_last_filter_variant.restype = C.c_char_p
+    lib.statmc_setup.argtypes = [C.c_int]
+    lib.statmc_set_significance.argtypes = [C.c_int]
+    lib.statmc_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    lib.statmc_free.argtypes = [C.c_void_p]
+    lib.statmc_memset.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    lib.statmc_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.statmc_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.statmc_stream_create.argtypes = [C.POINTER(C.c_void_p)]
+    lib.statmc_stream_destroy.argtypes = [C.c_void_p]
+    lib.statmc_synchronize.argtypes = [C.c_void_p]
+    lib.statmc_filter_f32.argtypes = [C.POINTER(FilterArgs)]
+    lib.statmc_filter_f32x3.argtypes = [C.POINTER(FilterArgs)]
+    lib.statmc_prepass.argtypes = [C.POINTER(FilterArgs), C.c_int]
+    lib.statmc_window_filter.argtypes = [C.POINTER(FilterArgs), C.c_int]
+    lib.statmc_calculate_mean_vars.argtypes = [C.c_uint8, C.c_uint16, C.c_uint16, C.c_int,
+                                               C.POINTER(Image), C.POINTER(Image), C.POINTER(Image),
+                                               C.c_int, C.c_void_p]
+    lib.statmc_accumulate.argtypes = [C.c_uint16, C.c_uint16, C.POINTER(StatType), C.c_int, C.c_void_p]
+    lib.statmc_merge_tiles.argtypes = [C.c_uint16, C.c_uint16, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p]
+    lib.statmc_tile_moments.argtypes = [C.c_uint16, C.c_uint16, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p]
+    lib.statmc_debug_force_filter_variant.argtypes = [C.c_int]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != STATMC_OK:
+        raise StatmcError(rc, load().statmc_last_error().decode())
+    return rc
+
+
+_setup_done = set()
+
+
+def setup(device=0):
+    if device not in _setup_done:
+        check(load().statmc_setup(int(device)))
+        _setup_done.add(device)
+
+
+def last_filter_variant():
+    return load().statmc_last_filter_variant().decode()
+
+
+def force_filter_variant(v):
+    """0 auto, 1 generic (global-memory) kernel, 2 runtime-radius LDS kernel."""
+    load().statmc_debug_force_filter_variant(int(v))
+
+
+# ------------------------------------------------------------------ torch marshalling
+def _torch():
+    import torch
+    return torch
+
+
+def current_stream_handle():
+    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def image_of(t):
+    """Describe a packed [H, W] or [H, W, C] device tensor as a statmc_image."""
+    assert t.is_cuda and t.is_contiguous(), "device images must be contiguous CUDA(HIP) tensors"
+    assert t.element_size() == 4
+    h, w = t.shape[0], t.shape[1]
+    c = t.shape[2] if t.dim() == 3 else 1
+    return Image(C.c_void_p(t.data_ptr()), w * c * 4, w, h)
+
+
+def _img_array(tensors):
+    arr = (Image * max(len(tensors), 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = image_of(t)
+    return arr
+
+
+def make_filter_args(n, mean, m2, m3, film, mean_corr, disc, film_filtered, g_buffers, g_sds=None,
+                     g_dr=None, filter_sd=10.0, radius=20, denoise_film=False, film_buffer=None,
+                     film_filtered_buffer=None, roi=None, stream=None, keep=None):
+    """Build a statmc_filter_args from lists of per-buffer device tensors (reference argument
+    order, estimator.cpp:437-459).  Returns (args, keepalive)."""
+    nb = len(mean_corr)
+    h, w = mean_corr[0].shape[0], mean_corr[0].shape[1]
+    a = FilterArgs()
+    ka = []
+    a.n_buffers, a.width, a.height = nb, w, h
+    a.filter_ds_factor = -0.5 / (filter_sd * filter_sd)   # estimator.h:259
+    a.filter_radius = radius
+    a.denoise_film = 1 if denoise_film else 0
+    for name, lst in (("n", n), ("mean", mean), ("m2", m2), ("m3", m3), ("film", film),
+                      ("mean_corr", mean_corr), ("discriminator", disc), ("film_filtered", film_filtered)):
+        if lst:
+            arr = _img_array(lst)
+            ka.append(arr)
+            setattr(a, name, arr)
+    if film_buffer is not None:
+        a.film_buffer = image_of(film_buffer)
+    if film_filtered_buffer is not None:
+        a.film_filtered_buffer = image_of(film_filtered_buffer)
+    ng = len(g_buffers)
+    if ng:
+        garr = _img_array(g_buffers)
+        gch = (C.c_uint8 * ng)(*[(g.shape[2] if g.dim() == 3 else 1) for g in g_buffers])
+        if g_dr is None:
+            g_dr = [-0.5 / (sd * sd) for sd in g_sds]      # estimator.cpp:16
+        gdr = (C.c_float * ng)(*g_dr)
+        ka += [garr, gch, gdr]
+        a.g_buffers, a.g_channel_counts, a.g_dr_factors = garr, gch, gdr
+    a.n_g_buffers = ng
+    a.stream = stream if stream is not None else current_stream_handle()
+    if roi is not None:
+        a.roi_x0, a.roi_y0, a.roi_x1, a.roi_y1 = roi
+    ka.append((n, mean, m2, m3, film, mean_corr, disc, film_filtered, g_buffers, film_buffer,
+               film_filtered_buffer))
+    return a, ka
+
+
+def prepass(args, channels):
+    check(load().statmc_prepass(C.byref(args), channels))
+
+
+def window_filter(args, channels):
+    check(load().statmc_window_filter(C.byref(args), channels))
+
+
+def filter_f32x3(args):
+    check(load().statmc_filter_f32x3(C.byref(args)))
+
+
+def filter_f32(args):
+    check(load().statmc_filter_f32(C.byref(args)))
+
+
+def make_stat_type(samples, state, transform, max_moment):
+    """samples: [S, H, W, C] device tensor; state: dict of device tensors n/mean/m2/m3/film_mean/film_m2."""
+    t = StatType()
+    c = samples.shape[3] if samples.dim() == 4 else 1
+    t.channels, t.transform, t.max_moment = c, int(bool(transform)), int(max_moment)
+    t.n_samples = samples.shape[0]
+    t.samples = samples.data_ptr()
+    t.n = state["n"].data_ptr()
+    t.mean = state["mean"].data_ptr()
+    t.m2 = state["m2"].data_ptr() if state.get("m2") is not None else None
+    t.m3 = state["m3"].data_ptr() if state.get("m3") is not None else None
+    t.film_mean = state["film_mean"].data_ptr() if state.get("film_mean") is not None else None
+    t.film_m2 = state["film_m2"].data_ptr() if state.get("film_m2") is not None else None
+    return t
+
+
+def accumulate(width, height, stat_types, stream=None):
+    arr = (StatType * max(len(stat_types), 1))(*stat_types)
+    check(load().statmc_accumulate(width, height, arr, len(stat_types),
+                                   stream if stream is not None else current_stream_handle()))
+
+
+def calculate_mean_vars(n, film_m2, film_var, row_n_quirk=True, stream=None):
+    h, w = n[0].shape
+    c = film_m2[0].shape[2] if film_m2[0].dim() == 3 else 1
+    check(load().statmc_calculate_mean_vars(len(n), w, h, c, _img_array(n), _img_array(film_m2),
+                                            _img_array(film_var), int(row_n_quirk),
+                                            stream if stream is not None else current_stream_handle()))
+
+
+def merge_tiles(width, height, channels, transform, tile_pixels, tile_bounds, tile_offsets, max_tile_pixels,
+                state, stream=None):
+    fm = state["film_mean"].data_ptr() if transform else None
+    f2 = state["film_m2"].data_ptr() if transform else None
+    check(load().statmc_merge_tiles(width, height, channels, int(bool(transform)), tile_pixels.data_ptr(),
+                                    tile_bounds.data_ptr(), tile_offsets.data_ptr(), tile_bounds.shape[0],
+                                    max_tile_pixels, state["n"].data_ptr(), state["mean"].data_ptr(),
+                                    state["m2"].data_ptr(), state["m3"].data_ptr(), fm, f2,
+                                    stream if stream is not None else current_stream_handle()))
+
+
+def tile_moments(values, tile_size, out, stream=None):
+    h, w = values.shape[0], values.shape[1]
+    c = values.shape[2] if values.dim() == 3 else 1
+    check(load().statmc_tile_moments(w, h, c, values.data_ptr(), tile_size, out.data_ptr(),
+                                     stream if stream is not None else current_stream_handle()))

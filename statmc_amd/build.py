@@ -1,0 +1,57 @@
+"""Builds libstatmc_hip.so for gfx950 with hipcc, in-tree (statmc_amd/libstatmc_hip.so)."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "libstatmc_hip.so")
+SOURCES = ["statmc_pointwise.hip", "statmc_filter.hip", "statmc_abi.hip"]
+HEADERS = ["statmc_device.h", "t_quantiles.h", os.path.join("..", "..", "include", "statmc.h")]
+# -ffp-contract=off: every fp32 op rounds once, in source order, like the CPU oracle build.
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: libstatmc_hip.so cannot be built")
+
+
+def needs_build():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return SO
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
+        if verbose and out:
+            print(out.decode(), file=sys.stderr)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+    subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,365 @@
+// statmc_abi.hip -- the extern "C" surface declared in include/statmc.h.
+// Validation + argument marshalling only; kernels live in statmc_pointwise.hip / statmc_filter.hip.
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "statmc_device.h"
+
+namespace statmc {
+hipError_t upload_t_tables();
+}
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local const char *g_variant = "none";
+int g_alpha_index = 0;
+bool g_ready = false;
+std::mutex g_mu;
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(STATMC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define NEED_READY()                                                                           \
+    do {                                                                                       \
+        if (!g_ready) return fail(STATMC_ERR_NO_DEVICE, "statmc_setup() has not been called"); \
+    } while (0)
+
+inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// spatial-exponent tables of the LDS filter, cached per (device, radius, ds)
+struct TabKey {
+    int dev, r;
+    float ds;
+    bool operator==(const TabKey &o) const { return dev == o.dev && r == o.r && memcmp(&ds, &o.ds, 4) == 0; }
+};
+struct TabHash {
+    size_t operator()(const TabKey &k) const {
+        unsigned u;
+        memcpy(&u, &k.ds, 4);
+        return (size_t)u * 1315423911u ^ (size_t)k.r * 2654435761u ^ (size_t)k.dev;
+    }
+};
+std::unordered_map<TabKey, float *, TabHash> g_tabs;
+
+int spatial_table(int radius, float ds, const float **out) {
+    *out = nullptr;
+    const size_t n = statmc::spatial_table_floats(radius);
+    if (n == 0) return STATMC_OK;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    const TabKey key{dev, radius, ds};
+    auto it = g_tabs.find(key);
+    if (it == g_tabs.end()) {
+        std::vector<float> host(n);
+        statmc::fill_spatial_table(host.data(), radius, ds);
+        float *d = nullptr;
+        HIP_TRY(hipMalloc(&d, n * sizeof(float)));
+        // synchronous copy: the table must be resident before any stream uses it
+        HIP_TRY(hipMemcpy(d, host.data(), n * sizeof(float), hipMemcpyHostToDevice));
+        it = g_tabs.emplace(key, d).first;
+    }
+    *out = it->second;
+    return STATMC_OK;
+}
+
+int check_image(const statmc_image &im, int w, int h, int channels, const char *what, int idx) {
+    if (!im.data) return fail(STATMC_ERR_INVALID, "%s[%d]: null device pointer", what, idx);
+    if (im.cols != w || im.rows != h)
+        return fail(STATMC_ERR_INVALID, "%s[%d]: %dx%d image, expected %dx%d", what, idx, im.cols, im.rows, w, h);
+    if (im.step != (size_t)w * channels * 4)
+        return fail(STATMC_ERR_UNSUPPORTED, "%s[%d]: row pitch %zu, this build needs packed rows (%zu)", what, idx,
+                    im.step, (size_t)w * channels * 4);
+    return STATMC_OK;
+}
+
+#define CHECK_IMG(im, ch, what, idx)                                          \
+    do {                                                                      \
+        int rc_ = check_image((im), W, H, (ch), (what), (idx));               \
+        if (rc_) return rc_;                                                  \
+    } while (0)
+
+int check_common(const statmc_filter_args *a, int channels) {
+    if (!a) return fail(STATMC_ERR_INVALID, "null args");
+    if (channels != 1 && channels != 3) return fail(STATMC_ERR_INVALID, "channels must be 1 or 3");
+    if (a->width == 0 || a->height == 0) return fail(STATMC_ERR_INVALID, "empty image");
+    if (a->n_buffers > STATMC_MAX_BUFFERS) return fail(STATMC_ERR_INVALID, "n_buffers > %d", STATMC_MAX_BUFFERS);
+    if (a->n_g_buffers > STATMC_MAX_GBUFFERS)
+        return fail(STATMC_ERR_UNSUPPORTED, "n_g_buffers > %d", STATMC_MAX_GBUFFERS);
+    return STATMC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *statmc_last_error(void) { return g_err; }
+const char *statmc_last_filter_variant(void) { return g_variant; }
+int statmc_version(void) { return 100; }
+
+int statmc_setup(int device) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return fail(STATMC_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= count) return fail(STATMC_ERR_INVALID, "device %d out of range [0,%d)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(STATMC_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
+                    prop.gcnArchName);
+    HIP_TRY(statmc::upload_t_tables());
+    g_ready = true;
+    return STATMC_OK;
+}
+
+int statmc_set_significance(int alpha_index) {
+    if (alpha_index < 0 || alpha_index > 2) return fail(STATMC_ERR_INVALID, "alpha_index must be 0, 1 or 2");
+    g_alpha_index = alpha_index;
+    return STATMC_OK;
+}
+int statmc_get_significance(void) { return g_alpha_index; }
+
+int statmc_malloc(void **dev_ptr, size_t bytes) {
+    if (!dev_ptr) return fail(STATMC_ERR_INVALID, "null dev_ptr");
+    HIP_TRY(hipMalloc(dev_ptr, bytes));
+    return STATMC_OK;
+}
+int statmc_free(void *dev_ptr) {
+    HIP_TRY(hipFree(dev_ptr));
+    return STATMC_OK;
+}
+int statmc_memset(void *dev_ptr, int value, size_t bytes, void *stream) {
+    HIP_TRY(hipMemsetAsync(dev_ptr, value, bytes, S(stream)));
+    return STATMC_OK;
+}
+int statmc_upload(void *dev_dst, const void *host_src, size_t bytes, void *stream) {
+    HIP_TRY(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, S(stream)));
+    return STATMC_OK;
+}
+int statmc_download(void *host_dst, const void *dev_src, size_t bytes, void *stream) {
+    HIP_TRY(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, S(stream)));
+    return STATMC_OK;
+}
+int statmc_stream_create(void **stream) {
+    if (!stream) return fail(STATMC_ERR_INVALID, "null stream");
+    hipStream_t s;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return STATMC_OK;
+}
+int statmc_stream_destroy(void *stream) {
+    HIP_TRY(hipStreamDestroy(S(stream)));
+    return STATMC_OK;
+}
+int statmc_synchronize(void *stream) {
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    return STATMC_OK;
+}
+
+int statmc_prepass(const statmc_filter_args *a, int channels) {
+    NEED_READY();
+    if (int rc = check_common(a, channels)) return rc;
+    const int W = a->width, H = a->height;
+    if (a->n_buffers && (!a->n || !a->mean || !a->m2 || !a->m3 || !a->mean_corr || !a->discriminator))
+        return fail(STATMC_ERR_INVALID, "null buffer table");
+    for (int b = 0; b < a->n_buffers; b++) {
+        CHECK_IMG(a->n[b], 1, "n", b);
+        CHECK_IMG(a->mean[b], channels, "mean", b);
+        CHECK_IMG(a->m2[b], channels, "m2", b);
+        CHECK_IMG(a->m3[b], channels, "m3", b);
+        CHECK_IMG(a->mean_corr[b], channels, "mean_corr", b);
+        CHECK_IMG(a->discriminator[b], channels, "discriminator", b);
+        statmc::PrepassArgs k;
+        k.n = static_cast<const int32_t *>(a->n[b].data);
+        k.mean = static_cast<const float *>(a->mean[b].data);
+        k.m2 = static_cast<const float *>(a->m2[b].data);
+        k.m3 = static_cast<const float *>(a->m3[b].data);
+        k.mean_corr = static_cast<float *>(a->mean_corr[b].data);
+        k.disc = static_cast<float *>(a->discriminator[b].data);
+        k.n_elems = (long long)W * H * channels;
+        k.channels = channels;
+        k.alpha_index = g_alpha_index;
+        HIP_TRY(statmc::launch_prepass(k, S(a->stream)));
+    }
+    return STATMC_OK;
+}
+
+int statmc_window_filter(const statmc_filter_args *a, int channels) {
+    NEED_READY();
+    if (int rc = check_common(a, channels)) return rc;
+    const int W = a->width, H = a->height;
+    if (a->n_buffers && (!a->mean_corr || !a->discriminator)) return fail(STATMC_ERR_INVALID, "null buffer table");
+    if (a->n_g_buffers && (!a->g_buffers || !a->g_channel_counts || !a->g_dr_factors))
+        return fail(STATMC_ERR_INVALID, "null G-buffer table");
+
+    statmc::FilterArgs k;
+    memset(&k, 0, sizeof(k));
+    k.width = W;
+    k.height = H;
+    const bool whole = a->roi_x0 == 0 && a->roi_y0 == 0 && a->roi_x1 == 0 && a->roi_y1 == 0;
+    k.rx0 = whole ? 0 : a->roi_x0;
+    k.ry0 = whole ? 0 : a->roi_y0;
+    k.rx1 = whole ? W : a->roi_x1;
+    k.ry1 = whole ? H : a->roi_y1;
+    if (k.rx0 < 0 || k.ry0 < 0 || k.rx1 > W || k.ry1 > H || k.rx0 >= k.rx1 || k.ry0 >= k.ry1)
+        return fail(STATMC_ERR_INVALID, "roi [%d,%d)x[%d,%d) outside the %dx%d image", k.rx0, k.rx1, k.ry0, k.ry1, W, H);
+    k.radius = a->filter_radius;
+    k.ds = a->filter_ds_factor;
+    k.n_g = (int)a->n_g_buffers;
+    for (int g = 0; g < k.n_g; g++) {
+        const int gc = a->g_channel_counts[g];
+        if (gc != 1 && gc != 3) return fail(STATMC_ERR_UNSUPPORTED, "g_buffers[%d]: %d channels", g, gc);
+        CHECK_IMG(a->g_buffers[g], gc, "g_buffers", g);
+        k.g[g].data = static_cast<const float *>(a->g_buffers[g].data);
+        k.g[g].channels = gc;
+        k.g[g].dr = a->g_dr_factors[g];
+    }
+    if (statmc::fast_path_eligible(k, channels)) {
+        if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
+        k.gscale0 = sqrtf(-k.g[0].dr * 1.44269504088896340736f);
+        k.gscale1 = sqrtf(-k.g[1].dr * 1.44269504088896340736f);
+    }
+    for (int b = 0; b < a->n_buffers; b++) {
+        // buffer 0 filters the "film" image into "film-f" when denoiseFilm is set
+        // (estimator.cpp:143-146,168-172; argument positions 12 and 20 of filter<T>)
+        const bool film = a->denoise_film && b == 0 && channels == 3;
+        const statmc_image &colour = film ? a->film_buffer : a->film[b];
+        const statmc_image &out = film ? a->film_filtered_buffer : a->film_filtered[b];
+        if (!film && (!a->film || !a->film_filtered)) return fail(STATMC_ERR_INVALID, "null film table");
+        CHECK_IMG(a->mean_corr[b], channels, "mean_corr", b);
+        CHECK_IMG(a->discriminator[b], channels, "discriminator", b);
+        CHECK_IMG(colour, channels, film ? "film_buffer" : "film", b);
+        CHECK_IMG(out, channels, film ? "film_filtered_buffer" : "film_filtered", b);
+        k.mean_corr = static_cast<const float *>(a->mean_corr[b].data);
+        k.disc = static_cast<const float *>(a->discriminator[b].data);
+        k.colour = static_cast<const float *>(colour.data);
+        k.out = static_cast<float *>(out.data);
+        if (k.out == k.colour) return fail(STATMC_ERR_INVALID, "filter cannot run in place (buffer %d)", b);
+        const char *variant = "none";
+        HIP_TRY(statmc::launch_window_filter(k, channels, S(a->stream), &variant));
+        g_variant = variant;
+    }
+    return STATMC_OK;
+}
+
+int statmc_filter_f32(const statmc_filter_args *a) {
+    if (int rc = statmc_prepass(a, 1)) return rc;
+    return statmc_window_filter(a, 1);
+}
+int statmc_filter_f32x3(const statmc_filter_args *a) {
+    if (int rc = statmc_prepass(a, 3)) return rc;
+    return statmc_window_filter(a, 3);
+}
+
+int statmc_calculate_mean_vars(uint8_t n_buffers, uint16_t width, uint16_t height, int channels,
+                               const statmc_image *n, const statmc_image *film_m2, const statmc_image *film_var,
+                               int row_n_quirk, void *stream) {
+    NEED_READY();
+    if (channels != 1 && channels != 3) return fail(STATMC_ERR_INVALID, "channels must be 1 or 3");
+    if (width == 0 || height == 0) return fail(STATMC_ERR_INVALID, "empty image");
+    if (n_buffers && (!n || !film_m2 || !film_var)) return fail(STATMC_ERR_INVALID, "null buffer table");
+    const int W = width, H = height;
+    for (int b = 0; b < n_buffers; b++) {
+        CHECK_IMG(n[b], 1, "n", b);
+        CHECK_IMG(film_m2[b], channels, "film_m2", b);
+        CHECK_IMG(film_var[b], channels, "film_var", b);
+        statmc::MeanVarsArgs k{static_cast<const int32_t *>(n[b].data), static_cast<const float *>(film_m2[b].data),
+                               static_cast<float *>(film_var[b].data), W, H, channels, row_n_quirk};
+        HIP_TRY(statmc::launch_mean_vars(k, S(stream)));
+    }
+    return STATMC_OK;
+}
+
+int statmc_accumulate(uint16_t width, uint16_t height, const statmc_stat_type *types, int n_types, void *stream) {
+    NEED_READY();
+    if (width == 0 || height == 0) return fail(STATMC_ERR_INVALID, "empty image");
+    if (n_types < 0 || n_types > statmc::kMaxStatTypes)
+        return fail(STATMC_ERR_INVALID, "n_types must be in [0,%d]", statmc::kMaxStatTypes);
+    if (n_types == 0) return STATMC_OK;
+    if (!types) return fail(STATMC_ERR_INVALID, "null types");
+    statmc::AccumulateArgs k;
+    memset(&k, 0, sizeof(k));
+    k.n_types = n_types;
+    for (int i = 0; i < n_types; i++) {
+        const statmc_stat_type &t = types[i];
+        if (t.channels != 1 && t.channels != 3) return fail(STATMC_ERR_INVALID, "types[%d]: channels must be 1 or 3", i);
+        if (t.max_moment < 1 || t.max_moment > 3) return fail(STATMC_ERR_INVALID, "types[%d]: max_moment must be 1..3", i);
+        if (t.n_samples < 0) return fail(STATMC_ERR_INVALID, "types[%d]: negative n_samples", i);
+        if (!t.n || !t.mean || (t.n_samples && !t.samples)) return fail(STATMC_ERR_INVALID, "types[%d]: null pointer", i);
+        if (t.max_moment >= 2 && !t.m2) return fail(STATMC_ERR_INVALID, "types[%d]: null m2", i);
+        if (t.max_moment >= 3 && !t.m3) return fail(STATMC_ERR_INVALID, "types[%d]: null m3", i);
+        if (t.transform && (!t.film_mean || !t.film_m2))
+            return fail(STATMC_ERR_INVALID, "types[%d]: transform types need film_mean and film_m2", i);
+        statmc::AccumulateType &d = k.t[i];
+        d.samples = t.samples;
+        d.n = t.n;
+        d.mean = t.mean;
+        d.m2 = t.m2;
+        d.m3 = t.m3;
+        d.film_mean = t.film_mean;
+        d.film_m2 = t.film_m2;
+        d.n_elems = (long long)width * height * t.channels;
+        d.channels = t.channels;
+        d.n_samples = t.n_samples;
+        d.transform = t.transform ? 1 : 0;
+        d.max_moment = t.max_moment;
+    }
+    HIP_TRY(statmc::launch_accumulate(k, S(stream)));
+    return STATMC_OK;
+}
+
+int statmc_merge_tiles(uint16_t width, uint16_t height, int channels, int transform, const void *tile_pixels,
+                       const int32_t *tile_bounds, const int64_t *tile_offsets, int n_tiles, int max_tile_pixels,
+                       int32_t *n, float *mean, float *m2, float *m3, float *film_mean, float *film_m2, void *stream) {
+    NEED_READY();
+    if (channels != 1 && channels != 3) return fail(STATMC_ERR_INVALID, "channels must be 1 or 3");
+    if (n_tiles < 0 || max_tile_pixels < 0) return fail(STATMC_ERR_INVALID, "negative tile count");
+    if (n_tiles == 0 || max_tile_pixels == 0) return STATMC_OK;
+    if (n_tiles > 65535) return fail(STATMC_ERR_UNSUPPORTED, "more than 65535 tiles per call");
+    if (!tile_pixels || !tile_bounds || !tile_offsets || !n || !mean || !m2 || !m3)
+        return fail(STATMC_ERR_INVALID, "null pointer");
+    if (transform && (!film_mean || !film_m2)) return fail(STATMC_ERR_INVALID, "transform merge needs film images");
+    statmc::MergeTilesArgs k{tile_pixels, tile_bounds, reinterpret_cast<const long long *>(tile_offsets),
+                             n, mean, m2, m3, film_mean, film_m2, width, height, channels, transform ? 1 : 0};
+    HIP_TRY(statmc::launch_merge_tiles(k, n_tiles, max_tile_pixels, S(stream)));
+    return STATMC_OK;
+}
+
+int statmc_tile_moments(uint16_t width, uint16_t height, int channels, const float *values, int tile_size,
+                        float *out, void *stream) {
+    NEED_READY();
+    if (channels < 1 || channels > 4) return fail(STATMC_ERR_INVALID, "channels must be 1..4");
+    if (tile_size != 8 && tile_size != 16) return fail(STATMC_ERR_INVALID, "tile_size must be 8 or 16");
+    if (!values || !out || width == 0 || height == 0) return fail(STATMC_ERR_INVALID, "null pointer / empty image");
+    statmc::TileMomentsArgs k{values, out, width, height, channels, tile_size,
+                              (width + tile_size - 1) / tile_size, (height + tile_size - 1) / tile_size};
+    HIP_TRY(statmc::launch_tile_moments(k, S(stream)));
+    return STATMC_OK;
+}
+
+// test/bench hook (not part of the reference surface): 0 auto, 1 generic, 2 runtime-radius LDS
+int statmc_debug_force_filter_variant(int v) {
+    statmc::set_filter_variant_override(v);
+    return STATMC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// statmc_device.h -- kernel-side argument blocks and launch prototypes shared by the
+// .hip translation units of libstatmc_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/statmc.h"
+
+namespace statmc {
+
+// ---------------------------------------------------------------- pointwise kernels
+struct PrepassArgs {
+    const int32_t *n;
+    const float *mean, *m2, *m3;
+    float *mean_corr, *disc;
+    long long n_elems;  // width*height*channels
+    int channels;
+    int alpha_index;
+};
+
+struct MeanVarsArgs {
+    const int32_t *n;
+    const float *film_m2;
+    float *film_var;
+    int width, height, channels, row_n_quirk;
+};
+
+constexpr int kMaxStatTypes = 8;
+struct AccumulateType {
+    const float *samples;
+    int32_t *n;
+    float *mean, *m2, *m3, *film_mean, *film_m2;
+    long long n_elems;  // width*height*channels
+    int channels, n_samples, transform, max_moment;
+};
+struct AccumulateArgs {
+    AccumulateType t[kMaxStatTypes];
+    int n_types;
+};
+
+struct MergeTilesArgs {
+    const void *tile_pixels;
+    const int32_t *tile_bounds;
+    const long long *tile_offsets;
+    int32_t *n;
+    float *mean, *m2, *m3, *film_mean, *film_m2;
+    int width, height, channels, transform;
+};
+
+struct TileMomentsArgs {
+    const float *values;
+    float *out;
+    int width, height, channels, tile_size, tiles_x, tiles_y;
+};
+
+// ---------------------------------------------------------------- window filter
+struct GBufferDesc {
+    const float *data;
+    int channels;
+    float dr;  // -0.5/sd^2
+};
+
+// one buffer (one colour image, one stat set) per launch
+struct FilterArgs {
+    const float *mean_corr, *disc, *colour;
+    float *out;
+    int width, height;           // local image
+    int rx0, ry0, rx1, ry1;      // output ROI
+    int radius;
+    float ds;                    // -0.5/sd_s^2
+    int n_g;
+    GBufferDesc g[STATMC_MAX_GBUFFERS];
+    // fast path only (T = float3, two 3-channel G-buffers):
+    const float *spatial_tab;    // [(2r+1)][2*RP+7] log2-domain spatial exponents, -inf outside r
+    float gscale0, gscale1;      // sqrt(-dr_g * log2(e))
+};
+
+hipError_t launch_prepass(const PrepassArgs &a, hipStream_t s);
+hipError_t launch_mean_vars(const MeanVarsArgs &a, hipStream_t s);
+hipError_t launch_accumulate(const AccumulateArgs &a, hipStream_t s);
+hipError_t launch_merge_tiles(const MergeTilesArgs &a, int n_tiles, int max_tile_pixels, hipStream_t s);
+hipError_t launch_tile_moments(const TileMomentsArgs &a, hipStream_t s);
+
+// Returns the variant name through *variant.  channels = 1 or 3.
+hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s, const char **variant);
+// Size in floats of the spatial table the fast path wants for radius r (0 if r unsupported).
+size_t spatial_table_floats(int radius);
+void fill_spatial_table(float *host_tab, int radius, float ds);
+bool fast_path_eligible(const FilterArgs &a, int channels);
+
+// force a variant for tests/benchmarks: 0 = auto, 1 = generic, 2 = lds_rt (runtime radius)
+void set_filter_variant_override(int v);
+
+}  // namespace statmc

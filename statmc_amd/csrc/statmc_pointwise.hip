@@ -1,0 +1,372 @@
+// statmc_pointwise.hip -- the HBM-bound kernels of the statistics path (gfx950).
+//
+//   prepass        (n, mean, m2, m3) -> Johnson-corrected mean + discriminator
+//   mean_vars      film_m2 / ((n-1) n)            (Estimator::CalculateMeanVars)
+//   accumulate     sample stream -> running moments (StatTile::Add*Sample* + Merge*Tile)
+//   merge_tiles    reference-layout AoS tiles -> planar images (Estimator::Merge*Tile)
+//   tile_moments   tile-local pooled moments by wavefront-level Welford/Chan merges
+//
+// Layout choice.  The reference images are interleaved (cv::Mat of Vec3f).  Every statistic on
+// this path is element-wise per channel, with only the sample count n shared by the channels
+// of a pixel, so the kernels treat an image as a flat array of width*height*channels scalar
+// "elements" and give each lane 4 consecutive elements: all traffic is 16 B per lane, 1 KiB
+// per wave instruction, whatever the channel count (no float3 gathers), and n is read through
+// the cache at element/channels.
+//
+// Arithmetic is written in the exact operation order of oracle/statmc_oracle.c and the file is
+// compiled with -ffp-contract=off, so everything except sqrt-vs-pow in the Box-Cox transform
+// rounds identically to the CPU restatement.
+
+#include "statmc_device.h"
+#include "t_quantiles.h"
+
+namespace statmc {
+
+// Student-t tables, uploaded once by statmc_setup() (hipMemcpyToSymbol).
+__device__ float g_tq[STATMC_TQ_N_TABLES][STATMC_TQ_N_DOF];
+
+hipError_t upload_t_tables() {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tq), statmc_tq_tables, sizeof(statmc_tq_tables));
+}
+
+__device__ __forceinline__ float t_quantile(int alpha_index, int dof) {
+    if (dof < 1) return __builtin_inff();
+    if (dof > STATMC_TQ_N_DOF) dof = STATMC_TQ_N_DOF;
+    return g_tq[alpha_index][dof - 1];
+}
+
+constexpr int kBlock = 256;
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+
+static inline int grid_for(long long work_items, int cap = 256 * 16) {
+    long long b = (work_items + kBlock - 1) / kBlock;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------ pre-pass
+__device__ __forceinline__ void prepass_elem(int ni, float t, float mu, float s2sum, float s3sum,
+                                             float &mc, float &dc) {
+    const float nf = (float)ni;
+    if (ni >= 2 && s2sum > 0.f) {
+        const float var = s2sum / (nf - 1.f);
+        const float mu3 = s3sum / nf;
+        mc = mu + mu3 / (6.f * var * nf);
+        dc = (t * t) * (var / nf);
+    } else {
+        mc = mu;
+        dc = ni >= 2 ? 0.f : __builtin_inff();
+    }
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(kBlock) void prepass_kernel(PrepassArgs a) {
+    const long long n_groups = (a.n_elems + 3) >> 2;
+    for (long long g = (long long)blockIdx.x * kBlock + threadIdx.x; g < n_groups;
+         g += (long long)gridDim.x * kBlock) {
+        const long long e0 = g << 2;
+        if (VEC4 && e0 + 4 <= a.n_elems) {
+            const float4 mu = *reinterpret_cast<const float4 *>(a.mean + e0);
+            const float4 s2 = *reinterpret_cast<const float4 *>(a.m2 + e0);
+            const float4 s3 = *reinterpret_cast<const float4 *>(a.m3 + e0);
+            float4 mc, dc;
+            const float *pmu = &mu.x, *ps2 = &s2.x, *ps3 = &s3.x;
+            float *pmc = &mc.x, *pdc = &dc.x;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int ni = a.n[(e0 + j) / a.channels];
+                prepass_elem(ni, t_quantile(a.alpha_index, ni - 1), pmu[j], ps2[j], ps3[j], pmc[j], pdc[j]);
+            }
+            *reinterpret_cast<float4 *>(a.mean_corr + e0) = mc;
+            *reinterpret_cast<float4 *>(a.disc + e0) = dc;
+        } else {
+            for (long long e = e0; e < a.n_elems && e < e0 + 4; e++) {
+                const int ni = a.n[e / a.channels];
+                float mc, dc;
+                prepass_elem(ni, t_quantile(a.alpha_index, ni - 1), a.mean[e], a.m2[e], a.m3[e], mc, dc);
+                a.mean_corr[e] = mc;
+                a.disc[e] = dc;
+            }
+        }
+    }
+}
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+hipError_t launch_prepass(const PrepassArgs &a, hipStream_t s) {
+    const bool vec = aligned16(a.mean) && aligned16(a.m2) && aligned16(a.m3) && aligned16(a.mean_corr) &&
+                     aligned16(a.disc);
+    const int grid = grid_for((a.n_elems + 3) / 4);
+    if (vec)
+        hipLaunchKernelGGL(prepass_kernel<true>, dim3(grid), dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL(prepass_kernel<false>, dim3(grid), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ mean vars
+__global__ __launch_bounds__(kBlock) void mean_vars_kernel(MeanVarsArgs a) {
+    const long long n_elems = (long long)a.width * a.height * a.channels;
+    for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < n_elems;
+         e += (long long)gridDim.x * kBlock) {
+        const long long px = e / a.channels;
+        const long long npx = a.row_n_quirk ? (px / a.width) * a.width : px;  // estimator.cpp:540,558
+        const float nf = (float)a.n[npx];
+        a.film_var[e] = a.film_m2[e] / ((nf - 1.f) * nf);
+    }
+}
+
+hipError_t launch_mean_vars(const MeanVarsArgs &a, hipStream_t s) {
+    const long long n_elems = (long long)a.width * a.height * a.channels;
+    hipLaunchKernelGGL(mean_vars_kernel, dim3(grid_for(n_elems)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ accumulate
+// One lane owns 4 consecutive PIXELS of one stat type (4*C consecutive scalar elements = C
+// float4 per image plane, one int4 of counts) and walks the batch's samples in order (sample s
+// of pixel p, channel c is at samples[s*n_elems + p*C + c]), so the update sequence per element
+// is the reference's (estimator.h:162-226).  Owning whole pixels keeps the count n private to
+// the lane (no cross-lane read/write race on n).  blockIdx.y selects the stat type.
+struct ElemState {
+    float mean, m2, m3, fmean, fm2;
+};
+
+template <int MAXM, bool TRANSFORM>
+__device__ __forceinline__ void add_sample(ElemState &st, float nf, float smp) {
+    // estimator.h:215 -- boxCox(sample, .5f) = (pow(v, .5) - 1) / .5
+    const float v = TRANSFORM ? (__builtin_sqrtf(smp) - 1.f) / .5f : smp;
+    const float d = v - st.mean;
+    const float dN = d / nf;
+    if (MAXM >= 3) {
+        const float d2 = d * d;
+        const float dN2 = dN * dN;
+        st.mean += dN;
+        st.m2 += d * (d - dN);
+        st.m3 += -3.f * dN * st.m2 + d * (d2 - dN2);
+    } else if (MAXM == 2) {
+        st.mean += dN;
+        st.m2 += d * (d - dN);
+    } else {
+        st.mean += dN;
+    }
+    if (TRANSFORM) {  // estimator.h:217-225
+        const float fd = smp - st.fmean;
+        const float fdN = fd / nf;
+        st.fmean += fdN;
+        st.fm2 += fd * (fd - fdN);
+    }
+}
+
+template <int C, int MAXM, bool TRANSFORM, bool VEC>
+__device__ __forceinline__ void accumulate_type(const AccumulateType &t) {
+    constexpr int NE = 4 * C;  // elements per lane
+    const long long n_px = t.n_elems / C;
+    const long long n_groups = (n_px + 3) >> 2;
+    const int S = t.n_samples;
+    for (long long g = (long long)blockIdx.x * kBlock + threadIdx.x; g < n_groups;
+         g += (long long)gridDim.x * kBlock) {
+        const long long p0 = g << 2;
+        const long long e0 = p0 * C;
+        if (VEC && p0 + 4 <= n_px) {
+            ElemState st[NE];
+            float tmp[NE];
+            const int4 n4 = *reinterpret_cast<const int4 *>(t.n + p0);
+            const int n0[4] = {n4.x, n4.y, n4.z, n4.w};
+#define STATMC_LOAD_PLANE(ptr, field, enabled)                                   \
+    if (enabled) {                                                               \
+        _Pragma("unroll") for (int k = 0; k < C; k++) {                          \
+            const float4 v = *reinterpret_cast<const float4 *>((ptr) + e0 + 4 * k); \
+            tmp[4 * k] = v.x; tmp[4 * k + 1] = v.y; tmp[4 * k + 2] = v.z; tmp[4 * k + 3] = v.w; \
+        }                                                                        \
+    } else {                                                                     \
+        _Pragma("unroll") for (int j = 0; j < NE; j++) tmp[j] = 0.f;             \
+    }                                                                            \
+    _Pragma("unroll") for (int j = 0; j < NE; j++) st[j].field = tmp[j];
+            STATMC_LOAD_PLANE(t.mean, mean, true)
+            STATMC_LOAD_PLANE(t.m2, m2, MAXM >= 2)
+            STATMC_LOAD_PLANE(t.m3, m3, MAXM >= 3)
+            STATMC_LOAD_PLANE(t.film_mean, fmean, TRANSFORM)
+            STATMC_LOAD_PLANE(t.film_m2, fm2, TRANSFORM)
+#undef STATMC_LOAD_PLANE
+            const float *sp = t.samples + e0;
+#pragma unroll 2
+            for (int s = 0; s < S; s++, sp += t.n_elems) {
+                float v[NE];
+#pragma unroll
+                for (int k = 0; k < C; k++) {
+                    const vfloat4 q = __builtin_nontemporal_load(reinterpret_cast<const vfloat4 *>(sp + 4 * k));
+                    v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+                }
+#pragma unroll
+                for (int j = 0; j < NE; j++)
+                    add_sample<MAXM, TRANSFORM>(st[j], (float)(n0[j / C] + s + 1), v[j]);
+            }
+#define STATMC_STORE_PLANE(ptr, field, enabled)                                  \
+    if (enabled) {                                                               \
+        _Pragma("unroll") for (int k = 0; k < C; k++)                            \
+            *reinterpret_cast<float4 *>((ptr) + e0 + 4 * k) =                    \
+                make_float4(st[4 * k].field, st[4 * k + 1].field, st[4 * k + 2].field, st[4 * k + 3].field); \
+    }
+            STATMC_STORE_PLANE(t.mean, mean, true)
+            STATMC_STORE_PLANE(t.m2, m2, MAXM >= 2)
+            STATMC_STORE_PLANE(t.m3, m3, MAXM >= 3)
+            STATMC_STORE_PLANE(t.film_mean, fmean, TRANSFORM)
+            STATMC_STORE_PLANE(t.film_m2, fm2, TRANSFORM)
+#undef STATMC_STORE_PLANE
+            // Merge*Tile casts the tile's uint64 count to int32 (estimator.cpp:347,380)
+            *reinterpret_cast<int4 *>(t.n + p0) = make_int4(n0[0] + S, n0[1] + S, n0[2] + S, n0[3] + S);
+        } else {
+            for (long long p = p0; p < n_px && p < p0 + 4; p++) {
+                const int n0 = t.n[p];
+                for (int c = 0; c < C; c++) {
+                    const long long e = p * C + c;
+                    ElemState st = {t.mean[e], MAXM >= 2 ? t.m2[e] : 0.f, MAXM >= 3 ? t.m3[e] : 0.f,
+                                    TRANSFORM ? t.film_mean[e] : 0.f, TRANSFORM ? t.film_m2[e] : 0.f};
+                    for (int s = 0; s < S; s++)
+                        add_sample<MAXM, TRANSFORM>(st, (float)(n0 + s + 1), t.samples[(long long)s * t.n_elems + e]);
+                    t.mean[e] = st.mean;
+                    if (MAXM >= 2) t.m2[e] = st.m2;
+                    if (MAXM >= 3) t.m3[e] = st.m3;
+                    if (TRANSFORM) {
+                        t.film_mean[e] = st.fmean;
+                        t.film_m2[e] = st.fm2;
+                    }
+                }
+                t.n[p] = n0 + S;
+            }
+        }
+    }
+}
+
+template <int C, bool VEC>
+__device__ __forceinline__ void accumulate_dispatch(const AccumulateType &t) {
+    if (t.transform) {
+        if (t.max_moment >= 3) accumulate_type<C, 3, true, VEC>(t);
+        else if (t.max_moment == 2) accumulate_type<C, 2, true, VEC>(t);
+        else accumulate_type<C, 1, true, VEC>(t);
+    } else {
+        if (t.max_moment >= 3) accumulate_type<C, 3, false, VEC>(t);
+        else if (t.max_moment == 2) accumulate_type<C, 2, false, VEC>(t);
+        else accumulate_type<C, 1, false, VEC>(t);
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void accumulate_kernel(AccumulateArgs a) {
+    const AccumulateType &t = a.t[blockIdx.y];
+    if (t.channels == 3) accumulate_dispatch<3, VEC>(t);
+    else accumulate_dispatch<1, VEC>(t);
+}
+
+hipError_t launch_accumulate(const AccumulateArgs &a, hipStream_t s) {
+    bool vec = true;
+    long long max_groups = 1;
+    for (int i = 0; i < a.n_types; i++) {
+        const AccumulateType &t = a.t[i];
+        vec = vec && aligned16(t.samples) && aligned16(t.n) && aligned16(t.mean) &&
+              (t.max_moment < 2 || aligned16(t.m2)) && (t.max_moment < 3 || aligned16(t.m3)) &&
+              (!t.transform || (aligned16(t.film_mean) && aligned16(t.film_m2))) &&
+              (t.n_elems % 4 == 0);  // sample planes stay 16-B aligned
+        const long long groups = (t.n_elems / t.channels + 3) / 4;
+        if (groups > max_groups) max_groups = groups;
+    }
+    const dim3 grid(grid_for(max_groups, 256 * 32), a.n_types);
+    if (vec)
+        hipLaunchKernelGGL(accumulate_kernel<true>, grid, dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL(accumulate_kernel<false>, grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ merge tiles
+// AoS StatTilePixel<T> (estimator.h:104-124): uint64 n at byte 0, then mean, m2, m3, filmMean,
+// filmM2 (T each) from byte 8; sizeof = 64 (T = float) / 128 (T = Vec3).
+template <int C>
+__global__ __launch_bounds__(kBlock) void merge_tiles_kernel(MergeTilesArgs a) {
+    const int t = blockIdx.y;
+    const int x0 = a.tile_bounds[4 * t], y0 = a.tile_bounds[4 * t + 1];
+    const int x1 = a.tile_bounds[4 * t + 2], y1 = a.tile_bounds[4 * t + 3];
+    const int tw = x1 - x0, npx = tw * (y1 - y0);
+    constexpr int kStride = C == 1 ? 64 : 128;
+    const unsigned char *base = static_cast<const unsigned char *>(a.tile_pixels) + a.tile_offsets[t] * kStride;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < npx; i += gridDim.x * kBlock) {
+        const int x = x0 + i % tw, y = y0 + i / tw;  // estimator.h:44-48
+        if (x >= a.width || y >= a.height) continue;
+        const long long off = (long long)y * a.width + x;
+        const unsigned char *px = base + (long long)i * kStride;
+        const unsigned long long cnt = *reinterpret_cast<const unsigned long long *>(px);
+        const float *f = reinterpret_cast<const float *>(px + 8);
+        a.n[off] = (int32_t)cnt;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            a.mean[off * C + c] = f[c];
+            a.m2[off * C + c] = f[C + c];
+            a.m3[off * C + c] = f[2 * C + c];
+            if (a.transform) {  // MergeTransformTile only (estimator.cpp:385-386)
+                a.film_mean[off * C + c] = f[3 * C + c];
+                a.film_m2[off * C + c] = f[4 * C + c];
+            }
+        }
+    }
+}
+
+hipError_t launch_merge_tiles(const MergeTilesArgs &a, int n_tiles, int max_tile_pixels, hipStream_t s) {
+    const dim3 grid((max_tile_pixels + kBlock - 1) / kBlock, n_tiles);
+    if (a.channels == 3)
+        hipLaunchKernelGGL(merge_tiles_kernel<3>, grid, dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL(merge_tiles_kernel<1>, grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ tile moments
+// One wavefront per (tile, channel): each lane folds its share of the tile's pixels with
+// Welford's update, then the 64 partial (count, mean, M2) triples are merged pairwise with
+// Chan's formula through wave shuffles.
+__device__ __forceinline__ void chan_merge(float &na, float &ma, float &sa, float nb, float mb, float sb) {
+    const float n = na + nb;
+    if (n > 0.f) {
+        const float d = mb - ma;
+        const float f = nb / n;
+        ma = ma + d * f;
+        sa = sa + sb + d * d * na * f;
+        na = n;
+    }
+}
+
+__global__ __launch_bounds__(64) void tile_moments_kernel(TileMomentsArgs a) {
+    const int tx = blockIdx.x, ty = blockIdx.y, c = blockIdx.z;
+    const int lane = threadIdx.x;
+    const int ts = a.tile_size, tpx = ts * ts;
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+    for (int i = lane; i < tpx; i += 64) {
+        const int x = tx * ts + i % ts, y = ty * ts + i / ts;
+        if (x < a.width && y < a.height) {
+            const float v = a.values[((long long)y * a.width + x) * a.channels + c];
+            cnt += 1.f;
+            const float d = v - mean;
+            mean += d / cnt;
+            m2 += d * (v - mean);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float nb = __shfl_xor(cnt, off, 64), mb = __shfl_xor(mean, off, 64), sb = __shfl_xor(m2, off, 64);
+        chan_merge(cnt, mean, m2, nb, mb, sb);
+    }
+    if (lane == 0) {
+        float *o = a.out + (((long long)ty * a.tiles_x + tx) * a.channels + c) * 3;
+        o[0] = cnt;
+        o[1] = mean;
+        o[2] = m2;
+    }
+}
+
+hipError_t launch_tile_moments(const TileMomentsArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(tile_moments_kernel, dim3(a.tiles_x, a.tiles_y, a.channels), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace statmc

@@ -1,0 +1,85 @@
+"""Device-side film statistics + the accumulate -> pre-pass -> window-filter pass, expressed
+with the reference's buffer names (t<type>-b<bounce>-{n,mean,m2,m3,film-mean,film-m2,mean-corr,
+discriminator,film-mean-f}, "film", "film-f"; estimator.cpp:101-161).  Holds torch tensors only
+as HBM allocations; all arithmetic happens in libstatmc_hip.so.
+"""
+import torch
+
+from . import api
+
+# (channels, transform, max_moment, filter sd) of the shipped denoise configuration
+# (statpath.cpp:1027-1160; scenes/render-denoise.pbrt:19-22) plus the two float G-buffers.
+STAT_TYPES = {
+    "radiance":   dict(channels=3, transform=True,  max_moment=3, sd=None),
+    "normal":     dict(channels=3, transform=False, max_moment=1, sd=0.1),
+    "albedo":     dict(channels=3, transform=False, max_moment=1, sd=0.02),
+    "depth":      dict(channels=1, transform=False, max_moment=1, sd=None),
+    "materialid": dict(channels=1, transform=False, max_moment=1, sd=None),
+}
+
+
+def new_state(height, width, channels, device, transform=True):
+    z = lambda: torch.zeros(height, width, channels, dtype=torch.float32, device=device)
+    st = dict(n=torch.zeros(height, width, dtype=torch.int32, device=device), mean=z(), m2=z(), m3=z())
+    if transform:
+        st["film_mean"], st["film_m2"] = z(), z()
+    else:  # non-transform types alias mean/m2 (estimator.cpp:127-137)
+        st["film_mean"], st["film_m2"] = None, None
+    return st
+
+
+class FilmStats:
+    """One GPU's block of the film: per-type running moments and the filter's work images."""
+
+    def __init__(self, width, height, device, types=("radiance", "normal", "albedo"),
+                 filter_sd=10.0, radius=20, g_buffers=("normal", "albedo"), g_sds=None):
+        api.setup(device.index if device.index is not None else 0)
+        self.width, self.height, self.device = width, height, device
+        self.types = list(types)
+        self.state = {t: new_state(height, width, STAT_TYPES[t]["channels"], device,
+                                   STAT_TYPES[t]["transform"]) for t in self.types}
+        self.filter_sd, self.radius = filter_sd, radius
+        self.g_names = list(g_buffers)
+        self.g_sds = list(g_sds) if g_sds is not None else [STAT_TYPES[g]["sd"] for g in self.g_names]
+        z3 = lambda: torch.zeros(height, width, 3, dtype=torch.float32, device=device)
+        self.mean_corr, self.disc, self.film, self.film_f = z3(), z3(), z3(), z3()
+
+    def reset(self):
+        for st in self.state.values():
+            for v in st.values():
+                if v is not None:
+                    v.zero_()
+
+    def accumulate(self, samples):
+        """samples: {type: [S, H, W, C]}; one kernel launch covers every stat type."""
+        sts = [api.make_stat_type(samples[t], self.state[t], STAT_TYPES[t]["transform"],
+                                  STAT_TYPES[t]["max_moment"]) for t in self.types if t in samples]
+        api.accumulate(self.width, self.height, sts)
+
+    def g_buffer(self, name):
+        return self.state[name]["mean"]  # film-mean == mean for non-transform types
+
+    def filter_args(self, roi=None, colour=None, out=None):
+        rad = self.state["radiance"]
+        colour = colour if colour is not None else rad["film_mean"]
+        out = out if out is not None else self.film_f
+        args, keep = api.make_filter_args(
+            n=[rad["n"]], mean=[rad["mean"]], m2=[rad["m2"]], m3=[rad["m3"]], film=[colour],
+            mean_corr=[self.mean_corr], disc=[self.disc], film_filtered=[out],
+            g_buffers=[self.g_buffer(g) for g in self.g_names], g_sds=self.g_sds,
+            filter_sd=self.filter_sd, radius=self.radius, denoise_film=False, roi=roi)
+        return args, keep
+
+    def prepass(self):
+        args, keep = self.filter_args()
+        api.prepass(args, 3)
+
+    def window_filter(self, roi=None):
+        args, keep = self.filter_args(roi=roi)
+        api.window_filter(args, 3)
+
+    def denoise(self):
+        """Estimator::Denoise for the RGB radiance buffer: pre-pass + window filter."""
+        args, keep = self.filter_args()
+        api.filter_f32x3(args)
+        return self.film_f
