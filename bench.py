@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py -- denoised Mpixels/s of the StatMC statistics hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input, per GPU:
+    accumulate   S samples/pixel x 11 channels (radiance RGB, normal, albedo, depth, material id)
+                 into the running moments          (StatTile::Add*Sample* + Merge*Tile)
+    pre-pass     (n, mean, m2, m3) -> Johnson-corrected mean + discriminator
+    [halo]       N > 1 only: r-pixel border of the 5 filter inputs from the neighbour blocks (RCCL)
+    filter       (2r+1)^2 statistics-gated cross-bilateral window over the colour image
+with every input already resident in HBM when the timed region starts.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 1920x1080 film,
+256 spp, 11-channel sample stream, shipped filter parameters (filtersd 10, filterradius 20,
+normal sd 0.1, albedo sd 0.02).  For N > 1 every rank owns one 1920x1080 block of an
+N-block film (2x1, 2x2, 4x2 blocks) -- weak scaling, value = all blocks' pixels / step time.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TOPS = 78.6          # fp32 VALU instructions/s (10^12): 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+FILTER_BYTES_PER_PX = 72       # 60 B in (5 float3 images) + 12 B out
+PREPASS_BYTES_PER_PX = 64      # 40 B in + 24 B out
+
+
+def accumulate_bytes_per_px(spp, types):
+    from statmc_amd.film import STAT_TYPES
+    total = 0
+    for t in types:
+        cfg = STAT_TYPES[t]
+        c = cfg["channels"]
+        planes = {1: 1, 2: 2, 3: 3}[cfg["max_moment"]] + (2 if cfg["transform"] else 0)
+        total += 4 * c * spp + 2 * (4 + 4 * c * planes)   # samples + RMW of n and the moment planes
+    return total
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--radius", type=int, default=20)
+    ap.add_argument("--filtersd", type=float, default=10.0)
+    ap.add_argument("--channels", type=int, default=11, choices=(9, 11))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=96, help="rows of the film the CPU baseline filters")
+    ap.add_argument("--cpu-acc-rows", type=int, default=16, help="rows of the film the CPU baseline accumulates")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, fs, samples, types):
+    """Times the CPU oracle (the restated reference algorithm, OpenMP over tiles / rows, all host
+    cores) on a bounded sample of the same workload.  Reported, never used by the GPU path."""
+    import numpy as np
+    from oracle import oracle
+    from statmc_amd.film import STAT_TYPES
+    W, H, S = args.width, args.height, args.spp
+    cores = oracle.num_threads()
+    # accumulate: a strip of `cpu_acc_rows` rows, all spp, all channels
+    ar = min(args.cpu_acc_rows, H)
+    y0 = (H - ar) // 2
+    t_acc = 0.0
+    for t in types:
+        smp = samples[t][:, y0:y0 + ar].contiguous().cpu().numpy()
+        st = oracle.new_state(ar, W, STAT_TYPES[t]["channels"])
+        t0 = time.perf_counter()
+        oracle.accumulate(st, smp, STAT_TYPES[t]["transform"], STAT_TYPES[t]["max_moment"])
+        t_acc += time.perf_counter() - t0
+    acc_s_per_px = t_acc / (ar * W)
+    # pre-pass + filter: `cpu_rows` output rows in the middle of the film, full window
+    rad = {k: v.cpu().numpy() for k, v in fs.state["radiance"].items() if v is not None}
+    gb = [fs.g_buffer(g).cpu().numpy() for g in fs.g_names]
+    t0 = time.perf_counter()
+    mc, dc = oracle.prepass(rad["n"], rad["mean"], rad["m2"], rad["m3"])
+    t_pre = time.perf_counter() - t0
+    fr = min(args.cpu_rows, H)
+    fy0 = (H - fr) // 2
+    t0 = time.perf_counter()
+    oracle.filter_image(mc, dc, rad["film_mean"], gb, [-0.5 / (sd * sd) for sd in fs.g_sds],
+                        -0.5 / (args.filtersd ** 2), args.radius, roi=(0, fy0, W, fy0 + fr))
+    t_flt = time.perf_counter() - t0
+    s_per_px = acc_s_per_px + t_pre / (W * H) + t_flt / (fr * W)
+    return {
+        "value": round(1e-6 / s_per_px, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+        "sample": "oracle (C restatement, OpenMP, %d threads): accumulate %d rows x %d px x %d spp x %d ch "
+                  "(%.2f s), pre-pass full frame (%.2f s), filter %d rows x %d px full window (%.2f s); "
+                  "per-pixel times summed and inverted" % (cores, ar, W, S, args.channels, t_acc, t_pre, fr, W, t_flt),
+        "accumulate_s_per_mpx": round(acc_s_per_px * 1e6, 4),
+        "filter_s_per_mpx": round(t_flt / (fr * W) * 1e6, 4),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
+                             "--nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a gfx950 GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from statmc_amd import api, film, sharding, synthetic
+    api.setup(local_rank)
+
+    W, H, S, r = args.width, args.height, args.spp, args.radius
+    types = list(synthetic.FEATURES) if args.channels == 11 else ["radiance", "normal", "albedo"]
+    layout = sharding.BlockLayout(rank, world, W, H, r)
+    fw, fh = layout.film_size
+    ox, oy = layout.origin
+
+    # ---- synthetic inputs, generated in place in HBM (seeded; same generator as the tests)
+    scene = synthetic.Scene(W, H, n_regions=12 * world, seed=1, device=dev, x_offset=ox, y_offset=oy,
+                            full_width=fw, full_height=fh)
+    samples = {t: [] for t in types}
+    chunk = 32
+    for s0 in range(0, S, chunk):
+        part = scene.samples(min(chunk, S - s0), seed=1000 * (rank + 1) + s0, features=types)
+        for t in types:
+            samples[t].append(part[t])
+    samples = {t: torch.cat(v, dim=0) for t, v in samples.items()}
+    fs = film.FilmStats(W, H, dev, types=types, filter_sd=args.filtersd, radius=r)
+
+    # padded filter inputs for the multi-GPU path (block + halo)
+    if world > 1:
+        pad = {k: layout.new_padded(3, dev) for k in ("mean_corr", "disc", "colour", "normal", "albedo")}
+        packed = layout.new_padded(15, dev)
+        out_pad = layout.new_padded(3, dev)
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    k_events = {"accumulate": [], "prepass": [], "halo": [], "filter": []}
+
+    def step(record):
+        e = [ev() for _ in range(5)] if record else None
+        if record: e[0].record()
+        fs.accumulate(samples)
+        if record: e[1].record()
+        fs.prepass()
+        if record: e[2].record()
+        if world == 1:
+            if record: e[3].record()
+            fs.window_filter()
+        else:
+            rad = fs.state["radiance"]
+            L = layout
+            inner = L.interior(packed)
+            inner[..., 0:3].copy_(fs.mean_corr)
+            inner[..., 3:6].copy_(fs.disc)
+            inner[..., 6:9].copy_(rad["film_mean"])
+            inner[..., 9:12].copy_(fs.g_buffer("normal"))
+            inner[..., 12:15].copy_(fs.g_buffer("albedo"))
+            sharding.exchange_halo(L, packed)
+            for i, k in enumerate(("mean_corr", "disc", "colour", "normal", "albedo")):
+                pad[k].copy_(packed[..., 3 * i:3 * i + 3])
+            if record: e[3].record()
+            a, keep = api.make_filter_args(
+                n=[], mean=[], m2=[], m3=[], film=[pad["colour"]], mean_corr=[pad["mean_corr"]],
+                disc=[pad["disc"]], film_filtered=[out_pad], g_buffers=[pad["normal"], pad["albedo"]],
+                g_sds=fs.g_sds, filter_sd=args.filtersd, radius=r, roi=L.roi)
+            api.window_filter(a, 3)
+        if record:
+            e[4].record()
+            for name, i in (("accumulate", 0), ("prepass", 1), ("halo", 2), ("filter", 3)):
+                k_events[name].append((e[i], e[i + 1]))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    variant = api.last_filter_variant()
+    ms = {k: (sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1)) for k, v in k_events.items()}
+    px_block = W * H
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * px_block * args.steps / elapsed / 1e6
+
+    result = None
+    if rank == 0:
+        flt_gbs = FILTER_BYTES_PER_PX * px_block / (ms["filter"] * 1e-3) / 1e9
+        acc_bpp = accumulate_bytes_per_px(S, types)
+        acc_gbs = acc_bpp * px_block / (ms["accumulate"] * 1e-3) / 1e9
+        pre_gbs = PREPASS_BYTES_PER_PX * px_block / (ms["prepass"] * 1e-3) / 1e9
+        taps = (2 * r + 1) ** 2
+        valu_tops = 28.0 * taps * px_block / (ms["filter"] * 1e-3) / 1e12  # 27 VALU + 1 extra slot for v_exp
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "filter_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "denoised_mpixels_per_s", "value": round(value, 3), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "StatMC accumulate+prepass+filter, %dx%d block/GPU, %d spp, %d-channel samples, "
+                            "filterradius %d, filtersd %g, G-buffers normal(sd 0.1)+albedo(sd 0.02) "
+                            "[BASELINE.json configs[2] shape, synthetic stream]" % (W, H, S, args.channels, r, args.filtersd),
+                "film": "%dx%d" % (fw, fh), "block_grid": "%dx%d" % (layout.gx, layout.gy),
+                "spp": S, "sample_channels": args.channels, "filter_variant": variant,
+                "parallelism": "film blocks x%d, RCCL halo exchange" % world if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "kernel": "window_filter_lds (%s)" % variant, "bound": "hbm",
+                "achieved": round(flt_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(flt_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": FILTER_BYTES_PER_PX * px_block,
+                "avg_launch_ms": round(ms["filter"], 4),
+                "note": "the r=%d window filter is a %d-tap fp32 stencil (VALU-bound, not HBM-bound); "
+                        "valu_frac is its fraction of the fp32 VALU issue peak" % (r, taps),
+                "valu_frac": round(valu_tops / VALU_PEAK_TOPS, 4),
+            },
+            "kernels": {
+                "accumulate": {"avg_ms": round(ms["accumulate"], 4), "bytes_per_px": acc_bpp,
+                               "achieved_GBs": round(acc_gbs, 1), "frac_hbm": round(acc_gbs / HBM_PEAK_GBS, 4)},
+                "prepass": {"avg_ms": round(ms["prepass"], 4), "bytes_per_px": PREPASS_BYTES_PER_PX,
+                            "achieved_GBs": round(pre_gbs, 1), "frac_hbm": round(pre_gbs / HBM_PEAK_GBS, 4)},
+                "halo_exchange": {"avg_ms": round(ms["halo"], 4)},
+                "filter": {"avg_ms": round(ms["filter"], 4), "mpixels_per_s": round(px_block / ms["filter"] / 1e3, 2)},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, fs, samples, types)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,105 @@
+"""Block decomposition of the film over the GPUs of one node and the halo exchange the window
+filter needs (new capability: the reference is single-GPU).
+
+Every rank owns one block of every per-pixel image.  Accumulation and the pre-pass are purely
+per-pixel, so they run on the owned block with no communication.  The window filter reads a
+(2r+1)^2 neighbourhood, so before it runs each rank fetches an r-pixel border of the five filter
+inputs (mean-corr, discriminator, colour, normal, albedo = 15 floats / pixel) from its
+neighbours: a two-phase exchange (left/right columns first, then top/bottom rows of the already
+widened block, which carries the corners along) = at most 4 point-to-point messages per rank
+over RCCL send/recv (xGMI is point-to-point, every neighbour is one hop).
+"""
+import torch
+import torch.distributed as dist
+
+GRIDS = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
+
+
+def grid_for(world_size):
+    if world_size in GRIDS:
+        return GRIDS[world_size]
+    return (world_size, 1)  # column strips for any other count
+
+
+class BlockLayout:
+    """Rank (bx, by) of a gx x gy grid of equal blocks (block_w x block_h pixels each)."""
+
+    def __init__(self, rank, world_size, block_w, block_h, radius, grid=None):
+        self.rank, self.world = rank, world_size
+        self.gx, self.gy = grid if grid is not None else grid_for(world_size)
+        assert self.gx * self.gy == world_size
+        self.bx, self.by = rank % self.gx, rank // self.gx
+        self.bw, self.bh, self.r = block_w, block_h, radius
+        self.left = self._nb(-1, 0)
+        self.right = self._nb(1, 0)
+        self.up = self._nb(0, -1)
+        self.down = self._nb(0, 1)
+        # halo widths actually present (no neighbour -> true film border -> no padding)
+        self.pl = radius if self.left is not None else 0
+        self.pr = radius if self.right is not None else 0
+        self.pt = radius if self.up is not None else 0
+        self.pb = radius if self.down is not None else 0
+        self.pw, self.ph = self.bw + self.pl + self.pr, self.bh + self.pt + self.pb
+
+    def _nb(self, dx, dy):
+        x, y = self.bx + dx, self.by + dy
+        if 0 <= x < self.gx and 0 <= y < self.gy:
+            return y * self.gx + x
+        return None
+
+    @property
+    def film_size(self):
+        return self.gx * self.bw, self.gy * self.bh
+
+    @property
+    def origin(self):
+        """Film coordinates of the block's first pixel."""
+        return self.bx * self.bw, self.by * self.bh
+
+    @property
+    def roi(self):
+        """Owned pixels inside the padded local image: (x0, y0, x1, y1)."""
+        return (self.pl, self.pt, self.pl + self.bw, self.pt + self.bh)
+
+    def new_padded(self, channels, device, dtype=torch.float32):
+        return torch.zeros(self.ph, self.pw, channels, dtype=dtype, device=device)
+
+    def interior(self, padded):
+        return padded[self.pt:self.pt + self.bh, self.pl:self.pl + self.bw]
+
+
+def exchange_halo(layout, padded, group=None):
+    """Fill the halo margins of `padded` ([ph, pw, C], interior already written) from the
+    neighbouring ranks.  Works on any backend (nccl == RCCL on ROCm, gloo on CPU)."""
+    L, r = layout, layout.r
+    if L.world == 1 or r == 0:
+        return
+
+    def phase(pairs):
+        ops, recvs = [], []
+        for peer, send_view, recv_view in pairs:
+            if peer is None:
+                continue
+            sbuf = send_view.contiguous()
+            rbuf = torch.empty_like(recv_view, memory_format=torch.contiguous_format)
+            ops.append(dist.P2POp(dist.isend, sbuf, peer, group=group))
+            ops.append(dist.P2POp(dist.irecv, rbuf, peer, group=group))
+            recvs.append((recv_view, rbuf))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for view, buf in recvs:
+            view.copy_(buf)
+
+    y0, y1 = L.pt, L.pt + L.bh
+    x0, x1 = L.pl, L.pl + L.bw
+    # phase 1: columns (owned rows only)
+    phase([
+        (L.left, padded[y0:y1, x0:x0 + r], padded[y0:y1, 0:x0]),
+        (L.right, padded[y0:y1, x1 - r:x1], padded[y0:y1, x1:x1 + L.pr]),
+    ])
+    # phase 2: rows over the full padded width (corners ride along)
+    phase([
+        (L.up, padded[y0:y0 + r, :], padded[0:y0, :]),
+        (L.down, padded[y1 - r:y1, :], padded[y1:y1 + L.pb, :]),
+    ])

@@ -1,0 +1,89 @@
+"""No-GPU checks of the C-ABI library: it loads, exports every symbol include/statmc.h
+declares, and refuses to compute without a device (no silent fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from statmc_amd import api, build
+    build.build()
+    return api.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "statmc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(statmc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_python_export_list_matches_header():
+    from statmc_amd import api
+    assert sorted(api.EXPORTS) == declared_symbols()
+
+
+def test_struct_layouts_match_header(lib):
+    """ctypes mirrors of statmc_image / statmc_filter_args / statmc_stat_type vs the C compiler."""
+    import subprocess
+    import tempfile
+    from statmc_amd import api
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "statmc.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(statmc_image), sizeof(statmc_filter_args),
+         sizeof(statmc_stat_type), offsetof(statmc_filter_args, film_buffer),
+         offsetof(statmc_filter_args, n_g_buffers), offsetof(statmc_filter_args, stream),
+         offsetof(statmc_filter_args, roi_x0), offsetof(statmc_stat_type, samples));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        got = [int(x) for x in subprocess.check_output([os.path.join(d, "t")]).split()]
+    fa, st = api.FilterArgs, api.StatType
+    assert got == [C.sizeof(api.Image), C.sizeof(fa), C.sizeof(st), fa.film_buffer.offset,
+                   fa.n_g_buffers.offset, fa.stream.offset, fa.roi_x0.offset, st.samples.offset]
+
+
+def test_no_device_means_error_not_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from statmc_amd import api
+    assert lib.statmc_setup(0) == api.ERR_NO_DEVICE
+    assert b"device" in lib.statmc_last_error().lower()
+    a = api.FilterArgs()
+    a.width, a.height = 8, 8
+    assert lib.statmc_filter_f32x3(C.byref(a)) == api.ERR_NO_DEVICE       # setup() was never successful
+    assert lib.statmc_accumulate(8, 8, None, 0, None) == api.ERR_NO_DEVICE
+    with pytest.raises(api.StatmcError):
+        api.setup(0)
+
+
+def test_product_does_not_import_oracle():
+    """The product path may not import, include or load the checker (oracle/) in any form."""
+    offenders = []
+    for base in ("statmc_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if not f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                    continue
+                for line in open(os.path.join(dirpath, f), errors="ignore"):
+                    code = line.split("//")[0].split("#")[0] if not line.lstrip().startswith("#include") else line
+                    if re.search(r"(import|include|CDLL|dlopen).*oracle", code):
+                        offenders.append((f, line.strip()))
+    assert not offenders, offenders

@@ -1,0 +1,352 @@
+"""GPU parity tests proper: every HIP entry point, called through the C ABI, against the CPU
+oracle on the same seeded inputs.  Bar: bit-exact for integer work and for every floating-point
+stage whose operations are IEEE-identical on both sides (raw-sample moments, pre-pass, mean-vars,
+tile scatter); <= 1e-5 relative L2 per channel (the tolerance BASELINE.json states) where the
+GPU uses sqrt for pow(x, 0.5) or v_exp_f32 for expf."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import FILTER_SD, RADIUS, SD_ALBEDO, SD_NORMAL, make_case, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+G_DR = [-0.5 / SD_NORMAL ** 2, -0.5 / SD_ALBEDO ** 2]
+TOL = 1e-5
+
+
+def to_dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def dev_state(st):
+    return {k: to_dev(v) for k, v in st.items()}
+
+
+# ------------------------------------------------------------------ accumulate
+@pytest.mark.parametrize("channels", [1, 3])
+@pytest.mark.parametrize("transform,max_moment", [(False, 1), (False, 2), (False, 3), (True, 1), (True, 2), (True, 3)])
+def test_accumulate_matches_oracle(gpu, oracle, channels, transform, max_moment):
+    rng = np.random.default_rng(10 * channels + max_moment)
+    H, W = 23, 37                                           # ragged: not a multiple of 4 pixels
+    batches = [4, 4, 8, 1]                                   # the reference's 4,4,8,... schedule + a single sample
+    smp = rng.lognormal(0, 1, size=(sum(batches), H, W, channels)).astype(np.float32)
+    smp[rng.random(smp.shape) < 0.2] = 0.0                   # zero-radiance paths -> Box-Cox -2
+    smp[3, 5, 7] *= 1000.0                                   # a firefly
+    ref = oracle.new_state(H, W, channels)
+    st = dev_state(oracle.new_state(H, W, channels))
+    s0 = 0
+    for b in batches:
+        part = np.ascontiguousarray(smp[s0:s0 + b])
+        oracle.accumulate(ref, part, transform, max_moment)
+        gpu.accumulate(W, H, [gpu.make_stat_type(to_dev(part), st, transform, max_moment)])
+        s0 += b
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy() for k, v in st.items()}
+    assert np.array_equal(got["n"], ref["n"])
+    if transform:
+        assert np.array_equal(got["film_mean"], ref["film_mean"])       # raw-sample moments: exact
+        assert np.array_equal(got["film_m2"], ref["film_m2"])
+        for k in ("mean", "m2", "m3"):
+            assert rel_l2(got[k], ref[k]) <= TOL, k
+    else:
+        for k in ("mean", "m2", "m3"):
+            assert np.array_equal(got[k], ref[k]), k
+    for k, lim in (("m2", 2), ("m3", 3)):                                # moments above max_moment stay untouched
+        if max_moment < lim:
+            assert not got[k].any()
+
+
+def test_accumulate_all_types_one_launch(gpu, oracle):
+    """The 11-channel sample vector: radiance, normal, albedo, depth, material id in one launch."""
+    from statmc_amd import film, synthetic
+    W, H, S = 52, 19, 6
+    scene, smp, ref = make_case(W, H, S, seed=4, features=synthetic.FEATURES)
+    fs = film.FilmStats(W, H, DEV, types=synthetic.FEATURES)
+    fs.accumulate({k: to_dev(v) for k, v in smp.items()})
+    torch.cuda.synchronize()
+    for t in synthetic.FEATURES:
+        assert np.array_equal(fs.state[t]["n"].cpu().numpy(), ref[t]["n"])
+        if t == "radiance":
+            assert rel_l2(fs.state[t]["mean"].cpu().numpy(), ref[t]["mean"]) <= TOL
+            assert np.array_equal(fs.state[t]["film_mean"].cpu().numpy(), ref[t]["film_mean"])
+        else:
+            assert np.array_equal(fs.state[t]["mean"].cpu().numpy(), ref[t]["mean"]), t
+
+
+def test_accumulate_empty_and_errors(gpu, oracle):
+    st = dev_state(oracle.new_state(4, 4, 3))
+    empty = torch.zeros(0, 4, 4, 3, device=DEV)
+    gpu.accumulate(4, 4, [gpu.make_stat_type(empty, st, True, 3)])      # zero samples: state untouched
+    torch.cuda.synchronize()
+    assert not st["n"].any() and not st["mean"].any()
+    gpu.accumulate(4, 4, [])                                            # no stat types: no-op
+    bad = gpu.make_stat_type(torch.zeros(1, 4, 4, 3, device=DEV), st, True, 3)
+    bad.max_moment = 4
+    with pytest.raises(gpu.StatmcError) as e:
+        gpu.accumulate(4, 4, [bad])
+    assert e.value.code == gpu.ERR_INVALID
+    bad = gpu.make_stat_type(torch.zeros(1, 4, 4, 3, device=DEV), st, True, 3)
+    bad.film_mean = None                                                # transform types need the film images
+    with pytest.raises(gpu.StatmcError):
+        gpu.accumulate(4, 4, [bad])
+
+
+# ------------------------------------------------------------------ merge tiles / mean vars / tile moments
+@pytest.mark.parametrize("channels,transform", [(1, False), (3, True), (3, False)])
+def test_merge_tiles_matches_oracle(gpu, oracle, channels, transform):
+    rng = np.random.default_rng(3)
+    W, H, ts = 41, 27, 16                                               # 16x16 tiles, ragged right/bottom
+    dt = oracle.TILE_PIXEL_DTYPE[channels]
+    bounds, offsets, tiles = [], [], []
+    off = 0
+    for y0 in range(0, H, ts):
+        for x0 in range(0, W, ts):
+            x1, y1 = min(x0 + ts, W), min(y0 + ts, H)
+            npx = (x1 - x0) * (y1 - y0)
+            t = np.zeros(npx, dtype=dt)
+            t["n"] = rng.integers(1, 1000, npx)
+            for k in ("mean", "m2", "m3", "film_mean", "film_m2"):
+                t[k] = rng.standard_normal(t[k].shape).astype(np.float32)
+            tiles.append(t)
+            bounds.append((x0, y0, x1, y1))
+            offsets.append(off)
+            off += npx
+    ref = oracle.new_state(H, W, channels)
+    for k in ref:
+        ref[k][...] = -7                                               # MergeTile leaves film images alone
+    st = dev_state(ref)
+    for t, b in zip(tiles, bounds):
+        oracle.merge_tile(t, channels, *b, ref, transform=transform)
+    raw = torch.from_numpy(np.concatenate(tiles).view(np.uint8)).to(DEV)
+    gpu.merge_tiles(W, H, channels, transform, raw, to_dev(np.array(bounds, np.int32)),
+                    to_dev(np.array(offsets, np.int64)), ts * ts, st)
+    torch.cuda.synchronize()
+    for k in ref:
+        assert np.array_equal(st[k].cpu().numpy(), ref[k]), k
+
+
+@pytest.mark.parametrize("channels", [1, 3])
+@pytest.mark.parametrize("quirk", [True, False])
+def test_mean_vars_matches_oracle(gpu, oracle, channels, quirk):
+    rng = np.random.default_rng(8)
+    H, W = 9, 31
+    n = rng.integers(2, 50, (H, W)).astype(np.int32)                   # non-uniform n pins the per-row quirk
+    m2 = rng.random((H, W, channels), dtype=np.float32)
+    out = torch.zeros(H, W, channels, device=DEV)
+    gpu.calculate_mean_vars([to_dev(n)], [to_dev(m2)], [out], row_n_quirk=quirk)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), oracle.mean_vars(n, m2, row_n_quirk=quirk))
+
+
+@pytest.mark.parametrize("tile_size", [8, 16])
+def test_tile_moments(gpu, tile_size):
+    rng = np.random.default_rng(1)
+    H, W, Cn = 37, 50, 3
+    v = rng.lognormal(0, 1, (H, W, Cn)).astype(np.float32)
+    ty, tx = -(-H // tile_size), -(-W // tile_size)
+    out = torch.zeros(ty, tx, Cn, 3, device=DEV)
+    gpu.tile_moments(to_dev(v), tile_size, out)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for j in range(ty):
+        for i in range(tx):
+            blk = v[j * tile_size:(j + 1) * tile_size, i * tile_size:(i + 1) * tile_size].astype(np.float64)
+            cnt = blk.shape[0] * blk.shape[1]
+            assert np.allclose(out[j, i, :, 0], cnt)
+            assert np.allclose(out[j, i, :, 1], blk.mean((0, 1)), rtol=1e-5)
+            assert np.allclose(out[j, i, :, 2], ((blk - blk.mean((0, 1))) ** 2).sum((0, 1)), rtol=1e-4)
+
+
+# ------------------------------------------------------------------ pre-pass
+@pytest.mark.parametrize("channels", [1, 3])
+def test_prepass_bit_exact(gpu, oracle, channels):
+    rng = np.random.default_rng(12)
+    H, W = 17, 29
+    n = rng.integers(0, 40, (H, W)).astype(np.int32)                   # includes n = 0, 1 (discriminator = inf)
+    n[0, :5] = [0, 1, 2, 4097, 100000]                                  # table edge and beyond
+    mean = rng.standard_normal((H, W, channels)).astype(np.float32)
+    m2 = rng.random((H, W, channels), dtype=np.float32)
+    m2[1, :4] = 0.0                                                     # zero variance
+    m3 = rng.standard_normal((H, W, channels)).astype(np.float32)
+    mean[2, 3] = np.nan                                                 # negative sample upstream
+    mc_ref, d_ref = oracle.prepass(n, mean, m2, m3)
+    mc, d = torch.zeros(H, W, channels, device=DEV), torch.zeros(H, W, channels, device=DEV)
+    dummy = torch.zeros(H, W, channels, device=DEV)
+    a, keep = gpu.make_filter_args([to_dev(n)], [to_dev(mean)], [to_dev(m2)], [to_dev(m3)], [dummy], [mc], [d],
+                                   [dummy.clone()], [], g_sds=[], radius=1)
+    gpu.prepass(a, channels)
+    torch.cuda.synchronize()
+    assert np.array_equal(mc.cpu().numpy(), mc_ref, equal_nan=True)
+    assert np.array_equal(d.cpu().numpy(), d_ref, equal_nan=True)
+
+
+def test_significance_levels(gpu, oracle):
+    n = np.full((4, 8), 12, np.int32)
+    rng = np.random.default_rng(0)
+    mean, m2, m3 = (rng.random((4, 8, 3), dtype=np.float32) for _ in range(3))
+    outs = []
+    try:
+        for idx in (0, 1, 2):
+            gpu.check(gpu.load().statmc_set_significance(idx))
+            mc, d = torch.zeros(4, 8, 3, device=DEV), torch.zeros(4, 8, 3, device=DEV)
+            dummy = torch.zeros(4, 8, 3, device=DEV)
+            a, keep = gpu.make_filter_args([to_dev(n)], [to_dev(mean)], [to_dev(m2)], [to_dev(m3)], [dummy], [mc],
+                                           [d], [dummy.clone()], [], g_sds=[], radius=1)
+            gpu.prepass(a, 3)
+            torch.cuda.synchronize()
+            assert np.array_equal(d.cpu().numpy(), oracle.prepass(n, mean, m2, m3, alpha_index=idx)[1])
+            outs.append(d.cpu().numpy())
+        assert (outs[1] > outs[0]).all() and (outs[0] > outs[2]).all()   # 0.002 > 0.005 > 0.05 quantiles
+        assert gpu.load().statmc_set_significance(3) == gpu.ERR_INVALID
+    finally:
+        gpu.load().statmc_set_significance(0)
+
+
+# ------------------------------------------------------------------ window filter
+def run_filter(gpu, mc, disc, colour, gbs, g_dr, filter_sd, radius, roi=None, channels=3, force=0):
+    out = torch.zeros_like(to_dev(colour))
+    a, keep = gpu.make_filter_args([], [], [], [], [to_dev(colour)], [to_dev(mc)], [to_dev(disc)], [out],
+                                   [to_dev(g) for g in gbs], g_dr=g_dr, filter_sd=filter_sd, radius=radius, roi=roi)
+    gpu.force_filter_variant(force)
+    try:
+        gpu.window_filter(a, channels)
+        torch.cuda.synchronize()
+    finally:
+        gpu.force_filter_variant(0)
+    return out.cpu().numpy(), gpu.last_filter_variant()
+
+
+def stats_case(oracle, W, H, spp, seed):
+    _, smp, st = make_case(W, H, spp, seed=seed)
+    rad = st["radiance"]
+    mc, disc = oracle.prepass(rad["n"], rad["mean"], rad["m2"], rad["m3"])
+    return mc, disc, rad["film_mean"], [st["normal"]["mean"], st["albedo"]["mean"]]
+
+
+@pytest.mark.parametrize("W,H,radius,sd,force,variant", [
+    (300, 41, 20, 10.0, 0, "lds_r20"),     # shipped default; 2 tile columns, ragged right edge, 6 tile rows
+    (300, 41, 20, 10.0, 2, "lds_rt"),
+    (300, 41, 20, 10.0, 1, "generic"),
+    (37, 21, 6, 3.0, 0, "lds_rt"),         # glass-caustics config; image smaller than one tile
+    (259, 9, 3, 2.0, 0, "lds_rt"),         # radius not a multiple of 4, width 4k+3
+    (64, 50, 1, 1.0, 0, "lds_rt"),
+    (45, 33, 24, 12.0, 0, "generic"),      # radius beyond the LDS kernel's range
+])
+def test_filter_matches_oracle(gpu, oracle, W, H, radius, sd, force, variant):
+    mc, disc, colour, gbs = stats_case(oracle, W, H, 8, seed=W + radius)
+    ref = oracle.filter_image(mc, disc, colour, gbs, G_DR, -0.5 / sd ** 2, radius)
+    out, v = run_filter(gpu, mc, disc, colour, gbs, G_DR, sd, radius, force=force)
+    assert v == variant
+    for c in range(3):
+        assert rel_l2(out[..., c], ref[..., c]) <= TOL, c
+
+
+def test_filter_low_spp_high_rejection(gpu, oracle):
+    """4 spp: wide confidence intervals at some pixels, heavy rejection at edges."""
+    mc, disc, colour, gbs = stats_case(oracle, 280, 30, 4, seed=77)
+    ref = oracle.filter_image(mc, disc, colour, gbs, G_DR, -0.5 / FILTER_SD ** 2, RADIUS)
+    out, v = run_filter(gpu, mc, disc, colour, gbs, G_DR, FILTER_SD, RADIUS)
+    assert v == "lds_r20"
+    assert max(rel_l2(out[..., c], ref[..., c]) for c in range(3)) <= TOL
+
+
+def test_filter_special_pixels(gpu, oracle):
+    """n < 2 (infinite discriminator), zero variance, NaN statistics (negative sample upstream),
+    and a pixel with no member at all (falls back to its own colour)."""
+    mc, disc, colour, gbs = stats_case(oracle, 270, 26, 8, seed=5)
+    disc[3, 10] = np.inf
+    disc[4, 100:140] = 0.0
+    mc[7, 200] = np.nan
+    mc[9, 50] = 1e6
+    disc[9, 50] = 0.0                                                   # rejects everyone but itself
+    mc[12, 60] = np.nan
+    disc[12, 60] = np.nan                                               # not even a member of itself
+    ref = oracle.filter_image(mc, disc, colour, gbs, G_DR, -0.5 / FILTER_SD ** 2, RADIUS)
+    assert np.array_equal(ref[12, 60], colour[12, 60])
+    for force in (0, 2, 1):
+        out, v = run_filter(gpu, mc, disc, colour, gbs, G_DR, FILTER_SD, RADIUS, force=force)
+        assert np.isfinite(out).all(), v
+        assert np.array_equal(out[12, 60], colour[12, 60]), v
+        assert max(rel_l2(out[..., c], ref[..., c]) for c in range(3)) <= TOL, v
+
+
+def test_filter_roi(gpu, oracle):
+    """The multi-GPU block path: outputs only inside the ROI, window clipped to the local image."""
+    mc, disc, colour, gbs = stats_case(oracle, 330, 60, 8, seed=6)
+    roi = (20, 20, 310, 40)
+    ref = oracle.filter_image(mc, disc, colour, gbs, G_DR, -0.5 / FILTER_SD ** 2, RADIUS, roi=roi)
+    for force in (0, 1):
+        out, v = run_filter(gpu, mc, disc, colour, gbs, G_DR, FILTER_SD, RADIUS, roi=roi, force=force)
+        assert not out[:20].any() and not out[40:].any() and not out[:, :20].any() and not out[:, 310:].any()
+        assert max(rel_l2(out[..., c], ref[..., c]) for c in range(3)) <= TOL, v
+
+
+@pytest.mark.parametrize("channels", [1, 3])
+def test_filter_generic_gbuffer_sets(gpu, oracle, channels):
+    """filter<float> and float G-buffers (depth / material id) go through the generic kernel."""
+    rng = np.random.default_rng(21)
+    H, W, r = 30, 44, 7
+    mc = rng.random((H, W, channels), dtype=np.float32)
+    disc = (0.1 * rng.random((H, W, channels))).astype(np.float32)
+    colour = rng.random((H, W, channels), dtype=np.float32)
+    gbs = [rng.random((H, W, 3), dtype=np.float32), rng.random((H, W, 1), dtype=np.float32),
+           rng.integers(0, 3, (H, W, 1)).astype(np.float32)]
+    g_dr = [-0.5 / 0.3 ** 2, -0.5 / 0.2 ** 2, -0.5 / 0.1 ** 2]
+    ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / 16.0, r)
+    out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, 4.0, r, channels=channels)
+    assert v == "generic"
+    assert rel_l2(out, ref) <= TOL
+    # no G-buffers at all
+    ref0 = oracle.filter_image(mc, disc, colour, [], [], -0.5 / 16.0, r)
+    out0, _ = run_filter(gpu, mc, disc, colour, [], [], 4.0, r, channels=channels)
+    assert rel_l2(out0, ref0) <= TOL
+
+
+def test_filter_entry_point_reference_argument_order(gpu, oracle):
+    """statmc_filter_f32x3 with the reference's argument block: nBuffers = 2, denoiseFilm set:
+    buffer 0 filters `film` into `film-f`, buffer 1 filters its own film-mean (estimator.cpp:465-487)."""
+    W, H = 264, 20
+    _, smp, st = make_case(W, H, 8, seed=31)
+    rad = st["radiance"]
+    film_img = (rad["film_mean"] * 1.5).astype(np.float32)            # the "film" image differs from t0 film-mean
+    d = {k: to_dev(v) for k, v in rad.items()}
+    mc = [torch.zeros(H, W, 3, device=DEV) for _ in range(2)]
+    dc = [torch.zeros(H, W, 3, device=DEV) for _ in range(2)]
+    ff = [torch.zeros(H, W, 3, device=DEV) for _ in range(2)]
+    film_f = torch.zeros(H, W, 3, device=DEV)
+    gb = [to_dev(st["normal"]["mean"]), to_dev(st["albedo"]["mean"])]
+    a, keep = gpu.make_filter_args([d["n"]] * 2, [d["mean"]] * 2, [d["m2"]] * 2, [d["m3"]] * 2,
+                                   [d["film_mean"]] * 2, mc, dc, ff, gb, g_sds=[SD_NORMAL, SD_ALBEDO],
+                                   filter_sd=FILTER_SD, radius=RADIUS, denoise_film=True,
+                                   film_buffer=to_dev(film_img), film_filtered_buffer=film_f)
+    gpu.filter_f32x3(a)
+    torch.cuda.synchronize()
+    mcr, dr = oracle.prepass(rad["n"], rad["mean"], rad["m2"], rad["m3"])
+    gbn = [st["normal"]["mean"], st["albedo"]["mean"]]
+    ref0 = oracle.filter_image(mcr, dr, film_img, gbn, G_DR, -0.5 / FILTER_SD ** 2, RADIUS)
+    ref1 = oracle.filter_image(mcr, dr, rad["film_mean"], gbn, G_DR, -0.5 / FILTER_SD ** 2, RADIUS)
+    assert np.array_equal(mc[1].cpu().numpy(), mcr) and np.array_equal(dc[0].cpu().numpy(), dr)
+    assert rel_l2(film_f.cpu().numpy(), ref0) <= TOL
+    assert rel_l2(ff[1].cpu().numpy(), ref1) <= TOL
+    assert not ff[0].any()                                             # buffer 0 wrote film-f, not t0-b0-film-mean-f
+
+
+def test_filter_argument_errors(gpu):
+    z = lambda c=3: torch.zeros(8, 8, c, device=DEV)
+    a, keep = gpu.make_filter_args([], [], [], [], [z()], [z()], [z()], [z()], [z()], g_sds=[0.1], radius=2)
+    a.roi_x1, a.roi_y1 = 20, 4                                         # ROI outside the image
+    with pytest.raises(gpu.StatmcError) as e:
+        gpu.window_filter(a, 3)
+    assert e.value.code == gpu.ERR_INVALID
+    img = z()
+    a, keep = gpu.make_filter_args([], [], [], [], [img], [z()], [z()], [img], [], g_sds=[], radius=2)
+    with pytest.raises(gpu.StatmcError):                               # in-place filtering is refused
+        gpu.window_filter(a, 3)
+    a, keep = gpu.make_filter_args([], [], [], [], [z()], [z()], [z()], [z()], [], g_sds=[], radius=2)
+    a.mean_corr[0].step = 8 * 3 * 4 + 64                               # pitched rows are not supported
+    with pytest.raises(gpu.StatmcError) as e:
+        gpu.window_filter(a, 3)
+    assert e.value.code == gpu.ERR_UNSUPPORTED

@@ -1,0 +1,192 @@
+"""CPU tests of the oracle itself: the one known-answer vector that exists for this path, and
+reference-free properties of the restated algorithms."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_known_answer_survey_appendix_a(oracle):
+    """float pixel, samples {0.25, 1.5, 0, 7.25, 0.5} through
+    AddTransformSampleM3 of the compiled reference header (estimator.h:188-226)."""
+    kat = json.load(open(os.path.join(GOLDEN, "kat_survey_appendix_a.json")))
+    px = oracle.add_samples_to_pixel(kat["samples"], 1, True, 3)
+    assert int(px["n"]) == kat["n"]
+    for k in ("mean", "m2", "m3", "film_mean", "film_m2"):
+        # the survey printed 9 significant digits: identical after rounding to float32
+        assert np.float32(px[k]) == np.float32(kat[k]), (k, px[k], kat[k])
+
+
+def test_box_cox(oracle):
+    assert oracle.box_cox(0.0) == -2.0              # zero-radiance paths (hard parts)
+    assert oracle.box_cox(1.0) == 0.0
+    assert oracle.box_cox(4.0) == 2.0
+    assert np.isnan(oracle.box_cox(-1e-6))          # tiny negative samples give NaN in the reference
+
+
+@pytest.mark.parametrize("channels", [1, 3])
+@pytest.mark.parametrize("max_moment", [1, 2, 3])
+@pytest.mark.parametrize("transform", [False, True])
+def test_accumulate_matches_float64_moments(oracle, channels, max_moment, transform):
+    rng = np.random.default_rng(5)
+    S, H, W = 24, 9, 21   # ragged vs the 16x16 tiles
+    smp = rng.lognormal(0, 1, size=(S, H, W, channels)).astype(np.float32)
+    st = oracle.new_state(H, W, channels)
+    oracle.accumulate(st, smp[:10], transform, max_moment)
+    oracle.accumulate(st, smp[10:], transform, max_moment)   # state persists across batches
+    assert (st["n"] == S).all()
+    v = smp.astype(np.float64)
+    tv = (np.sqrt(v) - 1) / 0.5 if transform else v
+    mean = tv.mean(0)
+    assert rel_l2(st["mean"], mean) < 1e-5
+    if max_moment >= 2:
+        assert rel_l2(st["m2"], ((tv - mean) ** 2).sum(0)) < 1e-4
+    else:
+        assert not st["m2"].any()
+    if max_moment >= 3:
+        assert rel_l2(st["m3"], ((tv - mean) ** 3).sum(0)) < 2e-3   # ill-conditioned in fp32
+    else:
+        assert not st["m3"].any()
+    if transform:
+        assert rel_l2(st["film_mean"], v.mean(0)) < 1e-5
+        assert rel_l2(st["film_m2"], ((v - v.mean(0)) ** 2).sum(0)) < 1e-4
+    else:   # AddSample copies mean/m2 (estimator.h:209-210)
+        assert np.array_equal(st["film_mean"], st["mean"])
+        assert np.array_equal(st["film_m2"], st["m2"])
+
+
+def test_accumulate_edge_cases(oracle):
+    # constant samples: m2 = m3 = 0 exactly; single sample: n = 1, mean = sample
+    st = oracle.new_state(4, 5, 3)
+    oracle.accumulate(st, np.full((6, 4, 5, 3), 0.75, np.float32), False, 3)
+    assert (st["mean"] == 0.75).all() and not st["m2"].any() and not st["m3"].any()
+    st = oracle.new_state(2, 2, 1)
+    oracle.accumulate(st, np.full((1, 2, 2, 1), 3.0, np.float32), True, 3)
+    assert (st["n"] == 1).all() and (st["mean"] == oracle.box_cox(3.0)).all() and (st["film_mean"] == 3.0).all()
+    # empty batch leaves the state alone
+    before = {k: v.copy() for k, v in st.items()}
+    oracle.accumulate(st, np.zeros((0, 2, 2, 1), np.float32), True, 3)
+    assert all(np.array_equal(before[k], st[k]) for k in st)
+
+
+def test_tile_order_is_irrelevant(oracle):
+    """Tiles are disjoint (statpath.cpp:132-190): any tile size gives the same images."""
+    rng = np.random.default_rng(2)
+    smp = rng.random((8, 33, 47, 3), dtype=np.float32)
+    a, b = oracle.new_state(33, 47, 3), oracle.new_state(33, 47, 3)
+    oracle.accumulate(a, smp, True, 3, tile_size=16, threads=1)
+    oracle.accumulate(b, smp, True, 3, tile_size=5, threads=0)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+
+
+def test_merge_tile_layout(oracle):
+    """StatTilePixel<Vec3> is 128 B, <float> 64 B (estimator.h:104-124); MergeTile does not
+    touch the film images, MergeTransformTile does (estimator.cpp:341-388)."""
+    assert oracle.TILE_PIXEL_DTYPE[1].itemsize == 64 and oracle.TILE_PIXEL_DTYPE[3].itemsize == 128
+    tile = np.zeros(6, dtype=oracle.TILE_PIXEL_DTYPE[3])   # 3 x 2 tile at (4, 1)
+    tile["n"] = np.arange(6) + (1 << 33)                    # uint64 -> int32 cast (estimator.cpp:347)
+    for i, k in enumerate(("mean", "m2", "m3", "film_mean", "film_m2")):
+        tile[k] = (np.arange(18).reshape(6, 3) + 100 * i).astype(np.float32)
+    st = oracle.new_state(5, 9, 3)
+    st["film_mean"][:] = -1
+    oracle.merge_tile(tile, 3, 4, 1, 7, 3, st, transform=False)
+    assert np.array_equal(st["n"][1:3, 4:7].ravel(), np.arange(6))
+    assert np.array_equal(st["m3"][2, 5], [212, 213, 214])
+    assert (st["film_mean"] == -1).all()
+    oracle.merge_tile(tile, 3, 4, 1, 7, 3, st, transform=True)
+    assert np.array_equal(st["film_m2"][1, 4], [400, 401, 402])
+    assert st["n"].sum() == 15 and st["mean"][0].sum() == 0
+
+
+def test_mean_vars_row_quirk(oracle):
+    n = np.array([[4, 9, 9], [2, 2, 5]], np.int32)
+    m2 = np.ones((2, 3, 3), np.float32)
+    exact = oracle.mean_vars(n, m2, row_n_quirk=False)
+    quirk = oracle.mean_vars(n, m2, row_n_quirk=True)      # estimator.cpp:540,558
+    assert np.allclose(exact[0, 1], 1 / 72) and np.allclose(quirk[0, 1], 1 / 12)
+    assert np.array_equal(exact[:, 0], quirk[:, 0])
+
+
+def test_prepass_spec(oracle):
+    n = np.array([[0, 1, 2, 16, 16]], np.int32)
+    mean = np.full((1, 5, 1), 0.5, np.float32)
+    m2 = np.array([0, 0, 2.0, 0.0, 30.0], np.float32).reshape(1, 5, 1)
+    m3 = np.array([0, 0, 1.0, 0.0, -12.0], np.float32).reshape(1, 5, 1)
+    mc, d = oracle.prepass(n, mean, m2, m3)
+    assert np.isinf(d[0, 0, 0]) and np.isinf(d[0, 1, 0]) and mc[0, 0, 0] == 0.5   # n < 2: cannot reject
+    assert d[0, 3, 0] == 0 and mc[0, 3, 0] == 0.5                                  # zero variance
+    var, t = 30.0 / 15, oracle.t_quantile(0, 15)
+    assert np.isclose(d[0, 4, 0], t * t * var / 16, rtol=1e-6)
+    assert np.isclose(mc[0, 4, 0], 0.5 + (-12.0 / 16) / (6 * var * 16), rtol=1e-6)  # Johnson
+
+
+def _joint_bilateral(colour, gbs, drs, ds, r):
+    """Independent numpy cross-bilateral filter (float64), window clipped at the border."""
+    h, w, c = colour.shape
+    out = np.zeros((h, w, c))
+    for y in range(h):
+        for x in range(w):
+            y0, y1, x0, x1 = max(0, y - r), min(h, y + r + 1), max(0, x - r), min(w, x + r + 1)
+            yy, xx = np.mgrid[y0:y1, x0:x1]
+            e = ds * ((yy - y) ** 2 + (xx - x) ** 2)
+            for g, dr in zip(gbs, drs):
+                e = e + dr * ((g[y0:y1, x0:x1].astype(np.float64) - g[y, x]) ** 2).sum(-1)
+            wgt = np.exp(e)
+            out[y, x] = (wgt[..., None] * colour[y0:y1, x0:x1]).sum((0, 1)) / wgt.sum()
+    return out
+
+
+def test_filter_without_gate_is_joint_bilateral(oracle):
+    rng = np.random.default_rng(9)
+    h, w, r = 13, 17, 4
+    colour = rng.random((h, w, 3), dtype=np.float32)
+    gb = [rng.random((h, w, 3), dtype=np.float32), rng.random((h, w, 1), dtype=np.float32)]
+    drs = [-0.5 / 0.4 ** 2, -0.5 / 0.7 ** 2]
+    mc = rng.random((h, w, 3), dtype=np.float32)
+    disc = np.full((h, w, 3), np.inf, np.float32)             # every pair passes
+    out = oracle.filter_image(mc, disc, colour, gb, drs, -0.5 / 3.0 ** 2, r)
+    assert rel_l2(out, _joint_bilateral(colour, gb, drs, -0.5 / 9.0, r)) < 1e-6
+
+
+def test_filter_properties(oracle):
+    rng = np.random.default_rng(4)
+    h, w = 12, 15
+    mc = rng.random((h, w, 3), dtype=np.float32)
+    disc = (0.05 * rng.random((h, w, 3))).astype(np.float32)
+    colour = rng.random((h, w, 3), dtype=np.float32)
+    gb = [rng.random((h, w, 3), dtype=np.float32)]
+    args = dict(g_buffers=gb, g_dr=[-2.0], ds=-0.02, radius=5)
+    # radius 0 -> identity; constant colour is a fixed point; zero discriminator keeps only equal means
+    assert np.array_equal(oracle.filter_image(mc, disc, colour, gb, [-2.0], -0.02, 0), colour)
+    const = np.full_like(colour, 0.25)
+    assert np.allclose(oracle.filter_image(mc, disc, const, **args), 0.25, rtol=1e-6)
+    assert np.array_equal(oracle.filter_image(mc, np.zeros_like(disc), colour, **args), colour)
+    # linear in the colour image (weights do not depend on it)
+    c2 = rng.random((h, w, 3), dtype=np.float32)
+    f1, f2 = oracle.filter_image(mc, disc, colour, **args), oracle.filter_image(mc, disc, c2, **args)
+    f12 = oracle.filter_image(mc, disc, (colour + 2 * c2).astype(np.float32), **args)
+    assert rel_l2(f12, f1 + 2 * f2) < 1e-6
+    # a NaN pixel (negative radiance sample) is excluded from its neighbours and passes through itself
+    mcn = mc.copy()
+    mcn[5, 7] = np.nan
+    fn = oracle.filter_image(mcn, disc, colour, **args)
+    assert np.isfinite(fn).all() and np.array_equal(fn[5, 7], colour[5, 7])
+    # ROI computes exactly the same values inside, leaves the rest untouched (zero)
+    roi = oracle.filter_image(mc, disc, colour, roi=(3, 2, 9, 8), **args)
+    assert np.array_equal(roi[2:8, 3:9], f1[2:8, 3:9]) and not roi[:2].any() and not roi[:, 9:].any()
+
+
+def test_filter_float_variant(oracle):
+    rng = np.random.default_rng(6)
+    h, w = 10, 11
+    mc = rng.random((h, w, 1), dtype=np.float32)
+    disc = (0.1 * rng.random((h, w, 1))).astype(np.float32)
+    colour = rng.random((h, w, 1), dtype=np.float32)
+    out = oracle.filter_image(mc, disc, colour, [], [], -0.05, 3)
+    assert out.shape == colour.shape and np.isfinite(out).all()
+    assert out.min() >= colour.min() - 1e-6 and out.max() <= colour.max() + 1e-6   # convex combination

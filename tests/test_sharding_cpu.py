@@ -1,0 +1,89 @@
+"""Multi-GPU path on CPU: block layout + halo exchange over gloo (world_size 2 and 4), and the
+filter applied per block on the exchanged halos equals the filter of the whole film."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, bw, bh, r, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import oracle
+    from statmc_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L = sharding.BlockLayout(rank, world, bw, bh, r)
+        fw, fh = L.film_size
+        rng = np.random.default_rng(123)                      # every rank builds the same film
+        film = {
+            "mc": rng.random((fh, fw, 3), dtype=np.float32),
+            "disc": (0.2 * rng.random((fh, fw, 3))).astype(np.float32),
+            "colour": rng.random((fh, fw, 3), dtype=np.float32),
+            "g0": rng.random((fh, fw, 3), dtype=np.float32),
+            "g1": rng.random((fh, fw, 3), dtype=np.float32),
+        }
+        ox, oy = L.origin
+        packed = L.new_padded(15, "cpu")
+        packed.fill_(float("nan"))
+        inner = L.interior(packed)
+        for i, k in enumerate(("mc", "disc", "colour", "g0", "g1")):
+            inner[..., 3 * i:3 * i + 3] = torch.from_numpy(film[k][oy:oy + bh, ox:ox + bw])
+        sharding.exchange_halo(L, packed)
+        # the padded block must now equal the film window around the block
+        want = np.concatenate([film[k] for k in ("mc", "disc", "colour", "g0", "g1")], axis=2)[
+            oy - L.pt:oy + bh + L.pb, ox - L.pl:ox + bw + L.pr]
+        ok_halo = np.array_equal(packed.numpy(), want)
+        # filter the block with ROI = owned pixels, compare with the whole-film filter
+        p = packed.numpy()
+        loc = [np.ascontiguousarray(p[..., 3 * i:3 * i + 3]) for i in range(5)]
+        drs, ds = [-0.5 / 0.3 ** 2, -0.5 / 0.5 ** 2], -0.5 / 4.0 ** 2
+        out = oracle.filter_image(loc[0], loc[1], loc[2], [loc[3], loc[4]], drs, ds, r, roi=L.roi, threads=1)
+        ref = oracle.filter_image(film["mc"], film["disc"], film["colour"], [film["g0"], film["g1"]], drs, ds, r,
+                                  roi=(ox, oy, ox + bw, oy + bh), threads=1)
+        x0, y0, x1, y1 = L.roi
+        ok_filter = np.array_equal(out[y0:y1, x0:x1], ref[oy:oy + bh, ox:ox + bw])
+        q.put((rank, ok_halo, ok_filter))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bw,bh,r", [(2, 24, 18, 5), (4, 16, 14, 6)])
+def test_halo_exchange_and_block_filter(world, bw, bh, r):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, bw, bh, r, q)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert res == [(rk, True, True) for rk in range(world)]
+
+
+def test_layouts():
+    from statmc_amd import sharding
+    assert sharding.grid_for(1) == (1, 1) and sharding.grid_for(2) == (2, 1)
+    assert sharding.grid_for(4) == (2, 2) and sharding.grid_for(8) == (4, 2)
+    L = sharding.BlockLayout(5, 8, 1920, 1080, 20)          # block (1, 1) of a 4 x 2 grid
+    assert (L.bx, L.by) == (1, 1) and (L.left, L.right, L.up, L.down) == (4, 6, 1, None)
+    assert (L.pw, L.ph) == (1960, 1100) and L.roi == (20, 20, 1940, 1100)
+    assert L.film_size == (7680, 2160) and L.origin == (1920, 1080)
+    one = sharding.BlockLayout(0, 1, 1920, 1080, 20)
+    assert (one.pw, one.ph) == (1920, 1080) and one.roi == (0, 0, 1920, 1080)
