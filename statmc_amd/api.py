@@ -99,6 +99,7 @@ def load():
     lib.statmc_tile_moments.argtypes = [C.c_uint16, C.c_uint16, C.c_int, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_void_p]
     lib.statmc_debug_force_filter_variant.argtypes = [C.c_int]
+    lib.statmc_debug_force_filter_parts.argtypes = [C.c_int]
     _lib = lib
     return lib
 
@@ -125,6 +126,11 @@ def last_filter_variant():
 def force_filter_variant(v):
     """0 auto, 1 generic (global-memory) kernel, 2 runtime-radius LDS kernel."""
     load().statmc_debug_force_filter_variant(int(v))
+
+
+def force_filter_parts(k):
+    """0 automatic; k >= 1: the LDS kernel sweeps the window with k workgroups per tile."""
+    load().statmc_debug_force_filter_parts(int(k))
 
 
 # ------------------------------------------------------------------ torch marshalling

@@ -81,6 +81,45 @@ int spatial_table(int radius, float ds, const float **out) {
     return STATMC_OK;
 }
 
+// workspace for the window filter's per-part partial sums, grown on demand, one per device
+struct Workspace {
+    float *ptr = nullptr;
+    size_t bytes = 0;
+};
+std::unordered_map<int, Workspace> g_ws;
+std::unordered_map<int, int> g_cus;
+
+int partial_workspace(size_t bytes, float **out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    Workspace &w = g_ws[dev];
+    if (w.bytes < bytes) {
+        if (w.ptr) {
+            HIP_TRY(hipDeviceSynchronize());  // earlier launches may still read the old block
+            HIP_TRY(hipFree(w.ptr));
+        }
+        w.ptr = nullptr;
+        w.bytes = 0;
+        HIP_TRY(hipMalloc(&w.ptr, bytes));
+        w.bytes = bytes;
+    }
+    *out = w.ptr;
+    return STATMC_OK;
+}
+
+int device_cus() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_cus.find(dev);
+    if (it != g_cus.end()) return it->second;
+    int n = 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    g_cus[dev] = n;
+    return n;
+}
+
 int check_image(const statmc_image &im, int w, int h, int channels, const char *what, int idx) {
     if (!im.data) return fail(STATMC_ERR_INVALID, "%s[%d]: null device pointer", what, idx);
     if (im.cols != w || im.rows != h)
@@ -237,6 +276,12 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
         if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
         k.gscale0 = sqrtf(-k.g[0].dr * 1.44269504088896340736f);
         k.gscale1 = sqrtf(-k.g[1].dr * 1.44269504088896340736f);
+        k.n_parts = statmc::lds_filter_parts(k, device_cus());
+        if (k.n_parts > 1) {
+            if (int rc = partial_workspace((size_t)k.n_parts * W * H * 4 * sizeof(float), &k.partial)) return rc;
+        }
+    } else {
+        k.n_parts = 1;
     }
     for (int b = 0; b < a->n_buffers; b++) {
         // buffer 0 filters the "film" image into "film-f" when denoiseFilm is set
@@ -356,9 +401,13 @@ int statmc_tile_moments(uint16_t width, uint16_t height, int channels, const flo
     return STATMC_OK;
 }
 
-// test/bench hook (not part of the reference surface): 0 auto, 1 generic, 2 runtime-radius LDS
-int statmc_debug_force_filter_variant(int v) {
+// test/bench hooks (not part of the reference surface)
+int statmc_debug_force_filter_variant(int v) {  // 0 auto, 1 generic, 2 runtime-radius LDS
     statmc::set_filter_variant_override(v);
+    return STATMC_OK;
+}
+int statmc_debug_force_filter_parts(int k) {  // 0 auto, k >= 1: window-sweep parts per tile
+    statmc::set_filter_parts_override(k);
     return STATMC_OK;
 }
 

@@ -74,6 +74,8 @@ struct FilterArgs {
     // fast path only (T = float3, two 3-channel G-buffers):
     const float *spatial_tab;    // [(2r+1)][2*RP+7] log2-domain spatial exponents, -inf outside r
     float gscale0, gscale1;      // sqrt(-dr_g * log2(e))
+    int n_parts;                 // window rows are swept by n_parts workgroups per tile ...
+    float *partial;              // ... which leave (acc.rgb, sum_w) here: [n_parts][height][width][4]
 };
 
 hipError_t launch_prepass(const PrepassArgs &a, hipStream_t s);
@@ -91,5 +93,8 @@ bool fast_path_eligible(const FilterArgs &a, int channels);
 
 // force a variant for tests/benchmarks: 0 = auto, 1 = generic, 2 = lds_rt (runtime radius)
 void set_filter_variant_override(int v);
+// parts per tile the LDS kernel would use for this ROI on a device with n_cus compute units
+int lds_filter_parts(const FilterArgs &a, int n_cus);
+void set_filter_parts_override(int k);  // 0 = automatic
 
 }  // namespace statmc

@@ -108,8 +108,20 @@ constexpr int kSlots = kTileH + 1;     // LDS row ring
 constexpr int kCh = 15;                // floats staged per pixel
 constexpr int kMaxR = 20;
 
-// plane order inside an LDS row
-enum { P_MC = 0, P_ND = 3, P_G0 = 6, P_G1 = 9, P_COL = 12 };
+// LDS row layout (floats; P = pitch = columns staged per row, a multiple of 4).
+// The 15 values of a pixel are stored as 6 channel PAIRS + 3 singles so that the inner loop can
+// use packed fp32 VALU ops (v_pk_add/mul/fma_f32: two channels per instruction) -- a wave can
+// issue one VALU instruction per 4 cycles, so with only 2 waves per SIMD the kernel is bound by
+// instruction issue, not by ALU width, and halving the instruction count of the channel-wise
+// work is what buys time:
+//   pair plane k (k = 0..5), half h (taps 0,1 / taps 2,3 of a 4-column group):
+//       float index (2k + h) * P + (col >> 2) * 4 + (col & 1) * 2 + c        c = 0, 1
+//     so one ds_read_b128 at lane stride 16 B returns {tap0.c0, tap0.c1, tap1.c0, tap1.c1}
+//   single plane s (s = 0..2): 12 P + s P + col
+enum { K_G01 = 0, K_G2A0 = 1, K_A12 = 2, K_MC01 = 3, K_ND01 = 4, K_COL01 = 5, S_MC2 = 0, S_ND2 = 1, S_COL2 = 2 };
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 __host__ __device__ constexpr int round_up4(int r) { return (r + 3) & ~3; }
 __host__ __device__ constexpr int tab_width(int rp) { return 2 * rp + 7; }
@@ -150,90 +162,114 @@ struct ChunkMask {
 };
 
 struct LaneState {
-    float pc[kPx][3], pd[kPx][3], pg0[kPx][3], pg1[kPx][3];
-    float acc[kPx][3], sw[kPx];
+    v2f pg[3][kPx];              // scaled (n0,n1), (n2,a0), (a1,a2) of the lane's pixels
+    v2f pmc01[kPx], pd01[kPx];   // corrected mean / discriminator, channels 0,1
+    float pmc2[kPx], pd2[kPx];   // ... channel 2
+    v2f acc01[kPx];
+    float acc2[kPx], sw[kPx];
 };
 
-// One read group: 4 taps (columns 4*lane + 4*j .. +3 of the staged row) against the lane's
-// 4 pixels.  `tabrow` points at the spatial exponents of this window row; MASK selects the
-// (tap, pixel) pairs that lie inside the window (all 16 in the runtime-radius variant, where
-// the table holds -inf outside the radius).
-template <unsigned MASK>
-__device__ __forceinline__ void eval_chunk(LaneState &st, const float *__restrict__ row, int pitch, int j,
-                                           const float *__restrict__ tabrow) {
-    float4 q[kCh];
+// Half of a read group = 2 taps (columns 4*(lane+j) + 2h, +1 of the staged row) x the lane's 4
+// pixels: 6 ds_read_b128 (channel pairs of both taps) + 3 ds_read_b64 (single channels).
+// Half groups are the unit of register double-buffering: at most 18 LDS reads are in flight per
+// wave (the lgkmcnt counter is 4 bits wide) and two operand sets cost 60 VGPRs.
+struct HalfChunk {
+    v4f qp[6];
+    v2f qs[3];
+};
+
+template <int H>
+__device__ __forceinline__ void load_half(HalfChunk &c, const float *__restrict__ row, int pitch, int j) {
 #pragma unroll
-    for (int ch = 0; ch < kCh; ch++) q[ch] = *reinterpret_cast<const float4 *>(row + ch * pitch + 4 * j);
+    for (int k = 0; k < 6; k++) c.qp[k] = *reinterpret_cast<const v4f *>(row + (2 * k + H) * pitch + 4 * j);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int s = 0; s < 3; s++) c.qs[s] = *reinterpret_cast<const v2f *>(row + (12 + s) * pitch + 4 * j + 2 * H);
+}
+
+// The window row's spatial exponents live in ONE VGPR spread over the wave's lanes (lane t holds
+// tab[t]); the entry of tap i / pixel k of read group j is lane 4j + i - k + 3, fetched with
+// v_readlane (wave-uniform index) -- no LDS or scalar-memory traffic in the inner loop.
+__device__ __forceinline__ float tab_at(float tabv, int idx) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tabv), idx));
+}
+
+// MASK: bit (i*4+k) set when tap i of the read group lies inside the window of pixel k (all 16
+// bits in the runtime-radius variant, where the table holds -inf beyond the radius).
+template <int H, unsigned MASK>
+__device__ __forceinline__ void compute_half(LaneState &st, const HalfChunk &c, float tabv, int j) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ii++) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int i = 2 * H + ii;
+        v2f q[6];  // tap i's channel pairs: low or high half of the b128
+#pragma unroll
+        for (int k = 0; k < 6; k++) q[k] = ii ? v2f{c.qp[k].z, c.qp[k].w} : v2f{c.qp[k].x, c.qp[k].y};
+        const float q_mc2 = c.qs[S_MC2][ii], q_nd2 = c.qs[S_ND2][ii], q_col2 = c.qs[S_COL2][ii];
 #pragma unroll
         for (int k = 0; k < kPx; k++) {
             if (!(MASK & (1u << (i * 4 + k)))) continue;
-            float e = tabrow[4 * j + i - k + 3];
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float d = st.pg0[k][c] - (&q[P_G0 + c].x)[i];
-                e = __builtin_fmaf(-d, d, e);
-            }
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float d = st.pg1[k][c] - (&q[P_G1 + c].x)[i];
-                e = __builtin_fmaf(-d, d, e);
-            }
-            float w = __builtin_amdgcn_exp2f(e);
-            bool member = true;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float d = st.pc[k][c] - (&q[P_MC + c].x)[i];
-                member = member & (__builtin_fmaf(d, d, (&q[P_ND + c].x)[i]) <= st.pd[k][c]);
-            }
+            const float tab = tab_at(tabv, 4 * j + i - k + 3);
+            // range weight: exp2(tab - |k_n dn|^2 - |k_a da|^2), two channels per instruction
+            v2f d = st.pg[0][k] - q[K_G01];
+            v2f e2 = -d * d;
+            d = st.pg[1][k] - q[K_G2A0];
+            e2 = __builtin_elementwise_fma(-d, d, e2);
+            d = st.pg[2][k] - q[K_A12];
+            e2 = __builtin_elementwise_fma(-d, d, e2);
+            float w = __builtin_amdgcn_exp2f((e2.x + tab) + e2.y);
+            // membership: fma(d, d, -D_q) <= D_p in every channel (bit-identical to the oracle)
+            d = st.pmc01[k] - q[K_MC01];
+            const v2f t01 = __builtin_elementwise_fma(d, d, q[K_ND01]);
+            const float db = st.pmc2[k] - q_mc2;
+            const float t2 = __builtin_fmaf(db, db, q_nd2);
+            const bool member = (t01.x <= st.pd01[k].x) & (t01.y <= st.pd01[k].y) & (t2 <= st.pd2[k]);
             w = member ? w : 0.f;
             st.sw[k] += w;
-#pragma unroll
-            for (int c = 0; c < 3; c++) st.acc[k][c] = __builtin_fmaf(w, (&q[P_COL + c].x)[i], st.acc[k][c]);
+            st.acc01[k] = __builtin_elementwise_fma(v2f{w, w}, q[K_COL01], st.acc01[k]);
+            st.acc2[k] = __builtin_fmaf(w, q_col2, st.acc2[k]);
         }
     }
 }
 
-// Compile-time radius: the read groups at the two ends of the span have (tap, pixel) pairs
-// outside the window and are peeled with their static masks; the groups in between are all
-// inside and run as a rolled loop (keeps the live set to one read group: 60 VGPRs of taps).
+// Sweep one window row.  Operand sets A (taps 0,1 of a read group) and B (taps 2,3) alternate:
+// while one is evaluated the other's LDS reads are in flight (with 2 waves per SIMD nothing
+// else hides LDS latency: a stalled wave costs half the SIMD's issue rate).
+// RT > 0 (compile-time radius, a multiple of 4): the first and last read groups hold
+// (tap, pixel) pairs outside the window and get their static masks; every group between is full.
 template <int RT>
-struct StaticSpan {
-    static constexpr int n_chunks = 2 * round_up4(RT) / 4 + 1;
-    template <int J>
-    static constexpr bool full() { return ChunkMask<J, RT>::value() == 0xFFFFu; }
-};
-
-template <int RT, int J, int JEND>
-__device__ __forceinline__ void eval_peeled(LaneState &st, const float *row, int pitch, const float *tabrow) {
-    if constexpr (J < JEND) {
-        eval_chunk<ChunkMask<J, RT>::value()>(st, row, pitch, J, tabrow);
-        eval_peeled<RT, J + 1, JEND>(st, row, pitch, tabrow);
-    }
-}
-
-template <int RT, int J = 0>
-constexpr int first_full() {
-    if constexpr (J >= StaticSpan<RT>::n_chunks) return J;
-    else if constexpr (StaticSpan<RT>::template full<J>()) return J;
-    else return first_full<RT, J + 1>();
-}
-template <int RT, int J>
-constexpr int end_full() {  // first non-full group at or after J
-    if constexpr (J >= StaticSpan<RT>::n_chunks) return J;
-    else if constexpr (!StaticSpan<RT>::template full<J>()) return J;
-    else return end_full<RT, J + 1>();
-}
-
-template <int RT>
-__device__ __forceinline__ void eval_row_static(LaneState &st, const float *row, int pitch, const float *tabrow) {
-    constexpr int f0 = first_full<RT>();
-    constexpr int f1 = end_full<RT, f0>();
-    eval_peeled<RT, 0, f0>(st, row, pitch, tabrow);
+__device__ __forceinline__ void eval_row(LaneState &st, const float *row, int pitch, float tabv, int n_chunks) {
+    HalfChunk A, B;
+    constexpr unsigned kFull = 0xFFFFu;
+    if constexpr (RT > 0) {
+        constexpr int n = 2 * round_up4(RT) / 4 + 1;
+        static_assert(RT % 4 == 0 && n >= 3, "static variant: radius multiple of 4");
+        static_assert(ChunkMask<1, RT>::value() == kFull && ChunkMask<n - 2, RT>::value() == kFull, "");
+        load_half<0>(A, row, pitch, 0);
+        load_half<1>(B, row, pitch, 0);
+        compute_half<0, ChunkMask<0, RT>::value()>(st, A, tabv, 0);
+        load_half<0>(A, row, pitch, 1);
+        compute_half<1, ChunkMask<0, RT>::value()>(st, B, tabv, 0);
 #pragma unroll 1
-    for (int j = f0; j < f1; j++) eval_chunk<0xFFFFu>(st, row, pitch, j, tabrow);
-    eval_peeled<RT, f1, StaticSpan<RT>::n_chunks>(st, row, pitch, tabrow);
+        for (int j = 1; j < n - 1; j++) {
+            load_half<1>(B, row, pitch, j);
+            compute_half<0, kFull>(st, A, tabv, j);
+            load_half<0>(A, row, pitch, j + 1);
+            compute_half<1, kFull>(st, B, tabv, j);
+        }
+        load_half<1>(B, row, pitch, n - 1);
+        compute_half<0, ChunkMask<n - 1, RT>::value()>(st, A, tabv, n - 1);
+        compute_half<1, ChunkMask<n - 1, RT>::value()>(st, B, tabv, n - 1);
+    } else {
+        load_half<0>(A, row, pitch, 0);
+#pragma unroll 1
+        for (int j = 0; j < n_chunks; j++) {
+            load_half<1>(B, row, pitch, j);
+            compute_half<0, kFull>(st, A, tabv, j);
+            load_half<0>(A, row, pitch, j + 1 < n_chunks ? j + 1 : j);
+            compute_half<1, kFull>(st, B, tabv, j);
+        }
+    }
 }
 
 // Stage one image row (image row yrow, columns x0-rp .. x0-rp+pitch) into an LDS ring slot.
@@ -257,22 +293,22 @@ __device__ __forceinline__ StagedPixel load_pixel(const FilterArgs &a, int x, in
 }
 
 __device__ __forceinline__ void store_pixel(float *slot, int pitch, int i, const StagedPixel &s, float k0, float k1) {
+    // taps outside the image get a NaN corrected mean: they fail every membership comparison
     const float nan = __builtin_nanf("");
-    slot[(P_MC + 0) * pitch + i] = s.valid ? s.mc.x : nan;
-    slot[(P_MC + 1) * pitch + i] = s.valid ? s.mc.y : nan;
-    slot[(P_MC + 2) * pitch + i] = s.valid ? s.mc.z : nan;
-    slot[(P_ND + 0) * pitch + i] = s.valid ? -s.d.x : 0.f;
-    slot[(P_ND + 1) * pitch + i] = s.valid ? -s.d.y : 0.f;
-    slot[(P_ND + 2) * pitch + i] = s.valid ? -s.d.z : 0.f;
-    slot[(P_G0 + 0) * pitch + i] = s.valid ? s.g0.x * k0 : 0.f;
-    slot[(P_G0 + 1) * pitch + i] = s.valid ? s.g0.y * k0 : 0.f;
-    slot[(P_G0 + 2) * pitch + i] = s.valid ? s.g0.z * k0 : 0.f;
-    slot[(P_G1 + 0) * pitch + i] = s.valid ? s.g1.x * k1 : 0.f;
-    slot[(P_G1 + 1) * pitch + i] = s.valid ? s.g1.y * k1 : 0.f;
-    slot[(P_G1 + 2) * pitch + i] = s.valid ? s.g1.z * k1 : 0.f;
-    slot[(P_COL + 0) * pitch + i] = s.valid ? s.col.x : 0.f;
-    slot[(P_COL + 1) * pitch + i] = s.valid ? s.col.y : 0.f;
-    slot[(P_COL + 2) * pitch + i] = s.valid ? s.col.z : 0.f;
+    const int pofs = ((i & 3) >> 1) * pitch + (i >> 2) * 4 + (i & 1) * 2;  // within a pair plane
+    auto pair = [&](int k, float c0, float c1) {
+        *reinterpret_cast<v2f *>(slot + 2 * k * pitch + pofs) = v2f{c0, c1};
+    };
+    const bool v = s.valid;
+    pair(K_G01, v ? s.g0.x * k0 : 0.f, v ? s.g0.y * k0 : 0.f);
+    pair(K_G2A0, v ? s.g0.z * k0 : 0.f, v ? s.g1.x * k1 : 0.f);
+    pair(K_A12, v ? s.g1.y * k1 : 0.f, v ? s.g1.z * k1 : 0.f);
+    pair(K_MC01, v ? s.mc.x : nan, v ? s.mc.y : nan);
+    pair(K_ND01, v ? -s.d.x : 0.f, v ? -s.d.y : 0.f);
+    pair(K_COL01, v ? s.col.x : 0.f, v ? s.col.y : 0.f);
+    slot[(12 + S_MC2) * pitch + i] = v ? s.mc.z : nan;
+    slot[(12 + S_ND2) * pitch + i] = v ? -s.d.z : 0.f;
+    slot[(12 + S_COL2) * pitch + i] = v ? s.col.z : 0.f;
 }
 
 // RT > 0: compile-time radius (window edges resolved statically); RT == 0: runtime radius
@@ -289,9 +325,25 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int x0 = a.rx0 + blockIdx.x * kTileW;
-    const int y0 = a.ry0 + blockIdx.y * kTileH;
+    // XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (each with its
+    // own 4 MiB L2), so workgroup b is given work item u such that every XCD walks one contiguous
+    // range of items: the parts of a tile and vertically adjacent tiles -- which stage the same
+    // image rows -- then hit in the same L2 instead of each fetching its own copy over the fabric.
+    // Placement only affects speed; the remap is a bijection for any grid size.
+    const int n_items = gridDim.x, b = blockIdx.x;
+    const int q8 = n_items >> 3, rem8 = n_items & 7, xcd = b & 7, idx = b >> 3;
+    const int u = xcd < rem8 ? xcd * (q8 + 1) + idx : rem8 * (q8 + 1) + (xcd - rem8) * q8 + idx;
+    const int part = u % a.n_parts, tile = u / a.n_parts;
+    const int tiles_x = (a.rx1 - a.rx0 + kTileW - 1) / kTileW;
+    const int x0 = a.rx0 + (tile % tiles_x) * kTileW;
+    const int y0 = a.ry0 + (tile / tiles_x) * kTileH;
     const float k0 = a.gscale0, k1 = a.gscale1;
+    // window rows [s0, s1) of the 2r+1 belong to this workgroup (`part`): splitting the
+    // window sweep over several workgroups per tile evens out the last round of the 1-WG-per-CU
+    // grid (1080 tiles on 256 CUs would otherwise leave 200 CUs idle for a fifth of the run).
+    const int n_rows = 2 * r + 1;
+    const int s0 = (n_rows * part) / a.n_parts;
+    const int s1 = (n_rows * (part + 1)) / a.n_parts;
 
     // ---- the lane's own 4 pixels (clamped into the image so the loads stay in bounds)
     LaneState st;
@@ -304,40 +356,45 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
         const f3 d = reinterpret_cast<const f3 *>(a.disc)[p];
         const f3 g0 = reinterpret_cast<const f3 *>(a.g[0].data)[p];
         const f3 g1 = reinterpret_cast<const f3 *>(a.g[1].data)[p];
-        st.pc[k][0] = mc.x; st.pc[k][1] = mc.y; st.pc[k][2] = mc.z;
-        st.pd[k][0] = d.x; st.pd[k][1] = d.y; st.pd[k][2] = d.z;
-        st.pg0[k][0] = g0.x * k0; st.pg0[k][1] = g0.y * k0; st.pg0[k][2] = g0.z * k0;
-        st.pg1[k][0] = g1.x * k1; st.pg1[k][1] = g1.y * k1; st.pg1[k][2] = g1.z * k1;
+        st.pg[0][k] = v2f{g0.x * k0, g0.y * k0};
+        st.pg[1][k] = v2f{g0.z * k0, g1.x * k1};
+        st.pg[2][k] = v2f{g1.y * k1, g1.z * k1};
+        st.pmc01[k] = v2f{mc.x, mc.y};
+        st.pmc2[k] = mc.z;
+        st.pd01[k] = v2f{d.x, d.y};
+        st.pd2[k] = d.z;
         st.sw[k] = 0.f;
-        st.acc[k][0] = st.acc[k][1] = st.acc[k][2] = 0.f;
+        st.acc01[k] = v2f{0.f, 0.f};
+        st.acc2[k] = 0.f;
     }
 
-    // ---- prologue: window rows rel = 0 .. kTileH-1 (image rows y0-r+rel) into slots 0..7
+    // ---- prologue: window rows rel = s0 .. s0+kTileH-1 (image rows y0-r+rel) into slots 0..7
     for (int idx = threadIdx.x; idx < kTileH * pitch; idx += kThreads) {
         const int rel = idx / pitch, i = idx - rel * pitch;
-        const StagedPixel s = load_pixel(a, x0 - rp + i, y0 - r + rel);
+        const StagedPixel s = load_pixel(a, x0 - rp + i, y0 - r + s0 + rel);
         store_pixel(lds + rel * slot_floats, pitch, i, s, k0, k1);
     }
     __syncthreads();
+    // spatial exponents of window row s0, one per lane (tw <= 47 < 64)
+    float tabv = lane < tw ? a.spatial_tab[s0 * tw + lane] : 0.f;
 
-    // ---- sweep the 2r+1 window rows; wave w works on window row rel = w + step
-    int slot = wave;  // (wave + step) % kSlots
-    int fill = kTileH;  // (step + kTileH) % kSlots: the slot the next row is staged into
-    for (int step = 0; step <= 2 * r; step++) {
+    // ---- sweep the window rows; wave w works on staged row rel = w + step
+    int slot = wave;  // (wave + step - s0) % kSlots
+    int fill = kTileH;  // (step - s0 + kTileH) % kSlots: the slot the next row is staged into
+    for (int step = s0; step < s1; step++) {
         // issue the global loads of the row needed by the next step early
-        const bool stage = step < 2 * r && (int)threadIdx.x < pitch;
+        const bool stage = step + 1 < s1 && (int)threadIdx.x < pitch;
         StagedPixel nxt;
         nxt.valid = false;
         if (stage) nxt = load_pixel(a, x0 - rp + (int)threadIdx.x, y0 - r + step + kTileH);
 
+        // prefetch the spatial exponents of the next window row
+        float tab_next = 0.f;
+        if (step + 1 < s1 && lane < tw) tab_next = a.spatial_tab[(step + 1) * tw + lane];
+
         const float *row = lds + slot * slot_floats + kPx * lane;
-        const float *tabrow = a.spatial_tab + step * tw;
-        if constexpr (RT > 0) {
-            eval_row_static<RT>(st, row, pitch, tabrow);
-        } else {
-#pragma unroll 1
-            for (int j = 0; j < n_chunks; j++) eval_chunk<0xFFFFu>(st, row, pitch, j, tabrow);
-        }
+        eval_row<RT>(st, row, pitch, tabv, n_chunks);
+        tabv = tab_next;
 
         if (stage) store_pixel(lds + fill * slot_floats, pitch, threadIdx.x, nxt, k0, k1);
         __syncthreads();
@@ -353,11 +410,16 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
             const int ox = x0 + kPx * lane + k;
             if (ox < a.rx1) {
                 const long long p = (long long)oy * a.width + ox;
+                if (a.n_parts > 1) {  // partial sums; combine_parts_kernel finishes the pixel
+                    reinterpret_cast<float4 *>(a.partial)[(long long)part * a.width * a.height + p] =
+                        make_float4(st.acc01[k].x, st.acc01[k].y, st.acc2[k], st.sw[k]);
+                    continue;
+                }
                 f3 o;
                 if (st.sw[k] > 0.f) {
-                    o.x = st.acc[k][0] / st.sw[k];
-                    o.y = st.acc[k][1] / st.sw[k];
-                    o.z = st.acc[k][2] / st.sw[k];
+                    o.x = st.acc01[k].x / st.sw[k];
+                    o.y = st.acc01[k].y / st.sw[k];
+                    o.z = st.acc2[k] / st.sw[k];
                 } else {
                     o = reinterpret_cast<const f3 *>(a.colour)[p];
                 }
@@ -365,6 +427,26 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
             }
         }
     }
+}
+
+// Sums the per-part partial (acc, sum_w) of every ROI pixel in part order and normalises.
+__global__ __launch_bounds__(256) void combine_parts_kernel(FilterArgs a) {
+    const int x = a.rx0 + blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = a.ry0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.rx1 || y >= a.ry1) return;
+    const long long p = (long long)y * a.width + x, plane = (long long)a.width * a.height;
+    float4 t = reinterpret_cast<const float4 *>(a.partial)[p];
+    for (int k = 1; k < a.n_parts; k++) {
+        const float4 u = reinterpret_cast<const float4 *>(a.partial)[k * plane + p];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    f3 o;
+    if (t.w > 0.f) {
+        o.x = t.x / t.w; o.y = t.y / t.w; o.z = t.z / t.w;
+    } else {
+        o = reinterpret_cast<const f3 *>(a.colour)[p];
+    }
+    reinterpret_cast<f3 *>(a.out)[p] = o;
 }
 
 bool fast_path_eligible(const FilterArgs &a, int channels) {
@@ -376,8 +458,29 @@ bool fast_path_eligible(const FilterArgs &a, int channels) {
     return true;
 }
 
+// Number of window-sweep parts per tile: the grid runs one workgroup per CU (LDS-bound), so its
+// makespan is ceil(tiles*parts / CUs) rounds of 1/parts tile-time each (+ a prologue per part,
+// about 0.2 window rows).  Pick the part count with the smallest estimate.
+int choose_parts(int tiles, int n_rows, int n_cus) {
+    int best = 1;
+    double best_cost = 1e30;
+    for (int k = 1; k <= 8 && k <= n_rows; k++) {
+        const long long wgs = (long long)tiles * k;
+        const double rounds = (double)((wgs + n_cus - 1) / n_cus);
+        const double cost = rounds * ((double)n_rows / k + 0.25);
+        if (cost < best_cost * 0.995) {
+            best_cost = cost;
+            best = k;
+        }
+    }
+    return best;
+}
+
+static int g_parts_override = 0;
+void set_filter_parts_override(int k) { g_parts_override = k; }
+
 template <int RT>
-static hipError_t launch_lds(const FilterArgs &a, hipStream_t s) {
+static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
     const int rp = RT > 0 ? round_up4(RT) : round_up4(a.radius);
     const size_t lds_bytes = (size_t)kSlots * kCh * (kTileW + 2 * rp) * sizeof(float);
     static bool attr_set = false;
@@ -387,9 +490,21 @@ static hipError_t launch_lds(const FilterArgs &a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const dim3 grid((a.rx1 - a.rx0 + kTileW - 1) / kTileW, (a.ry1 - a.ry0 + kTileH - 1) / kTileH);
+    const dim3 tiles((a.rx1 - a.rx0 + kTileW - 1) / kTileW, (a.ry1 - a.ry0 + kTileH - 1) / kTileH);
+    if (a.partial == nullptr) a.n_parts = 1;
+    const dim3 grid(tiles.x * tiles.y * a.n_parts);
     hipLaunchKernelGGL(window_filter_lds<RT>, grid, dim3(kThreads), lds_bytes, s, a);
+    if (a.n_parts > 1) {
+        const dim3 cgrid((a.rx1 - a.rx0 + 63) / 64, (a.ry1 - a.ry0 + 3) / 4);
+        hipLaunchKernelGGL(combine_parts_kernel, cgrid, dim3(256), 0, s, a);
+    }
     return hipGetLastError();
+}
+
+int lds_filter_parts(const FilterArgs &a, int n_cus) {
+    if (g_parts_override > 0) return g_parts_override < 2 * a.radius + 1 ? g_parts_override : 2 * a.radius + 1;
+    const int tiles = ((a.rx1 - a.rx0 + kTileW - 1) / kTileW) * ((a.ry1 - a.ry0 + kTileH - 1) / kTileH);
+    return choose_parts(tiles, 2 * a.radius + 1, n_cus);
 }
 
 hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s, const char **variant) {

@@ -133,12 +133,29 @@ struct ElemState {
     float mean, m2, m3, fmean, fm2;
 };
 
+// d / n for an integer-valued divisor n in [1, 2^24): `r` is 1/n refined from v_rcp_f32 by one
+// Newton step (shared by every division by the same count: all channels, both Welford chains),
+// then one residual correction of the quotient (Markstein).  Bit-identical to the IEEE
+// quotient for the operand ranges of this path (tests/test_gpu_parity.py::test_exact_division
+// sweeps n = 1..4096 against `/`); 3 + 3 instructions instead of ~10 per division.
+__device__ __forceinline__ float refined_rcp(float nf) {
+    const float y0 = __builtin_amdgcn_rcpf(nf);
+    const float e = __builtin_fmaf(-nf, y0, 1.f);
+    return __builtin_fmaf(e, y0, y0);
+}
+__device__ __forceinline__ float div_by_count(float d, float nf, float r) {
+    const float q0 = d * r;
+    const float rem = __builtin_fmaf(-q0, nf, d);
+    return __builtin_fmaf(rem, r, q0);
+}
+
 template <int MAXM, bool TRANSFORM>
-__device__ __forceinline__ void add_sample(ElemState &st, float nf, float smp) {
-    // estimator.h:215 -- boxCox(sample, .5f) = (pow(v, .5) - 1) / .5
-    const float v = TRANSFORM ? (__builtin_sqrtf(smp) - 1.f) / .5f : smp;
+__device__ __forceinline__ void add_sample(ElemState &st, float nf, float r, float smp) {
+    // estimator.h:215 -- boxCox(sample, .5f) = (pow(v, .5) - 1) / .5; v_sqrt_f32 (1 ulp) stands
+    // in for pow(v, .5), itself only faithfully rounded in the reference's libm.
+    const float v = TRANSFORM ? (__builtin_amdgcn_sqrtf(smp) - 1.f) / .5f : smp;
     const float d = v - st.mean;
-    const float dN = d / nf;
+    const float dN = div_by_count(d, nf, r);
     if (MAXM >= 3) {
         const float d2 = d * d;
         const float dN2 = dN * dN;
@@ -153,20 +170,20 @@ __device__ __forceinline__ void add_sample(ElemState &st, float nf, float smp) {
     }
     if (TRANSFORM) {  // estimator.h:217-225
         const float fd = smp - st.fmean;
-        const float fdN = fd / nf;
+        const float fdN = div_by_count(fd, nf, r);
         st.fmean += fdN;
         st.fm2 += fd * (fd - fdN);
     }
 }
 
 template <int C, int MAXM, bool TRANSFORM, bool VEC>
-__device__ __forceinline__ void accumulate_type(const AccumulateType &t) {
+__device__ __forceinline__ void accumulate_type(const AccumulateType &t, int n_types) {
     constexpr int NE = 4 * C;  // elements per lane
     const long long n_px = t.n_elems / C;
     const long long n_groups = (n_px + 3) >> 2;
     const int S = t.n_samples;
-    for (long long g = (long long)blockIdx.x * kBlock + threadIdx.x; g < n_groups;
-         g += (long long)gridDim.x * kBlock) {
+    const long long blk = blockIdx.x / n_types, nblk = gridDim.x / n_types;
+    for (long long g = blk * kBlock + threadIdx.x; g < n_groups; g += nblk * kBlock) {
         const long long p0 = g << 2;
         const long long e0 = p0 * C;
         if (VEC && p0 + 4 <= n_px) {
@@ -199,9 +216,14 @@ __device__ __forceinline__ void accumulate_type(const AccumulateType &t) {
                     const vfloat4 q = __builtin_nontemporal_load(reinterpret_cast<const vfloat4 *>(sp + 4 * k));
                     v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
                 }
+                float nf[4], rc[4];
 #pragma unroll
-                for (int j = 0; j < NE; j++)
-                    add_sample<MAXM, TRANSFORM>(st[j], (float)(n0[j / C] + s + 1), v[j]);
+                for (int p = 0; p < 4; p++) {
+                    nf[p] = (float)(n0[p] + s + 1);
+                    rc[p] = refined_rcp(nf[p]);
+                }
+#pragma unroll
+                for (int j = 0; j < NE; j++) add_sample<MAXM, TRANSFORM>(st[j], nf[j / C], rc[j / C], v[j]);
             }
 #define STATMC_STORE_PLANE(ptr, field, enabled)                                  \
     if (enabled) {                                                               \
@@ -224,8 +246,10 @@ __device__ __forceinline__ void accumulate_type(const AccumulateType &t) {
                     const long long e = p * C + c;
                     ElemState st = {t.mean[e], MAXM >= 2 ? t.m2[e] : 0.f, MAXM >= 3 ? t.m3[e] : 0.f,
                                     TRANSFORM ? t.film_mean[e] : 0.f, TRANSFORM ? t.film_m2[e] : 0.f};
-                    for (int s = 0; s < S; s++)
-                        add_sample<MAXM, TRANSFORM>(st, (float)(n0 + s + 1), t.samples[(long long)s * t.n_elems + e]);
+                    for (int s = 0; s < S; s++) {
+                        const float nf = (float)(n0 + s + 1);
+                        add_sample<MAXM, TRANSFORM>(st, nf, refined_rcp(nf), t.samples[(long long)s * t.n_elems + e]);
+                    }
                     t.mean[e] = st.mean;
                     if (MAXM >= 2) t.m2[e] = st.m2;
                     if (MAXM >= 3) t.m3[e] = st.m3;
@@ -241,23 +265,26 @@ __device__ __forceinline__ void accumulate_type(const AccumulateType &t) {
 }
 
 template <int C, bool VEC>
-__device__ __forceinline__ void accumulate_dispatch(const AccumulateType &t) {
+__device__ __forceinline__ void accumulate_dispatch(const AccumulateType &t, int n_types) {
     if (t.transform) {
-        if (t.max_moment >= 3) accumulate_type<C, 3, true, VEC>(t);
-        else if (t.max_moment == 2) accumulate_type<C, 2, true, VEC>(t);
-        else accumulate_type<C, 1, true, VEC>(t);
+        if (t.max_moment >= 3) accumulate_type<C, 3, true, VEC>(t, n_types);
+        else if (t.max_moment == 2) accumulate_type<C, 2, true, VEC>(t, n_types);
+        else accumulate_type<C, 1, true, VEC>(t, n_types);
     } else {
-        if (t.max_moment >= 3) accumulate_type<C, 3, false, VEC>(t);
-        else if (t.max_moment == 2) accumulate_type<C, 2, false, VEC>(t);
-        else accumulate_type<C, 1, false, VEC>(t);
+        if (t.max_moment >= 3) accumulate_type<C, 3, false, VEC>(t, n_types);
+        else if (t.max_moment == 2) accumulate_type<C, 2, false, VEC>(t, n_types);
+        else accumulate_type<C, 1, false, VEC>(t, n_types);
     }
 }
 
+// Stat types are interleaved over the 1-D grid (block b works on type b % n_types) so that the
+// ALU-heavy radiance blocks (Box-Cox + third moment + raw-sample Welford) and the purely
+// bandwidth-bound feature blocks are resident together instead of one after the other.
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void accumulate_kernel(AccumulateArgs a) {
-    const AccumulateType &t = a.t[blockIdx.y];
-    if (t.channels == 3) accumulate_dispatch<3, VEC>(t);
-    else accumulate_dispatch<1, VEC>(t);
+    const AccumulateType &t = a.t[blockIdx.x % a.n_types];
+    if (t.channels == 3) accumulate_dispatch<3, VEC>(t, a.n_types);
+    else accumulate_dispatch<1, VEC>(t, a.n_types);
 }
 
 hipError_t launch_accumulate(const AccumulateArgs &a, hipStream_t s) {
@@ -272,7 +299,7 @@ hipError_t launch_accumulate(const AccumulateArgs &a, hipStream_t s) {
         const long long groups = (t.n_elems / t.channels + 3) / 4;
         if (groups > max_groups) max_groups = groups;
     }
-    const dim3 grid(grid_for(max_groups, 256 * 32), a.n_types);
+    const dim3 grid(grid_for(max_groups, 256 * 8) * a.n_types);
     if (vec)
         hipLaunchKernelGGL(accumulate_kernel<true>, grid, dim3(kBlock), 0, s, a);
     else

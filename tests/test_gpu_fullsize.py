@@ -71,7 +71,7 @@ def test_filter_fullsize_properties(gpu, film1080):
     # constant image is a fixed point (weights are normalised)
     const = torch.full_like(colour, 0.375)
     fc = wf(gpu, fs, const, torch.zeros_like(colour))
-    assert float((fc - 0.375).abs().max()) < 1e-6
+    assert float((fc - 0.375).abs().max()) < 0.375 * 1e-5   # 1681 fp32 terms / their sum
     # linear in the colour image: weights depend on the statistics only
     c2 = torch.rand_like(colour)
     f2 = wf(gpu, fs, c2, torch.zeros_like(colour)).clone()
@@ -111,6 +111,7 @@ def test_block_decomposition_equals_whole_film(gpu, film1080):
     from statmc_amd import sharding
     fs, _ = film1080
     colour = fs.state["radiance"]["film_mean"]
+    gpu.force_filter_parts(2)      # same window-row split for the film and for the blocks
     whole = wf(gpu, fs, colour, torch.zeros_like(colour)).clone()
     imgs = dict(mean_corr=fs.mean_corr, disc=fs.disc, colour=colour, normal=fs.g_buffer("normal"), albedo=fs.g_buffer("albedo"))
     bw, bh = W // 2, H // 2
@@ -125,3 +126,4 @@ def test_block_decomposition_equals_whole_film(gpu, film1080):
         gpu.window_filter(a, 3)
         torch.cuda.synchronize()
         assert torch.equal(L.interior(out), whole[oy:oy + bh, ox:ox + bw]), rank
+    gpu.force_filter_parts(0)

@@ -59,6 +59,31 @@ def test_accumulate_matches_oracle(gpu, oracle, channels, transform, max_moment)
             assert not got[k].any()
 
 
+def test_exact_division_by_count(gpu, oracle):
+    """The kernel divides by the sample count with a refined reciprocal + residual correction
+    instead of the IEEE sequence; for this path's operands the quotient must be bit-identical:
+    counts 1..4200 (beyond the t-table), heavy-tailed samples, plain M1 and M3 chains."""
+    rng = np.random.default_rng(99)
+    H, W = 8, 8
+    for max_moment, n0, S in ((1, 0, 1400), (3, 0, 300), (1, 2999, 1201)):
+        smp = rng.lognormal(0, 2.5, size=(S, H, W, 3)).astype(np.float32)
+        smp[rng.random(smp.shape) < 0.1] = 0.0
+        smp[5] *= 1e6
+        smp[6] *= 1e-6
+        ref = oracle.new_state(H, W, 3)
+        if n0:                                   # continue from an existing count
+            ref["n"][...] = n0
+            ref["mean"][...] = rng.standard_normal((H, W, 3)).astype(np.float32)
+            ref["film_mean"][...] = ref["mean"]
+        st = dev_state(ref)
+        oracle.accumulate(ref, smp, False, max_moment)
+        gpu.accumulate(W, H, [gpu.make_stat_type(to_dev(smp), st, False, max_moment)])
+        torch.cuda.synchronize()
+        assert int(st["n"].max()) == n0 + S
+        for k in ("mean", "m2", "m3"):
+            assert np.array_equal(st[k].cpu().numpy(), ref[k]), (max_moment, n0, k)
+
+
 def test_accumulate_all_types_one_launch(gpu, oracle):
     """The 11-channel sample vector: radiance, normal, albedo, depth, material id in one launch."""
     from statmc_amd import film, synthetic
@@ -120,7 +145,11 @@ def test_merge_tiles_matches_oracle(gpu, oracle, channels, transform):
     st = dev_state(ref)
     for t, b in zip(tiles, bounds):
         oracle.merge_tile(t, channels, *b, ref, transform=transform)
-    raw = torch.from_numpy(np.concatenate(tiles).view(np.uint8)).to(DEV)
+    allpx = np.zeros(off, dtype=dt)          # np.concatenate would repack the padded struct dtype
+    for t, o in zip(tiles, offsets):
+        allpx[o:o + len(t)] = t
+    assert allpx.strides[0] == (64 if channels == 1 else 128)
+    raw = torch.from_numpy(allpx.view(np.uint8)).to(DEV)
     gpu.merge_tiles(W, H, channels, transform, raw, to_dev(np.array(bounds, np.int32)),
                     to_dev(np.array(offsets, np.int64)), ts * ts, st)
     torch.cuda.synchronize()
@@ -242,6 +271,21 @@ def test_filter_matches_oracle(gpu, oracle, W, H, radius, sd, force, variant):
     assert v == variant
     for c in range(3):
         assert rel_l2(out[..., c], ref[..., c]) <= TOL, c
+
+
+@pytest.mark.parametrize("parts", [1, 2, 3, 7, 41, 64])
+def test_filter_window_sweep_parts(gpu, oracle, parts):
+    """The LDS kernel splits the window rows over `parts` workgroups per tile (load balance);
+    partial sums are combined by a second kernel.  Any split must agree with the oracle."""
+    mc, disc, colour, gbs = stats_case(oracle, 300, 41, 8, seed=320)
+    ref = oracle.filter_image(mc, disc, colour, gbs, G_DR, -0.5 / FILTER_SD ** 2, RADIUS)
+    gpu.force_filter_parts(parts)
+    try:
+        out, v = run_filter(gpu, mc, disc, colour, gbs, G_DR, FILTER_SD, RADIUS)
+    finally:
+        gpu.force_filter_parts(0)
+    assert v == "lds_r20"
+    assert max(rel_l2(out[..., c], ref[..., c]) for c in range(3)) <= TOL
 
 
 def test_filter_low_spp_high_rejection(gpu, oracle):

@@ -67,6 +67,12 @@ for force in (0, 2):
     api.force_filter_variant(force)
     t_f = timeit(fs.window_filter, 3)
     print("filter %s: %.3f ms  %.1f Mpx/s  %.1f GB/s" % (api.last_filter_variant(), t_f, W * H / t_f / 1e3, W * H * 72 / t_f / 1e6))
+api.force_filter_variant(0)
+for parts in (1, 2, 3, 4, 5, 6, 8):
+    api.force_filter_parts(parts)
+    t_f = timeit(fs.window_filter, 5)
+    print("filter lds_r20 parts=%d: %.3f ms  %.1f Mpx/s" % (parts, t_f, W * H / t_f / 1e3))
+api.force_filter_parts(0)
 api.force_filter_variant(1)
 t_g = timeit(lambda: fs.window_filter(roi=(0, 0, 1920, 64)), 1)
 print("generic (64 rows): %.3f ms -> full %.1f ms" % (t_g, t_g * 1080 / 64))
