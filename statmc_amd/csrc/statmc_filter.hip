@@ -459,15 +459,16 @@ bool fast_path_eligible(const FilterArgs &a, int channels) {
 }
 
 // Number of window-sweep parts per tile: the grid runs one workgroup per CU (LDS-bound), so its
-// makespan is ceil(tiles*parts / CUs) rounds of 1/parts tile-time each (+ a prologue per part,
-// about 0.2 window rows).  Pick the part count with the smallest estimate.
+// makespan is ceil(tiles*parts / CUs) rounds of 1/parts tile-time each (+ a prologue per part
+// that stages 8 rows without compute to overlap, measured at about one window row of time).
+// Pick the part count with the smallest estimate.
 int choose_parts(int tiles, int n_rows, int n_cus) {
     int best = 1;
     double best_cost = 1e30;
     for (int k = 1; k <= 8 && k <= n_rows; k++) {
         const long long wgs = (long long)tiles * k;
         const double rounds = (double)((wgs + n_cus - 1) / n_cus);
-        const double cost = rounds * ((double)n_rows / k + 0.25);
+        const double cost = rounds * ((double)n_rows / k + 1.0);
         if (cost < best_cost * 0.995) {
             best_cost = cost;
             best = k;
