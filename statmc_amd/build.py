@@ -53,5 +53,27 @@ def build(force=False, verbose=False):
     return SO
 
 
+ROOT = os.path.dirname(HERE)
+DENOISE_BIN = os.path.join(ROOT, "tools", "bin", "statmc_denoise")
+
+
+def build_tools(force=False):
+    """g++ build of the C++ host side (include/statmc_denoiser.hpp + tools/statmc_denoise.cpp),
+    linked against libstatmc_hip.so."""
+    src = os.path.join(ROOT, "tools", "statmc_denoise.cpp")
+    deps = [src, os.path.join(ROOT, "include", "statmc_denoiser.hpp"), os.path.join(ROOT, "include", "statmc_pfm.hpp"),
+            os.path.join(ROOT, "include", "statmc.h"), SO]
+    if not force and os.path.exists(DENOISE_BIN) and all(os.path.getmtime(d) <= os.path.getmtime(DENOISE_BIN) for d in deps):
+        return DENOISE_BIN
+    build()
+    os.makedirs(os.path.dirname(DENOISE_BIN), exist_ok=True)
+    rocm_lib = os.path.join(os.path.dirname(os.path.dirname(_hipcc())), "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", DENOISE_BIN,
+                           "-L", HERE, "-lstatmc_hip", "-L", rocm_lib, "-Wl,-rpath,$ORIGIN/../../statmc_amd",
+                           "-Wl,-rpath," + rocm_lib])
+    return DENOISE_BIN
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build_tools(force="--force" in sys.argv))

@@ -1,0 +1,118 @@
+"""The C++ host side above the C ABI (include/statmc_denoiser.hpp), without a GPU: buffer
+catalogue, aliasing, upload / download sets and group counts of the shipped configurations,
+checked against what the reference's Estimator produces (rules at
+src/statistics/estimator.cpp:101-238 and statpath.cpp:1027-1173), and the PFM dump codec."""
+import subprocess
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def denoise_bin():
+    from statmc_amd import build
+    return build.build_tools()
+
+
+def alias_pairs(r):
+    # "alias t1 mean==film-mean 1 m2==film-m2 1"  or  "alias t0-b0-film-mean-f==film-f 1"
+    if len(r) == 3:
+        return [(r[1], int(r[2]))]
+    return [("%s %s" % (r[1], r[i]), int(r[i + 1])) for i in range(2, len(r), 2)]
+
+
+def catalogue(bin_path, *args):
+    out = subprocess.check_output([bin_path, "--catalogue"] + list(args), text=True)
+    rows = [l.split() for l in out.splitlines()]
+    return {
+        "buffers": [(r[1], r[2], int(r[3])) for r in rows if r[0] == "buffer"],
+        "upload": [r[1] for r in rows if r[0] == "upload"],
+        "download": [r[1] for r in rows if r[0] == "download"],
+        "gbuffers": [(r[1], int(r[2]), float(r[3])) for r in rows if r[0] == "gbuffer"],
+        "counts": next(r for r in rows if r[0] == "counts"),
+        "alias": dict(kv for r in rows if r[0] == "alias" for kv in alias_pairs(r)),
+    }
+
+
+SUFFIXES = ["n", "mean", "m2", "film-mean", "film-m2", "m3", "mean-corr", "discriminator", "film-mean-var", "film-mean-f"]
+
+
+def test_default_denoise_catalogue(denoise_bin):
+    """scenes/render-denoise.pbrt: t0 radiance (RGB, transform, M3), t1 normal, t2 albedo."""
+    c = catalogue(denoise_bin, "--config", "denoise", "--width", "32", "--height", "16")
+    names = [b[0] for b in c["buffers"]]
+    assert names == ["film", "film-f"] + ["t%d-b0-%s" % (t, s) for t in range(3) for s in SUFFIXES]   # 32 images
+    assert all(b[1] == ("i32" if b[0].endswith("-n") else "f32") for b in c["buffers"])
+    assert all(b[2] == (1 if b[0].endswith("-n") else 3) for b in c["buffers"])
+    # uploaded each iteration: 7 images = 19 words = 76 B/px; downloaded: film-f = 12 B/px
+    assert sorted(c["upload"]) == sorted(["film", "t0-b0-n", "t0-b0-mean", "t0-b0-m2", "t0-b0-m3",
+                                          "t1-b0-film-mean", "t2-b0-film-mean"])
+    assert c["download"] == ["film-f"]
+    words = {b[0]: b[2] for b in c["buffers"]}
+    assert sum(words[u] for u in c["upload"]) * 4 == 76
+    # G-buffers in type order with DR = -0.5/sd^2 (estimator.cpp:16): normal sd 0.1, albedo sd 0.02
+    assert [g[0] for g in c["gbuffers"]] == ["t1-b0-film-mean", "t2-b0-film-mean"]
+    assert np.isclose(c["gbuffers"][0][2], -50.0) and np.isclose(c["gbuffers"][1][2], -1250.0)
+    # filter<float3>(nBuffers = 1); filter<float> not called; ds = -0.5/10^2; r = 20
+    cnt = c["counts"]
+    assert cnt[2:4] == ["0", "0"] and cnt[5:7] == ["1", "0"] and cnt[8] == "1"
+    assert np.isclose(float(cnt[10]), -0.005) and cnt[12] == "20"
+    # non-transform types alias mean/film-mean, m2/film-m2; t0-b0-film-mean-f shares film-f's host image
+    assert c["alias"]["t0 mean==film-mean"] == 0 and c["alias"]["t1 mean==film-mean"] == 1
+    assert c["alias"]["t2 m2==film-m2"] == 1 and c["alias"]["t0-b0-film-mean-f==film-f"] == 1
+
+
+def test_acrr_catalogue(denoise_bin):
+    """scenes/acrr.pbrt: luminance radiance over 5 tracked bounces -> filter<float>, nBuffers = 5."""
+    c = catalogue(denoise_bin, "--config", "acrr")
+    names = [b[0] for b in c["buffers"]]
+    assert all("t0-b%d-mean" % j in names for j in range(5)) and "t0-b5-mean" not in names
+    assert all(b[2] == 1 for b in c["buffers"] if b[0].startswith("t0-"))
+    assert c["counts"][2] == "5" and c["counts"][5] == "0" and c["counts"][8] == "1"
+    # float path: film-mean uploaded and film-mean-f downloaded per bounce because acrr is on (estimator.cpp:225-229)
+    assert all("t0-b%d-film-mean" % j in c["upload"] and "t0-b%d-film-mean-f" % j in c["download"] for j in range(5))
+    assert "film" not in c["upload"] and "film-f" not in c["download"]          # denoiseFilm is off
+
+
+def test_smis_catalogue(denoise_bin):
+    """scenes/smis.pbrt: BSDF / light win rates, 6 bounces each, float, M3, no transform -> nBuffers = 12."""
+    c = catalogue(denoise_bin, "--config", "smis")
+    assert c["counts"][2] == "12" and c["counts"][5] == "0"
+    assert c["alias"]["t0 mean==film-mean"] == 1 and c["alias"]["t1 mean==film-mean"] == 1
+    assert "t1-b5-film-mean-f" in c["download"] and "t0-b0-film-mean" not in c["upload"]   # non-transform: no film upload
+    assert [g[0] for g in c["gbuffers"]] == ["t2-b0-film-mean", "t3-b0-film-mean"]
+
+
+def test_proden_and_ours_catalogues(denoise_bin):
+    c = catalogue(denoise_bin, "--config", "proden")    # scenes/render-for-proden.pbrt: CPU mean-vars only
+    assert c["counts"][2:4] == ["0", "0"] and c["counts"][5:7] == ["0", "3"] and c["counts"][8] == "0"
+    assert sorted(c["download"]) == ["t%d-b0-film-mean-var" % t for t in range(3)]
+    assert "t1-b0-film-m2" in c["upload"] and not c["gbuffers"]
+    c = catalogue(denoise_bin, "--config", "ours")      # scenes/render-for-ours.pbrt: statistics only, runCUDA = false
+    assert c["counts"][8] == "0" and not c["upload"] and not c["download"]
+    assert "t0-b0-m3" in [b[0] for b in c["buffers"]]
+
+
+def test_config_errors(denoise_bin):
+    r = subprocess.run([denoise_bin, "--catalogue", "--filterbuffers", "albedo,normal", "--filterbuffersds", "0.02"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "must match" in r.stderr      # statpath.cpp:1090-1093
+
+
+def test_pfm_roundtrip(tmp_path):
+    from statmc_amd import pfm
+    rng = np.random.default_rng(0)
+    rgb = rng.standard_normal((7, 5, 3)).astype(np.float32)
+    gray = rng.standard_normal((7, 5)).astype(np.float32)
+    n = rng.integers(0, 100, (7, 5)).astype(np.int32)
+    pfm.write_pfm(tmp_path / "a.pfm", rgb)
+    pfm.write_pfm(tmp_path / "b.pfm", gray)
+    pfm.write_pfm(tmp_path / "n.pfm", n)
+    assert np.array_equal(pfm.read_pfm(tmp_path / "a.pfm"), rgb)
+    assert np.array_equal(pfm.read_pfm(tmp_path / "b.pfm"), gray)
+    assert np.array_equal(pfm.read_pfm(tmp_path / "n.pfm").astype(np.int32), n)
+    raw = open(tmp_path / "a.pfm", "rb").read()
+    assert raw.startswith(b"PF\n5 7\n-1.000000\n")
+    # bottom-to-top: the first stored triple is the first pixel of the LAST row
+    first = np.frombuffer(raw[len(b"PF\n5 7\n-1.000000\n"):][:12], "<f4")
+    assert np.array_equal(first, rgb[-1, 0])

@@ -1,0 +1,36 @@
+"""Offline denoise of a statistics dump through the C++ host side (tools/statmc_denoise, the
+counterpart of `pbrt --denoise`, statpath.cpp:456-550): PFM dumps in, film-f.pfm out."""
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "case_*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_dump_to_denoised_image(gpu, tmp_path, path):
+    from statmc_amd import build, pfm
+    exe = build.build_tools()
+    g = np.load(path)
+    spp = int(g["spp"])
+    stem = str(tmp_path / "scene")
+    dump = {"film": g["film_mean"], "t0-b0-n": g["n"], "t0-b0-mean": g["mean"], "t0-b0-m2": g["m2"],
+            "t0-b0-m3": g["m3"], "t1-b0-film-mean": g["normal_mean"], "t2-b0-film-mean": g["albedo_mean"]}
+    for name, img in dump.items():                    # the outputregex of scenes/render-for-ours.pbrt:24
+        pfm.write_pfm("%s-%d-%s.pfm" % (stem, spp, name), img)
+    out = subprocess.run([exe, "--stem", stem, "--spp", str(spp), "--filtersd", str(float(g["filter_sd"])),
+                          "--filterradius", str(int(g["radius"])), "--warmup",
+                          "--output", "film-f,t0-b0-mean-corr,t0-b0-discriminator"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "HIP time [ns]:" in out.stdout and "Warm-Up" in out.stdout
+    film_f = pfm.read_pfm("%s-%d-film-f.pfm" % (stem, spp))
+    assert np.array_equal(pfm.read_pfm("%s-%d-t0-b0-mean-corr.pfm" % (stem, spp)), g["mean_corr"])
+    assert np.array_equal(pfm.read_pfm("%s-%d-t0-b0-discriminator.pfm" % (stem, spp)), g["discriminator"])
+    for c in range(3):
+        assert rel_l2(film_f[..., c], g["film_f"][..., c]) <= 1e-5

@@ -1,0 +1,218 @@
+// statmc_denoise -- offline denoising of a statistics dump, the counterpart of
+// `pbrt --denoise --writeimages scene.pbrt` (StatPathIntegrator::Denoise<T>,
+// src/statistics/statpath.cpp:456-550) on top of statmc::Estimator and libstatmc_hip.so.
+//
+//   statmc_denoise --stem out/scene --spp 4,8,16 [--filtersd 10] [--filterradius 20]
+//                  [--filterbuffers albedo,normal --filterbuffersds 0.02,0.1]
+//                  [--output 'film-f,t0-b0-mean-corr'] [--warmup]
+//   statmc_denoise --catalogue [--config denoise|acrr|smis|proden|ours] [--width W --height H]
+//
+// Per iteration it reads "<stem>-<spp>-film.pfm" and every "<stem>-<spp>-t<i>-b<j>-<suffix>.pfm"
+// whose suffix is one of n, mean, m2, m3, film-m2, mean-corr, discriminator, film-mean
+// (statpath.cpp:476-511), runs Upload / Denoise / Download / Synchronize (timed like the
+// reference's "CUDA time [ns]" bracket, statpath.cpp:520-527) and writes the selected buffers as
+// "<stem>-<spp>-<buffer>.pfm".  --catalogue prints the buffer catalogue of a shipped
+// configuration without touching a device (used by the CPU tests).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <sstream>
+#include <string>
+
+#include "statmc_denoiser.hpp"
+#include "statmc_pfm.hpp"
+
+using namespace statmc;
+
+static std::vector<std::string> split(const std::string &s) {
+    std::vector<std::string> out;
+    std::stringstream ss(s);
+    std::string item;
+    while (std::getline(ss, item, ','))
+        if (!item.empty()) out.push_back(item);
+    return out;
+}
+
+static bool fileExists(const std::string &p) {
+    FILE *f = std::fopen(p.c_str(), "rb");
+    if (f) std::fclose(f);
+    return f != nullptr;
+}
+
+// ReadFile (statpath.cpp:449-454): imread -> convertTo(buffer type) -> BGR2RGB
+static void readInto(const std::string &path, Buffer &b) {
+    PfmImage im = readPfm(path);
+    if (im.width != b.mat.cols || im.height != b.mat.rows || im.channels != b.mat.channels())
+        throw std::runtime_error(path + ": image shape does not match buffer " + b.name);
+    if (b.mat.type == I32C1) {
+        int32_t *dst = b.mat.ptr<int32_t>();
+        for (size_t i = 0; i < im.data.size(); i++) dst[i] = (int32_t)im.data[i];  // n is stored as float
+    } else {
+        std::memcpy(b.mat.ptr(), im.data.data(), im.data.size() * sizeof(float));
+    }
+}
+
+static StatPathParams shippedConfig(const std::string &name) {
+    StatPathParams p;
+    p.maxDepth = 65;
+    p.trackedBounces = 0;
+    if (name == "denoise") {  // scenes/render-denoise.pbrt, scenes/denoise.pbrt
+        p.denoiseImage = true;
+    } else if (name == "acrr") {  // scenes/acrr.pbrt
+        p.acrr = true;
+        p.trackedBounces = 5;
+        p.multiChannelStats = false;
+    } else if (name == "smis") {  // scenes/smis.pbrt
+        p.smis = true;
+        p.trackedBounces = 6;
+        p.multiChannelStats = false;
+    } else if (name == "proden") {  // scenes/render-for-proden.pbrt
+        p.calcProDenStats = true;
+    } else if (name == "ours") {  // scenes/render-for-ours.pbrt
+        p.calcStats = true;
+    } else {
+        throw std::runtime_error("unknown config " + name);
+    }
+    return p;
+}
+
+int main(int argc, char **argv) {
+    try {
+        std::string stem, sppList, output = "film-f", config = "denoise";
+        StatPathParams params = shippedConfig("denoise");
+        bool catalogue = false, warmup = false, configGiven = false;
+        int width = 64, height = 48;
+        for (int i = 1; i < argc; i++) {
+            const std::string a = argv[i];
+            auto next = [&]() -> std::string {
+                if (i + 1 >= argc) throw std::runtime_error("missing value after " + a);
+                return argv[++i];
+            };
+            if (a == "--stem") stem = next();
+            else if (a == "--spp") sppList = next();
+            else if (a == "--output") output = next();
+            else if (a == "--filtersd") params.filterSD = std::stof(next());
+            else if (a == "--filterradius") params.filterRadius = (unsigned char)std::stoi(next());
+            else if (a == "--filterbuffers") params.filterBuffers = split(next());
+            else if (a == "--filterbuffersds") {
+                params.filterBufferSDs.clear();
+                for (const auto &s : split(next())) params.filterBufferSDs.push_back(std::stof(s));
+            } else if (a == "--config") { config = next(); configGiven = true; }
+            else if (a == "--catalogue") catalogue = true;
+            else if (a == "--warmup") warmup = true;
+            else if (a == "--width") width = std::stoi(next());
+            else if (a == "--height") height = std::stoi(next());
+            else throw std::runtime_error("unknown option " + a);
+        }
+        if (configGiven) {
+            StatPathParams c = shippedConfig(config);
+            c.filterSD = params.filterSD;
+            c.filterRadius = params.filterRadius;
+            c.filterBuffers = params.filterBuffers;
+            c.filterBufferSDs = params.filterBufferSDs;
+            params = c;
+        }
+        const StatTypeConfigs cfgs = makeStatTypeConfigs(params);
+
+        if (catalogue) {
+            Buffer film("film", HostImage(height, width, F32C3), false);
+            BufferRegistry reg(film);
+            Estimator est(film, cfgs, params.filterSD, params.filterRadius, params.denoiseImage, params.acrr,
+                          params.smis, reg, /*allocateDevice=*/false);
+            est.AllocateBuffers(reg);
+            for (const auto &b : reg.buffers)
+                std::printf("buffer %s %s %d\n", b.name.c_str(), b.mat.type == I32C1 ? "i32" : "f32", b.mat.channels());
+            for (const Buffer *b : est.uploadBuffers) std::printf("upload %s\n", b->name.c_str());
+            for (const Buffer *b : est.downloadBuffers) std::printf("download %s\n", b->name.c_str());
+            for (size_t i = 0; i < est.gBuffers.size(); i++)
+                std::printf("gbuffer %s %d %.9g\n", est.gBuffers[i].name.c_str(), est.gBuffers[i].mat.channels(),
+                            est.gBufferDRFactors[i]);
+            std::printf("counts float %d %d rgb %d %d runCUDA %d ds %.9g radius %d\n", est.floatBufferCounts[0],
+                        est.floatBufferCounts[1], est.rgbBufferCounts[0], est.rgbBufferCounts[1], (int)est.runCUDA,
+                        est.filterDSFactor, (int)est.filterRadius);
+            // aliasing facts the reference relies on
+            for (unsigned char i = 0; i < est.statTypeConfigs.nEnabled; i++)
+                std::printf("alias t%d mean==film-mean %d m2==film-m2 %d\n", i,
+                            (int)est.meanBuffers[i][0].mat.sameStorage(est.filmBuffers[i][0].mat),
+                            (int)est.m2Buffers[i][0].mat.sameStorage(est.filmM2Buffers[i][0].mat));
+            if (!est.filmFilteredBuffers.empty() && !est.filmFilteredBuffers[0].empty())
+                std::printf("alias t0-b0-film-mean-f==film-f %d\n",
+                            (int)est.filmFilteredBuffers[0][0].mat.sameStorage(est.filmFilteredBuffer.mat));
+            return 0;
+        }
+
+        if (stem.empty() || sppList.empty()) throw std::runtime_error("--stem and --spp are required");
+        const std::vector<std::string> spps = split(sppList);
+        const std::string first = stem + "-" + spps[0] + "-film.pfm";
+        {
+            PfmImage im = readPfm(first);
+            width = im.width;
+            height = im.height;
+        }
+        Buffer film("film", HostImage(height, width, F32C3));
+        BufferRegistry reg(film);
+        Estimator est(film, cfgs, params.filterSD, params.filterRadius, params.denoiseImage, params.acrr, params.smis, reg);
+        est.AllocateBuffers(reg);
+        const std::vector<std::string> outputs = split(output);
+
+        auto iteration = [&](const std::string &spp, bool write) {
+            using clk = std::chrono::steady_clock;
+            auto t0 = clk::now();
+            const std::string prefix = stem + "-" + spp + "-";
+            if (fileExists(prefix + "film.pfm")) readInto(prefix + "film.pfm", est.filmBuffer);
+            struct Slot { const char *suffix; std::vector<std::vector<Buffer>> *bufs; };
+            const Slot slots[] = {{"n", &est.nBuffers}, {"mean", &est.meanBuffers}, {"m2", &est.m2Buffers},
+                                  {"m3", &est.m3Buffers}, {"film-m2", &est.filmM2Buffers},
+                                  {"mean-corr", &est.meanCorrBuffers}, {"discriminator", &est.discriminatorBuffers},
+                                  {"film-mean", &est.filmBuffers}};
+            for (const Slot &s : slots)
+                for (auto &perType : *s.bufs)
+                    for (Buffer &b : perType) {
+                        const std::string path = prefix + b.name + ".pfm";
+                        if (fileExists(path)) readInto(path, b);
+                    }
+            auto t1 = clk::now();
+            std::cout << "I/O time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count() << std::endl;
+            t0 = clk::now();
+            est.Upload();
+            est.Denoise();
+            est.Download();
+            est.Synchronize();
+            t1 = clk::now();
+            std::cout << "HIP time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count() << std::endl;
+            if (!write) return;
+            for (const auto &name : outputs) {
+                const Buffer *b = reg.find(name);
+                if (!b) throw std::runtime_error("no buffer named " + name);
+                HostImage host = b->mat;
+                if (std::find(est.downloadBuffers.begin(), est.downloadBuffers.end(), b) == est.downloadBuffers.end() &&
+                    (name.find("mean-corr") != std::string::npos || name.find("discriminator") != std::string::npos)) {
+                    // device-only outputs: fetch them explicitly
+                    b->gpuMat.download(host, est.stream);
+                    est.Synchronize();
+                }
+                if (host.type == I32C1) {
+                    std::vector<float> tmp((size_t)width * height);
+                    for (size_t i = 0; i < tmp.size(); i++) tmp[i] = (float)host.ptr<int32_t>()[i];
+                    writePfm(prefix + name + ".pfm", width, height, 1, tmp.data());
+                } else {
+                    writePfm(prefix + name + ".pfm", width, height, host.channels(), host.ptr<float>());
+                }
+            }
+        };
+        if (warmup) {  // --warmup (statpath.cpp:543-547)
+            std::cout << "==== Warm-Up Start ====" << std::endl;
+            iteration(spps[0], false);
+            std::cout << "==== Warm-Up End ====" << std::endl;
+        }
+        for (size_t i = 0; i < spps.size(); i++) {
+            std::cout << "Iteration: " << (i + 1) << std::endl;
+            iteration(spps[i], true);
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "statmc_denoise: %s\n", e.what());
+        return 1;
+    }
+}
