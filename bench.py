@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--filtersd", type=float, default=10.0)
     ap.add_argument("--channels", type=int, default=11, choices=(9, 11))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="gloo (+ --share-device) exercises the N > 1 code path on a 1-GPU box; halos go via the host")
+    ap.add_argument("--share-device", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--cpu-acc-rows", type=int, default=32, help="rows of the film the CPU baseline accumulates")
     return ap.parse_args()
 
@@ -136,11 +139,16 @@ def main():
                              "--nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a gfx950 GPU (no CPU fallback exists for the product path)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from statmc_amd import api, film, sharding, synthetic
     api.setup(local_rank)
@@ -191,7 +199,7 @@ def main():
             inner[..., 6:9].copy_(rad["film_mean"])
             inner[..., 9:12].copy_(fs.g_buffer("normal"))
             inner[..., 12:15].copy_(fs.g_buffer("albedo"))
-            sharding.exchange_halo(L, packed)
+            sharding.exchange_halo(L, packed, via_host=args.backend == "gloo")
             for i, k in enumerate(("mean_corr", "disc", "colour", "normal", "albedo")):
                 pad[k].copy_(packed[..., 3 * i:3 * i + 3])
             if record: e[3].record()
@@ -206,6 +214,7 @@ def main():
                 k_events[name].append((e[i], e[i + 1]))
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -219,7 +228,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

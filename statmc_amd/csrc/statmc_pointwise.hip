@@ -213,7 +213,12 @@ __device__ __forceinline__ void accumulate_type(const AccumulateType &t, int n_t
                 float v[NE];
 #pragma unroll
                 for (int k = 0; k < C; k++) {
-                    const vfloat4 q = __builtin_nontemporal_load(reinterpret_cast<const vfloat4 *>(sp + 4 * k));
+                    // C = 3: the three 16-B loads of a lane interleave across the wave (48-B lane
+                    // stride); they only coalesce through the cache, so they must be plain loads
+                    // (non-temporal ones re-fetch the shared lines: 4.8 vs 6.4 TB/s measured,
+                    // tools/microbench/hbm_read.hip).  C = 1 streams with non-temporal loads.
+                    const vfloat4 q = C == 1 ? __builtin_nontemporal_load(reinterpret_cast<const vfloat4 *>(sp + 4 * k))
+                                             : *reinterpret_cast<const vfloat4 *>(sp + 4 * k);
                     v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
                 }
                 float nf[4], rc[4];

@@ -68,9 +68,10 @@ class BlockLayout:
         return padded[self.pt:self.pt + self.bh, self.pl:self.pl + self.bw]
 
 
-def exchange_halo(layout, padded, group=None):
+def exchange_halo(layout, padded, group=None, via_host=False):
     """Fill the halo margins of `padded` ([ph, pw, C], interior already written) from the
-    neighbouring ranks.  Works on any backend (nccl == RCCL on ROCm, gloo on CPU)."""
+    neighbouring ranks.  Works on any backend (nccl == RCCL on ROCm, gloo on CPU).  via_host
+    stages the messages through host memory (gloo with device tensors: test setups only)."""
     L, r = layout, layout.r
     if L.world == 1 or r == 0:
         return
@@ -82,6 +83,8 @@ def exchange_halo(layout, padded, group=None):
                 continue
             sbuf = send_view.contiguous()
             rbuf = torch.empty_like(recv_view, memory_format=torch.contiguous_format)
+            if via_host:
+                sbuf, rbuf = sbuf.cpu(), rbuf.cpu()
             ops.append(dist.P2POp(dist.isend, sbuf, peer, group=group))
             ops.append(dist.P2POp(dist.irecv, rbuf, peer, group=group))
             recvs.append((recv_view, rbuf))
@@ -89,7 +92,7 @@ def exchange_halo(layout, padded, group=None):
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         for view, buf in recvs:
-            view.copy_(buf)
+            view.copy_(buf)  # (host -> device when via_host)
 
     y0, y1 = L.pt, L.pt + L.bh
     x0, x1 = L.pl, L.pl + L.bw
