@@ -277,13 +277,39 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
         k.gscale0 = sqrtf(-k.g[0].dr * 1.44269504088896340736f);
         k.gscale1 = sqrtf(-k.g[1].dr * 1.44269504088896340736f);
         k.n_parts = statmc::lds_filter_parts(k, device_cus());
-        if (k.n_parts > 1) {
-            if (int rc = partial_workspace((size_t)k.n_parts * W * H * 4 * sizeof(float), &k.partial)) return rc;
-        }
     } else {
         k.n_parts = 1;
     }
-    for (int b = 0; b < a->n_buffers; b++) {
+    const bool fast = statmc::lds_path_selected(k, channels);
+    if (fast) {
+        const int per_px = channels == 3 ? 4 : 8;
+        if (k.n_parts > 1) {
+            if (int rc = partial_workspace((size_t)k.n_parts * W * H * per_px * sizeof(float), &k.partial)) return rc;
+        }
+    }
+    const int group = (fast && channels == 1) ? 3 : 1;  // float buffers go three per launch on the fast path
+    for (int b0 = 0; b0 < a->n_buffers; b0 += group) {
+        const char *variant = "none";
+        if (group == 3) {
+            k.f_active = a->n_buffers - b0 < 3 ? a->n_buffers - b0 : 3;
+            if (!a->film || !a->film_filtered) return fail(STATMC_ERR_INVALID, "null film table");
+            for (int j = 0; j < 3; j++) {
+                const int b = b0 + (j < k.f_active ? j : k.f_active - 1);
+                CHECK_IMG(a->mean_corr[b], 1, "mean_corr", b);
+                CHECK_IMG(a->discriminator[b], 1, "discriminator", b);
+                CHECK_IMG(a->film[b], 1, "film", b);
+                CHECK_IMG(a->film_filtered[b], 1, "film_filtered", b);
+                k.f_mean_corr[j] = static_cast<const float *>(a->mean_corr[b].data);
+                k.f_disc[j] = static_cast<const float *>(a->discriminator[b].data);
+                k.f_colour[j] = static_cast<const float *>(a->film[b].data);
+                k.f_out[j] = static_cast<float *>(a->film_filtered[b].data);
+                if (k.f_out[j] == k.f_colour[j]) return fail(STATMC_ERR_INVALID, "filter cannot run in place (buffer %d)", b);
+            }
+            HIP_TRY(statmc::launch_window_filter(k, channels, S(a->stream), &variant));
+            g_variant = variant;
+            continue;
+        }
+        const int b = b0;
         // buffer 0 filters the "film" image into "film-f" when denoiseFilm is set
         // (estimator.cpp:143-146,168-172; argument positions 12 and 20 of filter<T>)
         const bool film = a->denoise_film && b == 0 && channels == 3;
@@ -299,7 +325,6 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
         k.colour = static_cast<const float *>(colour.data);
         k.out = static_cast<float *>(out.data);
         if (k.out == k.colour) return fail(STATMC_ERR_INVALID, "filter cannot run in place (buffer %d)", b);
-        const char *variant = "none";
         HIP_TRY(statmc::launch_window_filter(k, channels, S(a->stream), &variant));
         g_variant = variant;
     }

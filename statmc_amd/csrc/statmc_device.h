@@ -75,7 +75,12 @@ struct FilterArgs {
     const float *spatial_tab;    // [(2r+1)][2*RP+7] log2-domain spatial exponents, -inf outside r
     float gscale0, gscale1;      // sqrt(-dr_g * log2(e))
     int n_parts;                 // window rows are swept by n_parts workgroups per tile ...
-    float *partial;              // ... which leave (acc.rgb, sum_w) here: [n_parts][height][width][4]
+    float *partial;              // ... which leave their sums here: [n_parts][height][width][4 (RGB) | 8 (float x3)]
+    // fast path, filter<float>: up to three 1-channel buffers per launch (f_active of them real;
+    // the rest repeat the last one and are not stored)
+    const float *f_mean_corr[3], *f_disc[3], *f_colour[3];
+    float *f_out[3];
+    int f_active;
 };
 
 hipError_t launch_prepass(const PrepassArgs &a, hipStream_t s);
@@ -90,6 +95,7 @@ hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s
 size_t spatial_table_floats(int radius);
 void fill_spatial_table(float *host_tab, int radius, float ds);
 bool fast_path_eligible(const FilterArgs &a, int channels);
+bool lds_path_selected(const FilterArgs &a, int channels);
 
 // force a variant for tests/benchmarks: 0 = auto, 1 = generic, 2 = lds_rt (runtime radius)
 void set_filter_variant_override(int v);

@@ -167,6 +167,9 @@ struct LaneState {
     float pmc2[kPx], pd2[kPx];   // ... channel 2
     v2f acc01[kPx];
     float acc2[kPx], sw[kPx];
+    // float mode (three independent 1-channel buffers share the window sweep): per-buffer sums
+    v2f sw01[kPx];
+    float sw2[kPx];
 };
 
 // Half of a read group = 2 taps (columns 4*(lane+j) + 2h, +1 of the staged row) x the lane's 4
@@ -195,7 +198,10 @@ __device__ __forceinline__ float tab_at(float tabv, int idx) {
 
 // MASK: bit (i*4+k) set when tap i of the read group lies inside the window of pixel k (all 16
 // bits in the runtime-radius variant, where the table holds -inf beyond the radius).
-template <int H, unsigned MASK>
+// RGB = true: filter<float3> -- one buffer, membership is the AND over its three channels.
+// RGB = false: filter<float> -- the three "channels" are three independent 1-channel buffers
+// (ACRR bounces / SMIS win rates) that share the range weight but gate and normalise separately.
+template <int H, unsigned MASK, bool RGB>
 __device__ __forceinline__ void compute_half(LaneState &st, const HalfChunk &c, float tabv, int j) {
 #pragma unroll
     for (int ii = 0; ii < 2; ii++) {
@@ -223,11 +229,20 @@ __device__ __forceinline__ void compute_half(LaneState &st, const HalfChunk &c, 
             const v2f t01 = __builtin_elementwise_fma(d, d, q[K_ND01]);
             const float db = st.pmc2[k] - q_mc2;
             const float t2 = __builtin_fmaf(db, db, q_nd2);
-            const bool member = (t01.x <= st.pd01[k].x) & (t01.y <= st.pd01[k].y) & (t2 <= st.pd2[k]);
-            w = member ? w : 0.f;
-            st.sw[k] += w;
-            st.acc01[k] = __builtin_elementwise_fma(v2f{w, w}, q[K_COL01], st.acc01[k]);
-            st.acc2[k] = __builtin_fmaf(w, q_col2, st.acc2[k]);
+            if constexpr (RGB) {
+                const bool member = (t01.x <= st.pd01[k].x) & (t01.y <= st.pd01[k].y) & (t2 <= st.pd2[k]);
+                w = member ? w : 0.f;
+                st.sw[k] += w;
+                st.acc01[k] = __builtin_elementwise_fma(v2f{w, w}, q[K_COL01], st.acc01[k]);
+                st.acc2[k] = __builtin_fmaf(w, q_col2, st.acc2[k]);
+            } else {
+                const v2f w01 = v2f{t01.x <= st.pd01[k].x ? w : 0.f, t01.y <= st.pd01[k].y ? w : 0.f};
+                const float w2 = t2 <= st.pd2[k] ? w : 0.f;
+                st.sw01[k] += w01;
+                st.sw2[k] += w2;
+                st.acc01[k] = __builtin_elementwise_fma(w01, q[K_COL01], st.acc01[k]);
+                st.acc2[k] = __builtin_fmaf(w2, q_col2, st.acc2[k]);
+            }
         }
     }
 }
@@ -237,7 +252,7 @@ __device__ __forceinline__ void compute_half(LaneState &st, const HalfChunk &c, 
 // else hides LDS latency: a stalled wave costs half the SIMD's issue rate).
 // RT > 0 (compile-time radius, a multiple of 4): the first and last read groups hold
 // (tap, pixel) pairs outside the window and get their static masks; every group between is full.
-template <int RT>
+template <int RT, bool RGB>
 __device__ __forceinline__ void eval_row(LaneState &st, const float *row, int pitch, float tabv, int n_chunks) {
     HalfChunk A, B;
     constexpr unsigned kFull = 0xFFFFu;
@@ -247,27 +262,27 @@ __device__ __forceinline__ void eval_row(LaneState &st, const float *row, int pi
         static_assert(ChunkMask<1, RT>::value() == kFull && ChunkMask<n - 2, RT>::value() == kFull, "");
         load_half<0>(A, row, pitch, 0);
         load_half<1>(B, row, pitch, 0);
-        compute_half<0, ChunkMask<0, RT>::value()>(st, A, tabv, 0);
+        compute_half<0, ChunkMask<0, RT>::value(), RGB>(st, A, tabv, 0);
         load_half<0>(A, row, pitch, 1);
-        compute_half<1, ChunkMask<0, RT>::value()>(st, B, tabv, 0);
+        compute_half<1, ChunkMask<0, RT>::value(), RGB>(st, B, tabv, 0);
 #pragma unroll 1
         for (int j = 1; j < n - 1; j++) {
             load_half<1>(B, row, pitch, j);
-            compute_half<0, kFull>(st, A, tabv, j);
+            compute_half<0, kFull, RGB>(st, A, tabv, j);
             load_half<0>(A, row, pitch, j + 1);
-            compute_half<1, kFull>(st, B, tabv, j);
+            compute_half<1, kFull, RGB>(st, B, tabv, j);
         }
         load_half<1>(B, row, pitch, n - 1);
-        compute_half<0, ChunkMask<n - 1, RT>::value()>(st, A, tabv, n - 1);
-        compute_half<1, ChunkMask<n - 1, RT>::value()>(st, B, tabv, n - 1);
+        compute_half<0, ChunkMask<n - 1, RT>::value(), RGB>(st, A, tabv, n - 1);
+        compute_half<1, ChunkMask<n - 1, RT>::value(), RGB>(st, B, tabv, n - 1);
     } else {
         load_half<0>(A, row, pitch, 0);
 #pragma unroll 1
         for (int j = 0; j < n_chunks; j++) {
             load_half<1>(B, row, pitch, j);
-            compute_half<0, kFull>(st, A, tabv, j);
+            compute_half<0, kFull, RGB>(st, A, tabv, j);
             load_half<0>(A, row, pitch, j + 1 < n_chunks ? j + 1 : j);
-            compute_half<1, kFull>(st, B, tabv, j);
+            compute_half<1, kFull, RGB>(st, B, tabv, j);
         }
     }
 }
@@ -278,16 +293,23 @@ struct StagedPixel {
     bool valid;
 };
 
+template <bool RGB>
 __device__ __forceinline__ StagedPixel load_pixel(const FilterArgs &a, int x, int yrow) {
     StagedPixel s;
     s.valid = x >= 0 && x < a.width && yrow >= 0 && yrow < a.height;
     if (s.valid) {
         const long long q = (long long)yrow * a.width + x;
-        s.mc = reinterpret_cast<const f3 *>(a.mean_corr)[q];
-        s.d = reinterpret_cast<const f3 *>(a.disc)[q];
+        if constexpr (RGB) {
+            s.mc = reinterpret_cast<const f3 *>(a.mean_corr)[q];
+            s.d = reinterpret_cast<const f3 *>(a.disc)[q];
+            s.col = reinterpret_cast<const f3 *>(a.colour)[q];
+        } else {
+            s.mc = f3{a.f_mean_corr[0][q], a.f_mean_corr[1][q], a.f_mean_corr[2][q]};
+            s.d = f3{a.f_disc[0][q], a.f_disc[1][q], a.f_disc[2][q]};
+            s.col = f3{a.f_colour[0][q], a.f_colour[1][q], a.f_colour[2][q]};
+        }
         s.g0 = reinterpret_cast<const f3 *>(a.g[0].data)[q];
         s.g1 = reinterpret_cast<const f3 *>(a.g[1].data)[q];
-        s.col = reinterpret_cast<const f3 *>(a.colour)[q];
     }
     return s;
 }
@@ -313,7 +335,7 @@ __device__ __forceinline__ void store_pixel(float *slot, int pitch, int i, const
 
 // RT > 0: compile-time radius (window edges resolved statically); RT == 0: runtime radius
 // a.radius <= 20, every pair of every read group evaluated, the table masks taps beyond r.
-template <int RT>
+template <int RT, bool RGB>
 __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int r = RT > 0 ? RT : a.radius;
@@ -352,8 +374,14 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
     for (int k = 0; k < kPx; k++) {
         const int px = min(x0 + kPx * lane + k, a.width - 1);
         const long long p = (long long)py * a.width + px;
-        const f3 mc = reinterpret_cast<const f3 *>(a.mean_corr)[p];
-        const f3 d = reinterpret_cast<const f3 *>(a.disc)[p];
+        f3 mc, d;
+        if constexpr (RGB) {
+            mc = reinterpret_cast<const f3 *>(a.mean_corr)[p];
+            d = reinterpret_cast<const f3 *>(a.disc)[p];
+        } else {
+            mc = f3{a.f_mean_corr[0][p], a.f_mean_corr[1][p], a.f_mean_corr[2][p]};
+            d = f3{a.f_disc[0][p], a.f_disc[1][p], a.f_disc[2][p]};
+        }
         const f3 g0 = reinterpret_cast<const f3 *>(a.g[0].data)[p];
         const f3 g1 = reinterpret_cast<const f3 *>(a.g[1].data)[p];
         st.pg[0][k] = v2f{g0.x * k0, g0.y * k0};
@@ -366,12 +394,14 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
         st.sw[k] = 0.f;
         st.acc01[k] = v2f{0.f, 0.f};
         st.acc2[k] = 0.f;
+        st.sw01[k] = v2f{0.f, 0.f};
+        st.sw2[k] = 0.f;
     }
 
     // ---- prologue: window rows rel = s0 .. s0+kTileH-1 (image rows y0-r+rel) into slots 0..7
     for (int idx = threadIdx.x; idx < kTileH * pitch; idx += kThreads) {
         const int rel = idx / pitch, i = idx - rel * pitch;
-        const StagedPixel s = load_pixel(a, x0 - rp + i, y0 - r + s0 + rel);
+        const StagedPixel s = load_pixel<RGB>(a, x0 - rp + i, y0 - r + s0 + rel);
         store_pixel(lds + rel * slot_floats, pitch, i, s, k0, k1);
     }
     __syncthreads();
@@ -386,14 +416,14 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
         const bool stage = step + 1 < s1 && (int)threadIdx.x < pitch;
         StagedPixel nxt;
         nxt.valid = false;
-        if (stage) nxt = load_pixel(a, x0 - rp + (int)threadIdx.x, y0 - r + step + kTileH);
+        if (stage) nxt = load_pixel<RGB>(a, x0 - rp + (int)threadIdx.x, y0 - r + step + kTileH);
 
         // prefetch the spatial exponents of the next window row
         float tab_next = 0.f;
         if (step + 1 < s1 && lane < tw) tab_next = a.spatial_tab[(step + 1) * tw + lane];
 
         const float *row = lds + slot * slot_floats + kPx * lane;
-        eval_row<RT>(st, row, pitch, tabv, n_chunks);
+        eval_row<RT, RGB>(st, row, pitch, tabv, n_chunks);
         tabv = tab_next;
 
         if (stage) store_pixel(lds + fill * slot_floats, pitch, threadIdx.x, nxt, k0, k1);
@@ -410,47 +440,78 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
             const int ox = x0 + kPx * lane + k;
             if (ox < a.rx1) {
                 const long long p = (long long)oy * a.width + ox;
-                if (a.n_parts > 1) {  // partial sums; combine_parts_kernel finishes the pixel
-                    reinterpret_cast<float4 *>(a.partial)[(long long)part * a.width * a.height + p] =
-                        make_float4(st.acc01[k].x, st.acc01[k].y, st.acc2[k], st.sw[k]);
-                    continue;
-                }
-                f3 o;
-                if (st.sw[k] > 0.f) {
-                    o.x = st.acc01[k].x / st.sw[k];
-                    o.y = st.acc01[k].y / st.sw[k];
-                    o.z = st.acc2[k] / st.sw[k];
+                if constexpr (RGB) {
+                    if (a.n_parts > 1) {  // partial sums; combine_parts_kernel finishes the pixel
+                        reinterpret_cast<float4 *>(a.partial)[(long long)part * a.width * a.height + p] =
+                            make_float4(st.acc01[k].x, st.acc01[k].y, st.acc2[k], st.sw[k]);
+                        continue;
+                    }
+                    f3 o;
+                    if (st.sw[k] > 0.f) {
+                        o.x = st.acc01[k].x / st.sw[k];
+                        o.y = st.acc01[k].y / st.sw[k];
+                        o.z = st.acc2[k] / st.sw[k];
+                    } else {
+                        o = reinterpret_cast<const f3 *>(a.colour)[p];
+                    }
+                    reinterpret_cast<f3 *>(a.out)[p] = o;
                 } else {
-                    o = reinterpret_cast<const f3 *>(a.colour)[p];
+                    const float acc[3] = {st.acc01[k].x, st.acc01[k].y, st.acc2[k]};
+                    const float sw[3] = {st.sw01[k].x, st.sw01[k].y, st.sw2[k]};
+                    if (a.n_parts > 1) {  // two float4 per (part, pixel): sums, then weights
+                        float4 *dst = reinterpret_cast<float4 *>(a.partial) + 2 * ((long long)part * a.width * a.height + p);
+                        dst[0] = make_float4(acc[0], acc[1], acc[2], 0.f);
+                        dst[1] = make_float4(sw[0], sw[1], sw[2], 0.f);
+                        continue;
+                    }
+#pragma unroll
+                    for (int b = 0; b < 3; b++)
+                        if (b < a.f_active) a.f_out[b][p] = sw[b] > 0.f ? acc[b] / sw[b] : a.f_colour[b][p];
                 }
-                reinterpret_cast<f3 *>(a.out)[p] = o;
             }
         }
     }
 }
 
 // Sums the per-part partial (acc, sum_w) of every ROI pixel in part order and normalises.
+template <bool RGB>
 __global__ __launch_bounds__(256) void combine_parts_kernel(FilterArgs a) {
     const int x = a.rx0 + blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = a.ry0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= a.rx1 || y >= a.ry1) return;
     const long long p = (long long)y * a.width + x, plane = (long long)a.width * a.height;
-    float4 t = reinterpret_cast<const float4 *>(a.partial)[p];
-    for (int k = 1; k < a.n_parts; k++) {
-        const float4 u = reinterpret_cast<const float4 *>(a.partial)[k * plane + p];
-        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-    }
-    f3 o;
-    if (t.w > 0.f) {
-        o.x = t.x / t.w; o.y = t.y / t.w; o.z = t.z / t.w;
+    if constexpr (RGB) {
+        float4 t = reinterpret_cast<const float4 *>(a.partial)[p];
+        for (int k = 1; k < a.n_parts; k++) {
+            const float4 u = reinterpret_cast<const float4 *>(a.partial)[k * plane + p];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        f3 o;
+        if (t.w > 0.f) {
+            o.x = t.x / t.w; o.y = t.y / t.w; o.z = t.z / t.w;
+        } else {
+            o = reinterpret_cast<const f3 *>(a.colour)[p];
+        }
+        reinterpret_cast<f3 *>(a.out)[p] = o;
     } else {
-        o = reinterpret_cast<const f3 *>(a.colour)[p];
+        const float4 *src = reinterpret_cast<const float4 *>(a.partial);
+        float4 acc = src[2 * p], sw = src[2 * p + 1];
+        for (int k = 1; k < a.n_parts; k++) {
+            const float4 u = src[2 * (k * plane + p)], v = src[2 * (k * plane + p) + 1];
+            acc.x += u.x; acc.y += u.y; acc.z += u.z;
+            sw.x += v.x; sw.y += v.y; sw.z += v.z;
+        }
+        const float accs[3] = {acc.x, acc.y, acc.z}, sws[3] = {sw.x, sw.y, sw.z};
+#pragma unroll
+        for (int b = 0; b < 3; b++)
+            if (b < a.f_active) a.f_out[b][p] = sws[b] > 0.f ? accs[b] / sws[b] : a.f_colour[b][p];
     }
-    reinterpret_cast<f3 *>(a.out)[p] = o;
 }
 
+// The LDS kernel covers T = float3 (one RGB buffer) and T = float (three buffers per launch)
+// under two 3-channel G-buffers with finite, non-positive DR factors and radius 1..20.
 bool fast_path_eligible(const FilterArgs &a, int channels) {
-    if (channels != 3 || a.n_g != 2) return false;
+    if ((channels != 3 && channels != 1) || a.n_g != 2) return false;
     if (a.g[0].channels != 3 || a.g[1].channels != 3) return false;
     if (a.radius < 1 || a.radius > kMaxR) return false;
     if (!(a.g[0].dr <= 0.f) || !(a.g[1].dr <= 0.f)) return false;
@@ -480,13 +541,13 @@ int choose_parts(int tiles, int n_rows, int n_cus) {
 static int g_parts_override = 0;
 void set_filter_parts_override(int k) { g_parts_override = k; }
 
-template <int RT>
+template <int RT, bool RGB>
 static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
     const int rp = RT > 0 ? round_up4(RT) : round_up4(a.radius);
     const size_t lds_bytes = (size_t)kSlots * kCh * (kTileW + 2 * rp) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&window_filter_lds<RT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&window_filter_lds<RT, RGB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -494,10 +555,10 @@ static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
     const dim3 tiles((a.rx1 - a.rx0 + kTileW - 1) / kTileW, (a.ry1 - a.ry0 + kTileH - 1) / kTileH);
     if (a.partial == nullptr) a.n_parts = 1;
     const dim3 grid(tiles.x * tiles.y * a.n_parts);
-    hipLaunchKernelGGL(window_filter_lds<RT>, grid, dim3(kThreads), lds_bytes, s, a);
+    hipLaunchKernelGGL((window_filter_lds<RT, RGB>), grid, dim3(kThreads), lds_bytes, s, a);
     if (a.n_parts > 1) {
         const dim3 cgrid((a.rx1 - a.rx0 + 63) / 64, (a.ry1 - a.ry0 + 3) / 4);
-        hipLaunchKernelGGL(combine_parts_kernel, cgrid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(combine_parts_kernel<RGB>, cgrid, dim3(256), 0, s, a);
     }
     return hipGetLastError();
 }
@@ -508,15 +569,22 @@ int lds_filter_parts(const FilterArgs &a, int n_cus) {
     return choose_parts(tiles, 2 * a.radius + 1, n_cus);
 }
 
+// True when launch_window_filter will run the LDS kernel for these arguments (the C-ABI layer
+// groups float buffers three per launch only then).
+bool lds_path_selected(const FilterArgs &a, int channels) {
+    return fast_path_eligible(a, channels) && a.spatial_tab != nullptr && g_variant_override != 1;
+}
+
 hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s, const char **variant) {
-    const bool fast = fast_path_eligible(a, channels) && a.spatial_tab != nullptr && g_variant_override != 1;
+    const bool fast = lds_path_selected(a, channels);
     if (fast) {
+        const bool rgb = channels == 3;
         if (a.radius == 20 && g_variant_override != 2) {
-            *variant = "lds_r20";
-            return launch_lds<20>(a, s);
+            *variant = rgb ? "lds_r20" : "lds_r20_f";
+            return rgb ? launch_lds<20, true>(a, s) : launch_lds<20, false>(a, s);
         }
-        *variant = "lds_rt";
-        return launch_lds<0>(a, s);
+        *variant = rgb ? "lds_rt" : "lds_rt_f";
+        return rgb ? launch_lds<0, true>(a, s) : launch_lds<0, false>(a, s);
     }
     *variant = "generic";
     const dim3 grid((a.rx1 - a.rx0 + 31) / 32, (a.ry1 - a.ry0 + 7) / 8);

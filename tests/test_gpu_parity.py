@@ -349,6 +349,48 @@ def test_filter_generic_gbuffer_sets(gpu, oracle, channels):
     assert rel_l2(out0, ref0) <= TOL
 
 
+@pytest.mark.parametrize("n_buffers,radius,variant", [(5, 20, "lds_r20_f"), (12, 20, "lds_r20_f"), (4, 7, "lds_rt_f"), (1, 20, "lds_r20_f")])
+def test_filter_float_multibuffer_fast_path(gpu, oracle, n_buffers, radius, variant):
+    """filter<float> as ACRR (nBuffers = trackedbounces = 5) and SMIS (2 x 6 = 12) call it
+    (estimator.cpp:437-459): 1-channel buffers with their own statistics and colour, shared RGB
+    G-buffers; the LDS kernel takes them three per launch."""
+    W, H = 276, 27
+    _, smp, st = make_case(W, H, 8, seed=50 + n_buffers)
+    rng = np.random.default_rng(n_buffers)
+    gbs = [st["normal"]["mean"], st["albedo"]["mean"]]
+    lum = smp["radiance"].mean(axis=3, keepdims=True)            # luminance-like scalar samples
+    refs, args = [], dict(n=[], mean=[], m2=[], m3=[], film=[], mean_corr=[], disc=[], film_filtered=[])
+    for b in range(n_buffers):
+        s = oracle.new_state(H, W, 1)
+        scale = np.float32(1.0 / (1 + b))                           # deeper bounces carry less energy
+        oracle.accumulate(s, np.ascontiguousarray(lum * scale + rng.random(lum.shape, dtype=np.float32) * 0.01), True, 3)
+        mc, dc = oracle.prepass(s["n"], s["mean"], s["m2"], s["m3"])
+        refs.append(oracle.filter_image(mc, dc, s["film_mean"], gbs, G_DR, -0.5 / FILTER_SD ** 2, radius))
+        for k, v in (("n", s["n"]), ("mean", s["mean"]), ("m2", s["m2"]), ("m3", s["m3"]), ("film", s["film_mean"])):
+            args[k].append(to_dev(v))
+        for k in ("mean_corr", "disc", "film_filtered"):
+            args[k].append(torch.zeros(H, W, 1, device=DEV))
+    a, keep = gpu.make_filter_args(g_buffers=[to_dev(g) for g in gbs], g_sds=[SD_NORMAL, SD_ALBEDO],
+                                   filter_sd=FILTER_SD, radius=radius, **args)
+    gpu.filter_f32(a)
+    torch.cuda.synchronize()
+    assert gpu.last_filter_variant() == variant
+    for b in range(n_buffers):
+        assert rel_l2(args["film_filtered"][b].cpu().numpy(), refs[b]) <= TOL, b
+    # same call through the generic kernel
+    gpu.force_filter_variant(1)
+    try:
+        for t in args["film_filtered"]:
+            t.zero_()
+        gpu.filter_f32(a)
+        torch.cuda.synchronize()
+    finally:
+        gpu.force_filter_variant(0)
+    assert gpu.last_filter_variant() == "generic"
+    for b in range(n_buffers):
+        assert rel_l2(args["film_filtered"][b].cpu().numpy(), refs[b]) <= TOL, b
+
+
 def test_filter_entry_point_reference_argument_order(gpu, oracle):
     """statmc_filter_f32x3 with the reference's argument block: nBuffers = 2, denoiseFilm set:
     buffer 0 filters `film` into `film-f`, buffer 1 filters its own film-mean (estimator.cpp:465-487)."""
