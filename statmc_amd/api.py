@@ -100,6 +100,7 @@ def load():
                                         C.c_void_p, C.c_void_p]
     lib.statmc_debug_force_filter_variant.argtypes = [C.c_int]
     lib.statmc_debug_force_filter_parts.argtypes = [C.c_int]
+    lib.statmc_debug_accumulate_resident_blocks.argtypes = [C.c_int]
     _lib = lib
     return lib
 
@@ -126,6 +127,11 @@ def last_filter_variant():
 def force_filter_variant(v):
     """0 auto, 1 generic (global-memory) kernel, 2 runtime-radius LDS kernel."""
     load().statmc_debug_force_filter_variant(int(v))
+
+
+def accumulate_resident_blocks(n):
+    """0: default large grid; n > 0: the accumulate kernel runs as n resident workgroups."""
+    load().statmc_debug_accumulate_resident_blocks(int(n))
 
 
 def force_filter_parts(k):

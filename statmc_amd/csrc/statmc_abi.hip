@@ -20,6 +20,7 @@ namespace {
 thread_local char g_err[512] = "";
 thread_local const char *g_variant = "none";
 int g_alpha_index = 0;
+int g_accumulate_resident_blocks = 0;
 bool g_ready = false;
 std::mutex g_mu;
 
@@ -393,6 +394,7 @@ int statmc_accumulate(uint16_t width, uint16_t height, const statmc_stat_type *t
         d.transform = t.transform ? 1 : 0;
         d.max_moment = t.max_moment;
     }
+    k.resident_blocks = g_accumulate_resident_blocks;
     HIP_TRY(statmc::launch_accumulate(k, S(stream)));
     return STATMC_OK;
 }
@@ -429,6 +431,10 @@ int statmc_tile_moments(uint16_t width, uint16_t height, int channels, const flo
 // test/bench hooks (not part of the reference surface)
 int statmc_debug_force_filter_variant(int v) {  // 0 auto, 1 generic, 2 runtime-radius LDS
     statmc::set_filter_variant_override(v);
+    return STATMC_OK;
+}
+int statmc_debug_accumulate_resident_blocks(int n) {  // 0 large grid (default), n > 0: n resident workgroups
+    g_accumulate_resident_blocks = n < 0 ? 0 : n;
     return STATMC_OK;
 }
 int statmc_debug_force_filter_parts(int k) {  // 0 auto, k >= 1: window-sweep parts per tile

@@ -37,6 +37,7 @@ struct AccumulateType {
 struct AccumulateArgs {
     AccumulateType t[kMaxStatTypes];
     int n_types;
+    int resident_blocks;  // 0: large interleaved grid; > 0: that many workgroups walk all types
 };
 
 struct MergeTilesArgs {

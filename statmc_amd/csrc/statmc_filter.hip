@@ -247,42 +247,42 @@ __device__ __forceinline__ void compute_half(LaneState &st, const HalfChunk &c, 
     }
 }
 
-// Sweep one window row.  Operand sets A (taps 0,1 of a read group) and B (taps 2,3) alternate:
-// while one is evaluated the other's LDS reads are in flight (with 2 waves per SIMD nothing
-// else hides LDS latency: a stalled wave costs half the SIMD's issue rate).
+// Sweep one window row, one half read group (2 taps x 4 pixels) at a time.  A single operand set
+// keeps the kernel at <= 168 VGPRs, which leaves room on every SIMD for a wave of another kernel
+// (the sample accumulation of the next iteration runs beside the filter: bench.py); the second
+// wave of the workgroup on the SIMD covers the LDS latency.
 // RT > 0 (compile-time radius, a multiple of 4): the first and last read groups hold
 // (tap, pixel) pairs outside the window and get their static masks; every group between is full.
 template <int RT, bool RGB>
 __device__ __forceinline__ void eval_row(LaneState &st, const float *row, int pitch, float tabv, int n_chunks) {
-    HalfChunk A, B;
+    HalfChunk A;
     constexpr unsigned kFull = 0xFFFFu;
     if constexpr (RT > 0) {
         constexpr int n = 2 * round_up4(RT) / 4 + 1;
         static_assert(RT % 4 == 0 && n >= 3, "static variant: radius multiple of 4");
         static_assert(ChunkMask<1, RT>::value() == kFull && ChunkMask<n - 2, RT>::value() == kFull, "");
         load_half<0>(A, row, pitch, 0);
-        load_half<1>(B, row, pitch, 0);
         compute_half<0, ChunkMask<0, RT>::value(), RGB>(st, A, tabv, 0);
-        load_half<0>(A, row, pitch, 1);
-        compute_half<1, ChunkMask<0, RT>::value(), RGB>(st, B, tabv, 0);
+        load_half<1>(A, row, pitch, 0);
+        compute_half<1, ChunkMask<0, RT>::value(), RGB>(st, A, tabv, 0);
 #pragma unroll 1
         for (int j = 1; j < n - 1; j++) {
-            load_half<1>(B, row, pitch, j);
+            load_half<0>(A, row, pitch, j);
             compute_half<0, kFull, RGB>(st, A, tabv, j);
-            load_half<0>(A, row, pitch, j + 1);
-            compute_half<1, kFull, RGB>(st, B, tabv, j);
+            load_half<1>(A, row, pitch, j);
+            compute_half<1, kFull, RGB>(st, A, tabv, j);
         }
-        load_half<1>(B, row, pitch, n - 1);
+        load_half<0>(A, row, pitch, n - 1);
         compute_half<0, ChunkMask<n - 1, RT>::value(), RGB>(st, A, tabv, n - 1);
-        compute_half<1, ChunkMask<n - 1, RT>::value(), RGB>(st, B, tabv, n - 1);
+        load_half<1>(A, row, pitch, n - 1);
+        compute_half<1, ChunkMask<n - 1, RT>::value(), RGB>(st, A, tabv, n - 1);
     } else {
-        load_half<0>(A, row, pitch, 0);
 #pragma unroll 1
         for (int j = 0; j < n_chunks; j++) {
-            load_half<1>(B, row, pitch, j);
+            load_half<0>(A, row, pitch, j);
             compute_half<0, kFull, RGB>(st, A, tabv, j);
-            load_half<0>(A, row, pitch, j + 1 < n_chunks ? j + 1 : j);
-            compute_half<1, kFull, RGB>(st, B, tabv, j);
+            load_half<1>(A, row, pitch, j);
+            compute_half<1, kFull, RGB>(st, A, tabv, j);
         }
     }
 }

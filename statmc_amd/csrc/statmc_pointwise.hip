@@ -177,12 +177,11 @@ __device__ __forceinline__ void add_sample(ElemState &st, float nf, float r, flo
 }
 
 template <int C, int MAXM, bool TRANSFORM, bool VEC>
-__device__ __forceinline__ void accumulate_type(const AccumulateType &t, int n_types) {
+__device__ __forceinline__ void accumulate_type(const AccumulateType &t, long long blk, long long nblk) {
     constexpr int NE = 4 * C;  // elements per lane
     const long long n_px = t.n_elems / C;
     const long long n_groups = (n_px + 3) >> 2;
     const int S = t.n_samples;
-    const long long blk = blockIdx.x / n_types, nblk = gridDim.x / n_types;
     for (long long g = blk * kBlock + threadIdx.x; g < n_groups; g += nblk * kBlock) {
         const long long p0 = g << 2;
         const long long e0 = p0 * C;
@@ -207,20 +206,22 @@ __device__ __forceinline__ void accumulate_type(const AccumulateType &t, int n_t
             STATMC_LOAD_PLANE(t.film_mean, fmean, TRANSFORM)
             STATMC_LOAD_PLANE(t.film_m2, fm2, TRANSFORM)
 #undef STATMC_LOAD_PLANE
+            // Software-pipelined sample walk: the loads of the next U samples are issued before
+            // the current U are folded into the moments, so 2U sample rows per lane are in flight
+            // (the compiler would otherwise drain each unrolled body before loading again).
+            // C = 3: the three 16-B loads of a lane interleave across the wave (48-B lane stride);
+            // they only coalesce through the cache, so they must be plain loads (non-temporal ones
+            // re-fetch the shared lines: 4.8 vs 6.4 TB/s, tools/microbench/hbm_read.hip).  C = 1
+            // streams with non-temporal loads.
+            constexpr int U = C == 3 ? 2 : 4;
             const float *sp = t.samples + e0;
-#pragma unroll 2
-            for (int s = 0; s < S; s++, sp += t.n_elems) {
-                float v[NE];
+            auto load_sample = [&](vfloat4 (&dst)[C], const float *src) {
 #pragma unroll
-                for (int k = 0; k < C; k++) {
-                    // C = 3: the three 16-B loads of a lane interleave across the wave (48-B lane
-                    // stride); they only coalesce through the cache, so they must be plain loads
-                    // (non-temporal ones re-fetch the shared lines: 4.8 vs 6.4 TB/s measured,
-                    // tools/microbench/hbm_read.hip).  C = 1 streams with non-temporal loads.
-                    const vfloat4 q = C == 1 ? __builtin_nontemporal_load(reinterpret_cast<const vfloat4 *>(sp + 4 * k))
-                                             : *reinterpret_cast<const vfloat4 *>(sp + 4 * k);
-                    v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
-                }
+                for (int k = 0; k < C; k++)
+                    dst[k] = C == 1 ? __builtin_nontemporal_load(reinterpret_cast<const vfloat4 *>(src + 4 * k))
+                                    : *reinterpret_cast<const vfloat4 *>(src + 4 * k);
+            };
+            auto fold_sample = [&](const vfloat4 (&q)[C], int s) {
                 float nf[4], rc[4];
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
@@ -228,7 +229,31 @@ __device__ __forceinline__ void accumulate_type(const AccumulateType &t, int n_t
                     rc[p] = refined_rcp(nf[p]);
                 }
 #pragma unroll
-                for (int j = 0; j < NE; j++) add_sample<MAXM, TRANSFORM>(st[j], nf[j / C], rc[j / C], v[j]);
+                for (int j = 0; j < NE; j++) add_sample<MAXM, TRANSFORM>(st[j], nf[j / C], rc[j / C], q[j >> 2][j & 3]);
+            };
+            vfloat4 cur[U][C], nxt[U][C];
+            const int S_main = S - S % U;
+            if (S_main > 0) {
+#pragma unroll
+                for (int u = 0; u < U; u++) load_sample(cur[u], sp + (long long)u * t.n_elems);
+            }
+            for (int s = 0; s < S_main; s += U) {
+                const float *np = sp + (long long)(s + U) * t.n_elems;
+                if (s + U < S_main) {
+#pragma unroll
+                    for (int u = 0; u < U; u++) load_sample(nxt[u], np + (long long)u * t.n_elems);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) fold_sample(cur[u], s + u);
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int k = 0; k < C; k++) cur[u][k] = nxt[u][k];
+            }
+            for (int s = S_main; s < S; s++) {  // remainder (S not a multiple of U)
+                vfloat4 q[C];
+                load_sample(q, sp + (long long)s * t.n_elems);
+                fold_sample(q, s);
             }
 #define STATMC_STORE_PLANE(ptr, field, enabled)                                  \
     if (enabled) {                                                               \
@@ -270,26 +295,39 @@ __device__ __forceinline__ void accumulate_type(const AccumulateType &t, int n_t
 }
 
 template <int C, bool VEC>
-__device__ __forceinline__ void accumulate_dispatch(const AccumulateType &t, int n_types) {
+__device__ __forceinline__ void accumulate_dispatch(const AccumulateType &t, long long blk, long long nblk) {
     if (t.transform) {
-        if (t.max_moment >= 3) accumulate_type<C, 3, true, VEC>(t, n_types);
-        else if (t.max_moment == 2) accumulate_type<C, 2, true, VEC>(t, n_types);
-        else accumulate_type<C, 1, true, VEC>(t, n_types);
+        if (t.max_moment >= 3) accumulate_type<C, 3, true, VEC>(t, blk, nblk);
+        else if (t.max_moment == 2) accumulate_type<C, 2, true, VEC>(t, blk, nblk);
+        else accumulate_type<C, 1, true, VEC>(t, blk, nblk);
     } else {
-        if (t.max_moment >= 3) accumulate_type<C, 3, false, VEC>(t, n_types);
-        else if (t.max_moment == 2) accumulate_type<C, 2, false, VEC>(t, n_types);
-        else accumulate_type<C, 1, false, VEC>(t, n_types);
+        if (t.max_moment >= 3) accumulate_type<C, 3, false, VEC>(t, blk, nblk);
+        else if (t.max_moment == 2) accumulate_type<C, 2, false, VEC>(t, blk, nblk);
+        else accumulate_type<C, 1, false, VEC>(t, blk, nblk);
     }
 }
 
-// Stat types are interleaved over the 1-D grid (block b works on type b % n_types) so that the
-// ALU-heavy radiance blocks (Box-Cox + third moment + raw-sample Welford) and the purely
-// bandwidth-bound feature blocks are resident together instead of one after the other.
+// Default grid: stat types are interleaved over a large 1-D grid (block b works on type
+// b % n_types) so that the ALU-heavy radiance blocks (Box-Cox + third moment + raw-sample
+// Welford) and the purely bandwidth-bound feature blocks are resident together.
+// Resident grid (a.resident_blocks > 0): that many workgroups in total (e.g. one per CU); each
+// walks every stat type, starting at a different one, with a grid-stride loop.  It keeps the
+// kernel to one wave per SIMD so that the register file and the LDS of every CU stay free for
+// a co-resident VALU-bound kernel (the window filter of the previous iteration on another stream).
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void accumulate_kernel(AccumulateArgs a) {
+    if (a.resident_blocks > 0) {
+        for (int i = 0; i < a.n_types; i++) {
+            const AccumulateType &t = a.t[(blockIdx.x + i) % a.n_types];
+            if (t.channels == 3) accumulate_dispatch<3, VEC>(t, blockIdx.x, gridDim.x);
+            else accumulate_dispatch<1, VEC>(t, blockIdx.x, gridDim.x);
+        }
+        return;
+    }
     const AccumulateType &t = a.t[blockIdx.x % a.n_types];
-    if (t.channels == 3) accumulate_dispatch<3, VEC>(t, a.n_types);
-    else accumulate_dispatch<1, VEC>(t, a.n_types);
+    const long long blk = blockIdx.x / a.n_types, nblk = gridDim.x / a.n_types;
+    if (t.channels == 3) accumulate_dispatch<3, VEC>(t, blk, nblk);
+    else accumulate_dispatch<1, VEC>(t, blk, nblk);
 }
 
 hipError_t launch_accumulate(const AccumulateArgs &a, hipStream_t s) {
@@ -304,7 +342,7 @@ hipError_t launch_accumulate(const AccumulateArgs &a, hipStream_t s) {
         const long long groups = (t.n_elems / t.channels + 3) / 4;
         if (groups > max_groups) max_groups = groups;
     }
-    const dim3 grid(grid_for(max_groups, 256 * 8) * a.n_types);
+    const dim3 grid(a.resident_blocks > 0 ? a.resident_blocks : grid_for(max_groups, 256 * 8) * a.n_types);
     if (vec)
         hipLaunchKernelGGL(accumulate_kernel<true>, grid, dim3(kBlock), 0, s, a);
     else

@@ -101,6 +101,28 @@ def test_accumulate_all_types_one_launch(gpu, oracle):
             assert np.array_equal(fs.state[t]["mean"].cpu().numpy(), ref[t]["mean"]), t
 
 
+def test_accumulate_resident_grid(gpu, oracle):
+    """The resident-workgroup launch shape (few workgroups walking every stat type) gives the same
+    images as the default interleaved grid."""
+    from statmc_amd import film, synthetic
+    W, H, S = 61, 33, 7                                               # odd sample count: pipelined loop + remainder
+    scene, smp, ref = make_case(W, H, S, seed=9, features=synthetic.FEATURES)
+    gpu.accumulate_resident_blocks(3)
+    try:
+        fs = film.FilmStats(W, H, DEV, types=synthetic.FEATURES)
+        fs.accumulate({k: to_dev(v) for k, v in smp.items()})
+        torch.cuda.synchronize()
+    finally:
+        gpu.accumulate_resident_blocks(0)
+    for t in synthetic.FEATURES:
+        assert np.array_equal(fs.state[t]["n"].cpu().numpy(), ref[t]["n"])
+        if t == "radiance":
+            assert rel_l2(fs.state[t]["m3"].cpu().numpy(), ref[t]["m3"]) <= TOL
+            assert np.array_equal(fs.state[t]["film_m2"].cpu().numpy(), ref[t]["film_m2"])
+        else:
+            assert np.array_equal(fs.state[t]["mean"].cpu().numpy(), ref[t]["mean"]), t
+
+
 def test_accumulate_empty_and_errors(gpu, oracle):
     st = dev_state(oracle.new_state(4, 4, 3))
     empty = torch.zeros(0, 4, 4, 3, device=DEV)
