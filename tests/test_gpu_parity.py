@@ -442,6 +442,37 @@ def test_filter_entry_point_reference_argument_order(gpu, oracle):
     assert not ff[0].any()                                             # buffer 0 wrote film-f, not t0-b0-film-mean-f
 
 
+def test_maximum_width_and_empty_calls(gpu, oracle):
+    """The reference passes width/height as unsigned short (estimator.h:316-317): the widest film is
+    65535 columns.  Also: zero buffers is a no-op, an empty image is an error."""
+    W, H, S = 65535, 3, 4
+    rng = np.random.default_rng(65535)
+    smp = rng.lognormal(0, 1, size=(S, H, W, 3)).astype(np.float32)
+    gb = [rng.random((H, W, 3), dtype=np.float32), rng.random((H, W, 3), dtype=np.float32)]
+    ref = oracle.new_state(H, W, 3)
+    oracle.accumulate(ref, smp, True, 3)
+    st = dev_state(oracle.new_state(H, W, 3))
+    gpu.accumulate(W, H, [gpu.make_stat_type(to_dev(smp), st, True, 3)])
+    torch.cuda.synchronize()
+    assert np.array_equal(st["n"].cpu().numpy(), ref["n"]) and np.array_equal(st["film_mean"].cpu().numpy(), ref["film_mean"])
+    mc, dc = oracle.prepass(ref["n"], ref["mean"], ref["m2"], ref["m3"])
+    g_dr = [-0.5 / 0.5 ** 2, -0.5 / 0.4 ** 2]
+    want = oracle.filter_image(mc, dc, ref["film_mean"], gb, g_dr, -0.5 / 25.0, 8)
+    for force, variant in ((0, "lds_rt"), (1, "generic")):
+        out, v = run_filter(gpu, mc, dc, ref["film_mean"], gb, g_dr, 5.0, 8, force=force)
+        assert v == variant
+        assert max(rel_l2(out[..., c], want[..., c]) for c in range(3)) <= TOL, v
+    # zero buffers: nothing to do, no error; empty image: invalid
+    z = torch.zeros(4, 4, 3, device=DEV)
+    a, keep = gpu.make_filter_args([], [], [], [], [z], [z.clone()], [z.clone()], [z.clone()], [], g_sds=[], radius=2)
+    a.n_buffers = 0
+    gpu.filter_f32x3(a)
+    a.n_buffers, a.width = 1, 0
+    with pytest.raises(gpu.StatmcError) as e:
+        gpu.window_filter(a, 3)
+    assert e.value.code == gpu.ERR_INVALID
+
+
 def test_filter_argument_errors(gpu):
     z = lambda c=3: torch.zeros(8, 8, c, device=DEV)
     a, keep = gpu.make_filter_args([], [], [], [], [z()], [z()], [z()], [z()], [z()], g_sds=[0.1], radius=2)
