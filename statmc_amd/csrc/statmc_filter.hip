@@ -247,10 +247,9 @@ __device__ __forceinline__ void compute_half(LaneState &st, const HalfChunk &c, 
     }
 }
 
-// Sweep one window row, one half read group (2 taps x 4 pixels) at a time.  A single operand set
-// keeps the kernel at <= 168 VGPRs, which leaves room on every SIMD for a wave of another kernel
-// (the sample accumulation of the next iteration runs beside the filter: bench.py); the second
-// wave of the workgroup on the SIMD covers the LDS latency.
+// Sweep one window row, one half read group (2 taps x 4 pixels) at a time.  Register
+// double-buffering of the operand sets was measured and bought nothing (the second wave on the
+// SIMD already covers the LDS latency), so a single set is used: 164 VGPRs.
 // RT > 0 (compile-time radius, a multiple of 4): the first and last read groups hold
 // (tap, pixel) pairs outside the window and get their static masks; every group between is full.
 template <int RT, bool RGB>

@@ -213,7 +213,7 @@ __device__ __forceinline__ void accumulate_type(const AccumulateType &t, long lo
             // they only coalesce through the cache, so they must be plain loads (non-temporal ones
             // re-fetch the shared lines: 4.8 vs 6.4 TB/s, tools/microbench/hbm_read.hip).  C = 1
             // streams with non-temporal loads.
-            constexpr int U = C == 3 ? 2 : 4;
+            constexpr int U = C == 3 ? 3 : 6;
             const float *sp = t.samples + e0;
             auto load_sample = [&](vfloat4 (&dst)[C], const float *src) {
 #pragma unroll
@@ -310,10 +310,11 @@ __device__ __forceinline__ void accumulate_dispatch(const AccumulateType &t, lon
 // Default grid: stat types are interleaved over a large 1-D grid (block b works on type
 // b % n_types) so that the ALU-heavy radiance blocks (Box-Cox + third moment + raw-sample
 // Welford) and the purely bandwidth-bound feature blocks are resident together.
-// Resident grid (a.resident_blocks > 0): that many workgroups in total (e.g. one per CU); each
-// walks every stat type, starting at a different one, with a grid-stride loop.  It keeps the
-// kernel to one wave per SIMD so that the register file and the LDS of every CU stay free for
-// a co-resident VALU-bound kernel (the window filter of the previous iteration on another stream).
+// Resident grid (a.resident_blocks > 0, experiment hook): that many workgroups in total; each
+// walks every stat type, starting at a different one, with a grid-stride loop.  Measured use:
+// running this bandwidth-bound kernel beside the VALU-bound window filter of the previous
+// iteration on a second stream gains <= 15 % (the two contend for VALU issue), so bench.py
+// keeps the kernels back to back.
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void accumulate_kernel(AccumulateArgs a) {
     if (a.resident_blocks > 0) {

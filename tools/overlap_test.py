@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from statmc_amd import api, film, synthetic
 dev = torch.device("cuda:0"); api.setup(0)
-W, H, S = 1920, 1080, 128
+W, H, S = 1920, 1080, int(os.environ.get('S', '256'))
 sc = synthetic.Scene(W, H, seed=1, device=dev)
 chunks = [sc.samples(32, seed=10 + i) for i in range(S // 32)]
 smp = {t: torch.cat([c[t] for c in chunks]) for t in synthetic.FEATURES}
