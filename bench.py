@@ -150,7 +150,7 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    from statmc_amd import api, film, sharding, synthetic
+    from statmc_amd import api, film, pipeline, sharding, synthetic
     api.setup(local_rank)
 
     W, H, S, r = args.width, args.height, args.spp, args.radius
@@ -169,13 +169,9 @@ def main():
         for t in types:
             samples[t].append(part[t])
     samples = {t: torch.cat(v, dim=0) for t, v in samples.items()}
-    fs = film.FilmStats(W, H, dev, types=types, filter_sd=args.filtersd, radius=r)
-
-    # padded filter inputs for the multi-GPU path (block + halo)
-    if world > 1:
-        pad = {k: layout.new_padded(3, dev) for k in ("mean_corr", "disc", "colour", "normal", "albedo")}
-        packed = layout.new_padded(15, dev)
-        out_pad = layout.new_padded(3, dev)
+    pipe = pipeline.BlockPipeline(layout, dev, types, filter_sd=args.filtersd, radius=r,
+                                  via_host=args.backend == "gloo")
+    fs = pipe.fs
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     k_events = {"accumulate": [], "prepass": [], "halo": [], "filter": []}
@@ -183,31 +179,14 @@ def main():
     def step(record):
         e = [ev() for _ in range(5)] if record else None
         if record: e[0].record()
-        fs.accumulate(samples)
+        pipe.accumulate(samples)
         if record: e[1].record()
-        fs.prepass()
+        pipe.prepass()
         if record: e[2].record()
-        if world == 1:
-            if record: e[3].record()
-            fs.window_filter()
-        else:
-            rad = fs.state["radiance"]
-            L = layout
-            inner = L.interior(packed)
-            inner[..., 0:3].copy_(fs.mean_corr)
-            inner[..., 3:6].copy_(fs.disc)
-            inner[..., 6:9].copy_(rad["film_mean"])
-            inner[..., 9:12].copy_(fs.g_buffer("normal"))
-            inner[..., 12:15].copy_(fs.g_buffer("albedo"))
-            sharding.exchange_halo(L, packed, via_host=args.backend == "gloo")
-            for i, k in enumerate(("mean_corr", "disc", "colour", "normal", "albedo")):
-                pad[k].copy_(packed[..., 3 * i:3 * i + 3])
-            if record: e[3].record()
-            a, keep = api.make_filter_args(
-                n=[], mean=[], m2=[], m3=[], film=[pad["colour"]], mean_corr=[pad["mean_corr"]],
-                disc=[pad["disc"]], film_filtered=[out_pad], g_buffers=[pad["normal"], pad["albedo"]],
-                g_sds=fs.g_sds, filter_sd=args.filtersd, radius=r, roi=L.roi)
-            api.window_filter(a, 3)
+        if world > 1:
+            pipe.exchange()
+        if record: e[3].record()
+        pipe.window_filter()
         if record:
             e[4].record()
             for name, i in (("accumulate", 0), ("prepass", 1), ("halo", 2), ("filter", 3)):

@@ -1,0 +1,86 @@
+"""The N > 1 path end to end on the GPU: several ranks (gloo rendezvous, all on cuda:0 because
+the test box has one GPU; halos staged through the host) each run BlockPipeline on their block of
+a film; the assembled blocks must equal what one process computes on the whole film.  RCCL itself
+is exercised by the driver's multi-GPU bench; this pins everything around it."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+BW, BH, SPP, RADIUS = 272, 40, 6, 20
+TYPES = ("radiance", "normal", "albedo")
+
+
+def _film_samples(world):
+    """Whole-film sample stream, identical in every process (CPU generator, fixed seed)."""
+    from statmc_amd import sharding, synthetic
+    gx, gy = sharding.grid_for(world)
+    scene = synthetic.Scene(gx * BW, gy * BH, n_regions=9, seed=21)
+    return scene.samples(SPP, seed=22, features=TYPES)
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from statmc_amd import api, pipeline, sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        api.setup(0)
+        api.force_filter_parts(2)            # same window-row split as the single-process run
+        L = sharding.BlockLayout(rank, world, BW, BH, RADIUS)
+        ox, oy = L.origin
+        smp = {k: v[:, oy:oy + BH, ox:ox + BW].contiguous().to(dev) for k, v in _film_samples(world).items()}
+        pipe = pipeline.BlockPipeline(L, dev, TYPES, radius=RADIUS, via_host=True)
+        pipe.accumulate(smp)
+        out = pipe.denoise().clone()
+        torch.cuda.synchronize()
+        q.put((rank, ox, oy, out.cpu().numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_blocks_equal_whole_film(gpu, world):
+    from statmc_amd import pipeline, sharding
+    dev = torch.device("cuda:0")
+    gx, gy = sharding.grid_for(world)
+    whole = _film_samples(world)
+    gpu.force_filter_parts(2)
+    try:
+        one = pipeline.BlockPipeline(sharding.BlockLayout(0, 1, gx * BW, gy * BH, RADIUS), dev, TYPES, radius=RADIUS)
+        one.accumulate({k: v.to(dev) for k, v in whole.items()})
+        ref = one.denoise().cpu().numpy()
+    finally:
+        gpu.force_filter_parts(0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, q)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(g[0] for g in got) == list(range(world))
+    for rank, ox, oy, blk in got:
+        assert np.array_equal(blk, ref[oy:oy + BH, ox:ox + BW]), rank     # bit-identical
