@@ -1,6 +1,6 @@
 """Scratch: do accumulate (HBM-bound) and window filter (VALU-bound) overlap on two streams?"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from statmc_amd import api, film, synthetic
 dev = torch.device("cuda:0"); api.setup(0)

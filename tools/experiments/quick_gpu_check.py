@@ -1,6 +1,6 @@
 """First-contact GPU check: small parity vs the oracle + 1080p timings. Scratch tool."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from statmc_amd import api, film, synthetic

@@ -1,6 +1,6 @@
 """Scratch: per-type accumulate bandwidth at 1080p."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from statmc_amd import api, film, synthetic
 dev = torch.device("cuda:0"); api.setup(0)

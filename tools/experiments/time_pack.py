@@ -1,6 +1,6 @@
 """Scratch: cost of the pack / unpack copies around the halo exchange (no communication)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from statmc_amd import api, pipeline, sharding
 dev = torch.device("cuda:0"); api.setup(0)
