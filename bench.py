@@ -68,6 +68,7 @@ def cpu_baseline(args, fs, samples, types, budget_s=7.0):
     """Times the CPU oracle (the restated reference algorithm, OpenMP over tiles / rows, all host
     cores) on a bounded sample of the same workload: each leg is sized from a short probe so that
     it does about `budget_s` seconds of work.  Reported, never used by the GPU path."""
+    import numpy as np
     from oracle import oracle
     from statmc_amd.film import STAT_TYPES
     W, H, S = args.width, args.height, args.spp
@@ -116,6 +117,19 @@ def cpu_baseline(args, fs, samples, types, budget_s=7.0):
         flt_reps += 1
     flt_s_per_px = t_flt / (flt_reps * fr * W)
     s_per_px = acc_s_per_px + t_pre / (W * H) + flt_s_per_px
+
+    # ---- the same two legs on ONE thread (small strips), for the single-core figure
+    ar1 = min(2, ar)
+    t0 = time.perf_counter()
+    for t in types:
+        st = oracle.new_state(ar1, W, STAT_TYPES[t]["channels"])
+        oracle.accumulate(st, np.ascontiguousarray(host[t][:, :ar1]), STAT_TYPES[t]["transform"], STAT_TYPES[t]["max_moment"],
+                          threads=1)
+    acc1 = (time.perf_counter() - t0) / (ar1 * W)
+    fy1 = H // 2
+    t0 = time.perf_counter()
+    oracle.filter_image(mc, dc, rad["film_mean"], gb, g_dr, ds, args.radius, roi=(0, fy1, W, fy1 + 2), threads=1)
+    flt1 = (time.perf_counter() - t0) / (2 * W)
     return {
         "value": round(1e-6 / s_per_px, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
         "sample": "oracle (C restatement of the reference algorithm, OpenMP, %d threads): accumulate %d rows x %d px "
@@ -125,7 +139,46 @@ def cpu_baseline(args, fs, samples, types, budget_s=7.0):
                      2 * args.radius + 1, flt_reps, t_flt),
         "accumulate_s_per_mpx": round(acc_s_per_px * 1e6, 4),
         "filter_s_per_mpx": round(flt_s_per_px * 1e6, 4),
+        "single_thread": {"value": round(1e-6 / (acc1 + t_pre / (W * H) + flt1), 5), "unit": "Mpixels/s", "cores": 1,
+                          "sample": "accumulate %d rows, filter 2 rows, one thread" % ar1},
     }
+
+
+def host_copy_times(fs, dev):
+    """What the reference's `CUDA time` bracket adds when statistics are produced on the host
+    (statpath.cpp:409-417): Upload() of the 7 filter inputs (76 B/px) and Download() of film-f
+    (12 B/px), pinned host memory, through statmc_upload / statmc_download.  Never part of `value`."""
+    import ctypes as C
+    from statmc_amd import api
+    lib = api.load()
+    rad = fs.state["radiance"]
+    ups = [rad["film_mean"], rad["n"], rad["mean"], rad["m2"], rad["m3"], fs.g_buffer("normal"), fs.g_buffer("albedo")]
+    host_up = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in ups]
+    host_dn = torch.empty(fs.film_f.shape, dtype=torch.float32).pin_memory()
+    stream = api.current_stream_handle()
+
+    def upload():
+        for h, d in zip(host_up, ups):
+            api.check(lib.statmc_upload(C.c_void_p(d.data_ptr()), C.c_void_p(h.data_ptr()), h.numel() * 4, stream))
+
+    def download():
+        api.check(lib.statmc_download(C.c_void_p(host_dn.data_ptr()), C.c_void_p(fs.film_f.data_ptr()), host_dn.numel() * 4, stream))
+
+    out = {}
+    for name, fn, nbytes in (("upload", upload, sum(h.numel() * 4 for h in host_up)), ("download", download, host_dn.numel() * 4)):
+        for h in host_up:
+            h.zero_()
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        out[name + "_ms"] = round(ms, 3)
+        out[name + "_GBs"] = round(nbytes / ms / 1e6, 1)
+        out[name + "_bytes_per_px"] = nbytes // (fs.width * fs.height)
+    return out
 
 
 def main():
@@ -280,6 +333,8 @@ def main():
                 "filter": {"avg_ms": round(ms["filter"], 4), "mpixels_per_s": round(px_block / ms["filter"] / 1e3, 2)},
             },
         }
+        if world == 1:
+            result["host_copies"] = host_copy_times(fs, dev)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, fs, samples, types)
     if world > 1:

@@ -489,3 +489,28 @@ def test_filter_argument_errors(gpu):
     with pytest.raises(gpu.StatmcError) as e:
         gpu.window_filter(a, 3)
     assert e.value.code == gpu.ERR_UNSUPPORTED
+
+
+def test_device_memory_and_streams_roundtrip(gpu):
+    """statmc_malloc / upload / download / memset / stream_create / synchronize: the GpuMat +
+    cv::cuda::Stream roles of Buffer (buffer.h:25,57-63; estimator.h:326)."""
+    lib = gpu.load()
+    host = np.arange(1000, dtype=np.float32)
+    back = np.zeros_like(host)
+    dptr, stream = C.c_void_p(), C.c_void_p()
+    gpu.check(lib.statmc_malloc(C.byref(dptr), host.nbytes))
+    gpu.check(lib.statmc_stream_create(C.byref(stream)))
+    try:
+        gpu.check(lib.statmc_upload(dptr, host.ctypes.data, host.nbytes, stream))
+        gpu.check(lib.statmc_download(back.ctypes.data, dptr, host.nbytes, stream))
+        gpu.check(lib.statmc_synchronize(stream))
+        assert np.array_equal(back, host)
+        gpu.check(lib.statmc_memset(dptr, 0, host.nbytes, stream))
+        gpu.check(lib.statmc_download(back.ctypes.data, dptr, host.nbytes, stream))
+        gpu.check(lib.statmc_synchronize(stream))
+        assert not back.any()
+    finally:
+        gpu.check(lib.statmc_stream_destroy(stream))
+        gpu.check(lib.statmc_free(dptr))
+    assert lib.statmc_malloc(None, 16) == gpu.ERR_INVALID
+    assert lib.statmc_setup(99) == gpu.ERR_INVALID and b"out of range" in lib.statmc_last_error()
