@@ -201,48 +201,72 @@ __device__ __forceinline__ float tab_at(float tabv, int idx) {
 // RGB = true: filter<float3> -- one buffer, membership is the AND over its three channels.
 // RGB = false: filter<float> -- the three "channels" are three independent 1-channel buffers
 // (ACRR bounces / SMIS win rates) that share the range weight but gate and normalise separately.
+// Written stage by stage ACROSS the half group's 8 (tap, pixel) pairs: every stage is 8 independent instructions,
+// so a wave always has independent work to issue between the dependent steps of one (tap, pixel)
+// pair (sub -> mul -> fma -> fma -> add -> add -> exp -> select -> fma).  With only two waves
+// per SIMD the dependent-issue latency of a pair-by-pair stream is not hidden by other waves.
 template <int H, unsigned MASK, bool RGB>
 __device__ __forceinline__ void compute_half(LaneState &st, const HalfChunk &c, float tabv, int j) {
+    // e = 2 * ii + ... : the 2 taps x 4 pixels of the half group form 8 independent pair evaluations
+    constexpr int NE = 2 * kPx;
+    auto tap = [](int e) { return e / kPx; };   // ii
+    auto pix = [](int e) { return e % kPx; };   // k
+    auto on = [&](int e) { return (MASK & (1u << ((2 * H + tap(e)) * 4 + pix(e)))) != 0; };
+    v2f q[2][6];  // per tap: channel pairs = low or high half of the b128
 #pragma unroll
-    for (int ii = 0; ii < 2; ii++) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int i = 2 * H + ii;
-        v2f q[6];  // tap i's channel pairs: low or high half of the b128
+    for (int k = 0; k < 6; k++) {
+        q[0][k] = v2f{c.qp[k].x, c.qp[k].y};
+        q[1][k] = v2f{c.qp[k].z, c.qp[k].w};
+    }
+    v2f e2[NE], t01[NE];
+    float w[NE], t2[NE];
+    // range weight: exp2(tab - |k_n dn|^2 - |k_a da|^2), two channels per instruction
 #pragma unroll
-        for (int k = 0; k < 6; k++) q[k] = ii ? v2f{c.qp[k].z, c.qp[k].w} : v2f{c.qp[k].x, c.qp[k].y};
-        const float q_mc2 = c.qs[S_MC2][ii], q_nd2 = c.qs[S_ND2][ii], q_col2 = c.qs[S_COL2][ii];
+    for (int e = 0; e < NE; e++) if (on(e)) { const v2f d = st.pg[0][pix(e)] - q[tap(e)][K_G01]; e2[e] = -d * d; }
 #pragma unroll
-        for (int k = 0; k < kPx; k++) {
-            if (!(MASK & (1u << (i * 4 + k)))) continue;
-            const float tab = tab_at(tabv, 4 * j + i - k + 3);
-            // range weight: exp2(tab - |k_n dn|^2 - |k_a da|^2), two channels per instruction
-            v2f d = st.pg[0][k] - q[K_G01];
-            v2f e2 = -d * d;
-            d = st.pg[1][k] - q[K_G2A0];
-            e2 = __builtin_elementwise_fma(-d, d, e2);
-            d = st.pg[2][k] - q[K_A12];
-            e2 = __builtin_elementwise_fma(-d, d, e2);
-            float w = __builtin_amdgcn_exp2f((e2.x + tab) + e2.y);
-            // membership: fma(d, d, -D_q) <= D_p in every channel (bit-identical to the oracle)
-            d = st.pmc01[k] - q[K_MC01];
-            const v2f t01 = __builtin_elementwise_fma(d, d, q[K_ND01]);
-            const float db = st.pmc2[k] - q_mc2;
-            const float t2 = __builtin_fmaf(db, db, q_nd2);
-            if constexpr (RGB) {
-                const bool member = (t01.x <= st.pd01[k].x) & (t01.y <= st.pd01[k].y) & (t2 <= st.pd2[k]);
-                w = member ? w : 0.f;
-                st.sw[k] += w;
-                st.acc01[k] = __builtin_elementwise_fma(v2f{w, w}, q[K_COL01], st.acc01[k]);
-                st.acc2[k] = __builtin_fmaf(w, q_col2, st.acc2[k]);
-            } else {
-                const v2f w01 = v2f{t01.x <= st.pd01[k].x ? w : 0.f, t01.y <= st.pd01[k].y ? w : 0.f};
-                const float w2 = t2 <= st.pd2[k] ? w : 0.f;
-                st.sw01[k] += w01;
-                st.sw2[k] += w2;
-                st.acc01[k] = __builtin_elementwise_fma(w01, q[K_COL01], st.acc01[k]);
-                st.acc2[k] = __builtin_fmaf(w2, q_col2, st.acc2[k]);
-            }
+    for (int e = 0; e < NE; e++) if (on(e)) { const v2f d = st.pg[1][pix(e)] - q[tap(e)][K_G2A0]; e2[e] = __builtin_elementwise_fma(-d, d, e2[e]); }
+#pragma unroll
+    for (int e = 0; e < NE; e++) if (on(e)) { const v2f d = st.pg[2][pix(e)] - q[tap(e)][K_A12]; e2[e] = __builtin_elementwise_fma(-d, d, e2[e]); }
+#pragma unroll
+    for (int e = 0; e < NE; e++) if (on(e)) w[e] = (e2[e].x + tab_at(tabv, 4 * j + 2 * H + tap(e) - pix(e) + 3)) + e2[e].y;
+    // membership: fma(d, d, -D_q) <= D_p in every channel (bit-identical to the oracle)
+#pragma unroll
+    for (int e = 0; e < NE; e++) if (on(e)) { const v2f d = st.pmc01[pix(e)] - q[tap(e)][K_MC01]; t01[e] = __builtin_elementwise_fma(d, d, q[tap(e)][K_ND01]); }
+#pragma unroll
+    for (int e = 0; e < NE; e++) if (on(e)) { const float db = st.pmc2[pix(e)] - c.qs[S_MC2][tap(e)]; t2[e] = __builtin_fmaf(db, db, c.qs[S_ND2][tap(e)]); }
+#pragma unroll
+    for (int e = 0; e < NE; e++) if (on(e)) w[e] = __builtin_amdgcn_exp2f(w[e]);
+    if constexpr (RGB) {
+        // all three channels pass  <=>  max_c (t_c - D_p,c) <= 0.  (t - D <= 0) has exactly the truth
+        // value of the oracle's (t <= D); one max3 + one compare + one select stays on the VALU, where
+        // (3 compares, 2 scalar ANDs, select) serialises every pair through the scalar unit
+        // (VALU -> SGPR -> SALU -> VCC -> VALU).  v_max3 drops NaN operands, so a pixel with a NaN
+        // statistic is staged with NaN in all three channels (store_pixel).
+#pragma unroll
+        for (int e = 0; e < NE; e++) if (on(e)) { t01[e] = t01[e] - st.pd01[pix(e)]; t2[e] = t2[e] - st.pd2[pix(e)]; }
+#pragma unroll
+        for (int e = 0; e < NE; e++) if (on(e)) {
+            const float m = __builtin_fmaxf(__builtin_fmaxf(t01[e].x, t01[e].y), t2[e]);
+            w[e] = m <= 0.f ? w[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < NE; e++) if (on(e)) {
+            const int k = pix(e);
+            st.sw[k] += w[e];
+            st.acc01[k] = __builtin_elementwise_fma(v2f{w[e], w[e]}, q[tap(e)][K_COL01], st.acc01[k]);
+            st.acc2[k] = __builtin_fmaf(w[e], c.qs[S_COL2][tap(e)], st.acc2[k]);
+        }
+    } else {
+        // filter<float>: the three "channels" are independent buffers with their own gate and weight sum
+#pragma unroll
+        for (int e = 0; e < NE; e++) if (on(e)) {
+            const int k = pix(e);
+            const v2f w01 = v2f{t01[e].x <= st.pd01[k].x ? w[e] : 0.f, t01[e].y <= st.pd01[k].y ? w[e] : 0.f};
+            const float w2 = t2[e] <= st.pd2[k] ? w[e] : 0.f;
+            st.sw01[k] += w01;
+            st.sw2[k] += w2;
+            st.acc01[k] = __builtin_elementwise_fma(w01, q[tap(e)][K_COL01], st.acc01[k]);
+            st.acc2[k] = __builtin_fmaf(w2, c.qs[S_COL2][tap(e)], st.acc2[k]);
         }
     }
 }
@@ -252,36 +276,110 @@ __device__ __forceinline__ void compute_half(LaneState &st, const HalfChunk &c, 
 // SIMD already covers the LDS latency), so a single set is used: 164 VGPRs.
 // RT > 0 (compile-time radius, a multiple of 4): the first and last read groups hold
 // (tap, pixel) pairs outside the window and get their static masks; every group between is full.
-template <int RT, bool RGB>
+// ABL (diagnostic builds only, never dispatched by the ABI): 1 = no LDS reads in the sweep (one
+// operand set reused; times the pure VALU work), 2 = LDS reads but one token VALU op per read group
+// (times the operand feed), 0 = the real kernel.
+template <int RT, bool RGB, int ABL = 0>
 __device__ __forceinline__ void eval_row(LaneState &st, const float *row, int pitch, float tabv, int n_chunks) {
     HalfChunk A;
     constexpr unsigned kFull = 0xFFFFu;
-    if constexpr (RT > 0) {
+    if constexpr (ABL == 1) {
+        constexpr int n = 2 * round_up4(RT) / 4 + 1;
+        load_half<0>(A, row, pitch, 0);
+#pragma unroll 1
+        for (int j = 0; j < n; j++) {
+            // keep the whole operand set opaque per iteration (nothing may be hoisted out of the loop)
+            asm volatile("" : "+v"(A.qp[0]), "+v"(A.qp[1]), "+v"(A.qp[2]), "+v"(A.qp[3]), "+v"(A.qp[4]), "+v"(A.qp[5]),
+                              "+v"(A.qs[0]), "+v"(A.qs[1]), "+v"(A.qs[2]));
+            compute_half<0, kFull, RGB>(st, A, tabv, j);
+            compute_half<1, kFull, RGB>(st, A, tabv, j);
+        }
+    } else if constexpr (ABL == 4) {
+        // VALU work on a fixed operand set + the real LDS reads into a second set nobody computes on
+        constexpr int n = 2 * round_up4(RT) / 4 + 1;
+        HalfChunk B;
+        load_half<0>(A, row, pitch, 0);
+#pragma unroll 1
+        for (int j = 0; j < n; j++) {
+            asm volatile("" : "+v"(A.qp[0]), "+v"(A.qp[1]), "+v"(A.qp[2]), "+v"(A.qp[3]), "+v"(A.qp[4]), "+v"(A.qp[5]),
+                              "+v"(A.qs[0]), "+v"(A.qs[1]), "+v"(A.qs[2]));
+            load_half<1>(B, row, pitch, j);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_half<0, kFull, RGB>(st, A, tabv, j);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" :: "v"(B.qp[0]), "v"(B.qp[1]), "v"(B.qp[2]), "v"(B.qp[3]), "v"(B.qp[4]), "v"(B.qp[5]),
+                              "v"(B.qs[0]), "v"(B.qs[1]), "v"(B.qs[2]));
+            load_half<0>(B, row, pitch, j);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_half<1, kFull, RGB>(st, A, tabv, j);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" :: "v"(B.qp[0]), "v"(B.qp[1]), "v"(B.qp[2]), "v"(B.qp[3]), "v"(B.qp[4]), "v"(B.qp[5]),
+                              "v"(B.qs[0]), "v"(B.qs[1]), "v"(B.qs[2]));
+        }
+    } else if constexpr (ABL == 3) {
+        st.sw[0] += row[0];  // nothing but the row staging, barriers and prologue
+    } else if constexpr (ABL == 2) {
+        constexpr int n = 2 * round_up4(RT) / 4 + 1;
+#pragma unroll 1
+        for (int j = 0; j < n; j++) {
+            load_half<0>(A, row, pitch, j);
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 6; k++) t += A.qp[k].x + A.qp[k].w;
+            st.sw[0] += t + A.qs[0].x + A.qs[1].y + A.qs[2].x;
+            load_half<1>(A, row, pitch, j);
+            t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 6; k++) t += A.qp[k].y + A.qp[k].z;
+            st.sw[1] += t + A.qs[0].y + A.qs[1].x + A.qs[2].y;
+        }
+    } else if constexpr (RT > 0) {
+        // Software-pipelined: operand sets A (taps 0,1) and B (taps 2,3) alternate; the LDS reads
+        // of the set evaluated NEXT are issued before the current set's VALU work and pinned there
+        // with sched_barrier, so their latency is covered by ~270 VALU instructions and the wait in
+        // front of each compute phase is a counted lgkmcnt(9) that never stalls.  Without this the
+        // read latency is exposed in every half group (ablation: 2.85 ms vs 1.93 ms VALU-only).
         constexpr int n = 2 * round_up4(RT) / 4 + 1;
         static_assert(RT % 4 == 0 && n >= 3, "static variant: radius multiple of 4");
         static_assert(ChunkMask<1, RT>::value() == kFull && ChunkMask<n - 2, RT>::value() == kFull, "");
+        HalfChunk B;
         load_half<0>(A, row, pitch, 0);
+        load_half<1>(B, row, pitch, 0);
+        __builtin_amdgcn_sched_barrier(0);
         compute_half<0, ChunkMask<0, RT>::value(), RGB>(st, A, tabv, 0);
-        load_half<1>(A, row, pitch, 0);
-        compute_half<1, ChunkMask<0, RT>::value(), RGB>(st, A, tabv, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_half<0>(A, row, pitch, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_half<1, ChunkMask<0, RT>::value(), RGB>(st, B, tabv, 0);
 #pragma unroll 1
         for (int j = 1; j < n - 1; j++) {
-            load_half<0>(A, row, pitch, j);
+            __builtin_amdgcn_sched_barrier(0);
+            load_half<1>(B, row, pitch, j);
+            __builtin_amdgcn_sched_barrier(0);
             compute_half<0, kFull, RGB>(st, A, tabv, j);
-            load_half<1>(A, row, pitch, j);
-            compute_half<1, kFull, RGB>(st, A, tabv, j);
+            __builtin_amdgcn_sched_barrier(0);
+            load_half<0>(A, row, pitch, j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_half<1, kFull, RGB>(st, B, tabv, j);
         }
-        load_half<0>(A, row, pitch, n - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_half<1>(B, row, pitch, n - 1);
+        __builtin_amdgcn_sched_barrier(0);
         compute_half<0, ChunkMask<n - 1, RT>::value(), RGB>(st, A, tabv, n - 1);
-        load_half<1>(A, row, pitch, n - 1);
-        compute_half<1, ChunkMask<n - 1, RT>::value(), RGB>(st, A, tabv, n - 1);
+        compute_half<1, ChunkMask<n - 1, RT>::value(), RGB>(st, B, tabv, n - 1);
     } else {
+        HalfChunk B;
+        load_half<0>(A, row, pitch, 0);
 #pragma unroll 1
         for (int j = 0; j < n_chunks; j++) {
-            load_half<0>(A, row, pitch, j);
+            __builtin_amdgcn_sched_barrier(0);
+            load_half<1>(B, row, pitch, j);
+            __builtin_amdgcn_sched_barrier(0);
             compute_half<0, kFull, RGB>(st, A, tabv, j);
-            load_half<1>(A, row, pitch, j);
-            compute_half<1, kFull, RGB>(st, A, tabv, j);
+            __builtin_amdgcn_sched_barrier(0);
+            load_half<0>(A, row, pitch, j + 1 < n_chunks ? j + 1 : j);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_half<1, kFull, RGB>(st, B, tabv, j);
         }
     }
 }
@@ -313,14 +411,17 @@ __device__ __forceinline__ StagedPixel load_pixel(const FilterArgs &a, int x, in
     return s;
 }
 
-__device__ __forceinline__ void store_pixel(float *slot, int pitch, int i, const StagedPixel &s, float k0, float k1) {
+__device__ __forceinline__ void store_pixel(float *slot, int pitch, int i, const StagedPixel &s, float k0, float k1,
+                                            bool canon) {
     // taps outside the image get a NaN corrected mean: they fail every membership comparison
     const float nan = __builtin_nanf("");
     const int pofs = ((i & 3) >> 1) * pitch + (i >> 2) * 4 + (i & 1) * 2;  // within a pair plane
     auto pair = [&](int k, float c0, float c1) {
         *reinterpret_cast<v2f *>(slot + 2 * k * pitch + pofs) = v2f{c0, c1};
     };
-    const bool v = s.valid;
+    // RGB: a NaN in any statistic of the pixel -> NaN in every channel of its mean (the gate uses max3)
+    const bool v = s.valid && (!canon || (s.mc.x == s.mc.x && s.mc.y == s.mc.y && s.mc.z == s.mc.z &&
+                                         s.d.x == s.d.x && s.d.y == s.d.y && s.d.z == s.d.z));
     pair(K_G01, v ? s.g0.x * k0 : 0.f, v ? s.g0.y * k0 : 0.f);
     pair(K_G2A0, v ? s.g0.z * k0 : 0.f, v ? s.g1.x * k1 : 0.f);
     pair(K_A12, v ? s.g1.y * k1 : 0.f, v ? s.g1.z * k1 : 0.f);
@@ -334,7 +435,7 @@ __device__ __forceinline__ void store_pixel(float *slot, int pitch, int i, const
 
 // RT > 0: compile-time radius (window edges resolved statically); RT == 0: runtime radius
 // a.radius <= 20, every pair of every read group evaluated, the table masks taps beyond r.
-template <int RT, bool RGB>
+template <int RT, bool RGB, int ABL = 0>
 __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int r = RT > 0 ? RT : a.radius;
@@ -381,6 +482,10 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
             mc = f3{a.f_mean_corr[0][p], a.f_mean_corr[1][p], a.f_mean_corr[2][p]};
             d = f3{a.f_disc[0][p], a.f_disc[1][p], a.f_disc[2][p]};
         }
+        if constexpr (RGB) {  // same NaN canonicalisation as store_pixel: the gate is a max3
+            if (!(mc.x == mc.x && mc.y == mc.y && mc.z == mc.z && d.x == d.x && d.y == d.y && d.z == d.z))
+                mc.x = mc.y = mc.z = __builtin_nanf("");
+        }
         const f3 g0 = reinterpret_cast<const f3 *>(a.g[0].data)[p];
         const f3 g1 = reinterpret_cast<const f3 *>(a.g[1].data)[p];
         st.pg[0][k] = v2f{g0.x * k0, g0.y * k0};
@@ -401,7 +506,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
     for (int idx = threadIdx.x; idx < kTileH * pitch; idx += kThreads) {
         const int rel = idx / pitch, i = idx - rel * pitch;
         const StagedPixel s = load_pixel<RGB>(a, x0 - rp + i, y0 - r + s0 + rel);
-        store_pixel(lds + rel * slot_floats, pitch, i, s, k0, k1);
+        store_pixel(lds + rel * slot_floats, pitch, i, s, k0, k1, RGB);
     }
     __syncthreads();
     // spatial exponents of window row s0, one per lane (tw <= 47 < 64)
@@ -422,10 +527,16 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
         if (step + 1 < s1 && lane < tw) tab_next = a.spatial_tab[(step + 1) * tw + lane];
 
         const float *row = lds + slot * slot_floats + kPx * lane;
-        eval_row<RT, RGB>(st, row, pitch, tabv, n_chunks);
+        // Waves w and w+4 share a SIMD and run the same instruction stream: released together by the
+        // barrier they would read LDS together and then contend for the VALU together.  Holding the
+        // second half back for a fraction of a read group makes one wave's LDS wait fall into the
+        // other's compute phase.
+        if (wave >= 4)
+            for (int i = 0; i < a.stagger; i++) __builtin_amdgcn_s_sleep(1);  // 64 cycles each
+        eval_row<RT, RGB, ABL>(st, row, pitch, tabv, n_chunks);
         tabv = tab_next;
 
-        if (stage) store_pixel(lds + fill * slot_floats, pitch, threadIdx.x, nxt, k0, k1);
+        if (stage) store_pixel(lds + fill * slot_floats, pitch, threadIdx.x, nxt, k0, k1, RGB);
         __syncthreads();
         slot = slot + 1 == kSlots ? 0 : slot + 1;
         fill = fill + 1 == kSlots ? 0 : fill + 1;
@@ -538,23 +649,28 @@ int choose_parts(int tiles, int n_rows, int n_cus) {
 }
 
 static int g_parts_override = 0;
+static int g_ablation = 0;
+static int g_stagger = 0;
+void set_filter_stagger(int v) { g_stagger = v; }
+void set_filter_ablation(int v) { g_ablation = v; }
 void set_filter_parts_override(int k) { g_parts_override = k; }
 
-template <int RT, bool RGB>
+template <int RT, bool RGB, int ABL = 0>
 static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
     const int rp = RT > 0 ? round_up4(RT) : round_up4(a.radius);
     const size_t lds_bytes = (size_t)kSlots * kCh * (kTileW + 2 * rp) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&window_filter_lds<RT, RGB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&window_filter_lds<RT, RGB, ABL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const dim3 tiles((a.rx1 - a.rx0 + kTileW - 1) / kTileW, (a.ry1 - a.ry0 + kTileH - 1) / kTileH);
     if (a.partial == nullptr) a.n_parts = 1;
+    a.stagger = g_stagger;
     const dim3 grid(tiles.x * tiles.y * a.n_parts);
-    hipLaunchKernelGGL((window_filter_lds<RT, RGB>), grid, dim3(kThreads), lds_bytes, s, a);
+    hipLaunchKernelGGL((window_filter_lds<RT, RGB, ABL>), grid, dim3(kThreads), lds_bytes, s, a);
     if (a.n_parts > 1) {
         const dim3 cgrid((a.rx1 - a.rx0 + 63) / 64, (a.ry1 - a.ry0 + 3) / 4);
         hipLaunchKernelGGL(combine_parts_kernel<RGB>, cgrid, dim3(256), 0, s, a);
@@ -580,6 +696,10 @@ hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s
         const bool rgb = channels == 3;
         if (a.radius == 20 && g_variant_override != 2) {
             *variant = rgb ? "lds_r20" : "lds_r20_f";
+            if (rgb && g_ablation == 1) { *variant = "lds_r20_ablate_no_lds"; return launch_lds<20, true, 1>(a, s); }
+            if (rgb && g_ablation == 2) { *variant = "lds_r20_ablate_no_valu"; return launch_lds<20, true, 2>(a, s); }
+            if (rgb && g_ablation == 4) { *variant = "lds_r20_ablate_dead_lds_reads"; return launch_lds<20, true, 4>(a, s); }
+            if (rgb && g_ablation == 3) { *variant = "lds_r20_ablate_staging_only"; return launch_lds<20, true, 3>(a, s); }
             return rgb ? launch_lds<20, true>(a, s) : launch_lds<20, false>(a, s);
         }
         *variant = rgb ? "lds_rt" : "lds_rt_f";
