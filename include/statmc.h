@@ -96,6 +96,13 @@ typedef struct statmc_filter_args {
      * written for x in [roi_x0, roi_x1), y in [roi_y0, roi_y1) only; the window is still
      * clipped to the full [0,width) x [0,height) local image. */
     int32_t roi_x0, roi_y0, roi_x1, roi_y1;
+    /* Packed filter inputs (multi-GPU block path; data == NULL = not used).  A [height][width][15]
+     * fp32 image holding, per pixel, mean_corr.rgb, discriminator.rgb, colour.rgb, g_buffers[0].rgb,
+     * g_buffers[1].rgb -- the layout the halo exchange moves as one message.  When set,
+     * statmc_window_filter (T = float3, two 3-channel G-buffers, radius <= 20, n_buffers = 1) reads
+     * its inputs from it and ignores mean_corr / discriminator / film / g_buffers.
+     * statmc_pack_filter_inputs fills the owned block of such an image. */
+    statmc_image packed_inputs;
 } statmc_filter_args;
 
 /* Replace cv::cuda::stat_denoiser::filter<float> / filter<float3>: pre-pass + window filter. */
@@ -106,6 +113,12 @@ int statmc_filter_f32x3(const statmc_filter_args *args);
  * them; the bench times them separately).  channels = 1 or 3 selects T. */
 int statmc_prepass(const statmc_filter_args *args, int channels);     /* -> mean_corr, discriminator */
 int statmc_window_filter(const statmc_filter_args *args, int channels); /* mean_corr, discriminator -> filtered */
+
+/* Copies the five window-filter inputs of buffer 0 (mean_corr[0], discriminator[0], the colour
+ * image -- film_buffer if denoise_film, else film[0] --, g_buffers[0], g_buffers[1]; all
+ * width x height x 3) into the 15-channel image `packed` at pixel offset (dst_x0, dst_y0): the
+ * owned block inside a block + halo image.  One pass, 60 B read + 60 B written per pixel. */
+int statmc_pack_filter_inputs(const statmc_filter_args *args, const statmc_image *packed, int dst_x0, int dst_y0);
 
 /* Replaces cv::cuda::stat_denoiser::calculateMeanVars<T> (commented-out call,
  * src/statistics/estimator.cpp:501-521) and its CPU stand-in (estimator.cpp:524-568):

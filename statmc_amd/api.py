@@ -36,6 +36,7 @@ class FilterArgs(C.Structure):
         ("film_filtered", C.POINTER(Image)), ("film_filtered_buffer", Image),
         ("stream", C.c_void_p),
         ("roi_x0", C.c_int32), ("roi_y0", C.c_int32), ("roi_x1", C.c_int32), ("roi_y1", C.c_int32),
+        ("packed_inputs", Image),
     ]
 
 
@@ -52,7 +53,7 @@ EXPORTS = [
     "statmc_last_error", "statmc_setup", "statmc_set_significance", "statmc_get_significance",
     "statmc_malloc", "statmc_free", "statmc_memset", "statmc_upload", "statmc_download",
     "statmc_stream_create", "statmc_stream_destroy", "statmc_synchronize",
-    "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter",
+    "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs",
     "statmc_calculate_mean_vars", "statmc_accumulate", "statmc_merge_tiles", "statmc_tile_moments",
     "statmc_last_filter_variant", "statmc_version",
 ]
@@ -90,6 +91,7 @@ def load():
     lib.statmc_filter_f32x3.argtypes = [C.POINTER(FilterArgs)]
     lib.statmc_prepass.argtypes = [C.POINTER(FilterArgs), C.c_int]
     lib.statmc_window_filter.argtypes = [C.POINTER(FilterArgs), C.c_int]
+    lib.statmc_pack_filter_inputs.argtypes = [C.POINTER(FilterArgs), C.POINTER(Image), C.c_int, C.c_int]
     lib.statmc_calculate_mean_vars.argtypes = [C.c_uint8, C.c_uint16, C.c_uint16, C.c_int,
                                                C.POINTER(Image), C.POINTER(Image), C.POINTER(Image),
                                                C.c_int, C.c_void_p]
@@ -167,11 +169,13 @@ def _img_array(tensors):
 
 def make_filter_args(n, mean, m2, m3, film, mean_corr, disc, film_filtered, g_buffers, g_sds=None,
                      g_dr=None, filter_sd=10.0, radius=20, denoise_film=False, film_buffer=None,
-                     film_filtered_buffer=None, roi=None, stream=None, keep=None):
+                     film_filtered_buffer=None, roi=None, stream=None, keep=None, packed=None):
     """Build a statmc_filter_args from lists of per-buffer device tensors (reference argument
-    order, estimator.cpp:437-459).  Returns (args, keepalive)."""
-    nb = len(mean_corr)
-    h, w = mean_corr[0].shape[0], mean_corr[0].shape[1]
+    order, estimator.cpp:437-459).  Returns (args, keepalive).  packed: optional [H, W, 15]
+    block + halo tensor the window filter reads instead of the separate images."""
+    nb = len(mean_corr) if packed is None else 1
+    ref = mean_corr[0] if packed is None else packed
+    h, w = ref.shape[0], ref.shape[1]
     a = FilterArgs()
     ka = []
     a.n_buffers, a.width, a.height = nb, w, h
@@ -198,11 +202,18 @@ def make_filter_args(n, mean, m2, m3, film, mean_corr, disc, film_filtered, g_bu
         ka += [garr, gch, gdr]
         a.g_buffers, a.g_channel_counts, a.g_dr_factors = garr, gch, gdr
     a.n_g_buffers = ng
+    if packed is not None:
+        a.packed_inputs = Image(C.c_void_p(packed.data_ptr()), w * 15 * 4, w, h)
+        if g_dr is None:
+            g_dr = [-0.5 / (sd * sd) for sd in g_sds]
+        gdr = (C.c_float * 2)(*g_dr)
+        ka.append(gdr)
+        a.g_dr_factors, a.n_g_buffers = gdr, 2
     a.stream = stream if stream is not None else current_stream_handle()
     if roi is not None:
         a.roi_x0, a.roi_y0, a.roi_x1, a.roi_y1 = roi
     ka.append((n, mean, m2, m3, film, mean_corr, disc, film_filtered, g_buffers, film_buffer,
-               film_filtered_buffer))
+               film_filtered_buffer, packed))
     return a, ka
 
 
@@ -212,6 +223,12 @@ def prepass(args, channels):
 
 def window_filter(args, channels):
     check(load().statmc_window_filter(C.byref(args), channels))
+
+
+def pack_filter_inputs(args, packed, dst_x0, dst_y0):
+    """Owned block of the five filter inputs -> [Hp, Wp, 15] block + halo tensor at (dst_x0, dst_y0)."""
+    img = image_of(packed)
+    check(load().statmc_pack_filter_inputs(C.byref(args), C.byref(img), dst_x0, dst_y0))
 
 
 def filter_f32x3(args):

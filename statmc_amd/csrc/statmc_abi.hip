@@ -247,9 +247,12 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
     NEED_READY();
     if (int rc = check_common(a, channels)) return rc;
     const int W = a->width, H = a->height;
-    if (a->n_buffers && (!a->mean_corr || !a->discriminator)) return fail(STATMC_ERR_INVALID, "null buffer table");
-    if (a->n_g_buffers && (!a->g_buffers || !a->g_channel_counts || !a->g_dr_factors))
-        return fail(STATMC_ERR_INVALID, "null G-buffer table");
+    const bool packed_in = a->packed_inputs.data != nullptr;
+    if (!packed_in) {
+        if (a->n_buffers && (!a->mean_corr || !a->discriminator)) return fail(STATMC_ERR_INVALID, "null buffer table");
+        if (a->n_g_buffers && (!a->g_buffers || !a->g_channel_counts || !a->g_dr_factors))
+            return fail(STATMC_ERR_INVALID, "null G-buffer table");
+    }
 
     statmc::FilterArgs k;
     memset(&k, 0, sizeof(k));
@@ -265,6 +268,35 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
     k.radius = a->filter_radius;
     k.ds = a->filter_ds_factor;
     k.n_g = (int)a->n_g_buffers;
+    const bool packed = a->packed_inputs.data != nullptr;
+    if (packed) {
+        // block + halo path: everything the window filter reads comes from one 15-channel image
+        if (channels != 3 || a->n_buffers != 1 || a->n_g_buffers != 2 || !a->g_dr_factors)
+            return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs: needs T = float3, n_buffers = 1, two G-buffers");
+        CHECK_IMG(a->packed_inputs, 15, "packed_inputs", 0);
+        if (!a->film_filtered) return fail(STATMC_ERR_INVALID, "null film_filtered table");
+        CHECK_IMG(a->film_filtered[0], 3, "film_filtered", 0);
+        for (int g = 0; g < 2; g++) {
+            k.g[g].data = nullptr;
+            k.g[g].channels = 3;
+            k.g[g].dr = a->g_dr_factors[g];
+        }
+        if (!statmc::fast_path_eligible(k, 3))
+            return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs: radius must be 1..20 and DR factors finite and <= 0");
+        if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
+        k.gscale0 = sqrtf(-k.g[0].dr * 1.44269504088896340736f);
+        k.gscale1 = sqrtf(-k.g[1].dr * 1.44269504088896340736f);
+        k.n_parts = statmc::lds_filter_parts(k, device_cus());
+        if (k.n_parts > 1) {
+            if (int rc = partial_workspace((size_t)k.n_parts * W * H * 4 * sizeof(float), &k.partial)) return rc;
+        }
+        k.packed = static_cast<const float *>(a->packed_inputs.data);
+        k.out = static_cast<float *>(a->film_filtered[0].data);
+        const char *variant = "none";
+        HIP_TRY(statmc::launch_lds_packed(k, S(a->stream), &variant));
+        g_variant = variant;
+        return STATMC_OK;
+    }
     for (int g = 0; g < k.n_g; g++) {
         const int gc = a->g_channel_counts[g];
         if (gc != 1 && gc != 3) return fail(STATMC_ERR_UNSUPPORTED, "g_buffers[%d]: %d channels", g, gc);
@@ -329,6 +361,33 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
         HIP_TRY(statmc::launch_window_filter(k, channels, S(a->stream), &variant));
         g_variant = variant;
     }
+    return STATMC_OK;
+}
+
+int statmc_pack_filter_inputs(const statmc_filter_args *a, const statmc_image *packed, int dst_x0, int dst_y0) {
+    NEED_READY();
+    if (int rc = check_common(a, 3)) return rc;
+    if (!packed || !packed->data) return fail(STATMC_ERR_INVALID, "null packed image");
+    if (a->n_buffers < 1 || a->n_g_buffers != 2 || !a->mean_corr || !a->discriminator || !a->g_buffers)
+        return fail(STATMC_ERR_INVALID, "pack needs buffer 0 and two G-buffers");
+    const int W = a->width, H = a->height;
+    const bool film = a->denoise_film != 0;
+    if (!film && !a->film) return fail(STATMC_ERR_INVALID, "null film table");
+    const statmc_image &colour = film ? a->film_buffer : a->film[0];
+    CHECK_IMG(a->mean_corr[0], 3, "mean_corr", 0);
+    CHECK_IMG(a->discriminator[0], 3, "discriminator", 0);
+    CHECK_IMG(colour, 3, "colour", 0);
+    CHECK_IMG(a->g_buffers[0], 3, "g_buffers", 0);
+    CHECK_IMG(a->g_buffers[1], 3, "g_buffers", 1);
+    if (dst_x0 < 0 || dst_y0 < 0 || dst_x0 + W > packed->cols || dst_y0 + H > packed->rows)
+        return fail(STATMC_ERR_INVALID, "block %dx%d at (%d,%d) does not fit the %dx%d packed image", W, H, dst_x0, dst_y0,
+                    packed->cols, packed->rows);
+    if (packed->step != (size_t)packed->cols * 15 * 4) return fail(STATMC_ERR_UNSUPPORTED, "packed image must have packed rows");
+    statmc::PackArgs k{static_cast<const float *>(a->mean_corr[0].data), static_cast<const float *>(a->discriminator[0].data),
+                       static_cast<const float *>(colour.data), static_cast<const float *>(a->g_buffers[0].data),
+                       static_cast<const float *>(a->g_buffers[1].data), static_cast<float *>(packed->data),
+                       W, H, packed->cols, dst_x0, dst_y0};
+    HIP_TRY(statmc::launch_pack_inputs(k, S(a->stream)));
     return STATMC_OK;
 }
 

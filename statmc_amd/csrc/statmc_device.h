@@ -83,7 +83,15 @@ struct FilterArgs {
     float *f_out[3];
     int f_active;
     int stagger;                 // s_sleep argument for waves 4..7 after every barrier (0 = none)
+    const float *packed;         // optional [height][width][15] inputs: mc, disc, colour, g0, g1 (RGB each)
 };
+
+struct PackArgs {
+    const float *mean_corr, *disc, *colour, *g0, *g1;  // [src_h][src_w][3]
+    float *packed;                                      // [dst_h][dst_w][15]
+    int src_w, src_h, dst_w, dst_x0, dst_y0;
+};
+hipError_t launch_pack_inputs(const PackArgs &a, hipStream_t s);
 
 hipError_t launch_prepass(const PrepassArgs &a, hipStream_t s);
 hipError_t launch_mean_vars(const MeanVarsArgs &a, hipStream_t s);
@@ -93,6 +101,7 @@ hipError_t launch_tile_moments(const TileMomentsArgs &a, hipStream_t s);
 
 // Returns the variant name through *variant.  channels = 1 or 3.
 hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s, const char **variant);
+hipError_t launch_lds_packed(const FilterArgs &a, hipStream_t s, const char **variant);
 // Size in floats of the spatial table the fast path wants for radius r (0 if r unsupported).
 size_t spatial_table_floats(int radius);
 void fill_spatial_table(float *host_tab, int radius, float ds);

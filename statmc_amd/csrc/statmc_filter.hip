@@ -396,6 +396,11 @@ __device__ __forceinline__ StagedPixel load_pixel(const FilterArgs &a, int x, in
     s.valid = x >= 0 && x < a.width && yrow >= 0 && yrow < a.height;
     if (s.valid) {
         const long long q = (long long)yrow * a.width + x;
+        if (RGB && a.packed) {  // block + halo image of the multi-GPU path: 15 contiguous floats per pixel
+            const f3 *px = reinterpret_cast<const f3 *>(a.packed + q * 15);
+            s.mc = px[0]; s.d = px[1]; s.col = px[2]; s.g0 = px[3]; s.g1 = px[4];
+            return s;
+        }
         if constexpr (RGB) {
             s.mc = reinterpret_cast<const f3 *>(a.mean_corr)[q];
             s.d = reinterpret_cast<const f3 *>(a.disc)[q];
@@ -474,8 +479,11 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
     for (int k = 0; k < kPx; k++) {
         const int px = min(x0 + kPx * lane + k, a.width - 1);
         const long long p = (long long)py * a.width + px;
-        f3 mc, d;
-        if constexpr (RGB) {
+        f3 mc, d, g0, g1;
+        if (RGB && a.packed) {
+            const f3 *px = reinterpret_cast<const f3 *>(a.packed + p * 15);
+            mc = px[0]; d = px[1]; g0 = px[3]; g1 = px[4];
+        } else if constexpr (RGB) {
             mc = reinterpret_cast<const f3 *>(a.mean_corr)[p];
             d = reinterpret_cast<const f3 *>(a.disc)[p];
         } else {
@@ -486,8 +494,10 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
             if (!(mc.x == mc.x && mc.y == mc.y && mc.z == mc.z && d.x == d.x && d.y == d.y && d.z == d.z))
                 mc.x = mc.y = mc.z = __builtin_nanf("");
         }
-        const f3 g0 = reinterpret_cast<const f3 *>(a.g[0].data)[p];
-        const f3 g1 = reinterpret_cast<const f3 *>(a.g[1].data)[p];
+        if (!(RGB && a.packed)) {
+            g0 = reinterpret_cast<const f3 *>(a.g[0].data)[p];
+            g1 = reinterpret_cast<const f3 *>(a.g[1].data)[p];
+        }
         st.pg[0][k] = v2f{g0.x * k0, g0.y * k0};
         st.pg[1][k] = v2f{g0.z * k0, g1.x * k1};
         st.pg[2][k] = v2f{g1.y * k1, g1.z * k1};
@@ -562,7 +572,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
                         o.y = st.acc01[k].y / st.sw[k];
                         o.z = st.acc2[k] / st.sw[k];
                     } else {
-                        o = reinterpret_cast<const f3 *>(a.colour)[p];
+                        o = a.packed ? reinterpret_cast<const f3 *>(a.packed + p * 15)[2] : reinterpret_cast<const f3 *>(a.colour)[p];
                     }
                     reinterpret_cast<f3 *>(a.out)[p] = o;
                 } else {
@@ -600,7 +610,7 @@ __global__ __launch_bounds__(256) void combine_parts_kernel(FilterArgs a) {
         if (t.w > 0.f) {
             o.x = t.x / t.w; o.y = t.y / t.w; o.z = t.z / t.w;
         } else {
-            o = reinterpret_cast<const f3 *>(a.colour)[p];
+            o = a.packed ? reinterpret_cast<const f3 *>(a.packed + p * 15)[2] : reinterpret_cast<const f3 *>(a.colour)[p];
         }
         reinterpret_cast<f3 *>(a.out)[p] = o;
     } else {
@@ -616,6 +626,28 @@ __global__ __launch_bounds__(256) void combine_parts_kernel(FilterArgs a) {
         for (int b = 0; b < 3; b++)
             if (b < a.f_active) a.f_out[b][p] = sws[b] > 0.f ? accs[b] / sws[b] : a.f_colour[b][p];
     }
+}
+
+// Owned block of the five filter inputs -> 15-channel block + halo image (one pass).
+__global__ __launch_bounds__(256) void pack_inputs_kernel(PackArgs a) {
+    const long long n = (long long)a.src_w * a.src_h;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int y = (int)(i / a.src_w), x = (int)(i - (long long)y * a.src_w);
+        f3 *dst = reinterpret_cast<f3 *>(a.packed + ((long long)(y + a.dst_y0) * a.dst_w + (x + a.dst_x0)) * 15);
+        dst[0] = reinterpret_cast<const f3 *>(a.mean_corr)[i];
+        dst[1] = reinterpret_cast<const f3 *>(a.disc)[i];
+        dst[2] = reinterpret_cast<const f3 *>(a.colour)[i];
+        dst[3] = reinterpret_cast<const f3 *>(a.g0)[i];
+        dst[4] = reinterpret_cast<const f3 *>(a.g1)[i];
+    }
+}
+
+hipError_t launch_pack_inputs(const PackArgs &a, hipStream_t s) {
+    const long long n = (long long)a.src_w * a.src_h;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(pack_inputs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 // The LDS kernel covers T = float3 (one RGB buffer) and T = float (three buffers per launch)
@@ -688,6 +720,16 @@ int lds_filter_parts(const FilterArgs &a, int n_cus) {
 // groups float buffers three per launch only then).
 bool lds_path_selected(const FilterArgs &a, int channels) {
     return fast_path_eligible(a, channels) && a.spatial_tab != nullptr && g_variant_override != 1;
+}
+
+// Window filter reading the 15-channel block + halo image (multi-GPU path): LDS kernel only.
+hipError_t launch_lds_packed(const FilterArgs &a, hipStream_t s, const char **variant) {
+    if (a.radius == 20 && g_variant_override != 2) {
+        *variant = "lds_r20";
+        return launch_lds<20, true>(a, s);
+    }
+    *variant = "lds_rt";
+    return launch_lds<0, true>(a, s);
 }
 
 hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s, const char **variant) {

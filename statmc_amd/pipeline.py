@@ -6,7 +6,6 @@ import torch
 
 from . import api, film, sharding
 
-HALO_IMAGES = ("mean_corr", "disc", "colour", "normal", "albedo")
 
 
 class BlockPipeline:
@@ -16,9 +15,9 @@ class BlockPipeline:
         self.filter_sd, self.radius = filter_sd, radius
         self.multi = layout.world > 1
         if self.multi:
-            # block + halo: one 15-channel exchange buffer, five padded float3 filter inputs, padded output
+            # block + halo: one 15-channel image (mean-corr, discriminator, colour, normal, albedo per
+            # pixel) is what the pack kernel writes, the halo exchange moves and the filter reads
             self.packed = layout.new_padded(15, device)
-            self.pad = {k: layout.new_padded(3, device) for k in HALO_IMAGES}
             self.out_pad = layout.new_padded(3, device)
 
     def accumulate(self, samples):
@@ -28,16 +27,12 @@ class BlockPipeline:
         self.fs.prepass()
 
     def exchange(self):
-        """Pack the five filter inputs of the owned block, fetch the r-pixel border from the
-        neighbours (two-phase RCCL send/recv), unpack into the padded images."""
-        fs, L = self.fs, self.layout
-        rad = fs.state["radiance"]
-        inner = L.interior(self.packed)
-        for i, src in enumerate((fs.mean_corr, fs.disc, rad["film_mean"], fs.g_buffer("normal"), fs.g_buffer("albedo"))):
-            inner[..., 3 * i:3 * i + 3].copy_(src)
+        """Pack the five filter inputs of the owned block into the block + halo image (one HIP
+        pass), then fetch the r-pixel border from the neighbours (two-phase RCCL send/recv)."""
+        L = self.layout
+        args, keep = self.fs.filter_args()
+        api.pack_filter_inputs(args, self.packed, L.pl, L.pt)
         sharding.exchange_halo(L, self.packed, via_host=self.via_host)
-        for i, k in enumerate(HALO_IMAGES):
-            self.pad[k].copy_(self.packed[..., 3 * i:3 * i + 3])
 
     def window_filter(self):
         """Returns the filtered owned block ([bh, bw, 3] view)."""
@@ -46,9 +41,9 @@ class BlockPipeline:
             return self.fs.film_f
         L = self.layout
         a, keep = api.make_filter_args(
-            n=[], mean=[], m2=[], m3=[], film=[self.pad["colour"]], mean_corr=[self.pad["mean_corr"]],
-            disc=[self.pad["disc"]], film_filtered=[self.out_pad], g_buffers=[self.pad["normal"], self.pad["albedo"]],
-            g_sds=self.fs.g_sds, filter_sd=self.filter_sd, radius=self.radius, roi=L.roi)
+            n=[], mean=[], m2=[], m3=[], film=[], mean_corr=[], disc=[], film_filtered=[self.out_pad],
+            g_buffers=[], g_sds=self.fs.g_sds, filter_sd=self.filter_sd, radius=self.radius, roi=L.roi,
+            packed=self.packed)
         api.window_filter(a, 3)
         return L.interior(self.out_pad)
 

@@ -473,6 +473,41 @@ def test_maximum_width_and_empty_calls(gpu, oracle):
     assert e.value.code == gpu.ERR_INVALID
 
 
+def test_packed_inputs_path(gpu, oracle):
+    """statmc_pack_filter_inputs + packed_inputs (the multi-GPU block + halo image): pack a block
+    into the middle of a larger 15-channel image whose margins hold the true neighbouring pixels,
+    filter with the ROI = block; must equal the separate-image filter of the larger image."""
+    W, H, m = 300, 56, 20                                             # larger image; block = interior minus a margin of 20
+    mc, disc, colour, gbs = stats_case(oracle, W, H, 8, seed=404)
+    ref = oracle.filter_image(mc, disc, colour, gbs, G_DR, -0.5 / FILTER_SD ** 2, RADIUS, roi=(m, m, W - m, H - m))
+    full15 = np.concatenate([mc, disc, colour, gbs[0], gbs[1]], axis=2)
+    packed = to_dev(full15).clone()
+    packed[m:H - m, m:W - m] = float("nan")                           # the pack kernel must fill exactly this
+    blk = lambda a: to_dev(np.ascontiguousarray(a[m:H - m, m:W - m]))
+    dummy = torch.zeros(H - 2 * m, W - 2 * m, 3, device=DEV)
+    a, keep = gpu.make_filter_args([], [], [], [], [blk(colour)], [blk(mc)], [blk(disc)], [dummy],
+                                   [blk(gbs[0]), blk(gbs[1])], g_sds=[SD_NORMAL, SD_ALBEDO], radius=RADIUS)
+    gpu.pack_filter_inputs(a, packed, m, m)
+    torch.cuda.synchronize()
+    assert np.array_equal(packed.cpu().numpy(), full15)
+    out = torch.zeros(H, W, 3, device=DEV)
+    a2, keep2 = gpu.make_filter_args([], [], [], [], [], [], [], [out], [], g_sds=[SD_NORMAL, SD_ALBEDO],
+                                     filter_sd=FILTER_SD, radius=RADIUS, roi=(m, m, W - m, H - m), packed=packed)
+    gpu.window_filter(a2, 3)
+    torch.cuda.synchronize()
+    assert gpu.last_filter_variant() == "lds_r20"
+    got = out.cpu().numpy()
+    assert max(rel_l2(got[..., c], ref[..., c]) for c in range(3)) <= TOL
+    assert not got[:m].any() and not got[:, :m].any()
+    # the packed path is T = float3 only, and the block must fit
+    with pytest.raises(gpu.StatmcError) as e:
+        gpu.window_filter(a2, 1)
+    assert e.value.code == gpu.ERR_UNSUPPORTED
+    with pytest.raises(gpu.StatmcError) as e:
+        gpu.pack_filter_inputs(a, packed, W - 10, 0)
+    assert e.value.code == gpu.ERR_INVALID
+
+
 def test_filter_argument_errors(gpu):
     z = lambda c=3: torch.zeros(8, 8, c, device=DEV)
     a, keep = gpu.make_filter_args([], [], [], [], [z()], [z()], [z()], [z()], [z()], g_sds=[0.1], radius=2)

@@ -42,6 +42,16 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        _run(rank, world, q, dist, api, pipeline, sharding)
+    except Exception as e:                      # report instead of leaving the parent waiting
+        q.put((rank, "error", repr(e), None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(rank, world, q, dist, api, pipeline, sharding):
+    if True:
         dev = torch.device("cuda:0")
         api.setup(0)
         api.force_filter_parts(2)            # same window-row split as the single-process run
@@ -54,8 +64,6 @@ def _worker(rank, world, port, q):
         torch.cuda.synchronize()
         q.put((rank, ox, oy, out.cpu().numpy()))
         dist.barrier()
-    finally:
-        dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -77,10 +85,18 @@ def test_blocks_equal_whole_film(gpu, world):
     procs = [ctx.Process(target=_worker, args=(rk, world, port, q)) for rk in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=300) for _ in range(world)]
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    got = []
+    try:
+        for _ in range(world):
+            item = q.get(timeout=120)
+            assert item[1] != "error", item
+            got.append(item)
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
     assert sorted(g[0] for g in got) == list(range(world))
     for rank, ox, oy, blk in got:
         assert np.array_equal(blk, ref[oy:oy + BH, ox:ox + BW]), rank     # bit-identical

@@ -14,7 +14,7 @@ def wall(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-print("pack+unpack: %.3f ms" % wall(pipe.exchange))
+print("pack (HIP kernel, no exchange): %.3f ms" % wall(pipe.exchange))
 print("filter on padded block (ROI): %.3f ms" % wall(pipe.window_filter, 5))
 one = pipeline.BlockPipeline(sharding.BlockLayout(0, 1, 1920, 1080, 20), dev, ("radiance", "normal", "albedo"))
 print("filter on plain block: %.3f ms" % wall(one.window_filter, 5))
