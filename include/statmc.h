@@ -156,6 +156,13 @@ int statmc_merge_tiles(uint16_t width, uint16_t height, int channels, int transf
                        int32_t *n, float *mean, float *m2, float *m3, float *film_mean,
                        float *film_m2, void *stream);
 
+/* Film::UpdateImage on the device (src/core/film.cpp:188-222): reads the reference's AoS
+ * Film::Pixel array {float xyz[3]; float filterWeightSum; float splatXYZ[3]; float pad} (32 B per
+ * pixel, src/core/film.h:72-78) and writes the interleaved RGB "film" image the filter denoises:
+ * XYZ -> RGB, / weight sum, clamp >= 0, + splat_scale * splat RGB, * scale. */
+int statmc_film_update(const void *film_pixels, size_t n_pixels, float splat_scale, float scale, float *film_rgb,
+                       void *stream);
+
 /* Tile-local pooled moments of an image by wavefront-level Welford/Chan merges: for every
  * tile_size x tile_size tile writes {count, mean, M2} per channel of `values`
  * (out: [tiles_y][tiles_x][channels][3] fp32).  tile_size in {8, 16}. */

@@ -41,6 +41,7 @@ def lib():
         _lib.oracle_filter.argtypes = ([C.c_int] * 3 + [C.c_float, C.c_int] + [f32p] * 3 +
                                        [C.c_int, C.POINTER(f32p), C.POINTER(C.c_int), f32p, f32p] +
                                        [C.c_int] * 5)
+        _lib.oracle_film_update.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, f32p]
         _lib.oracle_num_threads.restype = C.c_int
     return _lib
 
@@ -114,6 +115,19 @@ def mean_vars(n, film_m2, row_n_quirk=True):
     c = film_m2.shape[2] if film_m2.ndim == 3 else 1
     out = np.empty_like(film_m2)
     lib().oracle_mean_vars(w, h, c, _i(n), _f(film_m2), _f(out), int(row_n_quirk))
+    return out
+
+
+FILM_PIXEL_DTYPE = np.dtype({"names": ["xyz", "filter_weight_sum", "splat_xyz", "pad"],
+                             "formats": [("<f4", (3,)), "<f4", ("<f4", (3,)), "<f4"], "offsets": [0, 12, 16, 28],
+                             "itemsize": 32})
+
+
+def film_update(pixels, splat_scale=1.0, scale=1.0):
+    """pixels: structured array of FILM_PIXEL_DTYPE, any shape; returns float32 [..., 3]."""
+    assert pixels.dtype == FILM_PIXEL_DTYPE and pixels.flags["C_CONTIGUOUS"]
+    out = np.empty(pixels.shape + (3,), np.float32)
+    lib().oracle_film_update(pixels.ctypes.data, pixels.size, float(splat_scale), float(scale), _f(out))
     return out
 
 

@@ -184,6 +184,32 @@ void oracle_mean_vars(int width, int height, int channels, const int32_t *n,
     }
 }
 
+/* spectrum.h:66-70 */
+static inline void xyz_to_rgb(const float xyz[3], float rgb[3]) {
+    rgb[0] = 3.240479f * xyz[0] - 1.537150f * xyz[1] - 0.498535f * xyz[2];
+    rgb[1] = -0.969256f * xyz[0] + 1.875991f * xyz[1] + 0.041556f * xyz[2];
+    rgb[2] = 0.055648f * xyz[0] - 0.204043f * xyz[1] + 1.057311f * xyz[2];
+}
+
+/* film.cpp:188-222 */
+void oracle_film_update(const oracle_film_pixel *pixels, size_t n_pixels, float splat_scale, float scale, float *rgb) {
+    for (size_t i = 0; i < n_pixels; i++) {
+        const oracle_film_pixel *p = &pixels[i];
+        float *o = rgb + 3 * i;
+        xyz_to_rgb(p->xyz, o);
+        if (p->filter_weight_sum != 0) {
+            const float inv = 1.f / p->filter_weight_sum;
+            for (int c = 0; c < 3; c++) o[c] = fmaxf(0.f, o[c] * inv);
+        }
+        float splat_rgb[3];
+        xyz_to_rgb(p->splat_xyz, splat_rgb);
+        for (int c = 0; c < 3; c++) {
+            o[c] += splat_scale * splat_rgb[c];
+            o[c] *= scale;
+        }
+    }
+}
+
 /* ---------------------------- filter spec v1 ------------------------------------------- */
 
 float oracle_t_quantile(int alpha_index, int dof) {

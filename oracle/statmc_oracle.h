@@ -77,6 +77,17 @@ void oracle_merge_tile(const void *tile_pixels, int channels, int x0, int y0, in
 void oracle_mean_vars(int width, int height, int channels, const int32_t *n,
                       const float *film_m2, float *film_mean_var, int row_n_quirk);
 
+/* a15: Film::UpdateImage (src/core/film.cpp:188-222) over the Film::Pixel array
+ * {float xyz[3]; float filterWeightSum; float splatXYZ[3]; float pad} (film.h:72-78, 32 B):
+ * XYZ -> RGB (spectrum.h:66-70), / weight sum, clamp >= 0, + splatScale * splat RGB, * scale. */
+typedef struct {
+    float xyz[3];
+    float filter_weight_sum;
+    float splat_xyz[3];
+    float pad;
+} oracle_film_pixel;
+void oracle_film_update(const oracle_film_pixel *pixels, size_t n_pixels, float splat_scale, float scale, float *rgb);
+
 /* ---- filter spec v1 (self-specified; see header comment) -------------------------------- */
 
 /* tq(dof) = two-sided Student-t quantile, table index alpha_index in {0: 0.005, 1: 0.002,

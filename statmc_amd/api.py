@@ -54,7 +54,7 @@ EXPORTS = [
     "statmc_malloc", "statmc_free", "statmc_memset", "statmc_upload", "statmc_download",
     "statmc_stream_create", "statmc_stream_destroy", "statmc_synchronize",
     "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs",
-    "statmc_calculate_mean_vars", "statmc_accumulate", "statmc_merge_tiles", "statmc_tile_moments",
+    "statmc_calculate_mean_vars", "statmc_accumulate", "statmc_merge_tiles", "statmc_tile_moments", "statmc_film_update",
     "statmc_last_filter_variant", "statmc_version",
 ]
 
@@ -100,6 +100,7 @@ def load():
                                        C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p]
     lib.statmc_tile_moments.argtypes = [C.c_uint16, C.c_uint16, C.c_int, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_void_p]
+    lib.statmc_film_update.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     lib.statmc_debug_force_filter_variant.argtypes = [C.c_int]
     lib.statmc_debug_force_filter_parts.argtypes = [C.c_int]
     lib.statmc_debug_accumulate_resident_blocks.argtypes = [C.c_int]
@@ -277,6 +278,12 @@ def merge_tiles(width, height, channels, transform, tile_pixels, tile_bounds, ti
                                     tile_bounds.data_ptr(), tile_offsets.data_ptr(), tile_bounds.shape[0],
                                     max_tile_pixels, state["n"].data_ptr(), state["mean"].data_ptr(),
                                     state["m2"].data_ptr(), state["m3"].data_ptr(), fm, f2,
+                                    stream if stream is not None else current_stream_handle()))
+
+
+def film_update(film_pixels, n_pixels, film_rgb, splat_scale=1.0, scale=1.0, stream=None):
+    """film_pixels: uint8 device tensor holding n_pixels Film::Pixel structs (32 B each)."""
+    check(load().statmc_film_update(film_pixels.data_ptr(), n_pixels, float(splat_scale), float(scale), film_rgb.data_ptr(),
                                     stream if stream is not None else current_stream_handle()))
 
 

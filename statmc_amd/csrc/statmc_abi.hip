@@ -475,6 +475,16 @@ int statmc_merge_tiles(uint16_t width, uint16_t height, int channels, int transf
     return STATMC_OK;
 }
 
+int statmc_film_update(const void *film_pixels, size_t n_pixels, float splat_scale, float scale, float *film_rgb,
+                       void *stream) {
+    NEED_READY();
+    if (n_pixels == 0) return STATMC_OK;
+    if (!film_pixels || !film_rgb) return fail(STATMC_ERR_INVALID, "null pointer");
+    if (reinterpret_cast<uintptr_t>(film_pixels) & 15) return fail(STATMC_ERR_INVALID, "Film::Pixel array must be 16-byte aligned");
+    HIP_TRY(statmc::launch_film_update(film_pixels, (long long)n_pixels, splat_scale, scale, film_rgb, S(stream)));
+    return STATMC_OK;
+}
+
 int statmc_tile_moments(uint16_t width, uint16_t height, int channels, const float *values, int tile_size,
                         float *out, void *stream) {
     NEED_READY();

@@ -98,6 +98,7 @@ hipError_t launch_mean_vars(const MeanVarsArgs &a, hipStream_t s);
 hipError_t launch_accumulate(const AccumulateArgs &a, hipStream_t s);
 hipError_t launch_merge_tiles(const MergeTilesArgs &a, int n_tiles, int max_tile_pixels, hipStream_t s);
 hipError_t launch_tile_moments(const TileMomentsArgs &a, hipStream_t s);
+hipError_t launch_film_update(const void *pixels, long long n, float splat_scale, float scale, float *rgb, hipStream_t s);
 
 // Returns the variant name through *variant.  channels = 1 or 3.
 hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s, const char **variant);

@@ -392,6 +392,42 @@ hipError_t launch_merge_tiles(const MergeTilesArgs &a, int n_tiles, int max_tile
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ film update
+// One lane per Film::Pixel (32 B AoS = two 16-B loads), interleaved RGB out.  film.cpp:188-222.
+__device__ __forceinline__ void xyz_to_rgb(const float xyz[3], float rgb[3]) {  // spectrum.h:66-70
+    rgb[0] = 3.240479f * xyz[0] - 1.537150f * xyz[1] - 0.498535f * xyz[2];
+    rgb[1] = -0.969256f * xyz[0] + 1.875991f * xyz[1] + 0.041556f * xyz[2];
+    rgb[2] = 0.055648f * xyz[0] - 0.204043f * xyz[1] + 1.057311f * xyz[2];
+}
+
+__global__ __launch_bounds__(kBlock) void film_update_kernel(const float4 *pixels, long long n, float splat_scale,
+                                                             float scale, float *rgb_out) {
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+        const float4 a = pixels[2 * i], b = pixels[2 * i + 1];  // {xyz, weight}, {splat xyz, pad}
+        const float xyz[3] = {a.x, a.y, a.z}, sxyz[3] = {b.x, b.y, b.z};
+        float o[3], s[3];
+        xyz_to_rgb(xyz, o);
+        if (a.w != 0.f) {
+            const float inv = 1.f / a.w;
+#pragma unroll
+            for (int c = 0; c < 3; c++) o[c] = __builtin_fmaxf(0.f, o[c] * inv);
+        }
+        xyz_to_rgb(sxyz, s);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            o[c] += splat_scale * s[c];
+            o[c] *= scale;
+            rgb_out[3 * i + c] = o[c];
+        }
+    }
+}
+
+hipError_t launch_film_update(const void *pixels, long long n, float splat_scale, float scale, float *rgb, hipStream_t s) {
+    hipLaunchKernelGGL(film_update_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, static_cast<const float4 *>(pixels), n,
+                       splat_scale, scale, rgb);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ tile moments
 // One wavefront per (tile, channel): each lane folds its share of the tile's pixels with
 // Welford's update, then the 64 partial (count, mean, M2) triples are merged pairwise with

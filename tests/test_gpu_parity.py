@@ -526,6 +526,21 @@ def test_filter_argument_errors(gpu):
     assert e.value.code == gpu.ERR_UNSUPPORTED
 
 
+def test_film_update_matches_oracle(gpu, oracle):
+    rng = np.random.default_rng(17)
+    n = 1237
+    px = np.zeros(n, dtype=oracle.FILM_PIXEL_DTYPE)
+    px["xyz"] = rng.random((n, 3)) * 4
+    px["filter_weight_sum"] = rng.integers(0, 5, n)            # includes zero weights
+    px["splat_xyz"] = rng.random((n, 3)) * (rng.random((n, 1)) < 0.1)
+    px["pad"] = np.nan                                          # the pad word must not leak
+    ref = oracle.film_update(px, splat_scale=0.25, scale=1.5)
+    out = torch.zeros(n, 3, device=DEV)
+    gpu.film_update(torch.from_numpy(px.view(np.uint8)).to(DEV), n, out, splat_scale=0.25, scale=1.5)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
 def test_device_memory_and_streams_roundtrip(gpu):
     """statmc_malloc / upload / download / memset / stream_create / synchronize: the GpuMat +
     cv::cuda::Stream roles of Buffer (buffer.h:25,57-63; estimator.h:326)."""

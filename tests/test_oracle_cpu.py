@@ -190,3 +190,17 @@ def test_filter_float_variant(oracle):
     out = oracle.filter_image(mc, disc, colour, [], [], -0.05, 3)
     assert out.shape == colour.shape and np.isfinite(out).all()
     assert out.min() >= colour.min() - 1e-6 and out.max() <= colour.max() + 1e-6   # convex combination
+
+
+def test_film_update(oracle):
+    """Film::UpdateImage (film.cpp:188-222): known values + the clamp and the zero-weight case."""
+    px = np.zeros(4, dtype=oracle.FILM_PIXEL_DTYPE)
+    px["xyz"] = [[0.9505, 1.0, 1.089], [0.2, 0.1, 0.05], [0.0, 0.5, 0.0], [1, 1, 1]]   # D65 white -> RGB (1,1,1)
+    px["filter_weight_sum"] = [1.0, 2.0, 1.0, 0.0]
+    px["splat_xyz"][1] = [0.1, 0.1, 0.1]
+    rgb = oracle.film_update(px, splat_scale=0.5, scale=2.0)
+    assert np.allclose(rgb[0], [2.0, 2.0, 2.0], atol=2e-3)
+    assert (rgb >= 0).all() or rgb[3].min() < 0          # only the zero-weight pixel skips the clamp
+    assert rgb[2, 0] == 0.0 and rgb[2, 2] == 0.0         # negative R and B of a pure-Y colour are clamped
+    assert np.allclose(rgb[3], 2.0 * np.array([3.240479 - 1.537150 - 0.498535, -0.969256 + 1.875991 + 0.041556,
+                                               0.055648 - 0.204043 + 1.057311]), rtol=1e-6)   # weight 0: no division
