@@ -564,3 +564,41 @@ def test_device_memory_and_streams_roundtrip(gpu):
         gpu.check(lib.statmc_free(dptr))
     assert lib.statmc_malloc(None, 16) == gpu.ERR_INVALID
     assert lib.statmc_setup(99) == gpu.ERR_INVALID and b"out of range" in lib.statmc_last_error()
+
+
+def test_filter_randomised_configurations(gpu, oracle):
+    """40 seeded random configurations: image size, radius, filter sds, ROI, window-sweep parts,
+    kernel variant -- every one against the oracle."""
+    rng = np.random.default_rng(20240607)
+    worst = 0.0
+    for case in range(40):
+        W = int(rng.integers(5, 420))
+        H = int(rng.integers(3, 48))
+        radius = int(rng.choice([1, 2, 3, 5, 6, 8, 11, 16, 20, 20, 20]))
+        sd = float(rng.uniform(1.0, 12.0))
+        g_sds = [float(rng.uniform(0.05, 0.5)), float(rng.uniform(0.01, 0.2))]
+        g_dr = [-0.5 / s ** 2 for s in g_sds]
+        mc = rng.standard_normal((H, W, 3)).astype(np.float32)
+        disc = (rng.random((H, W, 3)) ** 3 * 2.0).astype(np.float32)
+        if rng.random() < 0.3:
+            disc[rng.integers(0, H), rng.integers(0, W)] = np.inf
+        if rng.random() < 0.3:
+            mc[rng.integers(0, H), rng.integers(0, W), rng.integers(0, 3)] = np.nan      # one NaN channel
+        colour = rng.random((H, W, 3), dtype=np.float32) * 3
+        gbs = [rng.random((H, W, 3), dtype=np.float32), rng.random((H, W, 3), dtype=np.float32)]
+        roi = None
+        if rng.random() < 0.5 and W > 8 and H > 4:
+            x0, y0 = int(rng.integers(0, W // 2)), int(rng.integers(0, H // 2))
+            roi = (x0, y0, int(rng.integers(x0 + 1, W + 1)), int(rng.integers(y0 + 1, H + 1)))
+        ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / sd ** 2, radius, roi=roi)
+        force = int(rng.choice([0, 0, 2, 1]))
+        gpu.force_filter_parts(int(rng.choice([0, 1, 2, 5])))
+        try:
+            out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, sd, radius, roi=roi, force=force)
+        finally:
+            gpu.force_filter_parts(0)
+        assert np.isfinite(out).all(), (case, v)
+        err = max(rel_l2(out[..., c], ref[..., c]) for c in range(3))
+        worst = max(worst, err)
+        assert err <= TOL, (case, v, W, H, radius, roi, err)
+    assert worst > 0          # the GPU path really computed something different from a copy of the oracle
