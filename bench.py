@@ -283,7 +283,9 @@ def main():
         valu_rate = valu_slots / (ms["filter"] * 1e-3) / 1e12
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        # the committed PMC traffic figures were collected on the default workload only
+        default_cfg = (W, H, S, args.channels, r) == (1920, 1080, 256, 11, 20)
+        if default_cfg and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath))
             except Exception:
