@@ -4,14 +4,15 @@
 //   mean_vars      film_m2 / ((n-1) n)            (Estimator::CalculateMeanVars)
 //   accumulate     sample stream -> running moments (StatTile::Add*Sample* + Merge*Tile)
 //   merge_tiles    reference-layout AoS tiles -> planar images (Estimator::Merge*Tile)
+//   film_update    Film::Pixel AoS -> interleaved RGB "film" image (Film::UpdateImage)
 //   tile_moments   tile-local pooled moments by wavefront-level Welford/Chan merges
 //
-// Layout choice.  The reference images are interleaved (cv::Mat of Vec3f).  Every statistic on
-// this path is element-wise per channel, with only the sample count n shared by the channels
-// of a pixel, so the kernels treat an image as a flat array of width*height*channels scalar
-// "elements" and give each lane 4 consecutive elements: all traffic is 16 B per lane, 1 KiB
-// per wave instruction, whatever the channel count (no float3 gathers), and n is read through
-// the cache at element/channels.
+// Layout choice.  The reference images are interleaved (cv::Mat of Vec3f) and stay that way.
+// Every statistic on this path is element-wise per channel, with only the sample count n shared
+// by the channels of a pixel, so the kernels walk an image as a flat array of
+// width*height*channels scalars and give each lane 4 consecutive PIXELS (channels x float4 per
+// plane, one int4 of counts): all traffic is 16 B per lane, whatever the channel count (no
+// float3 gathers), and n never crosses lanes.
 //
 // Arithmetic is written in the exact operation order of oracle/statmc_oracle.c and the file is
 // compiled with -ffp-contract=off, so everything except sqrt-vs-pow in the Box-Cox transform
