@@ -45,6 +45,11 @@ int statmc_setup(int device);
  * of three tables (README.md:149,158): 0 -> 0.005 (default), 1 -> 0.002, 2 -> 0.05. */
 int statmc_set_significance(int alpha_index);
 int statmc_get_significance(void);
+/* Replaces the built-in table `alpha_index` with the caller's quantiles for dof = 1..n_dof
+ * (n_dof <= 4096; larger dof reuse the last entry).  The built-in tables are this build's choice
+ * (two-sided t_{1-alpha/2}); the reference's own `t_quantiles` arrays live in the un-vendored
+ * stat_denoiser.cu, and a user who has them can load them here.  Call after statmc_setup(). */
+int statmc_set_t_quantiles(int alpha_index, const float *quantiles, int n_dof);
 
 /* Device memory + copies: the GpuMat role inside Buffer (src/statistics/buffer.h:25,57-63). */
 int statmc_malloc(void **dev_ptr, size_t bytes);

@@ -41,6 +41,7 @@ def lib():
         _lib.oracle_filter.argtypes = ([C.c_int] * 3 + [C.c_float, C.c_int] + [f32p] * 3 +
                                        [C.c_int, C.POINTER(f32p), C.POINTER(C.c_int), f32p, f32p] +
                                        [C.c_int] * 5)
+        _lib.oracle_set_t_quantiles.argtypes = [C.c_int, f32p, C.c_int]
         _lib.oracle_film_update.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, f32p]
         _lib.oracle_num_threads.restype = C.c_int
     return _lib
@@ -62,6 +63,15 @@ def num_threads():
 
 def box_cox(v, lam=0.5):
     return lib().oracle_box_cox(float(v), float(lam))
+
+
+def set_t_quantiles(alpha_index, quantiles):
+    """quantiles: float32 array for dof 1..len, or None to restore the built-in table."""
+    if quantiles is None:
+        lib().oracle_set_t_quantiles(int(alpha_index), None, 0)
+    else:
+        q = np.ascontiguousarray(quantiles, dtype=np.float32)
+        lib().oracle_set_t_quantiles(int(alpha_index), _f(q), len(q))
 
 
 def t_quantile(alpha_index, dof):

@@ -212,10 +212,22 @@ void oracle_film_update(const oracle_film_pixel *pixels, size_t n_pixels, float 
 
 /* ---------------------------- filter spec v1 ------------------------------------------- */
 
+static float tq_override[ORACLE_TQ_N_TABLES][ORACLE_TQ_N_DOF];
+static int tq_overridden[ORACLE_TQ_N_TABLES];
+
+void oracle_set_t_quantiles(int alpha_index, const float *q, int n_dof) {
+    if (!q) {  /* back to the built-in table */
+        tq_overridden[alpha_index] = 0;
+        return;
+    }
+    for (int i = 0; i < ORACLE_TQ_N_DOF; i++) tq_override[alpha_index][i] = q[i < n_dof ? i : n_dof - 1];
+    tq_overridden[alpha_index] = 1;
+}
+
 float oracle_t_quantile(int alpha_index, int dof) {
     if (dof < 1) return INFINITY;
     if (dof > ORACLE_TQ_N_DOF) dof = ORACLE_TQ_N_DOF;
-    return oracle_tq_tables[alpha_index][dof - 1];
+    return tq_overridden[alpha_index] ? tq_override[alpha_index][dof - 1] : oracle_tq_tables[alpha_index][dof - 1];
 }
 
 void oracle_prepass(int width, int height, int channels, int alpha_index,

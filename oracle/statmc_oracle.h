@@ -93,6 +93,8 @@ void oracle_film_update(const oracle_film_pixel *pixels, size_t n_pixels, float 
 /* tq(dof) = two-sided Student-t quantile, table index alpha_index in {0: 0.005, 1: 0.002,
  * 2: 0.05}; dof < 1 -> +inf; dof clamped to the last table entry. */
 float oracle_t_quantile(int alpha_index, int dof);
+/* user-supplied quantiles for dof 1..n_dof in slot alpha_index (NULL restores the built-in table) */
+void oracle_set_t_quantiles(int alpha_index, const float *quantiles, int n_dof);
 
 /* Pre-pass: (n, mean, m2, m3) -> Johnson-corrected mean and discriminator, per channel. */
 void oracle_prepass(int width, int height, int channels, int alpha_index,

@@ -50,7 +50,7 @@ class StatType(C.Structure):
 
 
 EXPORTS = [
-    "statmc_last_error", "statmc_setup", "statmc_set_significance", "statmc_get_significance",
+    "statmc_last_error", "statmc_setup", "statmc_set_significance", "statmc_get_significance", "statmc_set_t_quantiles",
     "statmc_malloc", "statmc_free", "statmc_memset", "statmc_upload", "statmc_download",
     "statmc_stream_create", "statmc_stream_destroy", "statmc_synchronize",
     "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs",
@@ -79,6 +79,7 @@ def load():
     lib.statmc_last_filter_variant.restype = C.c_char_p
     lib.statmc_setup.argtypes = [C.c_int]
     lib.statmc_set_significance.argtypes = [C.c_int]
+    lib.statmc_set_t_quantiles.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_int]
     lib.statmc_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     lib.statmc_free.argtypes = [C.c_void_p]
     lib.statmc_memset.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]

@@ -13,6 +13,7 @@
 
 namespace statmc {
 hipError_t upload_t_tables();
+hipError_t upload_t_table(int alpha_index, const float *host_4096);
 }
 
 namespace {
@@ -177,6 +178,16 @@ int statmc_set_significance(int alpha_index) {
     return STATMC_OK;
 }
 int statmc_get_significance(void) { return g_alpha_index; }
+
+int statmc_set_t_quantiles(int alpha_index, const float *quantiles, int n_dof) {
+    NEED_READY();
+    if (alpha_index < 0 || alpha_index > 2) return fail(STATMC_ERR_INVALID, "alpha_index must be 0, 1 or 2");
+    if (!quantiles || n_dof < 1 || n_dof > 4096) return fail(STATMC_ERR_INVALID, "need 1..4096 quantiles");
+    std::vector<float> t(4096);
+    for (int i = 0; i < 4096; i++) t[i] = quantiles[i < n_dof ? i : n_dof - 1];
+    HIP_TRY(statmc::upload_t_table(alpha_index, t.data()));
+    return STATMC_OK;
+}
 
 int statmc_malloc(void **dev_ptr, size_t bytes) {
     if (!dev_ptr) return fail(STATMC_ERR_INVALID, "null dev_ptr");

@@ -30,6 +30,11 @@ hipError_t upload_t_tables() {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_tq), statmc_tq_tables, sizeof(statmc_tq_tables));
 }
 
+hipError_t upload_t_table(int alpha_index, const float *host_4096) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tq), host_4096, sizeof(float) * STATMC_TQ_N_DOF,
+                             sizeof(float) * STATMC_TQ_N_DOF * alpha_index);
+}
+
 __device__ __forceinline__ float t_quantile(int alpha_index, int dof) {
     if (dof < 1) return __builtin_inff();
     if (dof > STATMC_TQ_N_DOF) dof = STATMC_TQ_N_DOF;

@@ -256,6 +256,35 @@ def test_significance_levels(gpu, oracle):
         gpu.load().statmc_set_significance(0)
 
 
+def test_custom_t_quantile_table(gpu, oracle):
+    """A user-supplied quantile table (e.g. the reference's own array) replaces a built-in one."""
+    from scipy import stats
+    rng = np.random.default_rng(5)
+    n = rng.integers(2, 300, (6, 9)).astype(np.int32)
+    mean, m2, m3 = (rng.random((6, 9, 3), dtype=np.float32) for _ in range(3))
+    table = stats.t.ppf(1 - 0.01, np.arange(1, 201)).astype(np.float32)       # one-sided 1 %, only 200 dof
+    lib = gpu.load()
+    try:
+        gpu.check(lib.statmc_set_t_quantiles(2, table.ctypes.data_as(C.POINTER(C.c_float)), len(table)))
+        gpu.check(lib.statmc_set_significance(2))
+        oracle.set_t_quantiles(2, table)
+        mc, d = torch.zeros(6, 9, 3, device=DEV), torch.zeros(6, 9, 3, device=DEV)
+        dummy = torch.zeros(6, 9, 3, device=DEV)
+        a, keep = gpu.make_filter_args([to_dev(n)], [to_dev(mean)], [to_dev(m2)], [to_dev(m3)], [dummy], [mc], [d],
+                                       [dummy.clone()], [], g_sds=[], radius=1)
+        gpu.prepass(a, 3)
+        torch.cuda.synchronize()
+        want = oracle.prepass(n, mean, m2, m3, alpha_index=2)[1]
+        assert np.array_equal(d.cpu().numpy(), want)
+        assert oracle.t_quantile(2, 250) == table[-1]                           # beyond the table: last entry
+        assert lib.statmc_set_t_quantiles(5, table.ctypes.data_as(C.POINTER(C.c_float)), 10) == gpu.ERR_INVALID
+    finally:
+        oracle.set_t_quantiles(2, None)
+        gpu.check(lib.statmc_setup(0))           # setup() re-uploads the built-in tables
+        gpu.check(lib.statmc_set_significance(0))
+    assert oracle.t_quantile(2, 30) < oracle.t_quantile(0, 30)
+
+
 # ------------------------------------------------------------------ window filter
 def run_filter(gpu, mc, disc, colour, gbs, g_dr, filter_sd, radius, roi=None, channels=3, force=0):
     out = torch.zeros_like(to_dev(colour))
