@@ -213,7 +213,7 @@ def main():
     ox, oy = layout.origin
 
     # ---- synthetic inputs, generated in place in HBM (seeded; same generator as the tests)
-    scene = synthetic.Scene(W, H, n_regions=12 * world, seed=1, device=dev, x_offset=ox, y_offset=oy,
+    scene = synthetic.Scene(W, H, n_regions=min(12 * world, 32), seed=1, device=dev, x_offset=ox, y_offset=oy,
                             full_width=fw, full_height=fh)
     samples = {t: [] for t in types}
     chunk = 32
