@@ -114,17 +114,15 @@ constexpr int kSlots = kTileH + 1;     // LDS row ring
 constexpr int kCh = 15;                // floats staged per pixel
 constexpr int kMaxR = 20;
 
-// LDS row layout (floats; P = pitch = columns staged per row, a multiple of 4).
-// The 15 values of a pixel are stored as 6 channel PAIRS + 3 singles so that the inner loop can
-// use packed fp32 VALU ops (v_pk_add/mul/fma_f32: two channels per instruction) -- a wave can
-// issue one VALU instruction per 4 cycles, so with only 2 waves per SIMD the kernel is bound by
-// instruction issue, not by ALU width, and halving the instruction count of the channel-wise
-// work is what buys time:
-//   pair plane k (k = 0..5), half h (taps 0,1 / taps 2,3 of a 4-column group):
-//       float index (2k + h) * P + (col >> 2) * 4 + (col & 1) * 2 + c        c = 0, 1
-//     so one ds_read_b128 at lane stride 16 B returns {tap0.c0, tap0.c1, tap1.c0, tap1.c1}
-//   single plane s (s = 0..2): 12 P + s P + col
-enum { K_G01 = 0, K_G2A0 = 1, K_A12 = 2, K_MC01 = 3, K_ND01 = 4, K_COL01 = 5, S_MC2 = 0, S_ND2 = 1, S_COL2 = 2 };
+// LDS row layout (floats; P = pitch = columns staged per row, a multiple of 4): 15 planes of P
+// floats, one per channel -- scaled normal 0..2, scaled albedo 3..5, corrected mean 6..8,
+// -discriminator 9..11, colour 12..14.  A lane's ds_read_b128 of a plane returns one channel of 4
+// adjacent taps; consecutive lanes read consecutive 16 B (conflict-free).  The inner loop works on
+// TAP PAIRS with packed fp32 (v_pk_add/mul/fma_f32: both taps of a pair in one instruction, the
+// pixel's own value broadcast through op_sel): the kernel is bound by VALU instruction issue, and
+// pairing taps -- rather than channels -- needs no cross-half adds and also packs the
+// single-channel work (17 instructions per (tap, pixel) pair instead of 21).
+enum { C_G0 = 0, C_G1 = 3, C_MC = 6, C_ND = 9, C_COL = 12 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -167,225 +165,139 @@ struct ChunkMask {
     }
 };
 
+// The lane's own 4 pixels.  Accumulators are 2-wide: .x collects the even taps of every read
+// group, .y the odd ones; the epilogue adds the halves.
 struct LaneState {
-    v2f pg[3][kPx];              // scaled (n0,n1), (n2,a0), (a1,a2) of the lane's pixels
-    v2f pmc01[kPx], pd01[kPx];   // corrected mean / discriminator, channels 0,1
-    float pmc2[kPx], pd2[kPx];   // ... channel 2
-    v2f acc01[kPx];
-    float acc2[kPx], sw[kPx];
-    // float mode (three independent 1-channel buffers share the window sweep): per-buffer sums
-    v2f sw01[kPx];
-    float sw2[kPx];
+    float pg[kPx][6];            // scaled normal, scaled albedo
+    float pmc[kPx][3], pd[kPx][3];
+    v2f acc[kPx][3];
+    v2f sw[kPx][3];              // RGB uses sw[k][0] only; float mode has one weight sum per buffer
 };
 
-// Half of a read group = 2 taps (columns 4*(lane+j) + 2h, +1 of the staged row) x the lane's 4
-// pixels: 6 ds_read_b128 (channel pairs of both taps) + 3 ds_read_b64 (single channels).
-// Half groups are the unit of register double-buffering: at most 18 LDS reads are in flight per
-// wave (the lgkmcnt counter is 4 bits wide) and two operand sets cost 60 VGPRs.
+// Operands of half a read group: taps 2H, 2H+1 (columns 4*(lane+j) + 2H, +1 of the staged row) of
+// all 15 channels (ds_read_b64 each: consecutive lanes 16 B apart, conflict-free for b64), and the
+// window row's spatial exponents tab[4j .. 4j+7] (two broadcast ds_read_b128).
 struct HalfChunk {
-    v4f qp[6];
-    v2f qs[3];
+    v2f q[kCh];
+    v4f tb[2];
 };
 
 template <int H>
-__device__ __forceinline__ void load_half(HalfChunk &c, const float *__restrict__ row, int pitch, int j) {
+__device__ __forceinline__ void load_half(HalfChunk &c, const float *__restrict__ row, int pitch,
+                                          const float *__restrict__ tab, int j) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) c.qp[k] = *reinterpret_cast<const v4f *>(row + (2 * k + H) * pitch + 4 * j);
-#pragma unroll
-    for (int s = 0; s < 3; s++) c.qs[s] = *reinterpret_cast<const v2f *>(row + (12 + s) * pitch + 4 * j + 2 * H);
+    for (int ch = 0; ch < kCh; ch++) c.q[ch] = *reinterpret_cast<const v2f *>(row + ch * pitch + 4 * j + 2 * H);
+    c.tb[0] = *reinterpret_cast<const v4f *>(tab + 4 * j);
+    c.tb[1] = *reinterpret_cast<const v4f *>(tab + 4 * j + 4);
 }
 
-// The window row's spatial exponents live in ONE VGPR spread over the wave's lanes (lane t holds
-// tab[t]); the entry of tap i / pixel k of read group j is lane 4j + i - k + 3, fetched with
-// v_readlane (wave-uniform index) -- no LDS or scalar-memory traffic in the inner loop.
-__device__ __forceinline__ float tab_at(float tabv, int idx) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tabv), idx));
-}
-
-// MASK: bit (i*4+k) set when tap i of the read group lies inside the window of pixel k (all 16
-// bits in the runtime-radius variant, where the table holds -inf beyond the radius).
+// Taps 2H and 2H+1 of the read group against the lane's 4 pixels: 4 tap-pair evaluations, written
+// stage by stage across the pixels so every dependent step is followed by independent work.
+// MASK: bit (i*4+k) set when tap i lies inside the window of pixel k (all 16 bits in the
+// runtime-radius variant, where the table holds -inf beyond the radius); a pair is evaluated when
+// either of its taps is inside, the outside tap of a partial pair is switched off by the table
+// (static variant: by a compile-time zero weight).
 // RGB = true: filter<float3> -- one buffer, membership is the AND over its three channels.
 // RGB = false: filter<float> -- the three "channels" are three independent 1-channel buffers
 // (ACRR bounces / SMIS win rates) that share the range weight but gate and normalise separately.
-// Written stage by stage ACROSS the half group's 8 (tap, pixel) pairs: every stage is 8 independent instructions,
-// so a wave always has independent work to issue between the dependent steps of one (tap, pixel)
-// pair (sub -> mul -> fma -> fma -> add -> add -> exp -> select -> fma).  With only two waves
-// per SIMD the dependent-issue latency of a pair-by-pair stream is not hidden by other waves.
 template <int H, unsigned MASK, bool RGB>
-__device__ __forceinline__ void compute_half(LaneState &st, const HalfChunk &c, float tabv, int j) {
-    // e = 2 * ii + ... : the 2 taps x 4 pixels of the half group form 8 independent pair evaluations
-    constexpr int NE = 2 * kPx;
-    auto tap = [](int e) { return e / kPx; };   // ii
-    auto pix = [](int e) { return e % kPx; };   // k
-    auto on = [&](int e) { return (MASK & (1u << ((2 * H + tap(e)) * 4 + pix(e)))) != 0; };
-    v2f q[2][6];  // per tap: channel pairs = low or high half of the b128
+__device__ __forceinline__ void compute_half(LaneState &st, const HalfChunk &c) {
+    constexpr int i0 = 2 * H;
+    auto in0 = [](int k) { return (MASK & (1u << (i0 * 4 + k))) != 0; };
+    auto in1 = [](int k) { return (MASK & (1u << ((i0 + 1) * 4 + k))) != 0; };
+    auto on = [&](int k) { return in0(k) || in1(k); };
+    const v2f *q = c.q;
+    const float tb[8] = {c.tb[0].x, c.tb[0].y, c.tb[0].z, c.tb[0].w, c.tb[1].x, c.tb[1].y, c.tb[1].z, c.tb[1].w};
+
+    v2f e[kPx], u[kPx][3], w[kPx];
+    // range weight exponent: tab - |k_n dn|^2 - |k_a da|^2 for both taps at once
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        q[0][k] = v2f{c.qp[k].x, c.qp[k].y};
-        q[1][k] = v2f{c.qp[k].z, c.qp[k].w};
+    for (int k = 0; k < kPx; k++) if (on(k)) { const v2f d = st.pg[k][0] - q[C_G0]; e[k] = -d * d; }
+#pragma unroll
+    for (int ch = 1; ch < 6; ch++) {
+#pragma unroll
+        for (int k = 0; k < kPx; k++) if (on(k)) { const v2f d = st.pg[k][ch] - q[C_G0 + ch]; e[k] = __builtin_elementwise_fma(-d, d, e[k]); }
     }
-    v2f e2[NE], t01[NE];
-    float w[NE], t2[NE];
-    // range weight: exp2(tab - |k_n dn|^2 - |k_a da|^2), two channels per instruction
 #pragma unroll
-    for (int e = 0; e < NE; e++) if (on(e)) { const v2f d = st.pg[0][pix(e)] - q[tap(e)][K_G01]; e2[e] = -d * d; }
+    for (int k = 0; k < kPx; k++) if (on(k)) e[k] += v2f{tb[i0 - k + 3], tb[i0 - k + 4]};
+    // membership statistic per channel: t_c = fma(d_c, d_c, -D_q,c)  (the oracle's expression)
 #pragma unroll
-    for (int e = 0; e < NE; e++) if (on(e)) { const v2f d = st.pg[1][pix(e)] - q[tap(e)][K_G2A0]; e2[e] = __builtin_elementwise_fma(-d, d, e2[e]); }
+    for (int ch = 0; ch < 3; ch++) {
 #pragma unroll
-    for (int e = 0; e < NE; e++) if (on(e)) { const v2f d = st.pg[2][pix(e)] - q[tap(e)][K_A12]; e2[e] = __builtin_elementwise_fma(-d, d, e2[e]); }
+        for (int k = 0; k < kPx; k++) if (on(k)) { const v2f d = st.pmc[k][ch] - q[C_MC + ch]; u[k][ch] = __builtin_elementwise_fma(d, d, q[C_ND + ch]); }
+    }
 #pragma unroll
-    for (int e = 0; e < NE; e++) if (on(e)) w[e] = (e2[e].x + tab_at(tabv, 4 * j + 2 * H + tap(e) - pix(e) + 3)) + e2[e].y;
-    // membership: fma(d, d, -D_q) <= D_p in every channel (bit-identical to the oracle)
-#pragma unroll
-    for (int e = 0; e < NE; e++) if (on(e)) { const v2f d = st.pmc01[pix(e)] - q[tap(e)][K_MC01]; t01[e] = __builtin_elementwise_fma(d, d, q[tap(e)][K_ND01]); }
-#pragma unroll
-    for (int e = 0; e < NE; e++) if (on(e)) { const float db = st.pmc2[pix(e)] - c.qs[S_MC2][tap(e)]; t2[e] = __builtin_fmaf(db, db, c.qs[S_ND2][tap(e)]); }
-#pragma unroll
-    for (int e = 0; e < NE; e++) if (on(e)) w[e] = __builtin_amdgcn_exp2f(w[e]);
+    for (int k = 0; k < kPx; k++) if (on(k)) w[k] = v2f{__builtin_amdgcn_exp2f(e[k].x), __builtin_amdgcn_exp2f(e[k].y)};
     if constexpr (RGB) {
-        // all three channels pass  <=>  max_c (t_c - D_p,c) <= 0.  (t - D <= 0) has exactly the truth
-        // value of the oracle's (t <= D); one max3 + one compare + one select stays on the VALU, where
-        // (3 compares, 2 scalar ANDs, select) serialises every pair through the scalar unit
-        // (VALU -> SGPR -> SALU -> VCC -> VALU).  v_max3 drops NaN operands, so a pixel with a NaN
-        // statistic is staged with NaN in all three channels (store_pixel).
+        // all three channels pass  <=>  max_c (t_c - D_p,c) <= 0: (t - D <= 0) has exactly the truth
+        // value of the oracle's (t <= D); max3 + compare + select stays on the VALU, where 3 compares
+        // + 2 scalar ANDs send every pair through the scalar unit.  v_max3 drops NaN operands, so a
+        // pixel with a NaN statistic is staged with NaN in all three channels (store_pixel).
 #pragma unroll
-        for (int e = 0; e < NE; e++) if (on(e)) { t01[e] = t01[e] - st.pd01[pix(e)]; t2[e] = t2[e] - st.pd2[pix(e)]; }
+        for (int ch = 0; ch < 3; ch++) {
 #pragma unroll
-        for (int e = 0; e < NE; e++) if (on(e)) {
-            const float m = __builtin_fmaxf(__builtin_fmaxf(t01[e].x, t01[e].y), t2[e]);
-            w[e] = m <= 0.f ? w[e] : 0.f;
+            for (int k = 0; k < kPx; k++) if (on(k)) u[k][ch] = u[k][ch] - st.pd[k][ch];
         }
 #pragma unroll
-        for (int e = 0; e < NE; e++) if (on(e)) {
-            const int k = pix(e);
-            st.sw[k] += w[e];
-            st.acc01[k] = __builtin_elementwise_fma(v2f{w[e], w[e]}, q[tap(e)][K_COL01], st.acc01[k]);
-            st.acc2[k] = __builtin_fmaf(w[e], c.qs[S_COL2][tap(e)], st.acc2[k]);
+        for (int k = 0; k < kPx; k++) if (on(k)) {
+            const float m0 = __builtin_fmaxf(__builtin_fmaxf(u[k][0].x, u[k][1].x), u[k][2].x);
+            const float m1 = __builtin_fmaxf(__builtin_fmaxf(u[k][0].y, u[k][1].y), u[k][2].y);
+            w[k] = v2f{in0(k) && m0 <= 0.f ? w[k].x : 0.f, in1(k) && m1 <= 0.f ? w[k].y : 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < kPx; k++) if (on(k)) st.sw[k][0] += w[k];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+#pragma unroll
+            for (int k = 0; k < kPx; k++) if (on(k)) st.acc[k][ch] = __builtin_elementwise_fma(w[k], q[C_COL + ch], st.acc[k][ch]);
         }
     } else {
-        // filter<float>: the three "channels" are independent buffers with their own gate and weight sum
 #pragma unroll
-        for (int e = 0; e < NE; e++) if (on(e)) {
-            const int k = pix(e);
-            const v2f w01 = v2f{t01[e].x <= st.pd01[k].x ? w[e] : 0.f, t01[e].y <= st.pd01[k].y ? w[e] : 0.f};
-            const float w2 = t2[e] <= st.pd2[k] ? w[e] : 0.f;
-            st.sw01[k] += w01;
-            st.sw2[k] += w2;
-            st.acc01[k] = __builtin_elementwise_fma(w01, q[tap(e)][K_COL01], st.acc01[k]);
-            st.acc2[k] = __builtin_fmaf(w2, c.qs[S_COL2][tap(e)], st.acc2[k]);
+        for (int ch = 0; ch < 3; ch++) {
+#pragma unroll
+            for (int k = 0; k < kPx; k++) if (on(k)) {
+                const v2f wc = v2f{in0(k) && u[k][ch].x <= st.pd[k][ch] ? w[k].x : 0.f,
+                                   in1(k) && u[k][ch].y <= st.pd[k][ch] ? w[k].y : 0.f};
+                st.sw[k][ch] += wc;
+                st.acc[k][ch] = __builtin_elementwise_fma(wc, q[C_COL + ch], st.acc[k][ch]);
+            }
         }
     }
 }
 
-// Sweep one window row, one half read group (2 taps x 4 pixels) at a time.  Register
-// double-buffering of the operand sets was measured and bought nothing (the second wave on the
-// SIMD already covers the LDS latency), so a single set is used: 164 VGPRs.
-// RT > 0 (compile-time radius, a multiple of 4): the first and last read groups hold
-// (tap, pixel) pairs outside the window and get their static masks; every group between is full.
-// ABL (diagnostic builds only, never dispatched by the ABI): 1 = no LDS reads in the sweep (one
-// operand set reused; times the pure VALU work), 2 = LDS reads but one token VALU op per read group
-// (times the operand feed), 0 = the real kernel.
-template <int RT, bool RGB, int ABL = 0>
-__device__ __forceinline__ void eval_row(LaneState &st, const float *row, int pitch, float tabv, int n_chunks) {
-    HalfChunk A;
+// Sweep one window row: 2*rp/4 + 1 read groups.  RT > 0 (compile-time radius, a multiple of 4):
+// the first and last groups hold (tap, pixel) pairs outside the window and get their static
+// masks; every group between is full and runs as a rolled loop.
+template <int RT, bool RGB>
+__device__ __forceinline__ void eval_row(LaneState &st, const float *row, int pitch, const float *tab, int n_chunks) {
+    HalfChunk c;
     constexpr unsigned kFull = 0xFFFFu;
-    if constexpr (ABL == 1) {
-        constexpr int n = 2 * round_up4(RT) / 4 + 1;
-        load_half<0>(A, row, pitch, 0);
-#pragma unroll 1
-        for (int j = 0; j < n; j++) {
-            // keep the whole operand set opaque per iteration (nothing may be hoisted out of the loop)
-            asm volatile("" : "+v"(A.qp[0]), "+v"(A.qp[1]), "+v"(A.qp[2]), "+v"(A.qp[3]), "+v"(A.qp[4]), "+v"(A.qp[5]),
-                              "+v"(A.qs[0]), "+v"(A.qs[1]), "+v"(A.qs[2]));
-            compute_half<0, kFull, RGB>(st, A, tabv, j);
-            compute_half<1, kFull, RGB>(st, A, tabv, j);
-        }
-    } else if constexpr (ABL == 4) {
-        // VALU work on a fixed operand set + the real LDS reads into a second set nobody computes on
-        constexpr int n = 2 * round_up4(RT) / 4 + 1;
-        HalfChunk B;
-        load_half<0>(A, row, pitch, 0);
-#pragma unroll 1
-        for (int j = 0; j < n; j++) {
-            asm volatile("" : "+v"(A.qp[0]), "+v"(A.qp[1]), "+v"(A.qp[2]), "+v"(A.qp[3]), "+v"(A.qp[4]), "+v"(A.qp[5]),
-                              "+v"(A.qs[0]), "+v"(A.qs[1]), "+v"(A.qs[2]));
-            load_half<1>(B, row, pitch, j);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_half<0, kFull, RGB>(st, A, tabv, j);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" :: "v"(B.qp[0]), "v"(B.qp[1]), "v"(B.qp[2]), "v"(B.qp[3]), "v"(B.qp[4]), "v"(B.qp[5]),
-                              "v"(B.qs[0]), "v"(B.qs[1]), "v"(B.qs[2]));
-            load_half<0>(B, row, pitch, j);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_half<1, kFull, RGB>(st, A, tabv, j);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" :: "v"(B.qp[0]), "v"(B.qp[1]), "v"(B.qp[2]), "v"(B.qp[3]), "v"(B.qp[4]), "v"(B.qp[5]),
-                              "v"(B.qs[0]), "v"(B.qs[1]), "v"(B.qs[2]));
-        }
-    } else if constexpr (ABL == 3) {
-        st.sw[0] += row[0];  // nothing but the row staging, barriers and prologue
-    } else if constexpr (ABL == 2) {
-        constexpr int n = 2 * round_up4(RT) / 4 + 1;
-#pragma unroll 1
-        for (int j = 0; j < n; j++) {
-            load_half<0>(A, row, pitch, j);
-            float t = 0.f;
-#pragma unroll
-            for (int k = 0; k < 6; k++) t += A.qp[k].x + A.qp[k].w;
-            st.sw[0] += t + A.qs[0].x + A.qs[1].y + A.qs[2].x;
-            load_half<1>(A, row, pitch, j);
-            t = 0.f;
-#pragma unroll
-            for (int k = 0; k < 6; k++) t += A.qp[k].y + A.qp[k].z;
-            st.sw[1] += t + A.qs[0].y + A.qs[1].x + A.qs[2].y;
-        }
-    } else if constexpr (RT > 0) {
-        // Software-pipelined: operand sets A (taps 0,1) and B (taps 2,3) alternate; the LDS reads
-        // of the set evaluated NEXT are issued before the current set's VALU work and pinned there
-        // with sched_barrier, so their latency is covered by ~270 VALU instructions and the wait in
-        // front of each compute phase is a counted lgkmcnt(9) that never stalls.  Without this the
-        // read latency is exposed in every half group (ablation: 2.85 ms vs 1.93 ms VALU-only).
+    if constexpr (RT > 0) {
         constexpr int n = 2 * round_up4(RT) / 4 + 1;
         static_assert(RT % 4 == 0 && n >= 3, "static variant: radius multiple of 4");
         static_assert(ChunkMask<1, RT>::value() == kFull && ChunkMask<n - 2, RT>::value() == kFull, "");
-        HalfChunk B;
-        load_half<0>(A, row, pitch, 0);
-        load_half<1>(B, row, pitch, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_half<0, ChunkMask<0, RT>::value(), RGB>(st, A, tabv, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_half<0>(A, row, pitch, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_half<1, ChunkMask<0, RT>::value(), RGB>(st, B, tabv, 0);
+        load_half<0>(c, row, pitch, tab, 0);
+        compute_half<0, ChunkMask<0, RT>::value(), RGB>(st, c);
+        load_half<1>(c, row, pitch, tab, 0);
+        compute_half<1, ChunkMask<0, RT>::value(), RGB>(st, c);
 #pragma unroll 1
         for (int j = 1; j < n - 1; j++) {
-            __builtin_amdgcn_sched_barrier(0);
-            load_half<1>(B, row, pitch, j);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_half<0, kFull, RGB>(st, A, tabv, j);
-            __builtin_amdgcn_sched_barrier(0);
-            load_half<0>(A, row, pitch, j + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_half<1, kFull, RGB>(st, B, tabv, j);
+            load_half<0>(c, row, pitch, tab, j);
+            compute_half<0, kFull, RGB>(st, c);
+            load_half<1>(c, row, pitch, tab, j);
+            compute_half<1, kFull, RGB>(st, c);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        load_half<1>(B, row, pitch, n - 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_half<0, ChunkMask<n - 1, RT>::value(), RGB>(st, A, tabv, n - 1);
-        compute_half<1, ChunkMask<n - 1, RT>::value(), RGB>(st, B, tabv, n - 1);
+        load_half<0>(c, row, pitch, tab, n - 1);
+        compute_half<0, ChunkMask<n - 1, RT>::value(), RGB>(st, c);
+        load_half<1>(c, row, pitch, tab, n - 1);
+        compute_half<1, ChunkMask<n - 1, RT>::value(), RGB>(st, c);
     } else {
-        HalfChunk B;
-        load_half<0>(A, row, pitch, 0);
 #pragma unroll 1
         for (int j = 0; j < n_chunks; j++) {
-            __builtin_amdgcn_sched_barrier(0);
-            load_half<1>(B, row, pitch, j);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_half<0, kFull, RGB>(st, A, tabv, j);
-            __builtin_amdgcn_sched_barrier(0);
-            load_half<0>(A, row, pitch, j + 1 < n_chunks ? j + 1 : j);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_half<1, kFull, RGB>(st, B, tabv, j);
+            load_half<0>(c, row, pitch, tab, j);
+            compute_half<0, kFull, RGB>(st, c);
+            load_half<1>(c, row, pitch, tab, j);
+            compute_half<1, kFull, RGB>(st, c);
         }
     }
 }
@@ -424,29 +336,33 @@ __device__ __forceinline__ StagedPixel load_pixel(const FilterArgs &a, int x, in
 
 __device__ __forceinline__ void store_pixel(float *slot, int pitch, int i, const StagedPixel &s, float k0, float k1,
                                             bool canon) {
-    // taps outside the image get a NaN corrected mean: they fail every membership comparison
+    // Taps outside the image get a NaN corrected mean: they fail every membership comparison.
+    // RGB: a NaN in any statistic of the pixel -> the same treatment (the gate is a max3, which
+    // would drop a NaN in a single channel).
     const float nan = __builtin_nanf("");
-    const int pofs = ((i & 3) >> 1) * pitch + (i >> 2) * 4 + (i & 1) * 2;  // within a pair plane
-    auto pair = [&](int k, float c0, float c1) {
-        *reinterpret_cast<v2f *>(slot + 2 * k * pitch + pofs) = v2f{c0, c1};
-    };
-    // RGB: a NaN in any statistic of the pixel -> NaN in every channel of its mean (the gate uses max3)
     const bool v = s.valid && (!canon || (s.mc.x == s.mc.x && s.mc.y == s.mc.y && s.mc.z == s.mc.z &&
                                          s.d.x == s.d.x && s.d.y == s.d.y && s.d.z == s.d.z));
-    pair(K_G01, v ? s.g0.x * k0 : 0.f, v ? s.g0.y * k0 : 0.f);
-    pair(K_G2A0, v ? s.g0.z * k0 : 0.f, v ? s.g1.x * k1 : 0.f);
-    pair(K_A12, v ? s.g1.y * k1 : 0.f, v ? s.g1.z * k1 : 0.f);
-    pair(K_MC01, v ? s.mc.x : nan, v ? s.mc.y : nan);
-    pair(K_ND01, v ? -s.d.x : 0.f, v ? -s.d.y : 0.f);
-    pair(K_COL01, v ? s.col.x : 0.f, v ? s.col.y : 0.f);
-    slot[(12 + S_MC2) * pitch + i] = v ? s.mc.z : nan;
-    slot[(12 + S_ND2) * pitch + i] = v ? -s.d.z : 0.f;
-    slot[(12 + S_COL2) * pitch + i] = v ? s.col.z : 0.f;
+    float *p = slot + i;
+    p[(C_G0 + 0) * pitch] = v ? s.g0.x * k0 : 0.f;
+    p[(C_G0 + 1) * pitch] = v ? s.g0.y * k0 : 0.f;
+    p[(C_G0 + 2) * pitch] = v ? s.g0.z * k0 : 0.f;
+    p[(C_G1 + 0) * pitch] = v ? s.g1.x * k1 : 0.f;
+    p[(C_G1 + 1) * pitch] = v ? s.g1.y * k1 : 0.f;
+    p[(C_G1 + 2) * pitch] = v ? s.g1.z * k1 : 0.f;
+    p[(C_MC + 0) * pitch] = v ? s.mc.x : nan;
+    p[(C_MC + 1) * pitch] = v ? s.mc.y : nan;
+    p[(C_MC + 2) * pitch] = v ? s.mc.z : nan;
+    p[(C_ND + 0) * pitch] = v ? -s.d.x : 0.f;
+    p[(C_ND + 1) * pitch] = v ? -s.d.y : 0.f;
+    p[(C_ND + 2) * pitch] = v ? -s.d.z : 0.f;
+    p[(C_COL + 0) * pitch] = v ? s.col.x : 0.f;
+    p[(C_COL + 1) * pitch] = v ? s.col.y : 0.f;
+    p[(C_COL + 2) * pitch] = v ? s.col.z : 0.f;
 }
 
 // RT > 0: compile-time radius (window edges resolved statically); RT == 0: runtime radius
 // a.radius <= 20, every pair of every read group evaluated, the table masks taps beyond r.
-template <int RT, bool RGB, int ABL = 0>
+template <int RT, bool RGB>
 __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int r = RT > 0 ? RT : a.radius;
@@ -454,7 +370,9 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
     const int pitch = kTileW + 2 * rp;
     const int n_chunks = 2 * rp / 4 + 1;
     const int tw = tab_width(rp);
+    const int tw_pad = tw + 1;  // 2*rp + 8 floats: b128-aligned rows of the spatial table in LDS
     const int slot_floats = kCh * pitch;
+    float *tab_lds = lds + kSlots * slot_floats;  // two buffers: this window row's exponents / the next one's
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -504,18 +422,15 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
             g0 = reinterpret_cast<const f3 *>(a.g[0].data)[p];
             g1 = reinterpret_cast<const f3 *>(a.g[1].data)[p];
         }
-        st.pg[0][k] = v2f{g0.x * k0, g0.y * k0};
-        st.pg[1][k] = v2f{g0.z * k0, g1.x * k1};
-        st.pg[2][k] = v2f{g1.y * k1, g1.z * k1};
-        st.pmc01[k] = v2f{mc.x, mc.y};
-        st.pmc2[k] = mc.z;
-        st.pd01[k] = v2f{d.x, d.y};
-        st.pd2[k] = d.z;
-        st.sw[k] = 0.f;
-        st.acc01[k] = v2f{0.f, 0.f};
-        st.acc2[k] = 0.f;
-        st.sw01[k] = v2f{0.f, 0.f};
-        st.sw2[k] = 0.f;
+        st.pg[k][0] = g0.x * k0; st.pg[k][1] = g0.y * k0; st.pg[k][2] = g0.z * k0;
+        st.pg[k][3] = g1.x * k1; st.pg[k][4] = g1.y * k1; st.pg[k][5] = g1.z * k1;
+        st.pmc[k][0] = mc.x; st.pmc[k][1] = mc.y; st.pmc[k][2] = mc.z;
+        st.pd[k][0] = d.x; st.pd[k][1] = d.y; st.pd[k][2] = d.z;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            st.acc[k][ch] = v2f{0.f, 0.f};
+            st.sw[k][ch] = v2f{0.f, 0.f};
+        }
     }
 
     // ---- prologue: window rows rel = s0 .. s0+kTileH-1 (image rows y0-r+rel) into slots 0..7
@@ -524,9 +439,8 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
         const StagedPixel s = load_pixel<RGB>(a, x0 - rp + i, y0 - r + s0 + rel);
         store_pixel(lds + rel * slot_floats, pitch, i, s, k0, k1, RGB);
     }
+    if ((int)threadIdx.x < tw_pad) tab_lds[threadIdx.x] = (int)threadIdx.x < tw ? a.spatial_tab[s0 * tw + threadIdx.x] : 0.f;
     __syncthreads();
-    // spatial exponents of window row s0, one per lane (tw <= 47 < 64)
-    float tabv = lane < tw ? a.spatial_tab[s0 * tw + lane] : 0.f;
 
     // ---- sweep the window rows; wave w works on staged row rel = w + step
     int slot = wave;  // (wave + step - s0) % kSlots
@@ -538,20 +452,16 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
         nxt.valid = false;
         if (stage) nxt = load_pixel<RGB>(a, x0 - rp + (int)threadIdx.x, y0 - r + step + kTileH);
 
-        // prefetch the spatial exponents of the next window row
-        float tab_next = 0.f;
-        if (step + 1 < s1 && lane < tw) tab_next = a.spatial_tab[(step + 1) * tw + lane];
+        // the spatial exponents of the next window row go to the other table buffer (last wave's lanes)
+        const int ti = (int)threadIdx.x - (kThreads - 64);
+        const bool tstage = step + 1 < s1 && ti >= 0 && ti < tw_pad;
+        float tnext = 0.f;
+        if (tstage && ti < tw) tnext = a.spatial_tab[(step + 1) * tw + ti];
 
         const float *row = lds + slot * slot_floats + kPx * lane;
-        // Waves w and w+4 share a SIMD and run the same instruction stream: released together by the
-        // barrier they would read LDS together and then contend for the VALU together.  Holding the
-        // second half back for a fraction of a read group makes one wave's LDS wait fall into the
-        // other's compute phase.
-        if (wave >= 4)
-            for (int i = 0; i < a.stagger; i++) __builtin_amdgcn_s_sleep(1);  // 64 cycles each
-        eval_row<RT, RGB, ABL>(st, row, pitch, tabv, n_chunks);
-        tabv = tab_next;
+        eval_row<RT, RGB>(st, row, pitch, tab_lds + ((step - s0) & 1) * tw_pad, n_chunks);
 
+        if (tstage) tab_lds[((step - s0 + 1) & 1) * tw_pad + ti] = tnext;
         if (stage) store_pixel(lds + fill * slot_floats, pitch, threadIdx.x, nxt, k0, k1, RGB);
         __syncthreads();
         slot = slot + 1 == kSlots ? 0 : slot + 1;
@@ -566,24 +476,28 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
             const int ox = x0 + kPx * lane + k;
             if (ox < a.rx1) {
                 const long long p = (long long)oy * a.width + ox;
+                float acc[3], sw[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    acc[ch] = st.acc[k][ch].x + st.acc[k][ch].y;
+                    sw[ch] = st.sw[k][ch].x + st.sw[k][ch].y;
+                }
                 if constexpr (RGB) {
                     if (a.n_parts > 1) {  // partial sums; combine_parts_kernel finishes the pixel
                         reinterpret_cast<float4 *>(a.partial)[(long long)part * a.width * a.height + p] =
-                            make_float4(st.acc01[k].x, st.acc01[k].y, st.acc2[k], st.sw[k]);
+                            make_float4(acc[0], acc[1], acc[2], sw[0]);
                         continue;
                     }
                     f3 o;
-                    if (st.sw[k] > 0.f) {
-                        o.x = st.acc01[k].x / st.sw[k];
-                        o.y = st.acc01[k].y / st.sw[k];
-                        o.z = st.acc2[k] / st.sw[k];
+                    if (sw[0] > 0.f) {
+                        o.x = acc[0] / sw[0];
+                        o.y = acc[1] / sw[0];
+                        o.z = acc[2] / sw[0];
                     } else {
                         o = a.packed ? reinterpret_cast<const f3 *>(a.packed + p * 15)[2] : reinterpret_cast<const f3 *>(a.colour)[p];
                     }
                     reinterpret_cast<f3 *>(a.out)[p] = o;
                 } else {
-                    const float acc[3] = {st.acc01[k].x, st.acc01[k].y, st.acc2[k]};
-                    const float sw[3] = {st.sw01[k].x, st.sw01[k].y, st.sw2[k]};
                     if (a.n_parts > 1) {  // two float4 per (part, pixel): sums, then weights
                         float4 *dst = reinterpret_cast<float4 *>(a.partial) + 2 * ((long long)part * a.width * a.height + p);
                         dst[0] = make_float4(acc[0], acc[1], acc[2], 0.f);
@@ -693,13 +607,13 @@ void set_filter_stagger(int v) { g_stagger = v; }
 void set_filter_ablation(int v) { g_ablation = v; }
 void set_filter_parts_override(int k) { g_parts_override = k; }
 
-template <int RT, bool RGB, int ABL = 0>
+template <int RT, bool RGB>
 static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
     const int rp = RT > 0 ? round_up4(RT) : round_up4(a.radius);
-    const size_t lds_bytes = (size_t)kSlots * kCh * (kTileW + 2 * rp) * sizeof(float);
+    const size_t lds_bytes = ((size_t)kSlots * kCh * (kTileW + 2 * rp) + 2 * (2 * rp + 8)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&window_filter_lds<RT, RGB, ABL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&window_filter_lds<RT, RGB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -708,7 +622,7 @@ static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
     if (a.partial == nullptr) a.n_parts = 1;
     a.stagger = g_stagger;
     const dim3 grid(tiles.x * tiles.y * a.n_parts);
-    hipLaunchKernelGGL((window_filter_lds<RT, RGB, ABL>), grid, dim3(kThreads), lds_bytes, s, a);
+    hipLaunchKernelGGL((window_filter_lds<RT, RGB>), grid, dim3(kThreads), lds_bytes, s, a);
     if (a.n_parts > 1) {
         const dim3 cgrid((a.rx1 - a.rx0 + 63) / 64, (a.ry1 - a.ry0 + 3) / 4);
         hipLaunchKernelGGL(combine_parts_kernel<RGB>, cgrid, dim3(256), 0, s, a);
@@ -744,10 +658,6 @@ hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s
         const bool rgb = channels == 3;
         if (a.radius == 20 && g_variant_override != 2) {
             *variant = rgb ? "lds_r20" : "lds_r20_f";
-            if (rgb && g_ablation == 1) { *variant = "lds_r20_ablate_no_lds"; return launch_lds<20, true, 1>(a, s); }
-            if (rgb && g_ablation == 2) { *variant = "lds_r20_ablate_no_valu"; return launch_lds<20, true, 2>(a, s); }
-            if (rgb && g_ablation == 4) { *variant = "lds_r20_ablate_dead_lds_reads"; return launch_lds<20, true, 4>(a, s); }
-            if (rgb && g_ablation == 3) { *variant = "lds_r20_ablate_staging_only"; return launch_lds<20, true, 3>(a, s); }
             return rgb ? launch_lds<20, true>(a, s) : launch_lds<20, false>(a, s);
         }
         *variant = rgb ? "lds_rt" : "lds_rt_f";

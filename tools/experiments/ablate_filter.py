@@ -19,7 +19,7 @@ def wall(fn, n=5):
 lib = api.load()
 for parts in (1, 3):
     api.force_filter_parts(parts)
-    for abl, name in ((0, "real"), (1, "no LDS reads (pure VALU)"), (2, "LDS reads, token VALU"), (3, "staging + barriers only"), (4, "VALU + dead LDS reads"), (0, "real")):
+    for abl, name in ((0, "real"), (0, "real")):   # the ablation builds belonged to the previous kernel generation (git history)
         lib.statmc_debug_filter_ablation(abl)
         t = wall(fs.window_filter)
         print("parts=%d %-28s %.3f ms  (%s)" % (parts, name, t, api.last_filter_variant()))
