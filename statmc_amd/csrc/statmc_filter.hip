@@ -175,11 +175,12 @@ struct LaneState {
 };
 
 // Operands of half a read group: taps 2H, 2H+1 (columns 4*(lane+j) + 2H, +1 of the staged row) of
-// all 15 channels (ds_read_b64 each: consecutive lanes 16 B apart, conflict-free for b64), and the
-// window row's spatial exponents tab[4j .. 4j+7] (two broadcast ds_read_b128).
+// all 15 channels, and the spatial exponents of the 4 (tap pair, pixel) combinations.  The LDS
+// copy of the window row's table holds PAIRS, tabp[t] = (tab[t], tab[t+1]), so the pair for pixel k
+// -- taps at dx and dx+1 -- is one aligned 8-byte broadcast read and needs no register shuffling.
 struct HalfChunk {
     v2f q[kCh];
-    v4f tb[2];
+    v2f tp[kPx];  // tp[k] = (tab[4j + 2H - k + 3], tab[4j + 2H - k + 4])
 };
 
 template <int H>
@@ -187,8 +188,8 @@ __device__ __forceinline__ void load_half(HalfChunk &c, const float *__restrict_
                                           const float *__restrict__ tab, int j) {
 #pragma unroll
     for (int ch = 0; ch < kCh; ch++) c.q[ch] = *reinterpret_cast<const v2f *>(row + ch * pitch + 4 * j + 2 * H);
-    c.tb[0] = *reinterpret_cast<const v4f *>(tab + 4 * j);
-    c.tb[1] = *reinterpret_cast<const v4f *>(tab + 4 * j + 4);
+#pragma unroll
+    for (int k = 0; k < kPx; k++) c.tp[k] = *reinterpret_cast<const v2f *>(tab + 2 * (4 * j + 2 * H - k + 3));
 }
 
 // Taps 2H and 2H+1 of the read group against the lane's 4 pixels: 4 tap-pair evaluations, written
@@ -207,7 +208,6 @@ __device__ __forceinline__ void compute_half(LaneState &st, const HalfChunk &c) 
     auto in1 = [](int k) { return (MASK & (1u << ((i0 + 1) * 4 + k))) != 0; };
     auto on = [&](int k) { return in0(k) || in1(k); };
     const v2f *q = c.q;
-    const float tb[8] = {c.tb[0].x, c.tb[0].y, c.tb[0].z, c.tb[0].w, c.tb[1].x, c.tb[1].y, c.tb[1].z, c.tb[1].w};
 
     v2f e[kPx], u[kPx][3], w[kPx];
     // range weight exponent: tab - |k_n dn|^2 - |k_a da|^2 for both taps at once
@@ -219,7 +219,7 @@ __device__ __forceinline__ void compute_half(LaneState &st, const HalfChunk &c) 
         for (int k = 0; k < kPx; k++) if (on(k)) { const v2f d = st.pg[k][ch] - q[C_G0 + ch]; e[k] = __builtin_elementwise_fma(-d, d, e[k]); }
     }
 #pragma unroll
-    for (int k = 0; k < kPx; k++) if (on(k)) e[k] += v2f{tb[i0 - k + 3], tb[i0 - k + 4]};
+    for (int k = 0; k < kPx; k++) if (on(k)) e[k] += c.tp[k];
     // membership statistic per channel: t_c = fma(d_c, d_c, -D_q,c)  (the oracle's expression)
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
     const int pitch = kTileW + 2 * rp;
     const int n_chunks = 2 * rp / 4 + 1;
     const int tw = tab_width(rp);
-    const int tw_pad = tw + 1;  // 2*rp + 8 floats: b128-aligned rows of the spatial table in LDS
+    const int tw_pad = 2 * (tw + 1);  // pairs (tab[t], tab[t+1]) for t = 0 .. tw-1, + one pad pair
     const int slot_floats = kCh * pitch;
     float *tab_lds = lds + kSlots * slot_floats;  // two buffers: this window row's exponents / the next one's
 
@@ -439,7 +439,10 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
         const StagedPixel s = load_pixel<RGB>(a, x0 - rp + i, y0 - r + s0 + rel);
         store_pixel(lds + rel * slot_floats, pitch, i, s, k0, k1, RGB);
     }
-    if ((int)threadIdx.x < tw_pad) tab_lds[threadIdx.x] = (int)threadIdx.x < tw ? a.spatial_tab[s0 * tw + threadIdx.x] : 0.f;
+    if ((int)threadIdx.x < tw) {
+        const float *t = a.spatial_tab + s0 * tw + threadIdx.x;
+        *reinterpret_cast<v2f *>(tab_lds + 2 * threadIdx.x) = v2f{t[0], (int)threadIdx.x + 1 < tw ? t[1] : 0.f};
+    }
     __syncthreads();
 
     // ---- sweep the window rows; wave w works on staged row rel = w + step
@@ -454,14 +457,17 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
 
         // the spatial exponents of the next window row go to the other table buffer (last wave's lanes)
         const int ti = (int)threadIdx.x - (kThreads - 64);
-        const bool tstage = step + 1 < s1 && ti >= 0 && ti < tw_pad;
-        float tnext = 0.f;
-        if (tstage && ti < tw) tnext = a.spatial_tab[(step + 1) * tw + ti];
+        const bool tstage = step + 1 < s1 && ti >= 0 && ti < tw;
+        v2f tnext = v2f{0.f, 0.f};
+        if (tstage) {
+            const float *t = a.spatial_tab + (step + 1) * tw + ti;
+            tnext = v2f{t[0], ti + 1 < tw ? t[1] : 0.f};
+        }
 
         const float *row = lds + slot * slot_floats + kPx * lane;
         eval_row<RT, RGB>(st, row, pitch, tab_lds + ((step - s0) & 1) * tw_pad, n_chunks);
 
-        if (tstage) tab_lds[((step - s0 + 1) & 1) * tw_pad + ti] = tnext;
+        if (tstage) *reinterpret_cast<v2f *>(tab_lds + ((step - s0 + 1) & 1) * tw_pad + 2 * ti) = tnext;
         if (stage) store_pixel(lds + fill * slot_floats, pitch, threadIdx.x, nxt, k0, k1, RGB);
         __syncthreads();
         slot = slot + 1 == kSlots ? 0 : slot + 1;
@@ -610,7 +616,7 @@ void set_filter_parts_override(int k) { g_parts_override = k; }
 template <int RT, bool RGB>
 static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
     const int rp = RT > 0 ? round_up4(RT) : round_up4(a.radius);
-    const size_t lds_bytes = ((size_t)kSlots * kCh * (kTileW + 2 * rp) + 2 * (2 * rp + 8)) * sizeof(float);
+    const size_t lds_bytes = ((size_t)kSlots * kCh * (kTileW + 2 * rp) + 4 * (2 * rp + 8)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&window_filter_lds<RT, RGB>),
