@@ -10,26 +10,27 @@
 //  * window_filter_lds<R, RGB>  -- the hot kernel.  Two 3-channel G-buffers (the shipped
 //    configuration: filtering under normal + albedo), radius <= 20; RGB = true is filter<float3>
 //    (one RGB buffer), RGB = false is filter<float> (three 1-channel buffers per launch).
-//    This is a stencil, not a contraction: 1681 taps x 20 fp32 VALU instructions per pixel
+//    This is a stencil, not a contraction: 1681 taps x 17 fp32 VALU instructions per pixel
 //    against 72 B of compulsory HBM traffic, so the design goal is VALU issue rate, with LDS as
 //    the operand feed:
 //      - a 512-thread workgroup (8 waves = 2 per SIMD) owns a 256 x 8 output tile; each wave owns
 //        one row, each lane 4 adjacent pixels of it;
-//      - the 15 per-pixel floats a tap needs (corrected mean 3, -discriminator 3, scaled
-//        normal 3, scaled albedo 3, colour 3) are staged in LDS as channel-pair planes, one
-//        image row at a time, in a ring of 9 rows (8 live + 1 being filled) -- the full
-//        (256+40) x (8+40) halo would need 850 KB, the ring needs 156 KB of the CU's 160 KB;
-//      - per window row a lane reads its 44-column span in 11 read groups (12 ds_read_b128 of
-//        channel pairs + 3 of single channels, conflict-free: consecutive lanes read
-//        consecutive 16 B) and evaluates 4 taps x 4 pixels per group in registers, so every
-//        LDS value is used 4 times; channel pairs go through v_pk_add/mul/fma_f32;
-//      - G-buffers are pre-multiplied by sqrt(-DR_g * log2 e) when staged; the spatial term of
-//        the current window row sits in one VGPR across the wave's lanes and is fetched with
-//        v_readlane, so the range weight is 3 x (pk_sub, pk_mul|pk_fma) + 2 adds + v_exp_f32;
+//      - the 15 per-pixel floats a tap needs (scaled normal 3, scaled albedo 3, corrected mean 3,
+//        -discriminator 3, colour 3) are staged in LDS as 15 channel planes, one image row at a
+//        time, in a ring of 9 rows (8 live + 1 being filled) -- the full (256+40) x (8+40) halo
+//        would need 850 KB, the ring needs 156 KB of the CU's 160 KB;
+//      - per window row a lane reads its 44-column span in 11 read groups of 15 ds_read_b128
+//        (conflict-free: consecutive lanes read consecutive 16 B) and evaluates 4 taps x 4 pixels
+//        per group in registers, so every LDS value is used 4 times;
+//      - the work is done on TAP PAIRS with v_pk_add/mul/fma_f32 (both taps of a pair per
+//        instruction, the pixel's own value broadcast through op_sel): 17 instructions per
+//        (tap, pixel) pair.  G-buffers are pre-multiplied by sqrt(-DR_g * log2 e) when staged and
+//        the spatial term comes from a pairs table of the window row kept in LDS, so the range
+//        weight is 6 x (pk_sub, pk_mul|pk_fma) + pk_add per tap pair and one v_exp_f32 per tap;
 //      - membership keeps the oracle's arithmetic t_c = fma(d_c, d_c, -D_q,c) and tests
 //        max_c (t_c - D_p,c) <= 0 (same truth value as AND_c t_c <= D_p,c, no scalar-unit
-//        round trip); the work is written stage by stage across the 8 pairs of a half group so
-//        every dependent step is followed by independent instructions;
+//        round trip); the work is written stage by stage across the lane's 4 pixels so every
+//        dependent step is followed by independent instructions;
 //      - the window rows of a tile are split over `parts` workgroups (load balance of the
 //        1-workgroup-per-CU grid) whose partial sums combine_parts_kernel adds up; work items
 //        are remapped so that each XCD's L2 sees one contiguous range of tiles.
