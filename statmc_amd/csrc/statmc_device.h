@@ -34,10 +34,15 @@ struct AccumulateType {
     long long n_elems;  // width*height*channels
     int channels, n_samples, transform, max_moment;
 };
+constexpr int kMaxSlots = 32;
 struct AccumulateArgs {
     AccumulateType t[kMaxStatTypes];
     int n_types;
     int resident_blocks;  // 0: large interleaved grid; > 0: that many workgroups walk all types
+    // large grid: workgroup b serves slot b % n_slots; slots are dealt to types in proportion to cost
+    int n_slots;
+    int type_slots[kMaxStatTypes];
+    unsigned char slot_type[kMaxSlots], slot_rank[kMaxSlots];
 };
 
 struct MergeTilesArgs {

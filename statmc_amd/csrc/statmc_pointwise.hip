@@ -331,13 +331,42 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(AccumulateArgs a) {
         }
         return;
     }
-    const AccumulateType &t = a.t[blockIdx.x % a.n_types];
-    const long long blk = blockIdx.x / a.n_types, nblk = gridDim.x / a.n_types;
+    // Workgroups are dealt to the stat types in rounds of n_slots, each type holding a number of
+    // slots proportional to its cost (bytes per pixel, radiance weighted up for its ALU work), so
+    // that all types finish together instead of leaving the expensive one to run on alone.
+    const int slot = blockIdx.x % a.n_slots, round = blockIdx.x / a.n_slots, n_rounds = gridDim.x / a.n_slots;
+    const int ti = a.slot_type[slot];
+    const AccumulateType &t = a.t[ti];
+    const long long blk = (long long)round * a.type_slots[ti] + a.slot_rank[slot];
+    const long long nblk = (long long)n_rounds * a.type_slots[ti];
     if (t.channels == 3) accumulate_dispatch<3, VEC>(t, blk, nblk);
     else accumulate_dispatch<1, VEC>(t, blk, nblk);
 }
 
-hipError_t launch_accumulate(const AccumulateArgs &a, hipStream_t s) {
+hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
+    AccumulateArgs a = a_in;
+    // slots per type ~ relative cost: 4 B x channels per sample, x1.3 for transform types
+    a.n_slots = 0;
+    for (int i = 0; i < a.n_types; i++) {
+        int w = a.t[i].channels * (a.t[i].transform ? 4 : 3);  // 12 / 9 / 3 (rgb transform / rgb / float)
+        w = (w + 2) / 3;                                       // 4 / 3 / 1 slots
+        if (w < 1) w = 1;
+        a.type_slots[i] = w;
+        for (int r = 0; r < w && a.n_slots < kMaxSlots; r++) {
+            a.slot_type[a.n_slots] = (unsigned char)i;
+            a.slot_rank[a.n_slots] = (unsigned char)r;
+            a.n_slots++;
+        }
+    }
+    // interleave the slots of different types (round-robin over types) so neighbours differ
+    {
+        unsigned char st[kMaxSlots], sr[kMaxSlots];
+        int n = 0;
+        for (int r = 0; n < a.n_slots; r++)
+            for (int i = 0; i < a.n_types; i++)
+                if (r < a.type_slots[i]) { st[n] = (unsigned char)i; sr[n] = (unsigned char)r; n++; }
+        for (int k = 0; k < a.n_slots; k++) { a.slot_type[k] = st[k]; a.slot_rank[k] = sr[k]; }
+    }
     bool vec = true;
     long long max_groups = 1;
     for (int i = 0; i < a.n_types; i++) {
@@ -349,7 +378,8 @@ hipError_t launch_accumulate(const AccumulateArgs &a, hipStream_t s) {
         const long long groups = (t.n_elems / t.channels + 3) / 4;
         if (groups > max_groups) max_groups = groups;
     }
-    const dim3 grid(a.resident_blocks > 0 ? a.resident_blocks : grid_for(max_groups, 256 * 8) * a.n_types);
+    const int rounds = (grid_for(max_groups, 256 * 8) * a.n_types + a.n_slots - 1) / a.n_slots;
+    const dim3 grid(a.resident_blocks > 0 ? a.resident_blocks : rounds * a.n_slots);
     if (vec)
         hipLaunchKernelGGL(accumulate_kernel<true>, grid, dim3(kBlock), 0, s, a);
     else
