@@ -12,7 +12,7 @@ with every input already resident in HBM when the timed region starts.
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 1920x1080 film,
 256 spp, 11-channel sample stream, shipped filter parameters (filtersd 10, filterradius 20,
 normal sd 0.1, albedo sd 0.02).  For N > 1 every rank owns one 1920x1080 block of an
-N-block film (2x1, 2x2, 4x2 blocks) -- weak scaling, value = all blocks' pixels / step time.
+N-block film (1xN row strips by default, --grid blocks for 2x1 / 2x2 / 4x2) -- weak scaling, value = all blocks' pixels / step time.
 
 Prints ONE JSON line (rank 0).
 """
@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--radius", type=int, default=20)
     ap.add_argument("--filtersd", type=float, default=10.0)
     ap.add_argument("--channels", type=int, default=11, choices=(9, 11))
+    ap.add_argument("--grid", default="rows", choices=("rows", "blocks"),
+                    help="N > 1: rows = 1xN strips of full-width blocks (contiguous halo rows, default); "
+                         "blocks = 2x1 / 2x2 / 4x2 grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo (+ --share-device) exercises the N > 1 code path on a 1-GPU box; halos go via the host")
@@ -208,7 +211,8 @@ def main():
 
     W, H, S, r = args.width, args.height, args.spp, args.radius
     types = list(synthetic.FEATURES) if args.channels == 11 else ["radiance", "normal", "albedo"]
-    layout = sharding.BlockLayout(rank, world, W, H, r)
+    grid = sharding.row_strips(world) if args.grid == "rows" else sharding.grid_for(world)
+    layout = sharding.BlockLayout(rank, world, W, H, r, grid=grid)
     fw, fh = layout.film_size
     ox, oy = layout.origin
 

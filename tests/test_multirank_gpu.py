@@ -25,15 +25,20 @@ BW, BH, SPP, RADIUS = 272, 40, 6, 20
 TYPES = ("radiance", "normal", "albedo")
 
 
-def _film_samples(world):
+def _grid(world, rows):
+    from statmc_amd import sharding
+    return sharding.row_strips(world) if rows else sharding.grid_for(world)
+
+
+def _film_samples(world, rows):
     """Whole-film sample stream, identical in every process (CPU generator, fixed seed)."""
-    from statmc_amd import sharding, synthetic
-    gx, gy = sharding.grid_for(world)
+    from statmc_amd import synthetic
+    gx, gy = _grid(world, rows)
     scene = synthetic.Scene(gx * BW, gy * BH, n_regions=9, seed=21)
     return scene.samples(SPP, seed=22, features=TYPES)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, rows, port, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch.distributed as dist
@@ -42,7 +47,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        _run(rank, world, q, dist, api, pipeline, sharding)
+        _run(rank, world, rows, q, dist, api, pipeline, sharding)
     except Exception as e:                      # report instead of leaving the parent waiting
         q.put((rank, "error", repr(e), None))
         raise
@@ -50,14 +55,14 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _run(rank, world, q, dist, api, pipeline, sharding):
+def _run(rank, world, rows, q, dist, api, pipeline, sharding):
     if True:
         dev = torch.device("cuda:0")
         api.setup(0)
         api.force_filter_parts(2)            # same window-row split as the single-process run
-        L = sharding.BlockLayout(rank, world, BW, BH, RADIUS)
+        L = sharding.BlockLayout(rank, world, BW, BH, RADIUS, grid=_grid(world, rows))
         ox, oy = L.origin
-        smp = {k: v[:, oy:oy + BH, ox:ox + BW].contiguous().to(dev) for k, v in _film_samples(world).items()}
+        smp = {k: v[:, oy:oy + BH, ox:ox + BW].contiguous().to(dev) for k, v in _film_samples(world, rows).items()}
         pipe = pipeline.BlockPipeline(L, dev, TYPES, radius=RADIUS, via_host=True)
         pipe.accumulate(smp)
         out = pipe.denoise().clone()
@@ -66,12 +71,12 @@ def _run(rank, world, q, dist, api, pipeline, sharding):
         dist.barrier()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_blocks_equal_whole_film(gpu, world):
+@pytest.mark.parametrize("world,rows", [(2, False), (4, False), (3, True)], ids=["2x1", "2x2", "1x3-rows"])
+def test_blocks_equal_whole_film(gpu, world, rows):
     from statmc_amd import pipeline, sharding
     dev = torch.device("cuda:0")
-    gx, gy = sharding.grid_for(world)
-    whole = _film_samples(world)
+    gx, gy = _grid(world, rows)
+    whole = _film_samples(world, rows)
     gpu.force_filter_parts(2)
     try:
         one = pipeline.BlockPipeline(sharding.BlockLayout(0, 1, gx * BW, gy * BH, RADIUS), dev, TYPES, radius=RADIUS)
@@ -82,7 +87,7 @@ def test_blocks_equal_whole_film(gpu, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(rk, world, port, q)) for rk in range(world)]
+    procs = [ctx.Process(target=_worker, args=(rk, world, rows, port, q)) for rk in range(world)]
     for p in procs:
         p.start()
     got = []

@@ -18,7 +18,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, bw, bh, r, q):
+def _worker(rank, world, port, bw, bh, r, rows, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle import oracle
@@ -27,7 +27,7 @@ def _worker(rank, world, port, bw, bh, r, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        L = sharding.BlockLayout(rank, world, bw, bh, r)
+        L = sharding.BlockLayout(rank, world, bw, bh, r, grid=sharding.row_strips(world) if rows else None)
         fw, fh = L.film_size
         rng = np.random.default_rng(123)                      # every rank builds the same film
         film = {
@@ -62,12 +62,12 @@ def _worker(rank, world, port, bw, bh, r, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,bw,bh,r", [(2, 24, 18, 5), (4, 16, 14, 6)])
-def test_halo_exchange_and_block_filter(world, bw, bh, r):
+@pytest.mark.parametrize("world,bw,bh,r,rows", [(2, 24, 18, 5, False), (4, 16, 14, 6, False), (3, 20, 9, 4, True)])
+def test_halo_exchange_and_block_filter(world, bw, bh, r, rows):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(rk, world, port, bw, bh, r, q)) for rk in range(world)]
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, bw, bh, r, rows, q)) for rk in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -85,5 +85,8 @@ def test_layouts():
     assert (L.bx, L.by) == (1, 1) and (L.left, L.right, L.up, L.down) == (4, 6, 1, None)
     assert (L.pw, L.ph) == (1960, 1100) and L.roi == (20, 20, 1940, 1100)
     assert L.film_size == (7680, 2160) and L.origin == (1920, 1080)
+    S = sharding.BlockLayout(3, 8, 1920, 1080, 20, grid=sharding.row_strips(8))   # bench.py's default grid
+    assert (S.left, S.right, S.up, S.down) == (None, None, 2, 4) and (S.pw, S.ph) == (1920, 1120)
+    assert S.film_size == (1920, 8640) and S.origin == (0, 3240) and S.roi == (0, 20, 1920, 1100)
     one = sharding.BlockLayout(0, 1, 1920, 1080, 20)
     assert (one.pw, one.ph) == (1920, 1080) and one.roi == (0, 0, 1920, 1080)
