@@ -114,6 +114,13 @@ namespace stat_denoiser {
 
 inline void setup(int device = 0) { check(statmc_setup(device)); }
 inline void synchronize(Stream &s) { check(statmc_synchronize(s.handle())); }
+// The reference fixes the significance level at compile time by choosing one of three
+// `t_quantiles` tables (README.md:149,158); here it is a run-time setting: 0 -> 0.005 (default),
+// 1 -> 0.002, 2 -> 0.05, and a table can be replaced by the caller's own quantiles (dof 1..n).
+inline void setSignificance(int alphaIndex) { check(statmc_set_significance(alphaIndex)); }
+inline void setTQuantiles(int alphaIndex, const std::vector<float> &q) {
+    check(statmc_set_t_quantiles(alphaIndex, q.data(), (int)q.size()));
+}
 
 namespace detail {
 inline std::vector<statmc_image> descs(const std::vector<DeviceImage> &v) {

@@ -34,3 +34,39 @@ def test_dump_to_denoised_image(gpu, tmp_path, path):
     assert np.array_equal(pfm.read_pfm("%s-%d-t0-b0-discriminator.pfm" % (stem, spp)), g["discriminator"])
     for c in range(3):
         assert rel_l2(film_f[..., c], g["film_f"][..., c]) <= 1e-5
+
+
+def test_compare_against_reference_dumps_and_custom_quantiles(gpu, tmp_path):
+    """--compare: the route by which real StatMC output dumps (film-f written by the CUDA build) are
+    checked against this build -- here the golden outputs stand in for them.  --tquantiles loads a
+    caller's t table; with the built-in table written to a file the result must not change."""
+    import re
+    from statmc_amd import build, pfm
+    from oracle import oracle
+    exe = build.build_tools()
+    g = np.load(GOLDEN[0])
+    spp = int(g["spp"])
+    stem, ref = str(tmp_path / "scene"), str(tmp_path / "ref")
+    dump = {"film": g["film_mean"], "t0-b0-n": g["n"], "t0-b0-mean": g["mean"], "t0-b0-m2": g["m2"],
+            "t0-b0-m3": g["m3"], "t1-b0-film-mean": g["normal_mean"], "t2-b0-film-mean": g["albedo_mean"]}
+    for name, img in dump.items():
+        pfm.write_pfm("%s-%d-%s.pfm" % (stem, spp, name), img)
+    pfm.write_pfm("%s-%d-film-f.pfm" % (ref, spp), g["film_f"])
+    pfm.write_pfm("%s-%d-t0-b0-discriminator.pfm" % (ref, spp), g["discriminator"])
+    table = tmp_path / "tq.txt"
+    table.write_text("\n".join("%.9g" % oracle.t_quantile(0, dof) for dof in range(1, 4097)))
+    base = [exe, "--stem", stem, "--spp", str(spp), "--filtersd", str(float(g["filter_sd"])), "--filterradius",
+            str(int(g["radius"])), "--output", "film-f,t0-b0-discriminator", "--compare", ref]
+    for extra in ([], ["--tquantiles", str(table)]):
+        out = subprocess.run(base + extra, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        errs = {(m.group(1), int(m.group(2))): float(m.group(3))
+                for m in re.finditer(r"compare (\S+) ch(\d) rel_l2 (\S+)", out.stdout)}
+        assert set(errs) == {("film-f", 0), ("film-f", 1), ("film-f", 2)} | {("t0-b0-discriminator", c) for c in range(3)}
+        assert all(errs[("t0-b0-discriminator", c)] == 0.0 for c in range(3))
+        assert all(errs[("film-f", c)] <= 1e-5 for c in range(3))
+    # a different table must change the discriminator (the option is live)
+    table.write_text("\n".join("%.9g" % (2.0 * oracle.t_quantile(0, dof)) for dof in range(1, 4097)))
+    out = subprocess.run(base + ["--tquantiles", str(table)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert float(re.search(r"compare t0-b0-discriminator ch0 rel_l2 (\S+)", out.stdout).group(1)) > 0.5

@@ -5,6 +5,7 @@
 //   statmc_denoise --stem out/scene --spp 4,8,16 [--filtersd 10] [--filterradius 20]
 //                  [--filterbuffers albedo,normal --filterbuffersds 0.02,0.1]
 //                  [--output 'film-f,t0-b0-mean-corr'] [--warmup]
+//                  [--significance 0|1|2] [--tquantiles table.txt] [--compare other/stem]
 //   statmc_denoise --catalogue [--config denoise|acrr|smis|proden|ours] [--width W --height H]
 //
 // Per iteration it reads "<stem>-<spp>-film.pfm" and every "<stem>-<spp>-t<i>-b<j>-<suffix>.pfm"
@@ -13,9 +14,16 @@
 // reference's "CUDA time [ns]" bracket, statpath.cpp:520-527) and writes the selected buffers as
 // "<stem>-<spp>-<buffer>.pfm".  --catalogue prints the buffer catalogue of a shipped
 // configuration without touching a device (used by the CPU tests).
+// --compare S: after each iteration every written buffer is compared with "S-<spp>-<buffer>.pfm"
+// when that file exists (e.g. film-f / mean-corr / discriminator dumps written by the CUDA
+// StatMC) and the relative L2 error per channel is printed -- the check BASELINE's 1e-5 parity
+// bound is stated in.  --tquantiles loads whitespace-separated t quantiles for dof 1..n into the
+// selected significance slot (for users who have the reference's own tables).
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
 #include <iostream>
 #include <sstream>
 #include <string>
@@ -53,6 +61,28 @@ static void readInto(const std::string &path, Buffer &b) {
     }
 }
 
+// relative L2 error and largest absolute difference per channel of `got` against `want`
+static void compareImages(const std::string &name, const PfmImage &want, int width, int height, int channels,
+                          const float *got) {
+    if (want.width != width || want.height != height || want.channels != channels) {
+        std::printf("compare %s: shape mismatch (%dx%dx%d vs %dx%dx%d)\n", name.c_str(), want.width, want.height,
+                    want.channels, width, height, channels);
+        return;
+    }
+    for (int c = 0; c < channels; c++) {
+        double num = 0, den = 0, worst = 0;
+        for (size_t i = 0; i < (size_t)width * height; i++) {
+            const double a = got[i * channels + c], b = want.data[i * channels + c];
+            if (std::isnan(a) && std::isnan(b)) continue;
+            num += (a - b) * (a - b);
+            den += b * b;
+            worst = std::max(worst, std::fabs(a - b));
+        }
+        std::printf("compare %s ch%d rel_l2 %.6e max_abs %.6e\n", name.c_str(), c, den > 0 ? std::sqrt(num / den) : std::sqrt(num),
+                    worst);
+    }
+}
+
 static StatPathParams shippedConfig(const std::string &name) {
     StatPathParams p;
     p.maxDepth = 65;
@@ -79,7 +109,8 @@ static StatPathParams shippedConfig(const std::string &name) {
 
 int main(int argc, char **argv) {
     try {
-        std::string stem, sppList, output = "film-f", config = "denoise";
+        std::string stem, sppList, output = "film-f", config = "denoise", compareStem, tqFile;
+        int significance = 0;
         StatPathParams params = shippedConfig("denoise");
         bool catalogue = false, warmup = false, configGiven = false;
         int width = 64, height = 48;
@@ -101,6 +132,9 @@ int main(int argc, char **argv) {
             } else if (a == "--config") { config = next(); configGiven = true; }
             else if (a == "--catalogue") catalogue = true;
             else if (a == "--warmup") warmup = true;
+            else if (a == "--compare") compareStem = next();
+            else if (a == "--significance") significance = std::stoi(next());
+            else if (a == "--tquantiles") tqFile = next();
             else if (a == "--width") width = std::stoi(next());
             else if (a == "--height") height = std::stoi(next());
             else throw std::runtime_error("unknown option " + a);
@@ -154,6 +188,15 @@ int main(int argc, char **argv) {
         BufferRegistry reg(film);
         Estimator est(film, cfgs, params.filterSD, params.filterRadius, params.denoiseImage, params.acrr, params.smis, reg);
         est.AllocateBuffers(reg);
+        if (!tqFile.empty()) {
+            std::ifstream in(tqFile);
+            if (!in) throw std::runtime_error("cannot open " + tqFile);
+            std::vector<float> q;
+            for (float v; in >> v;) q.push_back(v);
+            if (q.empty()) throw std::runtime_error(tqFile + ": no quantiles");
+            stat_denoiser::setTQuantiles(significance, q);
+        }
+        stat_denoiser::setSignificance(significance);
         const std::vector<std::string> outputs = split(output);
 
         auto iteration = [&](const std::string &spp, bool write) {
@@ -192,13 +235,17 @@ int main(int argc, char **argv) {
                     b->gpuMat.download(host, est.stream);
                     est.Synchronize();
                 }
+                std::vector<float> tmp;
+                const float *pixels = host.type == I32C1 ? nullptr : host.ptr<float>();
                 if (host.type == I32C1) {
-                    std::vector<float> tmp((size_t)width * height);
+                    tmp.resize((size_t)width * height);
                     for (size_t i = 0; i < tmp.size(); i++) tmp[i] = (float)host.ptr<int32_t>()[i];
-                    writePfm(prefix + name + ".pfm", width, height, 1, tmp.data());
-                } else {
-                    writePfm(prefix + name + ".pfm", width, height, host.channels(), host.ptr<float>());
+                    pixels = tmp.data();
                 }
+                writePfm(prefix + name + ".pfm", width, height, host.channels(), pixels);
+                const std::string other = compareStem + "-" + spp + "-" + name + ".pfm";
+                if (!compareStem.empty() && fileExists(other))
+                    compareImages(name, readPfm(other), width, height, host.channels(), pixels);
             }
         };
         if (warmup) {  // --warmup (statpath.cpp:543-547)
