@@ -59,6 +59,53 @@ def test_accumulate_matches_oracle(gpu, oracle, channels, transform, max_moment)
             assert not got[k].any()
 
 
+def test_accumulate_randomised_configurations(gpu, oracle):
+    """30 seeded random launches: film size (down to 1 x 1), 0..19 samples, 1..6 stat types of mixed
+    channel count / transform / max moment in ONE launch, starting from a state with non-uniform
+    per-pixel counts (pixels of one film need not have seen the same number of samples)."""
+    rng = np.random.default_rng(777)
+    for case in range(30):
+        W, H = int(rng.integers(1, 300)), int(rng.integers(1, 24))
+        n_types = int(rng.integers(1, 7))
+        refs, devs, stypes, cfgs, keep = [], [], [], [], []
+        for t in range(n_types):
+            ch = int(rng.choice([1, 3]))
+            transform, mm = bool(rng.integers(0, 2)), int(rng.integers(1, 4))
+            S = int(rng.integers(0, 20))
+            smp = rng.lognormal(0, 1.5, size=(S, H, W, ch)).astype(np.float32)
+            smp[rng.random(smp.shape) < 0.2] = 0.0
+            ref = oracle.new_state(H, W, ch)
+            if rng.random() < 0.5:                          # continue from an earlier, ragged state
+                n0 = rng.integers(0, 40, size=(H, W)).astype(np.int32)
+                ref["n"][...] = n0
+                for k in ("mean", "m2", "m3", "film_mean", "film_m2"):
+                    ref[k][...] = (rng.random(ref[k].shape) * (n0[..., None] > 0)).astype(np.float32).reshape(ref[k].shape)
+                if not transform:
+                    ref["film_mean"][...] = ref["mean"]
+                    ref["film_m2"][...] = ref["m2"]
+            st = dev_state(ref)
+            oracle.accumulate(ref, smp, transform, mm)
+            d_smp = to_dev(smp)
+            keep.append(d_smp)                              # the descriptors hold raw pointers
+            stypes.append(gpu.make_stat_type(d_smp, st, transform, mm))
+            refs.append(ref); devs.append(st); cfgs.append((ch, transform, mm, S))
+        gpu.accumulate(W, H, stypes)
+        torch.cuda.synchronize()
+        for ref, st, cfg in zip(refs, devs, cfgs):
+            ch, transform, mm, S = cfg
+            got = {k: v.cpu().numpy() for k, v in st.items()}
+            assert np.array_equal(got["n"], ref["n"]), (case, cfg)
+            keys = ("mean", "m2", "m3")[:mm]
+            if transform:
+                assert np.array_equal(got["film_mean"], ref["film_mean"]), (case, cfg)
+                assert np.array_equal(got["film_m2"], ref["film_m2"]), (case, cfg)
+                for k in keys:
+                    assert rel_l2(got[k], ref[k]) <= TOL, (case, cfg, k)
+            else:
+                for k in keys:
+                    assert np.array_equal(got[k], ref[k]), (case, cfg, k)
+
+
 def test_exact_division_by_count(gpu, oracle):
     """The kernel divides by the sample count with a refined reciprocal + residual correction
     instead of the IEEE sequence; for this path's operands the quotient must be bit-identical:
