@@ -18,7 +18,21 @@
 // compiled with -ffp-contract=off, so everything except sqrt-vs-pow in the Box-Cox transform
 // rounds identically to the CPU restatement.
 
+#include <type_traits>
+
 #include "statmc_device.h"
+
+// sample rows in flight per lane (x2: current + next group) per kind of stat type; the defaults are
+// the measured optimum (tools/experiments/build_variant.sh sweeps them)
+#ifndef STATMC_ACC_U_RGB_T
+#define STATMC_ACC_U_RGB_T 3
+#endif
+#ifndef STATMC_ACC_U_RGB
+#define STATMC_ACC_U_RGB 3
+#endif
+#ifndef STATMC_ACC_U_F
+#define STATMC_ACC_U_F 6
+#endif
 #include "t_quantiles.h"
 
 namespace statmc {
@@ -219,7 +233,7 @@ __device__ __forceinline__ void accumulate_type(const AccumulateType &t, long lo
             // they only coalesce through the cache, so they must be plain loads (non-temporal ones
             // re-fetch the shared lines: 4.8 vs 6.4 TB/s, tools/microbench/hbm_read.hip).  C = 1
             // streams with non-temporal loads.
-            constexpr int U = C == 3 ? 3 : 6;
+            constexpr int U = C == 3 ? (TRANSFORM ? STATMC_ACC_U_RGB_T : STATMC_ACC_U_RGB) : STATMC_ACC_U_F;
             const float *sp = t.samples + e0;
             auto load_sample = [&](vfloat4 (&dst)[C], const float *src) {
 #pragma unroll
@@ -227,40 +241,56 @@ __device__ __forceinline__ void accumulate_type(const AccumulateType &t, long lo
                     dst[k] = C == 1 ? __builtin_nontemporal_load(reinterpret_cast<const vfloat4 *>(src + 4 * k))
                                     : *reinterpret_cast<const vfloat4 *>(src + 4 * k);
             };
-            auto fold_sample = [&](const vfloat4 (&q)[C], int s) {
+            // SAME: the lane's 4 pixels hold the same count (every film whose pixels have seen the
+            // same number of samples, i.e. all but adaptively sampled ones) -> one count conversion and
+            // one refined reciprocal per sample instead of four (a fifth of the kernel's VALU work).
+            auto fold_sample = [&](const vfloat4 (&q)[C], int s, auto same) {
                 float nf[4], rc[4];
+                if constexpr (decltype(same)::value) {
+                    const float nf0 = (float)(n0[0] + s + 1);
+                    const float rc0 = refined_rcp(nf0);
 #pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    nf[p] = (float)(n0[p] + s + 1);
-                    rc[p] = refined_rcp(nf[p]);
+                    for (int p = 0; p < 4; p++) { nf[p] = nf0; rc[p] = rc0; }
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        nf[p] = (float)(n0[p] + s + 1);
+                        rc[p] = refined_rcp(nf[p]);
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < NE; j++) add_sample<MAXM, TRANSFORM>(st[j], nf[j / C], rc[j / C], q[j >> 2][j & 3]);
             };
-            vfloat4 cur[U][C], nxt[U][C];
-            const int S_main = S - S % U;
-            if (S_main > 0) {
+            auto walk_samples = [&](auto same) {
+                vfloat4 cur[U][C], nxt[U][C];
+                const int S_main = S - S % U;
+                if (S_main > 0) {
 #pragma unroll
-                for (int u = 0; u < U; u++) load_sample(cur[u], sp + (long long)u * t.n_elems);
-            }
-            for (int s = 0; s < S_main; s += U) {
-                const float *np = sp + (long long)(s + U) * t.n_elems;
-                if (s + U < S_main) {
-#pragma unroll
-                    for (int u = 0; u < U; u++) load_sample(nxt[u], np + (long long)u * t.n_elems);
+                    for (int u = 0; u < U; u++) load_sample(cur[u], sp + (long long)u * t.n_elems);
                 }
+                for (int s = 0; s < S_main; s += U) {
+                    const float *np = sp + (long long)(s + U) * t.n_elems;
+                    if (s + U < S_main) {
 #pragma unroll
-                for (int u = 0; u < U; u++) fold_sample(cur[u], s + u);
+                        for (int u = 0; u < U; u++) load_sample(nxt[u], np + (long long)u * t.n_elems);
+                    }
 #pragma unroll
-                for (int u = 0; u < U; u++)
+                    for (int u = 0; u < U; u++) fold_sample(cur[u], s + u, same);
 #pragma unroll
-                    for (int k = 0; k < C; k++) cur[u][k] = nxt[u][k];
-            }
-            for (int s = S_main; s < S; s++) {  // remainder (S not a multiple of U)
-                vfloat4 q[C];
-                load_sample(q, sp + (long long)s * t.n_elems);
-                fold_sample(q, s);
-            }
+                    for (int u = 0; u < U; u++)
+#pragma unroll
+                        for (int k = 0; k < C; k++) cur[u][k] = nxt[u][k];
+                }
+                for (int s = S_main; s < S; s++) {  // remainder (S not a multiple of U)
+                    vfloat4 q[C];
+                    load_sample(q, sp + (long long)s * t.n_elems);
+                    fold_sample(q, s, same);
+                }
+            };
+            // wave-uniform choice: the fast walk only when every active lane qualifies
+            const bool lane_same = n0[0] == n0[1] && n0[1] == n0[2] && n0[2] == n0[3];
+            if (__builtin_amdgcn_ballot_w64(!lane_same) == 0) walk_samples(std::true_type{});
+            else walk_samples(std::false_type{});
 #define STATMC_STORE_PLANE(ptr, field, enabled)                                  \
     if (enabled) {                                                               \
         _Pragma("unroll") for (int k = 0; k < C; k++)                            \

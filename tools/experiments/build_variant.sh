@@ -1,0 +1,15 @@
+#!/bin/bash
+# build_variant.sh NAME [-DFLAG ...]: libstatmc_hip.so with extra compile flags -> tools/experiments/variants/NAME.so
+set -e
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+NAME=$1; shift
+OUT=$ROOT/tools/experiments/variants
+mkdir -p $OUT/obj_$NAME
+FLAGS="-O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-function"
+for f in statmc_pointwise statmc_filter statmc_abi; do
+  hipcc $FLAGS "$@" -c $ROOT/statmc_amd/csrc/$f.hip -o $OUT/obj_$NAME/$f.o &
+done
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/$NAME.so $OUT/obj_$NAME/*.o
+rm -rf $OUT/obj_$NAME
+echo $OUT/$NAME.so
