@@ -131,6 +131,42 @@ def test_exact_division_by_count(gpu, oracle):
             assert np.array_equal(st[k].cpu().numpy(), ref[k]), (max_moment, n0, k)
 
 
+def test_exact_division_any_count(gpu, oracle):
+    """Same property over the whole range a count can take before float(n) stops being exact:
+    every pixel starts from its own count n0 in [0, 2^24 - 2] (so the update divides by n0 + 1) with
+    a random running mean, and receives two samples.  Ragged counts take the general walk, a second
+    film with one count per 4-pixel group takes the shared-reciprocal walk."""
+    rng = np.random.default_rng(123)
+    H, W = 256, 1024
+    for shared in (False, True):
+        n0 = rng.integers(0, 2 ** 24 - 2, size=(H, W), dtype=np.int64)
+        n0[0, :64] = np.arange(64)                                  # the small counts, too
+        n0[1, :64] = 2 ** 24 - 3 - np.arange(64)
+        n0[2, :25] = 2 ** np.arange(25) - 1                          # divisors that are powers of two
+        n0[2, 24] = 2 ** 24 - 3
+        if shared:
+            n0 = np.repeat(n0[:, ::4], 4, axis=1)
+        smp = rng.lognormal(0, 2.5, size=(2, H, W, 3)).astype(np.float32)
+        smp[rng.random(smp.shape) < 0.1] = 0.0
+        ref = oracle.new_state(H, W, 3)
+        ref["n"][...] = n0.astype(np.int32)
+        for k in ("mean", "film_mean"):
+            ref[k][...] = (rng.standard_normal((H, W, 3)) * 3).astype(np.float32)
+        for k in ("m2", "film_m2"):
+            ref[k][...] = rng.lognormal(0, 2, size=(H, W, 3)).astype(np.float32)
+        ref["m3"][...] = rng.standard_normal((H, W, 3)).astype(np.float32)
+        st = dev_state(ref)
+        oracle.accumulate(ref, smp, True, 3)
+        gpu.accumulate(W, H, [gpu.make_stat_type(to_dev(smp), st, True, 3)])
+        torch.cuda.synchronize()
+        assert np.array_equal(st["n"].cpu().numpy(), ref["n"])
+        # the raw-sample Welford chain has no sqrt in it: every bit must agree
+        for k in ("film_mean", "film_m2"):
+            assert np.array_equal(st[k].cpu().numpy(), ref[k]), (shared, k)
+        for k in ("mean", "m2", "m3"):                              # Box-Cox side: sqrt vs pow
+            assert rel_l2(st[k].cpu().numpy(), ref[k]) <= TOL, (shared, k)
+
+
 def test_accumulate_all_types_one_launch(gpu, oracle):
     """The 11-channel sample vector: radiance, normal, albedo, depth, material id in one launch."""
     from statmc_amd import film, synthetic

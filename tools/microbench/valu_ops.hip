@@ -33,15 +33,23 @@ __global__ void kern(float *out, float a, float b) {
     if (MODE == 13) BODY(asm volatile("v_sub_f32_e32 %0, %0, %1" : "+v"(x[i]) : "v"(y[i])))
     if (MODE == 14) BODY(asm volatile("v_min_f32_e32 %0, %0, %1" : "+v"(x[i]) : "v"(y[i])))
     if (MODE == 15) BODY(asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(y[i]), "v"(b)))
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f px[U], py[U];
+#pragma unroll
+    for (int i = 0; i < U; i++) { px[i] = v2f{x[i], x[i] + 1.f}; py[i] = v2f{y[i], y[i] * 0.5f}; }
+    if (MODE == 16) BODY(asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(px[i]) : "v"(py[i])))
+    if (MODE == 17) BODY(asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(px[i]) : "v"(py[i])))
+    if (MODE == 18) BODY(asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(px[i]) : "v"(py[i])))
+    if (MODE == 19) BODY(asm volatile("v_pk_fma_f32 %0, %0, %2, %2\n\tv_fma_f32 %1, %1, %3, %3" : "+v"(px[i]), "+v"(x[i]) : "v"(py[i]), "v"(y[i])))
     float s = 0;
 #pragma unroll
-    for (int i = 0; i < U; i++) s += x[i];
+    for (int i = 0; i < U; i++) s += x[i] + px[i].x + px[i].y;
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
 template <int MODE>
 void run(const char *name, int instr_per_body) {
-    for (int w : {2, 4}) {
+    for (int w : {1, 2, 4}) {
         const int threads = 64 * 4 * w, blocks = 256;
         float *out;
         CHK(hipMalloc(&out, (size_t)blocks * threads * 4));
@@ -80,5 +88,9 @@ int main() {
     run<10>("v_and_b32", 1);
     run<6>("v_exp_f32", 1);
     run<11>("v_readlane_b32", 1);
+    run<16>("v_pk_fma_f32", 1);
+    run<17>("v_pk_add_f32", 1);
+    run<18>("v_pk_mul_f32", 1);
+    run<19>("v_pk_fma_f32 + v_fma_f32", 2);
     return 0;
 }
