@@ -151,6 +151,19 @@ typedef struct statmc_stat_type {
 int statmc_accumulate(uint16_t width, uint16_t height, const statmc_stat_type *types, int n_types,
                       void *stream);
 
+/* The same accumulation fed tile by tile, the way StatPathIntegrator::Render produces samples
+ * (src/statistics/statpath.cpp:132-190: 16 x 16 tiles; 355-371: every sample of a pixel is handed to
+ * the tile of every stat type; 381-388: Merge*Tiles once per tile and iteration).  Every type's
+ * `samples` is an arena in which tile k owns the block starting at float offset
+ * tile_offsets[k] * channels, laid out [tile_samples[k]][y1-y0][x1-x0][channels]: tile_samples[k]
+ * samples for each pixel of the tile (the same count for every type; 0 = tile untouched).
+ * tile_bounds = {x0,y0,x1,y1} per tile, tiles disjoint and inside the image.  All three tables are
+ * device arrays.  `n_samples` of the types is ignored.  Blocks whose offset, origin and width are
+ * multiples of 4 pixels (16 x 16 tiles of an image whose width is) take the vector path. */
+int statmc_accumulate_tiles(uint16_t width, uint16_t height, const statmc_stat_type *types, int n_types,
+                            const int32_t *tile_bounds, const int64_t *tile_offsets,
+                            const int32_t *tile_samples, int n_tiles, void *stream);
+
 /* Scatter of reference-layout AoS tiles (StatTilePixel<T>, estimator.h:104-124: 64 B for
  * T=float, 128 B for T=Vec3) that were accumulated on the host into the planar device images:
  * Estimator::MergeTile / MergeTransformTile.  tile_bounds = {x0,y0,x1,y1} per tile (device,

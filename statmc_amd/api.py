@@ -54,7 +54,7 @@ EXPORTS = [
     "statmc_malloc", "statmc_free", "statmc_memset", "statmc_upload", "statmc_download",
     "statmc_stream_create", "statmc_stream_destroy", "statmc_synchronize",
     "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs",
-    "statmc_calculate_mean_vars", "statmc_accumulate", "statmc_merge_tiles", "statmc_tile_moments", "statmc_film_update",
+    "statmc_calculate_mean_vars", "statmc_accumulate", "statmc_accumulate_tiles", "statmc_merge_tiles", "statmc_tile_moments", "statmc_film_update",
     "statmc_last_filter_variant", "statmc_version",
 ]
 
@@ -97,6 +97,8 @@ def load():
                                                C.POINTER(Image), C.POINTER(Image), C.POINTER(Image),
                                                C.c_int, C.c_void_p]
     lib.statmc_accumulate.argtypes = [C.c_uint16, C.c_uint16, C.POINTER(StatType), C.c_int, C.c_void_p]
+    lib.statmc_accumulate_tiles.argtypes = [C.c_uint16, C.c_uint16, C.POINTER(StatType), C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_int, C.c_void_p]
     lib.statmc_merge_tiles.argtypes = [C.c_uint16, C.c_uint16, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p]
     lib.statmc_tile_moments.argtypes = [C.c_uint16, C.c_uint16, C.c_int, C.c_void_p, C.c_int,
@@ -257,10 +259,27 @@ def make_stat_type(samples, state, transform, max_moment):
     return t
 
 
+def make_stat_type_arena(arena, channels, state, transform, max_moment):
+    """Stat type whose samples arrive tile by tile (accumulate_tiles): `arena` is a flat fp32 device tensor."""
+    t = make_stat_type(arena.view(1, 1, -1, 1), state, transform, max_moment)
+    t.channels, t.n_samples = int(channels), 0
+    return t
+
+
 def accumulate(width, height, stat_types, stream=None):
     arr = (StatType * max(len(stat_types), 1))(*stat_types)
     check(load().statmc_accumulate(width, height, arr, len(stat_types),
                                    stream if stream is not None else current_stream_handle()))
+
+
+def accumulate_tiles(width, height, stat_types, tile_bounds, tile_offsets, tile_samples, stream=None):
+    """stat_types: make_stat_type(arena, state, ...) per type, `arena` a flat device tensor holding the
+    tiles' sample blocks; tile_bounds int32 [n,4], tile_offsets int64 [n] (pixel-samples),
+    tile_samples int32 [n]: device tensors."""
+    arr = (StatType * max(len(stat_types), 1))(*stat_types)
+    check(load().statmc_accumulate_tiles(width, height, arr, len(stat_types), tile_bounds.data_ptr(),
+                                         tile_offsets.data_ptr(), tile_samples.data_ptr(), tile_bounds.shape[0],
+                                         stream if stream is not None else current_stream_handle()))
 
 
 def calculate_mean_vars(n, film_m2, film_var, row_n_quirk=True, stream=None):

@@ -430,6 +430,32 @@ int statmc_calculate_mean_vars(uint8_t n_buffers, uint16_t width, uint16_t heigh
     return STATMC_OK;
 }
 
+// validates one statmc_stat_type and translates it for the kernels (shared by both accumulate entries)
+static int fill_stat_type(const statmc_stat_type &t, int i, uint16_t width, uint16_t height, bool batch,
+                          statmc::AccumulateType &d) {
+    if (t.channels != 1 && t.channels != 3) return fail(STATMC_ERR_INVALID, "types[%d]: channels must be 1 or 3", i);
+    if (t.max_moment < 1 || t.max_moment > 3) return fail(STATMC_ERR_INVALID, "types[%d]: max_moment must be 1..3", i);
+    if (batch && t.n_samples < 0) return fail(STATMC_ERR_INVALID, "types[%d]: negative n_samples", i);
+    if (!t.n || !t.mean || ((!batch || t.n_samples) && !t.samples)) return fail(STATMC_ERR_INVALID, "types[%d]: null pointer", i);
+    if (t.max_moment >= 2 && !t.m2) return fail(STATMC_ERR_INVALID, "types[%d]: null m2", i);
+    if (t.max_moment >= 3 && !t.m3) return fail(STATMC_ERR_INVALID, "types[%d]: null m3", i);
+    if (t.transform && (!t.film_mean || !t.film_m2))
+        return fail(STATMC_ERR_INVALID, "types[%d]: transform types need film_mean and film_m2", i);
+    d.samples = t.samples;
+    d.n = t.n;
+    d.mean = t.mean;
+    d.m2 = t.m2;
+    d.m3 = t.m3;
+    d.film_mean = t.film_mean;
+    d.film_m2 = t.film_m2;
+    d.n_elems = (long long)width * height * t.channels;
+    d.channels = t.channels;
+    d.n_samples = t.n_samples;
+    d.transform = t.transform ? 1 : 0;
+    d.max_moment = t.max_moment;
+    return STATMC_OK;
+}
+
 int statmc_accumulate(uint16_t width, uint16_t height, const statmc_stat_type *types, int n_types, void *stream) {
     NEED_READY();
     if (width == 0 || height == 0) return fail(STATMC_ERR_INVALID, "empty image");
@@ -440,32 +466,35 @@ int statmc_accumulate(uint16_t width, uint16_t height, const statmc_stat_type *t
     statmc::AccumulateArgs k;
     memset(&k, 0, sizeof(k));
     k.n_types = n_types;
-    for (int i = 0; i < n_types; i++) {
-        const statmc_stat_type &t = types[i];
-        if (t.channels != 1 && t.channels != 3) return fail(STATMC_ERR_INVALID, "types[%d]: channels must be 1 or 3", i);
-        if (t.max_moment < 1 || t.max_moment > 3) return fail(STATMC_ERR_INVALID, "types[%d]: max_moment must be 1..3", i);
-        if (t.n_samples < 0) return fail(STATMC_ERR_INVALID, "types[%d]: negative n_samples", i);
-        if (!t.n || !t.mean || (t.n_samples && !t.samples)) return fail(STATMC_ERR_INVALID, "types[%d]: null pointer", i);
-        if (t.max_moment >= 2 && !t.m2) return fail(STATMC_ERR_INVALID, "types[%d]: null m2", i);
-        if (t.max_moment >= 3 && !t.m3) return fail(STATMC_ERR_INVALID, "types[%d]: null m3", i);
-        if (t.transform && (!t.film_mean || !t.film_m2))
-            return fail(STATMC_ERR_INVALID, "types[%d]: transform types need film_mean and film_m2", i);
-        statmc::AccumulateType &d = k.t[i];
-        d.samples = t.samples;
-        d.n = t.n;
-        d.mean = t.mean;
-        d.m2 = t.m2;
-        d.m3 = t.m3;
-        d.film_mean = t.film_mean;
-        d.film_m2 = t.film_m2;
-        d.n_elems = (long long)width * height * t.channels;
-        d.channels = t.channels;
-        d.n_samples = t.n_samples;
-        d.transform = t.transform ? 1 : 0;
-        d.max_moment = t.max_moment;
-    }
+    for (int i = 0; i < n_types; i++)
+        if (int rc = fill_stat_type(types[i], i, width, height, true, k.t[i])) return rc;
     k.resident_blocks = g_accumulate_resident_blocks;
     HIP_TRY(statmc::launch_accumulate(k, S(stream)));
+    return STATMC_OK;
+}
+
+int statmc_accumulate_tiles(uint16_t width, uint16_t height, const statmc_stat_type *types, int n_types,
+                            const int32_t *tile_bounds, const int64_t *tile_offsets, const int32_t *tile_samples,
+                            int n_tiles, void *stream) {
+    NEED_READY();
+    if (width == 0 || height == 0) return fail(STATMC_ERR_INVALID, "empty image");
+    if (n_types < 0 || n_types > statmc::kMaxStatTypes)
+        return fail(STATMC_ERR_INVALID, "n_types must be in [0,%d]", statmc::kMaxStatTypes);
+    if (n_tiles < 0) return fail(STATMC_ERR_INVALID, "negative tile count");
+    if (n_types == 0 || n_tiles == 0) return STATMC_OK;
+    if (!types || !tile_bounds || !tile_offsets || !tile_samples) return fail(STATMC_ERR_INVALID, "null pointer");
+    statmc::AccumulateTilesArgs k;
+    memset(&k, 0, sizeof(k));
+    k.n_types = n_types;
+    for (int i = 0; i < n_types; i++)
+        if (int rc = fill_stat_type(types[i], i, width, height, false, k.t[i])) return rc;
+    k.tile_bounds = tile_bounds;
+    k.tile_offsets = reinterpret_cast<const long long *>(tile_offsets);
+    k.tile_samples = tile_samples;
+    k.n_tiles = n_tiles;
+    k.width = width;
+    k.height = height;
+    HIP_TRY(statmc::launch_accumulate_tiles(k, S(stream)));
     return STATMC_OK;
 }
 

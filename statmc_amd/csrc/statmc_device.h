@@ -45,6 +45,18 @@ struct AccumulateArgs {
     unsigned char slot_type[kMaxSlots], slot_rank[kMaxSlots];
 };
 
+// samples of every type arrive tile by tile: AccumulateType::samples is the type's arena, tile k's
+// block starts at float offset tile_offsets[k] * channels and holds tile_samples[k] planes of
+// tile_h x tile_w pixels; AccumulateType::n_samples and n_elems are not used
+struct AccumulateTilesArgs {
+    AccumulateType t[kMaxStatTypes];
+    int n_types;
+    const int32_t *tile_bounds;      // device, {x0, y0, x1, y1} per tile
+    const long long *tile_offsets;   // device, in pixel-samples
+    const int32_t *tile_samples;     // device
+    int n_tiles, width, height, vec;
+};
+
 struct MergeTilesArgs {
     const void *tile_pixels;
     const int32_t *tile_bounds;
@@ -101,6 +113,7 @@ hipError_t launch_pack_inputs(const PackArgs &a, hipStream_t s);
 hipError_t launch_prepass(const PrepassArgs &a, hipStream_t s);
 hipError_t launch_mean_vars(const MeanVarsArgs &a, hipStream_t s);
 hipError_t launch_accumulate(const AccumulateArgs &a, hipStream_t s);
+hipError_t launch_accumulate_tiles(const AccumulateTilesArgs &a, hipStream_t s);
 hipError_t launch_merge_tiles(const MergeTilesArgs &a, int n_tiles, int max_tile_pixels, hipStream_t s);
 hipError_t launch_tile_moments(const TileMomentsArgs &a, hipStream_t s);
 hipError_t launch_film_update(const void *pixels, long long n, float splat_scale, float scale, float *rgb, hipStream_t s);

@@ -196,20 +196,19 @@ __device__ __forceinline__ void add_sample(ElemState &st, float nf, float r, flo
     }
 }
 
-template <int C, int MAXM, bool TRANSFORM, bool VEC>
-__device__ __forceinline__ void accumulate_type(const AccumulateType &t, long long blk, long long nblk) {
+// The lane's 4 consecutive pixels starting at film pixel p0 (16-B aligned planes): load the
+// state, fold S samples in order, store.  Sample s of the lane's elements is at sp + s * stride
+// (4*C consecutive floats): stride = n_elems for sample-major film planes, = tile pixels * C for
+// the tile-major arena of accumulate_tiles.
+template <int C, int MAXM, bool TRANSFORM>
+__device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long long p0, const float *sp,
+                                                long long stride, int S) {
     constexpr int NE = 4 * C;  // elements per lane
-    const long long n_px = t.n_elems / C;
-    const long long n_groups = (n_px + 3) >> 2;
-    const int S = t.n_samples;
-    for (long long g = blk * kBlock + threadIdx.x; g < n_groups; g += nblk * kBlock) {
-        const long long p0 = g << 2;
-        const long long e0 = p0 * C;
-        if (VEC && p0 + 4 <= n_px) {
-            ElemState st[NE];
-            float tmp[NE];
-            const int4 n4 = *reinterpret_cast<const int4 *>(t.n + p0);
-            const int n0[4] = {n4.x, n4.y, n4.z, n4.w};
+    const long long e0 = p0 * C;
+    ElemState st[NE];
+    float tmp[NE];
+    const int4 n4 = *reinterpret_cast<const int4 *>(t.n + p0);
+    const int n0[4] = {n4.x, n4.y, n4.z, n4.w};
 #define STATMC_LOAD_PLANE(ptr, field, enabled)                                   \
     if (enabled) {                                                               \
         _Pragma("unroll") for (int k = 0; k < C; k++) {                          \
@@ -220,112 +219,130 @@ __device__ __forceinline__ void accumulate_type(const AccumulateType &t, long lo
         _Pragma("unroll") for (int j = 0; j < NE; j++) tmp[j] = 0.f;             \
     }                                                                            \
     _Pragma("unroll") for (int j = 0; j < NE; j++) st[j].field = tmp[j];
-            STATMC_LOAD_PLANE(t.mean, mean, true)
-            STATMC_LOAD_PLANE(t.m2, m2, MAXM >= 2)
-            STATMC_LOAD_PLANE(t.m3, m3, MAXM >= 3)
-            STATMC_LOAD_PLANE(t.film_mean, fmean, TRANSFORM)
-            STATMC_LOAD_PLANE(t.film_m2, fm2, TRANSFORM)
+    STATMC_LOAD_PLANE(t.mean, mean, true)
+    STATMC_LOAD_PLANE(t.m2, m2, MAXM >= 2)
+    STATMC_LOAD_PLANE(t.m3, m3, MAXM >= 3)
+    STATMC_LOAD_PLANE(t.film_mean, fmean, TRANSFORM)
+    STATMC_LOAD_PLANE(t.film_m2, fm2, TRANSFORM)
 #undef STATMC_LOAD_PLANE
-            // Software-pipelined sample walk: the loads of the next U samples are issued before
-            // the current U are folded into the moments, so 2U sample rows per lane are in flight
-            // (the compiler would otherwise drain each unrolled body before loading again).
-            // C = 3: the three 16-B loads of a lane interleave across the wave (48-B lane stride);
-            // they only coalesce through the cache, so they must be plain loads (non-temporal ones
-            // re-fetch the shared lines: 4.8 vs 6.4 TB/s, tools/microbench/hbm_read.hip).  C = 1
-            // streams with non-temporal loads.
-            constexpr int U = C == 3 ? (TRANSFORM ? STATMC_ACC_U_RGB_T : STATMC_ACC_U_RGB) : STATMC_ACC_U_F;
-            const float *sp = t.samples + e0;
-            auto load_sample = [&](vfloat4 (&dst)[C], const float *src) {
+    // Software-pipelined sample walk: the loads of the next U samples are issued before
+    // the current U are folded into the moments, so 2U sample rows per lane are in flight
+    // (the compiler would otherwise drain each unrolled body before loading again).
+    // C = 3: the three 16-B loads of a lane interleave across the wave (48-B lane stride);
+    // they only coalesce through the cache, so they must be plain loads (non-temporal ones
+    // re-fetch the shared lines: 4.8 vs 6.4 TB/s, tools/microbench/hbm_read.hip).  C = 1
+    // streams with non-temporal loads.
+    constexpr int U = C == 3 ? (TRANSFORM ? STATMC_ACC_U_RGB_T : STATMC_ACC_U_RGB) : STATMC_ACC_U_F;
+    auto load_sample = [&](vfloat4 (&dst)[C], const float *src) {
 #pragma unroll
-                for (int k = 0; k < C; k++)
-                    dst[k] = C == 1 ? __builtin_nontemporal_load(reinterpret_cast<const vfloat4 *>(src + 4 * k))
-                                    : *reinterpret_cast<const vfloat4 *>(src + 4 * k);
-            };
-            // SAME: the lane's 4 pixels hold the same count (every film whose pixels have seen the
-            // same number of samples, i.e. all but adaptively sampled ones) -> one count conversion and
-            // one refined reciprocal per sample instead of four (a fifth of the kernel's VALU work).
-            auto fold_sample = [&](const vfloat4 (&q)[C], int s, auto same) {
-                float nf[4], rc[4];
-                if constexpr (decltype(same)::value) {
-                    const float nf0 = (float)(n0[0] + s + 1);
-                    const float rc0 = refined_rcp(nf0);
+        for (int k = 0; k < C; k++)
+            dst[k] = C == 1 ? __builtin_nontemporal_load(reinterpret_cast<const vfloat4 *>(src + 4 * k))
+                            : *reinterpret_cast<const vfloat4 *>(src + 4 * k);
+    };
+    // SAME: the lane's 4 pixels hold the same count (every film whose pixels have seen the
+    // same number of samples, i.e. all but adaptively sampled ones) -> one count conversion and
+    // one refined reciprocal per sample instead of four (a fifth of the kernel's VALU work).
+    auto fold_sample = [&](const vfloat4 (&q)[C], int s, auto same) {
+        float nf[4], rc[4];
+        if constexpr (decltype(same)::value) {
+            const float nf0 = (float)(n0[0] + s + 1);
+            const float rc0 = refined_rcp(nf0);
 #pragma unroll
-                    for (int p = 0; p < 4; p++) { nf[p] = nf0; rc[p] = rc0; }
-                } else {
+            for (int p = 0; p < 4; p++) { nf[p] = nf0; rc[p] = rc0; }
+        } else {
 #pragma unroll
-                    for (int p = 0; p < 4; p++) {
-                        nf[p] = (float)(n0[p] + s + 1);
-                        rc[p] = refined_rcp(nf[p]);
-                    }
-                }
+            for (int p = 0; p < 4; p++) {
+                nf[p] = (float)(n0[p] + s + 1);
+                rc[p] = refined_rcp(nf[p]);
+            }
+        }
 #pragma unroll
-                for (int j = 0; j < NE; j++) add_sample<MAXM, TRANSFORM>(st[j], nf[j / C], rc[j / C], q[j >> 2][j & 3]);
-            };
-            auto walk_samples = [&](auto same) {
-                vfloat4 cur[U][C], nxt[U][C];
-                const int S_main = S - S % U;
-                if (S_main > 0) {
+        for (int j = 0; j < NE; j++) add_sample<MAXM, TRANSFORM>(st[j], nf[j / C], rc[j / C], q[j >> 2][j & 3]);
+    };
+    auto walk_samples = [&](auto same) {
+        vfloat4 cur[U][C], nxt[U][C];
+        const int S_main = S - S % U;
+        if (S_main > 0) {
 #pragma unroll
-                    for (int u = 0; u < U; u++) load_sample(cur[u], sp + (long long)u * t.n_elems);
-                }
-                for (int s = 0; s < S_main; s += U) {
-                    const float *np = sp + (long long)(s + U) * t.n_elems;
-                    if (s + U < S_main) {
+            for (int u = 0; u < U; u++) load_sample(cur[u], sp + (long long)u * stride);
+        }
+        for (int s = 0; s < S_main; s += U) {
+            const float *np = sp + (long long)(s + U) * stride;
+            if (s + U < S_main) {
 #pragma unroll
-                        for (int u = 0; u < U; u++) load_sample(nxt[u], np + (long long)u * t.n_elems);
-                    }
+                for (int u = 0; u < U; u++) load_sample(nxt[u], np + (long long)u * stride);
+            }
 #pragma unroll
-                    for (int u = 0; u < U; u++) fold_sample(cur[u], s + u, same);
+            for (int u = 0; u < U; u++) fold_sample(cur[u], s + u, same);
 #pragma unroll
-                    for (int u = 0; u < U; u++)
+            for (int u = 0; u < U; u++)
 #pragma unroll
-                        for (int k = 0; k < C; k++) cur[u][k] = nxt[u][k];
-                }
-                for (int s = S_main; s < S; s++) {  // remainder (S not a multiple of U)
-                    vfloat4 q[C];
-                    load_sample(q, sp + (long long)s * t.n_elems);
-                    fold_sample(q, s, same);
-                }
-            };
-            // wave-uniform choice: the fast walk only when every active lane qualifies
-            const bool lane_same = n0[0] == n0[1] && n0[1] == n0[2] && n0[2] == n0[3];
-            if (__builtin_amdgcn_ballot_w64(!lane_same) == 0) walk_samples(std::true_type{});
-            else walk_samples(std::false_type{});
+                for (int k = 0; k < C; k++) cur[u][k] = nxt[u][k];
+        }
+        for (int s = S_main; s < S; s++) {  // remainder (S not a multiple of U)
+            vfloat4 q[C];
+            load_sample(q, sp + (long long)s * stride);
+            fold_sample(q, s, same);
+        }
+    };
+    // wave-uniform choice: the fast walk only when every active lane qualifies
+    const bool lane_same = n0[0] == n0[1] && n0[1] == n0[2] && n0[2] == n0[3];
+    if (__builtin_amdgcn_ballot_w64(!lane_same) == 0) walk_samples(std::true_type{});
+    else walk_samples(std::false_type{});
 #define STATMC_STORE_PLANE(ptr, field, enabled)                                  \
     if (enabled) {                                                               \
         _Pragma("unroll") for (int k = 0; k < C; k++)                            \
             *reinterpret_cast<float4 *>((ptr) + e0 + 4 * k) =                    \
                 make_float4(st[4 * k].field, st[4 * k + 1].field, st[4 * k + 2].field, st[4 * k + 3].field); \
     }
-            STATMC_STORE_PLANE(t.mean, mean, true)
-            STATMC_STORE_PLANE(t.m2, m2, MAXM >= 2)
-            STATMC_STORE_PLANE(t.m3, m3, MAXM >= 3)
-            STATMC_STORE_PLANE(t.film_mean, fmean, TRANSFORM)
-            STATMC_STORE_PLANE(t.film_m2, fm2, TRANSFORM)
+    STATMC_STORE_PLANE(t.mean, mean, true)
+    STATMC_STORE_PLANE(t.m2, m2, MAXM >= 2)
+    STATMC_STORE_PLANE(t.m3, m3, MAXM >= 3)
+    STATMC_STORE_PLANE(t.film_mean, fmean, TRANSFORM)
+    STATMC_STORE_PLANE(t.film_m2, fm2, TRANSFORM)
 #undef STATMC_STORE_PLANE
-            // Merge*Tile casts the tile's uint64 count to int32 (estimator.cpp:347,380)
-            *reinterpret_cast<int4 *>(t.n + p0) = make_int4(n0[0] + S, n0[1] + S, n0[2] + S, n0[3] + S);
+    // Merge*Tile casts the tile's uint64 count to int32 (estimator.cpp:347,380)
+    *reinterpret_cast<int4 *>(t.n + p0) = make_int4(n0[0] + S, n0[1] + S, n0[2] + S, n0[3] + S);
+}
+
+// One pixel, scalar accesses: unaligned images, ragged ends, tiles whose rows do not split into
+// 4-pixel groups.  Sample s of channel c is at sp[s * stride + c].
+template <int C, int MAXM, bool TRANSFORM>
+__device__ __forceinline__ void accumulate_pixel(const AccumulateType &t, long long p, const float *sp,
+                                                 long long stride, int S) {
+    const int n0 = t.n[p];
+    for (int c = 0; c < C; c++) {
+        const long long e = p * C + c;
+        ElemState st = {t.mean[e], MAXM >= 2 ? t.m2[e] : 0.f, MAXM >= 3 ? t.m3[e] : 0.f,
+                        TRANSFORM ? t.film_mean[e] : 0.f, TRANSFORM ? t.film_m2[e] : 0.f};
+        for (int s = 0; s < S; s++) {
+            const float nf = (float)(n0 + s + 1);
+            add_sample<MAXM, TRANSFORM>(st, nf, refined_rcp(nf), sp[(long long)s * stride + c]);
+        }
+        t.mean[e] = st.mean;
+        if (MAXM >= 2) t.m2[e] = st.m2;
+        if (MAXM >= 3) t.m3[e] = st.m3;
+        if (TRANSFORM) {
+            t.film_mean[e] = st.fmean;
+            t.film_m2[e] = st.fm2;
+        }
+    }
+    t.n[p] = n0 + S;
+}
+
+// Film-major batch: one lane owns 4 consecutive PIXELS of one stat type and walks the batch's
+// samples in order (sample s of pixel p, channel c is at samples[s*n_elems + p*C + c]).
+template <int C, int MAXM, bool TRANSFORM, bool VEC>
+__device__ __forceinline__ void accumulate_type(const AccumulateType &t, long long blk, long long nblk) {
+    const long long n_px = t.n_elems / C;
+    const long long n_groups = (n_px + 3) >> 2;
+    for (long long g = blk * kBlock + threadIdx.x; g < n_groups; g += nblk * kBlock) {
+        const long long p0 = g << 2;
+        if (VEC && p0 + 4 <= n_px) {
+            accumulate_lane<C, MAXM, TRANSFORM>(t, p0, t.samples + p0 * C, t.n_elems, t.n_samples);
         } else {
-            for (long long p = p0; p < n_px && p < p0 + 4; p++) {
-                const int n0 = t.n[p];
-                for (int c = 0; c < C; c++) {
-                    const long long e = p * C + c;
-                    ElemState st = {t.mean[e], MAXM >= 2 ? t.m2[e] : 0.f, MAXM >= 3 ? t.m3[e] : 0.f,
-                                    TRANSFORM ? t.film_mean[e] : 0.f, TRANSFORM ? t.film_m2[e] : 0.f};
-                    for (int s = 0; s < S; s++) {
-                        const float nf = (float)(n0 + s + 1);
-                        add_sample<MAXM, TRANSFORM>(st, nf, refined_rcp(nf), t.samples[(long long)s * t.n_elems + e]);
-                    }
-                    t.mean[e] = st.mean;
-                    if (MAXM >= 2) t.m2[e] = st.m2;
-                    if (MAXM >= 3) t.m3[e] = st.m3;
-                    if (TRANSFORM) {
-                        t.film_mean[e] = st.fmean;
-                        t.film_m2[e] = st.fm2;
-                    }
-                }
-                t.n[p] = n0 + S;
-            }
+            for (long long p = p0; p < n_px && p < p0 + 4; p++)
+                accumulate_pixel<C, MAXM, TRANSFORM>(t, p, t.samples + p * C, t.n_elems, t.n_samples);
         }
     }
 }
@@ -414,6 +431,85 @@ hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
         hipLaunchKernelGGL(accumulate_kernel<true>, grid, dim3(kBlock), 0, s, a);
     else
         hipLaunchKernelGGL(accumulate_kernel<false>, grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ accumulate, tile by tile
+// The same update fed the way StatPathIntegrator::Render produces samples (statpath.cpp:132-190,
+// 355-388): every tile of the film (16 x 16 there) hands over the samples of one iteration as one
+// block [S_tile][tile_h][tile_w][C] of a per-type arena, S_tile the same for every pixel of the
+// tile but free to differ between tiles.  One wave per (tile, type): a 16 x 16 tile is exactly
+// 64 lanes x 4 pixels, a sample plane of the block is one contiguous 1 / 3 KiB read of the wave.
+template <int C, int MAXM, bool TRANSFORM>
+__device__ __forceinline__ void accumulate_tile(const AccumulateType &t, const AccumulateTilesArgs &a, int x0, int y0,
+                                                int tw, int th, long long off, int S) {
+    const int lane = threadIdx.x & 63;
+    const int npx = tw * th;
+    const float *base = t.samples + off * C;
+    const long long stride = (long long)npx * C;
+    // rows split into 16-B aligned 4-pixel groups: tile width, tile origin, image width and the
+    // block's offset are all multiples of 4 (and the images themselves 16-B aligned: a.vec)
+    const bool fast = a.vec && ((tw | x0 | a.width) & 3) == 0 && (off & 3) == 0;
+    if (fast) {
+        for (int g = lane; g < (npx >> 2); g += 64) {
+            const int i = g << 2, row = i / tw, col = i - row * tw;
+            const long long p0 = (long long)(y0 + row) * a.width + x0 + col;
+            accumulate_lane<C, MAXM, TRANSFORM>(t, p0, base + (long long)i * C, stride, S);
+        }
+    } else {
+        for (int i = lane; i < npx; i += 64) {
+            const int row = i / tw, col = i - row * tw;
+            const long long p = (long long)(y0 + row) * a.width + x0 + col;
+            accumulate_pixel<C, MAXM, TRANSFORM>(t, p, base + (long long)i * C, stride, S);
+        }
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void accumulate_tile_dispatch(const AccumulateType &t, const AccumulateTilesArgs &a, int x0,
+                                                         int y0, int tw, int th, long long off, int S) {
+    if (t.transform) {
+        if (t.max_moment >= 3) accumulate_tile<C, 3, true>(t, a, x0, y0, tw, th, off, S);
+        else if (t.max_moment == 2) accumulate_tile<C, 2, true>(t, a, x0, y0, tw, th, off, S);
+        else accumulate_tile<C, 1, true>(t, a, x0, y0, tw, th, off, S);
+    } else {
+        if (t.max_moment >= 3) accumulate_tile<C, 3, false>(t, a, x0, y0, tw, th, off, S);
+        else if (t.max_moment == 2) accumulate_tile<C, 2, false>(t, a, x0, y0, tw, th, off, S);
+        else accumulate_tile<C, 1, false>(t, a, x0, y0, tw, th, off, S);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void accumulate_tiles_kernel(AccumulateTilesArgs a) {
+    const long long n_items = (long long)a.n_tiles * a.n_types;
+    const long long n_waves = (long long)gridDim.x * (kBlock / 64);
+    // item = (tile, type), types innermost: the waves of a workgroup work on the types of one
+    // tile, so ALU-heavy radiance items and bandwidth-only feature items share every CU
+    for (long long item = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); item < n_items; item += n_waves) {
+        const int tile = __builtin_amdgcn_readfirstlane((int)(item / a.n_types));
+        const int ti = __builtin_amdgcn_readfirstlane((int)(item % a.n_types));
+        const int x0 = a.tile_bounds[4 * tile], y0 = a.tile_bounds[4 * tile + 1];
+        const int x1 = a.tile_bounds[4 * tile + 2], y1 = a.tile_bounds[4 * tile + 3];
+        const int S = a.tile_samples[tile];
+        if (S <= 0 || x1 <= x0 || y1 <= y0) continue;
+        const AccumulateType &t = a.t[ti];
+        if (t.channels == 3) accumulate_tile_dispatch<3>(t, a, x0, y0, x1 - x0, y1 - y0, a.tile_offsets[tile], S);
+        else accumulate_tile_dispatch<1>(t, a, x0, y0, x1 - x0, y1 - y0, a.tile_offsets[tile], S);
+    }
+}
+
+hipError_t launch_accumulate_tiles(const AccumulateTilesArgs &a_in, hipStream_t s) {
+    AccumulateTilesArgs a = a_in;
+    bool vec = true;
+    for (int i = 0; i < a.n_types; i++) {
+        const AccumulateType &t = a.t[i];
+        vec = vec && aligned16(t.samples) && aligned16(t.n) && aligned16(t.mean) &&
+              (t.max_moment < 2 || aligned16(t.m2)) && (t.max_moment < 3 || aligned16(t.m3)) &&
+              (!t.transform || (aligned16(t.film_mean) && aligned16(t.film_m2)));
+    }
+    a.vec = vec ? 1 : 0;
+    const long long items = (long long)a.n_tiles * a.n_types;
+    const int grid = grid_for(items * 64, 256 * 8);  // one wave per item, at most 8 workgroups per CU
+    hipLaunchKernelGGL(accumulate_tiles_kernel, dim3(grid), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 

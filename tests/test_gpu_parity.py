@@ -167,6 +167,68 @@ def test_exact_division_any_count(gpu, oracle):
             assert rel_l2(st[k].cpu().numpy(), ref[k]) <= TOL, (shared, k)
 
 
+@pytest.mark.parametrize("W,H", [(64, 40), (50, 37), (16, 16)], ids=["vector-tiles", "scalar-tiles", "one-tile"])
+def test_accumulate_tiles_matches_oracle(gpu, oracle, W, H):
+    """statmc_accumulate_tiles: samples handed over tile by tile (16 x 16 tiles in shuffled order, a
+    different sample count per tile, some tiles empty), two iterations on the same state; the
+    reference result is the oracle run on every tile's sub-image.  (50, 37): image width and edge
+    tiles that do not split into aligned 4-pixel groups take the scalar path."""
+    rng = np.random.default_rng(W * 1000 + H)
+    cfgs = [("radiance", 3, True, 3), ("normal", 3, False, 1), ("depth", 1, False, 2)]
+    ref = {name: oracle.new_state(H, W, c) for name, c, _, _ in cfgs}
+    dev = {name: dev_state(ref[name]) for name, _, _, _ in cfgs}
+    tiles = [(x, y, min(x + 16, W), min(y + 16, H)) for y in range(0, H, 16) for x in range(0, W, 16)]
+    for it in range(2):
+        order = rng.permutation(len(tiles))
+        counts = rng.choice([0, 1, 3, 7, 12], size=len(tiles))
+        bounds, offsets, off = [], [], 0
+        blocks = {name: [] for name, _, _, _ in cfgs}
+        for k in order:
+            x0, y0, x1, y1 = tiles[k]
+            S, npx = int(counts[k]), (x1 - x0) * (y1 - y0)
+            bounds.append((x0, y0, x1, y1))
+            offsets.append(off)
+            size = (S * npx + 3) // 4 * 4                      # blocks start on 4-pixel-sample boundaries
+            for name, c, transform, mm in cfgs:
+                smp = rng.lognormal(0, 1.5, size=(S, y1 - y0, x1 - x0, c)).astype(np.float32)
+                smp[rng.random(smp.shape) < 0.15] = 0.0
+                blk = np.zeros(size * c, np.float32)
+                blk[:smp.size] = smp.ravel()
+                blocks[name].append(blk)
+                if S:
+                    sub = {key: np.ascontiguousarray(v[y0:y1, x0:x1]) for key, v in ref[name].items()}
+                    oracle.accumulate(sub, smp, transform, mm)
+                    for key, v in sub.items():
+                        ref[name][key][y0:y1, x0:x1] = v
+            off += size
+        arenas = {name: to_dev(np.concatenate(blocks[name])) for name, _, _, _ in cfgs}
+        sts = [gpu.make_stat_type_arena(arenas[name], c, dev[name], transform, mm) for name, c, transform, mm in cfgs]
+        gpu.accumulate_tiles(W, H, sts, to_dev(np.array(bounds, np.int32)), to_dev(np.array(offsets, np.int64)),
+                             to_dev(counts[order].astype(np.int32)))
+        torch.cuda.synchronize()
+    for name, c, transform, mm in cfgs:
+        got = {k: v.cpu().numpy() for k, v in dev[name].items()}
+        assert np.array_equal(got["n"], ref[name]["n"]), name
+        exact = ("mean", "m2", "m3")[:mm] if not transform else ("film_mean", "film_m2")
+        for k in exact:
+            assert np.array_equal(got[k], ref[name][k]), (name, k)
+        if transform:
+            for k in ("mean", "m2", "m3"):
+                assert rel_l2(got[k], ref[name][k]) <= TOL, (name, k)
+
+
+def test_accumulate_tiles_errors_and_empty(gpu):
+    st = dev_state({"n": np.zeros((16, 16), np.int32), "mean": np.zeros((16, 16, 3), np.float32)})
+    arena = torch.zeros(16, device=DEV)
+    t = gpu.make_stat_type_arena(arena, 3, st, False, 1)
+    z = torch.zeros(0, 4, dtype=torch.int32, device=DEV)
+    gpu.accumulate_tiles(16, 16, [t], z, torch.zeros(0, dtype=torch.int64, device=DEV), torch.zeros(0, dtype=torch.int32, device=DEV))
+    t.max_moment = 2                                               # m2 missing
+    b = torch.tensor([[0, 0, 16, 16]], dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError):
+        gpu.accumulate_tiles(16, 16, [t], b, torch.zeros(1, dtype=torch.int64, device=DEV), torch.ones(1, dtype=torch.int32, device=DEV))
+
+
 def test_accumulate_all_types_one_launch(gpu, oracle):
     """The 11-channel sample vector: radiance, normal, albedo, depth, material id in one launch."""
     from statmc_amd import film, synthetic
