@@ -54,6 +54,10 @@ int statmc_set_t_quantiles(int alpha_index, const float *quantiles, int n_dof);
 /* Device memory + copies: the GpuMat role inside Buffer (src/statistics/buffer.h:25,57-63). */
 int statmc_malloc(void **dev_ptr, size_t bytes);
 int statmc_free(void *dev_ptr);
+/* Page-locked host memory for the staging side of statmc_upload / statmc_download (sample arenas
+ * of the tile path, dump buffers): copies from it run at the full PCIe rate and stay asynchronous. */
+int statmc_malloc_host(void **host_ptr, size_t bytes);
+int statmc_free_host(void *host_ptr);
 int statmc_memset(void *dev_ptr, int value, size_t bytes, void *stream);
 int statmc_upload(void *dev_dst, const void *host_src, size_t bytes, void *stream);   /* Buffer::upload */
 int statmc_download(void *host_dst, const void *dev_src, size_t bytes, void *stream); /* Buffer::download */

@@ -14,6 +14,12 @@
 //   statmc::Estimator                    <- src/statistics/estimator.h:241-380, estimator.cpp:86-289,
 //                                           409-489, 571-573 (same member names, same buffer names,
 //                                           same aliasing and upload/download sets)
+//   statmc::StatTile<T>, Estimator::GetTiles / Merge[Transform]Tile(s)
+//                                        <- src/statistics/estimator.h:36-59,147-239, estimator.cpp:297-407:
+//                                           the tiles StatPathIntegrator::Render feeds sample by sample
+//                                           (statpath.cpp:355-388).  Here a tile RECORDS its samples; the
+//                                           merge hands them to the device, where statmc_accumulate_tiles
+//                                           runs the Add*Sample* arithmetic (Estimator::EnableDeviceAccumulation).
 //
 // Error behaviour: the reference has none at these call sites (OpenCV throws cv::Exception);
 // here every failing C call throws statmc::Error carrying statmc_last_error().
@@ -21,9 +27,12 @@
 #define STATMC_DENOISER_HPP
 
 #include <algorithm>
+#include <array>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <unordered_set>
@@ -354,6 +363,64 @@ inline StatTypeConfigs makeStatTypeConfigs(const StatPathParams &p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// pbrt's Point2i / Bounds2i (src/core/geometry.h) as far as the tile interface uses them.
+struct Point2i {
+    Point2i() = default;
+    Point2i(int x, int y) : x(x), y(y) {}
+    int x = 0, y = 0;
+};
+struct Bounds2i {  // pMax exclusive
+    Bounds2i() = default;
+    Bounds2i(const Point2i &a, const Point2i &b) : pMin(a), pMax(b) {}
+    int Area() const { return (pMax.x - pMin.x) * (pMax.y - pMin.y); }
+    Point2i pMin, pMax;
+};
+using Vec3 = float3;  // statpbrt.h:22
+
+// StatTile<T> (estimator.h:147-239) with the reference's constructor and Add*Sample* names, so
+// that Render<T>'s member-function pointers (statpath.cpp:97-116,166-170) bind unchanged.  The
+// reference updates StatTilePixel moments on the calling thread; this tile only records the
+// sample -- planes[s][pixel], sample-major, already the block layout of statmc_accumulate_tiles --
+// and the moments are updated on the device when the tile is merged.  Which of the six methods is
+// called does not matter here: the stat type's (transform, maxMoment) is applied at the merge, as
+// GetAddSampleFn derives the method from that same configuration.
+template <typename T>
+class StatTile {
+  public:
+    explicit StatTile(const Bounds2i &pixelBounds)
+        : pixelBounds(pixelBounds), tileWidth(std::max(0, pixelBounds.pMax.x - pixelBounds.pMin.x)),
+          nPixels((size_t)tileWidth * std::max(0, pixelBounds.pMax.y - pixelBounds.pMin.y)), counts(nPixels, 0u) {}
+    void AddSampleM1(const Point2i p, const T sample) { record(p, sample); }
+    void AddSampleM2(const Point2i p, const T sample) { record(p, sample); }
+    void AddSampleM3(const Point2i p, const T sample) { record(p, sample); }
+    void AddTransformSampleM1(const Point2i p, const T sample) { record(p, sample); }
+    void AddTransformSampleM2(const Point2i p, const T sample) { record(p, sample); }
+    void AddTransformSampleM3(const Point2i p, const T sample) { record(p, sample); }
+    Bounds2i GetPixelBounds() const { return pixelBounds; }
+    // samples recorded for pixel p since the last merge
+    unsigned pending(const Point2i p) const { return counts[index(p)]; }
+
+  private:
+    friend class Estimator;
+    size_t index(const Point2i p) const {
+        return (size_t)(p.y - pixelBounds.pMin.y) * tileWidth + (size_t)(p.x - pixelBounds.pMin.x);
+    }
+    void record(const Point2i p, const T &sample) {
+        const size_t i = index(p);
+        const uint32_t s = counts[i]++;
+        if (s >= planes.size()) planes.emplace_back(nPixels);
+        planes[s][i] = sample;
+    }
+    Bounds2i pixelBounds;
+    int tileWidth;
+    size_t nPixels;
+    // the merge interface is const in the reference (estimator.h:290-301); emptying the recorder is
+    // not part of the tile's observable state
+    mutable std::vector<uint32_t> counts;
+    std::vector<std::vector<T>> planes;
+};
+
+// ------------------------------------------------------------------------------------------
 // src/statistics/estimator.h:241-380.  Public members keep the reference's names because
 // StatPathIntegrator indexes them directly (statpath.cpp:308-311, 504-511).
 class Estimator {
@@ -518,7 +585,9 @@ class Estimator {
     }
 
     void Upload() {  // estimator.cpp:409-416
-        for (Buffer *b : uploadBuffers) b->upload(stream);
+        if (acc.enabled) FlushSamples();  // statistics are produced on the device: only the rest moves
+        for (Buffer *b : uploadBuffers)
+            if (!acc.enabled || !acc.deviceProduced.count(b)) b->upload(stream);
     }
     void Download() {  // estimator.cpp:418-425
         for (Buffer *b : downloadBuffers) b->download(stream);
@@ -555,6 +624,92 @@ class Estimator {
     }
     void Synchronize() { stat_denoiser::synchronize(stream); }  // estimator.cpp:571-573
 
+    // ---- the accumulation side: tiles in, statistics images on the device ------------------
+    // estimator.cpp:297-309.  (GetTilesF, the filter-weighted variant, is not used by Render.)
+    template <typename T>
+    std::vector<StatTile<T>> GetTiles(const Bounds2i &tilePixelBounds, const unsigned char bounceEnd) const {
+        return std::vector<StatTile<T>>(bounceEnd, StatTile<T>(tilePixelBounds));
+    }
+    template <typename T>
+    std::vector<std::vector<StatTile<T>>> GetTiles(const Bounds2i &tilePixelBounds, const unsigned char bounceEnd,
+                                                   const unsigned char n) const {
+        return std::vector<std::vector<StatTile<T>>>(bounceEnd, std::vector<StatTile<T>>(n, StatTile<T>(tilePixelBounds)));
+    }
+
+    // Switches Merge*Tile(s) from "nothing to merge into" to the device path: the n / mean / m2 / m3 /
+    // film-mean / film-m2 images of every enabled (type, bounce) live on the device, start at zero and
+    // are updated by statmc_accumulate_tiles; Upload() then moves only what the host still produces
+    // (the "film" image).  maxHostBytes bounds the page-locked staging the merges fill between flushes.
+    void EnableDeviceAccumulation(size_t maxHostBytes = (size_t)2 << 30) {
+        if (!allocateDevice) throw Error(STATMC_ERR_INVALID, "device accumulation needs device images");
+        std::lock_guard<std::mutex> lk(acc.mu);
+        acc.enabled = true;
+        acc.maxHostBytes = maxHostBytes;
+        acc.arenas.clear();
+        for (unsigned char i = 0; i < statTypeConfigs.nEnabled; i++) {
+            acc.arenas.emplace_back(statTypeConfigs.configs[i].nBounces);
+            for (unsigned char j = 0; j < statTypeConfigs.configs[i].nBounces; j++) {
+                for (auto *bufs : {&nBuffers, &meanBuffers, &m2Buffers, &m3Buffers, &filmBuffers, &filmM2Buffers}) {
+                    Buffer &b = (*bufs)[i][j];
+                    check(statmc_memset(b.gpuMat.data(), 0, b.gpuMat.bytes(), stream.handle()));
+                    acc.deviceProduced.insert(&b);
+                }
+            }
+        }
+    }
+    // Statistics of one stat type back to zero (the reference re-creates the it-radiance tiles
+    // every iteration, statpath.cpp:194-207).
+    void ResetStatistics(const unsigned char statTypeIndex) {
+        for (auto *bufs : {&nBuffers, &meanBuffers, &m2Buffers, &m3Buffers, &filmBuffers, &filmM2Buffers})
+            for (Buffer &b : (*bufs)[statTypeIndex])
+                check(statmc_memset(b.gpuMat.data(), 0, b.gpuMat.bytes(), stream.handle()));
+    }
+
+    // estimator.cpp:341-407.  Thread-safe (Render calls them from its worker threads, one tile
+    // each, statpath.cpp:381-388).  The samples recorded in the tile since its last merge are copied
+    // to the staging arena of (statTypeIndex, bounceIndex) and the tile is emptied.
+    template <typename T>
+    void MergeTile(const StatTile<T> &tile, const unsigned char statTypeIndex, const unsigned char bounceIndex) const {
+        mergeRecorded(tile, statTypeIndex, bounceIndex);
+    }
+    template <typename T>
+    void MergeTiles(const std::vector<StatTile<T>> &tiles, const StatTypeConfig &cfg) const {
+        for (unsigned char j = 0; j < cfg.nBounces; j++) MergeTile(tiles[j + cfg.bounceStart], cfg.index, j);
+    }
+    template <typename T>
+    void MergeTiles(const std::vector<std::vector<StatTile<T>>> &tiles, const std::vector<StatTypeConfig> &cfgs) const {
+        for (unsigned char i = 0; i < cfgs.size(); i++)
+            for (unsigned char j = 0; j < cfgs[i].nBounces; j++) MergeTile(tiles[j + cfgs[i].bounceStart][i], cfgs[i].index, j);
+    }
+    // The transform variants differ from the plain ones only in also writing film-mean / film-m2
+    // (estimator.cpp:385-386); on the device that follows from the type's `transform` flag.
+    template <typename T>
+    void MergeTransformTile(const StatTile<T> &tile, const unsigned char statTypeIndex, const unsigned char bounceIndex) const {
+        mergeRecorded(tile, statTypeIndex, bounceIndex);
+    }
+    template <typename T>
+    void MergeTransformTiles(const std::vector<StatTile<T>> &tiles, const StatTypeConfig &cfg) const {
+        MergeTiles(tiles, cfg);
+    }
+    template <typename T>
+    void MergeTransformTiles(const std::vector<std::vector<StatTile<T>>> &tiles, const std::vector<StatTypeConfig> &cfgs) const {
+        MergeTiles(tiles, cfgs);
+    }
+
+    // Uploads what the merges have staged and runs the accumulation (asynchronous on `stream`).
+    // Upload() calls it; call it yourself to bound the staging memory of a long iteration.
+    void FlushSamples() const {
+        std::lock_guard<std::mutex> lk(acc.mu);
+        flushLocked();
+    }
+    // Statistics images device -> host mats (dumps, OutputBufferSelection::Write); asynchronous.
+    void DownloadStatistics() {
+        for (unsigned char i = 0; i < statTypeConfigs.nEnabled; i++)
+            for (unsigned char j = 0; j < statTypeConfigs.configs[i].nBounces; j++)
+                for (auto *bufs : {&nBuffers, &meanBuffers, &m2Buffers, &m3Buffers, &filmBuffers, &filmM2Buffers})
+                    (*bufs)[i][j].download(stream);
+    }
+
     const unsigned short width, height;
     const float filterDSFactor;
     const unsigned char filterRadius;
@@ -585,6 +740,222 @@ class Estimator {
         if (std::find(v.begin(), v.end(), b) == v.end()) v.push_back(b);
     }
     const bool allocateDevice;
+
+    // ---- staging of recorded samples -----------------------------------------------------
+    // Between two flushes every merged tile owns one slot: a block of S x pixels "pixel-samples"
+    // at the same offset in the arena of every (type, bounce) -- all types of a tile see the same
+    // samples per pixel (statpath.cpp:355-371), so one tile table serves them all.
+    struct PinnedFloats {  // page-locked, grows by reallocation
+        ~PinnedFloats() { if (ptr) statmc_free_host(ptr); }
+        void reserve(size_t n, size_t keep) {
+            if (n <= cap) return;
+            size_t want = std::max(n, cap + cap / 2);
+            void *p = nullptr;
+            check(statmc_malloc_host(&p, want * sizeof(float)));
+            if (keep) std::memcpy(p, ptr, keep * sizeof(float));
+            if (ptr) statmc_free_host(ptr);
+            ptr = static_cast<float *>(p);
+            cap = want;
+        }
+        float *ptr = nullptr;
+        size_t cap = 0;
+    };
+    struct DeviceBytes {
+        ~DeviceBytes() { if (ptr) statmc_free(ptr); }
+        void reserve(size_t bytes) {
+            if (bytes <= cap) return;
+            if (ptr) statmc_free(ptr);
+            ptr = nullptr;
+            cap = 0;
+            check(statmc_malloc(&ptr, bytes));
+            cap = bytes;
+        }
+        void *ptr = nullptr;
+        size_t cap = 0;
+    };
+    struct Arena {
+        PinnedFloats host;
+        DeviceBytes dev;
+        size_t used = 0;                 // floats written since the last flush
+        std::vector<uint32_t> slots;     // slots this (type, bounce) has merged since the last flush
+    };
+    struct Slot {
+        int32_t x0, y0, x1, y1, samples;
+        int64_t offset;                  // in pixel-samples, a multiple of 4
+    };
+    struct Accumulation {
+        std::mutex mu;
+        bool enabled = false, uploadInFlight = false;
+        size_t maxHostBytes = 0, hostBytes = 0;
+        std::vector<std::vector<Arena>> arenas;  // [statTypeIndex][bounceIndex]
+        std::vector<Slot> slots;
+        std::map<std::array<int32_t, 4>, uint32_t> slotOf;
+        int64_t nextOffset = 0;
+        DeviceBytes tables;
+        std::unordered_set<const Buffer *> deviceProduced;
+    };
+    mutable Accumulation acc;
+
+    // host staging may be rewritten only after the copies of the previous flush have finished
+    void beginEpochLocked() const {
+        if (!acc.uploadInFlight) return;
+        check(statmc_synchronize(stream.handle()));
+        acc.uploadInFlight = false;
+    }
+
+    template <typename T>
+    void mergeRecorded(const StatTile<T> &tile, const unsigned char ti, const unsigned char bj) const {
+        constexpr int C = stat_denoiser::detail::channels<T>::value;
+        std::lock_guard<std::mutex> lk(acc.mu);
+        if (!acc.enabled)
+            throw Error(STATMC_ERR_INVALID, "Merge*Tile: call EnableDeviceAccumulation() first (tiles record samples; "
+                                            "the moments are computed on the device)");
+        if (ti >= acc.arenas.size() || bj >= acc.arenas[ti].size()) throw Error(STATMC_ERR_INVALID, "Merge*Tile: no such buffer");
+        if (statTypeConfigs.configs[ti].nChannels != C) throw Error(STATMC_ERR_INVALID, "Merge*Tile: channel count mismatch");
+        // every pixel that received samples received the same number, and those pixels form a
+        // rectangle (the whole tile, or its part inside the integrator's pixelbounds, statpath.cpp:261)
+        uint32_t S = 0;
+        for (uint32_t c : tile.counts) S = std::max(S, c);
+        if (S == 0) return;
+        const int tw = tile.tileWidth, th = tw ? (int)(tile.nPixels / tw) : 0;
+        int rx0 = tw, ry0 = th, rx1 = 0, ry1 = 0;
+        for (int y = 0; y < th; y++)
+            for (int x = 0; x < tw; x++)
+                if (tile.counts[(size_t)y * tw + x]) {
+                    rx0 = std::min(rx0, x); rx1 = std::max(rx1, x + 1);
+                    ry0 = std::min(ry0, y); ry1 = std::max(ry1, y + 1);
+                }
+        for (int y = 0; y < th; y++)
+            for (int x = 0; x < tw; x++) {
+                const bool inside = x >= rx0 && x < rx1 && y >= ry0 && y < ry1;
+                if (tile.counts[(size_t)y * tw + x] != (inside ? S : 0u))
+                    throw Error(STATMC_ERR_UNSUPPORTED, "Merge*Tile: pixels of one tile hold different sample counts");
+            }
+        const std::array<int32_t, 4> key = {tile.pixelBounds.pMin.x + rx0, tile.pixelBounds.pMin.y + ry0,
+                                            tile.pixelBounds.pMin.x + rx1, tile.pixelBounds.pMin.y + ry1};
+        if (key[0] < 0 || key[1] < 0 || key[2] > width || key[3] > height)
+            throw Error(STATMC_ERR_INVALID, "Merge*Tile: tile outside the image");
+        beginEpochLocked();
+        const size_t npx = (size_t)(rx1 - rx0) * (ry1 - ry0);
+        uint32_t slot;
+        auto it = acc.slotOf.find(key);
+        if (it == acc.slotOf.end()) {
+            slot = (uint32_t)acc.slots.size();
+            acc.slots.push_back(Slot{key[0], key[1], key[2], key[3], (int32_t)S, acc.nextOffset});
+            acc.slotOf.emplace(key, slot);
+            acc.nextOffset += (int64_t)((S * npx + 3) / 4 * 4);
+        } else {
+            slot = it->second;
+            if (acc.slots[slot].samples != (int32_t)S)
+                throw Error(STATMC_ERR_UNSUPPORTED, "Merge*Tile: the stat types of one tile hold different sample counts");
+        }
+        Arena &A = acc.arenas[ti][bj];
+        if (std::find(A.slots.begin(), A.slots.end(), slot) != A.slots.end())
+            throw Error(STATMC_ERR_INVALID, "Merge*Tile: tile merged twice");
+        const size_t off = (size_t)acc.slots[slot].offset * C, need = off + (S * npx + 3) / 4 * 4 * C;
+        const size_t before = A.host.cap;
+        A.host.reserve(need, A.used);
+        acc.hostBytes += (A.host.cap - before) * sizeof(float);
+        A.used = std::max(A.used, need);
+        const int rw = rx1 - rx0;
+        for (uint32_t s = 0; s < S; s++)
+            for (int y = ry0; y < ry1; y++)
+                std::memcpy(A.host.ptr + off + ((size_t)s * npx + (size_t)(y - ry0) * rw) * C,
+                            &tile.planes[s][(size_t)y * tw + rx0], (size_t)rw * C * sizeof(float));
+        A.slots.push_back(slot);
+        std::fill(tile.counts.begin(), tile.counts.end(), 0u);
+        size_t staged = 0;
+        for (const auto &per_type : acc.arenas)
+            for (const Arena &a : per_type) staged += a.used * sizeof(float);
+        if (staged > acc.maxHostBytes) flushLocked();
+    }
+
+    statmc_stat_type statTypeFor(unsigned char i, unsigned char j, const float *samples) const {
+        const StatTypeConfig &cfg = statTypeConfigs.configs[i];
+        statmc_stat_type t;
+        std::memset(&t, 0, sizeof(t));
+        t.channels = cfg.nChannels;
+        t.transform = cfg.transform ? 1 : 0;
+        t.max_moment = cfg.maxMoment;
+        t.samples = samples;
+        t.n = static_cast<int32_t *>(nBuffers[i][j].gpuMat.data());
+        t.mean = static_cast<float *>(meanBuffers[i][j].gpuMat.data());
+        t.m2 = static_cast<float *>(m2Buffers[i][j].gpuMat.data());
+        t.m3 = static_cast<float *>(m3Buffers[i][j].gpuMat.data());
+        if (cfg.transform) {  // otherwise film-mean / film-m2 are the mean / m2 images themselves
+            t.film_mean = static_cast<float *>(filmBuffers[i][j].gpuMat.data());
+            t.film_m2 = static_cast<float *>(filmM2Buffers[i][j].gpuMat.data());
+        }
+        return t;
+    }
+
+    void flushLocked() const {
+        if (acc.slots.empty()) return;
+        const size_t n = acc.slots.size();
+        // tile tables: bounds (int32 x 4), offsets (int64), samples (int32), one device block
+        std::vector<int64_t> offsets(n);
+        std::vector<int32_t> bounds(4 * n), samples(n);
+        for (size_t k = 0; k < n; k++) {
+            const Slot &s = acc.slots[k];
+            bounds[4 * k] = s.x0; bounds[4 * k + 1] = s.y0; bounds[4 * k + 2] = s.x1; bounds[4 * k + 3] = s.y1;
+            offsets[k] = s.offset;
+            samples[k] = s.samples;
+        }
+        const size_t tabBytes = n * (8 + 16 + 4);
+        acc.tables.reserve(tabBytes);
+        char *tab = static_cast<char *>(acc.tables.ptr);
+        // (synchronous copies of a few KB: the vectors die with this call)
+        check(statmc_upload(tab, offsets.data(), n * 8, stream.handle()));
+        check(statmc_upload(tab + n * 8, bounds.data(), n * 16, stream.handle()));
+        check(statmc_upload(tab + n * 24, samples.data(), n * 4, stream.handle()));
+        check(statmc_synchronize(stream.handle()));
+        std::vector<statmc_stat_type> full;
+        for (unsigned char i = 0; i < acc.arenas.size(); i++)
+            for (unsigned char j = 0; j < acc.arenas[i].size(); j++) {
+                Arena &A = acc.arenas[i][j];
+                if (A.slots.empty()) continue;
+                A.dev.reserve(A.used * sizeof(float));
+                check(statmc_upload(A.dev.ptr, A.host.ptr, A.used * sizeof(float), stream.handle()));
+                const statmc_stat_type t = statTypeFor(i, j, static_cast<const float *>(A.dev.ptr));
+                if (A.slots.size() == n) {
+                    full.push_back(t);
+                } else {  // this buffer saw only some of the tiles: its own, filtered table
+                    std::vector<int64_t> o;
+                    std::vector<int32_t> b, sm;
+                    for (uint32_t k : A.slots) {
+                        o.push_back(offsets[k]);
+                        sm.push_back(samples[k]);
+                        b.insert(b.end(), bounds.begin() + 4 * k, bounds.begin() + 4 * k + 4);
+                    }
+                    DeviceBytes own;
+                    const size_t m = o.size();
+                    own.reserve(m * 28);
+                    char *p = static_cast<char *>(own.ptr);
+                    check(statmc_upload(p, o.data(), m * 8, stream.handle()));
+                    check(statmc_upload(p + m * 8, b.data(), m * 16, stream.handle()));
+                    check(statmc_upload(p + m * 24, sm.data(), m * 4, stream.handle()));
+                    check(statmc_accumulate_tiles(width, height, &t, 1, reinterpret_cast<const int32_t *>(p + m * 8),
+                                                  reinterpret_cast<const int64_t *>(p), reinterpret_cast<const int32_t *>(p + m * 24),
+                                                  (int)m, stream.handle()));
+                    check(statmc_synchronize(stream.handle()));  // `own` is freed on scope exit
+                }
+            }
+        for (size_t first = 0; first < full.size(); first += 8) {  // kMaxStatTypes per launch
+            const int cnt = (int)std::min<size_t>(8, full.size() - first);
+            check(statmc_accumulate_tiles(width, height, full.data() + first, cnt, reinterpret_cast<const int32_t *>(tab + n * 8),
+                                          reinterpret_cast<const int64_t *>(tab), reinterpret_cast<const int32_t *>(tab + n * 24),
+                                          (int)n, stream.handle()));
+        }
+        acc.uploadInFlight = true;
+        acc.slots.clear();
+        acc.slotOf.clear();
+        acc.nextOffset = 0;
+        for (auto &per_type : acc.arenas)
+            for (Arena &a : per_type) {
+                a.used = 0;
+                a.slots.clear();
+            }
+    }
 };
 
 }  // namespace statmc

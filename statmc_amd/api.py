@@ -51,7 +51,7 @@ class StatType(C.Structure):
 
 EXPORTS = [
     "statmc_last_error", "statmc_setup", "statmc_set_significance", "statmc_get_significance", "statmc_set_t_quantiles",
-    "statmc_malloc", "statmc_free", "statmc_memset", "statmc_upload", "statmc_download",
+    "statmc_malloc", "statmc_free", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_download",
     "statmc_stream_create", "statmc_stream_destroy", "statmc_synchronize",
     "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs",
     "statmc_calculate_mean_vars", "statmc_accumulate", "statmc_accumulate_tiles", "statmc_merge_tiles", "statmc_tile_moments", "statmc_film_update",
@@ -82,6 +82,8 @@ def load():
     lib.statmc_set_t_quantiles.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_int]
     lib.statmc_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     lib.statmc_free.argtypes = [C.c_void_p]
+    lib.statmc_malloc_host.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    lib.statmc_free_host.argtypes = [C.c_void_p]
     lib.statmc_memset.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
     lib.statmc_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.statmc_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]

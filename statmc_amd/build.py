@@ -53,24 +53,29 @@ def build(force=False, verbose=False):
 
 ROOT = os.path.dirname(HERE)
 DENOISE_BIN = os.path.join(ROOT, "tools", "bin", "statmc_denoise")
+RENDER_SIM_BIN = os.path.join(ROOT, "tools", "bin", "statmc_render_sim")
+TOOLS = {DENOISE_BIN: "statmc_denoise.cpp", RENDER_SIM_BIN: "statmc_render_sim.cpp"}
 
 
 def build_tools(force=False):
-    """g++ build of the C++ host side (include/statmc_denoiser.hpp + tools/statmc_denoise.cpp),
-    linked against libstatmc_hip.so."""
-    src = os.path.join(ROOT, "tools", "statmc_denoise.cpp")
+    """g++ build of the C++ host side (include/statmc_denoiser.hpp + tools/*.cpp: the offline
+    denoise driver and the render-loop harness), linked against libstatmc_hip.so."""
     # An existing binary is used as is (no mtime comparison: a snapshot copy of the tree does not
     # keep a meaningful order of timestamps, and libstatmc_hip.so must never be rewritten while a
     # test process has it loaded); __graft_entry__.build() rebuilds with force=True.
-    if not force and os.path.exists(DENOISE_BIN):
+    if not force and all(os.path.exists(b) for b in TOOLS):
         return DENOISE_BIN
     if not os.path.exists(SO):
         build()
     os.makedirs(os.path.dirname(DENOISE_BIN), exist_ok=True)
     rocm_lib = os.path.join(os.path.dirname(os.path.dirname(_hipcc())), "lib")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", DENOISE_BIN,
-                           "-L", HERE, "-lstatmc_hip", "-L", rocm_lib, "-Wl,-rpath,$ORIGIN/../../statmc_amd",
-                           "-Wl,-rpath," + rocm_lib])
+    for binary, src in TOOLS.items():
+        if not force and os.path.exists(binary):
+            continue
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-ffp-contract=off", "-pthread",
+                               "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", src), "-o", binary,
+                               "-L", HERE, "-lstatmc_hip", "-L", rocm_lib, "-Wl,-rpath,$ORIGIN/../../statmc_amd",
+                               "-Wl,-rpath," + rocm_lib])
     return DENOISE_BIN
 
 

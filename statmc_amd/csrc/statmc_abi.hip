@@ -198,6 +198,15 @@ int statmc_free(void *dev_ptr) {
     HIP_TRY(hipFree(dev_ptr));
     return STATMC_OK;
 }
+int statmc_malloc_host(void **host_ptr, size_t bytes) {
+    if (!host_ptr) return fail(STATMC_ERR_INVALID, "null host_ptr");
+    HIP_TRY(hipHostMalloc(host_ptr, bytes, hipHostMallocDefault));
+    return STATMC_OK;
+}
+int statmc_free_host(void *host_ptr) {
+    HIP_TRY(hipHostFree(host_ptr));
+    return STATMC_OK;
+}
 int statmc_memset(void *dev_ptr, int value, size_t bytes, void *stream) {
     HIP_TRY(hipMemsetAsync(dev_ptr, value, bytes, S(stream)));
     return STATMC_OK;

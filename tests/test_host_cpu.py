@@ -116,3 +116,21 @@ def test_pfm_roundtrip(tmp_path):
     # bottom-to-top: the first stored triple is the first pixel of the LAST row
     first = np.frombuffer(raw[len(b"PF\n5 7\n-1.000000\n"):][:12], "<f4")
     assert np.array_equal(first, rgb[-1, 0])
+
+
+def test_render_sim_sample_source_restatement(denoise_bin):
+    """tests/test_render_sim_gpu.py restates the sample generator of tools/statmc_render_sim.cpp in
+    numpy; the two must agree bit for bit (checked here without a device: --print-sample)."""
+    import importlib.util
+    import os
+    from statmc_amd import build
+    spec = importlib.util.spec_from_file_location("render_sim_test", os.path.join(os.path.dirname(__file__), "test_render_sim_gpu.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    W, H, s0, S, seed = 88, 44, 3, 2, 5
+    rad, nrm, alb = mod.make_samples(seed, W, H, s0, S)
+    for x, y, s in [(0, 0, 3), (17, 5, 4), (87, 43, 3), (40, 21, 4), (24, 20, 3), (63, 39, 4), (25, 1, 3)]:
+        out = subprocess.check_output([build.RENDER_SIM_BIN, "--seed", str(seed), "--print-sample", str(x), str(y), str(s)], text=True)
+        ref = np.array([float.fromhex(v) for v in out.split()], np.float32)
+        got = np.concatenate([rad[s - s0, y, x], nrm[s - s0, y, x], alb[s - s0, y, x]])
+        assert np.array_equal(ref, got), (x, y, s)

@@ -1,0 +1,116 @@
+"""The accumulation side of the drop-in, driven the way StatPathIntegrator::Render drives it
+(tools/statmc_render_sim.cpp: 16 x 16 StatTile sets from Estimator::GetTiles, Add*Sample* through
+member-function pointers on worker threads, Merge[Transform]Tiles per tile, the exponential
+iteration schedule, Upload / Denoise / Download / Synchronize) -- checked against the CPU oracle fed
+with the same synthetic samples, which are restated here from the tool's generator."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+K_ALBEDO = np.array([[0.80, 0.25, 0.20], [0.15, 0.55, 0.85], [0.60, 0.60, 0.10]], np.float32)
+K_NORMAL = np.array([[0.0, 0.0, 1.0], [0.6, -0.8, 0.0], [-0.7071, 0.0, 0.7071]], np.float32)
+M32 = np.uint64(0xFFFFFFFF)
+
+
+def mix(a):
+    a = a.astype(np.uint64)
+    a ^= a >> np.uint64(16)
+    a = (a * np.uint64(0x7feb352d)) & M32
+    a ^= a >> np.uint64(15)
+    a = (a * np.uint64(0x846ca68b)) & M32
+    a ^= a >> np.uint64(16)
+    return a
+
+
+def draw(seed, x, y, sample, stream):
+    base = (np.uint64(0x9e3779b9) * ((x + 65536 * y).astype(np.uint64) & M32)) & M32
+    k = mix(np.uint64(seed) ^ base)
+    k = mix((k + np.uint64(sample)) & M32)
+    return mix((k + ((np.uint64(stream) * np.uint64(0x85ebca6b)) & M32)) & M32)
+
+
+def unit(key):
+    return (key >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
+def make_samples(seed, W, H, s0, S):
+    """[S, H, W, 3] radiance, normal, albedo samples number s0 .. s0+S-1 of every pixel (fp32, same
+    operation order as makeSample in tools/statmc_render_sim.cpp)."""
+    y, x = np.mgrid[0:H, 0:W]
+    region = ((x // 24) + (y // 20)) % 3
+    e = np.float32(0.5) + np.float32(0.5) * (((x * 7 + y * 3) % 32).astype(np.float32) / np.float32(32.0))
+    rad = np.zeros((S, H, W, 3), np.float32)
+    nrm = np.zeros_like(rad)
+    alb = np.zeros_like(rad)
+    for s in range(S):
+        black = (draw(seed, x, y, s0 + s, 3) & np.uint64(7)) == 0
+        for c in range(3):
+            u = unit(draw(seed, x, y, s0 + s, c))
+            t = np.float32(4.0) * (u * u)
+            rad[s, ..., c] = np.where(black, np.float32(0), (K_ALBEDO[region, c] * e) * t)
+            nrm[s, ..., c] = K_NORMAL[region, c] + (unit(draw(seed, x, y, s0 + s, 4 + c)) - np.float32(0.5)) * np.float32(0.02)
+            alb[s, ..., c] = K_ALBEDO[region, c] + (unit(draw(seed, x, y, s0 + s, 7 + c)) - np.float32(0.5)) * np.float32(0.01)
+    return rad, nrm, alb
+
+
+@pytest.mark.parametrize("W,H,stage_mb", [(88, 44, 1), (50, 37, 2048)], ids=["vector-tiles-small-staging", "scalar-tiles"])
+def test_render_loop_matches_oracle(gpu, oracle, tmp_path, W, H, stage_mb):
+    from statmc_amd import build, pfm
+    build.build_tools()
+    spp, iterations, seed, radius, sd = 4, 3, 5, 20, 10.0
+    stem = str(tmp_path / "sim")
+    out = subprocess.run([build.RENDER_SIM_BIN, "--width", str(W), "--height", str(H), "--spp", str(spp),
+                          "--iterations", str(iterations), "--threads", "4", "--seed", str(seed), "--stem", stem,
+                          "--filtersd", str(sd), "--filterradius", str(radius), "--stage-mb", str(stage_mb)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.count("CUDA time [ns]:") == iterations and "Iteration: 3" in out.stdout
+
+    st = {"rad": oracle.new_state(H, W, 3), "nrm": oracle.new_state(H, W, 3), "alb": oracle.new_state(H, W, 3)}
+    done = 0
+    for i in range(1, iterations + 1):
+        target = spp if i == 1 else spp << (i - 2)                 # statpath.cpp:272-279
+        rad, nrm, alb = make_samples(seed, W, H, done, target)
+        oracle.accumulate(st["rad"], rad, True, 3)
+        oracle.accumulate(st["nrm"], nrm, False, 1)
+        oracle.accumulate(st["alb"], alb, False, 1)
+        done += target
+        rd = lambda name: pfm.read_pfm("%s-%d-%s.pfm" % (stem, done, name))
+        assert np.array_equal(rd("t0-b0-n"), st["rad"]["n"].astype(np.float32))
+        # raw-sample moments and the plain feature means carry no sqrt: bit for bit
+        assert np.array_equal(rd("t0-b0-film-mean"), st["rad"]["film_mean"])
+        assert np.array_equal(rd("t0-b0-film-m2"), st["rad"]["film_m2"])
+        assert np.array_equal(rd("t1-b0-mean"), st["nrm"]["mean"])
+        assert np.array_equal(rd("t1-b0-film-mean"), st["nrm"]["mean"])     # non-transform: film-mean is mean
+        assert np.array_equal(rd("t2-b0-mean"), st["alb"]["mean"])
+        assert np.array_equal(rd("t1-b0-n"), st["nrm"]["n"].astype(np.float32))
+        for k in ("mean", "m2", "m3"):                                       # Box-Cox side: sqrt vs pow
+            assert rel_l2(rd("t0-b0-" + k), st["rad"][k]) <= 1e-5, (i, k)
+        # the denoised image from the device-side statistics vs the oracle's filter on its own
+        r = st["rad"]
+        mc, dc = oracle.prepass(r["n"], r["mean"], r["m2"], r["m3"])
+        ref = oracle.filter_image(mc, dc, r["film_mean"], [st["nrm"]["mean"], st["alb"]["mean"]],
+                                  [-0.5 / 0.1 ** 2, -0.5 / 0.02 ** 2], -0.5 / sd ** 2, radius)
+        got = rd("t0-b0-film-mean-f")
+        for c in range(3):
+            assert rel_l2(got[..., c], ref[..., c]) <= 1e-5, (i, c)
+
+
+def test_render_loop_statistics_only(gpu, tmp_path):
+    """`calcstats` configuration (scenes/render-for-ours.pbrt): statistics are accumulated and dumped,
+    no filter call (runCUDA false, statpath.cpp:1050-1051)."""
+    from statmc_amd import build, pfm
+    build.build_tools()
+    stem = str(tmp_path / "stats")
+    out = subprocess.run([build.RENDER_SIM_BIN, "--width", "48", "--height", "32", "--spp", "2", "--iterations", "2",
+                          "--stem", stem, "--no-denoise"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    n = pfm.read_pfm("%s-4-t0-b0-n.pfm" % stem)
+    assert np.all(n == 4.0)
+    assert not os.path.exists("%s-4-t0-b0-film-mean-f.pfm" % stem)

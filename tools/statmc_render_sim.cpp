@@ -1,0 +1,261 @@
+// statmc_render_sim -- the render loop of StatPathIntegrator::Render<T> (src/statistics/statpath.cpp:
+// 120-445) around statmc::Estimator, with the path tracer replaced by a counter-based synthetic
+// sample source.  It exercises the accumulation side of the drop-in exactly the way the reference
+// drives it:
+//
+//   * 16 x 16 tiles (statpath.cpp:132), one set of StatTile<T> per tile from Estimator::GetTiles
+//     (statpath.cpp:173-190), worker threads taking tiles (ParallelFor2D);
+//   * per pixel and sample the Add*Sample* method selected from the stat type's configuration is
+//     called through a member-function pointer (GetAddSampleFn, statpath.cpp:97-116, 355-371);
+//   * Merge[Transform]Tiles once per tile and iteration from the worker thread (statpath.cpp:381-388);
+//   * the exponential iteration schedule spp, spp, 2 spp, 4 spp, ... (statpath.cpp:272-279);
+//   * Upload / Denoise / Download / Synchronize on the main thread, timed and printed like the
+//     reference's "CUDA time [ns]" bracket (statpath.cpp:397-417);
+//   * dumps named <stem>-<total spp>-<buffer>.pfm (OutputBufferSelection::Write, statpath.cpp:421-427).
+//
+// The tiles record samples; the moments are accumulated on the device (statmc_accumulate_tiles).
+// The sample source is a pure function of (seed, x, y, sample index), restated in
+// tests/test_render_sim_gpu.py so that the dumps can be checked against the CPU oracle.
+//
+//   statmc_render_sim --width 96 --height 56 --spp 4 --iterations 3 --stem out/sim [--threads 4]
+//                     [--seed 1] [--filtersd 10] [--filterradius 20] [--stage-mb 2048] [--no-denoise]
+//   statmc_render_sim [--seed 1] --print-sample x y s     (prints one generated sample, no device)
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <thread>
+
+#include "statmc_denoiser.hpp"
+#include "statmc_pfm.hpp"
+
+using namespace statmc;
+
+// ---- synthetic sample source (all arithmetic in fp32, one rounding per operation) --------------
+static inline uint32_t mix(uint32_t a) {  // lowbias32
+    a ^= a >> 16;
+    a *= 0x7feb352dU;
+    a ^= a >> 15;
+    a *= 0x846ca68bU;
+    a ^= a >> 16;
+    return a;
+}
+static inline uint32_t draw(uint32_t seed, int x, int y, uint32_t sample, uint32_t stream) {
+    return mix(mix(mix(seed ^ (0x9e3779b9U * (uint32_t)(x + 65536 * y))) + sample) + stream * 0x85ebca6bU);
+}
+static inline float unit(uint32_t key) { return (float)(key >> 8) * (1.0f / 16777216.0f); }
+
+static const float kAlbedo[3][3] = {{0.80f, 0.25f, 0.20f}, {0.15f, 0.55f, 0.85f}, {0.60f, 0.60f, 0.10f}};
+static const float kNormal[3][3] = {{0.0f, 0.0f, 1.0f}, {0.6f, -0.8f, 0.0f}, {-0.7071f, 0.0f, 0.7071f}};
+
+struct PixelSample {
+    Vec3 radiance, normal, albedo;
+};
+static PixelSample makeSample(uint32_t seed, int x, int y, uint32_t s) {
+    const int region = ((x / 24) + (y / 20)) % 3;
+    const float e = 0.5f + 0.5f * ((float)((x * 7 + y * 3) % 32) / 32.0f);
+    const bool black = (draw(seed, x, y, s, 3) & 7u) == 0u;  // zero-radiance paths
+    float rad[3], nrm[3], alb[3];
+    for (int c = 0; c < 3; c++) {
+        const float u = unit(draw(seed, x, y, s, (uint32_t)c));
+        const float t = 4.0f * (u * u);
+        rad[c] = black ? 0.0f : (kAlbedo[region][c] * e) * t;
+        nrm[c] = kNormal[region][c] + (unit(draw(seed, x, y, s, 4u + c)) - 0.5f) * 0.02f;
+        alb[c] = kAlbedo[region][c] + (unit(draw(seed, x, y, s, 7u + c)) - 0.5f) * 0.01f;
+    }
+    return PixelSample{Vec3{rad[0], rad[1], rad[2]}, Vec3{nrm[0], nrm[1], nrm[2]}, Vec3{alb[0], alb[1], alb[2]}};
+}
+
+// GetAddSampleFn (statpath.cpp:97-116)
+template <typename T>
+using AddSampleFn = void (StatTile<T>::*)(const Point2i, const T);
+template <typename T>
+static AddSampleFn<T> GetAddSampleFn(const StatTypeConfig &cfg) {
+    if (cfg.transform) {
+        if (cfg.maxMoment == 3) return &StatTile<T>::AddTransformSampleM3;
+        if (cfg.maxMoment == 2) return &StatTile<T>::AddTransformSampleM2;
+        if (cfg.maxMoment == 1) return &StatTile<T>::AddTransformSampleM1;
+    } else {
+        if (cfg.maxMoment == 3) return &StatTile<T>::AddSampleM3;
+        if (cfg.maxMoment == 2) return &StatTile<T>::AddSampleM2;
+        if (cfg.maxMoment == 1) return &StatTile<T>::AddSampleM1;
+    }
+    return nullptr;
+}
+
+static void writeBuffer(const std::string &stem, unsigned spp, const Buffer &b) {
+    const std::string path = stem + "-" + std::to_string(spp) + "-" + b.name + ".pfm";
+    if (b.mat.type == I32C1) {  // n is written as float (buffer.h:51-54)
+        std::vector<float> f((size_t)b.mat.rows * b.mat.cols);
+        const int32_t *src = b.mat.ptr<int32_t>();
+        for (size_t i = 0; i < f.size(); i++) f[i] = (float)src[i];
+        writePfm(path, b.mat.cols, b.mat.rows, 1, f.data());
+    } else {
+        writePfm(path, b.mat.cols, b.mat.rows, b.mat.channels(), b.mat.ptr<float>());
+    }
+}
+
+int main(int argc, char **argv) {
+    int width = 96, height = 56, spp = 4, iterations = 3, threads = 4, stageMb = 2048;
+    unsigned seed = 1;
+    float filterSD = 10.f;
+    int filterRadius = 20;
+    bool denoise = true;
+    std::string stem;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto next = [&]() -> const char * {
+            if (i + 1 >= argc) {
+                std::fprintf(stderr, "missing value for %s\n", a.c_str());
+                std::exit(2);
+            }
+            return argv[++i];
+        };
+        if (a == "--width") width = std::atoi(next());
+        else if (a == "--height") height = std::atoi(next());
+        else if (a == "--spp") spp = std::atoi(next());
+        else if (a == "--iterations") iterations = std::atoi(next());
+        else if (a == "--threads") threads = std::atoi(next());
+        else if (a == "--seed") seed = (unsigned)std::strtoul(next(), nullptr, 10);
+        else if (a == "--filtersd") filterSD = (float)std::atof(next());
+        else if (a == "--filterradius") filterRadius = std::atoi(next());
+        else if (a == "--stage-mb") stageMb = std::atoi(next());
+        else if (a == "--stem") stem = next();
+        else if (a == "--no-denoise") denoise = false;
+        else if (a == "--print-sample") {  // x y s: the generator alone, no device (CPU test of the restatement)
+            const int x = std::atoi(next()), y = std::atoi(next());
+            const unsigned s = (unsigned)std::strtoul(next(), nullptr, 10);
+            const PixelSample p = makeSample(seed, x, y, s);
+            std::printf("%a %a %a %a %a %a %a %a %a\n", p.radiance.x, p.radiance.y, p.radiance.z, p.normal.x, p.normal.y,
+                        p.normal.z, p.albedo.x, p.albedo.y, p.albedo.z);
+            return 0;
+        } else {
+            std::fprintf(stderr, "unknown option %s\n", a.c_str());
+            return 2;
+        }
+    }
+    if (width <= 0 || height <= 0 || width > 65535 || height > 65535 || spp <= 0 || iterations <= 0 || threads <= 0) {
+        std::fprintf(stderr, "bad size / spp / iterations / threads\n");
+        return 2;
+    }
+    try {
+        // Integrator "statpath" "bool denoiseimage" ["true"] with filterbuffers albedo + normal
+        // (scenes/render-denoise.pbrt:19-22); `film` itself is not denoised here (no Film in this
+        // harness), so the colour is t0-b0-film-mean and the result t0-b0-film-mean-f.
+        StatPathParams params;
+        params.denoiseImage = denoise;
+        params.calcStats = !denoise;
+        params.filterSD = filterSD;
+        params.filterRadius = (unsigned char)filterRadius;
+        const StatTypeConfigs sCfgs = makeStatTypeConfigs(params);
+        Buffer film("film", HostImage(height, width, F32C3));
+        BufferRegistry reg(film);
+        Estimator estimator(film, sCfgs, filterSD, (unsigned char)filterRadius, /*denoiseFilm=*/false, false, false, reg);
+        estimator.AllocateBuffers(reg);
+        estimator.EnableDeviceAccumulation((size_t)stageMb << 20);
+
+        std::vector<StatTypeConfig> enabledRGBFeatureCfgs;  // statpath.cpp:160-163
+        for (unsigned char t : {(unsigned char)StatMaterialID, (unsigned char)StatDepth, (unsigned char)StatNormal,
+                                (unsigned char)StatAlbedo})
+            if (sCfgs[t].enable && sCfgs[t].nChannels == 3) enabledRGBFeatureCfgs.push_back(sCfgs[t]);
+        const unsigned char nRGBBuffers = (unsigned char)enabledRGBFeatureCfgs.size();
+        if (nRGBBuffers != 2) throw std::runtime_error("expected the normal and albedo feature types");
+
+        AddSampleFn<Vec3> AddLSampleFn = GetAddSampleFn<Vec3>(sCfgs[Radiance]);
+        AddSampleFn<Vec3> AddRGBGBufferSampleFn = GetAddSampleFn<Vec3>(sCfgs[StatNormal]);
+
+        const int tileSize = 16;  // statpath.cpp:132
+        const int nTilesX = (width + tileSize - 1) / tileSize, nTilesY = (height + tileSize - 1) / tileSize;
+        const int nTilesTotal = nTilesX * nTilesY;
+        std::vector<std::vector<StatTile<Vec3>>> lTiles(nTilesTotal);
+        std::vector<std::vector<std::vector<StatTile<Vec3>>>> rgbFeatureTiles(nTilesTotal);
+        auto tileBoundsOf = [&](int tileIndex) {
+            const int tx = tileIndex % nTilesX, ty = tileIndex / nTilesX;
+            return Bounds2i(Point2i(tx * tileSize, ty * tileSize),
+                            Point2i(std::min((tx + 1) * tileSize, width), std::min((ty + 1) * tileSize, height)));
+        };
+        for (int t = 0; t < nTilesTotal; t++) {  // statpath.cpp:173-190
+            lTiles[t] = estimator.GetTiles<Vec3>(tileBoundsOf(t), sCfgs[Radiance].bounceEnd);
+            rgbFeatureTiles[t] = estimator.GetTiles<Vec3>(tileBoundsOf(t), 1, nRGBBuffers);
+        }
+
+        unsigned done = 0;  // samples per pixel so far
+        for (int i = 1; i <= iterations; i++) {
+            const unsigned target = i == 1 ? (unsigned)spp : (unsigned)spp << std::max(i - 2, 0);  // statpath.cpp:272-279
+            auto begin = std::chrono::steady_clock::now();
+            std::atomic<int> nextTile{0};
+            std::atomic<bool> failed{false};
+            std::string failure;
+            std::mutex failMu;
+            auto worker = [&]() {
+                try {
+                    for (int t = nextTile.fetch_add(1); t < nTilesTotal; t = nextTile.fetch_add(1)) {
+                        const Bounds2i tb = tileBoundsOf(t);
+                        std::vector<StatTile<Vec3>> &tileLs = lTiles[t];
+                        std::vector<std::vector<StatTile<Vec3>>> &tileRGBFeatures = rgbFeatureTiles[t];
+                        for (int y = tb.pMin.y; y < tb.pMax.y; y++)
+                            for (int x = tb.pMin.x; x < tb.pMax.x; x++) {
+                                const Point2i actualPixel(x, y);
+                                for (unsigned s = 0; s < target; s++) {  // do { ... } while (StartNextSample())
+                                    const PixelSample smp = makeSample(seed, x, y, done + s);
+                                    for (unsigned char j = sCfgs[Radiance].bounceStart; j < sCfgs[Radiance].bounceEnd; j++)
+                                        (tileLs[j].*AddLSampleFn)(actualPixel, smp.radiance);
+                                    (tileRGBFeatures[0][0].*AddRGBGBufferSampleFn)(actualPixel, smp.normal);
+                                    (tileRGBFeatures[0][1].*AddRGBGBufferSampleFn)(actualPixel, smp.albedo);
+                                }
+                            }
+                        // Merge tiles into buffers (statpath.cpp:381-388)
+                        estimator.MergeTransformTiles(tileLs, sCfgs[Radiance]);
+                        estimator.MergeTiles(tileRGBFeatures, enabledRGBFeatureCfgs);
+                    }
+                } catch (const std::exception &e) {
+                    std::lock_guard<std::mutex> lk(failMu);
+                    failed = true;
+                    failure = e.what();
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int t = 0; t < threads; t++) pool.emplace_back(worker);
+            for (auto &t : pool) t.join();
+            if (failed) throw std::runtime_error(failure);
+            done += target;
+            auto end = std::chrono::steady_clock::now();
+            std::cout << "Iteration: " << i << std::endl;
+            std::cout << "SPP: " << target << std::endl;
+            std::cout << "Rendering time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(end - begin).count() << std::endl;
+
+            begin = std::chrono::steady_clock::now();
+            estimator.Upload();  // stages + accumulates the iteration's samples on the device
+            if (estimator.runCUDA) {
+                estimator.Denoise();
+                estimator.Download();
+            }
+            estimator.Synchronize();
+            end = std::chrono::steady_clock::now();
+            std::cout << "CUDA time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(end - begin).count() << std::endl;
+
+            begin = std::chrono::steady_clock::now();
+            if (!stem.empty()) {
+                estimator.DownloadStatistics();
+                for (auto *bufs : {&estimator.meanCorrBuffers, &estimator.discriminatorBuffers})
+                    if (estimator.runCUDA) (*bufs)[sCfgs[Radiance].index][0].download(estimator.stream);
+                estimator.Synchronize();
+                for (unsigned char t = 0; t < estimator.statTypeConfigs.nEnabled; t++)
+                    for (auto *bufs : {&estimator.nBuffers, &estimator.meanBuffers, &estimator.m2Buffers, &estimator.m3Buffers,
+                                       &estimator.filmBuffers, &estimator.filmM2Buffers})
+                        writeBuffer(stem, done, (*bufs)[t][0]);
+                if (estimator.runCUDA)
+                    for (auto *bufs : {&estimator.meanCorrBuffers, &estimator.discriminatorBuffers, &estimator.filmFilteredBuffers})
+                        writeBuffer(stem, done, (*bufs)[sCfgs[Radiance].index][0]);
+            }
+            end = std::chrono::steady_clock::now();
+            std::cout << "Output time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(end - begin).count() << std::endl;
+        }
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "statmc_render_sim: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
