@@ -114,3 +114,43 @@ def test_render_loop_statistics_only(gpu, tmp_path):
     n = pfm.read_pfm("%s-4-t0-b0-n.pfm" % stem)
     assert np.all(n == 4.0)
     assert not os.path.exists("%s-4-t0-b0-film-mean-f.pfm" % stem)
+
+
+def test_render_loop_acrr_float_buffers(gpu, oracle, tmp_path):
+    """Render<Float> (`multichannelstats` false, `acrr`): the luminance up to each of 5 tracked
+    bounces is one float stat buffer (StatTile<Float> per bounce, MergeTransformTiles over the
+    bounces), all five filtered by one filter<float> call (estimator.cpp:434-460)."""
+    from statmc_amd import build, pfm
+    build.build_tools()
+    W, H, spp, iterations, seed, radius, sd, nb = 64, 32, 4, 2, 9, 20, 10.0, 5
+    stem = str(tmp_path / "acrr")
+    out = subprocess.run([build.RENDER_SIM_BIN, "--config", "acrr", "--trackedbounces", str(nb), "--width", str(W),
+                          "--height", str(H), "--spp", str(spp), "--iterations", str(iterations), "--seed", str(seed),
+                          "--stem", stem], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    st = [oracle.new_state(H, W, 1) for _ in range(nb)]
+    nrm_st, alb_st = oracle.new_state(H, W, 3), oracle.new_state(H, W, 3)
+    done = 0
+    for i in range(1, iterations + 1):
+        target = spp if i == 1 else spp << (i - 2)
+        rad, nrm, alb = make_samples(seed, W, H, done, target)
+        oracle.accumulate(nrm_st, nrm, False, 1)
+        oracle.accumulate(alb_st, alb, False, 1)
+        for j in range(nb):
+            share = np.float32(j + 1) / np.float32(nb)
+            ls = rad * share
+            lum = (np.float32(0.212671) * ls[..., 0] + np.float32(0.715160) * ls[..., 1]) + np.float32(0.072169) * ls[..., 2]
+            oracle.accumulate(st[j], np.ascontiguousarray(lum[..., None]), True, 3)
+        done += target
+    rd = lambda name: pfm.read_pfm("%s-%d-%s.pfm" % (stem, done, name))
+    for j in range(nb):
+        pre = "t0-b%d-" % j
+        assert np.array_equal(rd(pre + "n"), st[j]["n"].astype(np.float32))
+        assert np.array_equal(rd(pre + "film-mean"), st[j]["film_mean"][..., 0]), j
+        assert np.array_equal(rd(pre + "film-m2"), st[j]["film_m2"][..., 0]), j
+        for k in ("mean", "m2", "m3"):
+            assert rel_l2(rd(pre + k), st[j][k][..., 0]) <= 1e-5, (j, k)
+        mc, dc = oracle.prepass(st[j]["n"], st[j]["mean"], st[j]["m2"], st[j]["m3"])
+        ref = oracle.filter_image(mc, dc, st[j]["film_mean"], [nrm_st["mean"], alb_st["mean"]],
+                                  [-0.5 / 0.1 ** 2, -0.5 / 0.02 ** 2], -0.5 / sd ** 2, radius)
+        assert rel_l2(rd(pre + "film-mean-f"), ref[..., 0]) <= 1e-5, j

@@ -19,6 +19,11 @@
 //
 //   statmc_render_sim --width 96 --height 56 --spp 4 --iterations 3 --stem out/sim [--threads 4]
 //                     [--seed 1] [--filtersd 10] [--filterradius 20] [--stage-mb 2048] [--no-denoise]
+//                     [--config denoise|acrr] [--trackedbounces 5]
+// --config denoise: Render<Vec3>, RGB radiance + normal + albedo, filter<float3> (scenes/render-denoise.pbrt).
+// --config acrr:    Render<Float>, "multichannelstats" false: the luminance of the path prefix up to each
+//                   of the tracked bounces is one float stat buffer, filtered together by filter<float>
+//                   (scenes/acrr.pbrt; estimator.cpp:434-460).
 //   statmc_render_sim [--seed 1] --print-sample x y s     (prints one generated sample, no device)
 #include <atomic>
 #include <chrono>
@@ -53,6 +58,13 @@ static const float kNormal[3][3] = {{0.0f, 0.0f, 1.0f}, {0.6f, -0.8f, 0.0f}, {-0
 struct PixelSample {
     Vec3 radiance, normal, albedo;
 };
+// GetStatSample<T> (statpath.h): the RGB triple, or its luminance (RGBSpectrum::y(), spectrum.h)
+template <typename T>
+static T GetStatSample(const Vec3 &L);
+template <>
+Vec3 GetStatSample<Vec3>(const Vec3 &L) { return L; }
+template <>
+float GetStatSample<float>(const Vec3 &L) { return 0.212671f * L.x + 0.715160f * L.y + 0.072169f * L.z; }
 static PixelSample makeSample(uint32_t seed, int x, int y, uint32_t s) {
     const int region = ((x / 24) + (y / 20)) % 3;
     const float e = 0.5f + 0.5f * ((float)((x * 7 + y * 3) % 32) / 32.0f);
@@ -97,13 +109,145 @@ static void writeBuffer(const std::string &stem, unsigned spp, const Buffer &b) 
     }
 }
 
-int main(int argc, char **argv) {
-    int width = 96, height = 56, spp = 4, iterations = 3, threads = 4, stageMb = 2048;
+struct Options {
+    int width = 96, height = 56, spp = 4, iterations = 3, threads = 4, stageMb = 2048, trackedBounces = 5;
     unsigned seed = 1;
     float filterSD = 10.f;
     int filterRadius = 20;
-    bool denoise = true;
+    bool denoise = true, acrr = false;
     std::string stem;
+};
+
+template <typename T>
+static void Render(const Options &o) {
+    const int width = o.width, height = o.height;
+    StatPathParams params;
+    params.acrr = o.acrr;
+    params.multiChannelStats = !o.acrr;
+    params.trackedBounces = o.trackedBounces;
+    params.denoiseImage = o.denoise && !o.acrr;
+    params.calcStats = !o.denoise && !o.acrr;
+    params.filterSD = o.filterSD;
+    params.filterRadius = (unsigned char)o.filterRadius;
+    const StatTypeConfigs sCfgs = makeStatTypeConfigs(params);
+    // `film` itself is not denoised here (no Film in this harness): the colour images are the
+    // t0-b<j>-film-mean buffers, the results t0-b<j>-film-mean-f.
+    Buffer film("film", HostImage(height, width, F32C3));
+    BufferRegistry reg(film);
+    Estimator estimator(film, sCfgs, o.filterSD, (unsigned char)o.filterRadius, /*denoiseFilm=*/false, o.acrr, false, reg);
+    estimator.AllocateBuffers(reg);
+    estimator.EnableDeviceAccumulation((size_t)o.stageMb << 20);
+
+    std::vector<StatTypeConfig> enabledRGBFeatureCfgs;  // statpath.cpp:160-163
+    for (unsigned char t : {(unsigned char)StatMaterialID, (unsigned char)StatDepth, (unsigned char)StatNormal,
+                            (unsigned char)StatAlbedo})
+        if (sCfgs[t].enable && sCfgs[t].nChannels == 3) enabledRGBFeatureCfgs.push_back(sCfgs[t]);
+    const unsigned char nRGBBuffers = (unsigned char)enabledRGBFeatureCfgs.size();
+    if (nRGBBuffers != 2) throw std::runtime_error("expected the normal and albedo feature types");
+
+    AddSampleFn<T> AddLSampleFn = GetAddSampleFn<T>(sCfgs[Radiance]);
+    AddSampleFn<Vec3> AddRGBGBufferSampleFn = GetAddSampleFn<Vec3>(sCfgs[StatNormal]);
+    const unsigned char nLs = sCfgs[Radiance].bounceEnd;
+
+    const int tileSize = 16;  // statpath.cpp:132
+    const int nTilesX = (width + tileSize - 1) / tileSize, nTilesY = (height + tileSize - 1) / tileSize;
+    const int nTilesTotal = nTilesX * nTilesY;
+    std::vector<std::vector<StatTile<T>>> lTiles(nTilesTotal);
+    std::vector<std::vector<std::vector<StatTile<Vec3>>>> rgbFeatureTiles(nTilesTotal);
+    auto tileBoundsOf = [&](int tileIndex) {
+        const int tx = tileIndex % nTilesX, ty = tileIndex / nTilesX;
+        return Bounds2i(Point2i(tx * tileSize, ty * tileSize),
+                        Point2i(std::min((tx + 1) * tileSize, width), std::min((ty + 1) * tileSize, height)));
+    };
+    for (int t = 0; t < nTilesTotal; t++) {  // statpath.cpp:173-190
+        lTiles[t] = estimator.GetTiles<T>(tileBoundsOf(t), sCfgs[Radiance].bounceEnd);
+        rgbFeatureTiles[t] = estimator.GetTiles<Vec3>(tileBoundsOf(t), 1, nRGBBuffers);
+    }
+
+    unsigned done = 0;  // samples per pixel so far
+    for (int i = 1; i <= o.iterations; i++) {
+        const unsigned target = i == 1 ? (unsigned)o.spp : (unsigned)o.spp << std::max(i - 2, 0);  // statpath.cpp:272-279
+        auto begin = std::chrono::steady_clock::now();
+        std::atomic<int> nextTile{0};
+        std::atomic<bool> failed{false};
+        std::string failure;
+        std::mutex failMu;
+        auto worker = [&]() {
+            try {
+                std::vector<Vec3> Ls(nLs);
+                for (int t = nextTile.fetch_add(1); t < nTilesTotal; t = nextTile.fetch_add(1)) {
+                    const Bounds2i tb = tileBoundsOf(t);
+                    std::vector<StatTile<T>> &tileLs = lTiles[t];
+                    std::vector<std::vector<StatTile<Vec3>>> &tileRGBFeatures = rgbFeatureTiles[t];
+                    for (int y = tb.pMin.y; y < tb.pMax.y; y++)
+                        for (int x = tb.pMin.x; x < tb.pMax.x; x++) {
+                            const Point2i actualPixel(x, y);
+                            for (unsigned s = 0; s < target; s++) {  // do { ... } while (StartNextSample())
+                                const PixelSample smp = makeSample(o.seed, x, y, done + s);
+                                // Li() leaves the radiance gathered up to bounce j in Ls[j]; here a fixed share
+                                for (unsigned char j = 0; j < nLs; j++) {
+                                    const float share = (float)(j + 1) / (float)nLs;
+                                    Ls[j] = Vec3{smp.radiance.x * share, smp.radiance.y * share, smp.radiance.z * share};
+                                }
+                                for (unsigned char j = sCfgs[Radiance].bounceStart; j < sCfgs[Radiance].bounceEnd; j++)
+                                    (tileLs[j].*AddLSampleFn)(actualPixel, GetStatSample<T>(Ls[j]));
+                                (tileRGBFeatures[0][0].*AddRGBGBufferSampleFn)(actualPixel, smp.normal);
+                                (tileRGBFeatures[0][1].*AddRGBGBufferSampleFn)(actualPixel, smp.albedo);
+                            }
+                        }
+                    // Merge tiles into buffers (statpath.cpp:381-388)
+                    estimator.MergeTransformTiles(tileLs, sCfgs[Radiance]);
+                    estimator.MergeTiles(tileRGBFeatures, enabledRGBFeatureCfgs);
+                }
+            } catch (const std::exception &e) {
+                std::lock_guard<std::mutex> lk(failMu);
+                failed = true;
+                failure = e.what();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < o.threads; t++) pool.emplace_back(worker);
+        for (auto &t : pool) t.join();
+        if (failed) throw std::runtime_error(failure);
+        done += target;
+        auto end = std::chrono::steady_clock::now();
+        std::cout << "Iteration: " << i << std::endl;
+        std::cout << "SPP: " << target << std::endl;
+        std::cout << "Rendering time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(end - begin).count() << std::endl;
+
+        begin = std::chrono::steady_clock::now();
+        estimator.Upload();  // stages + accumulates the iteration's samples on the device
+        if (estimator.runCUDA) {
+            estimator.Denoise();
+            estimator.Download();
+        }
+        estimator.Synchronize();
+        end = std::chrono::steady_clock::now();
+        std::cout << "CUDA time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(end - begin).count() << std::endl;
+
+        begin = std::chrono::steady_clock::now();
+        if (!o.stem.empty()) {
+            const unsigned char rad = sCfgs[Radiance].index;
+            estimator.DownloadStatistics();
+            if (estimator.runCUDA)
+                for (auto *bufs : {&estimator.meanCorrBuffers, &estimator.discriminatorBuffers})
+                    for (Buffer &b : (*bufs)[rad]) b.download(estimator.stream);
+            estimator.Synchronize();
+            for (unsigned char t = 0; t < estimator.statTypeConfigs.nEnabled; t++)
+                for (auto *bufs : {&estimator.nBuffers, &estimator.meanBuffers, &estimator.m2Buffers, &estimator.m3Buffers,
+                                   &estimator.filmBuffers, &estimator.filmM2Buffers})
+                    for (const Buffer &b : (*bufs)[t]) writeBuffer(o.stem, done, b);
+            if (estimator.runCUDA)
+                for (auto *bufs : {&estimator.meanCorrBuffers, &estimator.discriminatorBuffers, &estimator.filmFilteredBuffers})
+                    for (const Buffer &b : (*bufs)[rad]) writeBuffer(o.stem, done, b);
+        }
+        end = std::chrono::steady_clock::now();
+        std::cout << "Output time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(end - begin).count() << std::endl;
+    }
+}
+
+int main(int argc, char **argv) {
+    Options o;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> const char * {
@@ -113,21 +257,29 @@ int main(int argc, char **argv) {
             }
             return argv[++i];
         };
-        if (a == "--width") width = std::atoi(next());
-        else if (a == "--height") height = std::atoi(next());
-        else if (a == "--spp") spp = std::atoi(next());
-        else if (a == "--iterations") iterations = std::atoi(next());
-        else if (a == "--threads") threads = std::atoi(next());
-        else if (a == "--seed") seed = (unsigned)std::strtoul(next(), nullptr, 10);
-        else if (a == "--filtersd") filterSD = (float)std::atof(next());
-        else if (a == "--filterradius") filterRadius = std::atoi(next());
-        else if (a == "--stage-mb") stageMb = std::atoi(next());
-        else if (a == "--stem") stem = next();
-        else if (a == "--no-denoise") denoise = false;
-        else if (a == "--print-sample") {  // x y s: the generator alone, no device (CPU test of the restatement)
+        if (a == "--width") o.width = std::atoi(next());
+        else if (a == "--height") o.height = std::atoi(next());
+        else if (a == "--spp") o.spp = std::atoi(next());
+        else if (a == "--iterations") o.iterations = std::atoi(next());
+        else if (a == "--threads") o.threads = std::atoi(next());
+        else if (a == "--seed") o.seed = (unsigned)std::strtoul(next(), nullptr, 10);
+        else if (a == "--filtersd") o.filterSD = (float)std::atof(next());
+        else if (a == "--filterradius") o.filterRadius = std::atoi(next());
+        else if (a == "--stage-mb") o.stageMb = std::atoi(next());
+        else if (a == "--trackedbounces") o.trackedBounces = std::atoi(next());
+        else if (a == "--stem") o.stem = next();
+        else if (a == "--no-denoise") o.denoise = false;
+        else if (a == "--config") {
+            const std::string c = next();
+            if (c != "denoise" && c != "acrr") {
+                std::fprintf(stderr, "unknown config %s\n", c.c_str());
+                return 2;
+            }
+            o.acrr = c == "acrr";
+        } else if (a == "--print-sample") {  // x y s: the generator alone, no device (CPU test of the restatement)
             const int x = std::atoi(next()), y = std::atoi(next());
             const unsigned s = (unsigned)std::strtoul(next(), nullptr, 10);
-            const PixelSample p = makeSample(seed, x, y, s);
+            const PixelSample p = makeSample(o.seed, x, y, s);
             std::printf("%a %a %a %a %a %a %a %a %a\n", p.radiance.x, p.radiance.y, p.radiance.z, p.normal.x, p.normal.y,
                         p.normal.z, p.albedo.x, p.albedo.y, p.albedo.z);
             return 0;
@@ -136,123 +288,14 @@ int main(int argc, char **argv) {
             return 2;
         }
     }
-    if (width <= 0 || height <= 0 || width > 65535 || height > 65535 || spp <= 0 || iterations <= 0 || threads <= 0) {
-        std::fprintf(stderr, "bad size / spp / iterations / threads\n");
+    if (o.width <= 0 || o.height <= 0 || o.width > 65535 || o.height > 65535 || o.spp <= 0 || o.iterations <= 0 ||
+        o.threads <= 0 || o.trackedBounces < 1 || o.trackedBounces > 16) {
+        std::fprintf(stderr, "bad size / spp / iterations / threads / trackedbounces\n");
         return 2;
     }
     try {
-        // Integrator "statpath" "bool denoiseimage" ["true"] with filterbuffers albedo + normal
-        // (scenes/render-denoise.pbrt:19-22); `film` itself is not denoised here (no Film in this
-        // harness), so the colour is t0-b0-film-mean and the result t0-b0-film-mean-f.
-        StatPathParams params;
-        params.denoiseImage = denoise;
-        params.calcStats = !denoise;
-        params.filterSD = filterSD;
-        params.filterRadius = (unsigned char)filterRadius;
-        const StatTypeConfigs sCfgs = makeStatTypeConfigs(params);
-        Buffer film("film", HostImage(height, width, F32C3));
-        BufferRegistry reg(film);
-        Estimator estimator(film, sCfgs, filterSD, (unsigned char)filterRadius, /*denoiseFilm=*/false, false, false, reg);
-        estimator.AllocateBuffers(reg);
-        estimator.EnableDeviceAccumulation((size_t)stageMb << 20);
-
-        std::vector<StatTypeConfig> enabledRGBFeatureCfgs;  // statpath.cpp:160-163
-        for (unsigned char t : {(unsigned char)StatMaterialID, (unsigned char)StatDepth, (unsigned char)StatNormal,
-                                (unsigned char)StatAlbedo})
-            if (sCfgs[t].enable && sCfgs[t].nChannels == 3) enabledRGBFeatureCfgs.push_back(sCfgs[t]);
-        const unsigned char nRGBBuffers = (unsigned char)enabledRGBFeatureCfgs.size();
-        if (nRGBBuffers != 2) throw std::runtime_error("expected the normal and albedo feature types");
-
-        AddSampleFn<Vec3> AddLSampleFn = GetAddSampleFn<Vec3>(sCfgs[Radiance]);
-        AddSampleFn<Vec3> AddRGBGBufferSampleFn = GetAddSampleFn<Vec3>(sCfgs[StatNormal]);
-
-        const int tileSize = 16;  // statpath.cpp:132
-        const int nTilesX = (width + tileSize - 1) / tileSize, nTilesY = (height + tileSize - 1) / tileSize;
-        const int nTilesTotal = nTilesX * nTilesY;
-        std::vector<std::vector<StatTile<Vec3>>> lTiles(nTilesTotal);
-        std::vector<std::vector<std::vector<StatTile<Vec3>>>> rgbFeatureTiles(nTilesTotal);
-        auto tileBoundsOf = [&](int tileIndex) {
-            const int tx = tileIndex % nTilesX, ty = tileIndex / nTilesX;
-            return Bounds2i(Point2i(tx * tileSize, ty * tileSize),
-                            Point2i(std::min((tx + 1) * tileSize, width), std::min((ty + 1) * tileSize, height)));
-        };
-        for (int t = 0; t < nTilesTotal; t++) {  // statpath.cpp:173-190
-            lTiles[t] = estimator.GetTiles<Vec3>(tileBoundsOf(t), sCfgs[Radiance].bounceEnd);
-            rgbFeatureTiles[t] = estimator.GetTiles<Vec3>(tileBoundsOf(t), 1, nRGBBuffers);
-        }
-
-        unsigned done = 0;  // samples per pixel so far
-        for (int i = 1; i <= iterations; i++) {
-            const unsigned target = i == 1 ? (unsigned)spp : (unsigned)spp << std::max(i - 2, 0);  // statpath.cpp:272-279
-            auto begin = std::chrono::steady_clock::now();
-            std::atomic<int> nextTile{0};
-            std::atomic<bool> failed{false};
-            std::string failure;
-            std::mutex failMu;
-            auto worker = [&]() {
-                try {
-                    for (int t = nextTile.fetch_add(1); t < nTilesTotal; t = nextTile.fetch_add(1)) {
-                        const Bounds2i tb = tileBoundsOf(t);
-                        std::vector<StatTile<Vec3>> &tileLs = lTiles[t];
-                        std::vector<std::vector<StatTile<Vec3>>> &tileRGBFeatures = rgbFeatureTiles[t];
-                        for (int y = tb.pMin.y; y < tb.pMax.y; y++)
-                            for (int x = tb.pMin.x; x < tb.pMax.x; x++) {
-                                const Point2i actualPixel(x, y);
-                                for (unsigned s = 0; s < target; s++) {  // do { ... } while (StartNextSample())
-                                    const PixelSample smp = makeSample(seed, x, y, done + s);
-                                    for (unsigned char j = sCfgs[Radiance].bounceStart; j < sCfgs[Radiance].bounceEnd; j++)
-                                        (tileLs[j].*AddLSampleFn)(actualPixel, smp.radiance);
-                                    (tileRGBFeatures[0][0].*AddRGBGBufferSampleFn)(actualPixel, smp.normal);
-                                    (tileRGBFeatures[0][1].*AddRGBGBufferSampleFn)(actualPixel, smp.albedo);
-                                }
-                            }
-                        // Merge tiles into buffers (statpath.cpp:381-388)
-                        estimator.MergeTransformTiles(tileLs, sCfgs[Radiance]);
-                        estimator.MergeTiles(tileRGBFeatures, enabledRGBFeatureCfgs);
-                    }
-                } catch (const std::exception &e) {
-                    std::lock_guard<std::mutex> lk(failMu);
-                    failed = true;
-                    failure = e.what();
-                }
-            };
-            std::vector<std::thread> pool;
-            for (int t = 0; t < threads; t++) pool.emplace_back(worker);
-            for (auto &t : pool) t.join();
-            if (failed) throw std::runtime_error(failure);
-            done += target;
-            auto end = std::chrono::steady_clock::now();
-            std::cout << "Iteration: " << i << std::endl;
-            std::cout << "SPP: " << target << std::endl;
-            std::cout << "Rendering time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(end - begin).count() << std::endl;
-
-            begin = std::chrono::steady_clock::now();
-            estimator.Upload();  // stages + accumulates the iteration's samples on the device
-            if (estimator.runCUDA) {
-                estimator.Denoise();
-                estimator.Download();
-            }
-            estimator.Synchronize();
-            end = std::chrono::steady_clock::now();
-            std::cout << "CUDA time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(end - begin).count() << std::endl;
-
-            begin = std::chrono::steady_clock::now();
-            if (!stem.empty()) {
-                estimator.DownloadStatistics();
-                for (auto *bufs : {&estimator.meanCorrBuffers, &estimator.discriminatorBuffers})
-                    if (estimator.runCUDA) (*bufs)[sCfgs[Radiance].index][0].download(estimator.stream);
-                estimator.Synchronize();
-                for (unsigned char t = 0; t < estimator.statTypeConfigs.nEnabled; t++)
-                    for (auto *bufs : {&estimator.nBuffers, &estimator.meanBuffers, &estimator.m2Buffers, &estimator.m3Buffers,
-                                       &estimator.filmBuffers, &estimator.filmM2Buffers})
-                        writeBuffer(stem, done, (*bufs)[t][0]);
-                if (estimator.runCUDA)
-                    for (auto *bufs : {&estimator.meanCorrBuffers, &estimator.discriminatorBuffers, &estimator.filmFilteredBuffers})
-                        writeBuffer(stem, done, (*bufs)[sCfgs[Radiance].index][0]);
-            }
-            end = std::chrono::steady_clock::now();
-            std::cout << "Output time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(end - begin).count() << std::endl;
-        }
+        if (o.acrr) Render<float>(o);  // StatPathIntegrator::Render dispatches on enableMultiChannelStats
+        else Render<Vec3>(o);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "statmc_render_sim: %s\n", e.what());
         return 1;
