@@ -555,14 +555,6 @@ int statmc_debug_accumulate_resident_blocks(int n) {  // 0 large grid (default),
     g_accumulate_resident_blocks = n < 0 ? 0 : n;
     return STATMC_OK;
 }
-int statmc_debug_filter_ablation(int v) {  // timing-only diagnostic builds (wrong outputs): 1 no LDS reads, 2 no VALU work
-    statmc::set_filter_ablation(v);
-    return STATMC_OK;
-}
-int statmc_debug_filter_stagger(int v) {
-    statmc::set_filter_stagger(v);
-    return STATMC_OK;
-}
 int statmc_debug_force_filter_parts(int k) {  // 0 auto, k >= 1: window-sweep parts per tile
     statmc::set_filter_parts_override(k);
     return STATMC_OK;

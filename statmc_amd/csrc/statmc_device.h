@@ -99,7 +99,6 @@ struct FilterArgs {
     const float *f_mean_corr[3], *f_disc[3], *f_colour[3];
     float *f_out[3];
     int f_active;
-    int stagger;                 // s_sleep argument for waves 4..7 after every barrier (0 = none)
     const float *packed;         // optional [height][width][15] inputs: mc, disc, colour, g0, g1 (RGB each)
 };
 
@@ -132,7 +131,5 @@ void set_filter_variant_override(int v);
 // parts per tile the LDS kernel would use for this ROI on a device with n_cus compute units
 int lds_filter_parts(const FilterArgs &a, int n_cus);
 void set_filter_parts_override(int k);  // 0 = automatic
-void set_filter_stagger(int v);
-void set_filter_ablation(int v);        // diagnostic timing builds of lds_r20 (outputs are wrong): 0 off
 
 }  // namespace statmc

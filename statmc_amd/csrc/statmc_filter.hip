@@ -608,10 +608,6 @@ int choose_parts(int tiles, int n_rows, int n_cus) {
 }
 
 static int g_parts_override = 0;
-static int g_ablation = 0;
-static int g_stagger = 0;
-void set_filter_stagger(int v) { g_stagger = v; }
-void set_filter_ablation(int v) { g_ablation = v; }
 void set_filter_parts_override(int k) { g_parts_override = k; }
 
 template <int RT, bool RGB>
@@ -627,7 +623,6 @@ static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
     }
     const dim3 tiles((a.rx1 - a.rx0 + kTileW - 1) / kTileW, (a.ry1 - a.ry0 + kTileH - 1) / kTileH);
     if (a.partial == nullptr) a.n_parts = 1;
-    a.stagger = g_stagger;
     const dim3 grid(tiles.x * tiles.y * a.n_parts);
     hipLaunchKernelGGL((window_filter_lds<RT, RGB>), grid, dim3(kThreads), lds_bytes, s, a);
     if (a.n_parts > 1) {
