@@ -41,6 +41,11 @@ const char *statmc_last_error(void);
  * Selects the device, uploads the Student-t quantile tables. Idempotent per device. */
 int statmc_setup(int device);
 
+/* Makes `device` current for the calling thread (HIP's current device is per thread): a thread
+ * other than the one that ran statmc_setup -- e.g. a render worker whose Merge*Tiles call triggers a
+ * flush -- calls this before using a device other than 0. */
+int statmc_set_device(int device);
+
 /* The reference picks the significance level at compile time by pointing `t_quantiles` at one
  * of three tables (README.md:149,158): 0 -> 0.005 (default), 1 -> 0.002, 2 -> 0.05. */
 int statmc_set_significance(int alpha_index);

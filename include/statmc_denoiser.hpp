@@ -432,7 +432,7 @@ class Estimator {
           filterDSFactor(-.5f / (filterSD * filterSD)), filterRadius(filterRadius), denoiseFilm(denoiseFilm),
           acrrEnabled(acrrEnabled), smisEnabled(smisEnabled), filmBuffer(filmBuffer),
           filmFilteredBuffer("film-f", HostImage(filmBuffer.mat.rows, filmBuffer.mat.cols, F32C3), allocateDevice),
-          allocateDevice(allocateDevice) {
+          allocateDevice(allocateDevice), device(device) {
         floatBufferCounts.assign(nCUDAGroupIndices, 0);
         rgbBufferCounts.assign(nCUDAGroupIndices, 0);
         // only the enabled configs are kept (estimator.h:269-270)
@@ -740,6 +740,7 @@ class Estimator {
         if (std::find(v.begin(), v.end(), b) == v.end()) v.push_back(b);
     }
     const bool allocateDevice;
+    const int device;
 
     // ---- staging of recorded samples -----------------------------------------------------
     // Between two flushes every merged tile owns one slot: a block of S x pixels "pixel-samples"
@@ -799,6 +800,7 @@ class Estimator {
     // host staging may be rewritten only after the copies of the previous flush have finished
     void beginEpochLocked() const {
         if (!acc.uploadInFlight) return;
+        check(statmc_set_device(device));
         check(statmc_synchronize(stream.handle()));
         acc.uploadInFlight = false;
     }
@@ -891,6 +893,7 @@ class Estimator {
 
     void flushLocked() const {
         if (acc.slots.empty()) return;
+        check(statmc_set_device(device));  // a render worker thread may be the one that flushes
         const size_t n = acc.slots.size();
         // tile tables: bounds (int32 x 4), offsets (int64), samples (int32), one device block
         std::vector<int64_t> offsets(n);

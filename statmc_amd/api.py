@@ -50,7 +50,7 @@ class StatType(C.Structure):
 
 
 EXPORTS = [
-    "statmc_last_error", "statmc_setup", "statmc_set_significance", "statmc_get_significance", "statmc_set_t_quantiles",
+    "statmc_last_error", "statmc_setup", "statmc_set_device", "statmc_set_significance", "statmc_get_significance", "statmc_set_t_quantiles",
     "statmc_malloc", "statmc_free", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_download",
     "statmc_stream_create", "statmc_stream_destroy", "statmc_synchronize",
     "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs",

@@ -172,6 +172,12 @@ int statmc_setup(int device) {
     return STATMC_OK;
 }
 
+int statmc_set_device(int device) {
+    NEED_READY();
+    HIP_TRY(hipSetDevice(device));
+    return STATMC_OK;
+}
+
 int statmc_set_significance(int alpha_index) {
     if (alpha_index < 0 || alpha_index > 2) return fail(STATMC_ERR_INVALID, "alpha_index must be 0, 1 or 2");
     g_alpha_index = alpha_index;
@@ -200,7 +206,7 @@ int statmc_free(void *dev_ptr) {
 }
 int statmc_malloc_host(void **host_ptr, size_t bytes) {
     if (!host_ptr) return fail(STATMC_ERR_INVALID, "null host_ptr");
-    HIP_TRY(hipHostMalloc(host_ptr, bytes, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(host_ptr, bytes, hipHostMallocPortable));
     return STATMC_OK;
 }
 int statmc_free_host(void *host_ptr) {
