@@ -266,7 +266,12 @@ void oracle_filter(int width, int height, int channels, float ds, int radius,
         for (int x = rx0; x < rx1; x++) {
             const size_t p = (size_t)y * width + x;
             float sum_w = 0.f, acc[3] = {0.f, 0.f, 0.f};
-            for (int dy = -radius; dy <= radius; dy++) {
+            /* a pixel whose corrected mean is not finite takes no part: it filters nothing (its output
+             * is its own colour) and joins no other window.  (NaN does so by itself; +-inf would pass
+             * `inf <= inf` against a pixel with fewer than two samples.) */
+            int p_valid = 1;
+            for (int c = 0; c < channels; c++) p_valid &= isfinite(mean_corr[p * channels + c]) != 0;
+            for (int dy = -radius; p_valid && dy <= radius; dy++) {
                 const int qy = y + dy;
                 if (qy < 0 || qy >= height) continue;
                 for (int dx = -radius; dx <= radius; dx++) {
@@ -275,6 +280,7 @@ void oracle_filter(int width, int height, int channels, float ds, int radius,
                     const size_t q = (size_t)qy * width + qx;
                     /* membership: every channel must pass fma(d,d,-D_q) <= D_p */
                     int member = 1;
+                    for (int c = 0; c < channels; c++) member &= isfinite(mean_corr[q * channels + c]) != 0;
                     for (int c = 0; c < channels; c++) {
                         const float d = mean_corr[p * channels + c] - mean_corr[q * channels + c];
                         const float lhs = fmaf(d, d, -disc[q * channels + c]);

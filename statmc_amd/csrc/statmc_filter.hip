@@ -70,7 +70,11 @@ __global__ __launch_bounds__(256) void window_filter_generic(FilterArgs a) {
     }
     float sum_w = 0.f;
     const int r = a.radius;
-    for (int dy = -r; dy <= r; dy++) {
+    // a pixel with a non-finite corrected mean takes no part (spec: DESIGN.md "Filter spec")
+    bool p_valid = true;
+#pragma unroll
+    for (int c = 0; c < C; c++) p_valid = p_valid && __builtin_isfinite(pc[c]);
+    for (int dy = -r; p_valid && dy <= r; dy++) {
         const int qy = y + dy;
         if (qy < 0 || qy >= a.height) continue;
         for (int dx = -r; dx <= r; dx++) {
@@ -78,6 +82,8 @@ __global__ __launch_bounds__(256) void window_filter_generic(FilterArgs a) {
             if (qx < 0 || qx >= a.width) continue;
             const long long q = (long long)qy * a.width + qx;
             bool member = true;
+#pragma unroll
+            for (int c = 0; c < C; c++) member = member & __builtin_isfinite(a.mean_corr[q * C + c]);
 #pragma unroll
             for (int c = 0; c < C; c++) {
                 const float d = pc[c] - a.mean_corr[q * C + c];
@@ -335,14 +341,27 @@ __device__ __forceinline__ StagedPixel load_pixel(const FilterArgs &a, int x, in
     return s;
 }
 
-__device__ __forceinline__ void store_pixel(float *slot, int pitch, int i, const StagedPixel &s, float k0, float k1,
-                                            bool canon) {
-    // Taps outside the image get a NaN corrected mean: they fail every membership comparison.
-    // RGB: a NaN in any statistic of the pixel -> the same treatment (the gate is a max3, which
-    // would drop a NaN in a single channel).
+// Staging rule for the corrected mean (it is what switches a tap off in the inner loop: a NaN
+// there fails every comparison).  Outside the image: NaN.  RGB (one buffer, gate = max3 over the
+// channels, which would drop a NaN in a single channel): a non-finite corrected mean or a NaN
+// discriminator in ANY channel makes the whole pixel NaN.  Float mode (three independent buffers):
+// per buffer, a non-finite corrected mean becomes NaN (a NaN discriminator already fails its compare).
+// +-inf must go too: against a pixel with fewer than two samples (discriminator +inf) it would pass
+// as `inf <= inf` in the oracle's form of the test and as NaN in the max3 form.
+__device__ __forceinline__ f3 canonical_mean(const f3 &mc, const f3 &d, bool valid, bool rgb) {
     const float nan = __builtin_nanf("");
-    const bool v = s.valid && (!canon || (s.mc.x == s.mc.x && s.mc.y == s.mc.y && s.mc.z == s.mc.z &&
-                                         s.d.x == s.d.x && s.d.y == s.d.y && s.d.z == s.d.z));
+    const bool fx = __builtin_isfinite(mc.x), fy = __builtin_isfinite(mc.y), fz = __builtin_isfinite(mc.z);
+    if (rgb) {
+        const bool v = valid && fx && fy && fz && d.x == d.x && d.y == d.y && d.z == d.z;
+        return v ? mc : f3{nan, nan, nan};
+    }
+    return f3{valid && fx ? mc.x : nan, valid && fy ? mc.y : nan, valid && fz ? mc.z : nan};
+}
+
+__device__ __forceinline__ void store_pixel(float *slot, int pitch, int i, const StagedPixel &s, float k0, float k1,
+                                            bool rgb) {
+    const bool v = s.valid;
+    const f3 mc = canonical_mean(s.mc, s.d, v, rgb);
     float *p = slot + i;
     p[(C_G0 + 0) * pitch] = v ? s.g0.x * k0 : 0.f;
     p[(C_G0 + 1) * pitch] = v ? s.g0.y * k0 : 0.f;
@@ -350,9 +369,9 @@ __device__ __forceinline__ void store_pixel(float *slot, int pitch, int i, const
     p[(C_G1 + 0) * pitch] = v ? s.g1.x * k1 : 0.f;
     p[(C_G1 + 1) * pitch] = v ? s.g1.y * k1 : 0.f;
     p[(C_G1 + 2) * pitch] = v ? s.g1.z * k1 : 0.f;
-    p[(C_MC + 0) * pitch] = v ? s.mc.x : nan;
-    p[(C_MC + 1) * pitch] = v ? s.mc.y : nan;
-    p[(C_MC + 2) * pitch] = v ? s.mc.z : nan;
+    p[(C_MC + 0) * pitch] = mc.x;
+    p[(C_MC + 1) * pitch] = mc.y;
+    p[(C_MC + 2) * pitch] = mc.z;
     p[(C_ND + 0) * pitch] = v ? -s.d.x : 0.f;
     p[(C_ND + 1) * pitch] = v ? -s.d.y : 0.f;
     p[(C_ND + 2) * pitch] = v ? -s.d.z : 0.f;
@@ -415,10 +434,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
             mc = f3{a.f_mean_corr[0][p], a.f_mean_corr[1][p], a.f_mean_corr[2][p]};
             d = f3{a.f_disc[0][p], a.f_disc[1][p], a.f_disc[2][p]};
         }
-        if constexpr (RGB) {  // same NaN canonicalisation as store_pixel: the gate is a max3
-            if (!(mc.x == mc.x && mc.y == mc.y && mc.z == mc.z && d.x == d.x && d.y == d.y && d.z == d.z))
-                mc.x = mc.y = mc.z = __builtin_nanf("");
-        }
+        mc = canonical_mean(mc, d, true, RGB);  // the same rule as for the staged taps
         if (!(RGB && a.packed)) {
             g0 = reinterpret_cast<const f3 *>(a.g[0].data)[p];
             g1 = reinterpret_cast<const f3 *>(a.g[1].data)[p];

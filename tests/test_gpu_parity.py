@@ -513,6 +513,53 @@ def test_filter_special_pixels(gpu, oracle):
         assert max(rel_l2(out[..., c], ref[..., c]) for c in range(3)) <= TOL, v
 
 
+def test_filter_non_finite_corrected_mean(gpu, oracle):
+    """A pixel whose corrected mean is +-inf (all channels or one) takes no part -- in particular it
+    must not slip into the window of a neighbour with fewer than two samples (discriminator +inf),
+    where the oracle's `inf <= inf` and the kernel's max3 form would disagree.  Found by
+    tools/experiments/fuzz_gpu.py (tiny images, +inf mean next to +inf discriminator)."""
+    for W, H, radius in ((2, 1, 1), (6, 2, 8), (270, 12, 20), (33, 9, 5)):
+        rng = np.random.default_rng(W * 7 + H)
+        mc = rng.standard_normal((H, W, 3)).astype(np.float32)
+        disc = (rng.random((H, W, 3)) * 2).astype(np.float32)
+        colour = rng.random((H, W, 3), dtype=np.float32) * 3
+        gbs = [rng.random((H, W, 3), dtype=np.float32), rng.random((H, W, 3), dtype=np.float32)]
+        mc[0, 0] = np.inf
+        disc[0, W - 1] = np.inf                                        # a neighbour that accepts everything finite
+        if W > 8:
+            mc[H // 2, 5, 1] = -np.inf                                  # one channel only
+            disc[H // 2, 7] = np.inf
+            mc[H - 1, 3] = np.inf
+            disc[H - 1, 3] = np.inf                                     # both at the same pixel
+        g_dr = [-0.5 / 0.3 ** 2, -0.5 / 0.2 ** 2]
+        ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / FILTER_SD ** 2, radius)
+        assert np.array_equal(ref[0, 0], colour[0, 0])                  # filters nothing: its own colour
+        for force in (0, 2, 1):
+            out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, FILTER_SD, radius, force=force)
+            assert np.isfinite(out).all(), v
+            assert np.array_equal(out[0, 0], colour[0, 0]), v
+            assert max(rel_l2(out[..., c], ref[..., c]) for c in range(3)) <= TOL, (v, W, H)
+    # filter<float>: validity is per buffer
+    W, H = 40, 6
+    rng = np.random.default_rng(3)
+    mcs = [rng.standard_normal((H, W)).astype(np.float32) for _ in range(3)]
+    dcs = [(rng.random((H, W)) * 2).astype(np.float32) for _ in range(3)]
+    cols = [rng.random((H, W), dtype=np.float32) for _ in range(3)]
+    gbs = [rng.random((H, W, 3), dtype=np.float32), rng.random((H, W, 3), dtype=np.float32)]
+    mcs[1][2, 10] = np.inf
+    dcs[1][2, 12] = np.inf
+    dcs[0][2, 12] = np.inf
+    g_dr = [-0.5 / 0.3 ** 2, -0.5 / 0.2 ** 2]
+    outs = [torch.zeros(H, W, device=DEV) for _ in range(3)]
+    a, keep = gpu.make_filter_args([], [], [], [], [to_dev(c) for c in cols], [to_dev(m) for m in mcs], [to_dev(d) for d in dcs],
+                                   outs, [to_dev(g) for g in gbs], g_dr=g_dr, filter_sd=FILTER_SD, radius=20)
+    gpu.window_filter(a, 1)
+    torch.cuda.synchronize()
+    for b in range(3):
+        ref = oracle.filter_image(mcs[b], dcs[b], cols[b], gbs, g_dr, -0.5 / FILTER_SD ** 2, 20)
+        assert rel_l2(outs[b].cpu().numpy(), ref) <= TOL, b
+
+
 def test_filter_roi(gpu, oracle):
     """The multi-GPU block path: outputs only inside the ROI, window clipped to the local image."""
     mc, disc, colour, gbs = stats_case(oracle, 330, 60, 8, seed=6)

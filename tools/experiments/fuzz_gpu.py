@@ -1,0 +1,123 @@
+"""Scratch: long randomised differential run of the HIP entry points against the CPU oracle
+(the seeded short versions live in tests/test_gpu_parity.py).
+usage: fuzz_gpu.py [seconds] [first_case]      run cases first_case, first_case+1, ... for `seconds`
+       fuzz_gpu.py --case N                    re-run one case and print where it differs"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from oracle import oracle
+from statmc_amd import api as gpu
+import test_gpu_parity as T
+oracle.build(); gpu.setup(0)
+
+
+def filter_case(case, verbose=False):
+    rng = np.random.default_rng(1000003 * 17 + case)
+    W = int(rng.choice([rng.integers(1, 12), rng.integers(12, 300), rng.integers(250, 800)]))
+    H = int(rng.choice([rng.integers(1, 6), rng.integers(6, 70)]))
+    radius = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 13, 19, 20, 20, 20, 21, 25]))
+    sd = float(rng.uniform(0.7, 15.0))
+    g_sds = [float(10 ** rng.uniform(-2, 0)), float(10 ** rng.uniform(-2.3, 0))]
+    g_dr = [-0.5 / s ** 2 for s in g_sds]
+    scale = float(10 ** rng.uniform(-3, 3))
+    mc = (rng.standard_normal((H, W, 3)) * scale).astype(np.float32)
+    disc = ((rng.random((H, W, 3)) ** 3) * 2.0 * scale * scale).astype(np.float32)
+    inj = []
+    for _ in range(int(rng.integers(0, 4))):
+        y, x = int(rng.integers(0, H)), int(rng.integers(0, W))
+        kind = int(rng.integers(0, 5))
+        inj.append((kind, x, y))
+        if kind == 0: disc[y, x] = np.inf
+        elif kind == 1: mc[y, x, rng.integers(0, 3)] = np.nan
+        elif kind == 2: disc[y, x] = 0.0
+        elif kind == 3: mc[y, x] = np.inf
+        else: disc[y, x, rng.integers(0, 3)] = np.nan
+    colour = (rng.random((H, W, 3), dtype=np.float32) * 3 * float(10 ** rng.uniform(-2, 3))).astype(np.float32)
+    gbs = [rng.random((H, W, 3), dtype=np.float32) * 2 - 1, rng.random((H, W, 3), dtype=np.float32)]
+    if rng.random() < 0.3:   # piecewise-constant features: many exactly equal taps
+        gbs = [(np.round(g * 2) / 2).astype(np.float32) for g in gbs]
+    roi = None
+    if rng.random() < 0.4 and W > 2 and H > 2:
+        x0, y0 = int(rng.integers(0, W - 1)), int(rng.integers(0, H - 1))
+        roi = (x0, y0, int(rng.integers(x0 + 1, W + 1)), int(rng.integers(y0 + 1, H + 1)))
+    ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / sd ** 2, radius, roi=roi)
+    force = int(rng.choice([0, 0, 0, 2, 1]))
+    parts = int(rng.choice([0, 0, 1, 2, 3, 5, 41]))
+    gpu.force_filter_parts(parts)
+    try:
+        out, v = T.run_filter(gpu, mc, disc, colour, gbs, g_dr, sd, radius, roi=roi, force=force)
+    finally:
+        gpu.force_filter_parts(0)
+    mask = np.isfinite(ref)
+    ok = np.array_equal(np.isfinite(out), mask)
+    err = 0.0
+    if ok and mask.any():
+        err = max(T.rel_l2(np.where(mask[..., c], out[..., c], 0), np.where(mask[..., c], ref[..., c], 0)) for c in range(3))
+    desc = dict(case=case, W=W, H=H, radius=radius, sd=round(sd, 3), g_sds=[round(g, 4) for g in g_sds], scale=scale, roi=roi,
+                force=force, parts=parts, variant=v, inj=inj, err=err, finite_ok=ok)
+    if verbose:
+        print(desc)
+        d = np.abs(out.astype(np.float64) - ref) / (np.abs(ref) + 1e-30)
+        d[~mask] = 0
+        idx = np.argsort(d.max(axis=2).ravel())[::-1][:8]
+        for i in idx:
+            y, x = divmod(int(i), W)
+            print("  (x=%d,y=%d) gpu %s ref %s colour %s" % (x, y, out[y, x], ref[y, x], colour[y, x]))
+    return (ok and err <= 1e-5), desc
+
+
+def accumulate_case(case):
+    rng = np.random.default_rng(1000003 * 31 + case)
+    W2, H2 = int(rng.integers(1, 90)), int(rng.integers(1, 40))
+    C = int(rng.choice([1, 3])); tr = bool(rng.integers(0, 2)); mm = int(rng.integers(1, 4)); S = int(rng.choice([0, 1, 2, 3, 5, 7, 16, 33]))
+    st = oracle.new_state(H2, W2, C)
+    if rng.random() < 0.5:
+        st["n"][...] = rng.integers(0, 5000, size=(H2, W2)).astype(np.int32)
+        for k in ("mean", "film_mean"): st[k][...] = rng.standard_normal((H2, W2, C)).astype(np.float32)
+        for k in ("m2", "film_m2", "m3"): st[k][...] = rng.random((H2, W2, C)).astype(np.float32)
+    smp = (rng.lognormal(0, 2.0, size=(S, H2, W2, C)) * float(10 ** rng.uniform(-3, 3))).astype(np.float32)
+    smp[rng.random(smp.shape) < 0.2] = 0.0
+    dst = T.dev_state(st)
+    oracle.accumulate(st, smp, tr, mm)
+    gpu.accumulate(W2, H2, [gpu.make_stat_type(T.to_dev(smp), dst, tr, mm)])
+    torch.cuda.synchronize()
+    bad = []
+    for k in ("n", "mean", "m2", "m3", "film_mean", "film_m2"):
+        if k == "m2" and mm < 2: continue
+        if k == "m3" and mm < 3: continue
+        if k in ("film_mean", "film_m2") and not tr: continue
+        got = dst[k].cpu().numpy()
+        if (not tr) or k in ("n", "film_mean", "film_m2"):
+            good = np.array_equal(got, st[k])
+        elif k == "m3":   # sums of cubes cancel (exactly 0 after two samples): error against the size of the terms
+            den = np.sqrt((st["m2"].astype(np.float64) ** 3).sum()) + 1e-300
+            good = np.sqrt(((got.astype(np.float64) - st[k]) ** 2).sum()) / den <= 1e-5
+        else:
+            good = T.rel_l2(got, st[k]) <= 1e-5
+        if not good: bad.append(k)
+    return not bad, dict(case=case, W=W2, H=H2, C=C, transform=tr, max_moment=mm, S=S, bad=bad)
+
+
+if len(sys.argv) > 2 and sys.argv[1] == "--case":
+    print(filter_case(int(sys.argv[2]), verbose=True)[0])
+    print(accumulate_case(int(sys.argv[2])))
+    sys.exit(0)
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+case = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+t_end = time.time() + budget
+n = fails = 0
+worst = 0.0
+while time.time() < t_end:
+    ok, d = filter_case(case)
+    worst = max(worst, d["err"])
+    if not ok:
+        fails += 1
+        print("FAIL filter", d, flush=True)
+    ok, d = accumulate_case(case)
+    if not ok:
+        fails += 1
+        print("FAIL accumulate", d, flush=True)
+    case += 1
+    n += 1
+print("cases %d (next %d), worst filter rel L2 %.3g, failures %d" % (n, case, worst, fails))
