@@ -99,9 +99,121 @@ def accumulate_case(case):
     return not bad, dict(case=case, W=W2, H=H2, C=C, transform=tr, max_moment=mm, S=S, bad=bad)
 
 
+def prepass_case(case):
+    rng = np.random.default_rng(1000003 * 43 + case)
+    W, H, C = int(rng.integers(1, 70)), int(rng.integers(1, 20)), int(rng.choice([1, 3]))
+    n = rng.choice([0, 1, 2, 3, 7, 64, 4095, 4096, 4097, 5000, 100000], size=(H, W)).astype(np.int32)
+    scale = float(10 ** rng.uniform(-4, 4))
+    shape = (H, W, C)
+    mean = (rng.standard_normal(shape) * scale).astype(np.float32)
+    m2 = (rng.random(shape) ** 2 * scale * scale * 50).astype(np.float32)
+    m3 = (rng.standard_normal(shape) * scale ** 3 * 100).astype(np.float32)
+    m2[rng.random(shape) < 0.1] = 0.0
+    m2[rng.random(shape) < 0.02] = -1.0
+    m3[rng.random(shape) < 0.02] = np.nan
+    mean[rng.random(shape) < 0.02] = np.inf
+    alpha = int(rng.integers(0, 3))
+    mc_ref, dc_ref = oracle.prepass(n, mean, m2, m3, alpha_index=alpha)
+    mc, dc = torch.zeros(shape, device=T.DEV), torch.zeros(shape, device=T.DEV)
+    dummy = torch.zeros(shape, device=T.DEV)
+    a, keep = gpu.make_filter_args([T.to_dev(n)], [T.to_dev(mean)], [T.to_dev(m2)], [T.to_dev(m3)], [dummy], [mc], [dc], [dummy],
+                                   [], g_dr=[], filter_sd=10.0, radius=1)
+    gpu.check(gpu.load().statmc_set_significance(alpha))
+    try:
+        gpu.prepass(a, C)
+        torch.cuda.synchronize()
+    finally:
+        gpu.load().statmc_set_significance(0)
+    eq = lambda x, y: np.array_equal(x, y, equal_nan=True)
+    ok = eq(mc.cpu().numpy(), mc_ref) and eq(dc.cpu().numpy(), dc_ref)
+    return ok, dict(case=case, W=W, H=H, C=C, alpha=alpha, scale=scale)
+
+
+def float_filter_case(case):
+    rng = np.random.default_rng(1000003 * 59 + case)
+    W, H = int(rng.integers(1, 330)), int(rng.integers(1, 30))
+    nb = int(rng.integers(1, 8)); radius = int(rng.choice([1, 3, 6, 8, 13, 20, 20, 22]))
+    sd = float(rng.uniform(1, 12)); g_sds = [float(rng.uniform(0.05, 0.6)), float(rng.uniform(0.02, 0.5))]
+    g_dr = [-0.5 / x ** 2 for x in g_sds]
+    gbs = [rng.random((H, W, 3), dtype=np.float32) * 2 - 1, rng.random((H, W, 3), dtype=np.float32)]
+    mcs = [rng.standard_normal((H, W, 1)).astype(np.float32) for _ in range(nb)]
+    dcs = [((rng.random((H, W, 1)) ** 3) * 2).astype(np.float32) for _ in range(nb)]
+    cols = [rng.random((H, W, 1), dtype=np.float32) * 5 for _ in range(nb)]
+    for b in range(nb):
+        for _ in range(int(rng.integers(0, 3))):
+            y, x = int(rng.integers(0, H)), int(rng.integers(0, W))
+            k = int(rng.integers(0, 4))
+            if k == 0: dcs[b][y, x] = np.inf
+            elif k == 1: mcs[b][y, x] = np.nan
+            elif k == 2: mcs[b][y, x] = np.inf
+            else: dcs[b][y, x] = np.nan
+    outs = [torch.zeros(H, W, 1, device=T.DEV) for _ in range(nb)]
+    a, keep = gpu.make_filter_args([], [], [], [], [T.to_dev(c) for c in cols], [T.to_dev(m) for m in mcs], [T.to_dev(d) for d in dcs],
+                                   outs, [T.to_dev(g) for g in gbs], g_dr=g_dr, filter_sd=sd, radius=radius)
+    force = int(rng.choice([0, 0, 2, 1]))
+    gpu.force_filter_variant(force)
+    try:
+        gpu.window_filter(a, 1)
+        torch.cuda.synchronize()
+    finally:
+        gpu.force_filter_variant(0)
+    worst = 0.0
+    for b in range(nb):
+        ref = oracle.filter_image(mcs[b], dcs[b], cols[b], gbs, g_dr, -0.5 / sd ** 2, radius)
+        worst = max(worst, T.rel_l2(outs[b].cpu().numpy(), ref))
+    return worst <= 1e-5, dict(case=case, W=W, H=H, nb=nb, radius=radius, force=force, variant=gpu.last_filter_variant(), err=worst)
+
+
+def tiles_case(case):
+    rng = np.random.default_rng(1000003 * 71 + case)
+    W, H = int(rng.integers(1, 130)), int(rng.integers(1, 60))
+    ts = int(rng.choice([4, 8, 12, 16, 16, 16, 20, 32]))
+    C = int(rng.choice([1, 3])); tr = bool(rng.integers(0, 2)); mm = int(rng.integers(1, 4))
+    ref = oracle.new_state(H, W, C)
+    if rng.random() < 0.5:
+        ref["n"][...] = rng.integers(0, 300, size=(H, W)).astype(np.int32)
+        for k in ("mean", "film_mean"): ref[k][...] = rng.standard_normal((H, W, C)).astype(np.float32)
+        for k in ("m2", "film_m2", "m3"): ref[k][...] = rng.random((H, W, C)).astype(np.float32)
+    dev = T.dev_state(ref)
+    tiles = [(x, y, min(x + ts, W), min(y + ts, H)) for y in range(0, H, ts) for x in range(0, W, ts)]
+    order = rng.permutation(len(tiles))
+    bounds, offsets, counts, blocks, off = [], [], [], [], 0
+    pad4 = bool(rng.integers(0, 2))
+    for k in order:
+        x0, y0, x1, y1 = tiles[k]
+        S = int(rng.choice([0, 1, 2, 3, 5, 9, 17])); npx = (x1 - x0) * (y1 - y0)
+        smp = rng.lognormal(0, 1.5, size=(S, y1 - y0, x1 - x0, C)).astype(np.float32)
+        size = (S * npx + 3) // 4 * 4 if pad4 else S * npx
+        blk = np.zeros(size * C, np.float32); blk[:smp.size] = smp.ravel()
+        bounds.append((x0, y0, x1, y1)); offsets.append(off); counts.append(S); blocks.append(blk); off += size
+        if S:
+            sub = {key: np.ascontiguousarray(v[y0:y1, x0:x1]) for key, v in ref.items()}
+            oracle.accumulate(sub, smp, tr, mm)
+            for key, v in sub.items(): ref[key][y0:y1, x0:x1] = v
+    arena = T.to_dev(np.concatenate(blocks + [np.zeros(4, np.float32)]))
+    st = gpu.make_stat_type_arena(arena, C, dev, tr, mm)
+    gpu.accumulate_tiles(W, H, [st], T.to_dev(np.array(bounds, np.int32).reshape(-1, 4)), T.to_dev(np.array(offsets, np.int64)),
+                         T.to_dev(np.array(counts, np.int32)))
+    torch.cuda.synchronize()
+    bad = []
+    for k in ("n", "mean", "m2", "m3", "film_mean", "film_m2"):
+        if k == "m2" and mm < 2: continue
+        if k == "m3" and mm < 3: continue
+        if k in ("film_mean", "film_m2") and not tr: continue
+        got = dev[k].cpu().numpy()
+        if (not tr) or k in ("n", "film_mean", "film_m2"): good = np.array_equal(got, ref[k])
+        elif k == "m3":
+            den = np.sqrt((ref["m2"].astype(np.float64) ** 3).sum()) + 1e-300
+            good = np.sqrt(((got.astype(np.float64) - ref[k]) ** 2).sum()) / den <= 1e-5
+        else: good = T.rel_l2(got, ref[k]) <= 1e-5
+        if not good: bad.append(k)
+    return not bad, dict(case=case, W=W, H=H, ts=ts, C=C, transform=tr, max_moment=mm, pad4=pad4, bad=bad)
+
+
 if len(sys.argv) > 2 and sys.argv[1] == "--case":
     print(filter_case(int(sys.argv[2]), verbose=True)[0])
-    print(accumulate_case(int(sys.argv[2])))
+    for fn in (accumulate_case, prepass_case, float_filter_case, tiles_case):
+        print(fn.__name__, fn(int(sys.argv[2])))
     sys.exit(0)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 case = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -114,10 +226,12 @@ while time.time() < t_end:
     if not ok:
         fails += 1
         print("FAIL filter", d, flush=True)
-    ok, d = accumulate_case(case)
-    if not ok:
-        fails += 1
-        print("FAIL accumulate", d, flush=True)
+    for name, fn in (("accumulate", accumulate_case), ("prepass", prepass_case), ("float_filter", float_filter_case),
+                     ("tiles", tiles_case)):
+        ok, d = fn(case)
+        if not ok:
+            fails += 1
+            print("FAIL", name, d, flush=True)
     case += 1
     n += 1
 print("cases %d (next %d), worst filter rel L2 %.3g, failures %d" % (n, case, worst, fails))
