@@ -208,68 +208,86 @@ __device__ __forceinline__ void load_half(HalfChunk &c, const float *__restrict_
 // RGB = true: filter<float3> -- one buffer, membership is the AND over its three channels.
 // RGB = false: filter<float> -- the three "channels" are three independent 1-channel buffers
 // (ACRR bounces / SMIS win rates) that share the range weight but gate and normalise separately.
-template <int H, unsigned MASK, bool RGB>
-__device__ __forceinline__ void compute_half(LaneState &st, const HalfChunk &c) {
-    constexpr int i0 = 2 * H;
-    auto in0 = [](int k) { return (MASK & (1u << (i0 * 4 + k))) != 0; };
-    auto in1 = [](int k) { return (MASK & (1u << ((i0 + 1) * 4 + k))) != 0; };
-    auto on = [&](int k) { return in0(k) || in1(k); };
-    const v2f *q = c.q;
+template <int H, unsigned MASK>
+struct TapMask {
+    static constexpr int i0 = 2 * H;
+    static constexpr bool in0(int k) { return (MASK & (1u << (i0 * 4 + k))) != 0; }
+    static constexpr bool in1(int k) { return (MASK & (1u << ((i0 + 1) * 4 + k))) != 0; }
+    static constexpr bool on(int k) { return in0(k) || in1(k); }
+};
 
-    v2f e[kPx], u[kPx][3], w[kPx];
-    // range weight exponent: tab - |k_n dn|^2 - |k_a da|^2 for both taps at once
+// range weight exponent of a tap pair against the lane's 4 pixels: tab - |k_n dn|^2 - |k_a da|^2
+template <int H, unsigned MASK>
+__device__ __forceinline__ void range_exponent(const LaneState &st, const v2f *g, const v2f *tp, v2f (&e)[kPx]) {
+    using M = TapMask<H, MASK>;
 #pragma unroll
-    for (int k = 0; k < kPx; k++) if (on(k)) { const v2f d = st.pg[k][0] - q[C_G0]; e[k] = -d * d; }
+    for (int k = 0; k < kPx; k++) if (M::on(k)) { const v2f d = st.pg[k][0] - g[0]; e[k] = -d * d; }
 #pragma unroll
     for (int ch = 1; ch < 6; ch++) {
 #pragma unroll
-        for (int k = 0; k < kPx; k++) if (on(k)) { const v2f d = st.pg[k][ch] - q[C_G0 + ch]; e[k] = __builtin_elementwise_fma(-d, d, e[k]); }
+        for (int k = 0; k < kPx; k++) if (M::on(k)) { const v2f d = st.pg[k][ch] - g[ch]; e[k] = __builtin_elementwise_fma(-d, d, e[k]); }
     }
 #pragma unroll
-    for (int k = 0; k < kPx; k++) if (on(k)) e[k] += c.tp[k];
+    for (int k = 0; k < kPx; k++) if (M::on(k)) e[k] += tp[k];
+}
+
+// membership gate, weight and accumulation of a tap pair (mc / nd / col: corrected mean,
+// -discriminator, colour of the two taps, 3 channels each)
+template <int H, unsigned MASK, bool RGB>
+__device__ __forceinline__ void gate_accumulate(LaneState &st, const v2f (&e)[kPx], const v2f *mc, const v2f *nd, const v2f *col) {
+    using M = TapMask<H, MASK>;
+    v2f u[kPx][3], w[kPx];
     // membership statistic per channel: t_c = fma(d_c, d_c, -D_q,c)  (the oracle's expression)
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
 #pragma unroll
-        for (int k = 0; k < kPx; k++) if (on(k)) { const v2f d = st.pmc[k][ch] - q[C_MC + ch]; u[k][ch] = __builtin_elementwise_fma(d, d, q[C_ND + ch]); }
+        for (int k = 0; k < kPx; k++) if (M::on(k)) { const v2f d = st.pmc[k][ch] - mc[ch]; u[k][ch] = __builtin_elementwise_fma(d, d, nd[ch]); }
     }
 #pragma unroll
-    for (int k = 0; k < kPx; k++) if (on(k)) w[k] = v2f{__builtin_amdgcn_exp2f(e[k].x), __builtin_amdgcn_exp2f(e[k].y)};
+    for (int k = 0; k < kPx; k++) if (M::on(k)) w[k] = v2f{__builtin_amdgcn_exp2f(e[k].x), __builtin_amdgcn_exp2f(e[k].y)};
     if constexpr (RGB) {
-        // all three channels pass  <=>  max_c (t_c - D_p,c) <= 0: (t - D <= 0) has exactly the truth
-        // value of the oracle's (t <= D); max3 + compare + select stays on the VALU, where 3 compares
-        // + 2 scalar ANDs send every pair through the scalar unit.  v_max3 drops NaN operands, so a
-        // pixel with a NaN statistic is staged with NaN in all three channels (store_pixel).
+        // all three channels pass  <=>  max_c (t_c - D_p,c) <= 0: (t - D <= 0) has the truth value of the
+        // oracle's (t <= D) for every finite t; max3 + compare + select stays on the VALU, where 3
+        // compares + 2 scalar ANDs send every pair through the scalar unit.  v_max3 drops NaN operands,
+        // so a pixel with a NaN statistic or a non-finite mean is staged with NaN in all three
+        // channels (canonical_mean).
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
 #pragma unroll
-            for (int k = 0; k < kPx; k++) if (on(k)) u[k][ch] = u[k][ch] - st.pd[k][ch];
+            for (int k = 0; k < kPx; k++) if (M::on(k)) u[k][ch] = u[k][ch] - st.pd[k][ch];
         }
 #pragma unroll
-        for (int k = 0; k < kPx; k++) if (on(k)) {
+        for (int k = 0; k < kPx; k++) if (M::on(k)) {
             const float m0 = __builtin_fmaxf(__builtin_fmaxf(u[k][0].x, u[k][1].x), u[k][2].x);
             const float m1 = __builtin_fmaxf(__builtin_fmaxf(u[k][0].y, u[k][1].y), u[k][2].y);
-            w[k] = v2f{in0(k) && m0 <= 0.f ? w[k].x : 0.f, in1(k) && m1 <= 0.f ? w[k].y : 0.f};
+            w[k] = v2f{M::in0(k) && m0 <= 0.f ? w[k].x : 0.f, M::in1(k) && m1 <= 0.f ? w[k].y : 0.f};
         }
 #pragma unroll
-        for (int k = 0; k < kPx; k++) if (on(k)) st.sw[k][0] += w[k];
+        for (int k = 0; k < kPx; k++) if (M::on(k)) st.sw[k][0] += w[k];
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
 #pragma unroll
-            for (int k = 0; k < kPx; k++) if (on(k)) st.acc[k][ch] = __builtin_elementwise_fma(w[k], q[C_COL + ch], st.acc[k][ch]);
+            for (int k = 0; k < kPx; k++) if (M::on(k)) st.acc[k][ch] = __builtin_elementwise_fma(w[k], col[ch], st.acc[k][ch]);
         }
     } else {
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
 #pragma unroll
-            for (int k = 0; k < kPx; k++) if (on(k)) {
-                const v2f wc = v2f{in0(k) && u[k][ch].x <= st.pd[k][ch] ? w[k].x : 0.f,
-                                   in1(k) && u[k][ch].y <= st.pd[k][ch] ? w[k].y : 0.f};
+            for (int k = 0; k < kPx; k++) if (M::on(k)) {
+                const v2f wc = v2f{M::in0(k) && u[k][ch].x <= st.pd[k][ch] ? w[k].x : 0.f,
+                                   M::in1(k) && u[k][ch].y <= st.pd[k][ch] ? w[k].y : 0.f};
                 st.sw[k][ch] += wc;
-                st.acc[k][ch] = __builtin_elementwise_fma(wc, q[C_COL + ch], st.acc[k][ch]);
+                st.acc[k][ch] = __builtin_elementwise_fma(wc, col[ch], st.acc[k][ch]);
             }
         }
     }
+}
+
+template <int H, unsigned MASK, bool RGB>
+__device__ __forceinline__ void compute_half(LaneState &st, const HalfChunk &c) {
+    v2f e[kPx];
+    range_exponent<H, MASK>(st, c.q + C_G0, c.tp, e);
+    gate_accumulate<H, MASK, RGB>(st, e, c.q + C_MC, c.q + C_ND, c.q + C_COL);
 }
 
 // Sweep one window row: 2*rp/4 + 1 read groups.  RT > 0 (compile-time radius, a multiple of 4):
@@ -308,7 +326,6 @@ __device__ __forceinline__ void eval_row(LaneState &st, const float *row, int pi
         }
     }
 }
-
 // Stage one image row (image row yrow, columns x0-rp .. x0-rp+pitch) into an LDS ring slot.
 struct StagedPixel {
     f3 mc, d, g0, g1, col;
