@@ -8,7 +8,8 @@
 //   statmc::stat_denoiser::setup / filter<T> / calculateMeanVars<T> / synchronize
 //                                        <- cv::cuda::stat_denoiser::* (estimator.h:280,
 //                                           estimator.cpp:437-487, 501-521, 572)
-//   statmc::Buffer, BufferRegistry       <- src/statistics/buffer.h:19-80
+//   statmc::Buffer, BufferRegistry, OutputBufferSelection
+//                                        <- src/statistics/buffer.h:19-108, buffer.cpp:12-79
 //   statmc::StatTypeConfig(s), enums     <- src/statistics/estimator.h:61-102, statpath.h:20-36
 //   statmc::makeStatTypeConfigs          <- CreateStatPathIntegrator's rules, statpath.cpp:1013-1173
 //   statmc::Estimator                    <- src/statistics/estimator.h:241-380, estimator.cpp:86-289,
@@ -33,12 +34,14 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <regex>
 #include <stdexcept>
 #include <string>
 #include <unordered_set>
 #include <vector>
 
 #include "statmc.h"
+#include "statmc_pfm.hpp"
 
 namespace statmc {
 
@@ -234,6 +237,58 @@ class BufferRegistry {
         return nullptr;
     }
     std::vector<Buffer> buffers;
+};
+
+// src/statistics/buffer.h:82-108, buffer.cpp:12-53: the buffers of a registry whose names match a
+// regular expression (the integrator's "outputregex", statpath.cpp:1003-1011), written as
+// "<stem>[-<suffix>]-<buffer name>.<ext>".  The reference writes through cv::imwrite (any format
+// OpenCV knows; the statistics workflow uses .pfm, README.md "outputregex"); this build writes PFM
+// only.  Display() (tev, src/display) is out of scope.
+class OutputBufferSelection {
+  public:
+    OutputBufferSelection(const BufferRegistry &reg, const std::string &filename) {
+        SetFilename(filename);
+        for (const Buffer &b : reg.buffers) buffers.push_back(b);
+    }
+    OutputBufferSelection(const BufferRegistry &reg, const std::regex &regex, const std::string &filename) {
+        SetFilename(filename);
+        for (const Buffer &b : reg.buffers)
+            if (std::regex_match(b.name, regex)) buffers.push_back(b);
+    }
+    // buffer.cpp:31-35: everything that is not float (the int32 counts) is converted to float
+    void PrepareOutput() const {
+        outMats.assign(buffers.size(), std::vector<float>());
+        for (size_t i = 0; i < buffers.size(); i++) {
+            const Buffer &b = buffers[i];
+            if (b.mat.type != I32C1) continue;
+            const int32_t *src = b.mat.ptr<int32_t>();
+            outMats[i].resize((size_t)b.mat.rows * b.mat.cols);
+            for (size_t k = 0; k < outMats[i].size(); k++) outMats[i][k] = (float)src[k];
+        }
+    }
+    void Write(const std::string &filenameSuffix = "") const {  // buffer.cpp:37-53
+        if (filenameExtension != "pfm") throw Error(STATMC_ERR_UNSUPPORTED, "OutputBufferSelection::Write: only .pfm is written");
+        if (outMats.size() != buffers.size()) PrepareOutput();
+        for (size_t i = 0; i < buffers.size(); i++) {
+            const Buffer &b = buffers[i];
+            const std::string filename = (filenameSuffix.empty() ? filenameStem : filenameStem + "-" + filenameSuffix) + "-" +
+                                         b.name + "." + filenameExtension;
+            const float *data = b.mat.type == I32C1 ? outMats[i].data() : b.mat.ptr<float>();
+            writePfm(filename, b.mat.cols, b.mat.rows, b.mat.channels(), data);
+        }
+    }
+    std::string GetFilenameStem() const { return filenameStem; }
+    const std::vector<Buffer> &selected() const { return buffers; }
+
+  private:
+    void SetFilename(const std::string &filename) {  // buffer.cpp:75-79
+        const size_t pos = filename.find_last_of(".");
+        filenameStem = filename.substr(0, pos);
+        filenameExtension = pos == std::string::npos ? std::string() : filename.substr(pos + 1);
+    }
+    std::vector<Buffer> buffers;
+    mutable std::vector<std::vector<float>> outMats;
+    std::string filenameStem, filenameExtension;
 };
 
 // src/statistics/statpath.h:28-36 and estimator.h:68-71

@@ -109,11 +109,16 @@ def test_render_loop_statistics_only(gpu, tmp_path):
     build.build_tools()
     stem = str(tmp_path / "stats")
     out = subprocess.run([build.RENDER_SIM_BIN, "--width", "48", "--height", "32", "--spp", "2", "--iterations", "2",
-                          "--stem", stem, "--no-denoise"], capture_output=True, text=True)
+                          "--stem", stem, "--no-denoise", "--outputregex", "film|t[0-9]+-b[0-9]+-(n|mean|m2|m3)"],
+                         capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
+    assert "CUDA time [ns]: " in out.stdout
     n = pfm.read_pfm("%s-4-t0-b0-n.pfm" % stem)
     assert np.all(n == 4.0)
+    # OutputBufferSelection: only the buffers the regular expression matches are written
+    assert os.path.exists("%s-4-film.pfm" % stem) and os.path.exists("%s-4-t2-b0-mean.pfm" % stem)
     assert not os.path.exists("%s-4-t0-b0-film-mean-f.pfm" % stem)
+    assert not os.path.exists("%s-4-t0-b0-film-m2.pfm" % stem)
 
 
 def test_render_loop_acrr_float_buffers(gpu, oracle, tmp_path):

@@ -19,7 +19,7 @@
 //
 //   statmc_render_sim --width 96 --height 56 --spp 4 --iterations 3 --stem out/sim [--threads 4]
 //                     [--seed 1] [--filtersd 10] [--filterradius 20] [--stage-mb 2048] [--no-denoise]
-//                     [--config denoise|acrr] [--trackedbounces 5]
+//                     [--config denoise|acrr] [--trackedbounces 5] [--outputregex '.*']
 // --config denoise: Render<Vec3>, RGB radiance + normal + albedo, filter<float3> (scenes/render-denoise.pbrt).
 // --config acrr:    Render<Float>, "multichannelstats" false: the luminance of the path prefix up to each
 //                   of the tracked bounces is one float stat buffer, filtered together by filter<float>
@@ -97,25 +97,13 @@ static AddSampleFn<T> GetAddSampleFn(const StatTypeConfig &cfg) {
     return nullptr;
 }
 
-static void writeBuffer(const std::string &stem, unsigned spp, const Buffer &b) {
-    const std::string path = stem + "-" + std::to_string(spp) + "-" + b.name + ".pfm";
-    if (b.mat.type == I32C1) {  // n is written as float (buffer.h:51-54)
-        std::vector<float> f((size_t)b.mat.rows * b.mat.cols);
-        const int32_t *src = b.mat.ptr<int32_t>();
-        for (size_t i = 0; i < f.size(); i++) f[i] = (float)src[i];
-        writePfm(path, b.mat.cols, b.mat.rows, 1, f.data());
-    } else {
-        writePfm(path, b.mat.cols, b.mat.rows, b.mat.channels(), b.mat.ptr<float>());
-    }
-}
-
 struct Options {
     int width = 96, height = 56, spp = 4, iterations = 3, threads = 4, stageMb = 2048, trackedBounces = 5;
     unsigned seed = 1;
     float filterSD = 10.f;
     int filterRadius = 20;
     bool denoise = true, acrr = false;
-    std::string stem;
+    std::string stem, outputRegex = ".*";
 };
 
 template <typename T>
@@ -163,6 +151,8 @@ static void Render(const Options &o) {
         lTiles[t] = estimator.GetTiles<T>(tileBoundsOf(t), sCfgs[Radiance].bounceEnd);
         rgbFeatureTiles[t] = estimator.GetTiles<Vec3>(tileBoundsOf(t), 1, nRGBBuffers);
     }
+
+    const OutputBufferSelection outBufSel(reg, std::regex(o.outputRegex), (o.stem.empty() ? std::string("out") : o.stem) + ".pfm");
 
     unsigned done = 0;  // samples per pixel so far
     for (int i = 1; i <= o.iterations; i++) {
@@ -226,20 +216,16 @@ static void Render(const Options &o) {
         std::cout << "CUDA time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(end - begin).count() << std::endl;
 
         begin = std::chrono::steady_clock::now();
-        if (!o.stem.empty()) {
-            const unsigned char rad = sCfgs[Radiance].index;
+        if (!o.stem.empty()) {  // statpath.cpp:419-427: outBufSel.PrepareOutput(); outBufSel.Write(total spp)
+            // what lives only on the device comes to the host mats first: the statistics, and the
+            // filter's device-only by-products (mean-corr, discriminator)
             estimator.DownloadStatistics();
             if (estimator.runCUDA)
                 for (auto *bufs : {&estimator.meanCorrBuffers, &estimator.discriminatorBuffers})
-                    for (Buffer &b : (*bufs)[rad]) b.download(estimator.stream);
+                    for (Buffer &b : (*bufs)[sCfgs[Radiance].index]) b.download(estimator.stream);
             estimator.Synchronize();
-            for (unsigned char t = 0; t < estimator.statTypeConfigs.nEnabled; t++)
-                for (auto *bufs : {&estimator.nBuffers, &estimator.meanBuffers, &estimator.m2Buffers, &estimator.m3Buffers,
-                                   &estimator.filmBuffers, &estimator.filmM2Buffers})
-                    for (const Buffer &b : (*bufs)[t]) writeBuffer(o.stem, done, b);
-            if (estimator.runCUDA)
-                for (auto *bufs : {&estimator.meanCorrBuffers, &estimator.discriminatorBuffers, &estimator.filmFilteredBuffers})
-                    for (const Buffer &b : (*bufs)[rad]) writeBuffer(o.stem, done, b);
+            outBufSel.PrepareOutput();
+            outBufSel.Write(std::to_string(done));
         }
         end = std::chrono::steady_clock::now();
         std::cout << "Output time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(end - begin).count() << std::endl;
@@ -268,6 +254,7 @@ int main(int argc, char **argv) {
         else if (a == "--stage-mb") o.stageMb = std::atoi(next());
         else if (a == "--trackedbounces") o.trackedBounces = std::atoi(next());
         else if (a == "--stem") o.stem = next();
+        else if (a == "--outputregex") o.outputRegex = next();
         else if (a == "--no-denoise") o.denoise = false;
         else if (a == "--config") {
             const std::string c = next();
