@@ -159,3 +159,44 @@ def test_render_loop_acrr_float_buffers(gpu, oracle, tmp_path):
         ref = oracle.filter_image(mc, dc, st[j]["film_mean"], [nrm_st["mean"], alb_st["mean"]],
                                   [-0.5 / 0.1 ** 2, -0.5 / 0.02 ** 2], -0.5 / sd ** 2, radius)
         assert rel_l2(rd(pre + "film-mean-f"), ref[..., 0]) <= 1e-5, j
+
+
+def test_render_loop_smis_tallies(gpu, oracle, tmp_path):
+    """`smis`: per tracked bounce a BSDF and a light win-rate tally (float, plain M3, no radiance
+    type), merged through MergeTiles(vector<vector<StatTile<Float>>>, {cfg, cfg}) (statpath.cpp:385-386)
+    and filtered by one filter<float> call over 2 x bounces buffers."""
+    from statmc_amd import build, pfm
+    build.build_tools()
+    W, H, spp, iterations, seed, radius, sd, nb = 48, 32, 4, 2, 3, 20, 10.0, 3
+    stem = str(tmp_path / "smis")
+    out = subprocess.run([build.RENDER_SIM_BIN, "--config", "smis", "--trackedbounces", str(nb), "--width", str(W),
+                          "--height", str(H), "--spp", str(spp), "--iterations", str(iterations), "--seed", str(seed),
+                          "--stem", stem], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    y, x = np.mgrid[0:H, 0:W]
+    st = [[oracle.new_state(H, W, 1) for _ in range(nb)] for _ in range(2)]
+    nrm_st, alb_st = oracle.new_state(H, W, 3), oracle.new_state(H, W, 3)
+    done = 0
+    for i in range(1, iterations + 1):
+        target = spp if i == 1 else spp << (i - 2)
+        _, nrm, alb = make_samples(seed, W, H, done, target)
+        oracle.accumulate(nrm_st, nrm, False, 1)
+        oracle.accumulate(alb_st, alb, False, 1)
+        for ti, base in ((0, 20), (1, 40)):
+            for j in range(nb):
+                smp = np.stack([((draw(seed, x, y, done + s, base + j) >> np.uint64(3)) & np.uint64(1)).astype(np.float32)
+                                for s in range(target)])[..., None]
+                oracle.accumulate(st[ti][j], np.ascontiguousarray(smp), False, 3)
+        done += target
+    rd = lambda name: pfm.read_pfm("%s-%d-%s.pfm" % (stem, done, name))
+    for ti in range(2):
+        for j in range(nb):
+            pre, s = "t%d-b%d-" % (ti, j), st[ti][j]
+            assert np.array_equal(rd(pre + "n"), s["n"].astype(np.float32))
+            for k in ("mean", "m2", "m3"):
+                assert np.array_equal(rd(pre + k), s[k][..., 0]), (ti, j, k)
+            mc, dc = oracle.prepass(s["n"], s["mean"], s["m2"], s["m3"])
+            ref = oracle.filter_image(mc, dc, s["mean"], [nrm_st["mean"], alb_st["mean"]],
+                                      [-0.5 / 0.1 ** 2, -0.5 / 0.02 ** 2], -0.5 / sd ** 2, radius)
+            assert rel_l2(rd(pre + "film-mean-f"), ref[..., 0]) <= 1e-5, (ti, j)
+    assert np.array_equal(rd("t2-b0-mean"), nrm_st["mean"]) and np.array_equal(rd("t3-b0-mean"), alb_st["mean"])

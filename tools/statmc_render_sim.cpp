@@ -19,11 +19,13 @@
 //
 //   statmc_render_sim --width 96 --height 56 --spp 4 --iterations 3 --stem out/sim [--threads 4]
 //                     [--seed 1] [--filtersd 10] [--filterradius 20] [--stage-mb 2048] [--no-denoise]
-//                     [--config denoise|acrr] [--trackedbounces 5] [--outputregex '.*']
+//                     [--config denoise|acrr|smis] [--trackedbounces 5] [--outputregex '.*']
 // --config denoise: Render<Vec3>, RGB radiance + normal + albedo, filter<float3> (scenes/render-denoise.pbrt).
 // --config acrr:    Render<Float>, "multichannelstats" false: the luminance of the path prefix up to each
 //                   of the tracked bounces is one float stat buffer, filtered together by filter<float>
 //                   (scenes/acrr.pbrt; estimator.cpp:434-460).
+// --config smis:    no radiance statistics; per tracked bounce two float tallies (BSDF / light win rate,
+//                   plain M3) through the nested MergeTiles overload, filter<float> over 2 x bounces buffers.
 //   statmc_render_sim [--seed 1] --print-sample x y s     (prints one generated sample, no device)
 #include <atomic>
 #include <chrono>
@@ -102,7 +104,7 @@ struct Options {
     unsigned seed = 1;
     float filterSD = 10.f;
     int filterRadius = 20;
-    bool denoise = true, acrr = false;
+    bool denoise = true, acrr = false, smis = false;
     std::string stem, outputRegex = ".*";
 };
 
@@ -111,10 +113,11 @@ static void Render(const Options &o) {
     const int width = o.width, height = o.height;
     StatPathParams params;
     params.acrr = o.acrr;
+    params.smis = o.smis;
     params.multiChannelStats = !o.acrr;
     params.trackedBounces = o.trackedBounces;
-    params.denoiseImage = o.denoise && !o.acrr;
-    params.calcStats = !o.denoise && !o.acrr;
+    params.denoiseImage = o.denoise && !o.acrr && !o.smis;
+    params.calcStats = !o.denoise && !o.acrr && !o.smis;
     params.filterSD = o.filterSD;
     params.filterRadius = (unsigned char)o.filterRadius;
     const StatTypeConfigs sCfgs = makeStatTypeConfigs(params);
@@ -122,7 +125,7 @@ static void Render(const Options &o) {
     // t0-b<j>-film-mean buffers, the results t0-b<j>-film-mean-f.
     Buffer film("film", HostImage(height, width, F32C3));
     BufferRegistry reg(film);
-    Estimator estimator(film, sCfgs, o.filterSD, (unsigned char)o.filterRadius, /*denoiseFilm=*/false, o.acrr, false, reg);
+    Estimator estimator(film, sCfgs, o.filterSD, (unsigned char)o.filterRadius, /*denoiseFilm=*/false, o.acrr, o.smis, reg);
     estimator.AllocateBuffers(reg);
     estimator.EnableDeviceAccumulation((size_t)o.stageMb << 20);
 
@@ -134,7 +137,10 @@ static void Render(const Options &o) {
     if (nRGBBuffers != 2) throw std::runtime_error("expected the normal and albedo feature types");
 
     AddSampleFn<T> AddLSampleFn = GetAddSampleFn<T>(sCfgs[Radiance]);
+    AddSampleFn<float> AddMISWinRateSampleFn = GetAddSampleFn<float>(sCfgs[MISBSDFWinRate]);
     AddSampleFn<Vec3> AddRGBGBufferSampleFn = GetAddSampleFn<Vec3>(sCfgs[StatNormal]);
+    const bool misEnabled = sCfgs[MISBSDFWinRate].enable && sCfgs[MISLightWinRate].enable;
+    const std::vector<StatTypeConfig> misCfgs = {sCfgs[MISBSDFWinRate], sCfgs[MISLightWinRate]};
     const unsigned char nLs = sCfgs[Radiance].bounceEnd;
 
     const int tileSize = 16;  // statpath.cpp:132
@@ -142,6 +148,7 @@ static void Render(const Options &o) {
     const int nTilesTotal = nTilesX * nTilesY;
     std::vector<std::vector<StatTile<T>>> lTiles(nTilesTotal);
     std::vector<std::vector<std::vector<StatTile<Vec3>>>> rgbFeatureTiles(nTilesTotal);
+    std::vector<std::vector<std::vector<StatTile<float>>>> misTallyTiles(nTilesTotal);
     auto tileBoundsOf = [&](int tileIndex) {
         const int tx = tileIndex % nTilesX, ty = tileIndex / nTilesX;
         return Bounds2i(Point2i(tx * tileSize, ty * tileSize),
@@ -150,6 +157,7 @@ static void Render(const Options &o) {
     for (int t = 0; t < nTilesTotal; t++) {  // statpath.cpp:173-190
         lTiles[t] = estimator.GetTiles<T>(tileBoundsOf(t), sCfgs[Radiance].bounceEnd);
         rgbFeatureTiles[t] = estimator.GetTiles<Vec3>(tileBoundsOf(t), 1, nRGBBuffers);
+        misTallyTiles[t] = estimator.GetTiles<float>(tileBoundsOf(t), sCfgs[MISBSDFWinRate].bounceEnd, 2);
     }
 
     const OutputBufferSelection outBufSel(reg, std::regex(o.outputRegex), (o.stem.empty() ? std::string("out") : o.stem) + ".pfm");
@@ -169,6 +177,7 @@ static void Render(const Options &o) {
                     const Bounds2i tb = tileBoundsOf(t);
                     std::vector<StatTile<T>> &tileLs = lTiles[t];
                     std::vector<std::vector<StatTile<Vec3>>> &tileRGBFeatures = rgbFeatureTiles[t];
+                    std::vector<std::vector<StatTile<float>>> &tileMISTallies = misTallyTiles[t];
                     for (int y = tb.pMin.y; y < tb.pMax.y; y++)
                         for (int x = tb.pMin.x; x < tb.pMax.x; x++) {
                             const Point2i actualPixel(x, y);
@@ -181,12 +190,20 @@ static void Render(const Options &o) {
                                 }
                                 for (unsigned char j = sCfgs[Radiance].bounceStart; j < sCfgs[Radiance].bounceEnd; j++)
                                     (tileLs[j].*AddLSampleFn)(actualPixel, GetStatSample<T>(Ls[j]));
+                                // MIS tallies per bounce: which technique won the sample (statpath.cpp:361-364)
+                                for (unsigned char j = sCfgs[MISBSDFWinRate].bounceStart; j < sCfgs[MISBSDFWinRate].bounceEnd; j++) {
+                                    const float bsdf = (float)((draw(o.seed, x, y, done + s, 20u + j) >> 3) & 1u);
+                                    const float light = (float)((draw(o.seed, x, y, done + s, 40u + j) >> 3) & 1u);
+                                    (tileMISTallies[j][0].*AddMISWinRateSampleFn)(actualPixel, bsdf);
+                                    (tileMISTallies[j][1].*AddMISWinRateSampleFn)(actualPixel, light);
+                                }
                                 (tileRGBFeatures[0][0].*AddRGBGBufferSampleFn)(actualPixel, smp.normal);
                                 (tileRGBFeatures[0][1].*AddRGBGBufferSampleFn)(actualPixel, smp.albedo);
                             }
                         }
                     // Merge tiles into buffers (statpath.cpp:381-388)
-                    estimator.MergeTransformTiles(tileLs, sCfgs[Radiance]);
+                    if (sCfgs[Radiance].enable) estimator.MergeTransformTiles(tileLs, sCfgs[Radiance]);
+                    if (misEnabled) estimator.MergeTiles(tileMISTallies, misCfgs);
                     estimator.MergeTiles(tileRGBFeatures, enabledRGBFeatureCfgs);
                 }
             } catch (const std::exception &e) {
@@ -222,7 +239,8 @@ static void Render(const Options &o) {
             estimator.DownloadStatistics();
             if (estimator.runCUDA)
                 for (auto *bufs : {&estimator.meanCorrBuffers, &estimator.discriminatorBuffers})
-                    for (Buffer &b : (*bufs)[sCfgs[Radiance].index]) b.download(estimator.stream);
+                    for (auto &perType : *bufs)
+                        for (Buffer &b : perType) b.download(estimator.stream);
             estimator.Synchronize();
             outBufSel.PrepareOutput();
             outBufSel.Write(std::to_string(done));
@@ -258,11 +276,12 @@ int main(int argc, char **argv) {
         else if (a == "--no-denoise") o.denoise = false;
         else if (a == "--config") {
             const std::string c = next();
-            if (c != "denoise" && c != "acrr") {
+            if (c != "denoise" && c != "acrr" && c != "smis") {
                 std::fprintf(stderr, "unknown config %s\n", c.c_str());
                 return 2;
             }
             o.acrr = c == "acrr";
+            o.smis = c == "smis";
         } else if (a == "--print-sample") {  // x y s: the generator alone, no device (CPU test of the restatement)
             const int x = std::atoi(next()), y = std::atoi(next());
             const unsigned s = (unsigned)std::strtoul(next(), nullptr, 10);
