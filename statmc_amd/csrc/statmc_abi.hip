@@ -83,22 +83,31 @@ int spatial_table(int radius, float ds, const float **out) {
     return STATMC_OK;
 }
 
-// workspace for the window filter's per-part partial sums, grown on demand, one per device
+// workspace for the window filter's per-part partial sums, grown on demand, one per (device,
+// stream): filter calls on different streams may be in flight together and must not share it
 struct Workspace {
     float *ptr = nullptr;
     size_t bytes = 0;
 };
-std::unordered_map<int, Workspace> g_ws;
+struct WsKey {
+    int dev;
+    void *stream;
+    bool operator==(const WsKey &o) const { return dev == o.dev && stream == o.stream; }
+};
+struct WsHash {
+    size_t operator()(const WsKey &k) const { return std::hash<void *>()(k.stream) ^ ((size_t)k.dev * 0x9e3779b97f4a7c15ull); }
+};
+std::unordered_map<WsKey, Workspace, WsHash> g_ws;
 std::unordered_map<int, int> g_cus;
 
-int partial_workspace(size_t bytes, float **out) {
+int partial_workspace(size_t bytes, void *stream, float **out) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_mu);
-    Workspace &w = g_ws[dev];
+    Workspace &w = g_ws[WsKey{dev, stream}];
     if (w.bytes < bytes) {
         if (w.ptr) {
-            HIP_TRY(hipDeviceSynchronize());  // earlier launches may still read the old block
+            HIP_TRY(hipStreamSynchronize(S(stream)));  // earlier launches on this stream may still read the old block
             HIP_TRY(hipFree(w.ptr));
         }
         w.ptr = nullptr;
@@ -314,7 +323,7 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
         k.gscale1 = sqrtf(-k.g[1].dr * 1.44269504088896340736f);
         k.n_parts = statmc::lds_filter_parts(k, device_cus());
         if (k.n_parts > 1) {
-            if (int rc = partial_workspace((size_t)k.n_parts * W * H * 4 * sizeof(float), &k.partial)) return rc;
+            if (int rc = partial_workspace((size_t)k.n_parts * W * H * 4 * sizeof(float), a->stream, &k.partial)) return rc;
         }
         k.packed = static_cast<const float *>(a->packed_inputs.data);
         k.out = static_cast<float *>(a->film_filtered[0].data);
@@ -343,7 +352,7 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
     if (fast) {
         const int per_px = channels == 3 ? 4 : 8;
         if (k.n_parts > 1) {
-            if (int rc = partial_workspace((size_t)k.n_parts * W * H * per_px * sizeof(float), &k.partial)) return rc;
+            if (int rc = partial_workspace((size_t)k.n_parts * W * H * per_px * sizeof(float), a->stream, &k.partial)) return rc;
         }
     }
     const int group = (fast && channels == 1) ? 3 : 1;  // float buffers go three per launch on the fast path

@@ -560,6 +560,30 @@ def test_filter_non_finite_corrected_mean(gpu, oracle):
         assert rel_l2(outs[b].cpu().numpy(), ref) <= TOL, b
 
 
+def test_filters_on_two_streams(gpu, oracle):
+    """Two window filters in flight on two streams (different images): the per-part partial sums
+    live in a workspace per (device, stream), so neither call sees the other's."""
+    cases = [stats_case(oracle, 600, 48, 8, seed=21), stats_case(oracle, 600, 48, 8, seed=22)]
+    refs = [oracle.filter_image(mc, dc, col, gbs, G_DR, -0.5 / FILTER_SD ** 2, RADIUS) for mc, dc, col, gbs in cases]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs, keeps = [], []
+    for rep in range(3):
+        outs = []
+        for (mc, dc, col, gbs), st in zip(cases, streams):
+            with torch.cuda.stream(st):
+                out = torch.zeros(48, 600, 3, device=DEV)
+                a, keep = gpu.make_filter_args([], [], [], [], [to_dev(col)], [to_dev(mc)], [to_dev(dc)], [out],
+                                               [to_dev(g) for g in gbs], g_dr=G_DR, filter_sd=FILTER_SD, radius=RADIUS)
+                gpu.force_filter_parts(3)
+                gpu.window_filter(a, 3)
+                outs.append(out)
+                keeps.append((a, keep))
+        torch.cuda.synchronize()
+        for out, ref in zip(outs, refs):
+            assert max(rel_l2(out.cpu().numpy()[..., c], ref[..., c]) for c in range(3)) <= TOL
+    gpu.force_filter_parts(0)
+
+
 def test_filter_roi(gpu, oracle):
     """The multi-GPU block path: outputs only inside the ROI, window clipped to the local image."""
     mc, disc, colour, gbs = stats_case(oracle, 330, 60, 8, seed=6)
