@@ -134,6 +134,12 @@ int statmc_window_filter(const statmc_filter_args *args, int channels); /* mean_
  * owned block inside a block + halo image.  One pass, 60 B read + 60 B written per pixel. */
 int statmc_pack_filter_inputs(const statmc_filter_args *args, const statmc_image *packed, int dst_x0, int dst_y0);
 
+/* statmc_prepass (T = float3, buffer 0) and statmc_pack_filter_inputs in one pass over the block:
+ * reads n, mean, m2, m3, the colour image and the two G-buffers, writes the packed image; mean_corr[0] /
+ * discriminator[0] are written as well when those tables are given (the reference keeps them as
+ * device images), and skipped when they are NULL. */
+int statmc_prepass_pack(const statmc_filter_args *args, const statmc_image *packed, int dst_x0, int dst_y0);
+
 /* Replaces cv::cuda::stat_denoiser::calculateMeanVars<T> (commented-out call,
  * src/statistics/estimator.cpp:501-521) and its CPU stand-in (estimator.cpp:524-568):
  * film_var = film_m2 / ((n-1)*n).  row_n_quirk != 0 reproduces the CPU loop reading n once

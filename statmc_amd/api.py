@@ -53,7 +53,7 @@ EXPORTS = [
     "statmc_last_error", "statmc_setup", "statmc_set_device", "statmc_set_significance", "statmc_get_significance", "statmc_set_t_quantiles",
     "statmc_malloc", "statmc_free", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_download",
     "statmc_stream_create", "statmc_stream_destroy", "statmc_synchronize",
-    "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs",
+    "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs", "statmc_prepass_pack",
     "statmc_calculate_mean_vars", "statmc_accumulate", "statmc_accumulate_tiles", "statmc_merge_tiles", "statmc_tile_moments", "statmc_film_update",
     "statmc_last_filter_variant", "statmc_version",
 ]
@@ -95,6 +95,7 @@ def load():
     lib.statmc_prepass.argtypes = [C.POINTER(FilterArgs), C.c_int]
     lib.statmc_window_filter.argtypes = [C.POINTER(FilterArgs), C.c_int]
     lib.statmc_pack_filter_inputs.argtypes = [C.POINTER(FilterArgs), C.POINTER(Image), C.c_int, C.c_int]
+    lib.statmc_prepass_pack.argtypes = [C.POINTER(FilterArgs), C.POINTER(Image), C.c_int, C.c_int]
     lib.statmc_calculate_mean_vars.argtypes = [C.c_uint8, C.c_uint16, C.c_uint16, C.c_int,
                                                C.POINTER(Image), C.POINTER(Image), C.POINTER(Image),
                                                C.c_int, C.c_void_p]
@@ -179,8 +180,9 @@ def make_filter_args(n, mean, m2, m3, film, mean_corr, disc, film_filtered, g_bu
     """Build a statmc_filter_args from lists of per-buffer device tensors (reference argument
     order, estimator.cpp:437-459).  Returns (args, keepalive).  packed: optional [H, W, 15]
     block + halo tensor the window filter reads instead of the separate images."""
-    nb = len(mean_corr) if packed is None else 1
-    ref = mean_corr[0] if packed is None else packed
+    tables = [mean_corr, mean, film, film_filtered, n]
+    nb = max(len(t) for t in tables) if packed is None else 1
+    ref = next(t[0] for t in tables if t) if packed is None else packed
     h, w = ref.shape[0], ref.shape[1]
     a = FilterArgs()
     ka = []
@@ -235,6 +237,13 @@ def pack_filter_inputs(args, packed, dst_x0, dst_y0):
     """Owned block of the five filter inputs -> [Hp, Wp, 15] block + halo tensor at (dst_x0, dst_y0)."""
     img = image_of(packed)
     check(load().statmc_pack_filter_inputs(C.byref(args), C.byref(img), dst_x0, dst_y0))
+
+
+def prepass_pack(args, packed, dst_x0, dst_y0):
+    """Pre-pass of buffer 0 + pack of the five filter inputs in one pass (mean_corr / discriminator are
+    also written to their own images when the args carry them)."""
+    img = image_of(packed)
+    check(load().statmc_prepass_pack(C.byref(args), C.byref(img), dst_x0, dst_y0))
 
 
 def filter_f32x3(args):

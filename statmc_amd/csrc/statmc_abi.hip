@@ -426,6 +426,43 @@ int statmc_pack_filter_inputs(const statmc_filter_args *a, const statmc_image *p
     return STATMC_OK;
 }
 
+int statmc_prepass_pack(const statmc_filter_args *a, const statmc_image *packed, int dst_x0, int dst_y0) {
+    NEED_READY();
+    if (int rc = check_common(a, 3)) return rc;
+    if (!packed || !packed->data) return fail(STATMC_ERR_INVALID, "null packed image");
+    if (a->n_buffers < 1 || a->n_g_buffers != 2 || !a->n || !a->mean || !a->m2 || !a->m3 || !a->g_buffers)
+        return fail(STATMC_ERR_INVALID, "prepass_pack needs buffer 0 (n, mean, m2, m3) and two G-buffers");
+    const int W = a->width, H = a->height;
+    const bool film = a->denoise_film != 0;
+    if (!film && !a->film) return fail(STATMC_ERR_INVALID, "null film table");
+    const statmc_image &colour = film ? a->film_buffer : a->film[0];
+    CHECK_IMG(a->n[0], 1, "n", 0);
+    CHECK_IMG(a->mean[0], 3, "mean", 0);
+    CHECK_IMG(a->m2[0], 3, "m2", 0);
+    CHECK_IMG(a->m3[0], 3, "m3", 0);
+    CHECK_IMG(colour, 3, "colour", 0);
+    CHECK_IMG(a->g_buffers[0], 3, "g_buffers", 0);
+    CHECK_IMG(a->g_buffers[1], 3, "g_buffers", 1);
+    float *mc = nullptr, *dc = nullptr;
+    if (a->mean_corr && a->discriminator && a->mean_corr[0].data && a->discriminator[0].data) {
+        CHECK_IMG(a->mean_corr[0], 3, "mean_corr", 0);
+        CHECK_IMG(a->discriminator[0], 3, "discriminator", 0);
+        mc = static_cast<float *>(a->mean_corr[0].data);
+        dc = static_cast<float *>(a->discriminator[0].data);
+    }
+    if (dst_x0 < 0 || dst_y0 < 0 || dst_x0 + W > packed->cols || dst_y0 + H > packed->rows)
+        return fail(STATMC_ERR_INVALID, "block %dx%d at (%d,%d) does not fit the %dx%d packed image", W, H, dst_x0, dst_y0,
+                    packed->cols, packed->rows);
+    if (packed->step != (size_t)packed->cols * 15 * 4) return fail(STATMC_ERR_UNSUPPORTED, "packed image must have packed rows");
+    statmc::PrepassPackArgs k{static_cast<const int32_t *>(a->n[0].data), static_cast<const float *>(a->mean[0].data),
+                              static_cast<const float *>(a->m2[0].data), static_cast<const float *>(a->m3[0].data),
+                              static_cast<const float *>(colour.data), static_cast<const float *>(a->g_buffers[0].data),
+                              static_cast<const float *>(a->g_buffers[1].data), mc, dc, static_cast<float *>(packed->data),
+                              W, H, packed->cols, dst_x0, dst_y0, g_alpha_index};
+    HIP_TRY(statmc::launch_prepass_pack(k, S(a->stream)));
+    return STATMC_OK;
+}
+
 int statmc_filter_f32(const statmc_filter_args *a) {
     if (int rc = statmc_prepass(a, 1)) return rc;
     return statmc_window_filter(a, 1);

@@ -109,6 +109,17 @@ struct PackArgs {
 };
 hipError_t launch_pack_inputs(const PackArgs &a, hipStream_t s);
 
+// pre-pass and pack in one pass (RGB): statistics + colour + two G-buffers in, packed image out
+// (mean_corr / disc also written to their own images when the pointers are set)
+struct PrepassPackArgs {
+    const int32_t *n;
+    const float *mean, *m2, *m3, *colour, *g0, *g1;
+    float *mean_corr, *disc;   // optional
+    float *packed;             // [dst_h][dst_w][15]
+    int src_w, src_h, dst_w, dst_x0, dst_y0, alpha_index;
+};
+hipError_t launch_prepass_pack(const PrepassPackArgs &a, hipStream_t s);
+
 hipError_t launch_prepass(const PrepassArgs &a, hipStream_t s);
 hipError_t launch_mean_vars(const MeanVarsArgs &a, hipStream_t s);
 hipError_t launch_accumulate(const AccumulateArgs &a, hipStream_t s);

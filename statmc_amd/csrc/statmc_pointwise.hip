@@ -125,6 +125,42 @@ hipError_t launch_prepass(const PrepassArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ pre-pass + pack
+// The multi-GPU block path needs the five filter inputs of the owned block as one 15-channel block +
+// halo image (statmc_filter.hip: pack_inputs_kernel).  Doing the pre-pass in the same pass saves the
+// round trip of mean_corr / disc through HBM (184 -> 136 B per pixel, or 160 with the two by-products
+// still written out) and a launch.  Same prepass_elem, same bits.
+struct f3p {
+    float x, y, z;
+};
+__global__ __launch_bounds__(kBlock) void prepass_pack_kernel(PrepassPackArgs a) {
+    const long long n_px = (long long)a.src_w * a.src_h;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n_px; i += (long long)gridDim.x * kBlock) {
+        const int y = (int)(i / a.src_w), x = (int)(i - (long long)y * a.src_w);
+        const int ni = a.n[i];
+        const float t = t_quantile(a.alpha_index, ni - 1);
+        const f3p mu = reinterpret_cast<const f3p *>(a.mean)[i], s2 = reinterpret_cast<const f3p *>(a.m2)[i],
+                  s3 = reinterpret_cast<const f3p *>(a.m3)[i];
+        f3p mc, dc;
+        prepass_elem(ni, t, mu.x, s2.x, s3.x, mc.x, dc.x);
+        prepass_elem(ni, t, mu.y, s2.y, s3.y, mc.y, dc.y);
+        prepass_elem(ni, t, mu.z, s2.z, s3.z, mc.z, dc.z);
+        if (a.mean_corr) reinterpret_cast<f3p *>(a.mean_corr)[i] = mc;
+        if (a.disc) reinterpret_cast<f3p *>(a.disc)[i] = dc;
+        f3p *dst = reinterpret_cast<f3p *>(a.packed + ((long long)(y + a.dst_y0) * a.dst_w + (x + a.dst_x0)) * 15);
+        dst[0] = mc;
+        dst[1] = dc;
+        dst[2] = reinterpret_cast<const f3p *>(a.colour)[i];
+        dst[3] = reinterpret_cast<const f3p *>(a.g0)[i];
+        dst[4] = reinterpret_cast<const f3p *>(a.g1)[i];
+    }
+}
+
+hipError_t launch_prepass_pack(const PrepassPackArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(prepass_pack_kernel, dim3(grid_for((long long)a.src_w * a.src_h)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ mean vars
 __global__ __launch_bounds__(kBlock) void mean_vars_kernel(MeanVarsArgs a) {
     const long long n_elems = (long long)a.width * a.height * a.channels;

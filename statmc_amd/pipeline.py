@@ -24,15 +24,19 @@ class BlockPipeline:
         self.fs.accumulate(samples)
 
     def prepass(self):
-        self.fs.prepass()
-
-    def exchange(self):
-        """Pack the five filter inputs of the owned block into the block + halo image (one HIP
-        pass), then fetch the r-pixel border from the neighbours (two-phase RCCL send/recv)."""
+        """Single GPU: the pre-pass.  Multi-GPU: pre-pass and pack of the owned block in one HIP pass --
+        the five filter inputs go straight into the block + halo image, mean-corr / discriminator are
+        still written out as the reference's device images."""
+        if not self.multi:
+            self.fs.prepass()
+            return
         L = self.layout
         args, keep = self.fs.filter_args()
-        api.pack_filter_inputs(args, self.packed, L.pl, L.pt)
-        sharding.exchange_halo(L, self.packed, via_host=self.via_host)
+        api.prepass_pack(args, self.packed, L.pl, L.pt)
+
+    def exchange(self):
+        """Fetch the r-pixel border of the block + halo image from the neighbours (RCCL send/recv)."""
+        sharding.exchange_halo(self.layout, self.packed, via_host=self.via_host)
 
     def window_filter(self):
         """Returns the filtered owned block ([bh, bw, 3] view)."""

@@ -753,6 +753,38 @@ def test_packed_inputs_path(gpu, oracle):
     assert e.value.code == gpu.ERR_INVALID
 
 
+def test_prepass_pack_equals_prepass_then_pack(gpu, oracle):
+    """statmc_prepass_pack (the multi-GPU path's single pass) writes the same bits as statmc_prepass
+    followed by statmc_pack_filter_inputs, with and without the mean_corr / discriminator by-products."""
+    W, H, mx, my = 116, 34, 20, 7
+    _, smp, st = make_case(W, H, 6, seed=77)
+    rad = st["radiance"]
+    rad["n"][3, 5] = 1                                                 # infinite discriminator
+    rad["n"][4, 6] = 0
+    rad["m2"][5, 7] = 0.0
+    mc_ref, dc_ref = oracle.prepass(rad["n"], rad["mean"], rad["m2"], rad["m3"])
+    dev = {k: to_dev(v) for k, v in rad.items()}
+    g0, g1 = to_dev(st["normal"]["mean"]), to_dev(st["albedo"]["mean"])
+    want = np.full((H + 2 * my, W + 2 * mx, 15), -7.0, np.float32)
+    want[my:my + H, mx:mx + W] = np.concatenate([mc_ref, dc_ref, rad["film_mean"], st["normal"]["mean"], st["albedo"]["mean"]], axis=2)
+    for with_outputs in (True, False):
+        mc, dc = torch.zeros(H, W, 3, device=DEV), torch.zeros(H, W, 3, device=DEV)
+        packed = torch.full((H + 2 * my, W + 2 * mx, 15), -7.0, device=DEV)
+        a, keep = gpu.make_filter_args([dev["n"]], [dev["mean"]], [dev["m2"]], [dev["m3"]], [dev["film_mean"]],
+                                       [mc] if with_outputs else [], [dc] if with_outputs else [], [torch.zeros(H, W, 3, device=DEV)],
+                                       [g0, g1], g_sds=[SD_NORMAL, SD_ALBEDO], radius=RADIUS)
+        gpu.prepass_pack(a, packed, mx, my)
+        torch.cuda.synchronize()
+        assert np.array_equal(packed.cpu().numpy(), want, equal_nan=True)
+        if with_outputs:
+            assert np.array_equal(mc.cpu().numpy(), mc_ref) and np.array_equal(dc.cpu().numpy(), dc_ref)
+        else:
+            assert not mc.any() and not dc.any()
+    with pytest.raises(gpu.StatmcError) as e:
+        gpu.prepass_pack(a, packed, W, 0)
+    assert e.value.code == gpu.ERR_INVALID
+
+
 def test_filter_argument_errors(gpu):
     z = lambda c=3: torch.zeros(8, 8, c, device=DEV)
     a, keep = gpu.make_filter_args([], [], [], [], [z()], [z()], [z()], [z()], [z()], g_sds=[0.1], radius=2)
