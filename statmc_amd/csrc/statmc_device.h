@@ -85,6 +85,7 @@ struct FilterArgs {
     float *out;
     int width, height;           // local image
     int rx0, ry0, rx1, ry1;      // output ROI
+    int rx_split, n_main_items;  // LDS kernel: regular tiles cover [rx0, rx_split), DUAL tiles [rx_split, rx1)
     int radius;
     float ds;                    // -0.5/sd_s^2
     int n_g;

@@ -43,6 +43,8 @@
 
 #include <math.h>
 
+#include <algorithm>
+
 #include <utility>
 
 #include "statmc_device.h"
@@ -120,6 +122,18 @@ constexpr int kThreads = 64 * kTileH;  // 512
 constexpr int kSlots = kTileH + 1;     // LDS row ring
 constexpr int kCh = 15;                // floats staged per pixel
 constexpr int kMaxR = 20;
+
+// Tile geometry of the LDS kernel.  Regular: 256 x 8 pixels, wave = one row.  DUAL: 128 x 15 pixels
+// for the last tile column of images whose width leaves at most half a tile over (1920 = 7.5 x 256):
+// the lower and upper half of every wave own different rows (w and w + 8), so that column costs 72
+// workgroups at 1080p instead of 135 half-empty ones; the 16-slot ring of 168-column rows fits the
+// same 160 KB of LDS.
+template <bool DUAL>
+struct Geo {
+    static constexpr int W = DUAL ? 32 * kPx : kTileW;     // tile width in pixels
+    static constexpr int ROWS = DUAL ? 2 * kTileH - 1 : kTileH;
+    static constexpr int SLOTS = ROWS + 1;                 // LDS row ring
+};
 
 // LDS row layout (floats; P = pitch = columns staged per row, a multiple of 4): 15 planes of P
 // floats, one per channel -- scaled normal 0..2, scaled albedo 3..5, corrected mean 6..8,
@@ -399,32 +413,29 @@ __device__ __forceinline__ void store_pixel(float *slot, int pitch, int i, const
 
 // RT > 0: compile-time radius (window edges resolved statically); RT == 0: runtime radius
 // a.radius <= 20, every pair of every read group evaluated, the table masks taps beyond r.
-template <int RT, bool RGB>
-__global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+// One work item: `part` of tile `tile` of the tile grid laid over columns [cx0, cx1) of the ROI.
+template <int RT, bool RGB, bool DUAL>
+__device__ __forceinline__ void filter_tile(const FilterArgs &a, float *lds, int u, int cx0, int cx1) {
+    using G = Geo<DUAL>;
     const int r = RT > 0 ? RT : a.radius;
     const int rp = RT > 0 ? round_up4(RT) : round_up4(a.radius);
-    const int pitch = kTileW + 2 * rp;
+    const int pitch = G::W + 2 * rp;
     const int n_chunks = 2 * rp / 4 + 1;
     const int tw = tab_width(rp);
     const int tw_pad = 2 * (tw + 1);  // pairs (tab[t], tab[t+1]) for t = 0 .. tw-1, + one pad pair
     const int slot_floats = kCh * pitch;
-    float *tab_lds = lds + kSlots * slot_floats;  // two buffers: this window row's exponents / the next one's
+    float *tab_lds = lds + G::SLOTS * slot_floats;  // two buffers: this window row's exponents / the next one's
 
-    const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    // XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (each with its
-    // own 4 MiB L2), so workgroup b is given work item u such that every XCD walks one contiguous
-    // range of items: the parts of a tile and vertically adjacent tiles -- which stage the same
-    // image rows -- then hit in the same L2 instead of each fetching its own copy over the fabric.
-    // Placement only affects speed; the remap is a bijection for any grid size.
-    const int n_items = gridDim.x, b = blockIdx.x;
-    const int q8 = n_items >> 3, rem8 = n_items & 7, xcd = b & 7, idx = b >> 3;
-    const int u = xcd < rem8 ? xcd * (q8 + 1) + idx : rem8 * (q8 + 1) + (xcd - rem8) * q8 + idx;
+    // lane -> (row of the tile, 4-pixel column group): regular tiles give a wave one row; DUAL tiles give
+    // its lower half row `wave` and its upper half row `wave + 8` (row 15 of a 15-row tile does not exist:
+    // those 32 lanes compute a clamped copy and store nothing)
+    const int lane = DUAL ? (int)(threadIdx.x & 31) : (int)(threadIdx.x & 63);
+    const int trow = DUAL ? wave + kTileH * (int)((threadIdx.x >> 5) & 1) : wave;
     const int part = u % a.n_parts, tile = u / a.n_parts;
-    const int tiles_x = (a.rx1 - a.rx0 + kTileW - 1) / kTileW;
-    const int x0 = a.rx0 + (tile % tiles_x) * kTileW;
-    const int y0 = a.ry0 + (tile / tiles_x) * kTileH;
+    const int tiles_x = (cx1 - cx0 + G::W - 1) / G::W;
+    const int x0 = cx0 + (tile % tiles_x) * G::W;
+    const int y0 = a.ry0 + (tile / tiles_x) * G::ROWS;
     const float k0 = a.gscale0, k1 = a.gscale1;
     // window rows [s0, s1) of the 2r+1 belong to this workgroup (`part`): splitting the
     // window sweep over several workgroups per tile evens out the last round of the 1-WG-per-CU
@@ -435,7 +446,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
 
     // ---- the lane's own 4 pixels (clamped into the image so the loads stay in bounds)
     LaneState st;
-    const int py = min(y0 + wave, a.height - 1);
+    const int py = min(y0 + trow, a.height - 1);
 #pragma unroll
     for (int k = 0; k < kPx; k++) {
         const int px = min(x0 + kPx * lane + k, a.width - 1);
@@ -467,8 +478,8 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
         }
     }
 
-    // ---- prologue: window rows rel = s0 .. s0+kTileH-1 (image rows y0-r+rel) into slots 0..7
-    for (int idx = threadIdx.x; idx < kTileH * pitch; idx += kThreads) {
+    // ---- prologue: window rows rel = s0 .. s0+ROWS-1 (image rows y0-r+rel) into slots 0..ROWS-1
+    for (int idx = threadIdx.x; idx < G::ROWS * pitch; idx += kThreads) {
         const int rel = idx / pitch, i = idx - rel * pitch;
         const StagedPixel s = load_pixel<RGB>(a, x0 - rp + i, y0 - r + s0 + rel);
         store_pixel(lds + rel * slot_floats, pitch, i, s, k0, k1, RGB);
@@ -479,15 +490,15 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
     }
     __syncthreads();
 
-    // ---- sweep the window rows; wave w works on staged row rel = w + step
-    int slot = wave;  // (wave + step - s0) % kSlots
-    int fill = kTileH;  // (step - s0 + kTileH) % kSlots: the slot the next row is staged into
+    // ---- sweep the window rows; tile row t works on staged row rel = t + step
+    int slot = trow;     // (trow + step - s0) % SLOTS
+    int fill = G::ROWS;  // (step - s0 + ROWS) % SLOTS: the slot the next row is staged into
     for (int step = s0; step < s1; step++) {
         // issue the global loads of the row needed by the next step early
         const bool stage = step + 1 < s1 && (int)threadIdx.x < pitch;
         StagedPixel nxt;
         nxt.valid = false;
-        if (stage) nxt = load_pixel<RGB>(a, x0 - rp + (int)threadIdx.x, y0 - r + step + kTileH);
+        if (stage) nxt = load_pixel<RGB>(a, x0 - rp + (int)threadIdx.x, y0 - r + step + G::ROWS);
 
         // the spatial exponents of the next window row go to the other table buffer (last wave's lanes)
         const int ti = (int)threadIdx.x - (kThreads - 64);
@@ -504,17 +515,17 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
         if (tstage) *reinterpret_cast<v2f *>(tab_lds + ((step - s0 + 1) & 1) * tw_pad + 2 * ti) = tnext;
         if (stage) store_pixel(lds + fill * slot_floats, pitch, threadIdx.x, nxt, k0, k1, RGB);
         __syncthreads();
-        slot = slot + 1 == kSlots ? 0 : slot + 1;
-        fill = fill + 1 == kSlots ? 0 : fill + 1;
+        slot = slot + 1 == G::SLOTS ? 0 : slot + 1;
+        fill = fill + 1 == G::SLOTS ? 0 : fill + 1;
     }
 
     // ---- epilogue
-    const int oy = y0 + wave;
-    if (oy < a.ry1) {
+    const int oy = y0 + trow;
+    if (trow < G::ROWS && oy < a.ry1) {
 #pragma unroll
         for (int k = 0; k < kPx; k++) {
             const int ox = x0 + kPx * lane + k;
-            if (ox < a.rx1) {
+            if (ox < cx1) {
                 const long long p = (long long)oy * a.width + ox;
                 float acc[3], sw[3];
 #pragma unroll
@@ -551,6 +562,23 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
             }
         }
     }
+}
+
+// The kernel: regular tiles over columns [rx0, rx_split), DUAL tiles over [rx_split, rx1), one grid.
+// The DUAL items come last in item order, i.e. they are dispatched last and fill the final round.
+// XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB
+// L2), so workgroup b is given work item u such that every XCD walks one contiguous range of items:
+// the parts of a tile and vertically adjacent tiles -- which stage the same image rows -- then hit in
+// the same L2 instead of each fetching its own copy over the fabric.  Placement only affects speed;
+// the remap is a bijection for any grid size.
+template <int RT, bool RGB>
+__global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int n_items = gridDim.x, b = blockIdx.x;
+    const int q8 = n_items >> 3, rem8 = n_items & 7, xcd = b & 7, idx = b >> 3;
+    const int u = xcd < rem8 ? xcd * (q8 + 1) + idx : rem8 * (q8 + 1) + (xcd - rem8) * q8 + idx;
+    if (u < a.n_main_items) filter_tile<RT, RGB, false>(a, lds, u, a.rx0, a.rx_split);
+    else filter_tile<RT, RGB, true>(a, lds, u - a.n_main_items, a.rx_split, a.rx1);
 }
 
 // Sums the per-part partial (acc, sum_w) of every ROI pixel in part order and normalises.
@@ -643,10 +671,36 @@ int choose_parts(int tiles, int n_rows, int n_cus) {
 static int g_parts_override = 0;
 void set_filter_parts_override(int k) { g_parts_override = k; }
 
+// Where the ROI is cut: columns [rx0, split) go to regular 256-wide tiles, [split, rx1) -- at most half
+// a tile -- to the DUAL tiles (split == rx1: no DUAL column).
+static int dual_split(const FilterArgs &a) {
+    const int rem = (a.rx1 - a.rx0) % kTileW;
+    return rem > 0 && rem <= Geo<true>::W ? a.rx1 - rem : a.rx1;
+}
+static int lds_tiles(const FilterArgs &a) {
+    const int split = dual_split(a), h = a.ry1 - a.ry0;
+    int tiles = ((split - a.rx0 + kTileW - 1) / kTileW) * ((h + Geo<false>::ROWS - 1) / Geo<false>::ROWS);
+    if (split < a.rx1) tiles += (h + Geo<true>::ROWS - 1) / Geo<true>::ROWS;
+    return tiles;
+}
+
+template <bool DUAL>
+static size_t lds_bytes_for(int rp) {
+    using G = Geo<DUAL>;
+    return ((size_t)G::SLOTS * kCh * (G::W + 2 * rp) + 4 * (2 * rp + 8)) * sizeof(float);
+}
+
 template <int RT, bool RGB>
 static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
+    if (a.partial == nullptr) a.n_parts = 1;
+    if (a.rx1 <= a.rx0 || a.ry1 <= a.ry0) return hipSuccess;
     const int rp = RT > 0 ? round_up4(RT) : round_up4(a.radius);
-    const size_t lds_bytes = ((size_t)kSlots * kCh * (kTileW + 2 * rp) + 4 * (2 * rp + 8)) * sizeof(float);
+    a.rx_split = dual_split(a);
+    const int h = a.ry1 - a.ry0;
+    const int main_tiles = ((a.rx_split - a.rx0 + kTileW - 1) / kTileW) * ((h + Geo<false>::ROWS - 1) / Geo<false>::ROWS);
+    const int dual_tiles = a.rx_split < a.rx1 ? (h + Geo<true>::ROWS - 1) / Geo<true>::ROWS : 0;
+    a.n_main_items = main_tiles * a.n_parts;
+    const size_t lds_bytes = std::max(main_tiles ? lds_bytes_for<false>(rp) : 0, dual_tiles ? lds_bytes_for<true>(rp) : 0);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&window_filter_lds<RT, RGB>),
@@ -654,10 +708,7 @@ static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const dim3 tiles((a.rx1 - a.rx0 + kTileW - 1) / kTileW, (a.ry1 - a.ry0 + kTileH - 1) / kTileH);
-    if (a.partial == nullptr) a.n_parts = 1;
-    const dim3 grid(tiles.x * tiles.y * a.n_parts);
-    hipLaunchKernelGGL((window_filter_lds<RT, RGB>), grid, dim3(kThreads), lds_bytes, s, a);
+    hipLaunchKernelGGL((window_filter_lds<RT, RGB>), dim3((main_tiles + dual_tiles) * a.n_parts), dim3(kThreads), lds_bytes, s, a);
     if (a.n_parts > 1) {
         const dim3 cgrid((a.rx1 - a.rx0 + 63) / 64, (a.ry1 - a.ry0 + 3) / 4);
         hipLaunchKernelGGL(combine_parts_kernel<RGB>, cgrid, dim3(256), 0, s, a);
@@ -667,8 +718,7 @@ static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
 
 int lds_filter_parts(const FilterArgs &a, int n_cus) {
     if (g_parts_override > 0) return g_parts_override < 2 * a.radius + 1 ? g_parts_override : 2 * a.radius + 1;
-    const int tiles = ((a.rx1 - a.rx0 + kTileW - 1) / kTileW) * ((a.ry1 - a.ry0 + kTileH - 1) / kTileH);
-    return choose_parts(tiles, 2 * a.radius + 1, n_cus);
+    return choose_parts(lds_tiles(a), 2 * a.radius + 1, n_cus);
 }
 
 // True when launch_window_filter will run the LDS kernel for these arguments (the C-ABI layer
