@@ -18,9 +18,9 @@ inputs = [fs.mean_corr, fs.disc, fs.state["radiance"]["film_mean"], fs.g_buffer(
 small = torch.rand(1 << 22, device=dev) + 1.0
 def touch():
     for t in inputs: t.sum()
-def valu():
+def valu(n=12):
     x = small
-    for _ in range(12): x = torch.lgamma(x) + 2.0
+    for _ in range(n): x = torch.lgamma(x) + 2.0
 def timed(pre, n=10):
     ts = []
     for _ in range(n):
@@ -39,7 +39,9 @@ def back_to_back(n=10):
     return e0.elapsed_time(e1) / n
 print("filter back to back            %.3f ms" % back_to_back())
 for name, pre in (("after accumulate", lambda: None), ("after accumulate + input touch", touch),
-                  ("after accumulate + VALU work", valu), ("after accumulate + both", lambda: (valu(), touch()))):
+                  ("after accumulate + VALU work", valu), ("after accumulate + both", lambda: (valu(), touch())),
+                  ("after accumulate + 1 ms VALU", lambda: valu(70)), ("after accumulate + 3 ms VALU", lambda: valu(210)),
+                  ("after accumulate + 3 ms filter x1", lambda: fs.window_filter())):
     print("%-32s avg %.3f  min %.3f ms" % ((name,) + timed(pre)))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); valu(); e1.record(); torch.cuda.synchronize(); print("VALU filler takes %.3f ms" % e0.elapsed_time(e1))
