@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <array>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -699,8 +700,13 @@ class Estimator {
         if (!allocateDevice) throw Error(STATMC_ERR_INVALID, "device accumulation needs device images");
         std::lock_guard<std::mutex> lk(acc.mu);
         acc.enabled = true;
-        acc.maxHostBytes = maxHostBytes;
         acc.arenas.clear();
+        // every (type, bounce) arena holds the same number of pixel-samples: the page-locked
+        // staging is split in proportion to the channel counts
+        size_t floatsPerPixelSample = 0;
+        for (unsigned char i = 0; i < statTypeConfigs.nEnabled; i++)
+            floatsPerPixelSample += (size_t)statTypeConfigs.configs[i].nChannels * statTypeConfigs.configs[i].nBounces;
+        acc.capacity = (int64_t)(maxHostBytes / (sizeof(float) * std::max<size_t>(floatsPerPixelSample, 1))) / 4 * 4;
         for (unsigned char i = 0; i < statTypeConfigs.nEnabled; i++) {
             acc.arenas.emplace_back(statTypeConfigs.configs[i].nBounces);
             for (unsigned char j = 0; j < statTypeConfigs.configs[i].nBounces; j++) {
@@ -754,8 +760,8 @@ class Estimator {
     // Uploads what the merges have staged and runs the accumulation (asynchronous on `stream`).
     // Upload() calls it; call it yourself to bound the staging memory of a long iteration.
     void FlushSamples() const {
-        std::lock_guard<std::mutex> lk(acc.mu);
-        flushLocked();
+        std::unique_lock<std::mutex> lk(acc.mu);
+        flushLocked(lk);
     }
     // Statistics images device -> host mats (dumps, OutputBufferSelection::Write); asynchronous.
     void DownloadStatistics() {
@@ -801,17 +807,14 @@ class Estimator {
     // Between two flushes every merged tile owns one slot: a block of S x pixels "pixel-samples"
     // at the same offset in the arena of every (type, bounce) -- all types of a tile see the same
     // samples per pixel (statpath.cpp:355-371), so one tile table serves them all.
-    struct PinnedFloats {  // page-locked, grows by reallocation
+    struct PinnedFloats {  // page-locked, allocated once (its address must not move: merges copy into it unlocked)
         ~PinnedFloats() { if (ptr) statmc_free_host(ptr); }
-        void reserve(size_t n, size_t keep) {
-            if (n <= cap) return;
-            size_t want = std::max(n, cap + cap / 2);
+        void allocate(size_t n) {
+            if (ptr) return;
             void *p = nullptr;
-            check(statmc_malloc_host(&p, want * sizeof(float)));
-            if (keep) std::memcpy(p, ptr, keep * sizeof(float));
-            if (ptr) statmc_free_host(ptr);
+            check(statmc_malloc_host(&p, n * sizeof(float)));
             ptr = static_cast<float *>(p);
-            cap = want;
+            cap = n;
         }
         float *ptr = nullptr;
         size_t cap = 0;
@@ -832,7 +835,6 @@ class Estimator {
     struct Arena {
         PinnedFloats host;
         DeviceBytes dev;
-        size_t used = 0;                 // floats written since the last flush
         std::vector<uint32_t> slots;     // slots this (type, bounce) has merged since the last flush
     };
     struct Slot {
@@ -841,8 +843,10 @@ class Estimator {
     };
     struct Accumulation {
         std::mutex mu;
+        std::condition_variable idle;    // signalled when the last unlocked copy has finished
+        int writers = 0;                 // merges copying into the arenas right now (outside the lock)
         bool enabled = false, uploadInFlight = false;
-        size_t maxHostBytes = 0, hostBytes = 0;
+        int64_t capacity = 0;            // pixel-samples per arena
         std::vector<std::vector<Arena>> arenas;  // [statTypeIndex][bounceIndex]
         std::vector<Slot> slots;
         std::map<std::array<int32_t, 4>, uint32_t> slotOf;
@@ -863,12 +867,6 @@ class Estimator {
     template <typename T>
     void mergeRecorded(const StatTile<T> &tile, const unsigned char ti, const unsigned char bj) const {
         constexpr int C = stat_denoiser::detail::channels<T>::value;
-        std::lock_guard<std::mutex> lk(acc.mu);
-        if (!acc.enabled)
-            throw Error(STATMC_ERR_INVALID, "Merge*Tile: call EnableDeviceAccumulation() first (tiles record samples; "
-                                            "the moments are computed on the device)");
-        if (ti >= acc.arenas.size() || bj >= acc.arenas[ti].size()) throw Error(STATMC_ERR_INVALID, "Merge*Tile: no such buffer");
-        if (statTypeConfigs.configs[ti].nChannels != C) throw Error(STATMC_ERR_INVALID, "Merge*Tile: channel count mismatch");
         // every pixel that received samples received the same number, and those pixels form a
         // rectangle (the whole tile, or its part inside the integrator's pixelbounds, statpath.cpp:261)
         uint32_t S = 0;
@@ -892,39 +890,53 @@ class Estimator {
                                             tile.pixelBounds.pMin.x + rx1, tile.pixelBounds.pMin.y + ry1};
         if (key[0] < 0 || key[1] < 0 || key[2] > width || key[3] > height)
             throw Error(STATMC_ERR_INVALID, "Merge*Tile: tile outside the image");
-        beginEpochLocked();
         const size_t npx = (size_t)(rx1 - rx0) * (ry1 - ry0);
-        uint32_t slot;
-        auto it = acc.slotOf.find(key);
-        if (it == acc.slotOf.end()) {
-            slot = (uint32_t)acc.slots.size();
-            acc.slots.push_back(Slot{key[0], key[1], key[2], key[3], (int32_t)S, acc.nextOffset});
-            acc.slotOf.emplace(key, slot);
-            acc.nextOffset += (int64_t)((S * npx + 3) / 4 * 4);
-        } else {
-            slot = it->second;
-            if (acc.slots[slot].samples != (int32_t)S)
-                throw Error(STATMC_ERR_UNSUPPORTED, "Merge*Tile: the stat types of one tile hold different sample counts");
+        const int64_t need = (int64_t)((S * npx + 3) / 4 * 4);
+        float *dst = nullptr;
+        {   // ---- under the lock: find or make the tile's slot, claim it for this buffer
+            std::unique_lock<std::mutex> lk(acc.mu);
+            if (!acc.enabled)
+                throw Error(STATMC_ERR_INVALID, "Merge*Tile: call EnableDeviceAccumulation() first (tiles record samples; "
+                                                "the moments are computed on the device)");
+            if (ti >= acc.arenas.size() || bj >= acc.arenas[ti].size()) throw Error(STATMC_ERR_INVALID, "Merge*Tile: no such buffer");
+            if (statTypeConfigs.configs[ti].nChannels != C) throw Error(STATMC_ERR_INVALID, "Merge*Tile: channel count mismatch");
+            if (need > acc.capacity) throw Error(STATMC_ERR_INVALID, "Merge*Tile: one tile's samples exceed the staging size");
+            auto it = acc.slotOf.find(key);
+            if (it == acc.slotOf.end() && acc.nextOffset + need > acc.capacity) {
+                flushLocked(lk);  // staging full: hand over what is there (waits for the copies in progress)
+                it = acc.slotOf.end();
+            }
+            beginEpochLocked();
+            uint32_t slot;
+            if (it == acc.slotOf.end()) {
+                slot = (uint32_t)acc.slots.size();
+                acc.slots.push_back(Slot{key[0], key[1], key[2], key[3], (int32_t)S, acc.nextOffset});
+                acc.slotOf.emplace(key, slot);
+                acc.nextOffset += need;
+            } else {
+                slot = it->second;
+                if (acc.slots[slot].samples != (int32_t)S)
+                    throw Error(STATMC_ERR_UNSUPPORTED, "Merge*Tile: the stat types of one tile hold different sample counts");
+            }
+            Arena &A = acc.arenas[ti][bj];
+            if (std::find(A.slots.begin(), A.slots.end(), slot) != A.slots.end())
+                throw Error(STATMC_ERR_INVALID, "Merge*Tile: tile merged twice");
+            A.host.allocate((size_t)acc.capacity * C);
+            A.slots.push_back(slot);
+            dst = A.host.ptr + (size_t)acc.slots[slot].offset * C;
+            acc.writers++;
         }
-        Arena &A = acc.arenas[ti][bj];
-        if (std::find(A.slots.begin(), A.slots.end(), slot) != A.slots.end())
-            throw Error(STATMC_ERR_INVALID, "Merge*Tile: tile merged twice");
-        const size_t off = (size_t)acc.slots[slot].offset * C, need = off + (S * npx + 3) / 4 * 4 * C;
-        const size_t before = A.host.cap;
-        A.host.reserve(need, A.used);
-        acc.hostBytes += (A.host.cap - before) * sizeof(float);
-        A.used = std::max(A.used, need);
+        // ---- outside the lock: the copy (the arena does not move; a flush waits for writers == 0)
         const int rw = rx1 - rx0;
         for (uint32_t s = 0; s < S; s++)
             for (int y = ry0; y < ry1; y++)
-                std::memcpy(A.host.ptr + off + ((size_t)s * npx + (size_t)(y - ry0) * rw) * C,
-                            &tile.planes[s][(size_t)y * tw + rx0], (size_t)rw * C * sizeof(float));
-        A.slots.push_back(slot);
+                std::memcpy(dst + ((size_t)s * npx + (size_t)(y - ry0) * rw) * C, &tile.planes[s][(size_t)y * tw + rx0],
+                            (size_t)rw * C * sizeof(float));
         std::fill(tile.counts.begin(), tile.counts.end(), 0u);
-        size_t staged = 0;
-        for (const auto &per_type : acc.arenas)
-            for (const Arena &a : per_type) staged += a.used * sizeof(float);
-        if (staged > acc.maxHostBytes) flushLocked();
+        {
+            std::lock_guard<std::mutex> lk(acc.mu);
+            if (--acc.writers == 0) acc.idle.notify_all();
+        }
     }
 
     statmc_stat_type statTypeFor(unsigned char i, unsigned char j, const float *samples) const {
@@ -946,9 +958,11 @@ class Estimator {
         return t;
     }
 
-    void flushLocked() const {
+    void flushLocked(std::unique_lock<std::mutex> &lk) const {
+        acc.idle.wait(lk, [&] { return acc.writers == 0; });  // merges still copying into the arenas
         if (acc.slots.empty()) return;
         check(statmc_set_device(device));  // a render worker thread may be the one that flushes
+        const size_t used = (size_t)acc.nextOffset;  // pixel-samples staged in every arena
         const size_t n = acc.slots.size();
         // tile tables: bounds (int32 x 4), offsets (int64), samples (int32), one device block
         std::vector<int64_t> offsets(n);
@@ -972,8 +986,9 @@ class Estimator {
             for (unsigned char j = 0; j < acc.arenas[i].size(); j++) {
                 Arena &A = acc.arenas[i][j];
                 if (A.slots.empty()) continue;
-                A.dev.reserve(A.used * sizeof(float));
-                check(statmc_upload(A.dev.ptr, A.host.ptr, A.used * sizeof(float), stream.handle()));
+                const size_t bytes = used * statTypeConfigs.configs[i].nChannels * sizeof(float);
+                A.dev.reserve(bytes);
+                check(statmc_upload(A.dev.ptr, A.host.ptr, bytes, stream.handle()));
                 const statmc_stat_type t = statTypeFor(i, j, static_cast<const float *>(A.dev.ptr));
                 if (A.slots.size() == n) {
                     full.push_back(t);
@@ -1009,10 +1024,7 @@ class Estimator {
         acc.slotOf.clear();
         acc.nextOffset = 0;
         for (auto &per_type : acc.arenas)
-            for (Arena &a : per_type) {
-                a.used = 0;
-                a.slots.clear();
-            }
+            for (Arena &a : per_type) a.slots.clear();
     }
 };
 
