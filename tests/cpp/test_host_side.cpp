@@ -1,0 +1,91 @@
+// CPU-only checks of the C++ host side (include/statmc_denoiser.hpp), built with
+// -fsanitize=address,undefined by tests/test_host_cpu.py: the StatTile recorder, Estimator::GetTiles,
+// the error paths that need no device, OutputBufferSelection + the PFM codec.  Links against
+// libstatmc_hip.so only for the symbols; nothing here touches a GPU.
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+
+#include "statmc_denoiser.hpp"
+
+using namespace statmc;
+
+#define REQUIRE(cond)                                                              \
+    do {                                                                           \
+        if (!(cond)) {                                                             \
+            std::fprintf(stderr, "%s:%d: REQUIRE(%s) failed\n", __FILE__, __LINE__, #cond); \
+            std::exit(1);                                                          \
+        }                                                                          \
+    } while (0)
+
+template <class F>
+static bool throwsError(F f, int code) {
+    try {
+        f();
+    } catch (const Error &e) {
+        return e.code == code;
+    }
+    return false;
+}
+
+int main(int argc, char **argv) {
+    const std::string tmp = argc > 1 ? argv[1] : "/tmp";
+
+    // ---- StatTile: same index rule as Tile<T>::GetPixel (estimator.h:44-48), one plane per sample
+    {
+        StatTile<Vec3> tile(Bounds2i(Point2i(16, 32), Point2i(29, 40)));  // 13 x 8, clipped edge tile
+        REQUIRE(tile.GetPixelBounds().Area() == 13 * 8);
+        for (int s = 0; s < 3; s++)
+            for (int y = 32; y < 40; y++)
+                for (int x = 16; x < 29; x++) tile.AddTransformSampleM3(Point2i(x, y), Vec3{(float)x, (float)y, (float)s});
+        REQUIRE(tile.pending(Point2i(16, 32)) == 3 && tile.pending(Point2i(28, 39)) == 3);
+        void (StatTile<Vec3>::*fn)(const Point2i, const Vec3) = &StatTile<Vec3>::AddSampleM1;  // binds like statpath.cpp:166
+        (tile.*fn)(Point2i(20, 35), Vec3{1, 2, 3});
+        REQUIRE(tile.pending(Point2i(20, 35)) == 4);
+        StatTile<float> empty(Bounds2i(Point2i(5, 5), Point2i(5, 9)));  // degenerate bounds: no pixels
+        REQUIRE(empty.GetPixelBounds().Area() == 0);
+    }
+
+    // ---- Estimator without a device: catalogue, GetTiles, merge refused, config errors
+    {
+        StatPathParams p;
+        p.denoiseImage = true;
+        const StatTypeConfigs cfgs = makeStatTypeConfigs(p);
+        Buffer film("film", HostImage(24, 40, F32C3), /*allocateDevice=*/false);
+        BufferRegistry reg(film);
+        Estimator est(film, cfgs, 10.f, 20, false, false, false, reg, /*allocateDevice=*/false);
+        est.AllocateBuffers(reg);
+        REQUIRE(reg.find("t0-b0-m3") && reg.find("t2-b0-film-mean") && !reg.find("t3-b0-n"));
+        auto tiles = est.GetTiles<Vec3>(Bounds2i(Point2i(0, 0), Point2i(16, 16)), cfgs[Radiance].bounceEnd);
+        REQUIRE(tiles.size() == 1);
+        auto nested = est.GetTiles<Vec3>(Bounds2i(Point2i(0, 0), Point2i(16, 16)), 1, 2);
+        REQUIRE(nested.size() == 1 && nested[0].size() == 2);
+        tiles[0].AddTransformSampleM3(Point2i(3, 4), Vec3{1, 1, 1});
+        REQUIRE(throwsError([&] { est.MergeTransformTiles(tiles, cfgs[Radiance]); }, STATMC_ERR_INVALID));   // not enabled
+        REQUIRE(throwsError([&] { est.EnableDeviceAccumulation(); }, STATMC_ERR_INVALID));                    // no device images
+        StatPathParams bad;
+        bad.denoiseImage = true;
+        bad.filterBufferSDs = {0.1f};
+        REQUIRE(throwsError([&] { makeStatTypeConfigs(bad); }, STATMC_ERR_INVALID));
+
+        // ---- OutputBufferSelection: regex over the registry, PrepareOutput converts n, Write -> PFM
+        HostImage &nMat = est.nBuffers[0][0].mat;
+        for (int i = 0; i < 24 * 40; i++) nMat.ptr<int32_t>()[i] = i % 7;
+        float *mean = est.meanBuffers[0][0].mat.ptr<float>();
+        for (int i = 0; i < 24 * 40 * 3; i++) mean[i] = 0.25f * (float)i;
+        const OutputBufferSelection sel(reg, std::regex("t0-b0-(n|mean)"), tmp + "/host.pfm");
+        REQUIRE(sel.selected().size() == 2 && sel.GetFilenameStem() == tmp + "/host");
+        sel.PrepareOutput();
+        sel.Write("8");
+        const PfmImage n = readPfm(tmp + "/host-8-t0-b0-n.pfm"), m = readPfm(tmp + "/host-8-t0-b0-mean.pfm");
+        REQUIRE(n.channels == 1 && n.width == 40 && n.height == 24 && m.channels == 3);
+        for (int i = 0; i < 24 * 40; i++) REQUIRE(n.data[i] == (float)(i % 7));
+        for (int i = 0; i < 24 * 40 * 3; i++) REQUIRE(m.data[i] == 0.25f * (float)i);
+        const OutputBufferSelection all(reg, tmp + "/all.pfm");
+        REQUIRE(all.selected().size() == reg.buffers.size());
+        const OutputBufferSelection png(reg, std::regex("film"), tmp + "/x.png");
+        REQUIRE(throwsError([&] { png.Write(); }, STATMC_ERR_UNSUPPORTED));
+    }
+    std::puts("host side ok");
+    return 0;
+}
