@@ -31,6 +31,7 @@
 #include <array>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -642,6 +643,7 @@ class Estimator {
 
     void Upload() {  // estimator.cpp:409-416
         if (acc.enabled) FlushSamples();  // statistics are produced on the device: only the rest moves
+        if (acc.dry) return;
         for (Buffer *b : uploadBuffers)
             if (!acc.enabled || !acc.deviceProduced.count(b)) b->upload(stream);
     }
@@ -696,10 +698,13 @@ class Estimator {
     // film-mean / film-m2 images of every enabled (type, bounce) live on the device, start at zero and
     // are updated by statmc_accumulate_tiles; Upload() then moves only what the host still produces
     // (the "film" image).  maxHostBytes bounds the page-locked staging the merges fill between flushes.
-    void EnableDeviceAccumulation(size_t maxHostBytes = (size_t)2 << 30) {
-        if (!allocateDevice) throw Error(STATMC_ERR_INVALID, "device accumulation needs device images");
+    // dryRun (tests of the staging logic on machines without a GPU): plain host memory, and a flush
+    // only counts what it would have handed to the device (stagedMerges()).
+    void EnableDeviceAccumulation(size_t maxHostBytes = (size_t)2 << 30, bool dryRun = false) {
+        if (!allocateDevice && !dryRun) throw Error(STATMC_ERR_INVALID, "device accumulation needs device images");
         std::lock_guard<std::mutex> lk(acc.mu);
         acc.enabled = true;
+        acc.dry = dryRun;
         acc.arenas.clear();
         // every (type, bounce) arena holds the same number of pixel-samples: the page-locked
         // staging is split in proportion to the channel counts
@@ -712,7 +717,7 @@ class Estimator {
             for (unsigned char j = 0; j < statTypeConfigs.configs[i].nBounces; j++) {
                 for (auto *bufs : {&nBuffers, &meanBuffers, &m2Buffers, &m3Buffers, &filmBuffers, &filmM2Buffers}) {
                     Buffer &b = (*bufs)[i][j];
-                    check(statmc_memset(b.gpuMat.data(), 0, b.gpuMat.bytes(), stream.handle()));
+                    if (!dryRun) check(statmc_memset(b.gpuMat.data(), 0, b.gpuMat.bytes(), stream.handle()));
                     acc.deviceProduced.insert(&b);
                 }
             }
@@ -763,6 +768,9 @@ class Estimator {
         std::unique_lock<std::mutex> lk(acc.mu);
         flushLocked(lk);
     }
+    // (tile, buffer) merges handed over by flushes so far, and the number of flushes
+    size_t stagedMerges() const { std::lock_guard<std::mutex> lk(acc.mu); return acc.flushedMerges; }
+    size_t flushes() const { std::lock_guard<std::mutex> lk(acc.mu); return acc.nFlushes; }
     // Statistics images device -> host mats (dumps, OutputBufferSelection::Write); asynchronous.
     void DownloadStatistics() {
         for (unsigned char i = 0; i < statTypeConfigs.nEnabled; i++)
@@ -808,16 +816,22 @@ class Estimator {
     // at the same offset in the arena of every (type, bounce) -- all types of a tile see the same
     // samples per pixel (statpath.cpp:355-371), so one tile table serves them all.
     struct PinnedFloats {  // page-locked, allocated once (its address must not move: merges copy into it unlocked)
-        ~PinnedFloats() { if (ptr) statmc_free_host(ptr); }
-        void allocate(size_t n) {
+        ~PinnedFloats() {
+            if (ptr && pinned) statmc_free_host(ptr);
+            if (ptr && !pinned) std::free(ptr);
+        }
+        void allocate(size_t n, bool pin) {
             if (ptr) return;
             void *p = nullptr;
-            check(statmc_malloc_host(&p, n * sizeof(float)));
+            if (pin) check(statmc_malloc_host(&p, n * sizeof(float)));
+            else if (!(p = std::malloc(n * sizeof(float)))) throw std::bad_alloc();
             ptr = static_cast<float *>(p);
             cap = n;
+            pinned = pin;
         }
         float *ptr = nullptr;
         size_t cap = 0;
+        bool pinned = true;
     };
     struct DeviceBytes {
         ~DeviceBytes() { if (ptr) statmc_free(ptr); }
@@ -845,7 +859,8 @@ class Estimator {
         std::mutex mu;
         std::condition_variable idle;    // signalled when the last unlocked copy has finished
         int writers = 0;                 // merges copying into the arenas right now (outside the lock)
-        bool enabled = false, uploadInFlight = false;
+        bool enabled = false, uploadInFlight = false, dry = false;
+        size_t flushedMerges = 0, nFlushes = 0;
         int64_t capacity = 0;            // pixel-samples per arena
         std::vector<std::vector<Arena>> arenas;  // [statTypeIndex][bounceIndex]
         std::vector<Slot> slots;
@@ -859,6 +874,10 @@ class Estimator {
     // host staging may be rewritten only after the copies of the previous flush have finished
     void beginEpochLocked() const {
         if (!acc.uploadInFlight) return;
+        if (acc.dry) {
+            acc.uploadInFlight = false;
+            return;
+        }
         check(statmc_set_device(device));
         check(statmc_synchronize(stream.handle()));
         acc.uploadInFlight = false;
@@ -921,7 +940,7 @@ class Estimator {
             Arena &A = acc.arenas[ti][bj];
             if (std::find(A.slots.begin(), A.slots.end(), slot) != A.slots.end())
                 throw Error(STATMC_ERR_INVALID, "Merge*Tile: tile merged twice");
-            A.host.allocate((size_t)acc.capacity * C);
+            A.host.allocate((size_t)acc.capacity * C, !acc.dry);
             A.slots.push_back(slot);
             dst = A.host.ptr + (size_t)acc.slots[slot].offset * C;
             acc.writers++;
@@ -961,6 +980,13 @@ class Estimator {
     void flushLocked(std::unique_lock<std::mutex> &lk) const {
         acc.idle.wait(lk, [&] { return acc.writers == 0; });  // merges still copying into the arenas
         if (acc.slots.empty()) return;
+        acc.nFlushes++;
+        for (const auto &per_type : acc.arenas)
+            for (const Arena &a : per_type) acc.flushedMerges += a.slots.size();
+        if (acc.dry) {
+            resetEpochLocked();
+            return;
+        }
         check(statmc_set_device(device));  // a render worker thread may be the one that flushes
         const size_t used = (size_t)acc.nextOffset;  // pixel-samples staged in every arena
         const size_t n = acc.slots.size();
@@ -1019,6 +1045,10 @@ class Estimator {
                                           reinterpret_cast<const int64_t *>(tab), reinterpret_cast<const int32_t *>(tab + n * 24),
                                           (int)n, stream.handle()));
         }
+        resetEpochLocked();
+    }
+
+    void resetEpochLocked() const {
         acc.uploadInFlight = true;
         acc.slots.clear();
         acc.slotOf.clear();

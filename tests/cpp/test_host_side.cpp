@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <thread>
+#include <atomic>
 
 #include "statmc_denoiser.hpp"
 
@@ -85,6 +87,54 @@ int main(int argc, char **argv) {
         REQUIRE(all.selected().size() == reg.buffers.size());
         const OutputBufferSelection png(reg, std::regex("film"), tmp + "/x.png");
         REQUIRE(throwsError([&] { png.Write(); }, STATMC_ERR_UNSUPPORTED));
+    }
+    // ---- the staging logic under threads (dry run: no device): 8 workers merge 3 buffers of every tile
+    // of a 200 x 120 film for 3 iterations through a staging so small that it flushes many times
+    {
+        StatPathParams p;
+        p.denoiseImage = true;
+        const StatTypeConfigs cfgs = makeStatTypeConfigs(p);
+        const int W = 200, H = 120, ts = 16, tx = (W + ts - 1) / ts, ty = (H + ts - 1) / ts, nTiles = tx * ty;
+        Buffer film("film", HostImage(H, W, F32C3), false);
+        BufferRegistry reg(film);
+        Estimator est(film, cfgs, 10.f, 20, false, false, false, reg, false);
+        est.AllocateBuffers(reg);
+        est.EnableDeviceAccumulation((size_t)1 << 20, /*dryRun=*/true);
+        std::vector<StatTypeConfig> feat = {cfgs[StatNormal], cfgs[StatAlbedo]};
+        std::vector<std::vector<StatTile<Vec3>>> lTiles(nTiles);
+        std::vector<std::vector<std::vector<StatTile<Vec3>>>> fTiles(nTiles);
+        auto bounds = [&](int t) {
+            const int x = t % tx, y = t / tx;
+            return Bounds2i(Point2i(x * ts, y * ts), Point2i(std::min((x + 1) * ts, W), std::min((y + 1) * ts, H)));
+        };
+        for (int t = 0; t < nTiles; t++) {
+            lTiles[t] = est.GetTiles<Vec3>(bounds(t), 1);
+            fTiles[t] = est.GetTiles<Vec3>(bounds(t), 1, 2);
+        }
+        for (int it = 0; it < 3; it++) {
+            std::atomic<int> next{0};
+            std::vector<std::thread> pool;
+            for (int w = 0; w < 8; w++)
+                pool.emplace_back([&] {
+                    for (int t = next.fetch_add(1); t < nTiles; t = next.fetch_add(1)) {
+                        const Bounds2i b = bounds(t);
+                        for (int y = b.pMin.y; y < b.pMax.y; y++)
+                            for (int x = b.pMin.x; x < b.pMax.x; x++)
+                                for (int s = 0; s < 5; s++) {
+                                    lTiles[t][0].AddTransformSampleM3(Point2i(x, y), Vec3{1.f, 2.f, (float)s});
+                                    fTiles[t][0][0].AddSampleM1(Point2i(x, y), Vec3{0.f, 0.f, 1.f});
+                                    fTiles[t][0][1].AddSampleM1(Point2i(x, y), Vec3{.5f, .5f, .5f});
+                                }
+                        est.MergeTransformTiles(lTiles[t], cfgs[Radiance]);
+                        est.MergeTiles(fTiles[t], feat);
+                    }
+                });
+            for (auto &th : pool) th.join();
+            est.Upload();  // flushes the rest
+            REQUIRE(est.stagedMerges() == (size_t)(it + 1) * nTiles * 3);
+        }
+        REQUIRE(est.flushes() > 10);  // the 1 MiB staging filled up many times
+        REQUIRE(lTiles[0][0].pending(Point2i(0, 0)) == 0);
     }
     std::puts("host side ok");
     return 0;

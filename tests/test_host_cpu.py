@@ -136,20 +136,23 @@ def test_render_sim_sample_source_restatement(denoise_bin):
         assert np.array_equal(ref, got), (x, y, s)
 
 
-def test_cpp_host_side_under_sanitizers(tmp_path):
-    """StatTile recorder, Estimator::GetTiles, device-free error paths, OutputBufferSelection + PFM: a C++
-    test program built with AddressSanitizer + UBSan (CPU build; nothing in it touches a GPU)."""
+@pytest.mark.parametrize("sanitizer", ["address,undefined", "thread"])
+def test_cpp_host_side_under_sanitizers(tmp_path, sanitizer):
+    """StatTile recorder, Estimator::GetTiles, device-free error paths, OutputBufferSelection + PFM, and the
+    merge / flush staging logic under 8 threads (dry run): a C++ test program built with AddressSanitizer +
+    UBSan, and again with ThreadSanitizer (CPU builds; nothing in it touches a GPU)."""
     import os
     from statmc_amd import build
     build.build()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "test_host_side")
     rocm_lib = os.path.join(os.path.dirname(os.path.dirname(build._hipcc())), "lib")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-                           "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "test_host_side.cpp"), "-o", exe,
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-pthread", "-fsanitize=" + sanitizer,
+                           "-fno-sanitize-recover=all", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "test_host_side.cpp"), "-o", exe,
                            "-L", os.path.dirname(build.SO), "-lstatmc_hip", "-L", rocm_lib,
                            "-Wl,-rpath," + os.path.dirname(build.SO), "-Wl,-rpath," + rocm_lib])
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0", TSAN_OPTIONS="halt_on_error=1")
     out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "host side ok" in out.stdout
