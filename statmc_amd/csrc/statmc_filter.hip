@@ -247,13 +247,15 @@ __device__ __forceinline__ void range_exponent(const LaneState &st, const v2f *g
 
 // membership gate, weight and accumulation of a tap pair (mc / nd / col: corrected mean,
 // -discriminator, colour of the two taps, 3 channels each)
-template <int H, unsigned MASK, bool RGB>
+template <int H, unsigned MASK, int K>
 __device__ __forceinline__ void gate_accumulate(LaneState &st, const v2f (&e)[kPx], const v2f *mc, const v2f *nd, const v2f *col) {
     using M = TapMask<H, MASK>;
+    constexpr bool RGB = K == 0;
+    constexpr int NB = RGB ? 3 : K;  // float mode: only the K real buffers of the launch are gated and summed
     v2f u[kPx][3], w[kPx];
     // membership statistic per channel: t_c = fma(d_c, d_c, -D_q,c)  (the oracle's expression)
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) {
+    for (int ch = 0; ch < NB; ch++) {
 #pragma unroll
         for (int k = 0; k < kPx; k++) if (M::on(k)) { const v2f d = st.pmc[k][ch] - mc[ch]; u[k][ch] = __builtin_elementwise_fma(d, d, nd[ch]); }
     }
@@ -285,7 +287,7 @@ __device__ __forceinline__ void gate_accumulate(LaneState &st, const v2f (&e)[kP
         }
     } else {
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
+        for (int ch = 0; ch < NB; ch++) {
 #pragma unroll
             for (int k = 0; k < kPx; k++) if (M::on(k)) {
                 const v2f wc = v2f{M::in0(k) && u[k][ch].x <= st.pd[k][ch] ? w[k].x : 0.f,
@@ -297,17 +299,17 @@ __device__ __forceinline__ void gate_accumulate(LaneState &st, const v2f (&e)[kP
     }
 }
 
-template <int H, unsigned MASK, bool RGB>
+template <int H, unsigned MASK, int K>
 __device__ __forceinline__ void compute_half(LaneState &st, const HalfChunk &c) {
     v2f e[kPx];
     range_exponent<H, MASK>(st, c.q + C_G0, c.tp, e);
-    gate_accumulate<H, MASK, RGB>(st, e, c.q + C_MC, c.q + C_ND, c.q + C_COL);
+    gate_accumulate<H, MASK, K>(st, e, c.q + C_MC, c.q + C_ND, c.q + C_COL);
 }
 
 // Sweep one window row: 2*rp/4 + 1 read groups.  RT > 0 (compile-time radius, a multiple of 4):
 // the first and last groups hold (tap, pixel) pairs outside the window and get their static
 // masks; every group between is full and runs as a rolled loop.
-template <int RT, bool RGB>
+template <int RT, int K>
 __device__ __forceinline__ void eval_row(LaneState &st, const float *row, int pitch, const float *tab, int n_chunks) {
     HalfChunk c;
     constexpr unsigned kFull = 0xFFFFu;
@@ -316,27 +318,27 @@ __device__ __forceinline__ void eval_row(LaneState &st, const float *row, int pi
         static_assert(RT % 4 == 0 && n >= 3, "static variant: radius multiple of 4");
         static_assert(ChunkMask<1, RT>::value() == kFull && ChunkMask<n - 2, RT>::value() == kFull, "");
         load_half<0>(c, row, pitch, tab, 0);
-        compute_half<0, ChunkMask<0, RT>::value(), RGB>(st, c);
+        compute_half<0, ChunkMask<0, RT>::value(), K>(st, c);
         load_half<1>(c, row, pitch, tab, 0);
-        compute_half<1, ChunkMask<0, RT>::value(), RGB>(st, c);
+        compute_half<1, ChunkMask<0, RT>::value(), K>(st, c);
 #pragma unroll 1
         for (int j = 1; j < n - 1; j++) {
             load_half<0>(c, row, pitch, tab, j);
-            compute_half<0, kFull, RGB>(st, c);
+            compute_half<0, kFull, K>(st, c);
             load_half<1>(c, row, pitch, tab, j);
-            compute_half<1, kFull, RGB>(st, c);
+            compute_half<1, kFull, K>(st, c);
         }
         load_half<0>(c, row, pitch, tab, n - 1);
-        compute_half<0, ChunkMask<n - 1, RT>::value(), RGB>(st, c);
+        compute_half<0, ChunkMask<n - 1, RT>::value(), K>(st, c);
         load_half<1>(c, row, pitch, tab, n - 1);
-        compute_half<1, ChunkMask<n - 1, RT>::value(), RGB>(st, c);
+        compute_half<1, ChunkMask<n - 1, RT>::value(), K>(st, c);
     } else {
 #pragma unroll 1
         for (int j = 0; j < n_chunks; j++) {
             load_half<0>(c, row, pitch, tab, j);
-            compute_half<0, kFull, RGB>(st, c);
+            compute_half<0, kFull, K>(st, c);
             load_half<1>(c, row, pitch, tab, j);
-            compute_half<1, kFull, RGB>(st, c);
+            compute_half<1, kFull, K>(st, c);
         }
     }
 }
@@ -414,9 +416,10 @@ __device__ __forceinline__ void store_pixel(float *slot, int pitch, int i, const
 // RT > 0: compile-time radius (window edges resolved statically); RT == 0: runtime radius
 // a.radius <= 20, every pair of every read group evaluated, the table masks taps beyond r.
 // One work item: `part` of tile `tile` of the tile grid laid over columns [cx0, cx1) of the ROI.
-template <int RT, bool RGB, bool DUAL>
+template <int RT, int K, bool DUAL>
 __device__ __forceinline__ void filter_tile(const FilterArgs &a, float *lds, int u, int cx0, int cx1) {
     using G = Geo<DUAL>;
+    constexpr bool RGB = K == 0;  // K = 0: filter<float3>; K = 1..3: filter<float> with K real buffers in this launch
     const int r = RT > 0 ? RT : a.radius;
     const int rp = RT > 0 ? round_up4(RT) : round_up4(a.radius);
     const int pitch = G::W + 2 * rp;
@@ -510,7 +513,7 @@ __device__ __forceinline__ void filter_tile(const FilterArgs &a, float *lds, int
         }
 
         const float *row = lds + slot * slot_floats + kPx * lane;
-        eval_row<RT, RGB>(st, row, pitch, tab_lds + ((step - s0) & 1) * tw_pad, n_chunks);
+        eval_row<RT, K>(st, row, pitch, tab_lds + ((step - s0) & 1) * tw_pad, n_chunks);
 
         if (tstage) *reinterpret_cast<v2f *>(tab_lds + ((step - s0 + 1) & 1) * tw_pad + 2 * ti) = tnext;
         if (stage) store_pixel(lds + fill * slot_floats, pitch, threadIdx.x, nxt, k0, k1, RGB);
@@ -571,14 +574,14 @@ __device__ __forceinline__ void filter_tile(const FilterArgs &a, float *lds, int
 // the parts of a tile and vertically adjacent tiles -- which stage the same image rows -- then hit in
 // the same L2 instead of each fetching its own copy over the fabric.  Placement only affects speed;
 // the remap is a bijection for any grid size.
-template <int RT, bool RGB>
+template <int RT, int K>
 __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n_items = gridDim.x, b = blockIdx.x;
     const int q8 = n_items >> 3, rem8 = n_items & 7, xcd = b & 7, idx = b >> 3;
     const int u = xcd < rem8 ? xcd * (q8 + 1) + idx : rem8 * (q8 + 1) + (xcd - rem8) * q8 + idx;
-    if (u < a.n_main_items) filter_tile<RT, RGB, false>(a, lds, u, a.rx0, a.rx_split);
-    else filter_tile<RT, RGB, true>(a, lds, u - a.n_main_items, a.rx_split, a.rx1);
+    if (u < a.n_main_items) filter_tile<RT, K, false>(a, lds, u, a.rx0, a.rx_split);
+    else filter_tile<RT, K, true>(a, lds, u - a.n_main_items, a.rx_split, a.rx1);
 }
 
 // Sums the per-part partial (acc, sum_w) of every ROI pixel in part order and normalises.
@@ -690,7 +693,7 @@ static size_t lds_bytes_for(int rp) {
     return ((size_t)G::SLOTS * kCh * (G::W + 2 * rp) + 4 * (2 * rp + 8)) * sizeof(float);
 }
 
-template <int RT, bool RGB>
+template <int RT, int K>
 static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
     if (a.partial == nullptr) a.n_parts = 1;
     if (a.rx1 <= a.rx0 || a.ry1 <= a.ry0) return hipSuccess;
@@ -703,15 +706,15 @@ static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
     const size_t lds_bytes = std::max(main_tiles ? lds_bytes_for<false>(rp) : 0, dual_tiles ? lds_bytes_for<true>(rp) : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&window_filter_lds<RT, RGB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&window_filter_lds<RT, K>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((window_filter_lds<RT, RGB>), dim3((main_tiles + dual_tiles) * a.n_parts), dim3(kThreads), lds_bytes, s, a);
+    hipLaunchKernelGGL((window_filter_lds<RT, K>), dim3((main_tiles + dual_tiles) * a.n_parts), dim3(kThreads), lds_bytes, s, a);
     if (a.n_parts > 1) {
         const dim3 cgrid((a.rx1 - a.rx0 + 63) / 64, (a.ry1 - a.ry0 + 3) / 4);
-        hipLaunchKernelGGL(combine_parts_kernel<RGB>, cgrid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(combine_parts_kernel<K == 0>, cgrid, dim3(256), 0, s, a);
     }
     return hipGetLastError();
 }
@@ -731,10 +734,10 @@ bool lds_path_selected(const FilterArgs &a, int channels) {
 hipError_t launch_lds_packed(const FilterArgs &a, hipStream_t s, const char **variant) {
     if (a.radius == 20 && g_variant_override != 2) {
         *variant = "lds_r20";
-        return launch_lds<20, true>(a, s);
+        return launch_lds<20, 0>(a, s);
     }
     *variant = "lds_rt";
-    return launch_lds<0, true>(a, s);
+    return launch_lds<0, 0>(a, s);
 }
 
 hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s, const char **variant) {
@@ -743,10 +746,12 @@ hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s
         const bool rgb = channels == 3;
         if (a.radius == 20 && g_variant_override != 2) {
             *variant = rgb ? "lds_r20" : "lds_r20_f";
-            return rgb ? launch_lds<20, true>(a, s) : launch_lds<20, false>(a, s);
+            if (rgb) return launch_lds<20, 0>(a, s);
+            return a.f_active >= 3 ? launch_lds<20, 3>(a, s) : a.f_active == 2 ? launch_lds<20, 2>(a, s) : launch_lds<20, 1>(a, s);
         }
         *variant = rgb ? "lds_rt" : "lds_rt_f";
-        return rgb ? launch_lds<0, true>(a, s) : launch_lds<0, false>(a, s);
+        if (rgb) return launch_lds<0, 0>(a, s);
+        return a.f_active >= 3 ? launch_lds<0, 3>(a, s) : a.f_active == 2 ? launch_lds<0, 2>(a, s) : launch_lds<0, 1>(a, s);
     }
     *variant = "generic";
     const dim3 grid((a.rx1 - a.rx0 + 31) / 32, (a.ry1 - a.ry0 + 7) / 8);
