@@ -2,14 +2,14 @@
 //
 // Replaces the window part of cv::cuda::stat_denoiser::filter<T> (call sites
 // src/statistics/estimator.cpp:437-487 of the reference; its CUDA source is not in the tree,
-// the arithmetic is this build's own frozen spec: DESIGN.md "Filter spec v1", restated on the
+// the arithmetic is this build's own frozen spec: DESIGN.md "Filter spec v1.1", restated on the
 // CPU in oracle/statmc_oracle.c:oracle_filter).
 //
 // Two implementations:
 //
-//  * window_filter_lds<R, RGB>  -- the hot kernel.  Two 3-channel G-buffers (the shipped
-//    configuration: filtering under normal + albedo), radius <= 20; RGB = true is filter<float3>
-//    (one RGB buffer), RGB = false is filter<float> (three 1-channel buffers per launch).
+//  * window_filter_lds<R, K>  -- the hot kernel.  Two 3-channel G-buffers (the shipped
+//    configuration: filtering under normal + albedo), radius <= 20; K = 0 is filter<float3>
+//    (one RGB buffer), K = 1..3 is filter<float> (up to three 1-channel buffers per launch, K real).
 //    This is a stencil, not a contraction: 1681 taps x 17 fp32 VALU instructions per pixel
 //    against 72 B of compulsory HBM traffic, so the design goal is VALU issue rate, with LDS as
 //    the operand feed:
@@ -31,11 +31,14 @@
 //        max_c (t_c - D_p,c) <= 0 (same truth value as AND_c t_c <= D_p,c, no scalar-unit
 //        round trip); the work is written stage by stage across the lane's 4 pixels so every
 //        dependent step is followed by independent instructions;
-//      - the window rows of a tile are split over `parts` workgroups (load balance of the
-//        1-workgroup-per-CU grid) whose partial sums combine_parts_kernel adds up; work items
-//        are remapped so that each XCD's L2 sees one contiguous range of tiles.
-//    Taps outside the image (and pixels with NaN statistics) are staged with a NaN corrected
-//    mean, which fails every comparison, so clipping costs nothing in the inner loop.
+//      - a last tile column of at most half a tile (1920 = 7.5 x 256) is covered by DUAL tiles,
+//        128 x 15 pixels with the two halves of every wave on different rows, work items of the
+//        same grid: 1080p is 945 + 72 workgroups = 4 rounds of the 1-workgroup-per-CU grid;
+//      - where the tile count does not fill the rounds, the window rows of a tile are split over
+//        `parts` workgroups whose partial sums combine_parts_kernel adds up; work items are
+//        remapped so that each XCD's L2 sees one contiguous range of tiles.
+//    Taps outside the image (and pixels with NaN statistics or a non-finite mean) are staged with a
+//    NaN corrected mean, which fails every comparison, so clipping costs nothing in the inner loop.
 //
 //  * window_filter_generic<C> -- any radius, any G-buffer set, T = float or float3, one lane
 //    per pixel straight from global memory.  Correctness path for configurations the hot
