@@ -447,8 +447,10 @@ __device__ __forceinline__ void filter_tile(const FilterArgs &a, float *lds, int
     // window sweep over several workgroups per tile evens out the last round of the 1-WG-per-CU
     // grid (1080 tiles on 256 CUs would otherwise leave 200 CUs idle for a fifth of the run).
     const int n_rows = 2 * r + 1;
-    const int s0 = (n_rows * part) / a.n_parts;
-    const int s1 = (n_rows * (part + 1)) / a.n_parts;
+    // ... clipped to the window rows that reach the image for at least one row of the tile (tiles at
+    // the top and bottom of the film would otherwise sweep up to 13 rows of nothing but invalid taps)
+    const int s0 = max((n_rows * part) / a.n_parts, r - y0 - (G::ROWS - 1));
+    const int s1 = min((n_rows * (part + 1)) / a.n_parts, a.height + r - y0);
 
     // ---- the lane's own 4 pixels (clamped into the image so the loads stay in bounds)
     LaneState st;
