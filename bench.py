@@ -133,8 +133,15 @@ def cpu_baseline(args, fs, samples, types, budget_s=7.0):
     t0 = time.perf_counter()
     oracle.filter_image(mc, dc, rad["film_mean"], gb, g_dr, ds, args.radius, roi=(0, fy1, W, fy1 + 2), threads=1)
     flt1 = (time.perf_counter() - t0) / (2 * W)
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        pass
     return {
         "value": round(1e-6 / s_per_px, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+        "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count(),
         "sample": "oracle (C restatement of the reference algorithm, OpenMP, %d threads): accumulate %d rows x %d px "
                   "x %d spp x %d ch, %d repetitions (%.1f s); pre-pass full frame (%.2f s); filter %d rows x %d px, "
                   "full %dx%d window, %d repetitions (%.1f s); per-pixel times summed and inverted"
