@@ -67,10 +67,11 @@ def test_render_loop_matches_oracle(gpu, oracle, tmp_path, W, H, stage_mb):
     stem = str(tmp_path / "sim")
     out = subprocess.run([build.RENDER_SIM_BIN, "--width", str(W), "--height", str(H), "--spp", str(spp),
                           "--iterations", str(iterations), "--threads", "4", "--seed", str(seed), "--stem", stem,
-                          "--filtersd", str(sd), "--filterradius", str(radius), "--stage-mb", str(stage_mb)],
+                          "--filtersd", str(sd), "--filterradius", str(radius), "--stage-mb", str(stage_mb), "--warmup"],
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
-    assert out.stdout.count("CUDA time [ns]:") == iterations and "Iteration: 3" in out.stdout
+    # --warmup: one throw-away iteration whose statistics must not survive into the real run
+    assert out.stdout.count("CUDA time [ns]:") == iterations + 1 and "Iteration: 3" in out.stdout and "Warm-Up End" in out.stdout
 
     st = {"rad": oracle.new_state(H, W, 3), "nrm": oracle.new_state(H, W, 3), "alb": oracle.new_state(H, W, 3)}
     done = 0

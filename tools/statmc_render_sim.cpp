@@ -19,7 +19,7 @@
 //
 //   statmc_render_sim --width 96 --height 56 --spp 4 --iterations 3 --stem out/sim [--threads 4]
 //                     [--seed 1] [--filtersd 10] [--filterradius 20] [--stage-mb 2048] [--no-denoise]
-//                     [--config denoise|acrr|smis] [--trackedbounces 5] [--outputregex '.*']
+//                     [--config denoise|acrr|smis] [--trackedbounces 5] [--outputregex '.*'] [--warmup]
 // --config denoise: Render<Vec3>, RGB radiance + normal + albedo, filter<float3> (scenes/render-denoise.pbrt).
 // --config acrr:    Render<Float>, "multichannelstats" false: the luminance of the path prefix up to each
 //                   of the tracked bounces is one float stat buffer, filtered together by filter<float>
@@ -104,7 +104,7 @@ struct Options {
     unsigned seed = 1;
     float filterSD = 10.f;
     int filterRadius = 20;
-    bool denoise = true, acrr = false, smis = false;
+    bool denoise = true, acrr = false, smis = false, warmUp = false;
     std::string stem, outputRegex = ".*";
 };
 
@@ -163,7 +163,8 @@ static void Render(const Options &o) {
     const OutputBufferSelection outBufSel(reg, std::regex(o.outputRegex), (o.stem.empty() ? std::string("out") : o.stem) + ".pfm");
 
     unsigned done = 0;  // samples per pixel so far
-    for (int i = 1; i <= o.iterations; i++) {
+    auto RenderLoop = [&](const int nIterations, const bool writeOutput) {
+    for (int i = 1; i <= nIterations; i++) {
         const unsigned target = i == 1 ? (unsigned)o.spp : (unsigned)o.spp << std::max(i - 2, 0);  // statpath.cpp:272-279
         auto begin = std::chrono::steady_clock::now();
         std::atomic<int> nextTile{0};
@@ -233,7 +234,7 @@ static void Render(const Options &o) {
         std::cout << "CUDA time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(end - begin).count() << std::endl;
 
         begin = std::chrono::steady_clock::now();
-        if (!o.stem.empty()) {  // statpath.cpp:419-427: outBufSel.PrepareOutput(); outBufSel.Write(total spp)
+        if (!o.stem.empty() && writeOutput) {  // statpath.cpp:419-427: outBufSel.PrepareOutput(); outBufSel.Write(total spp)
             // what lives only on the device comes to the host mats first: the statistics, and the
             // filter's device-only by-products (mean-corr, discriminator)
             estimator.DownloadStatistics();
@@ -248,6 +249,17 @@ static void Render(const Options &o) {
         end = std::chrono::steady_clock::now();
         std::cout << "Output time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(end - begin).count() << std::endl;
     }
+    };
+
+    if (o.warmUp) {  // statpath.cpp:433-437: one throw-away iteration, then everything starts over
+        std::cout << "==== Warm-Up Start ====" << std::endl;
+        RenderLoop(1, false);
+        std::cout << "==== Warm-Up End ====" << std::endl;
+        // the reference re-creates its tiles, i.e. all statistics, for the real run
+        for (unsigned char t = 0; t < estimator.statTypeConfigs.nEnabled; t++) estimator.ResetStatistics(t);
+        done = 0;
+    }
+    RenderLoop(o.iterations, true);
 }
 
 int main(int argc, char **argv) {
@@ -274,6 +286,7 @@ int main(int argc, char **argv) {
         else if (a == "--stem") o.stem = next();
         else if (a == "--outputregex") o.outputRegex = next();
         else if (a == "--no-denoise") o.denoise = false;
+        else if (a == "--warmup") o.warmUp = true;
         else if (a == "--config") {
             const std::string c = next();
             if (c != "denoise" && c != "acrr" && c != "smis") {
