@@ -371,8 +371,9 @@ __device__ __forceinline__ StagedPixel load_pixel(const FilterArgs &a, int x, in
             s.d = f3{a.f_disc[0][q], a.f_disc[1][q], a.f_disc[2][q]};
             s.col = f3{a.f_colour[0][q], a.f_colour[1][q], a.f_colour[2][q]};
         }
-        s.g0 = reinterpret_cast<const f3 *>(a.g[0].data)[q];
-        s.g1 = reinterpret_cast<const f3 *>(a.g[1].data)[q];
+        // a G-buffer slot with factor 0 (absent: fewer than two G-buffers) is never read
+        s.g0 = a.gscale0 != 0.f ? reinterpret_cast<const f3 *>(a.g[0].data)[q] : f3{0.f, 0.f, 0.f};
+        s.g1 = a.gscale1 != 0.f ? reinterpret_cast<const f3 *>(a.g[1].data)[q] : f3{0.f, 0.f, 0.f};
     }
     return s;
 }
@@ -472,8 +473,8 @@ __device__ __forceinline__ void filter_tile(const FilterArgs &a, float *lds, int
         }
         mc = canonical_mean(mc, d, true, RGB);  // the same rule as for the staged taps
         if (!(RGB && a.packed)) {
-            g0 = reinterpret_cast<const f3 *>(a.g[0].data)[p];
-            g1 = reinterpret_cast<const f3 *>(a.g[1].data)[p];
+            g0 = k0 != 0.f ? reinterpret_cast<const f3 *>(a.g[0].data)[p] : f3{0.f, 0.f, 0.f};
+            g1 = k1 != 0.f ? reinterpret_cast<const f3 *>(a.g[1].data)[p] : f3{0.f, 0.f, 0.f};
         }
         st.pg[k][0] = g0.x * k0; st.pg[k][1] = g0.y * k0; st.pg[k][2] = g0.z * k0;
         st.pg[k][3] = g1.x * k1; st.pg[k][4] = g1.y * k1; st.pg[k][5] = g1.z * k1;
@@ -647,13 +648,15 @@ hipError_t launch_pack_inputs(const PackArgs &a, hipStream_t s) {
 }
 
 // The LDS kernel covers T = float3 (one RGB buffer) and T = float (three buffers per launch)
-// under two 3-channel G-buffers with finite, non-positive DR factors and radius 1..20.
+// under at most two 3-channel G-buffers with finite, non-positive DR factors and radius 1..20 (it is
+// written for two; an absent one is a slot with factor 0 that is never read).
 bool fast_path_eligible(const FilterArgs &a, int channels) {
-    if ((channels != 3 && channels != 1) || a.n_g != 2) return false;
-    if (a.g[0].channels != 3 || a.g[1].channels != 3) return false;
+    if ((channels != 3 && channels != 1) || a.n_g > 2) return false;
+    for (int g = 0; g < a.n_g; g++) {
+        if (a.g[g].channels != 3) return false;
+        if (!(a.g[g].dr <= 0.f) || !isfinite(a.g[g].dr)) return false;
+    }
     if (a.radius < 1 || a.radius > kMaxR) return false;
-    if (!(a.g[0].dr <= 0.f) || !(a.g[1].dr <= 0.f)) return false;
-    if (!isfinite(a.g[0].dr) || !isfinite(a.g[1].dr)) return false;
     return true;
 }
 

@@ -616,6 +616,30 @@ def test_filter_generic_gbuffer_sets(gpu, oracle, channels):
     assert rel_l2(out0, ref0) <= TOL
 
 
+@pytest.mark.parametrize("channels", [1, 3])
+@pytest.mark.parametrize("n_g", [0, 1])
+def test_filter_fewer_gbuffers_on_the_lds_kernel(gpu, oracle, channels, n_g):
+    """`filterbuffers ["albedo"]` or none at all: the LDS kernel is written for two RGB G-buffers and
+    runs with an absent one as a slot of factor 0 that is never read; same result as the generic
+    kernel and the oracle."""
+    rng = np.random.default_rng(100 + 10 * channels + n_g)
+    H, W, r = 40, 300, 20
+    mc = rng.standard_normal((H, W, channels)).astype(np.float32)
+    disc = ((rng.random((H, W, channels)) ** 2) * 2).astype(np.float32)
+    colour = rng.random((H, W, channels), dtype=np.float32) * 4
+    gbs = [rng.random((H, W, 3), dtype=np.float32)][:n_g]
+    g_dr = [-0.5 / 0.2 ** 2][:n_g]
+    ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / FILTER_SD ** 2, r)
+    out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, FILTER_SD, r, channels=channels)
+    assert v == ("lds_r20" if channels == 3 else "lds_r20_f")
+    for c in range(channels):
+        assert rel_l2(out[..., c], ref[..., c]) <= TOL
+    out_g, v_g = run_filter(gpu, mc, disc, colour, gbs, g_dr, FILTER_SD, r, channels=channels, force=1)
+    assert v_g == "generic"
+    for c in range(channels):
+        assert rel_l2(out_g[..., c], ref[..., c]) <= TOL
+
+
 @pytest.mark.parametrize("n_buffers,radius,variant", [(5, 20, "lds_r20_f"), (12, 20, "lds_r20_f"), (4, 7, "lds_rt_f"), (1, 20, "lds_r20_f")])
 def test_filter_float_multibuffer_fast_path(gpu, oracle, n_buffers, radius, variant):
     """filter<float> as ACRR (nBuffers = trackedbounces = 5) and SMIS (2 x 6 = 12) call it
