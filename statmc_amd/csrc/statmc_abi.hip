@@ -342,8 +342,7 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
     }
     if (statmc::fast_path_eligible(k, channels)) {
         if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
-        k.gscale0 = k.n_g > 0 ? sqrtf(-k.g[0].dr * 1.44269504088896340736f) : 0.f;
-        k.gscale1 = k.n_g > 1 ? sqrtf(-k.g[1].dr * 1.44269504088896340736f) : 0.f;
+        statmc::set_feature_layout(k);
         k.n_parts = statmc::lds_filter_parts(k, device_cus());
     } else {
         k.n_parts = 1;

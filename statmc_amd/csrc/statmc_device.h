@@ -93,6 +93,15 @@ struct FilterArgs {
     // fast path only (T = float3, two 3-channel G-buffers):
     const float *spatial_tab;    // [(2r+1)][2*RP+7] log2-domain spatial exponents, -inf outside r
     float gscale0, gscale1;      // sqrt(-dr_g * log2(e))
+    // G-buffer sets other than "up to two RGB images" whose channels still fit the kernel's six feature
+    // slots (e.g. normal + depth + material id): slot f reads data[pixel * stride + offset] * scale;
+    // gscale0 = gscale1 = 1 then.  scale 0 = empty slot.
+    int feat_generic;
+    struct FeatSlot {
+        const float *data;
+        int stride, offset;
+        float scale;
+    } feat[6];
     int n_parts;                 // window rows are swept by n_parts workgroups per tile ...
     float *partial;              // ... which leave their sums here: [n_parts][height][width][4 (RGB) | 8 (float x3)]
     // fast path, filter<float>: up to three 1-channel buffers per launch (f_active of them real;
@@ -136,6 +145,7 @@ hipError_t launch_lds_packed(const FilterArgs &a, hipStream_t s, const char **va
 size_t spatial_table_floats(int radius);
 void fill_spatial_table(float *host_tab, int radius, float ds);
 bool fast_path_eligible(const FilterArgs &a, int channels);
+void set_feature_layout(FilterArgs &a);   // gscale0/1, feat[] of an eligible G-buffer set
 bool lds_path_selected(const FilterArgs &a, int channels);
 
 // force a variant for tests/benchmarks: 0 = auto, 1 = generic, 2 = lds_rt (runtime radius)

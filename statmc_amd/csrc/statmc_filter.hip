@@ -351,6 +351,22 @@ struct StagedPixel {
     bool valid;
 };
 
+// The six feature values of pixel q (before the k0 / k1 scaling of the two-RGB-buffer layout; already
+// scaled, with k0 = k1 = 1, in the generic slot layout).  A slot or buffer with factor 0 is never read.
+__device__ __forceinline__ void load_features(const FilterArgs &a, long long q, f3 &g0, f3 &g1) {
+    if (a.feat_generic) {
+        float v[6];
+#pragma unroll
+        for (int f = 0; f < 6; f++)
+            v[f] = a.feat[f].scale != 0.f ? a.feat[f].data[q * a.feat[f].stride + a.feat[f].offset] * a.feat[f].scale : 0.f;
+        g0 = f3{v[0], v[1], v[2]};
+        g1 = f3{v[3], v[4], v[5]};
+        return;
+    }
+    g0 = a.gscale0 != 0.f ? reinterpret_cast<const f3 *>(a.g[0].data)[q] : f3{0.f, 0.f, 0.f};
+    g1 = a.gscale1 != 0.f ? reinterpret_cast<const f3 *>(a.g[1].data)[q] : f3{0.f, 0.f, 0.f};
+}
+
 template <bool RGB>
 __device__ __forceinline__ StagedPixel load_pixel(const FilterArgs &a, int x, int yrow) {
     StagedPixel s;
@@ -371,9 +387,7 @@ __device__ __forceinline__ StagedPixel load_pixel(const FilterArgs &a, int x, in
             s.d = f3{a.f_disc[0][q], a.f_disc[1][q], a.f_disc[2][q]};
             s.col = f3{a.f_colour[0][q], a.f_colour[1][q], a.f_colour[2][q]};
         }
-        // a G-buffer slot with factor 0 (absent: fewer than two G-buffers) is never read
-        s.g0 = a.gscale0 != 0.f ? reinterpret_cast<const f3 *>(a.g[0].data)[q] : f3{0.f, 0.f, 0.f};
-        s.g1 = a.gscale1 != 0.f ? reinterpret_cast<const f3 *>(a.g[1].data)[q] : f3{0.f, 0.f, 0.f};
+        load_features(a, q, s.g0, s.g1);
     }
     return s;
 }
@@ -472,10 +486,7 @@ __device__ __forceinline__ void filter_tile(const FilterArgs &a, float *lds, int
             d = f3{a.f_disc[0][p], a.f_disc[1][p], a.f_disc[2][p]};
         }
         mc = canonical_mean(mc, d, true, RGB);  // the same rule as for the staged taps
-        if (!(RGB && a.packed)) {
-            g0 = k0 != 0.f ? reinterpret_cast<const f3 *>(a.g[0].data)[p] : f3{0.f, 0.f, 0.f};
-            g1 = k1 != 0.f ? reinterpret_cast<const f3 *>(a.g[1].data)[p] : f3{0.f, 0.f, 0.f};
-        }
+        if (!(RGB && a.packed)) load_features(a, p, g0, g1);
         st.pg[k][0] = g0.x * k0; st.pg[k][1] = g0.y * k0; st.pg[k][2] = g0.z * k0;
         st.pg[k][3] = g1.x * k1; st.pg[k][4] = g1.y * k1; st.pg[k][5] = g1.z * k1;
         st.pmc[k][0] = mc.x; st.pmc[k][1] = mc.y; st.pmc[k][2] = mc.z;
@@ -648,16 +659,41 @@ hipError_t launch_pack_inputs(const PackArgs &a, hipStream_t s) {
 }
 
 // The LDS kernel covers T = float3 (one RGB buffer) and T = float (three buffers per launch)
-// under at most two 3-channel G-buffers with finite, non-positive DR factors and radius 1..20 (it is
-// written for two; an absent one is a slot with factor 0 that is never read).
+// under G-buffers of 1 or 3 channels whose channel counts add up to at most six (the kernel's feature
+// slots; written for two RGB images, an absent one is a slot with factor 0 that is never read), finite
+// non-positive DR factors and radius 1..20.
 bool fast_path_eligible(const FilterArgs &a, int channels) {
-    if ((channels != 3 && channels != 1) || a.n_g > 2) return false;
+    if (channels != 3 && channels != 1) return false;
+    int slots = 0;
     for (int g = 0; g < a.n_g; g++) {
-        if (a.g[g].channels != 3) return false;
+        if (a.g[g].channels != 1 && a.g[g].channels != 3) return false;
         if (!(a.g[g].dr <= 0.f) || !isfinite(a.g[g].dr)) return false;
+        slots += a.g[g].channels;
     }
+    if (slots > 6) return false;
     if (a.radius < 1 || a.radius > kMaxR) return false;
     return true;
+}
+
+// Feature layout of the LDS kernel for an eligible G-buffer set: up to two RGB images keep the vector
+// loads (k0, k1 per image); anything else is spread over the six slots, one channel each.
+void set_feature_layout(FilterArgs &a) {
+    constexpr float kL2e = 1.44269504088896340736f;
+    bool rgb_pair = a.n_g <= 2;
+    for (int g = 0; g < a.n_g; g++) rgb_pair = rgb_pair && a.g[g].channels == 3;
+    for (int f = 0; f < 6; f++) a.feat[f] = FilterArgs::FeatSlot{nullptr, 0, 0, 0.f};
+    if (rgb_pair) {
+        a.feat_generic = 0;
+        a.gscale0 = a.n_g > 0 ? sqrtf(-a.g[0].dr * kL2e) : 0.f;
+        a.gscale1 = a.n_g > 1 ? sqrtf(-a.g[1].dr * kL2e) : 0.f;
+        return;
+    }
+    a.feat_generic = 1;
+    a.gscale0 = a.gscale1 = 1.f;
+    int f = 0;
+    for (int g = 0; g < a.n_g; g++)
+        for (int c = 0; c < a.g[g].channels; c++, f++)
+            a.feat[f] = FilterArgs::FeatSlot{a.g[g].data, a.g[g].channels, c, sqrtf(-a.g[g].dr * kL2e)};
 }
 
 // Number of window-sweep parts per tile: the grid runs one workgroup per CU (LDS-bound), so its

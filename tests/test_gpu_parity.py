@@ -597,9 +597,10 @@ def test_filter_roi(gpu, oracle):
 
 @pytest.mark.parametrize("channels", [1, 3])
 def test_filter_generic_gbuffer_sets(gpu, oracle, channels):
-    """filter<float> and float G-buffers (depth / material id) go through the generic kernel."""
+    """G-buffer sets with float images (depth / material id): up to six channels in total are spread
+    over the LDS kernel's six feature slots; more than that goes through the generic kernel."""
     rng = np.random.default_rng(21)
-    H, W, r = 30, 44, 7
+    H, W, r = 30, 300, 7
     mc = rng.random((H, W, channels), dtype=np.float32)
     disc = (0.1 * rng.random((H, W, channels))).astype(np.float32)
     colour = rng.random((H, W, channels), dtype=np.float32)
@@ -608,8 +609,20 @@ def test_filter_generic_gbuffer_sets(gpu, oracle, channels):
     g_dr = [-0.5 / 0.3 ** 2, -0.5 / 0.2 ** 2, -0.5 / 0.1 ** 2]
     ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / 16.0, r)
     out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, 4.0, r, channels=channels)
-    assert v == "generic"
+    assert v == ("lds_rt" if channels == 3 else "lds_rt_f")           # 3 + 1 + 1 channels: slot layout
     assert rel_l2(out, ref) <= TOL
+    out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, 4.0, r, channels=channels, force=1)
+    assert v == "generic" and rel_l2(out, ref) <= TOL
+    # float image first, r = 20 instantiation
+    gbs2, dr2 = [gbs[1], gbs[0]], [g_dr[1], g_dr[0]]
+    ref2 = oracle.filter_image(mc, disc, colour, gbs2, dr2, -0.5 / 100.0, 20)
+    out2, v2 = run_filter(gpu, mc, disc, colour, gbs2, dr2, 10.0, 20, channels=channels)
+    assert v2 == ("lds_r20" if channels == 3 else "lds_r20_f") and rel_l2(out2, ref2) <= TOL
+    # seven channels do not fit
+    gbs7 = [gbs[0], rng.random((H, W, 3), dtype=np.float32), gbs[1]]
+    ref7 = oracle.filter_image(mc, disc, colour, gbs7, g_dr, -0.5 / 16.0, r)
+    out7, v7 = run_filter(gpu, mc, disc, colour, gbs7, g_dr, 4.0, r, channels=channels)
+    assert v7 == "generic" and rel_l2(out7, ref7) <= TOL
     # no G-buffers at all
     ref0 = oracle.filter_image(mc, disc, colour, [], [], -0.5 / 16.0, r)
     out0, _ = run_filter(gpu, mc, disc, colour, [], [], 4.0, r, channels=channels)
