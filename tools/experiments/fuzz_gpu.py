@@ -34,7 +34,11 @@ def filter_case(case, verbose=False):
         elif kind == 3: mc[y, x] = np.inf
         else: disc[y, x, rng.integers(0, 3)] = np.nan
     colour = (rng.random((H, W, 3), dtype=np.float32) * 3 * float(10 ** rng.uniform(-2, 3))).astype(np.float32)
-    gbs = [rng.random((H, W, 3), dtype=np.float32) * 2 - 1, rng.random((H, W, 3), dtype=np.float32)]
+    layouts = [[3, 3]] * 6 + [[3], [], [3, 1, 1], [1, 3], [1, 1, 1, 1, 1, 1], [3, 3, 1], [1]]
+    layout = layouts[int(rng.integers(0, len(layouts)))]
+    gbs = [(rng.random((H, W, c), dtype=np.float32) * 2 - (i % 2)).astype(np.float32) for i, c in enumerate(layout)]
+    g_sds = (g_sds + [float(10 ** rng.uniform(-1.5, 0)) for _ in layout])[:len(layout)]
+    g_dr = [-0.5 / s ** 2 for s in g_sds]
     if rng.random() < 0.3:   # piecewise-constant features: many exactly equal taps
         gbs = [(np.round(g * 2) / 2).astype(np.float32) for g in gbs]
     roi = None
@@ -55,7 +59,7 @@ def filter_case(case, verbose=False):
     if ok and mask.any():
         err = max(T.rel_l2(np.where(mask[..., c], out[..., c], 0), np.where(mask[..., c], ref[..., c], 0)) for c in range(3))
     desc = dict(case=case, W=W, H=H, radius=radius, sd=round(sd, 3), g_sds=[round(g, 4) for g in g_sds], scale=scale, roi=roi,
-                force=force, parts=parts, variant=v, inj=inj, err=err, finite_ok=ok)
+                force=force, parts=parts, variant=v, inj=inj, err=err, finite_ok=ok, layout=layout)
     if verbose:
         print(desc)
         d = np.abs(out.astype(np.float64) - ref) / (np.abs(ref) + 1e-30)
