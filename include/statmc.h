@@ -38,23 +38,60 @@ extern "C" {
 const char *statmc_last_error(void);
 
 /* Replaces cv::cuda::stat_denoiser::setup()  (src/statistics/estimator.h:280).
- * Selects the device, uploads the Student-t quantile tables. Idempotent per device. */
+ * Selects the device, uploads the Student-t quantile tables. Idempotent per device.
+ *
+ * All library state is kept PER DEVICE (quantile tables, significance level, filter spec, kernel
+ * attributes, workspaces): a process that drives several GPUs -- one Estimator per device, the
+ * one-process-eight-devices host design -- calls statmc_setup(d) once for each and every setter
+ * below acts on the calling thread's current device (statmc_set_device). */
 int statmc_setup(int device);
 
 /* Makes `device` current for the calling thread (HIP's current device is per thread): a thread
  * other than the one that ran statmc_setup -- e.g. a render worker whose Merge*Tiles call triggers a
- * flush -- calls this before using a device other than 0. */
+ * flush -- calls this before using a device other than 0.  The device must have been set up. */
 int statmc_set_device(int device);
 
 /* The reference picks the significance level at compile time by pointing `t_quantiles` at one
- * of three tables (README.md:149,158): 0 -> 0.005 (default), 1 -> 0.002, 2 -> 0.05. */
+ * of three tables (README.md:149,158): 0 -> 0.005 (default), 1 -> 0.002, 2 -> 0.05.
+ * Acts on the current device. */
 int statmc_set_significance(int alpha_index);
 int statmc_get_significance(void);
-/* Replaces the built-in table `alpha_index` with the caller's quantiles for dof = 1..n_dof
- * (n_dof <= 4096; larger dof reuse the last entry).  The built-in tables are this build's choice
- * (two-sided t_{1-alpha/2}); the reference's own `t_quantiles` arrays live in the un-vendored
- * stat_denoiser.cu, and a user who has them can load them here.  Call after statmc_setup(). */
-int statmc_set_t_quantiles(int alpha_index, const float *quantiles, int n_dof);
+/* Replaces the built-in table `table` of the current device with the caller's quantiles for
+ * dof = 1..n_dof (n_dof <= 4096; larger dof reuse the last entry).  table = alpha_index (0..2) for the
+ * two-sided tables t_{1-alpha/2}, 3 + alpha_index for the one-sided ones t_{1-alpha} (see
+ * statmc_filter_spec.sides).  The built-in tables are this build's choice; the reference's own
+ * `t_quantiles` arrays live in the un-vendored stat_denoiser.cu, and a user who has them can load them
+ * here; quantiles == NULL with n_dof == 0 restores the built-in table.  Call after statmc_setup()
+ * (a repeated statmc_setup of the same device keeps what was loaded). */
+int statmc_set_t_quantiles(int table, const float *quantiles, int n_dof);
+
+/* ---- filter spec: everything about cv::cuda::stat_denoiser::filter<T> that the reference tree does
+ * not fix (its CUDA source is in the un-vendored submodule src/ext/opencv_contrib, .gitmodules:19-21;
+ * only the call sites src/statistics/estimator.cpp:437-487 and the buffer meanings README.md:317-325
+ * are in the tree).  Every open choice is a field, so that pinning this build to dumps of the CUDA
+ * denoiser is a search over specs (tools/fit_spec.py), not a kernel rewrite.  All-zero = this build's
+ * default ("spec v2").  The hand-tuned LDS kernels implement the default
+ * gate / channel rule / dof / border; any other value runs the general kernel (same results as the
+ * CPU oracle, ~15x slower).  `sides` and `small_n` only change the pre-pass. */
+#define STATMC_GATE_SYMMETRIC 0   /* member <=> fma(d, d, -(D_p + D_q)) <= 0, i.e. d^2 <= D_p + D_q        */
+#define STATMC_GATE_ASYMMETRIC 1  /* member <=> fma(d, d, -D_q) <= D_p      (this build's spec v1.x)       */
+#define STATMC_CHANNELS_AND 0     /* every channel of an RGB buffer must pass                              */
+#define STATMC_CHANNELS_JOINT 1   /* sum over channels of the left sides <= sum of the right sides        */
+#define STATMC_SIDES_TWO 0        /* tabulated quantile t_{1-alpha/2, dof}                                */
+#define STATMC_SIDES_ONE 1        /* t_{1-alpha, dof}                                                     */
+#define STATMC_DOF_PIXEL 0        /* discriminator = t(n-1)^2 s^2/n per pixel                             */
+#define STATMC_DOF_WELCH 1        /* discriminator image = s^2/n; each pair looks t up at floor(Welch-
+                                     Satterthwaite dof) and tests d^2 <= t^2 (v_p + v_q)                  */
+#define STATMC_BORDER_CLIP 0      /* taps outside the image are skipped                                   */
+#define STATMC_BORDER_CLAMP 1     /* tap coordinates are clamped to the image (edge pixels repeat)        */
+#define STATMC_SMALL_N_ACCEPT 0   /* n < 2: discriminator +inf, the pixel passes every test               */
+#define STATMC_SMALL_N_EXCLUDE 1  /* n < 2: the pixel takes no part in any window                         */
+typedef struct statmc_filter_spec {
+    int32_t gate, channel_rule, sides, dof, border, small_n;
+} statmc_filter_spec;
+/* Acts on the current device; applies to every later pre-pass / window-filter call on it. */
+int statmc_set_filter_spec(const statmc_filter_spec *spec);
+int statmc_get_filter_spec(statmc_filter_spec *spec);
 
 /* Device memory + copies: the GpuMat role inside Buffer (src/statistics/buffer.h:25,57-63). */
 int statmc_malloc(void **dev_ptr, size_t bytes);
@@ -117,6 +154,11 @@ typedef struct statmc_filter_args {
      * its inputs from it and ignores mean_corr / discriminator / film / g_buffers.
      * statmc_pack_filter_inputs fills the owned block of such an image. */
     statmc_image packed_inputs;
+    /* Film coordinates of local pixel (0, 0) (multi-GPU block path; 0, 0 = the local image is the film).  The
+     * window filter lays its work tiles on a grid fixed in FILM coordinates, so a pixel's sums are formed in the
+     * same order whether it is filtered as part of the whole film or of a block + halo image: block-decomposed
+     * results are bit-identical to the single-GPU result. */
+    int32_t film_x0, film_y0;
 } statmc_filter_args;
 
 /* Replace cv::cuda::stat_denoiser::filter<float> / filter<float3>: pre-pass + window filter. */

@@ -135,6 +135,43 @@ inline void setSignificance(int alphaIndex) { check(statmc_set_significance(alph
 inline void setTQuantiles(int alphaIndex, const std::vector<float> &q) {
     check(statmc_set_t_quantiles(alphaIndex, q.data(), (int)q.size()));
 }
+// What the tree does not fix about filter<T> (statmc_filter_spec in statmc.h): gate form, channel rule,
+// one- or two-sided quantile, per-pixel or Welch dof, border policy, n < 2.  Default-constructed = spec v2.
+inline void setFilterSpec(const statmc_filter_spec &spec) { check(statmc_set_filter_spec(&spec)); }
+inline statmc_filter_spec getFilterSpec() {
+    statmc_filter_spec s;
+    check(statmc_get_filter_spec(&s));
+    return s;
+}
+// "gate=asym,channels=joint,sides=one,dof=welch,border=clamp,small_n=exclude" (any subset, any order;
+// the other value of each field is its default: sym / and / two / pixel / clip / accept)
+inline statmc_filter_spec parseFilterSpec(const std::string &text) {
+    statmc_filter_spec s = {0, 0, 0, 0, 0, 0};
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t end = text.find(',', pos);
+        if (end == std::string::npos) end = text.size();
+        const std::string item = text.substr(pos, end - pos);
+        pos = end + 1;
+        if (item.empty()) continue;
+        const size_t eq = item.find('=');
+        if (eq == std::string::npos) throw std::runtime_error("filter spec: expected key=value, got '" + item + "'");
+        const std::string k = item.substr(0, eq), v = item.substr(eq + 1);
+        auto pick = [&](const char *zero, const char *one) -> int32_t {
+            if (v == zero || v == "0") return 0;
+            if (v == one || v == "1") return 1;
+            throw std::runtime_error("filter spec: " + k + " is '" + zero + "' or '" + one + "', not '" + v + "'");
+        };
+        if (k == "gate") s.gate = pick("sym", "asym");
+        else if (k == "channels") s.channel_rule = pick("and", "joint");
+        else if (k == "sides") s.sides = pick("two", "one");
+        else if (k == "dof") s.dof = pick("pixel", "welch");
+        else if (k == "border") s.border = pick("clip", "clamp");
+        else if (k == "small_n") s.small_n = pick("accept", "exclude");
+        else throw std::runtime_error("filter spec: unknown field '" + k + "'");
+    }
+    return s;
+}
 
 namespace detail {
 inline std::vector<statmc_image> descs(const std::vector<DeviceImage> &v) {

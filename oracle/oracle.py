@@ -20,6 +20,25 @@ def build(force=False):
     return _SO
 
 
+class FilterSpec(C.Structure):
+    """oracle_filter_spec: the choices SURVEY.md App. B leaves open.  All-zero = default (spec v2)."""
+    _fields_ = [("gate", C.c_int32), ("channel_rule", C.c_int32), ("sides", C.c_int32), ("dof", C.c_int32),
+                ("border", C.c_int32), ("small_n", C.c_int32)]
+
+    def __init__(self, gate=0, channel_rule=0, sides=0, dof=0, border=0, small_n=0):
+        super().__init__(gate, channel_rule, sides, dof, border, small_n)
+
+    def as_tuple(self):
+        return (self.gate, self.channel_rule, self.sides, self.dof, self.border, self.small_n)
+
+
+GATE_SYMMETRIC, GATE_ASYMMETRIC = 0, 1
+CHANNELS_AND, CHANNELS_JOINT = 0, 1
+SIDES_TWO, SIDES_ONE = 0, 1
+DOF_PIXEL, DOF_WELCH = 0, 1
+BORDER_CLIP, BORDER_CLAMP = 0, 1
+SMALL_N_ACCEPT, SMALL_N_EXCLUDE = 0, 1
+
 _lib = None
 
 
@@ -42,6 +61,11 @@ def lib():
                                        [C.c_int, C.POINTER(f32p), C.POINTER(C.c_int), f32p, f32p] +
                                        [C.c_int] * 5)
         _lib.oracle_set_t_quantiles.argtypes = [C.c_int, f32p, C.c_int]
+        _lib.oracle_set_fp_contract.argtypes = [C.c_int]
+        _lib.oracle_prepass_spec.argtypes = [C.c_int] * 4 + [C.POINTER(FilterSpec), i32p] + [f32p] * 5
+        _lib.oracle_filter_spec_run.argtypes = ([C.c_int] * 3 + [C.c_float, C.c_int, C.c_int, C.POINTER(FilterSpec), i32p] +
+                                                [f32p] * 3 + [C.c_int, C.POINTER(f32p), C.POINTER(C.c_int), f32p, f32p] +
+                                                [C.c_int] * 5)
         _lib.oracle_film_update.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, f32p]
         _lib.oracle_num_threads.restype = C.c_int
     return _lib
@@ -61,12 +85,19 @@ def num_threads():
     return lib().oracle_num_threads()
 
 
+def set_fp_contract(on):
+    """True: the accumulation / film arithmetic fuses what clang -O3 -march=native -ffp-contract=on (the
+    reference's own build recipe) fuses in StatTile<Float> and Film::UpdateImage; False (default): no FMA."""
+    lib().oracle_set_fp_contract(int(bool(on)))
+
+
 def box_cox(v, lam=0.5):
     return lib().oracle_box_cox(float(v), float(lam))
 
 
 def set_t_quantiles(alpha_index, quantiles):
-    """quantiles: float32 array for dof 1..len, or None to restore the built-in table."""
+    """quantiles: float32 array for dof 1..len, or None to restore the built-in table.  alpha_index is the table
+    slot: 0..2 two-sided, 3..5 one-sided."""
     if quantiles is None:
         lib().oracle_set_t_quantiles(int(alpha_index), None, 0)
     else:
@@ -141,16 +172,19 @@ def film_update(pixels, splat_scale=1.0, scale=1.0):
     return out
 
 
-def prepass(n, mean, m2, m3, alpha_index=0):
+def prepass(n, mean, m2, m3, alpha_index=0, spec=None):
     h, w = n.shape
     c = mean.shape[2] if mean.ndim == 3 else 1
     mc, disc = np.empty_like(mean), np.empty_like(mean)
-    lib().oracle_prepass(w, h, c, alpha_index, _i(n), _f(mean), _f(m2), _f(m3), _f(mc), _f(disc))
+    spec = spec if spec is not None else FilterSpec()
+    lib().oracle_prepass_spec(w, h, c, alpha_index, C.byref(spec), _i(n), _f(mean), _f(m2), _f(m3), _f(mc), _f(disc))
     return mc, disc
 
 
-def filter_image(mean_corr, disc, colour, g_buffers, g_dr, ds, radius, roi=None, threads=0):
-    """g_buffers: list of [H, W, Cg] (or [H, W]) float32 arrays; g_dr: list of -0.5/sd^2."""
+def filter_image(mean_corr, disc, colour, g_buffers, g_dr, ds, radius, roi=None, threads=0, spec=None, n=None,
+                 alpha_index=0):
+    """g_buffers: list of [H, W, Cg] (or [H, W]) float32 arrays; g_dr: list of -0.5/sd^2.
+    spec: FilterSpec (default: spec v2); n: the int32 sample counts, needed in Welch mode only."""
     h, w = mean_corr.shape[:2]
     c = mean_corr.shape[2] if mean_corr.ndim == 3 else 1
     gs = [np.ascontiguousarray(g, dtype=np.float32) for g in g_buffers]
@@ -160,6 +194,9 @@ def filter_image(mean_corr, disc, colour, g_buffers, g_dr, ds, radius, roi=None,
     gdr = np.asarray(list(g_dr) + ([] if ng else [0.0]), dtype=np.float32)
     out = np.zeros_like(colour)
     x0, y0, x1, y1 = roi if roi is not None else (0, 0, w, h)
-    lib().oracle_filter(w, h, c, float(ds), int(radius), _f(mean_corr), _f(disc), _f(colour),
-                        ng, gptrs, gch, _f(gdr), _f(out), x0, y0, x1, y1, threads)
+    spec = spec if spec is not None else FilterSpec()
+    assert spec.dof == DOF_PIXEL or n is not None, "Welch mode reads the sample counts"
+    lib().oracle_filter_spec_run(w, h, c, float(ds), int(radius), int(alpha_index), C.byref(spec),
+                                 _i(n) if n is not None else None, _f(mean_corr), _f(disc), _f(colour),
+                                 ng, gptrs, gch, _f(gdr), _f(out), x0, y0, x1, y1, threads)
     return out

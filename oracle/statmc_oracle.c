@@ -15,6 +15,23 @@
 #include <omp.h>
 #endif
 
+/* FP contraction mode of the restated reference arithmetic.
+ *   0 (default): every multiply and add rounds separately -- what g++ emits for the reference (gcc's
+ *      -ffp-contract=fast only acts with -march flags that have FMA; the survey's probe build was plain -O2).
+ *   1: what the reference's OWN recipe emits on an FMA-capable host: scripts/_build.sh:14-19,37-41 builds with
+ *      clang++ -O3 -march=native, and clang's default -ffp-contract=on fuses a multiply with the add or subtract
+ *      that consumes it inside ONE source expression.  In StatTile<Float> (estimator.h:173-205,217-225) that is
+ *      `m2 += d * (d - dN)` -> fma(d, d - dN, m2), `m3 += -3.f * dN * m2 + d * (d2 - dN2)` ->
+ *      m3 + fma(-3.f * dN, m2, d * (d2 - dN2)), `filmM2 += filmD * (filmD - filmDN)` -> fma(...); in
+ *      StatTile<Vec3> the multiply and the add sit in different inlined operator functions (cv::Vec operators,
+ *      estimator.h:127-133), which clang's source-level contraction does not fuse.  XYZToRGB (spectrum.h:66-70)
+ *      and `rgb += splatScale * splatRGB` in Film::UpdateImage (film.cpp:194,211-213) fuse as well.
+ *      Checked against AMD clang 22 (-O3 -march=x86-64-v3) on a restatement of those expressions: the emitted
+ *      vfmadd instructions are exactly the ones written below. */
+static int g_fp_contract = 0;
+void oracle_set_fp_contract(int on) { g_fp_contract = on ? 1 : 0; }
+int oracle_get_fp_contract(void) { return g_fp_contract; }
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
@@ -33,37 +50,50 @@ static inline void add_m1(uint64_t n, float *mean, float s) {
     *mean += dN;
 }
 /* estimator.h:173-186 */
-static inline void add_m2(uint64_t n, float *mean, float *m2, float s) {
+static inline void add_m2(uint64_t n, float *mean, float *m2, float s, int contract) {
     const float d = s - *mean;
     const float dN = d / (float)n;
     *mean += dN;
-    *m2 += d * (d - dN);
+    if (contract)
+        *m2 = fmaf(d, d - dN, *m2);
+    else
+        *m2 += d * (d - dN);
 }
 /* estimator.h:187-205; note m3 uses the already updated m2 */
-static inline void add_m3(uint64_t n, float *mean, float *m2, float *m3, float s) {
+static inline void add_m3(uint64_t n, float *mean, float *m2, float *m3, float s, int contract) {
     const float d = s - *mean;
     const float d2 = d * d;
     const float dN = d / (float)n;
     const float dN2 = dN * dN;
     *mean += dN;
-    *m2 += d * (d - dN);
-    *m3 += -3.f * dN * *m2 + d * (d2 - dN2);
+    if (contract) {
+        *m2 = fmaf(d, d - dN, *m2);
+        *m3 += fmaf(-3.f * dN, *m2, d * (d2 - dN2));
+    } else {
+        *m2 += d * (d - dN);
+        *m3 += -3.f * dN * *m2 + d * (d2 - dN2);
+    }
 }
 
+/* `scalar`: the pixel belongs to a StatTile<Float> (the only tiles whose updates clang contracts) */
 static inline void add_channel(uint64_t n, float *mean, float *m2, float *m3, float *fmean,
-                               float *fm2, float s, int transform, int max_moment) {
+                               float *fm2, float s, int transform, int max_moment, int scalar) {
+    const int contract = g_fp_contract && scalar;
     const float v = transform ? oracle_box_cox(s, .5f) : s; /* estimator.h:215 */
     if (max_moment >= 3)
-        add_m3(n, mean, m2, m3, v);
+        add_m3(n, mean, m2, m3, v, contract);
     else if (max_moment == 2)
-        add_m2(n, mean, m2, v);
+        add_m2(n, mean, m2, v, contract);
     else
         add_m1(n, mean, v);
     if (transform) { /* estimator.h:217-225, n is the already incremented count */
         const float fd = s - *fmean;
         const float fdN = fd / (float)n;
         *fmean += fdN;
-        *fm2 += fd * (fd - fdN);
+        if (contract)
+            *fm2 = fmaf(fd, fd - fdN, *fm2);
+        else
+            *fm2 += fd * (fd - fdN);
     } else { /* estimator.h:209-210 */
         *fmean = *mean;
         *fm2 = *m2;
@@ -75,13 +105,13 @@ void oracle_add_sample(void *px, int channels, const float *sample, int transfor
         oracle_tile_pixel_f1 *p = (oracle_tile_pixel_f1 *)px;
         p->n++;
         add_channel(p->n, &p->mean, &p->m2, &p->m3, &p->film_mean, &p->film_m2, sample[0],
-                    transform, max_moment);
+                    transform, max_moment, 1);
     } else {
         oracle_tile_pixel_f3 *p = (oracle_tile_pixel_f3 *)px;
         p->n++;
         for (int c = 0; c < 3; c++)
             add_channel(p->n, &p->mean[c], &p->m2[c], &p->m3[c], &p->film_mean[c], &p->film_m2[c],
-                        sample[c], transform, max_moment);
+                        sample[c], transform, max_moment, 0);
     }
 }
 
@@ -186,6 +216,12 @@ void oracle_mean_vars(int width, int height, int channels, const int32_t *n,
 
 /* spectrum.h:66-70 */
 static inline void xyz_to_rgb(const float xyz[3], float rgb[3]) {
+    if (g_fp_contract) { /* a*x - b*y - c*z as clang fuses it: fma(z, -c, fma(x, a, -b * y)) */
+        rgb[0] = fmaf(xyz[2], -0.498535f, fmaf(xyz[0], 3.240479f, -1.537150f * xyz[1]));
+        rgb[1] = fmaf(xyz[2], 0.041556f, fmaf(xyz[0], -0.969256f, 1.875991f * xyz[1]));
+        rgb[2] = fmaf(xyz[2], 1.057311f, fmaf(xyz[0], 0.055648f, -0.204043f * xyz[1]));
+        return;
+    }
     rgb[0] = 3.240479f * xyz[0] - 1.537150f * xyz[1] - 0.498535f * xyz[2];
     rgb[1] = -0.969256f * xyz[0] + 1.875991f * xyz[1] + 0.041556f * xyz[2];
     rgb[2] = 0.055648f * xyz[0] - 0.204043f * xyz[1] + 1.057311f * xyz[2];
@@ -204,40 +240,48 @@ void oracle_film_update(const oracle_film_pixel *pixels, size_t n_pixels, float 
         float splat_rgb[3];
         xyz_to_rgb(p->splat_xyz, splat_rgb);
         for (int c = 0; c < 3; c++) {
-            o[c] += splat_scale * splat_rgb[c];
+            o[c] = g_fp_contract ? fmaf(splat_scale, splat_rgb[c], o[c]) : o[c] + splat_scale * splat_rgb[c];
             o[c] *= scale;
         }
     }
 }
 
-/* ---------------------------- filter spec v1 ------------------------------------------- */
+/* ---------------------------- filter spec v2 -------------------------------------------
+ * The reference's arithmetic for this half is not in the tree (header comment of statmc_oracle.h).  What the
+ * tree leaves open (SURVEY.md App. B "Unknown") is carried by oracle_filter_spec; the all-zero spec is this
+ * build's default. */
+
+void oracle_default_spec(oracle_filter_spec *s) { memset(s, 0, sizeof(*s)); }
 
 static float tq_override[ORACLE_TQ_N_TABLES][ORACLE_TQ_N_DOF];
 static int tq_overridden[ORACLE_TQ_N_TABLES];
 
-void oracle_set_t_quantiles(int alpha_index, const float *q, int n_dof) {
+void oracle_set_t_quantiles(int table, const float *q, int n_dof) {
     if (!q) {  /* back to the built-in table */
-        tq_overridden[alpha_index] = 0;
+        tq_overridden[table] = 0;
         return;
     }
-    for (int i = 0; i < ORACLE_TQ_N_DOF; i++) tq_override[alpha_index][i] = q[i < n_dof ? i : n_dof - 1];
-    tq_overridden[alpha_index] = 1;
+    for (int i = 0; i < ORACLE_TQ_N_DOF; i++) tq_override[table][i] = q[i < n_dof ? i : n_dof - 1];
+    tq_overridden[table] = 1;
 }
 
-float oracle_t_quantile(int alpha_index, int dof) {
+/* table = alpha_index (0..2) + 3 * sides */
+float oracle_t_quantile(int table, int dof) {
     if (dof < 1) return INFINITY;
     if (dof > ORACLE_TQ_N_DOF) dof = ORACLE_TQ_N_DOF;
-    return tq_overridden[alpha_index] ? tq_override[alpha_index][dof - 1] : oracle_tq_tables[alpha_index][dof - 1];
+    return tq_overridden[table] ? tq_override[table][dof - 1] : oracle_tq_tables[table][dof - 1];
 }
 
-void oracle_prepass(int width, int height, int channels, int alpha_index,
-                    const int32_t *n, const float *mean, const float *m2, const float *m3,
-                    float *mean_corr, float *discriminator) {
+void oracle_prepass_spec(int width, int height, int channels, int alpha_index, const oracle_filter_spec *spec,
+                         const int32_t *n, const float *mean, const float *m2, const float *m3,
+                         float *mean_corr, float *discriminator) {
     const size_t npx = (size_t)width * height;
+    const int table = alpha_index + ORACLE_TQ_N_ALPHAS * (spec->sides ? 1 : 0);
     for (size_t i = 0; i < npx; i++) {
         const int32_t ni = n[i];
         const float nf = (float)ni;
-        const float t = oracle_t_quantile(alpha_index, ni - 1);
+        /* Welch mode keeps the quantile out of the per-pixel term: the pair looks it up at its own dof */
+        const float t = spec->dof == ORACLE_DOF_WELCH ? 1.f : oracle_t_quantile(table, ni - 1);
         for (int c = 0; c < channels; c++) {
             const size_t e = i * channels + c;
             const float mu = mean[e], s2sum = m2[e];
@@ -245,7 +289,10 @@ void oracle_prepass(int width, int height, int channels, int alpha_index,
                 const float var = s2sum / (nf - 1.f);  /* unbiased sample variance s^2 */
                 const float mu3 = m3[e] / nf;          /* third central sample moment */
                 mean_corr[e] = mu + mu3 / (6.f * var * nf); /* Johnson (1978) */
-                discriminator[e] = (t * t) * (var / nf);    /* squared CI half-width */
+                discriminator[e] = (t * t) * (var / nf);    /* squared CI half-width (Welch: var / n) */
+            } else if (ni < 2 && spec->small_n == ORACLE_SMALL_N_EXCLUDE) {
+                mean_corr[e] = NAN;  /* the pixel takes no part in any window */
+                discriminator[e] = NAN;
             } else {
                 mean_corr[e] = mu;
                 discriminator[e] = ni >= 2 ? 0.f : INFINITY;
@@ -254,10 +301,69 @@ void oracle_prepass(int width, int height, int channels, int alpha_index,
     }
 }
 
-void oracle_filter(int width, int height, int channels, float ds, int radius,
-                   const float *mean_corr, const float *disc, const float *colour,
-                   int n_g, const float *const *g_buffers, const int *g_channels, const float *g_dr,
-                   float *out, int rx0, int ry0, int rx1, int ry1, int threads) {
+void oracle_prepass(int width, int height, int channels, int alpha_index,
+                    const int32_t *n, const float *mean, const float *m2, const float *m3,
+                    float *mean_corr, float *discriminator) {
+    oracle_filter_spec spec;
+    oracle_default_spec(&spec);
+    oracle_prepass_spec(width, height, channels, alpha_index, &spec, n, mean, m2, m3, mean_corr, discriminator);
+}
+
+/* a pixel takes part in windows (as centre and as tap) when its corrected mean is finite in every channel, its
+ * discriminator is not NaN and its colour is finite (v2: a NaN / inf colour would otherwise spread to every
+ * window that accepts the pixel; the reference never produces one -- statpath.cpp:333-351 blacks such samples) */
+static int pixel_valid(int channels, const float *mc, const float *disc, const float *colour, size_t p) {
+    int v = 1;
+    for (int c = 0; c < channels; c++) {
+        v &= isfinite(mc[p * channels + c]) != 0;
+        v &= !isnan(disc[p * channels + c]);
+        v &= isfinite(colour[p * channels + c]) != 0;
+    }
+    return v;
+}
+
+/* membership of the pair (p, q); both already known to be valid pixels */
+static int pair_member(const oracle_filter_spec *spec, int channels, int table, const float *mc, const float *disc,
+                       const int32_t *n, size_t p, size_t q) {
+    int all = 1;
+    float lhs_sum = 0.f, rhs_sum = 0.f;
+    for (int c = 0; c < channels; c++) {
+        const float d = mc[p * channels + c] - mc[q * channels + c];
+        const float Dp = disc[p * channels + c], Dq = disc[q * channels + c];
+        float lhs, rhs;
+        if (spec->dof == ORACLE_DOF_WELCH) {
+            /* disc holds v = s^2 / n; the pair's quantile is looked up at the Welch-Satterthwaite dof */
+            const float s = Dp + Dq;
+            float Dsum = s;  /* 0 (both variances zero) and +inf (a pixel with fewer than two samples) stay */
+            if (s > 0.f && isfinite(s)) {
+                const float nu = (s * s) / (Dp * Dp / ((float)n[p] - 1.f) + Dq * Dq / ((float)n[q] - 1.f));
+                int dof = nu >= 1.f ? (nu < (float)ORACLE_TQ_N_DOF ? (int)nu : ORACLE_TQ_N_DOF) : 1;
+                const float t = oracle_t_quantile(table, dof);
+                Dsum = (t * t) * s;
+            }
+            lhs = fmaf(d, d, -Dsum);
+            rhs = 0.f;
+        } else if (spec->gate == ORACLE_GATE_ASYMMETRIC) {
+            lhs = fmaf(d, d, -Dq); /* spec v1.x */
+            rhs = Dp;
+        } else {
+            lhs = fmaf(d, d, -(Dp + Dq)); /* d^2 <= D_p + D_q, the same bits for (p, q) and (q, p) */
+            rhs = 0.f;
+        }
+        all &= (lhs <= rhs);
+        lhs_sum = c == 0 ? lhs : lhs_sum + lhs;
+        rhs_sum = c == 0 ? rhs : rhs_sum + rhs;
+    }
+    return spec->channel_rule == ORACLE_CHANNELS_JOINT ? (lhs_sum <= rhs_sum) : all;
+}
+
+void oracle_filter_spec_run(int width, int height, int channels, float ds, int radius, int alpha_index,
+                            const oracle_filter_spec *spec, const int32_t *n,
+                            const float *mean_corr, const float *disc, const float *colour,
+                            int n_g, const float *const *g_buffers, const int *g_channels, const float *g_dr,
+                            float *out, int rx0, int ry0, int rx1, int ry1, int threads) {
+    const int table = alpha_index + ORACLE_TQ_N_ALPHAS * (spec->sides ? 1 : 0);
+    const int clamp = spec->border == ORACLE_BORDER_CLAMP;
 #ifdef _OPENMP
     if (threads <= 0) threads = omp_get_max_threads();
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
@@ -266,27 +372,22 @@ void oracle_filter(int width, int height, int channels, float ds, int radius,
         for (int x = rx0; x < rx1; x++) {
             const size_t p = (size_t)y * width + x;
             float sum_w = 0.f, acc[3] = {0.f, 0.f, 0.f};
-            /* a pixel whose corrected mean is not finite takes no part: it filters nothing (its output
-             * is its own colour) and joins no other window.  (NaN does so by itself; +-inf would pass
-             * `inf <= inf` against a pixel with fewer than two samples.) */
-            int p_valid = 1;
-            for (int c = 0; c < channels; c++) p_valid &= isfinite(mean_corr[p * channels + c]) != 0;
+            const int p_valid = pixel_valid(channels, mean_corr, disc, colour, p);
             for (int dy = -radius; p_valid && dy <= radius; dy++) {
-                const int qy = y + dy;
-                if (qy < 0 || qy >= height) continue;
+                int qy = y + dy;
+                if (qy < 0 || qy >= height) {
+                    if (!clamp) continue;
+                    qy = qy < 0 ? 0 : height - 1;
+                }
                 for (int dx = -radius; dx <= radius; dx++) {
-                    const int qx = x + dx;
-                    if (qx < 0 || qx >= width) continue;
-                    const size_t q = (size_t)qy * width + qx;
-                    /* membership: every channel must pass fma(d,d,-D_q) <= D_p */
-                    int member = 1;
-                    for (int c = 0; c < channels; c++) member &= isfinite(mean_corr[q * channels + c]) != 0;
-                    for (int c = 0; c < channels; c++) {
-                        const float d = mean_corr[p * channels + c] - mean_corr[q * channels + c];
-                        const float lhs = fmaf(d, d, -disc[q * channels + c]);
-                        member &= (lhs <= disc[p * channels + c]);
+                    int qx = x + dx;
+                    if (qx < 0 || qx >= width) {
+                        if (!clamp) continue;
+                        qx = qx < 0 ? 0 : width - 1;
                     }
-                    if (!member) continue;
+                    const size_t q = (size_t)qy * width + qx;
+                    if (!pixel_valid(channels, mean_corr, disc, colour, q)) continue;
+                    if (!pair_member(spec, channels, table, mean_corr, disc, n, p, q)) continue;
                     float e = ds * (float)(dx * dx + dy * dy);
                     for (int g = 0; g < n_g; g++) {
                         const int gc = g_channels[g];
@@ -309,4 +410,14 @@ void oracle_filter(int width, int height, int channels, float ds, int radius,
                 out[p * channels + c] = sum_w > 0.f ? acc[c] / sum_w : colour[p * channels + c];
         }
     }
+}
+
+void oracle_filter(int width, int height, int channels, float ds, int radius,
+                   const float *mean_corr, const float *disc, const float *colour,
+                   int n_g, const float *const *g_buffers, const int *g_channels, const float *g_dr,
+                   float *out, int rx0, int ry0, int rx1, int ry1, int threads) {
+    oracle_filter_spec spec;
+    oracle_default_spec(&spec);
+    oracle_filter_spec_run(width, height, channels, ds, radius, 0, &spec, NULL, mean_corr, disc, colour, n_g, g_buffers,
+                           g_channels, g_dr, out, rx0, ry0, rx1, ry1, threads);
 }

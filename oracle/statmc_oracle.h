@@ -15,7 +15,8 @@
  *     cg-tuwien/StatMC-opencv_contrib (modules/cudaimgproc/src/cuda/stat_denoiser.cu, pinned
  *     version unknown, README says OpenCV 4.8.1).  Only its call sites are in the tree
  *     (estimator.cpp:437-487).  This file restates the published algorithm as the build's own
- *     frozen spec (DESIGN.md "Filter spec v1"): PARITY UNPINNED.
+ *     spec (DESIGN.md "Filter spec v2"; every choice the tree leaves open is an option of
+ *     oracle_filter_spec): PARITY UNPINNED.
  */
 #ifndef STATMC_ORACLE_H
 #define STATMC_ORACLE_H
@@ -88,18 +89,47 @@ typedef struct {
 } oracle_film_pixel;
 void oracle_film_update(const oracle_film_pixel *pixels, size_t n_pixels, float splat_scale, float scale, float *rgb);
 
-/* ---- filter spec v1 (self-specified; see header comment) -------------------------------- */
+/* FP contraction of the restated reference arithmetic: 0 (default) = every operation rounds on its own (a g++
+ * build of the reference); 1 = the fused multiply-adds clang -O3 -march=native (the reference's own recipe,
+ * scripts/_build.sh:14-19,37-41; -ffp-contract=on is clang's default) emits in StatTile<Float> and
+ * Film::UpdateImage.  See statmc_oracle.c. */
+void oracle_set_fp_contract(int on);
+int oracle_get_fp_contract(void);
 
-/* tq(dof) = two-sided Student-t quantile, table index alpha_index in {0: 0.005, 1: 0.002,
- * 2: 0.05}; dof < 1 -> +inf; dof clamped to the last table entry. */
-float oracle_t_quantile(int alpha_index, int dof);
-/* user-supplied quantiles for dof 1..n_dof in slot alpha_index (NULL restores the built-in table) */
-void oracle_set_t_quantiles(int alpha_index, const float *quantiles, int n_dof);
+/* ---- filter spec v2 (self-specified; see header comment) --------------------------------
+ * Everything SURVEY.md App. B lists as unknown about cv::cuda::stat_denoiser::filter<T> is a field here, mirrored
+ * by statmc_filter_spec of the C ABI (include/statmc.h).  All-zero = this build's default. */
+enum { ORACLE_GATE_SYMMETRIC = 0, ORACLE_GATE_ASYMMETRIC = 1 };
+enum { ORACLE_CHANNELS_AND = 0, ORACLE_CHANNELS_JOINT = 1 };
+enum { ORACLE_SIDES_TWO = 0, ORACLE_SIDES_ONE = 1 };
+enum { ORACLE_DOF_PIXEL = 0, ORACLE_DOF_WELCH = 1 };
+enum { ORACLE_BORDER_CLIP = 0, ORACLE_BORDER_CLAMP = 1 };
+enum { ORACLE_SMALL_N_ACCEPT = 0, ORACLE_SMALL_N_EXCLUDE = 1 };
+typedef struct {
+    int32_t gate;         /* SYMMETRIC: fma(d, d, -(D_p + D_q)) <= 0;  ASYMMETRIC (spec v1): fma(d, d, -D_q) <= D_p */
+    int32_t channel_rule; /* AND: every channel passes;  JOINT: sum_c lhs_c <= sum_c rhs_c */
+    int32_t sides;        /* TWO: t_{1-alpha/2};  ONE: t_{1-alpha} */
+    int32_t dof;          /* PIXEL: D = t(n-1)^2 s^2/n per pixel;  WELCH: the discriminator image holds s^2/n and the
+                             pair takes t at floor(Welch-Satterthwaite dof); the gate form is then symmetric */
+    int32_t border;       /* CLIP: taps outside the image are skipped;  CLAMP: their coordinates are clamped */
+    int32_t small_n;      /* ACCEPT: n < 2 -> D = +inf (passes every test);  EXCLUDE: the pixel takes no part */
+} oracle_filter_spec;
+void oracle_default_spec(oracle_filter_spec *spec);
+
+/* tq(dof) = Student-t quantile of table `table` = alpha_index + 3 * sides (alpha_index in {0: 0.005, 1: 0.002,
+ * 2: 0.05}); dof < 1 -> +inf; dof clamped to the last table entry. */
+float oracle_t_quantile(int table, int dof);
+/* user-supplied quantiles for dof 1..n_dof in table slot `table` (NULL restores the built-in table) */
+void oracle_set_t_quantiles(int table, const float *quantiles, int n_dof);
 
 /* Pre-pass: (n, mean, m2, m3) -> Johnson-corrected mean and discriminator, per channel. */
 void oracle_prepass(int width, int height, int channels, int alpha_index,
                     const int32_t *n, const float *mean, const float *m2, const float *m3,
                     float *mean_corr, float *discriminator);
+
+void oracle_prepass_spec(int width, int height, int channels, int alpha_index, const oracle_filter_spec *spec,
+                         const int32_t *n, const float *mean, const float *m2, const float *m3,
+                         float *mean_corr, float *discriminator);
 
 /* Window filter of one buffer.
  *   channels          : 1 (filter<float>) or 3 (filter<float3>)
@@ -114,6 +144,14 @@ void oracle_filter(int width, int height, int channels, float ds, int radius,
                    const float *mean_corr, const float *disc, const float *colour,
                    int n_g, const float *const *g_buffers, const int *g_channels, const float *g_dr,
                    float *out, int rx0, int ry0, int rx1, int ry1, int threads);
+
+/* The same under a non-default spec.  n (the sample counts) is read in Welch mode only and may be NULL otherwise;
+ * alpha_index selects the quantile table of the Welch lookup. */
+void oracle_filter_spec_run(int width, int height, int channels, float ds, int radius, int alpha_index,
+                            const oracle_filter_spec *spec, const int32_t *n,
+                            const float *mean_corr, const float *disc, const float *colour,
+                            int n_g, const float *const *g_buffers, const int *g_channels, const float *g_dr,
+                            float *out, int rx0, int ry0, int rx1, int ry1, int threads);
 
 int oracle_num_threads(void);
 

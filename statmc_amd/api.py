@@ -37,7 +37,20 @@ class FilterArgs(C.Structure):
         ("stream", C.c_void_p),
         ("roi_x0", C.c_int32), ("roi_y0", C.c_int32), ("roi_x1", C.c_int32), ("roi_y1", C.c_int32),
         ("packed_inputs", Image),
+        ("film_x0", C.c_int32), ("film_y0", C.c_int32),
     ]
+
+
+class FilterSpec(C.Structure):
+    """statmc_filter_spec: what the reference tree leaves open about filter<T>.  All-zero = default."""
+    _fields_ = [("gate", C.c_int32), ("channel_rule", C.c_int32), ("sides", C.c_int32), ("dof", C.c_int32),
+                ("border", C.c_int32), ("small_n", C.c_int32)]
+
+    def __init__(self, gate=0, channel_rule=0, sides=0, dof=0, border=0, small_n=0):
+        super().__init__(gate, channel_rule, sides, dof, border, small_n)
+
+    def as_tuple(self):
+        return (self.gate, self.channel_rule, self.sides, self.dof, self.border, self.small_n)
 
 
 class StatType(C.Structure):
@@ -51,6 +64,7 @@ class StatType(C.Structure):
 
 EXPORTS = [
     "statmc_last_error", "statmc_setup", "statmc_set_device", "statmc_set_significance", "statmc_get_significance", "statmc_set_t_quantiles",
+    "statmc_set_filter_spec", "statmc_get_filter_spec",
     "statmc_malloc", "statmc_free", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_download",
     "statmc_stream_create", "statmc_stream_destroy", "statmc_synchronize",
     "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs", "statmc_prepass_pack",
@@ -80,6 +94,8 @@ def load():
     lib.statmc_setup.argtypes = [C.c_int]
     lib.statmc_set_significance.argtypes = [C.c_int]
     lib.statmc_set_t_quantiles.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_int]
+    lib.statmc_set_filter_spec.argtypes = [C.POINTER(FilterSpec)]
+    lib.statmc_get_filter_spec.argtypes = [C.POINTER(FilterSpec)]
     lib.statmc_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     lib.statmc_free.argtypes = [C.c_void_p]
     lib.statmc_malloc_host.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
@@ -109,6 +125,7 @@ def load():
     lib.statmc_film_update.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     lib.statmc_debug_force_filter_variant.argtypes = [C.c_int]
     lib.statmc_debug_force_filter_parts.argtypes = [C.c_int]
+    lib.statmc_debug_last_filter_parts.restype = C.c_int
     lib.statmc_debug_accumulate_resident_blocks.argtypes = [C.c_int]
     _lib = lib
     return lib
@@ -127,6 +144,18 @@ def setup(device=0):
     if device not in _setup_done:
         check(load().statmc_setup(int(device)))
         _setup_done.add(device)
+
+
+def set_filter_spec(spec=None, **fields):
+    """Filter spec of the current device: a FilterSpec, or its fields by keyword; no argument = default."""
+    spec = spec if spec is not None else FilterSpec(**fields)
+    check(load().statmc_set_filter_spec(C.byref(spec)))
+
+
+def get_filter_spec():
+    spec = FilterSpec()
+    check(load().statmc_get_filter_spec(C.byref(spec)))
+    return spec
 
 
 def last_filter_variant():
@@ -176,7 +205,7 @@ def _img_array(tensors):
 
 def make_filter_args(n, mean, m2, m3, film, mean_corr, disc, film_filtered, g_buffers, g_sds=None,
                      g_dr=None, filter_sd=10.0, radius=20, denoise_film=False, film_buffer=None,
-                     film_filtered_buffer=None, roi=None, stream=None, keep=None, packed=None):
+                     film_filtered_buffer=None, roi=None, stream=None, keep=None, packed=None, film_origin=None):
     """Build a statmc_filter_args from lists of per-buffer device tensors (reference argument
     order, estimator.cpp:437-459).  Returns (args, keepalive).  packed: optional [H, W, 15]
     block + halo tensor the window filter reads instead of the separate images."""
@@ -220,6 +249,8 @@ def make_filter_args(n, mean, m2, m3, film, mean_corr, disc, film_filtered, g_bu
     a.stream = stream if stream is not None else current_stream_handle()
     if roi is not None:
         a.roi_x0, a.roi_y0, a.roi_x1, a.roi_y1 = roi
+    if film_origin is not None:   # film coordinates of local pixel (0, 0): block + halo images of the multi-GPU path
+        a.film_x0, a.film_y0 = film_origin
     ka.append((n, mean, m2, m3, film, mean_corr, disc, film_filtered, g_buffers, film_buffer,
                film_filtered_buffer, packed))
     return a, ka

@@ -11,19 +11,38 @@
 
 #include "statmc_device.h"
 
-namespace statmc {
-hipError_t upload_t_tables();
-hipError_t upload_t_table(int alpha_index, const float *host_4096);
-}
+#include <atomic>
+
+#include "t_quantiles.h"
 
 namespace {
 
 thread_local char g_err[512] = "";
 thread_local const char *g_variant = "none";
-int g_alpha_index = 0;
-int g_accumulate_resident_blocks = 0;
-bool g_ready = false;
+thread_local int g_last_parts = 0;
+std::atomic<int> g_accumulate_resident_blocks{0};
 std::mutex g_mu;
+
+// Everything the library remembers is kept per device (one Estimator per device in a process that drives
+// several GPUs; cf. one cv::cuda::Stream per Estimator, src/statistics/estimator.h:326): readiness (the
+// quantile tables are a per-device __device__ symbol), significance level, filter spec, CU count.
+struct DeviceState {
+    bool ready = false;
+    int alpha_index = 0;
+    statmc_filter_spec spec = {0, 0, 0, 0, 0, 0};
+    int cus = 0;
+};
+std::unordered_map<int, DeviceState> g_dev;  // guarded by g_mu
+
+// snapshot of the current device's state; ready == false when statmc_setup has not run for it
+DeviceState current_state(int *dev_out = nullptr) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return DeviceState();
+    if (dev_out) *dev_out = dev;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_dev.find(dev);
+    return it == g_dev.end() ? DeviceState() : it->second;
+}
 
 int fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -39,9 +58,11 @@ int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(STATMC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-#define NEED_READY()                                                                           \
-    do {                                                                                       \
-        if (!g_ready) return fail(STATMC_ERR_NO_DEVICE, "statmc_setup() has not been called"); \
+#define NEED_READY()                                                                                      \
+    const DeviceState dstate = current_state();                                                           \
+    do {                                                                                                  \
+        if (!dstate.ready)                                                                                \
+            return fail(STATMC_ERR_NO_DEVICE, "statmc_setup() has not been called for the current device"); \
     } while (0)
 
 inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
@@ -98,7 +119,6 @@ struct WsHash {
     size_t operator()(const WsKey &k) const { return std::hash<void *>()(k.stream) ^ ((size_t)k.dev * 0x9e3779b97f4a7c15ull); }
 };
 std::unordered_map<WsKey, Workspace, WsHash> g_ws;
-std::unordered_map<int, int> g_cus;
 
 int partial_workspace(size_t bytes, void *stream, float **out) {
     int dev = 0;
@@ -119,17 +139,19 @@ int partial_workspace(size_t bytes, void *stream, float **out) {
     return STATMC_OK;
 }
 
-int device_cus() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_cus.find(dev);
-    if (it != g_cus.end()) return it->second;
-    int n = 256;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-    g_cus[dev] = n;
-    return n;
+// kernel-side view of the current device's filter spec
+void apply_spec(const DeviceState &d, statmc::FilterArgs &k, const statmc_filter_args *a) {
+    k.gate = d.spec.gate;
+    k.channel_rule = d.spec.channel_rule;
+    k.dof = d.spec.dof;
+    k.border = d.spec.border;
+    k.n = nullptr;
+    k.tq = nullptr;
+    if (d.spec.dof == STATMC_DOF_WELCH)
+        k.tq = statmc::t_table_device_ptr(d.alpha_index + STATMC_TQ_N_ALPHAS * (d.spec.sides ? 1 : 0));
+    (void)a;
 }
+int prepass_table(const DeviceState &d) { return d.alpha_index + STATMC_TQ_N_ALPHAS * (d.spec.sides ? 1 : 0); }
 
 int check_image(const statmc_image &im, int w, int h, int channels, const char *what, int idx) {
     if (!im.data) return fail(STATMC_ERR_INVALID, "%s[%d]: null device pointer", what, idx);
@@ -176,31 +198,71 @@ int statmc_setup(int device) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(STATMC_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
                     prop.gcnArchName);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_dev[device].ready) return STATMC_OK;  // idempotent: settings and loaded tables of the device stay
+    }
     HIP_TRY(statmc::upload_t_tables());
-    g_ready = true;
+    int cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 256;
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceState &d = g_dev[device];
+    d.ready = true;
+    d.cus = cus;
     return STATMC_OK;
 }
 
 int statmc_set_device(int device) {
-    NEED_READY();
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_dev.find(device);
+        if (it == g_dev.end() || !it->second.ready)
+            return fail(STATMC_ERR_NO_DEVICE, "statmc_setup(%d) has not been called", device);
+    }
     HIP_TRY(hipSetDevice(device));
     return STATMC_OK;
 }
 
 int statmc_set_significance(int alpha_index) {
     if (alpha_index < 0 || alpha_index > 2) return fail(STATMC_ERR_INVALID, "alpha_index must be 0, 1 or 2");
-    g_alpha_index = alpha_index;
+    int dev = 0;
+    NEED_READY();
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_dev[dev].alpha_index = alpha_index;
     return STATMC_OK;
 }
-int statmc_get_significance(void) { return g_alpha_index; }
+int statmc_get_significance(void) { return current_state().alpha_index; }
 
-int statmc_set_t_quantiles(int alpha_index, const float *quantiles, int n_dof) {
+int statmc_set_filter_spec(const statmc_filter_spec *spec) {
+    if (!spec) return fail(STATMC_ERR_INVALID, "null spec");
+    const int32_t v[6] = {spec->gate, spec->channel_rule, spec->sides, spec->dof, spec->border, spec->small_n};
+    for (int i = 0; i < 6; i++)
+        if (v[i] != 0 && v[i] != 1) return fail(STATMC_ERR_INVALID, "filter spec field %d: %d is not 0 or 1", i, v[i]);
+    int dev = 0;
     NEED_READY();
-    if (alpha_index < 0 || alpha_index > 2) return fail(STATMC_ERR_INVALID, "alpha_index must be 0, 1 or 2");
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_dev[dev].spec = *spec;
+    return STATMC_OK;
+}
+int statmc_get_filter_spec(statmc_filter_spec *spec) {
+    if (!spec) return fail(STATMC_ERR_INVALID, "null spec");
+    *spec = current_state().spec;
+    return STATMC_OK;
+}
+
+int statmc_set_t_quantiles(int table, const float *quantiles, int n_dof) {
+    NEED_READY();
+    if (table < 0 || table >= STATMC_TQ_N_TABLES) return fail(STATMC_ERR_INVALID, "table must be 0..%d", STATMC_TQ_N_TABLES - 1);
+    if (!quantiles && n_dof == 0) {  // back to the built-in table
+        HIP_TRY(statmc::upload_t_table(table, statmc_tq_tables[table]));
+        return STATMC_OK;
+    }
     if (!quantiles || n_dof < 1 || n_dof > 4096) return fail(STATMC_ERR_INVALID, "need 1..4096 quantiles");
     std::vector<float> t(4096);
     for (int i = 0; i < 4096; i++) t[i] = quantiles[i < n_dof ? i : n_dof - 1];
-    HIP_TRY(statmc::upload_t_table(alpha_index, t.data()));
+    HIP_TRY(statmc::upload_t_table(table, t.data()));
     return STATMC_OK;
 }
 
@@ -272,7 +334,9 @@ int statmc_prepass(const statmc_filter_args *a, int channels) {
         k.disc = static_cast<float *>(a->discriminator[b].data);
         k.n_elems = (long long)W * H * channels;
         k.channels = channels;
-        k.alpha_index = g_alpha_index;
+        k.table = prepass_table(dstate);
+        k.welch = dstate.spec.dof == STATMC_DOF_WELCH;
+        k.small_n_exclude = dstate.spec.small_n == STATMC_SMALL_N_EXCLUDE;
         HIP_TRY(statmc::launch_prepass(k, S(a->stream)));
     }
     return STATMC_OK;
@@ -303,6 +367,11 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
     k.radius = a->filter_radius;
     k.ds = a->filter_ds_factor;
     k.n_g = (int)a->n_g_buffers;
+    apply_spec(dstate, k, a);
+    if (k.dof == STATMC_DOF_WELCH) {
+        if (!k.tq) return fail(STATMC_ERR_HIP, "quantile table of the device not found");
+        if (packed_in || !a->n) return fail(STATMC_ERR_INVALID, "Welch dof: the window filter reads the sample counts (args->n)");
+    }
     const bool packed = a->packed_inputs.data != nullptr;
     if (packed) {
         // block + halo path: everything the window filter reads comes from one 15-channel image
@@ -317,11 +386,13 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
             k.g[g].dr = a->g_dr_factors[g];
         }
         if (!statmc::fast_path_eligible(k, 3))
-            return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs: radius must be 1..20 and DR factors finite and <= 0");
+            return fail(STATMC_ERR_UNSUPPORTED,
+                        "packed_inputs: radius must be 1..20, DR factors finite and <= 0, and the filter spec the default "
+                        "one (gate, channel rule, dof, border)");
         if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
         k.gscale0 = sqrtf(-k.g[0].dr * 1.44269504088896340736f);
         k.gscale1 = sqrtf(-k.g[1].dr * 1.44269504088896340736f);
-        k.n_parts = statmc::lds_filter_parts(k, device_cus());
+        k.n_parts = statmc::lds_filter_parts(k, dstate.cus);
         if (k.n_parts > 1) {
             if (int rc = partial_workspace((size_t)k.n_parts * W * H * 4 * sizeof(float), a->stream, &k.partial)) return rc;
         }
@@ -330,6 +401,7 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
         const char *variant = "none";
         HIP_TRY(statmc::launch_lds_packed(k, S(a->stream), &variant));
         g_variant = variant;
+        g_last_parts = k.n_parts;
         return STATMC_OK;
     }
     for (int g = 0; g < k.n_g; g++) {
@@ -343,7 +415,7 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
     if (statmc::fast_path_eligible(k, channels)) {
         if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
         statmc::set_feature_layout(k);
-        k.n_parts = statmc::lds_filter_parts(k, device_cus());
+        k.n_parts = statmc::lds_filter_parts(k, dstate.cus);
     } else {
         k.n_parts = 1;
     }
@@ -374,6 +446,7 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
             }
             HIP_TRY(statmc::launch_window_filter(k, channels, S(a->stream), &variant));
             g_variant = variant;
+            g_last_parts = k.n_parts;
             continue;
         }
         const int b = b0;
@@ -391,9 +464,14 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
         k.disc = static_cast<const float *>(a->discriminator[b].data);
         k.colour = static_cast<const float *>(colour.data);
         k.out = static_cast<float *>(out.data);
+        if (k.dof == STATMC_DOF_WELCH) {
+            CHECK_IMG(a->n[b], 1, "n", b);
+            k.n = static_cast<const int32_t *>(a->n[b].data);
+        }
         if (k.out == k.colour) return fail(STATMC_ERR_INVALID, "filter cannot run in place (buffer %d)", b);
         HIP_TRY(statmc::launch_window_filter(k, channels, S(a->stream), &variant));
         g_variant = variant;
+        g_last_parts = k.n_parts;
     }
     return STATMC_OK;
 }
@@ -457,7 +535,8 @@ int statmc_prepass_pack(const statmc_filter_args *a, const statmc_image *packed,
                               static_cast<const float *>(a->m2[0].data), static_cast<const float *>(a->m3[0].data),
                               static_cast<const float *>(colour.data), static_cast<const float *>(a->g_buffers[0].data),
                               static_cast<const float *>(a->g_buffers[1].data), mc, dc, static_cast<float *>(packed->data),
-                              W, H, packed->cols, dst_x0, dst_y0, g_alpha_index};
+                              W, H, packed->cols, dst_x0, dst_y0, prepass_table(dstate),
+                              dstate.spec.dof == STATMC_DOF_WELCH, dstate.spec.small_n == STATMC_SMALL_N_EXCLUDE};
     HIP_TRY(statmc::launch_prepass_pack(k, S(a->stream)));
     return STATMC_OK;
 }
@@ -606,6 +685,7 @@ int statmc_debug_accumulate_resident_blocks(int n) {  // 0 large grid (default),
     g_accumulate_resident_blocks = n < 0 ? 0 : n;
     return STATMC_OK;
 }
+int statmc_debug_last_filter_parts(void) { return g_last_parts; }  // parts per tile of this thread's last window filter
 int statmc_debug_force_filter_parts(int k) {  // 0 auto, k >= 1: window-sweep parts per tile
     statmc::set_filter_parts_override(k);
     return STATMC_OK;

@@ -16,7 +16,9 @@ struct PrepassArgs {
     float *mean_corr, *disc;
     long long n_elems;  // width*height*channels
     int channels;
-    int alpha_index;
+    int table;            // alpha_index + 3 * sides
+    int welch;            // discriminator = s^2 / n (no quantile)
+    int small_n_exclude;  // n < 2 -> NaN mean / discriminator
 };
 
 struct MeanVarsArgs {
@@ -83,6 +85,10 @@ struct GBufferDesc {
 struct FilterArgs {
     const float *mean_corr, *disc, *colour;
     float *out;
+    // filter spec (statmc_filter_spec): the LDS kernels implement the all-default case only
+    int gate, channel_rule, dof, border;
+    const int32_t *n;            // Welch mode: sample counts
+    const float *tq;             // Welch mode: this device's quantile table (4096 entries)
     int width, height;           // local image
     int rx0, ry0, rx1, ry1;      // output ROI
     int rx_split, n_main_items;  // LDS kernel: regular tiles cover [rx0, rx_split), DUAL tiles [rx_split, rx1)
@@ -126,10 +132,13 @@ struct PrepassPackArgs {
     const float *mean, *m2, *m3, *colour, *g0, *g1;
     float *mean_corr, *disc;   // optional
     float *packed;             // [dst_h][dst_w][15]
-    int src_w, src_h, dst_w, dst_x0, dst_y0, alpha_index;
+    int src_w, src_h, dst_w, dst_x0, dst_y0, table, welch, small_n_exclude;
 };
 hipError_t launch_prepass_pack(const PrepassPackArgs &a, hipStream_t s);
 
+hipError_t upload_t_tables();
+hipError_t upload_t_table(int table, const float *host_4096);
+const float *t_table_device_ptr(int table);  // current device's copy of quantile table `table`
 hipError_t launch_prepass(const PrepassArgs &a, hipStream_t s);
 hipError_t launch_mean_vars(const MeanVarsArgs &a, hipStream_t s);
 hipError_t launch_accumulate(const AccumulateArgs &a, hipStream_t s);

@@ -47,19 +47,69 @@
 #include <math.h>
 
 #include <algorithm>
-
+#include <atomic>
+#include <mutex>
+#include <set>
 #include <utility>
 
 #include "statmc_device.h"
 
 namespace statmc {
 
-static int g_variant_override = 0;
+static std::atomic<int> g_variant_override{0};
 void set_filter_variant_override(int v) { g_variant_override = v; }
 
 constexpr float kLog2e = 1.44269504088896340736f;
 
 // ====================================================================== generic kernel
+// Every option of statmc_filter_spec, one lane per pixel, straight from global memory; the statements
+// follow oracle/statmc_oracle.c:oracle_filter_spec_run line by line (same operation order, no contraction).
+template <int C>
+__device__ __forceinline__ bool pixel_valid(const FilterArgs &a, long long p) {
+    bool v = true;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        v = v && __builtin_isfinite(a.mean_corr[p * C + c]);
+        v = v && !__builtin_isnan(a.disc[p * C + c]);
+        v = v && __builtin_isfinite(a.colour[p * C + c]);
+    }
+    return v;
+}
+
+template <int C>
+__device__ __forceinline__ bool pair_member(const FilterArgs &a, const float *pc, const float *pd, long long p, long long q) {
+    bool all = true;
+    float lhs_sum = 0.f, rhs_sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const float d = pc[c] - a.mean_corr[q * C + c];
+        const float Dp = pd[c], Dq = a.disc[q * C + c];
+        float lhs, rhs;
+        if (a.dof == STATMC_DOF_WELCH) {
+            const float s = Dp + Dq;
+            float Dsum = s;
+            if (s > 0.f && __builtin_isfinite(s)) {
+                const float nu = (s * s) / (Dp * Dp / ((float)a.n[p] - 1.f) + Dq * Dq / ((float)a.n[q] - 1.f));
+                const int dof = nu >= 1.f ? (nu < 4096.f ? (int)nu : 4096) : 1;
+                const float t = a.tq[dof - 1];
+                Dsum = (t * t) * s;
+            }
+            lhs = __builtin_fmaf(d, d, -Dsum);
+            rhs = 0.f;
+        } else if (a.gate == STATMC_GATE_ASYMMETRIC) {
+            lhs = __builtin_fmaf(d, d, -Dq);
+            rhs = Dp;
+        } else {
+            lhs = __builtin_fmaf(d, d, -(Dp + Dq));
+            rhs = 0.f;
+        }
+        all = all & (lhs <= rhs);
+        lhs_sum = c == 0 ? lhs : lhs_sum + lhs;
+        rhs_sum = c == 0 ? rhs : rhs_sum + rhs;
+    }
+    return a.channel_rule == STATMC_CHANNELS_JOINT ? (lhs_sum <= rhs_sum) : all;
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void window_filter_generic(FilterArgs a) {
     const int x = a.rx0 + blockIdx.x * 32 + (threadIdx.x & 31);
@@ -75,26 +125,24 @@ __global__ __launch_bounds__(256) void window_filter_generic(FilterArgs a) {
     }
     float sum_w = 0.f;
     const int r = a.radius;
-    // a pixel with a non-finite corrected mean takes no part (spec: DESIGN.md "Filter spec")
-    bool p_valid = true;
-#pragma unroll
-    for (int c = 0; c < C; c++) p_valid = p_valid && __builtin_isfinite(pc[c]);
+    const bool clamp = a.border == STATMC_BORDER_CLAMP;
+    // a pixel whose statistics or colour are not finite takes no part (spec: DESIGN.md "Filter spec")
+    const bool p_valid = pixel_valid<C>(a, p);
     for (int dy = -r; p_valid && dy <= r; dy++) {
-        const int qy = y + dy;
-        if (qy < 0 || qy >= a.height) continue;
+        int qy = y + dy;
+        if (qy < 0 || qy >= a.height) {
+            if (!clamp) continue;
+            qy = qy < 0 ? 0 : a.height - 1;
+        }
         for (int dx = -r; dx <= r; dx++) {
-            const int qx = x + dx;
-            if (qx < 0 || qx >= a.width) continue;
-            const long long q = (long long)qy * a.width + qx;
-            bool member = true;
-#pragma unroll
-            for (int c = 0; c < C; c++) member = member & __builtin_isfinite(a.mean_corr[q * C + c]);
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                const float d = pc[c] - a.mean_corr[q * C + c];
-                member = member & (__builtin_fmaf(d, d, -a.disc[q * C + c]) <= pd[c]);
+            int qx = x + dx;
+            if (qx < 0 || qx >= a.width) {
+                if (!clamp) continue;
+                qx = qx < 0 ? 0 : a.width - 1;
             }
-            if (!member) continue;
+            const long long q = (long long)qy * a.width + qx;
+            if (!pixel_valid<C>(a, q)) continue;
+            if (!pair_member<C>(a, pc, pd, p, q)) continue;
             float e = a.ds * (float)(dx * dx + dy * dy);
             for (int g = 0; g < a.n_g; g++) {
                 const int gc = a.g[g].channels;
@@ -256,25 +304,23 @@ __device__ __forceinline__ void gate_accumulate(LaneState &st, const v2f (&e)[kP
     constexpr bool RGB = K == 0;
     constexpr int NB = RGB ? 3 : K;  // float mode: only the K real buffers of the launch are gated and summed
     v2f u[kPx][3], w[kPx];
-    // membership statistic per channel: t_c = fma(d_c, d_c, -D_q,c)  (the oracle's expression)
+    // membership statistic per channel: t_c = fma(d_c, d_c, -(D_p,c + D_q,c))  (the oracle's expression; nd = -D_q)
 #pragma unroll
     for (int ch = 0; ch < NB; ch++) {
 #pragma unroll
-        for (int k = 0; k < kPx; k++) if (M::on(k)) { const v2f d = st.pmc[k][ch] - mc[ch]; u[k][ch] = __builtin_elementwise_fma(d, d, nd[ch]); }
+        for (int k = 0; k < kPx; k++) if (M::on(k)) {
+            const v2f d = st.pmc[k][ch] - mc[ch];
+            const v2f s = nd[ch] - st.pd[k][ch];
+            u[k][ch] = __builtin_elementwise_fma(d, d, s);
+        }
     }
 #pragma unroll
     for (int k = 0; k < kPx; k++) if (M::on(k)) w[k] = v2f{__builtin_amdgcn_exp2f(e[k].x), __builtin_amdgcn_exp2f(e[k].y)};
     if constexpr (RGB) {
-        // all three channels pass  <=>  max_c (t_c - D_p,c) <= 0: (t - D <= 0) has the truth value of the
-        // oracle's (t <= D) for every finite t; max3 + compare + select stays on the VALU, where 3
+        // all three channels pass  <=>  max_c t_c <= 0; max3 + compare + select stays on the VALU, where 3
         // compares + 2 scalar ANDs send every pair through the scalar unit.  v_max3 drops NaN operands,
-        // so a pixel with a NaN statistic or a non-finite mean is staged with NaN in all three
-        // channels (canonical_mean).
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-#pragma unroll
-            for (int k = 0; k < kPx; k++) if (M::on(k)) u[k][ch] = u[k][ch] - st.pd[k][ch];
-        }
+        // so a pixel that takes no part (NaN statistic, non-finite mean or colour) is staged with NaN in
+        // all three channels of its mean (canonical_mean).
 #pragma unroll
         for (int k = 0; k < kPx; k++) if (M::on(k)) {
             const float m0 = __builtin_fmaxf(__builtin_fmaxf(u[k][0].x, u[k][1].x), u[k][2].x);
@@ -293,8 +339,8 @@ __device__ __forceinline__ void gate_accumulate(LaneState &st, const v2f (&e)[kP
         for (int ch = 0; ch < NB; ch++) {
 #pragma unroll
             for (int k = 0; k < kPx; k++) if (M::on(k)) {
-                const v2f wc = v2f{M::in0(k) && u[k][ch].x <= st.pd[k][ch] ? w[k].x : 0.f,
-                                   M::in1(k) && u[k][ch].y <= st.pd[k][ch] ? w[k].y : 0.f};
+                const v2f wc = v2f{M::in0(k) && u[k][ch].x <= 0.f ? w[k].x : 0.f,
+                                   M::in1(k) && u[k][ch].y <= 0.f ? w[k].y : 0.f};
                 st.sw[k][ch] += wc;
                 st.acc[k][ch] = __builtin_elementwise_fma(wc, col[ch], st.acc[k][ch]);
             }
@@ -392,27 +438,35 @@ __device__ __forceinline__ StagedPixel load_pixel(const FilterArgs &a, int x, in
     return s;
 }
 
-// Staging rule for the corrected mean (it is what switches a tap off in the inner loop: a NaN
-// there fails every comparison).  Outside the image: NaN.  RGB (one buffer, gate = max3 over the
-// channels, which would drop a NaN in a single channel): a non-finite corrected mean or a NaN
-// discriminator in ANY channel makes the whole pixel NaN.  Float mode (three independent buffers):
-// per buffer, a non-finite corrected mean becomes NaN (a NaN discriminator already fails its compare).
-// +-inf must go too: against a pixel with fewer than two samples (discriminator +inf) it would pass
-// as `inf <= inf` in the oracle's form of the test and as NaN in the max3 form.
-__device__ __forceinline__ f3 canonical_mean(const f3 &mc, const f3 &d, bool valid, bool rgb) {
-    const float nan = __builtin_nanf("");
-    const bool fx = __builtin_isfinite(mc.x), fy = __builtin_isfinite(mc.y), fz = __builtin_isfinite(mc.z);
+// Which pixels take part in windows (spec v2, oracle pixel_valid): corrected mean finite, discriminator
+// not NaN, colour finite -- per pixel for an RGB buffer (all three channels), per buffer in float mode
+// (three independent 1-channel buffers); pixels outside the image never do.  vx/vy/vz: the verdict per
+// channel (RGB: all three equal).
+struct Validity {
+    bool x, y, z;
+};
+__device__ __forceinline__ Validity pixel_validity(const f3 &mc, const f3 &d, const f3 &col, bool in_image, bool rgb) {
+    const bool vx = in_image && __builtin_isfinite(mc.x) && d.x == d.x && __builtin_isfinite(col.x);
+    const bool vy = in_image && __builtin_isfinite(mc.y) && d.y == d.y && __builtin_isfinite(col.y);
+    const bool vz = in_image && __builtin_isfinite(mc.z) && d.z == d.z && __builtin_isfinite(col.z);
     if (rgb) {
-        const bool v = valid && fx && fy && fz && d.x == d.x && d.y == d.y && d.z == d.z;
-        return v ? mc : f3{nan, nan, nan};
+        const bool v = vx && vy && vz;
+        return Validity{v, v, v};
     }
-    return f3{valid && fx ? mc.x : nan, valid && fy ? mc.y : nan, valid && fz ? mc.z : nan};
+    return Validity{vx, vy, vz};
+}
+// Staging rule for the corrected mean: it is what switches a tap off in the inner loop -- NaN there
+// fails every comparison (and v_max3 drops a NaN in a single channel, hence all three for RGB).
+__device__ __forceinline__ f3 canonical_mean(const f3 &mc, const Validity &v) {
+    const float nan = __builtin_nanf("");
+    return f3{v.x ? mc.x : nan, v.y ? mc.y : nan, v.z ? mc.z : nan};
 }
 
 __device__ __forceinline__ void store_pixel(float *slot, int pitch, int i, const StagedPixel &s, float k0, float k1,
                                             bool rgb) {
     const bool v = s.valid;
-    const f3 mc = canonical_mean(s.mc, s.d, v, rgb);
+    const Validity ok = pixel_validity(s.mc, s.d, s.col, v, rgb);
+    const f3 mc = canonical_mean(s.mc, ok);
     float *p = slot + i;
     p[(C_G0 + 0) * pitch] = v ? s.g0.x * k0 : 0.f;
     p[(C_G0 + 1) * pitch] = v ? s.g0.y * k0 : 0.f;
@@ -423,12 +477,14 @@ __device__ __forceinline__ void store_pixel(float *slot, int pitch, int i, const
     p[(C_MC + 0) * pitch] = mc.x;
     p[(C_MC + 1) * pitch] = mc.y;
     p[(C_MC + 2) * pitch] = mc.z;
-    p[(C_ND + 0) * pitch] = v ? -s.d.x : 0.f;
-    p[(C_ND + 1) * pitch] = v ? -s.d.y : 0.f;
-    p[(C_ND + 2) * pitch] = v ? -s.d.z : 0.f;
-    p[(C_COL + 0) * pitch] = v ? s.col.x : 0.f;
-    p[(C_COL + 1) * pitch] = v ? s.col.y : 0.f;
-    p[(C_COL + 2) * pitch] = v ? s.col.z : 0.f;
+    p[(C_ND + 0) * pitch] = ok.x ? -s.d.x : 0.f;
+    p[(C_ND + 1) * pitch] = ok.y ? -s.d.y : 0.f;
+    p[(C_ND + 2) * pitch] = ok.z ? -s.d.z : 0.f;
+    // the colour of a pixel that takes no part is staged as 0: its weight is 0, and 0 * NaN would
+    // otherwise poison the sums of every window that covers it
+    p[(C_COL + 0) * pitch] = ok.x ? s.col.x : 0.f;
+    p[(C_COL + 1) * pitch] = ok.y ? s.col.y : 0.f;
+    p[(C_COL + 2) * pitch] = ok.z ? s.col.z : 0.f;
 }
 
 // RT > 0: compile-time radius (window edges resolved statically); RT == 0: runtime radius
@@ -474,18 +530,20 @@ __device__ __forceinline__ void filter_tile(const FilterArgs &a, float *lds, int
     for (int k = 0; k < kPx; k++) {
         const int px = min(x0 + kPx * lane + k, a.width - 1);
         const long long p = (long long)py * a.width + px;
-        f3 mc, d, g0, g1;
+        f3 mc, d, g0, g1, col;
         if (RGB && a.packed) {
             const f3 *px = reinterpret_cast<const f3 *>(a.packed + p * 15);
-            mc = px[0]; d = px[1]; g0 = px[3]; g1 = px[4];
+            mc = px[0]; d = px[1]; col = px[2]; g0 = px[3]; g1 = px[4];
         } else if constexpr (RGB) {
             mc = reinterpret_cast<const f3 *>(a.mean_corr)[p];
             d = reinterpret_cast<const f3 *>(a.disc)[p];
+            col = reinterpret_cast<const f3 *>(a.colour)[p];
         } else {
             mc = f3{a.f_mean_corr[0][p], a.f_mean_corr[1][p], a.f_mean_corr[2][p]};
             d = f3{a.f_disc[0][p], a.f_disc[1][p], a.f_disc[2][p]};
+            col = f3{a.f_colour[0][p], a.f_colour[1][p], a.f_colour[2][p]};
         }
-        mc = canonical_mean(mc, d, true, RGB);  // the same rule as for the staged taps
+        mc = canonical_mean(mc, pixel_validity(mc, d, col, true, RGB));  // the same rule as for the staged taps
         if (!(RGB && a.packed)) load_features(a, p, g0, g1);
         st.pg[k][0] = g0.x * k0; st.pg[k][1] = g0.y * k0; st.pg[k][2] = g0.z * k0;
         st.pg[k][3] = g1.x * k1; st.pg[k][4] = g1.y * k1; st.pg[k][5] = g1.z * k1;
@@ -664,6 +722,10 @@ hipError_t launch_pack_inputs(const PackArgs &a, hipStream_t s) {
 // non-positive DR factors and radius 1..20.
 bool fast_path_eligible(const FilterArgs &a, int channels) {
     if (channels != 3 && channels != 1) return false;
+    // the LDS kernels implement the default spec; every other one runs the general kernel
+    if (a.gate != STATMC_GATE_SYMMETRIC || a.channel_rule != STATMC_CHANNELS_AND || a.dof != STATMC_DOF_PIXEL ||
+        a.border != STATMC_BORDER_CLIP)
+        return false;
     int slots = 0;
     for (int g = 0; g < a.n_g; g++) {
         if (a.g[g].channels != 1 && a.g[g].channels != 3) return false;
@@ -715,7 +777,7 @@ int choose_parts(int tiles, int n_rows, int n_cus) {
     return best;
 }
 
-static int g_parts_override = 0;
+static std::atomic<int> g_parts_override{0};
 void set_filter_parts_override(int k) { g_parts_override = k; }
 
 // Where the ROI is cut: columns [rx0, split) go to regular 256-wide tiles, [split, rx1) -- at most half
@@ -737,6 +799,20 @@ static size_t lds_bytes_for(int rp) {
     return ((size_t)G::SLOTS * kCh * (G::W + 2 * rp) + 4 * (2 * rp + 8)) * sizeof(float);
 }
 
+// The 160 KB dynamic-LDS attribute is a property of (kernel, device): set once for each pair.
+static hipError_t allow_full_lds(const void *kernel) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void *>> done;
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({dev, kernel})) return hipSuccess;
+    if (hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e != hipSuccess)
+        return e;
+    done.insert({dev, kernel});
+    return hipSuccess;
+}
+
 template <int RT, int K>
 static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
     if (a.partial == nullptr) a.n_parts = 1;
@@ -748,13 +824,7 @@ static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
     const int dual_tiles = a.rx_split < a.rx1 ? (h + Geo<true>::ROWS - 1) / Geo<true>::ROWS : 0;
     a.n_main_items = main_tiles * a.n_parts;
     const size_t lds_bytes = std::max(main_tiles ? lds_bytes_for<false>(rp) : 0, dual_tiles ? lds_bytes_for<true>(rp) : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&window_filter_lds<RT, K>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = allow_full_lds(reinterpret_cast<const void *>(&window_filter_lds<RT, K>)); e != hipSuccess) return e;
     hipLaunchKernelGGL((window_filter_lds<RT, K>), dim3((main_tiles + dual_tiles) * a.n_parts), dim3(kThreads), lds_bytes, s, a);
     if (a.n_parts > 1) {
         const dim3 cgrid((a.rx1 - a.rx0 + 63) / 64, (a.ry1 - a.ry0 + 3) / 4);
@@ -764,7 +834,8 @@ static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
 }
 
 int lds_filter_parts(const FilterArgs &a, int n_cus) {
-    if (g_parts_override > 0) return g_parts_override < 2 * a.radius + 1 ? g_parts_override : 2 * a.radius + 1;
+    const int forced = g_parts_override;
+    if (forced > 0) return forced < 2 * a.radius + 1 ? forced : 2 * a.radius + 1;
     return choose_parts(lds_tiles(a), 2 * a.radius + 1, n_cus);
 }
 

@@ -44,15 +44,21 @@ hipError_t upload_t_tables() {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_tq), statmc_tq_tables, sizeof(statmc_tq_tables));
 }
 
-hipError_t upload_t_table(int alpha_index, const float *host_4096) {
+hipError_t upload_t_table(int table, const float *host_4096) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_tq), host_4096, sizeof(float) * STATMC_TQ_N_DOF,
-                             sizeof(float) * STATMC_TQ_N_DOF * alpha_index);
+                             sizeof(float) * STATMC_TQ_N_DOF * table);
+}
+const float *t_table_device_ptr(int table) {
+    float *base = nullptr;
+    if (hipGetSymbolAddress(reinterpret_cast<void **>(&base), HIP_SYMBOL(g_tq)) != hipSuccess) return nullptr;
+    return base + (size_t)table * STATMC_TQ_N_DOF;
 }
 
-__device__ __forceinline__ float t_quantile(int alpha_index, int dof) {
+// table = alpha_index + 3 * sides (t_quantiles.h)
+__device__ __forceinline__ float t_quantile(int table, int dof) {
     if (dof < 1) return __builtin_inff();
     if (dof > STATMC_TQ_N_DOF) dof = STATMC_TQ_N_DOF;
-    return g_tq[alpha_index][dof - 1];
+    return g_tq[table][dof - 1];
 }
 
 constexpr int kBlock = 256;
@@ -66,14 +72,18 @@ static inline int grid_for(long long work_items, int cap = 256 * 16) {
 }
 
 // ------------------------------------------------------------------ pre-pass
+// t = 1 in Welch mode (the pair looks its quantile up itself); exclude: n < 2 takes the pixel out of every window
 __device__ __forceinline__ void prepass_elem(int ni, float t, float mu, float s2sum, float s3sum,
-                                             float &mc, float &dc) {
+                                             float &mc, float &dc, bool exclude_small_n = false) {
     const float nf = (float)ni;
     if (ni >= 2 && s2sum > 0.f) {
         const float var = s2sum / (nf - 1.f);
         const float mu3 = s3sum / nf;
         mc = mu + mu3 / (6.f * var * nf);
         dc = (t * t) * (var / nf);
+    } else if (ni < 2 && exclude_small_n) {
+        mc = __builtin_nanf("");
+        dc = __builtin_nanf("");
     } else {
         mc = mu;
         dc = ni >= 2 ? 0.f : __builtin_inff();
@@ -96,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void prepass_kernel(PrepassArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int ni = a.n[(e0 + j) / a.channels];
-                prepass_elem(ni, t_quantile(a.alpha_index, ni - 1), pmu[j], ps2[j], ps3[j], pmc[j], pdc[j]);
+                prepass_elem(ni, a.welch ? 1.f : t_quantile(a.table, ni - 1), pmu[j], ps2[j], ps3[j], pmc[j], pdc[j], a.small_n_exclude);
             }
             *reinterpret_cast<float4 *>(a.mean_corr + e0) = mc;
             *reinterpret_cast<float4 *>(a.disc + e0) = dc;
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void prepass_kernel(PrepassArgs a) {
             for (long long e = e0; e < a.n_elems && e < e0 + 4; e++) {
                 const int ni = a.n[e / a.channels];
                 float mc, dc;
-                prepass_elem(ni, t_quantile(a.alpha_index, ni - 1), a.mean[e], a.m2[e], a.m3[e], mc, dc);
+                prepass_elem(ni, a.welch ? 1.f : t_quantile(a.table, ni - 1), a.mean[e], a.m2[e], a.m3[e], mc, dc, a.small_n_exclude);
                 a.mean_corr[e] = mc;
                 a.disc[e] = dc;
             }
@@ -138,13 +148,13 @@ __global__ __launch_bounds__(kBlock) void prepass_pack_kernel(PrepassPackArgs a)
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n_px; i += (long long)gridDim.x * kBlock) {
         const int y = (int)(i / a.src_w), x = (int)(i - (long long)y * a.src_w);
         const int ni = a.n[i];
-        const float t = t_quantile(a.alpha_index, ni - 1);
+        const float t = a.welch ? 1.f : t_quantile(a.table, ni - 1);
         const f3p mu = reinterpret_cast<const f3p *>(a.mean)[i], s2 = reinterpret_cast<const f3p *>(a.m2)[i],
                   s3 = reinterpret_cast<const f3p *>(a.m3)[i];
         f3p mc, dc;
-        prepass_elem(ni, t, mu.x, s2.x, s3.x, mc.x, dc.x);
-        prepass_elem(ni, t, mu.y, s2.y, s3.y, mc.y, dc.y);
-        prepass_elem(ni, t, mu.z, s2.z, s3.z, mc.z, dc.z);
+        prepass_elem(ni, t, mu.x, s2.x, s3.x, mc.x, dc.x, a.small_n_exclude);
+        prepass_elem(ni, t, mu.y, s2.y, s3.y, mc.y, dc.y, a.small_n_exclude);
+        prepass_elem(ni, t, mu.z, s2.z, s3.z, mc.z, dc.z, a.small_n_exclude);
         if (a.mean_corr) reinterpret_cast<f3p *>(a.mean_corr)[i] = mc;
         if (a.disc) reinterpret_cast<f3p *>(a.disc)[i] = dc;
         f3p *dst = reinterpret_cast<f3p *>(a.packed + ((long long)(y + a.dst_y0) * a.dst_w + (x + a.dst_x0)) * 15);

@@ -122,8 +122,164 @@ def test_block_decomposition_equals_whole_film(gpu, film1080):
         out = torch.zeros_like(loc["colour"])
         a, keep = gpu.make_filter_args([], [], [], [], [loc["colour"]], [loc["mean_corr"]], [loc["disc"]], [out],
                                        [loc["normal"], loc["albedo"]], g_sds=[SD_NORMAL, SD_ALBEDO],
-                                       filter_sd=FILTER_SD, radius=RADIUS, roi=L.roi)
+                                       filter_sd=FILTER_SD, radius=RADIUS, roi=L.roi, film_origin=(ox - L.pl, oy - L.pt))
         gpu.window_filter(a, 3)
         torch.cuda.synchronize()
         assert torch.equal(L.interior(out), whole[oy:oy + bh, ox:ox + bw]), rank
     gpu.force_filter_parts(0)
+
+
+# ====================================================================== every BASELINE.json config
+# configs[0] 256x256 / 16 spp, configs[1] 1280x720 / 64 spp, configs[2] 1920x1080 / 256 spp,
+# configs[3] 1920x1080 / 64 spp cut 2x2, configs[4] 3840x2160 cut 4x2 (spp bounded here: the per-pixel update
+# does not depend on how many samples came before, test_batches_chain_exactly / the 256-spp test below).
+def oracle_strip(oracle, fs, colour, roi):
+    x0, y0, x1, y1 = roi
+    return oracle.filter_image(fs.mean_corr.cpu().numpy(), fs.disc.cpu().numpy(), colour.cpu().numpy(),
+                               [fs.g_buffer("normal").cpu().numpy(), fs.g_buffer("albedo").cpu().numpy()], G_DR,
+                               -0.5 / FILTER_SD ** 2, RADIUS, roi=roi)[y0:y1, x0:x1]
+
+
+def check_strips(gpu, oracle, fs, rois, also_generic=True):
+    colour = fs.state["radiance"]["film_mean"]
+    whole = wf(gpu, fs, colour, torch.zeros_like(colour)).clone()
+    variant = gpu.last_filter_variant()
+    assert variant.startswith("lds"), variant
+    assert torch.isfinite(whole).all()
+    for roi in rois:
+        x0, y0, x1, y1 = roi
+        ref = oracle_strip(oracle, fs, colour, roi)
+        got = whole[y0:y1, x0:x1].cpu().numpy()
+        for c in range(3):
+            assert rel_l2(got[..., c], ref[..., c]) <= 1e-5, (roi, c)
+        if also_generic:
+            b = wf(gpu, fs, colour, torch.zeros_like(colour), roi=roi, force=1)[y0:y1, x0:x1].cpu().numpy()
+            assert rel_l2(b, ref) <= 1e-5, roi
+            # the ROI call of the LDS kernel gives what the whole-film call gave
+            a = wf(gpu, fs, colour, torch.zeros_like(colour), roi=roi)[y0:y1, x0:x1].cpu().numpy()
+            assert rel_l2(a, got) <= 1e-6, roi
+    return whole
+
+
+def blocks_equal_whole(gpu, fs, gx, gy, parts=2):
+    """gx x gy block decomposition (each block + its r-pixel halo filtered on its own) == whole film, bit for bit."""
+    from statmc_amd import sharding
+    colour = fs.state["radiance"]["film_mean"]
+    Wf, Hf = fs.width, fs.height
+    gpu.force_filter_parts(parts)
+    try:
+        whole = wf(gpu, fs, colour, torch.zeros_like(colour)).clone()
+        imgs = dict(mean_corr=fs.mean_corr, disc=fs.disc, colour=colour, normal=fs.g_buffer("normal"), albedo=fs.g_buffer("albedo"))
+        bw, bh = Wf // gx, Hf // gy
+        for rank in range(gx * gy):
+            L = sharding.BlockLayout(rank, gx * gy, bw, bh, RADIUS, grid=(gx, gy))
+            ox, oy = L.origin
+            loc = {k: v[oy - L.pt:oy + bh + L.pb, ox - L.pl:ox + bw + L.pr].contiguous() for k, v in imgs.items()}
+            out = torch.zeros_like(loc["colour"])
+            a, keep = gpu.make_filter_args([], [], [], [], [loc["colour"]], [loc["mean_corr"]], [loc["disc"]], [out],
+                                           [loc["normal"], loc["albedo"]], g_sds=[SD_NORMAL, SD_ALBEDO],
+                                           filter_sd=FILTER_SD, radius=RADIUS, roi=L.roi, film_origin=(ox - L.pl, oy - L.pt))
+            gpu.window_filter(a, 3)
+            torch.cuda.synchronize()
+            assert torch.equal(L.interior(out), whole[oy:oy + bh, ox:ox + bw]), (gx, gy, rank)
+    finally:
+        gpu.force_filter_parts(0)
+
+
+def make_film(gpu, W, H, spp, seed=1, types=("radiance", "normal", "albedo"), chunk=32):
+    from statmc_amd import film, synthetic
+    scene = synthetic.Scene(W, H, seed=seed, device=DEV)
+    fs = film.FilmStats(W, H, DEV, types=types)
+    for s0 in range(0, spp, chunk):
+        fs.accumulate(scene.samples(min(chunk, spp - s0), seed=seed * 1000 + s0, features=types))
+    fs.prepass()
+    torch.cuda.synchronize()
+    return fs
+
+
+def test_config0_256x256_16spp_end_to_end(gpu, oracle):
+    """configs[0]: the CPU-plumbing shape, HIP against the oracle over the whole film, every stage."""
+    from conftest import make_case
+    from statmc_amd import film
+    W0, H0, S = 256, 256, 16
+    scene, smp, st = make_case(W0, H0, S, seed=4)
+    fs = film.FilmStats(W0, H0, DEV)
+    fs.accumulate({k: torch.from_numpy(v).to(DEV) for k, v in smp.items()})
+    out = fs.denoise().cpu().numpy()
+    torch.cuda.synchronize()
+    rad = st["radiance"]
+    assert np.array_equal(fs.state["radiance"]["n"].cpu().numpy(), rad["n"])
+    assert np.array_equal(fs.state["radiance"]["film_mean"].cpu().numpy(), rad["film_mean"])
+    mc, dc = oracle.prepass(rad["n"], rad["mean"], rad["m2"], rad["m3"])
+    ref = oracle.filter_image(mc, dc, rad["film_mean"], [st["normal"]["mean"], st["albedo"]["mean"]], G_DR,
+                              -0.5 / FILTER_SD ** 2, RADIUS)
+    for c in range(3):
+        assert rel_l2(out[..., c], ref[..., c]) <= 1e-5, c
+    assert rel_l2(fs.mean_corr.cpu().numpy(), mc) <= 1e-5
+
+
+def test_config1_1280x720_64spp(gpu, oracle):
+    """configs[1]: 1280x720 / 64 spp.  5 tile columns: the shape whose default dispatch splits the window sweep
+    over several workgroups per tile and sums the parts in a second kernel."""
+    fs = make_film(gpu, 1280, 720, 64, seed=3)
+    assert int(fs.state["radiance"]["n"].min()) == 64
+    check_strips(gpu, oracle, fs, [(0, 352, 1280, 364), (0, 0, 300, 8), (1280 - 300, 720 - 8, 1280, 720), (1000, 0, 1280, 6)])
+    parts = gpu.load().statmc_debug_last_filter_parts()
+    assert parts >= 1
+    # any other split of the sweep agrees with the default one
+    colour = fs.state["radiance"]["film_mean"]
+    base = wf(gpu, fs, colour, torch.zeros_like(colour)).clone()
+    for forced in (1, 3):
+        gpu.force_filter_parts(forced)
+        try:
+            other = wf(gpu, fs, colour, torch.zeros_like(colour))
+        finally:
+            gpu.force_filter_parts(0)
+        assert rel_l2(other.cpu().numpy(), base.cpu().numpy()) <= 1e-6, forced
+
+
+def test_config2_1080p_256spp(gpu, oracle):
+    """configs[2] at its full sample count: one 256-sample launch == the reference's schedule 4+4+8+...+128
+    chained (bit for bit), then strips of the filter against the oracle."""
+    from statmc_amd import film, synthetic
+    types = synthetic.FEATURES
+    scene = synthetic.Scene(W, H, seed=1, device=DEV)
+    smp = {t: [] for t in types}
+    for s0 in range(0, 256, 32):
+        part = scene.samples(32, seed=7000 + s0, features=types)
+        for t in types:
+            smp[t].append(part[t])
+    smp = {t: torch.cat(v, dim=0) for t, v in smp.items()}
+    one = film.FilmStats(W, H, DEV, types=types)
+    one.accumulate(smp)
+    chained = film.FilmStats(W, H, DEV, types=types)
+    s0 = 0
+    for b in synthetic.sample_schedule(256):
+        chained.accumulate({t: v[s0:s0 + b] for t, v in smp.items()})
+        s0 += b
+    torch.cuda.synchronize()
+    assert s0 == 256
+    for t in types:
+        for k, v in one.state[t].items():
+            if v is not None:
+                assert torch.equal(v, chained.state[t][k]), (t, k)
+    assert int(one.state["radiance"]["n"].min()) == 256 == int(one.state["materialid"]["n"].max())
+    x = smp["radiance"][:, 700:704].double()
+    assert rel_l2(one.state["radiance"]["film_mean"][700:704].cpu().numpy(), x.mean(0).cpu().numpy()) < 1e-6
+    del smp, chained
+    one.prepass()
+    check_strips(gpu, oracle, one, [(0, 536, W, 544), (W - 280, H - 6, W, H)], also_generic=False)
+
+
+def test_config3_1080p_64spp_2x2_blocks(gpu):
+    """configs[3]: one 1920x1080 film cut 2x2 (960x540 blocks + halo) == the whole film, bit for bit."""
+    fs = make_film(gpu, W, H, 64, seed=5)
+    blocks_equal_whole(gpu, fs, 2, 2)
+
+
+def test_config4_4k_strips_and_4x2_blocks(gpu, oracle):
+    """configs[4]: 3840x2160.  Strip + corners against the oracle, and the 8-GPU partition (4x2 blocks of
+    960x1080) against the whole film."""
+    fs = make_film(gpu, 3840, 2160, 16, seed=6)
+    check_strips(gpu, oracle, fs, [(0, 1076, 3840, 1082), (0, 0, 280, 6), (3840 - 280, 2160 - 6, 3840, 2160)], also_generic=False)
+    blocks_equal_whole(gpu, fs, 4, 2)

@@ -422,11 +422,31 @@ def test_custom_t_quantile_table(gpu, oracle):
         want = oracle.prepass(n, mean, m2, m3, alpha_index=2)[1]
         assert np.array_equal(d.cpu().numpy(), want)
         assert oracle.t_quantile(2, 250) == table[-1]                           # beyond the table: last entry
-        assert lib.statmc_set_t_quantiles(5, table.ctypes.data_as(C.POINTER(C.c_float)), 10) == gpu.ERR_INVALID
+        assert lib.statmc_set_t_quantiles(6, table.ctypes.data_as(C.POINTER(C.c_float)), 10) == gpu.ERR_INVALID
+        # a repeated setup of the device keeps its loaded table and its significance level (per-device state)
+        gpu.check(lib.statmc_setup(0))
+        assert lib.statmc_get_significance() == 2
+        d.zero_()
+        gpu.prepass(a, 3)
+        torch.cuda.synchronize()
+        assert np.array_equal(d.cpu().numpy(), want)
+        # ... and the same table serves a pre-pass on a second stream
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            d2 = torch.zeros(6, 9, 3, device=DEV)
+            a2, keep2 = gpu.make_filter_args([to_dev(n)], [to_dev(mean)], [to_dev(m2)], [to_dev(m3)], [dummy], [mc.clone()], [d2],
+                                             [dummy.clone()], [], g_sds=[], radius=1)
+            gpu.prepass(a2, 3)
+        torch.cuda.synchronize()
+        assert np.array_equal(d2.cpu().numpy(), want)
     finally:
         oracle.set_t_quantiles(2, None)
-        gpu.check(lib.statmc_setup(0))           # setup() re-uploads the built-in tables
+        gpu.check(lib.statmc_set_t_quantiles(2, None, 0))   # back to the built-in table
         gpu.check(lib.statmc_set_significance(0))
+    d.zero_()
+    gpu.prepass(a, 3)
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy(), oracle.prepass(n, mean, m2, m3, alpha_index=0)[1])
     assert oracle.t_quantile(2, 30) < oracle.t_quantile(0, 30)
 
 
@@ -916,3 +936,140 @@ def test_filter_randomised_configurations(gpu, oracle):
         worst = max(worst, err)
         assert err <= TOL, (case, v, W, H, radius, roi, err)
     assert worst > 0          # the GPU path really computed something different from a copy of the oracle
+
+
+# ------------------------------------------------------------------ filter spec v2: every open choice, HIP == oracle
+import itertools
+
+SPEC_VARIANTS = [dict(zip(("gate", "channel_rule", "sides", "dof", "border", "small_n"), v))
+                 for v in itertools.product((0, 1), repeat=6)]
+
+
+def spec_id(v):
+    return "".join(str(v[k]) for k in ("gate", "channel_rule", "sides", "dof", "border", "small_n"))
+
+
+def run_spec(gpu, oracle, st, spec_kw, radius, sd, channels=3, alpha_index=0, force=0):
+    """pre-pass + window filter through the C ABI under a spec; returns (mc, disc, out, variant, oracle triple)."""
+    rad = st["radiance"]
+    n = rad["n"]
+    pick = (lambda a: a) if channels == 3 else (lambda a: np.ascontiguousarray(a[..., :1]))
+    gbs = [st["normal"]["mean"], st["albedo"]["mean"]]
+    ospec = oracle.FilterSpec(**spec_kw)
+    omc, odc = oracle.prepass(n, pick(rad["mean"]), pick(rad["m2"]), pick(rad["m3"]), alpha_index=alpha_index, spec=ospec)
+    oout = oracle.filter_image(omc, odc, pick(rad["film_mean"]), gbs, G_DR, -0.5 / sd ** 2, radius, spec=ospec, n=n,
+                               alpha_index=alpha_index)
+    h, w = n.shape
+    mc, dc, out = (torch.zeros(h, w, channels, device=DEV) for _ in range(3))
+    a, keep = gpu.make_filter_args([to_dev(n)], [to_dev(pick(rad["mean"]))], [to_dev(pick(rad["m2"]))], [to_dev(pick(rad["m3"]))],
+                                   [to_dev(pick(rad["film_mean"]))], [mc], [dc], [out], [to_dev(g) for g in gbs],
+                                   g_dr=G_DR, filter_sd=sd, radius=radius)
+    gpu.set_filter_spec(**spec_kw)
+    gpu.check(gpu.load().statmc_set_significance(alpha_index))
+    gpu.force_filter_variant(force)
+    try:
+        (gpu.filter_f32x3 if channels == 3 else gpu.filter_f32)(a)
+        torch.cuda.synchronize()
+        variant = gpu.last_filter_variant()
+    finally:
+        gpu.force_filter_variant(0)
+        gpu.set_filter_spec()
+        gpu.load().statmc_set_significance(0)
+    return mc.cpu().numpy(), dc.cpu().numpy(), out.cpu().numpy(), variant, (omc, odc, oout)
+
+
+@pytest.mark.parametrize("spec_kw", SPEC_VARIANTS, ids=[spec_id(v) for v in SPEC_VARIANTS])
+def test_filter_spec_variants_match_oracle(gpu, oracle, spec_kw):
+    """All 64 combinations of the six open choices (gate form, channel rule, quantile sides, dof, border,
+    n < 2): pre-pass bit-exact, window filter <= 1e-5 per channel, on a 3-spp case (wide intervals, many
+    decisions near the threshold) with a one-sample pixel and a non-default significance level."""
+    _, smp, st = make_case(90, 30, 3, seed=17)
+    st["radiance"]["n"][5, 7] = 1
+    st["radiance"]["n"][20, 60:64] = 0
+    mc, dc, out, variant, (omc, odc, oout) = run_spec(gpu, oracle, st, spec_kw, radius=7, sd=4.0, alpha_index=2)
+    assert np.array_equal(mc, omc, equal_nan=True) and np.array_equal(dc, odc, equal_nan=True)
+    default_kernel_spec = not (spec_kw["gate"] or spec_kw["channel_rule"] or spec_kw["dof"] or spec_kw["border"])
+    assert variant == ("lds_rt" if default_kernel_spec else "generic"), variant
+    for c in range(3):
+        assert rel_l2(out[..., c], oout[..., c]) <= TOL, c
+
+
+@pytest.mark.parametrize("spec_kw", [dict(), dict(gate=1), dict(dof=1), dict(border=1, channel_rule=1), dict(sides=1, small_n=1)],
+                         ids=["default", "asym", "welch", "clamp+joint", "one-sided+exclude"])
+@pytest.mark.parametrize("channels", [1, 3])
+def test_filter_spec_r20_and_float(gpu, oracle, spec_kw, channels):
+    """The shipped radius / sd under a few specs, RGB and float buffers; the default spec must stay on the LDS kernel."""
+    _, smp, st = make_case(280, 26, 4, seed=23)
+    mc, dc, out, variant, (omc, odc, oout) = run_spec(gpu, oracle, st, spec_kw, radius=RADIUS, sd=FILTER_SD, channels=channels)
+    assert np.array_equal(dc, odc, equal_nan=True)
+    fast = not (spec_kw.get("gate") or spec_kw.get("channel_rule") or spec_kw.get("dof") or spec_kw.get("border"))
+    assert variant == (("lds_r20" if channels == 3 else "lds_r20_f") if fast else "generic")
+    for c in range(channels):
+        assert rel_l2(out[..., c], oout[..., c]) <= TOL, c
+
+
+def test_filter_spec_errors_and_per_device_state(gpu):
+    lib = gpu.load()
+    bad = gpu.FilterSpec(gate=2)
+    assert lib.statmc_set_filter_spec(C.byref(bad)) == gpu.ERR_INVALID
+    assert lib.statmc_set_filter_spec(None) == gpu.ERR_INVALID
+    gpu.set_filter_spec(border=1, sides=1)
+    try:
+        assert gpu.get_filter_spec().as_tuple() == (0, 0, 1, 0, 1, 0)
+        gpu.check(lib.statmc_setup(0))                       # idempotent: the device keeps its settings
+        assert gpu.get_filter_spec().as_tuple() == (0, 0, 1, 0, 1, 0)
+        # Welch mode needs the sample counts at the window filter
+        z = torch.zeros(8, 8, 3, device=DEV)
+        a, keep = gpu.make_filter_args([], [], [], [], [z], [z.clone()], [z.clone()], [z.clone()], [], g_sds=[], radius=2)
+        gpu.set_filter_spec(dof=1)
+        assert lib.statmc_window_filter(C.byref(a), 3) == gpu.ERR_INVALID
+    finally:
+        gpu.set_filter_spec()
+    assert gpu.get_filter_spec().as_tuple() == (0,) * 6
+    # a device that was never set up is refused
+    assert lib.statmc_set_device(torch.cuda.device_count() + 3) == gpu.ERR_NO_DEVICE
+
+
+def test_filter_non_finite_colour(gpu, oracle):
+    """a NaN / inf colour at a pixel that is not a member (or not valid) used to reach the sums of
+    the LDS kernel as 0 * NaN.  Spec v2: such a pixel takes no part; all three kernels agree with the oracle."""
+    for radius, sd in ((20, 10.0), (7, 4.0)):
+        mc, disc, colour, gbs = stats_case(oracle, 300, 30, 6, seed=31 + radius)
+        colour = colour.copy()
+        colour[3, 40, 1] = np.nan            # valid statistics, NaN colour
+        colour[9, 250] = np.inf
+        mc[15, 100] = np.nan                 # invalid statistics AND non-finite colour
+        colour[15, 100] = np.nan
+        mc[20, 20] = 1e9                     # valid, member of no other window, finite colour
+        disc[20, 20] = 0.0
+        colour[21, 21, 0] = -np.inf
+        ref = oracle.filter_image(mc, disc, colour, gbs, G_DR, -0.5 / sd ** 2, radius)
+        bad = ~np.isfinite(ref)
+        assert bad.sum() == 1 + 3 + 3 + 1    # only the pixels themselves
+        for force in (0, 2, 1):
+            out, v = run_filter(gpu, mc, disc, colour, gbs, G_DR, sd, radius, force=force)
+            assert np.array_equal(~np.isfinite(out), bad), v
+            ok = ~bad
+            for c in range(3):
+                assert rel_l2(out[..., c][ok[..., c]], ref[..., c][ok[..., c]]) <= TOL, (v, c)
+    # float mode: per buffer
+    W, H = 48, 6
+    rng = np.random.default_rng(8)
+    mcs = [rng.standard_normal((H, W)).astype(np.float32) for _ in range(3)]
+    dcs = [(rng.random((H, W)) * 2).astype(np.float32) for _ in range(3)]
+    cols = [rng.random((H, W), dtype=np.float32) for _ in range(3)]
+    gbs = [rng.random((H, W, 3), dtype=np.float32), rng.random((H, W, 3), dtype=np.float32)]
+    cols[1][2, 10] = np.nan
+    cols[2][4, 30] = np.inf
+    g_dr = [-0.5 / 0.3 ** 2, -0.5 / 0.2 ** 2]
+    outs = [torch.zeros(H, W, device=DEV) for _ in range(3)]
+    a, keep = gpu.make_filter_args([], [], [], [], [to_dev(c) for c in cols], [to_dev(m) for m in mcs], [to_dev(d) for d in dcs],
+                                   outs, [to_dev(g) for g in gbs], g_dr=g_dr, filter_sd=FILTER_SD, radius=20)
+    gpu.window_filter(a, 1)
+    torch.cuda.synchronize()
+    for b in range(3):
+        ref = oracle.filter_image(mcs[b], dcs[b], cols[b], gbs, g_dr, -0.5 / FILTER_SD ** 2, 20)
+        o = outs[b].cpu().numpy()
+        assert np.array_equal(np.isfinite(o), np.isfinite(ref)), b
+        ok = np.isfinite(ref)
+        assert rel_l2(o[ok], ref[ok]) <= TOL, b

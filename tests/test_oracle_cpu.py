@@ -204,3 +204,193 @@ def test_film_update(oracle):
     assert rgb[2, 0] == 0.0 and rgb[2, 2] == 0.0         # negative R and B of a pure-Y colour are clamped
     assert np.allclose(rgb[3], 2.0 * np.array([3.240479 - 1.537150 - 0.498535, -0.969256 + 1.875991 + 0.041556,
                                                0.055648 - 0.204043 + 1.057311]), rtol=1e-6)   # weight 0: no division
+
+
+# ------------------------------------------------------------------ filter spec v2: the open choices
+def _spec_case(oracle, seed=3, W=40, H=22, spp=6):
+    from conftest import make_case
+    _, smp, st = make_case(W, H, spp, seed=seed)
+    return st
+
+
+SPEC_FIELDS = ("gate", "channel_rule", "sides", "dof", "border", "small_n")
+
+
+def test_default_spec_is_symmetric_in_the_pair(oracle):
+    """Spec v2: member(p, q) and the range weight have the same bits for (p, q) and (q, p), so the weight
+    matrix of a window is symmetric -- what lets a kernel evaluate every pair once.  Read off the filter
+    itself: with the indicator image of pixel a as colour, out[b] = w(b, a) / sum_w(b), and a constant image
+    filtered WITHOUT normalisation is not available, so the check is on membership (w > 0) and on the ratio
+    w(b, a) / w(a, b) = sum_w(a) / sum_w(b), with sum_w taken from a second indicator pair."""
+    st = _spec_case(oracle)
+    rad = st["radiance"]
+    mc, dc = oracle.prepass(rad["n"], rad["mean"], rad["m2"], rad["m3"])
+    H, W = rad["n"].shape
+    gbs, g_dr, ds, r = [st["normal"]["mean"], st["albedo"]["mean"]], [-50.0, -1250.0], -0.005, 6
+    rng = np.random.default_rng(0)
+
+    def column(a):   # w(b, a) / sum_w(b) for every b
+        ind = np.zeros((H, W, 3), np.float32)
+        ind[a] = 1.0
+        return oracle.filter_image(mc, dc, ind, gbs, g_dr, ds, r)[..., 0]
+
+    cols = {}
+    pts = [(int(rng.integers(0, H)), int(rng.integers(0, W))) for _ in range(10)]
+    pts += [(p[0] + int(rng.integers(-r, r + 1)), p[1] + int(rng.integers(-r, r + 1))) for p in pts]
+    pts = [p for p in pts if 0 <= p[0] < H and 0 <= p[1] < W]
+    for a in pts:
+        cols[a] = column(a)
+    n_pairs = 0
+    for a in pts:
+        for b in pts:
+            if a == b or abs(a[0] - b[0]) > r or abs(a[1] - b[1]) > r:
+                continue
+            n_pairs += 1
+            wba, wab = cols[a][b], cols[b][a]          # normalised by sum_w(b) and sum_w(a)
+            assert (wba > 0) == (wab > 0)              # a is a member of b's window  <=>  b of a's
+            if wba > 0:                                # same weight: w(b,a) sum_w... ratios agree with the self weights
+                sa, sb = 1.0 / cols[a][a], 1.0 / cols[b][b]   # w(a, a) = 1, so the diagonal entry is 1 / sum_w
+                assert abs(wba * sb - wab * sa) <= 1e-5 * wba * sb
+    assert n_pairs > 10
+
+
+@pytest.mark.parametrize("field", SPEC_FIELDS)
+def test_each_spec_field_changes_the_result_and_keeps_the_invariants(oracle, field):
+    """Every option is live (flipping it changes some pixel of a noisy low-spp case) and every variant keeps
+    what all of them must keep: a constant colour image is a fixed point, output within the window's range."""
+    st = _spec_case(oracle, seed=11, spp=3)
+    rad = st["radiance"]
+    n = rad["n"].copy()
+    n[2, 3] = 1                                   # one pixel with fewer than two samples
+    gbs, g_dr, ds, r = [st["normal"]["mean"], st["albedo"]["mean"]], [-50.0, -1250.0], -0.005, 5
+    base = oracle.FilterSpec()
+    var = oracle.FilterSpec(**{field: 1})
+    outs = []
+    for spec in (base, var):
+        mc, dc = oracle.prepass(n, rad["mean"], rad["m2"], rad["m3"], spec=spec)
+        out = oracle.filter_image(mc, dc, rad["film_mean"], gbs, g_dr, ds, r, spec=spec, n=n)
+        const = oracle.filter_image(mc, dc, np.full_like(rad["film_mean"], 0.25), gbs, g_dr, ds, r, spec=spec, n=n)
+        assert np.abs(const - 0.25).max() < 1e-6
+        assert np.isfinite(out).all()
+        assert out.min() >= rad["film_mean"].min() - 1e-6 and out.max() <= rad["film_mean"].max() + 1e-4
+        outs.append(out)
+    if field != "gate":   # the two gate forms differ by the rounding of one fma: decisions rarely flip
+        assert not np.array_equal(outs[0], outs[1]), field
+
+
+def test_spec_semantics(oracle):
+    """What each option means, on hand-built statistics."""
+    H, W = 1, 3
+    mc = np.zeros((H, W, 3), np.float32)
+    dc = np.zeros((H, W, 3), np.float32)
+    col = np.zeros((H, W, 3), np.float32)
+    col[0, :, 0] = (1.0, 2.0, 4.0)
+    col[..., 1:] = 1.0
+    # pixel 1 differs from pixel 0 by d = (1, 0, 0); D_0 = 0.6, D_1 = 0.6 in channel 0: d^2 = 1 <= 1.2 passes
+    # symmetrically, fails asymmetrically the way fma(d, d, -D_q) <= D_p reads: 1 - 0.6 = 0.4 <= 0.6 passes too;
+    # make it bite: D_0 = 0.9, D_1 = 0.05 -> sym: 1 <= 0.95 fails; asym (p=0,q=1): 1 - 0.05 <= 0.9 fails; equal.
+    mc[0, 1, 0] = 1.0
+    dc[0, 0, :] = 0.9
+    dc[0, 1, :] = 0.2
+    dc[0, 2, :] = 5.0
+    mc[0, 2, 0] = -1.5
+    f = lambda **kw: oracle.filter_image(mc, dc, col, [], [], -0.5, 2, spec=oracle.FilterSpec(**kw))
+    a = f()
+    # pair (0,1): d^2 = 1 <= 0.9 + 0.2 = 1.1 -> members of each other under every per-channel rule
+    assert a[0, 0, 0] != col[0, 0, 0] and a[0, 1, 0] != col[0, 1, 0]
+    # joint rule: channels 1 and 2 have d = 0, their slack 2 * (D_p + D_q) lets the pair (1, 2) in, which the AND rule
+    # rejects: d = 2.5, d^2 = 6.25 > 0.2 + 5.0
+    j = f(channel_rule=oracle.CHANNELS_JOINT)
+    w12_and = oracle.filter_image(mc, dc, np.eye(3, dtype=np.float32)[None, :, :].copy(), [], [], -0.5, 2)[0, 1, 2]
+    w12_joint = oracle.filter_image(mc, dc, np.eye(3, dtype=np.float32)[None, :, :].copy(), [], [], -0.5, 2,
+                                    spec=oracle.FilterSpec(channel_rule=oracle.CHANNELS_JOINT))[0, 1, 2]
+    assert w12_and == 0.0 and w12_joint > 0.0
+    assert not np.array_equal(a, j)
+    # clamp: the edge pixels repeat, so pixel 0's own colour weighs more than under clipping
+    c = f(border=oracle.BORDER_CLAMP)
+    assert abs(c[0, 0, 0] - col[0, 0, 0]) < abs(a[0, 0, 0] - col[0, 0, 0])
+    # small_n exclude: a pixel with one sample drops out of every window and keeps its colour
+    n = np.array([[5, 1, 5]], np.int32)
+    mean = mc.copy()
+    m2 = np.ones_like(mc)
+    m3 = np.zeros_like(mc)
+    spec = oracle.FilterSpec(small_n=oracle.SMALL_N_EXCLUDE)
+    mcx, dcx = oracle.prepass(n, mean, m2, m3, spec=spec)
+    assert np.isnan(mcx[0, 1]).all() and np.isnan(dcx[0, 1]).all()
+    out = oracle.filter_image(mcx, dcx, col, [], [], -0.5, 2, spec=spec)
+    assert np.array_equal(out[0, 1], col[0, 1])
+    mca, dca = oracle.prepass(n, mean, m2, m3)
+    assert np.isinf(dca[0, 1]).all() and np.array_equal(mca[0, 1], mean[0, 1])
+    # one-sided quantiles are smaller: narrower intervals
+    d1 = oracle.prepass(n, mean, m2, m3, spec=oracle.FilterSpec(sides=oracle.SIDES_ONE))[1]
+    assert (d1[0, 0] < dca[0, 0]).all()
+    # Welch: the discriminator image is s^2 / n and equal-n, equal-variance pairs get dof = 2(n - 1)
+    sw = oracle.FilterSpec(dof=oracle.DOF_WELCH)
+    mcw, dcw = oracle.prepass(n, mean, m2, m3, spec=sw)
+    assert np.allclose(dcw[0, 0], (1.0 / 4) / 5)
+    t8 = oracle.t_quantile(0, 8)
+    thr = np.sqrt(t8 * t8 * 2 * dcw[0, 0, 0])          # |d| at which the pair (0, 2) flips
+    for d, member in ((thr * 0.999, True), (thr * 1.001, False)):
+        mcw2 = np.zeros_like(mcw)
+        mcw2[0, 2, 0] = d
+        ind = np.zeros((1, 3, 3), np.float32)
+        ind[0, 2] = 1
+        w = oracle.filter_image(mcw2, dcw, ind, [], [], -0.5, 2, spec=sw, n=n)[0, 0, 0]
+        assert (w > 0) == member
+
+
+def test_non_finite_colour_takes_the_pixel_out(oracle):
+    """Spec v2: a pixel whose colour is NaN / inf takes no part -- it poisons no window and keeps its own colour."""
+    st = _spec_case(oracle, seed=5)
+    rad = st["radiance"]
+    mc, dc = oracle.prepass(rad["n"], rad["mean"], rad["m2"], rad["m3"])
+    col = rad["film_mean"].copy()
+    col[4, 7, 1] = np.nan
+    col[10, 20] = np.inf
+    out = oracle.filter_image(mc, dc, col, [st["normal"]["mean"], st["albedo"]["mean"]], [-50.0, -1250.0], -0.005, 8)
+    bad = ~np.isfinite(out)
+    assert bad.sum() == 4 and bad[4, 7, 1] and bad[10, 20].all()
+    mc2 = mc.copy()
+    mc2[4, 7] = np.nan
+    mc2[10, 20] = np.nan
+    ref = oracle.filter_image(mc2, dc, np.nan_to_num(col, nan=0.0, posinf=0.0), [st["normal"]["mean"], st["albedo"]["mean"]],
+                              [-50.0, -1250.0], -0.005, 8)
+    mask = np.ones(out.shape, bool)
+    mask[4, 7] = False
+    mask[10, 20] = False
+    assert np.array_equal(out[mask], ref[mask])
+
+
+# ------------------------------------------------------------------ FP contraction of the reference's own build
+def test_fp_contract_mode(oracle):
+    """clang -O3 -march=native (the reference's recipe) fuses m2 / m3 / filmM2 updates of StatTile<Float>; the Vec3
+    tiles are not contracted.  The mode changes scalar-tile results a little and RGB-tile results not at all."""
+    rng = np.random.default_rng(9)
+    S, H, W = 256, 4, 16
+    smp1 = (rng.lognormal(0, 1.2, size=(S, H, W, 1)) * (rng.random((S, H, W, 1)) > 0.2)).astype(np.float32)
+    smp3 = np.repeat(smp1, 3, axis=3).copy()
+    res = {}
+    try:
+        for mode in (False, True):
+            oracle.set_fp_contract(mode)
+            s1, s3 = oracle.new_state(H, W, 1), oracle.new_state(H, W, 3)
+            oracle.accumulate(s1, smp1, True, 3)
+            oracle.accumulate(s3, smp3, True, 3)
+            res[mode] = (s1, s3)
+    finally:
+        oracle.set_fp_contract(False)
+    for k in ("mean", "m2", "m3", "film_mean", "film_m2"):
+        assert np.array_equal(res[False][1][k], res[True][1][k]), k          # Vec3 tiles: identical
+        assert np.array_equal(res[False][0][k][..., 0], res[False][1][k][..., 0]), k   # un-contracted: scalar == vector lanes
+    assert np.array_equal(res[False][0]["mean"], res[True][0]["mean"])          # the mean update has nothing to fuse
+    assert not np.array_equal(res[False][0]["m2"], res[True][0]["m2"])
+    for k, tol in (("m2", 1e-6), ("film_m2", 1e-6), ("m3", 1e-4)):
+        assert rel_l2(res[True][0][k], res[False][0][k]) < tol, k
+    # the survey's known-answer vector came from a g++ -O2 probe build (no FMA): the contracted mode may differ from it
+    kat = json.load(open(os.path.join(GOLDEN, "kat_survey_appendix_a.json")))
+    try:
+        oracle.set_fp_contract(True)
+        px = oracle.add_samples_to_pixel(kat["samples"], 1, True, 3)
+    finally:
+        oracle.set_fp_contract(False)
+    assert abs(float(px["m3"]) - kat["m3"]) <= 1e-5 * abs(kat["m3"])

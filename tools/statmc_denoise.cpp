@@ -6,6 +6,7 @@
 //                  [--filterbuffers albedo,normal --filterbuffersds 0.02,0.1]
 //                  [--output 'film-f,t0-b0-mean-corr'] [--warmup]
 //                  [--significance 0|1|2] [--tquantiles table.txt] [--compare other/stem]
+//                  [--spec gate=sym|asym,channels=and|joint,sides=two|one,dof=pixel|welch,border=clip|clamp,small_n=accept|exclude]
 //   statmc_denoise --catalogue [--config denoise|acrr|smis|proden|ours] [--width W --height H]
 //
 // Per iteration it reads "<stem>-<spp>-film.pfm" and every "<stem>-<spp>-t<i>-b<j>-<suffix>.pfm"
@@ -109,7 +110,7 @@ static StatPathParams shippedConfig(const std::string &name) {
 
 int main(int argc, char **argv) {
     try {
-        std::string stem, sppList, output = "film-f", config = "denoise", compareStem, tqFile;
+        std::string stem, sppList, output = "film-f", config = "denoise", compareStem, tqFile, specText;
         int significance = 0;
         StatPathParams params = shippedConfig("denoise");
         bool catalogue = false, warmup = false, configGiven = false;
@@ -135,6 +136,7 @@ int main(int argc, char **argv) {
             else if (a == "--compare") compareStem = next();
             else if (a == "--significance") significance = std::stoi(next());
             else if (a == "--tquantiles") tqFile = next();
+            else if (a == "--spec") specText = next();
             else if (a == "--width") width = std::stoi(next());
             else if (a == "--height") height = std::stoi(next());
             else throw std::runtime_error("unknown option " + a);
@@ -194,9 +196,12 @@ int main(int argc, char **argv) {
             std::vector<float> q;
             for (float v; in >> v;) q.push_back(v);
             if (q.empty()) throw std::runtime_error(tqFile + ": no quantiles");
-            stat_denoiser::setTQuantiles(significance, q);
+            // the table the pre-pass will read: one-sided tables sit behind the two-sided ones
+            const statmc_filter_spec sp = stat_denoiser::parseFilterSpec(specText);
+            stat_denoiser::setTQuantiles(significance + (sp.sides ? 3 : 0), q);
         }
         stat_denoiser::setSignificance(significance);
+        stat_denoiser::setFilterSpec(stat_denoiser::parseFilterSpec(specText));
         const std::vector<std::string> outputs = split(output);
 
         auto iteration = [&](const std::string &spp, bool write) {
