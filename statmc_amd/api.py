@@ -163,7 +163,7 @@ def last_filter_variant():
 
 
 def force_filter_variant(v):
-    """0 auto, 1 generic (global-memory) kernel, 2 runtime-radius LDS kernel."""
+    """0 auto, 1 generic (global-memory) kernel, 2 runtime-radius one-sided LDS kernel, 3 one-sided r = 20 LDS kernel."""
     load().statmc_debug_force_filter_variant(int(v))
 
 

@@ -151,6 +151,17 @@ void apply_spec(const DeviceState &d, statmc::FilterArgs &k, const statmc_filter
         k.tq = statmc::t_table_device_ptr(d.alpha_index + STATMC_TQ_N_ALPHAS * (d.spec.sides ? 1 : 0));
     (void)a;
 }
+// pair-symmetric kernel: tile range, parts and the patch workspace of this launch
+int prepare_sym(const DeviceState &d, statmc::FilterArgs &k, const statmc_filter_args *a) {
+    k.sym.fx0 = a->film_x0;
+    k.sym.fy0 = a->film_y0;
+    statmc::sym_geometry(k);
+    k.n_parts = statmc::sym_filter_parts(k, d.cus);
+    float *ws = nullptr;
+    if (int rc = partial_workspace(statmc::sym_patch_floats(k, k.n_parts) * sizeof(float), a->stream, &ws)) return rc;
+    k.sym.patch = reinterpret_cast<float4 *>(ws);
+    return STATMC_OK;
+}
 int prepass_table(const DeviceState &d) { return d.alpha_index + STATMC_TQ_N_ALPHAS * (d.spec.sides ? 1 : 0); }
 
 int check_image(const statmc_image &im, int w, int h, int channels, const char *what, int idx) {
@@ -392,9 +403,13 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
         if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
         k.gscale0 = sqrtf(-k.g[0].dr * 1.44269504088896340736f);
         k.gscale1 = sqrtf(-k.g[1].dr * 1.44269504088896340736f);
-        k.n_parts = statmc::lds_filter_parts(k, dstate.cus);
-        if (k.n_parts > 1) {
-            if (int rc = partial_workspace((size_t)k.n_parts * W * H * 4 * sizeof(float), a->stream, &k.partial)) return rc;
+        if (statmc::sym_path_selected(k, 3)) {
+            if (int rc = prepare_sym(dstate, k, a)) return rc;
+        } else {
+            k.n_parts = statmc::lds_filter_parts(k, dstate.cus);
+            if (k.n_parts > 1) {
+                if (int rc = partial_workspace((size_t)k.n_parts * W * H * 4 * sizeof(float), a->stream, &k.partial)) return rc;
+            }
         }
         k.packed = static_cast<const float *>(a->packed_inputs.data);
         k.out = static_cast<float *>(a->film_filtered[0].data);
@@ -420,7 +435,9 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
         k.n_parts = 1;
     }
     const bool fast = statmc::lds_path_selected(k, channels);
-    if (fast) {
+    if (fast && statmc::sym_path_selected(k, channels)) {
+        if (int rc = prepare_sym(dstate, k, a)) return rc;
+    } else if (fast) {
         const int per_px = channels == 3 ? 4 : 8;
         if (k.n_parts > 1) {
             if (int rc = partial_workspace((size_t)k.n_parts * W * H * per_px * sizeof(float), a->stream, &k.partial)) return rc;

@@ -116,6 +116,13 @@ struct FilterArgs {
     float *f_out[3];
     int f_active;
     const float *packed;         // optional [height][width][15] inputs: mc, disc, colour, g0, g1 (RGB each)
+    // pair-symmetric kernel (statmc_filter_sym.hip): tiles of 256 x 4 pixels on a grid fixed in film coordinates
+    struct SymGeom {
+        int tx0, ty0, ntx, nty;   // tile range of the launch (film tile indices)
+        int fx0, fy0;             // film coordinates of local pixel (0, 0)
+        long long item_stride4;   // float4 per work item (tile, part) in the patch workspace
+        float4 *patch;            // [items][p-side 4 x 256 | q-side rows x 296] (sum w*colour rgb, sum w)
+    } sym;
 };
 
 struct PackArgs {
@@ -157,8 +164,19 @@ bool fast_path_eligible(const FilterArgs &a, int channels);
 void set_feature_layout(FilterArgs &a);   // gscale0/1, feat[] of an eligible G-buffer set
 bool lds_path_selected(const FilterArgs &a, int channels);
 
-// force a variant for tests/benchmarks: 0 = auto, 1 = generic, 2 = lds_rt (runtime radius)
+// force a variant for tests/benchmarks: 0 = auto, 1 = generic, 2 = lds_rt (one-sided, runtime radius),
+// 3 = lds_r20 (one-sided, compile-time radius 20; the kernel the pair-symmetric one replaced)
 void set_filter_variant_override(int v);
+// pair-symmetric kernel
+bool sym_eligible(const FilterArgs &a, int channels);
+bool sym_path_selected(const FilterArgs &a, int channels);   // eligible and not overridden
+void sym_geometry(FilterArgs &a);                            // fills a.sym.tx0 .. nty from the ROI and film origin
+int sym_tiles(const FilterArgs &a);
+int sym_filter_parts(const FilterArgs &a, int n_cus);
+size_t sym_patch_floats(const FilterArgs &a, int n_parts);
+hipError_t launch_sym(FilterArgs a, hipStream_t s);
+int choose_parts(int tiles, int n_rows, int n_cus);
+int filter_parts_override();
 // parts per tile the LDS kernel would use for this ROI on a device with n_cus compute units
 int lds_filter_parts(const FilterArgs &a, int n_cus);
 void set_filter_parts_override(int k);  // 0 = automatic

@@ -53,13 +53,13 @@
 #include <utility>
 
 #include "statmc_device.h"
+#include "statmc_filter_common.h"
 
 namespace statmc {
 
 static std::atomic<int> g_variant_override{0};
 void set_filter_variant_override(int v) { g_variant_override = v; }
 
-constexpr float kLog2e = 1.44269504088896340736f;
 
 // ====================================================================== generic kernel
 // Every option of statmc_filter_spec, one lane per pixel, straight from global memory; the statements
@@ -194,10 +194,6 @@ struct Geo {
 // pixel's own value broadcast through op_sel): the kernel is bound by VALU instruction issue, and
 // pairing taps -- rather than channels -- needs no cross-half adds and also packs the
 // single-channel work (17 instructions per (tap, pixel) pair instead of 21).
-enum { C_G0 = 0, C_G1 = 3, C_MC = 6, C_ND = 9, C_COL = 12 };
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
 
 __host__ __device__ constexpr int round_up4(int r) { return (r + 3) & ~3; }
 __host__ __device__ constexpr int tab_width(int rp) { return 2 * rp + 7; }
@@ -217,10 +213,6 @@ void fill_spatial_table(float *tab, int radius, float ds) {
             tab[(dy + radius) * tw + i] = (dx >= -radius && dx <= radius) ? e * kLog2e : -INFINITY;
         }
 }
-
-struct f3 {
-    float x, y, z;
-};
 
 template <int J, int RT>
 struct ChunkMask {
@@ -391,102 +383,6 @@ __device__ __forceinline__ void eval_row(LaneState &st, const float *row, int pi
         }
     }
 }
-// Stage one image row (image row yrow, columns x0-rp .. x0-rp+pitch) into an LDS ring slot.
-struct StagedPixel {
-    f3 mc, d, g0, g1, col;
-    bool valid;
-};
-
-// The six feature values of pixel q (before the k0 / k1 scaling of the two-RGB-buffer layout; already
-// scaled, with k0 = k1 = 1, in the generic slot layout).  A slot or buffer with factor 0 is never read.
-__device__ __forceinline__ void load_features(const FilterArgs &a, long long q, f3 &g0, f3 &g1) {
-    if (a.feat_generic) {
-        float v[6];
-#pragma unroll
-        for (int f = 0; f < 6; f++)
-            v[f] = a.feat[f].scale != 0.f ? a.feat[f].data[q * a.feat[f].stride + a.feat[f].offset] * a.feat[f].scale : 0.f;
-        g0 = f3{v[0], v[1], v[2]};
-        g1 = f3{v[3], v[4], v[5]};
-        return;
-    }
-    g0 = a.gscale0 != 0.f ? reinterpret_cast<const f3 *>(a.g[0].data)[q] : f3{0.f, 0.f, 0.f};
-    g1 = a.gscale1 != 0.f ? reinterpret_cast<const f3 *>(a.g[1].data)[q] : f3{0.f, 0.f, 0.f};
-}
-
-template <bool RGB>
-__device__ __forceinline__ StagedPixel load_pixel(const FilterArgs &a, int x, int yrow) {
-    StagedPixel s;
-    s.valid = x >= 0 && x < a.width && yrow >= 0 && yrow < a.height;
-    if (s.valid) {
-        const long long q = (long long)yrow * a.width + x;
-        if (RGB && a.packed) {  // block + halo image of the multi-GPU path: 15 contiguous floats per pixel
-            const f3 *px = reinterpret_cast<const f3 *>(a.packed + q * 15);
-            s.mc = px[0]; s.d = px[1]; s.col = px[2]; s.g0 = px[3]; s.g1 = px[4];
-            return s;
-        }
-        if constexpr (RGB) {
-            s.mc = reinterpret_cast<const f3 *>(a.mean_corr)[q];
-            s.d = reinterpret_cast<const f3 *>(a.disc)[q];
-            s.col = reinterpret_cast<const f3 *>(a.colour)[q];
-        } else {
-            s.mc = f3{a.f_mean_corr[0][q], a.f_mean_corr[1][q], a.f_mean_corr[2][q]};
-            s.d = f3{a.f_disc[0][q], a.f_disc[1][q], a.f_disc[2][q]};
-            s.col = f3{a.f_colour[0][q], a.f_colour[1][q], a.f_colour[2][q]};
-        }
-        load_features(a, q, s.g0, s.g1);
-    }
-    return s;
-}
-
-// Which pixels take part in windows (spec v2, oracle pixel_valid): corrected mean finite, discriminator
-// not NaN, colour finite -- per pixel for an RGB buffer (all three channels), per buffer in float mode
-// (three independent 1-channel buffers); pixels outside the image never do.  vx/vy/vz: the verdict per
-// channel (RGB: all three equal).
-struct Validity {
-    bool x, y, z;
-};
-__device__ __forceinline__ Validity pixel_validity(const f3 &mc, const f3 &d, const f3 &col, bool in_image, bool rgb) {
-    const bool vx = in_image && __builtin_isfinite(mc.x) && d.x == d.x && __builtin_isfinite(col.x);
-    const bool vy = in_image && __builtin_isfinite(mc.y) && d.y == d.y && __builtin_isfinite(col.y);
-    const bool vz = in_image && __builtin_isfinite(mc.z) && d.z == d.z && __builtin_isfinite(col.z);
-    if (rgb) {
-        const bool v = vx && vy && vz;
-        return Validity{v, v, v};
-    }
-    return Validity{vx, vy, vz};
-}
-// Staging rule for the corrected mean: it is what switches a tap off in the inner loop -- NaN there
-// fails every comparison (and v_max3 drops a NaN in a single channel, hence all three for RGB).
-__device__ __forceinline__ f3 canonical_mean(const f3 &mc, const Validity &v) {
-    const float nan = __builtin_nanf("");
-    return f3{v.x ? mc.x : nan, v.y ? mc.y : nan, v.z ? mc.z : nan};
-}
-
-__device__ __forceinline__ void store_pixel(float *slot, int pitch, int i, const StagedPixel &s, float k0, float k1,
-                                            bool rgb) {
-    const bool v = s.valid;
-    const Validity ok = pixel_validity(s.mc, s.d, s.col, v, rgb);
-    const f3 mc = canonical_mean(s.mc, ok);
-    float *p = slot + i;
-    p[(C_G0 + 0) * pitch] = v ? s.g0.x * k0 : 0.f;
-    p[(C_G0 + 1) * pitch] = v ? s.g0.y * k0 : 0.f;
-    p[(C_G0 + 2) * pitch] = v ? s.g0.z * k0 : 0.f;
-    p[(C_G1 + 0) * pitch] = v ? s.g1.x * k1 : 0.f;
-    p[(C_G1 + 1) * pitch] = v ? s.g1.y * k1 : 0.f;
-    p[(C_G1 + 2) * pitch] = v ? s.g1.z * k1 : 0.f;
-    p[(C_MC + 0) * pitch] = mc.x;
-    p[(C_MC + 1) * pitch] = mc.y;
-    p[(C_MC + 2) * pitch] = mc.z;
-    p[(C_ND + 0) * pitch] = ok.x ? -s.d.x : 0.f;
-    p[(C_ND + 1) * pitch] = ok.y ? -s.d.y : 0.f;
-    p[(C_ND + 2) * pitch] = ok.z ? -s.d.z : 0.f;
-    // the colour of a pixel that takes no part is staged as 0: its weight is 0, and 0 * NaN would
-    // otherwise poison the sums of every window that covers it
-    p[(C_COL + 0) * pitch] = ok.x ? s.col.x : 0.f;
-    p[(C_COL + 1) * pitch] = ok.y ? s.col.y : 0.f;
-    p[(C_COL + 2) * pitch] = ok.z ? s.col.z : 0.f;
-}
-
 // RT > 0: compile-time radius (window edges resolved statically); RT == 0: runtime radius
 // a.radius <= 20, every pair of every read group evaluated, the table masks taps beyond r.
 // One work item: `part` of tile `tile` of the tile grid laid over columns [cx0, cx1) of the ROI.
@@ -779,6 +675,16 @@ int choose_parts(int tiles, int n_rows, int n_cus) {
 
 static std::atomic<int> g_parts_override{0};
 void set_filter_parts_override(int k) { g_parts_override = k; }
+int filter_parts_override() { return g_parts_override; }
+
+bool sym_path_selected(const FilterArgs &a, int channels) {
+    return sym_eligible(a, channels) && a.spatial_tab != nullptr && g_variant_override == 0;
+}
+int sym_filter_parts(const FilterArgs &a, int n_cus) {
+    const int forced = g_parts_override;
+    if (forced > 0) return forced < 21 ? forced : 21;
+    return choose_parts(sym_tiles(a), 21, n_cus);
+}
 
 // Where the ROI is cut: columns [rx0, split) go to regular 256-wide tiles, [split, rx1) -- at most half
 // a tile -- to the DUAL tiles (split == rx1: no DUAL column).
@@ -847,6 +753,10 @@ bool lds_path_selected(const FilterArgs &a, int channels) {
 
 // Window filter reading the 15-channel block + halo image (multi-GPU path): LDS kernel only.
 hipError_t launch_lds_packed(const FilterArgs &a, hipStream_t s, const char **variant) {
+    if (a.sym.patch != nullptr) {
+        *variant = "sym_r20";
+        return launch_sym(a, s);
+    }
     if (a.radius == 20 && g_variant_override != 2) {
         *variant = "lds_r20";
         return launch_lds<20, 0>(a, s);
@@ -857,6 +767,10 @@ hipError_t launch_lds_packed(const FilterArgs &a, hipStream_t s, const char **va
 
 hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s, const char **variant) {
     const bool fast = lds_path_selected(a, channels);
+    if (fast && channels == 3 && a.sym.patch != nullptr) {
+        *variant = "sym_r20";
+        return launch_sym(a, s);
+    }
     if (fast) {
         const bool rgb = channels == 3;
         if (a.radius == 20 && g_variant_override != 2) {

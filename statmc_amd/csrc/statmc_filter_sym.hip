@@ -1,0 +1,630 @@
+// statmc_filter_sym.hip -- the pair-symmetric window filter (gfx950): filter<float3>, radius 20, default spec.
+//
+// Replaces the window part of cv::cuda::stat_denoiser::filter<float3> (call site
+// src/statistics/estimator.cpp:465-487 of the reference; CUDA source not in the tree, arithmetic = this
+// build's spec v2, oracle/statmc_oracle.c:oracle_filter_spec_run).
+//
+// Why.  The filter is a (2r+1)^2 = 1681-tap stencil bound by VALU issue (33 fp32 lane-operations per
+// (tap, pixel) pair, against 72 B of HBM traffic per pixel).  Under spec v2 both the range weight and the
+// membership gate of a pair have the SAME BITS for (p, q) and (q, p):
+//     e_pq = ds |p - q|^2 + sum_g DR_g |G_p - G_q|^2          (squares of differences)
+//     member_pq  <=>  max_c fma(d_c, d_c, -(D_p,c + D_q,c)) <= 0,   d_c = mc_p,c - mc_q,c
+// so every unordered pair is evaluated ONCE -- by its upper pixel p, over the half window {dy > 0} -- and the
+// weight is added to both sides: w * colour_q to p (registers) and w * colour_p to q (LDS accumulator rows).
+// 29 operations for weight + gate and 4 + 4 for the two accumulations = 37 per pair = 18.5 per directed tap.
+//
+// Shape of the work.
+//   * Tile = 256 x 4 pixels on a grid fixed in FILM coordinates (so that block-decomposed multi-GPU runs
+//     form every sum in the same order as a whole-film run: bit-identical results).  A 512-thread workgroup
+//     = 8 waves, TWO waves per tile row: wave (t, h) owns row t and half h of the window columns
+//     (h = 0: dx in [-20, 0], h = 1: dx in [1, 20]); a lane owns 4 adjacent pixels.  Both halves of a row keep
+//     the pixels' own data in registers; their partial sums meet in the epilogue.
+//   * Step s = window row dy = s, s = 0..20.  At step s the wave of tile row t sweeps image row y0 + t + s:
+//     4 live rows + 1 being staged = a ring of 5 LDS slots.  A slot holds the 15 input planes of a row
+//     (296 columns = tile + 2 x 20 halo) AND its 2 x 4 accumulator planes (Sigma w*colour, Sigma w; one copy
+//     per window half, because the two waves of a row hit the same columns at the same time).  Everything a
+//     row needs lives exactly as long as the row: 5 x 296 x 23 floats = 136 KB of the CU's 160 KB.
+//     (One wave per row and 8 rows -- the geometry of the one-sided kernel -- would need 202 KB.)
+//   * dy = 0: the pairs inside a row are the taps dx in [1, 20] of half 1 (the accumulator row is the wave's own
+//     row); half 0 only adds the pixel's own tap.
+//   * q-side scatter: per read group a lane reads the 4 x 2 accumulator values of its two taps, adds its four
+//     pixels' w * colour_p with the same packed FMAs that serve the p side, and writes them back.  Plain
+//     read-modify-write: within a step one wave owns an accumulator row copy, and the LDS executes a wave's
+//     instructions in order, so the lane that continues a column sees its neighbour's sum.  (ds_add_f32
+//     costs ~190 cycles per wave instruction on gfx950 -- tools/microbench/lds_scatter.hip -- 30x the RMW.)
+//   * When a row leaves the ring its two accumulator copies are added and written to the work item's PATCH in
+//     global memory; the p-side sums of the tile go there too.  combine_sym_kernel then gathers, for every
+//     output pixel, the patches that hold a share of it (its own tile's p-side, the q-side rows of the <= 6
+//     tile rows above it and of the horizontal neighbours whose halo covers it) in a fixed order, and
+//     normalises.  The sweep of a tile can be split over `parts` workgroups (steps [s_a, s_b) each) with no
+//     further mechanism: a part is just a patch.
+#include <algorithm>
+#include <mutex>
+#include <set>
+#include <utility>
+
+#include "statmc_device.h"
+#include "statmc_filter_common.h"
+
+// timing-only ablation builds (tools/experiments/ablate_sym.sh); results are wrong with any bit set
+#ifndef STATMC_SYM_ABLATE
+#define STATMC_SYM_ABLATE 0
+#endif
+
+namespace statmc {
+namespace sym {
+
+constexpr int kAblate = STATMC_SYM_ABLATE;  // 1 no q side, 2 no row staging, 4 no flush, 8 no sweep arithmetic, 16 no barrier
+constexpr int kR = 20;
+constexpr int kPx = 4;                    // pixels per lane
+constexpr int kW = 64 * kPx;              // 256 tile columns
+constexpr int kRows = 4;                  // tile rows (two waves each)
+constexpr int kSlots = kRows + 1;         // LDS row ring
+constexpr int kP = kW + 2 * kR;           // 296 staged columns per row
+constexpr int kIn = 15;                   // input planes per row
+constexpr int kQ = 8;                     // accumulator planes per row: 2 copies x (r, g, b, w)
+constexpr int kSlotFloats = (kIn + kQ) * kP;
+constexpr int kThreads = 512;
+constexpr int kSteps = kR + 1;            // dy = 0 .. 20
+constexpr int kTabW = 2 * kR + 7;         // entries per window row of the spatial table: index dx + kR + 3
+constexpr int kTabPad = 2 * (kTabW + 1);  // LDS copy: pairs (tab[t], tab[t+1])
+constexpr int kChunks = 2 * kR / 4 + 1;   // 11 read groups per window row
+constexpr int kMid = kChunks / 2;         // 5: the group that holds dx = 0
+constexpr int kPatchP = kRows * kW;       // float4 per patch: p-side piece
+// LDS-DMA staging: every wave fetches and stages its own 40 of the 296 columns of a row (wave 7: the last 16), five
+// RGB images (or one 15-float AoS image) = 150 pieces of 16 B per wave and row, landing in a wave-private raw area
+constexpr int kWaveCols = 40;
+constexpr int kRawFloats = kWaveCols * 15;                  // 600 floats = 150 pieces per wave
+constexpr int kRawTotal = 8 * kRawFloats;
+constexpr size_t kLdsBytes = (size_t)(kSlots * kSlotFloats + 2 * kTabPad + kRawTotal) * sizeof(float);
+static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+
+__host__ __device__ inline int step_lo(int part, int n_parts) { return (kSteps * part) / n_parts; }
+__host__ __device__ inline int q_rows_max(int n_parts) { return (kSteps + n_parts - 1) / n_parts + 3; }  // rows s_a .. s_b+2
+
+// The lane's own 4 pixels.  Their values enter the packed instructions as broadcasts of ONE half of a register
+// pair (op_sel), so two different scalars share every pair: 6 + 6 + 4 pairs per pixel instead of 15 + 15
+// registers holding (x, x) duplicates -- which is what a `v2f{x, x}` splat of a scalar compiles to.
+struct Lane {
+    v2f pg[kPx][3];    // scaled features: (n.x, n.y), (n.z, a.x), (a.y, a.z)
+    v2f ms[kPx][3];    // per channel (corrected mean, discriminator)
+    v2f pc[kPx][2];    // colour (r, g), (b, -)
+    v2f acc[kPx][3];   // .x even taps, .y odd taps of every read group
+    v2f sw[kPx];
+};
+// The three packed instructions that take a broadcast half of a pair, spelled out: written as shuffles the
+// broadcasts are loop-invariant, get hoisted out of the sweep and come back as (x, x) register pairs of their own.
+// `half` is a constant after unrolling.
+__device__ __forceinline__ v2f sub_bc(const v2f &pair, int half, const v2f &t) {   // bc(pair.half) - t
+    v2f d;
+    if (half) asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(pair), "v"(t));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(pair), "v"(t));
+    return d;
+}
+__device__ __forceinline__ v2f rsub_bc(const v2f &t, const v2f &pair, int half) {  // t - bc(pair.half)
+    v2f d;
+    if (half) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(t), "v"(pair));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(t), "v"(pair));
+    return d;
+}
+__device__ __forceinline__ v2f fma_bc(const v2f &w, const v2f &pair, int half, const v2f &acc) {  // w * bc(pair.half) + acc
+    v2f d;
+    if (half) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(d) : "v"(w), "v"(pair), "v"(acc));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(w), "v"(pair), "v"(acc));
+    return d;
+}
+
+// bit (i*4+k): tap i of read group J lies at dx in [LO, HI] from pixel k
+template <int J, int LO, int HI>
+struct Mask {
+    static constexpr unsigned value() {
+        unsigned m = 0;
+        for (int i = 0; i < 4; i++)
+            for (int k = 0; k < 4; k++) {
+                const int dx = 4 * J - kR + i - k;
+                if (dx >= LO && dx <= HI) m |= 1u << (i * 4 + k);
+            }
+        return m;
+    }
+};
+
+// tap pair H (taps 2H, 2H+1) of a read group against pixel k
+template <int H, unsigned MASK>
+struct Taps {
+    static constexpr int i0 = 2 * H;
+    static constexpr bool in0(int k) { return (MASK & (1u << (i0 * 4 + k))) != 0; }
+    static constexpr bool in1(int k) { return (MASK & (1u << ((i0 + 1) * 4 + k))) != 0; }
+    static constexpr bool on(int k) { return in0(k) || in1(k); }
+    static constexpr bool any() { return on(0) || on(1) || on(2) || on(3); }
+};
+
+template <int H>
+__device__ __forceinline__ v2f pair_of(const v4f &v) {
+    return H == 0 ? __builtin_shufflevector(v, v, 0, 1) : __builtin_shufflevector(v, v, 2, 3);
+}
+
+// range weight exponent of tap pair H against the lane's 4 pixels: tab - |k_n dn|^2 - |k_a da|^2 (log2 domain)
+template <int H, unsigned MASK>
+__device__ __forceinline__ void range_exponent(const Lane &st, const v4f *g, const float *__restrict__ tab, int j, v2f (&e)[kPx]) {
+    using M = Taps<H, MASK>;
+    v2f tp[kPx];
+#pragma unroll
+    for (int k = 0; k < kPx; k++) if (M::on(k)) tp[k] = *reinterpret_cast<const v2f *>(tab + 2 * (4 * j + 2 * H - k + 3));
+#pragma unroll
+    for (int k = 0; k < kPx; k++) if (M::on(k)) { const v2f d = sub_bc(st.pg[k][0], 0, pair_of<H>(g[0])); e[k] = -d * d; }
+#pragma unroll
+    for (int ch = 1; ch < 6; ch++) {
+#pragma unroll
+        for (int k = 0; k < kPx; k++) if (M::on(k)) { const v2f d = sub_bc(st.pg[k][ch >> 1], ch & 1, pair_of<H>(g[ch])); e[k] = __builtin_elementwise_fma(-d, d, e[k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < kPx; k++) if (M::on(k)) e[k] += tp[k];
+}
+
+// membership gate and weight of tap pair H: w = member ? exp2(e) : 0   (mcn: corrected mean planes 0..2, -D planes 3..5)
+template <int H, unsigned MASK>
+__device__ __forceinline__ void gate_weight(const Lane &st, const v4f *mcn, const v2f (&e)[kPx], v2f (&w)[kPx]) {
+    using M = Taps<H, MASK>;
+    v2f u[kPx][3];
+    // membership statistic per channel: fma(d, d, -(D_p + D_q))
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+#pragma unroll
+        for (int k = 0; k < kPx; k++) if (M::on(k)) {
+            const v2f d = sub_bc(st.ms[k][ch], 0, pair_of<H>(mcn[ch]));
+            const v2f s = rsub_bc(pair_of<H>(mcn[3 + ch]), st.ms[k][ch], 1);
+            u[k][ch] = __builtin_elementwise_fma(d, d, s);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kPx; k++) if (M::on(k)) w[k] = v2f{__builtin_amdgcn_exp2f(e[k].x), __builtin_amdgcn_exp2f(e[k].y)};
+    // all three channels pass <=> max_c <= 0; v_max3 drops NaN operands, which is why a pixel that takes no
+    // part is staged with NaN in all three channels of its mean
+#pragma unroll
+    for (int k = 0; k < kPx; k++) if (M::on(k)) {
+        const float m0 = __builtin_fmaxf(__builtin_fmaxf(u[k][0].x, u[k][1].x), u[k][2].x);
+        const float m1 = __builtin_fmaxf(__builtin_fmaxf(u[k][0].y, u[k][1].y), u[k][2].y);
+        w[k] = v2f{M::in0(k) && m0 <= 0.f ? w[k].x : 0.f, M::in1(k) && m1 <= 0.f ? w[k].y : 0.f};
+    }
+}
+
+// p side: the lane's pixels collect w * colour_q; q side (SYM): the taps' accumulators collect w * colour_p
+template <int H, unsigned MASK, bool SYM>
+__device__ __forceinline__ void accumulate(Lane &st, const v4f *col, const v2f (&w)[kPx], v2f (&qv)[4]) {
+    using M = Taps<H, MASK>;
+#pragma unroll
+    for (int k = 0; k < kPx; k++) if (M::on(k)) st.sw[k] += w[k];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+#pragma unroll
+        for (int k = 0; k < kPx; k++) if (M::on(k)) st.acc[k][ch] = __builtin_elementwise_fma(w[k], pair_of<H>(col[ch]), st.acc[k][ch]);
+    }
+    if constexpr (SYM) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+#pragma unroll
+            for (int k = 0; k < kPx; k++) if (M::on(k)) qv[ch] = fma_bc(w[k], st.pc[k][ch >> 1], ch & 1, qv[ch]);
+        }
+#pragma unroll
+        for (int k = 0; k < kPx; k++) if (M::on(k)) qv[3] += w[k];
+    }
+}
+
+// One read group (4 taps) against the lane's 4 pixels.  Every LDS operand is one ds_read_b128 of a channel plane
+// (consecutive lanes read consecutive 16 B: conflict-free); the group runs in three phases -- range exponents
+// (6 feature planes), gates and weights (6 statistics planes), accumulation (3 colour planes + the 4 accumulator
+// planes of the taps) -- so that only one phase's operands are live at a time; the next phase's loads are issued
+// before the current phase's arithmetic.
+template <unsigned MASK, bool SYM>
+__device__ __forceinline__ void chunk(Lane &st, const float *__restrict__ row, const float *__restrict__ tab, float *__restrict__ qrow, int j) {
+    using M0 = Taps<0, MASK>;
+    using M1 = Taps<1, MASK>;
+    const float *r = row + 4 * j;
+    v4f g[6], mcn[6], col[3], q4[4];
+#pragma unroll
+    for (int ch = 0; ch < 6; ch++) g[ch] = *reinterpret_cast<const v4f *>(r + (C_G0 + ch) * kP);
+    v2f e0[kPx], e1[kPx], w0[kPx], w1[kPx];
+    if constexpr (M0::any()) range_exponent<0, MASK>(st, g, tab, j, e0);
+    if constexpr (M1::any()) range_exponent<1, MASK>(st, g, tab, j, e1);
+#pragma unroll
+    for (int ch = 0; ch < 6; ch++) mcn[ch] = *reinterpret_cast<const v4f *>(r + (C_MC + ch) * kP);
+    if constexpr (M0::any()) gate_weight<0, MASK>(st, mcn, e0, w0);
+    if constexpr (M1::any()) gate_weight<1, MASK>(st, mcn, e1, w1);
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) col[ch] = *reinterpret_cast<const v4f *>(r + (C_COL + ch) * kP);
+    if constexpr (SYM) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) q4[v] = *reinterpret_cast<const v4f *>(qrow + 4 * j + v * kP);
+    }
+    v2f qa[4], qb[4];
+    if constexpr (SYM) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) { qa[v] = pair_of<0>(q4[v]); qb[v] = pair_of<1>(q4[v]); }
+    }
+    if constexpr (M0::any()) accumulate<0, MASK, SYM>(st, col, w0, qa);
+    if constexpr (M1::any()) accumulate<1, MASK, SYM>(st, col, w1, qb);
+    if constexpr (SYM) {
+#pragma unroll
+        for (int v = 0; v < 4; v++)
+            *reinterpret_cast<v4f *>(qrow + 4 * j + v * kP) = v4f{qa[v].x, qa[v].y, qb[v].x, qb[v].y};
+    }
+}
+
+// Half h of the window columns of one window row.  row / qrow point at the lane's first staged column
+// (column 4*lane of the slot); qrow at plane 0 of the wave's accumulator copy.
+// dy > 0: h = 0 sweeps dx in [-20, 0], h = 1 dx in [1, 20], every pair feeding both its pixels.
+// dy = 0: the pairs of a row are the taps dx in [1, 20] of half 1 (again feeding both pixels); half 0 is left with
+// the pixel's own tap dx = 0 (p side only).
+template <int HF>
+__device__ __forceinline__ void eval_half_row(Lane &st, const float *row, const float *tab, float *qrow, bool dy0) {
+    constexpr unsigned kFull = 0xFFFFu;
+    if constexpr (HF == 0) {
+        if (dy0) {
+            chunk<Mask<kMid, 0, 0>::value(), false>(st, row, tab, qrow, kMid);
+            return;
+        }
+        static_assert(Mask<1, -kR, 0>::value() == kFull && Mask<kMid - 1, -kR, 0>::value() == kFull, "");
+        chunk<Mask<0, -kR, 0>::value(), true>(st, row, tab, qrow, 0);
+#pragma unroll 1
+        for (int j = 1; j < kMid; j++) chunk<kFull, true>(st, row, tab, qrow, j);
+        chunk<Mask<kMid, -kR, 0>::value(), true>(st, row, tab, qrow, kMid);
+    } else {
+        static_assert(Mask<kMid + 1, 1, kR>::value() == kFull && Mask<kChunks - 2, 1, kR>::value() == kFull, "");
+        chunk<Mask<kMid, 1, kR>::value(), true>(st, row, tab, qrow, kMid);
+#pragma unroll 1
+        for (int j = kMid + 1; j < kChunks - 1; j++) chunk<kFull, true>(st, row, tab, qrow, j);
+        chunk<Mask<kChunks - 1, 1, kR>::value(), true>(st, row, tab, qrow, kChunks - 1);
+    }
+}
+
+// pixel (x, yrow) of the five input images (two RGB G-buffers at most; an absent one has factor 0 and is not read)
+__device__ __forceinline__ StagedPixel load_px(const FilterArgs &a, int x, int yrow) {
+    StagedPixel s;
+    s.valid = x >= 0 && x < a.width && yrow >= 0 && yrow < a.height;
+    if (s.valid) {
+        const long long q = (long long)yrow * a.width + x;
+        if (a.packed) {
+            const f3 *px = reinterpret_cast<const f3 *>(a.packed + q * 15);
+            s.mc = px[0]; s.d = px[1]; s.col = px[2]; s.g0 = px[3]; s.g1 = px[4];
+            return s;
+        }
+        s.mc = reinterpret_cast<const f3 *>(a.mean_corr)[q];
+        s.d = reinterpret_cast<const f3 *>(a.disc)[q];
+        s.col = reinterpret_cast<const f3 *>(a.colour)[q];
+        s.g0 = a.gscale0 != 0.f ? reinterpret_cast<const f3 *>(a.g[0].data)[q] : f3{0.f, 0.f, 0.f};
+        s.g1 = a.gscale1 != 0.f ? reinterpret_cast<const f3 *>(a.g[1].data)[q] : f3{0.f, 0.f, 0.f};
+    }
+    return s;
+}
+
+// stage column i of a row: inputs as the one-sided kernel stages them, accumulators cleared
+__device__ __forceinline__ void stage_store(float *slot, int i, const StagedPixel &s, float k0, float k1) {
+    store_pixel(slot, kP, i, s, k0, k1, true);
+#pragma unroll
+    for (int v = 0; v < kQ; v++) slot[(kIn + v) * kP + i] = 0.f;
+}
+
+// the accumulators of row `rel` (tile-relative) leave the ring: copy A + copy B -> patch
+__device__ __forceinline__ void flush_q(const float *slot, int i, float4 *patch_q_row) {
+    const float *q = slot + kIn * kP + i;
+    patch_q_row[i] = make_float4(q[0 * kP] + q[4 * kP], q[1 * kP] + q[5 * kP], q[2 * kP] + q[6 * kP], q[3 * kP] + q[7 * kP]);
+}
+
+// Issue the LDS-DMA transfers of image row `yrow`, columns [xw0, xw0 + ncols) -> the wave's raw area.  Nothing
+// passes through registers and nothing waits: the data is used one step later.  Pieces never straddle the image
+// border (xw0 and the image width are multiples of 4 pixels = 3 or 15 pieces); pieces outside the image are skipped
+// and their stale bytes are never looked at (validity is decided from coordinates).
+__device__ __forceinline__ void dma_row(const FilterArgs &a, float *raw_w, int lane, int xw0, int yrow, int ncols) {
+    if (yrow < 0 || yrow >= a.height) return;
+    const int per_img = ncols * 3 / 4, total = 5 * per_img;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int idx = 64 * j + lane;
+        if (idx < total) {
+            const float *src;
+            bool inside;
+            if (a.packed) {
+                const long long f = (long long)xw0 * 15 + 4 * idx;   // float offset inside the AoS row
+                inside = f >= 0 && f + 4 <= (long long)a.width * 15;
+                src = a.packed + (long long)yrow * a.width * 15 + f;
+            } else {
+                const int m = idx / per_img, p = idx - m * per_img;
+                const float *img = m == 0 ? a.mean_corr : m == 1 ? a.disc : m == 2 ? a.colour : m == 3 ? a.g[0].data : a.g[1].data;
+                const long long f = (long long)xw0 * 3 + 4 * p;
+                inside = f >= 0 && f + 4 <= (long long)a.width * 3 && img != nullptr;
+                src = img + (long long)yrow * a.width * 3 + f;
+            }
+            if (inside)
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(raw_w + 256 * j), 16, 0, 0);
+        }
+    }
+}
+
+// column c of the wave's raw area -> the staged pixel (image order in the raw area: mean, discriminator, colour, g0, g1)
+__device__ __forceinline__ StagedPixel raw_pixel(const FilterArgs &a, const float *raw_w, int c, int ncols, int x, int yrow) {
+    StagedPixel s;
+    s.valid = x >= 0 && x < a.width && yrow >= 0 && yrow < a.height;
+    const int im = a.packed ? 3 : ncols * 3, px = a.packed ? 15 : 3;   // float stride between images / pixels
+    const float *r = raw_w + c * px;
+    s.mc = f3{r[0], r[1], r[2]};
+    s.d = f3{r[im], r[im + 1], r[im + 2]};
+    s.col = f3{r[2 * im], r[2 * im + 1], r[2 * im + 2]};
+    s.g0 = a.gscale0 != 0.f ? f3{r[3 * im], r[3 * im + 1], r[3 * im + 2]} : f3{0.f, 0.f, 0.f};
+    s.g1 = a.gscale1 != 0.f ? f3{r[4 * im], r[4 * im + 1], r[4 * im + 2]} : f3{0.f, 0.f, 0.f};
+    return s;
+}
+
+// DMA = rows are staged by LDS-DMA (two RGB G-buffers or the packed image, 16-byte aligned images whose width and
+// film x-origin are multiples of 4 pixels); otherwise through registers (any layout the one-sided kernel accepts).
+template <bool DMA>
+__global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // XCD-aware work mapping (as in the one-sided kernel): each XCD walks a contiguous range of items
+    const int n_items = gridDim.x, b = blockIdx.x;
+    const int q8 = n_items >> 3, rem8 = n_items & 7, xcd = b & 7, idx = b >> 3;
+    const int u = xcd < rem8 ? xcd * (q8 + 1) + idx : rem8 * (q8 + 1) + (xcd - rem8) * q8 + idx;
+
+    const int part = u % a.n_parts, tile = u / a.n_parts;
+    const int x0 = kW * (a.sym.tx0 + tile % a.sym.ntx) - a.sym.fx0;     // local coordinates of the tile
+    const int y0 = kRows * (a.sym.ty0 + tile / a.sym.ntx) - a.sym.fy0;
+    const int s_a = step_lo(part, a.n_parts);
+    const int s_b = min(step_lo(part + 1, a.n_parts), a.height - y0);  // window rows below the image are not swept
+    const int q_first = s_a;   // accumulator rows the item flushes: tile-relative rows s_a .. s_b+2
+    float4 *patch = a.sym.patch + (long long)u * a.sym.item_stride4;
+    float4 *patch_q = patch + kPatchP;
+    float *tab_lds = lds + kSlots * kSlotFloats;
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int trow = wave & 3, half = wave >> 2;
+    const float k0 = a.gscale0, k1 = a.gscale1;
+    constexpr int tw = kTabW;
+
+    // ---- the lane's own 4 pixels (loads clamped into the image; outside it the pixel takes no part)
+    Lane st;
+    const int py = y0 + trow;
+    const int pyc = min(max(py, 0), a.height - 1);
+#pragma unroll
+    for (int k = 0; k < kPx; k++) {
+        const int px = x0 + kPx * lane + k;
+        const int pxc = min(max(px, 0), a.width - 1);
+        const long long p = (long long)pyc * a.width + pxc;
+        f3 mc, d, g0, g1, col;
+        if (a.packed) {
+            const f3 *q = reinterpret_cast<const f3 *>(a.packed + p * 15);
+            mc = q[0]; d = q[1]; col = q[2]; g0 = q[3]; g1 = q[4];
+        } else {
+            mc = reinterpret_cast<const f3 *>(a.mean_corr)[p];
+            d = reinterpret_cast<const f3 *>(a.disc)[p];
+            col = reinterpret_cast<const f3 *>(a.colour)[p];
+            g0 = a.gscale0 != 0.f ? reinterpret_cast<const f3 *>(a.g[0].data)[p] : f3{0.f, 0.f, 0.f};
+            g1 = a.gscale1 != 0.f ? reinterpret_cast<const f3 *>(a.g[1].data)[p] : f3{0.f, 0.f, 0.f};
+        }
+        const bool inside = px >= 0 && px < a.width && py >= 0 && py < a.height;
+        const Validity ok = pixel_validity(mc, d, col, inside, true);
+        mc = canonical_mean(mc, ok);
+        st.pg[k][0] = v2f{g0.x * k0, g0.y * k0};
+        st.pg[k][1] = v2f{g0.z * k0, g1.x * k1};
+        st.pg[k][2] = v2f{g1.y * k1, g1.z * k1};
+        st.ms[k][0] = v2f{mc.x, d.x};
+        st.ms[k][1] = v2f{mc.y, d.y};
+        st.ms[k][2] = v2f{mc.z, d.z};
+        // a pixel that takes no part adds nothing to its taps: weight 0, colour 0 (0 * NaN would poison them)
+        st.pc[k][0] = v2f{ok.x ? col.x : 0.f, ok.x ? col.y : 0.f};
+        st.pc[k][1] = v2f{ok.x ? col.z : 0.f, 0.f};
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) st.acc[k][ch] = v2f{0.f, 0.f};
+        st.sw[k] = v2f{0.f, 0.f};
+    }
+
+    // wave-local staging geometry (DMA): this wave's columns of every staged row
+    float *raw_w = tab_lds + 2 * kTabPad + wave * kRawFloats;
+    const int wcol0 = kWaveCols * wave;                                // first staged column (0..295) of the wave
+    const int ncols = min(kWaveCols, kP - wcol0);                     // 40, wave 7: 16
+    if (s_a < s_b) {
+        if constexpr (DMA) {   // the first row the sweep will need beyond the prologue: on its way during the prologue
+            if (s_a + 1 < s_b && !(kAblate & 2)) dma_row(a, raw_w, lane, x0 - kR + wcol0, y0 + s_a + kRows, ncols);
+        }
+        // ---- prologue: rows rel = s_a .. s_a+3 (image rows y0 + rel) into slots rel % 5
+        for (int idx2 = threadIdx.x; idx2 < kRows * kP; idx2 += kThreads) {
+            const int rr = idx2 / kP, i = idx2 - rr * kP;
+            const int rel = s_a + rr;
+            const StagedPixel s = load_px(a, x0 - kR + i, y0 + rel);
+            stage_store(lds + (rel % kSlots) * kSlotFloats, i, s, k0, k1);
+        }
+        if ((int)threadIdx.x < tw) {
+            const float *t = a.spatial_tab + (s_a + kR) * tw + threadIdx.x;
+            *reinterpret_cast<v2f *>(tab_lds + 2 * threadIdx.x) = v2f{t[0], (int)threadIdx.x + 1 < tw ? t[1] : 0.f};
+        }
+        __syncthreads();
+
+        // ---- sweep
+        for (int s = s_a; s < s_b; s++) {
+            const int i = DMA ? wcol0 + lane : (int)threadIdx.x;             // the staged column this thread looks after
+            const bool mine = DMA ? lane < ncols : i < kP;
+            const bool stage = s + 1 < s_b && mine && !(kAblate & 2);
+            StagedPixel nxt;
+            nxt.valid = false;
+            if constexpr (!DMA) {
+                if (stage) nxt = load_px(a, x0 - kR + i, y0 + s + kRows);
+            }
+            // the row that went dead at the last barrier hands its accumulators to the patch
+            const int dead = s - 1;
+            if (mine && dead >= q_first && y0 + dead >= 0 && !(kAblate & 4))
+                flush_q(lds + (dead % kSlots) * kSlotFloats, i, patch_q + (long long)(dead - q_first) * kP);
+            if constexpr (DMA) {
+                // the row fetched during the last step: raw area -> its slot (the dead row's), accumulators cleared;
+                // then the fetch of the row after it starts and has this whole step to land
+                if (s + 1 < s_b && !(kAblate & 2)) {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's own transfers
+                    if (stage) {
+                        const StagedPixel sp = raw_pixel(a, raw_w, lane, ncols, x0 - kR + i, y0 + s + kRows);
+                        stage_store(lds + ((s + kRows) % kSlots) * kSlotFloats, i, sp, k0, k1);
+                    }
+                    if (s + 2 < s_b) {
+                        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the raw area has been read
+                        dma_row(a, raw_w, lane, x0 - kR + wcol0, y0 + s + 1 + kRows, ncols);
+                    }
+                }
+            }
+            const int ti = (int)threadIdx.x - (kThreads - 64);
+            const bool tstage = s + 1 < s_b && ti >= 0 && ti < tw;
+            v2f tnext = v2f{0.f, 0.f};
+            if (tstage) {
+                const float *t = a.spatial_tab + (s + 1 + kR) * tw + ti;
+                tnext = v2f{t[0], ti + 1 < tw ? t[1] : 0.f};
+            }
+
+            float *slot = lds + ((s + trow) % kSlots) * kSlotFloats;
+            const float *row = slot + kPx * lane;
+            float *qrow = slot + (kIn + 4 * half) * kP + kPx * lane;
+            const float *tab = tab_lds + ((s - s_a) & 1) * kTabPad;
+            if (kAblate & 8) {
+            } else if (half == 0) {
+                eval_half_row<0>(st, row, tab, qrow, s == 0);
+            } else {
+                eval_half_row<1>(st, row, tab, qrow, s == 0);
+            }
+
+            if (tstage) *reinterpret_cast<v2f *>(tab_lds + ((s - s_a + 1) & 1) * kTabPad + 2 * ti) = tnext;
+            if constexpr (!DMA) {
+                if (stage) stage_store(lds + ((s + kRows) % kSlots) * kSlotFloats, i, nxt, k0, k1);
+            }
+            if (!(kAblate & 16)) __syncthreads();
+        }
+        // ---- the rows still in the ring: rel = s_b-1 .. s_b+2
+        for (int idx2 = threadIdx.x; idx2 < kRows * kP; idx2 += kThreads) {
+            const int rr = idx2 / kP, i = idx2 - rr * kP;
+            const int rel = s_b - 1 + rr;
+            if (rel >= q_first && y0 + rel >= 0 && y0 + rel < a.height)
+                flush_q(lds + (rel % kSlots) * kSlotFloats, i, patch_q + (long long)(rel - q_first) * kP);
+        }
+        __syncthreads();
+    }
+
+    // ---- p side: half 1 hands its sums to half 0 through LDS, half 0 writes the patch
+    float *ex = lds;  // [trow][v][256]
+    if (half == 1) {
+#pragma unroll
+        for (int k = 0; k < kPx; k++) {
+            float *e = ex + trow * 4 * kW + kPx * lane + k;
+            e[0 * kW] = st.acc[k][0].x + st.acc[k][0].y;
+            e[1 * kW] = st.acc[k][1].x + st.acc[k][1].y;
+            e[2 * kW] = st.acc[k][2].x + st.acc[k][2].y;
+            e[3 * kW] = st.sw[k].x + st.sw[k].y;
+        }
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+        for (int k = 0; k < kPx; k++) {
+            const float *e = ex + trow * 4 * kW + kPx * lane + k;
+            patch[trow * kW + kPx * lane + k] =
+                make_float4((st.acc[k][0].x + st.acc[k][0].y) + e[0 * kW], (st.acc[k][1].x + st.acc[k][1].y) + e[1 * kW],
+                            (st.acc[k][2].x + st.acc[k][2].y) + e[2 * kW], (st.sw[k].x + st.sw[k].y) + e[3 * kW]);
+        }
+    }
+}
+
+__device__ __forceinline__ int floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+// Gathers the shares of every ROI pixel from the patches, in a fixed (film-anchored) order, and normalises.
+__global__ __launch_bounds__(256) void combine_sym_kernel(FilterArgs a) {
+    const int x = a.rx0 + blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = a.ry0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.rx1 || y >= a.ry1) return;
+    const int X = x + a.sym.fx0, Y = y + a.sym.fy0;
+    const int ty_own = floordiv(Y, kRows), tx_own = floordiv(X, kW);
+    const int ty_lo = max(floordiv(Y - (kSteps + kRows - 2) + kRows - 1, kRows), a.sym.ty0);  // 4 Ty + 23 >= Y
+    const int ty_hi = min(ty_own, a.sym.ty0 + a.sym.nty - 1);
+    const int tx_lo = max(floordiv(X + kR - (kP - 1) + kW - 1, kW), a.sym.tx0);              // X - 256 Tx + 20 <= 295
+    const int tx_hi = min(floordiv(X + kR, kW), a.sym.tx0 + a.sym.ntx - 1);
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int Ty = ty_lo; Ty <= ty_hi; Ty++) {
+        const int rel = Y - kRows * Ty;  // 0 .. 23
+        for (int Tx = tx_lo; Tx <= tx_hi; Tx++) {
+            const int c = X - kW * Tx + kR;  // 0 .. 295
+            const long long item0 = ((long long)(Ty - a.sym.ty0) * a.sym.ntx + (Tx - a.sym.tx0)) * a.n_parts;
+            for (int k = 0; k < a.n_parts; k++) {
+                const float4 *patch = a.sym.patch + (item0 + k) * a.sym.item_stride4;
+                const int s_a = step_lo(k, a.n_parts), s_b = step_lo(k + 1, a.n_parts), q_first = s_a;
+                if (Ty == ty_own && Tx == tx_own) {
+                    const float4 v = patch[rel * kW + (X - kW * Tx)];
+                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+                }
+                if (rel >= q_first && rel < s_b + 3) {
+                    const float4 v = patch[kPatchP + (long long)(rel - q_first) * kP + c];
+                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+                }
+            }
+        }
+    }
+    const long long p = (long long)y * a.width + x;
+    f3 o;
+    if (t.w > 0.f) {
+        o.x = t.x / t.w; o.y = t.y / t.w; o.z = t.z / t.w;
+    } else {
+        o = a.packed ? reinterpret_cast<const f3 *>(a.packed + p * 15)[2] : reinterpret_cast<const f3 *>(a.colour)[p];
+    }
+    reinterpret_cast<f3 *>(a.out)[p] = o;
+}
+
+static int floordiv_h(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+}  // namespace sym
+
+// Tile range of a launch: every tile of the film grid that holds a pixel whose upper half-window reaches the
+// ROI (rows ry0-20 .. ry1-1, columns rx0-20 .. rx1+19, clipped to the local image).
+void sym_geometry(FilterArgs &a) {
+    using namespace sym;
+    const int ex0 = std::max(0, a.rx0 - kR), ex1 = std::min(a.width, a.rx1 + kR);
+    const int ey0 = std::max(0, a.ry0 - kR), ey1 = a.ry1;
+    a.sym.tx0 = floordiv_h(ex0 + a.sym.fx0, kW);
+    a.sym.ty0 = floordiv_h(ey0 + a.sym.fy0, kRows);
+    a.sym.ntx = floordiv_h(ex1 - 1 + a.sym.fx0, kW) - a.sym.tx0 + 1;
+    a.sym.nty = floordiv_h(ey1 - 1 + a.sym.fy0, kRows) - a.sym.ty0 + 1;
+}
+int sym_tiles(const FilterArgs &a) { return a.sym.ntx * a.sym.nty; }
+size_t sym_patch_floats(const FilterArgs &a, int n_parts) {
+    return (size_t)sym_tiles(a) * n_parts * (sym::kPatchP + (size_t)sym::q_rows_max(n_parts) * sym::kP) * 4;
+}
+
+// filter<float3>, radius 20, default spec, G-buffers = up to two RGB images (other sets: the one-sided kernel)
+bool sym_eligible(const FilterArgs &a, int channels) {
+    if (channels != 3 || a.radius != sym::kR || !fast_path_eligible(a, channels)) return false;
+    if (a.n_g > 2) return false;
+    for (int g = 0; g < a.n_g; g++)
+        if (a.g[g].channels != 3) return false;
+    return true;
+}
+
+hipError_t launch_sym(FilterArgs a, hipStream_t s) {
+    using namespace sym;
+    if (a.rx1 <= a.rx0 || a.ry1 <= a.ry0) return hipSuccess;
+    a.sym.item_stride4 = kPatchP + (long long)q_rows_max(a.n_parts) * kP;
+    // LDS-DMA staging needs whole 16-byte pieces: images 16-byte aligned, width and film x-origin multiples of 4 pixels
+    auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    bool dma = a.width % 4 == 0 && a.sym.fx0 % 4 == 0;
+    if (a.packed) dma = dma && al16(a.packed);
+    else dma = dma && al16(a.mean_corr) && al16(a.disc) && al16(a.colour) && (a.gscale0 == 0.f || al16(a.g[0].data)) &&
+               (a.gscale1 == 0.f || al16(a.g[1].data));
+    const void *kernel = dma ? reinterpret_cast<const void *>(&window_filter_sym<true>) : reinterpret_cast<const void *>(&window_filter_sym<false>);
+    static std::mutex mu;
+    static std::set<std::pair<int, const void *>> done;
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!done.count({dev, kernel})) {
+            if (hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e != hipSuccess) return e;
+            done.insert({dev, kernel});
+        }
+    }
+    if (dma) hipLaunchKernelGGL(window_filter_sym<true>, dim3(sym_tiles(a) * a.n_parts), dim3(kThreads), kLdsBytes, s, a);
+    else hipLaunchKernelGGL(window_filter_sym<false>, dim3(sym_tiles(a) * a.n_parts), dim3(kThreads), kLdsBytes, s, a);
+    const dim3 cgrid((a.rx1 - a.rx0 + 63) / 64, (a.ry1 - a.ry0 + 3) / 4);
+    hipLaunchKernelGGL(combine_sym_kernel, cgrid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace statmc

@@ -66,7 +66,7 @@ def test_filter_fullsize_properties(gpu, film1080):
     fs, _ = film1080
     colour = fs.state["radiance"]["film_mean"]
     f1 = wf(gpu, fs, colour, torch.zeros_like(colour)).clone()
-    assert gpu.last_filter_variant() == "lds_r20"
+    assert gpu.last_filter_variant() == "sym_r20"
     assert torch.isfinite(f1).all()
     # constant image is a fixed point (weights are normalised)
     const = torch.full_like(colour, 0.375)

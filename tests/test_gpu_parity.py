@@ -472,7 +472,8 @@ def stats_case(oracle, W, H, spp, seed):
 
 
 @pytest.mark.parametrize("W,H,radius,sd,force,variant", [
-    (300, 41, 20, 10.0, 0, "lds_r20"),     # shipped default; 2 tile columns, ragged right edge, 6 tile rows
+    (300, 41, 20, 10.0, 0, "sym_r20"),     # shipped default; 2 tile columns, ragged right edge, 11 tile rows
+    (300, 41, 20, 10.0, 3, "lds_r20"),     # the one-sided r = 20 kernel
     (300, 41, 20, 10.0, 2, "lds_rt"),
     (300, 41, 20, 10.0, 1, "generic"),
     (37, 21, 6, 3.0, 0, "lds_rt"),         # glass-caustics config; image smaller than one tile
@@ -500,7 +501,7 @@ def test_filter_window_sweep_parts(gpu, oracle, parts):
         out, v = run_filter(gpu, mc, disc, colour, gbs, G_DR, FILTER_SD, RADIUS)
     finally:
         gpu.force_filter_parts(0)
-    assert v == "lds_r20"
+    assert v == "sym_r20"
     assert max(rel_l2(out[..., c], ref[..., c]) for c in range(3)) <= TOL
 
 
@@ -509,7 +510,7 @@ def test_filter_low_spp_high_rejection(gpu, oracle):
     mc, disc, colour, gbs = stats_case(oracle, 280, 30, 4, seed=77)
     ref = oracle.filter_image(mc, disc, colour, gbs, G_DR, -0.5 / FILTER_SD ** 2, RADIUS)
     out, v = run_filter(gpu, mc, disc, colour, gbs, G_DR, FILTER_SD, RADIUS)
-    assert v == "lds_r20"
+    assert v == "sym_r20"
     assert max(rel_l2(out[..., c], ref[..., c]) for c in range(3)) <= TOL
 
 
@@ -526,7 +527,7 @@ def test_filter_special_pixels(gpu, oracle):
     disc[12, 60] = np.nan                                               # not even a member of itself
     ref = oracle.filter_image(mc, disc, colour, gbs, G_DR, -0.5 / FILTER_SD ** 2, RADIUS)
     assert np.array_equal(ref[12, 60], colour[12, 60])
-    for force in (0, 2, 1):
+    for force in (0, 3, 2, 1):
         out, v = run_filter(gpu, mc, disc, colour, gbs, G_DR, FILTER_SD, RADIUS, force=force)
         assert np.isfinite(out).all(), v
         assert np.array_equal(out[12, 60], colour[12, 60]), v
@@ -554,7 +555,7 @@ def test_filter_non_finite_corrected_mean(gpu, oracle):
         g_dr = [-0.5 / 0.3 ** 2, -0.5 / 0.2 ** 2]
         ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / FILTER_SD ** 2, radius)
         assert np.array_equal(ref[0, 0], colour[0, 0])                  # filters nothing: its own colour
-        for force in (0, 2, 1):
+        for force in (0, 3, 2, 1):
             out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, FILTER_SD, radius, force=force)
             assert np.isfinite(out).all(), v
             assert np.array_equal(out[0, 0], colour[0, 0]), v
@@ -637,7 +638,7 @@ def test_filter_generic_gbuffer_sets(gpu, oracle, channels):
     gbs2, dr2 = [gbs[1], gbs[0]], [g_dr[1], g_dr[0]]
     ref2 = oracle.filter_image(mc, disc, colour, gbs2, dr2, -0.5 / 100.0, 20)
     out2, v2 = run_filter(gpu, mc, disc, colour, gbs2, dr2, 10.0, 20, channels=channels)
-    assert v2 == ("lds_r20" if channels == 3 else "lds_r20_f") and rel_l2(out2, ref2) <= TOL
+    assert v2 == ("sym_r20" if channels == 3 else "lds_r20_f") and rel_l2(out2, ref2) <= TOL
     # seven channels do not fit
     gbs7 = [gbs[0], rng.random((H, W, 3), dtype=np.float32), gbs[1]]
     ref7 = oracle.filter_image(mc, disc, colour, gbs7, g_dr, -0.5 / 16.0, r)
@@ -664,7 +665,7 @@ def test_filter_fewer_gbuffers_on_the_lds_kernel(gpu, oracle, channels, n_g):
     g_dr = [-0.5 / 0.2 ** 2][:n_g]
     ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / FILTER_SD ** 2, r)
     out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, FILTER_SD, r, channels=channels)
-    assert v == ("lds_r20" if channels == 3 else "lds_r20_f")
+    assert v == ("sym_r20" if channels == 3 else "lds_r20_f")
     for c in range(channels):
         assert rel_l2(out[..., c], ref[..., c]) <= TOL
     out_g, v_g = run_filter(gpu, mc, disc, colour, gbs, g_dr, FILTER_SD, r, channels=channels, force=1)
@@ -797,7 +798,7 @@ def test_packed_inputs_path(gpu, oracle):
                                      filter_sd=FILTER_SD, radius=RADIUS, roi=(m, m, W - m, H - m), packed=packed)
     gpu.window_filter(a2, 3)
     torch.cuda.synchronize()
-    assert gpu.last_filter_variant() == "lds_r20"
+    assert gpu.last_filter_variant() == "sym_r20"
     got = out.cpu().numpy()
     assert max(rel_l2(got[..., c], ref[..., c]) for c in range(3)) <= TOL
     assert not got[:m].any() and not got[:, :m].any()
@@ -1003,7 +1004,7 @@ def test_filter_spec_r20_and_float(gpu, oracle, spec_kw, channels):
     mc, dc, out, variant, (omc, odc, oout) = run_spec(gpu, oracle, st, spec_kw, radius=RADIUS, sd=FILTER_SD, channels=channels)
     assert np.array_equal(dc, odc, equal_nan=True)
     fast = not (spec_kw.get("gate") or spec_kw.get("channel_rule") or spec_kw.get("dof") or spec_kw.get("border"))
-    assert variant == (("lds_r20" if channels == 3 else "lds_r20_f") if fast else "generic")
+    assert variant == (("sym_r20" if channels == 3 else "lds_r20_f") if fast else "generic")
     for c in range(channels):
         assert rel_l2(out[..., c], oout[..., c]) <= TOL, c
 
@@ -1046,7 +1047,7 @@ def test_filter_non_finite_colour(gpu, oracle):
         ref = oracle.filter_image(mc, disc, colour, gbs, G_DR, -0.5 / sd ** 2, radius)
         bad = ~np.isfinite(ref)
         assert bad.sum() == 1 + 3 + 3 + 1    # only the pixels themselves
-        for force in (0, 2, 1):
+        for force in (0, 3, 2, 1):
             out, v = run_filter(gpu, mc, disc, colour, gbs, G_DR, sd, radius, force=force)
             assert np.array_equal(~np.isfinite(out), bad), v
             ok = ~bad
