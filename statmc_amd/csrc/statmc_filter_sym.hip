@@ -57,8 +57,8 @@ namespace sym {
 constexpr int kAblate = STATMC_SYM_ABLATE;  // 1 no q side, 2 no row staging, 4 no flush, 8 no sweep arithmetic, 16 no barrier
 constexpr int kR = 20;
 constexpr int kPx = 4;                    // pixels per lane
-constexpr int kW = 64 * kPx;              // 256 tile columns
-constexpr int kRows = 4;                  // tile rows (two waves each)
+constexpr int kW = 32 * kPx;              // 128 tile columns: half a wave per row
+constexpr int kRows = 8;                  // tile rows: wave (t, h) owns rows t (lanes 0-31) and t + 4 (lanes 32-63)
 constexpr int kSlots = kRows + 1;         // LDS row ring
 constexpr int kP = kW + 2 * kR;           // 296 staged columns per row
 constexpr int kIn = 15;                   // input planes per row
@@ -71,16 +71,16 @@ constexpr int kTabPad = 2 * (kTabW + 1);  // LDS copy: pairs (tab[t], tab[t+1])
 constexpr int kChunks = 2 * kR / 4 + 1;   // 11 read groups per window row
 constexpr int kMid = kChunks / 2;         // 5: the group that holds dx = 0
 constexpr int kPatchP = kRows * kW;       // float4 per patch: p-side piece
-// LDS-DMA staging: every wave fetches and stages its own 40 of the 296 columns of a row (wave 7: the last 16), five
-// RGB images (or one 15-float AoS image) = 150 pieces of 16 B per wave and row, landing in a wave-private raw area
-constexpr int kWaveCols = 40;
-constexpr int kRawFloats = kWaveCols * 15;                  // 600 floats = 150 pieces per wave
+// LDS-DMA staging: waves 0..6 each fetch and stage their own 24 of the 168 columns of a row, five RGB images (or
+// one 15-float AoS image) = 90 pieces of 16 B per wave and row, landing in a wave-private raw area
+constexpr int kWaveCols = 24;                               // 7 x 24 = 168 columns; wave 7 stages none
+constexpr int kRawFloats = kWaveCols * 15;                  // 360 floats = 90 pieces per wave
 constexpr int kRawTotal = 8 * kRawFloats;
 constexpr size_t kLdsBytes = (size_t)(kSlots * kSlotFloats + 2 * kTabPad + kRawTotal) * sizeof(float);
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 
 __host__ __device__ inline int step_lo(int part, int n_parts) { return (kSteps * part) / n_parts; }
-__host__ __device__ inline int q_rows_max(int n_parts) { return (kSteps + n_parts - 1) / n_parts + 3; }  // rows s_a .. s_b+2
+__host__ __device__ inline int q_rows_max(int n_parts) { return (kSteps + n_parts - 1) / n_parts + kRows - 1; }  // rows s_a .. s_b+6
 
 // The lane's own 4 pixels.  Their values enter the packed instructions as broadcasts of ONE half of a register
 // pair (op_sel), so two different scalars share every pair: 6 + 6 + 4 pairs per pixel instead of 15 + 15
@@ -318,7 +318,7 @@ __device__ __forceinline__ void dma_row(const FilterArgs &a, float *raw_w, int l
     if (yrow < 0 || yrow >= a.height) return;
     const int per_img = ncols * 3 / 4, total = 5 * per_img;
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
+    for (int j = 0; j < 2; j++) {
         const int idx = 64 * j + lane;
         if (idx < total) {
             const float *src;
@@ -376,7 +376,9 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int trow = wave & 3, half = wave >> 2;
+    const int lane32 = lane & 31;                       // 4-pixel column group of the lane inside its row
+    const int trow = (wave & 3) + 4 * (lane >> 5);      // lower / upper half of the wave: rows t and t + 4
+    const int half = wave >> 2;
     const float k0 = a.gscale0, k1 = a.gscale1;
     constexpr int tw = kTabW;
 
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     const int pyc = min(max(py, 0), a.height - 1);
 #pragma unroll
     for (int k = 0; k < kPx; k++) {
-        const int px = x0 + kPx * lane + k;
+        const int px = x0 + kPx * lane32 + k;
         const int pxc = min(max(px, 0), a.width - 1);
         const long long p = (long long)pyc * a.width + pxc;
         f3 mc, d, g0, g1, col;
@@ -420,12 +422,12 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     // wave-local staging geometry (DMA): this wave's columns of every staged row
     float *raw_w = tab_lds + 2 * kTabPad + wave * kRawFloats;
     const int wcol0 = kWaveCols * wave;                                // first staged column (0..295) of the wave
-    const int ncols = min(kWaveCols, kP - wcol0);                     // 40, wave 7: 16
+    const int ncols = max(0, min(kWaveCols, kP - wcol0));             // 24, wave 7: 0
     if (s_a < s_b) {
         if constexpr (DMA) {   // the first row the sweep will need beyond the prologue: on its way during the prologue
             if (s_a + 1 < s_b && !(kAblate & 2)) dma_row(a, raw_w, lane, x0 - kR + wcol0, y0 + s_a + kRows, ncols);
         }
-        // ---- prologue: rows rel = s_a .. s_a+3 (image rows y0 + rel) into slots rel % 5
+        // ---- prologue: rows rel = s_a .. s_a+7 (image rows y0 + rel) into slots rel % 9
         for (int idx2 = threadIdx.x; idx2 < kRows * kP; idx2 += kThreads) {
             const int rr = idx2 / kP, i = idx2 - rr * kP;
             const int rel = s_a + rr;
@@ -475,9 +477,9 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
                 tnext = v2f{t[0], ti + 1 < tw ? t[1] : 0.f};
             }
 
-            float *slot = lds + ((s + trow) % kSlots) * kSlotFloats;
-            const float *row = slot + kPx * lane;
-            float *qrow = slot + (kIn + 4 * half) * kP + kPx * lane;
+            float *slot = lds + ((s + trow) % kSlots) * kSlotFloats;   // per lane: the two halves of a wave differ
+            const float *row = slot + kPx * lane32;
+            float *qrow = slot + (kIn + 4 * half) * kP + kPx * lane32;
             const float *tab = tab_lds + ((s - s_a) & 1) * kTabPad;
             if (kAblate & 8) {
             } else if (half == 0) {
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             }
             if (!(kAblate & 16)) __syncthreads();
         }
-        // ---- the rows still in the ring: rel = s_b-1 .. s_b+2
+        // ---- the rows still in the ring: rel = s_b-1 .. s_b+6
         for (int idx2 = threadIdx.x; idx2 < kRows * kP; idx2 += kThreads) {
             const int rr = idx2 / kP, i = idx2 - rr * kP;
             const int rel = s_b - 1 + rr;
@@ -503,11 +505,11 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     }
 
     // ---- p side: half 1 hands its sums to half 0 through LDS, half 0 writes the patch
-    float *ex = lds;  // [trow][v][256]
+    float *ex = lds;  // [trow][v][kW]
     if (half == 1) {
 #pragma unroll
         for (int k = 0; k < kPx; k++) {
-            float *e = ex + trow * 4 * kW + kPx * lane + k;
+            float *e = ex + trow * 4 * kW + kPx * lane32 + k;
             e[0 * kW] = st.acc[k][0].x + st.acc[k][0].y;
             e[1 * kW] = st.acc[k][1].x + st.acc[k][1].y;
             e[2 * kW] = st.acc[k][2].x + st.acc[k][2].y;
@@ -518,8 +520,8 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     if (half == 0) {
 #pragma unroll
         for (int k = 0; k < kPx; k++) {
-            const float *e = ex + trow * 4 * kW + kPx * lane + k;
-            patch[trow * kW + kPx * lane + k] =
+            const float *e = ex + trow * 4 * kW + kPx * lane32 + k;
+            patch[trow * kW + kPx * lane32 + k] =
                 make_float4((st.acc[k][0].x + st.acc[k][0].y) + e[0 * kW], (st.acc[k][1].x + st.acc[k][1].y) + e[1 * kW],
                             (st.acc[k][2].x + st.acc[k][2].y) + e[2 * kW], (st.sw[k].x + st.sw[k].y) + e[3 * kW]);
         }
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(256) void combine_sym_kernel(FilterArgs a) {
                     const float4 v = patch[rel * kW + (X - kW * Tx)];
                     t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
                 }
-                if (rel >= q_first && rel < s_b + 3) {
+                if (rel >= q_first && rel < s_b + kRows - 1) {
                     const float4 v = patch[kPatchP + (long long)(rel - q_first) * kP + c];
                     t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
                 }
