@@ -172,6 +172,7 @@ bool sym_eligible(const FilterArgs &a, int channels);
 bool sym_path_selected(const FilterArgs &a, int channels);   // eligible and not overridden
 void sym_geometry(FilterArgs &a);                            // fills a.sym.tx0 .. nty from the ROI and film origin
 int sym_tiles(const FilterArgs &a);
+int sym_choose_parts(int tiles, int n_cus);
 int sym_filter_parts(const FilterArgs &a, int n_cus);
 size_t sym_patch_floats(const FilterArgs &a, int n_parts);
 hipError_t launch_sym(FilterArgs a, hipStream_t s);

@@ -683,7 +683,7 @@ bool sym_path_selected(const FilterArgs &a, int channels) {
 int sym_filter_parts(const FilterArgs &a, int n_cus) {
     const int forced = g_parts_override;
     if (forced > 0) return forced < 21 ? forced : 21;
-    return choose_parts(sym_tiles(a), 21, n_cus);
+    return sym_choose_parts(sym_tiles(a), n_cus);
 }
 
 // Where the ROI is cut: columns [rx0, split) go to regular 256-wide tiles, [split, rx1) -- at most half

@@ -587,6 +587,22 @@ void sym_geometry(FilterArgs &a) {
     a.sym.nty = floordiv_h(ey1 - 1 + a.sym.fy0, kRows) - a.sym.ty0 + 1;
 }
 int sym_tiles(const FilterArgs &a) { return a.sym.ntx * a.sym.nty; }
+
+// Parts per tile: the grid runs one workgroup per CU, so its makespan is ceil(items / CUs) rounds of 21 / parts steps
+// each, plus what an item pays before its first step (prologue: 8 rows staged, measured at about 2.5 steps).
+int sym_choose_parts(int tiles, int n_cus) {
+    int best = 1;
+    double best_cost = 1e30;
+    for (int k = 1; k <= 8; k++) {
+        const double rounds = (double)(((long long)tiles * k + n_cus - 1) / n_cus);
+        const double cost = rounds * ((double)sym::kSteps / k + 2.5);
+        if (cost < best_cost * 0.98) {
+            best_cost = cost;
+            best = k;
+        }
+    }
+    return best;
+}
 size_t sym_patch_floats(const FilterArgs &a, int n_parts) {
     return (size_t)sym_tiles(a) * n_parts * (sym::kPatchP + (size_t)sym::q_rows_max(n_parts) * sym::kP) * 4;
 }

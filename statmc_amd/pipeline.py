@@ -44,10 +44,13 @@ class BlockPipeline:
             self.fs.window_filter()
             return self.fs.film_f
         L = self.layout
+        ox, oy = L.origin
+        # film_origin: the filter's work tiles sit on a grid fixed in film coordinates, so every pixel's sums are
+        # formed in the same order as in a whole-film run (bit-identical results, tests/test_multirank_gpu.py)
         a, keep = api.make_filter_args(
             n=[], mean=[], m2=[], m3=[], film=[], mean_corr=[], disc=[], film_filtered=[self.out_pad],
             g_buffers=[], g_sds=self.fs.g_sds, filter_sd=self.filter_sd, radius=self.radius, roi=L.roi,
-            packed=self.packed)
+            packed=self.packed, film_origin=(ox - L.pl, oy - L.pt))
         api.window_filter(a, 3)
         return L.interior(self.out_pad)
 

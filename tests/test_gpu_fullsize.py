@@ -144,7 +144,7 @@ def check_strips(gpu, oracle, fs, rois, also_generic=True):
     colour = fs.state["radiance"]["film_mean"]
     whole = wf(gpu, fs, colour, torch.zeros_like(colour)).clone()
     variant = gpu.last_filter_variant()
-    assert variant.startswith("lds"), variant
+    assert variant == "sym_r20", variant
     assert torch.isfinite(whole).all()
     for roi in rois:
         x0, y0, x1, y1 = roi
