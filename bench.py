@@ -11,8 +11,10 @@ with every input already resident in HBM when the timed region starts.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 1920x1080 film,
 256 spp, 11-channel sample stream, shipped filter parameters (filtersd 10, filterradius 20,
-normal sd 0.1, albedo sd 0.02).  For N > 1 every rank owns one 1920x1080 block of an
-N-block film (1xN row strips by default, --grid blocks for 2x1 / 2x2 / 4x2) -- weak scaling, value = all blocks' pixels / step time.
+normal sd 0.1, albedo sd 0.02).  For N > 1 the SAME film is cut into N blocks (1xN row strips by
+default -- 1920x540, 1920x270, 1920x135 -- or --grid blocks for 2x1 / 2x2 / 4x2: 960x1080, 960x540,
+480x540), one per rank: strong scaling, value = film pixels / step time ("1920x1080 @1/2/4/8 GPU").
+--film 3840x2160 is configs[4]'s film; --scaling weak gives every rank its own --film-sized block instead.
 
 Prints ONE JSON line (rank 0).
 """
@@ -48,10 +50,13 @@ def accumulate_bytes_per_px(spp, types):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=300, help="default: about 2 s of timed work on one GPU")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--film", default=None, help="WxH of the film (default 1920x1080; 3840x2160 = BASELINE configs[4])")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"),
+                    help="N > 1: strong = one film cut into N blocks (default); weak = one film-sized block per rank")
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--radius", type=int, default=20)
     ap.add_argument("--filtersd", type=float, default=10.0)
@@ -64,7 +69,11 @@ def parse():
                     help="gloo (+ --share-device) exercises the N > 1 code path on a 1-GPU box; halos go via the host")
     ap.add_argument("--share-device", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--cpu-acc-rows", type=int, default=32, help="rows of the film the CPU baseline accumulates")
-    return ap.parse_args()
+    ap.add_argument("--no-host-legs", action="store_true", help="skip the secondary host-side measurements (N = 1)")
+    args = ap.parse_args()
+    if args.film:
+        args.width, args.height = (int(v) for v in args.film.lower().split("x"))
+    return args
 
 
 def cpu_baseline(args, fs, samples, types, budget_s=7.0):
@@ -154,41 +163,157 @@ def cpu_baseline(args, fs, samples, types, budget_s=7.0):
     }
 
 
+def numa_facts(dev_index):
+    """Where the GPU and this process sit: a pinned buffer on the far socket is what a 10x slower Upload looks like."""
+    out = {}
+    try:
+        import glob
+        bus = torch.cuda.get_device_properties(dev_index).pci_bus_id if hasattr(torch.cuda.get_device_properties(dev_index), "pci_bus_id") else None
+        nodes = {}
+        for pth in glob.glob("/sys/bus/pci/devices/*/numa_node"):
+            d = os.path.basename(os.path.dirname(pth))
+            try:
+                cls = open(os.path.join(os.path.dirname(pth), "class")).read().strip()
+            except OSError:
+                continue
+            if cls.startswith("0x0302") or cls.startswith("0x0380") or cls.startswith("0x1200"):   # display / accelerators
+                nodes[d] = int(open(pth).read().strip())
+        out["gpu_numa_nodes"] = nodes
+        out["pci_bus_id"] = bus
+        out["process_cpus"] = len(os.sched_getaffinity(0))
+        cur = open("/proc/self/stat").read().split()[38]
+        out["cpu_now"] = int(cur)
+        for n in glob.glob("/sys/devices/system/node/node*/cpulist"):
+            out.setdefault("node_cpulists", {})[os.path.basename(os.path.dirname(n))] = open(n).read().strip()
+    except Exception as e:                                      # diagnostics only
+        out["error"] = repr(e)
+    return out
+
+
 def host_copy_times(fs, dev):
     """What the reference's `CUDA time` bracket adds when statistics are produced on the host
     (statpath.cpp:409-417): Upload() of the 7 filter inputs (76 B/px) and Download() of film-f
-    (12 B/px), pinned host memory, through statmc_upload / statmc_download.  Never part of `value`."""
+    (12 B/px) through statmc_upload / statmc_download from buffers of statmc_malloc_host (page-locked by the
+    library, written once before timing so that every page exists).  Best and median of 7.  Never part of `value`."""
     import ctypes as C
     from statmc_amd import api
     lib = api.load()
     rad = fs.state["radiance"]
     ups = [rad["film_mean"], rad["n"], rad["mean"], rad["m2"], rad["m3"], fs.g_buffer("normal"), fs.g_buffer("albedo")]
-    host_up = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in ups]
-    host_dn = torch.empty(fs.film_f.shape, dtype=torch.float32).pin_memory()
     stream = api.current_stream_handle()
+    host = []
+    for t in ups + [fs.film_f]:
+        p = C.c_void_p()
+        api.check(lib.statmc_malloc_host(C.byref(p), t.numel() * 4))
+        C.memset(p, 1, t.numel() * 4)
+        host.append(p)
 
     def upload():
-        for h, d in zip(host_up, ups):
-            api.check(lib.statmc_upload(C.c_void_p(d.data_ptr()), C.c_void_p(h.data_ptr()), h.numel() * 4, stream))
+        for h, d in zip(host[:-1], ups):
+            api.check(lib.statmc_upload(C.c_void_p(d.data_ptr()), h, d.numel() * 4, stream))
 
     def download():
-        api.check(lib.statmc_download(C.c_void_p(host_dn.data_ptr()), C.c_void_p(fs.film_f.data_ptr()), host_dn.numel() * 4, stream))
+        api.check(lib.statmc_download(host[-1], C.c_void_p(fs.film_f.data_ptr()), fs.film_f.numel() * 4, stream))
 
+    keep = [t.clone() for t in ups]                      # the uploads overwrite the statistics: put them back after
     out = {}
-    for name, fn, nbytes in (("upload", upload, sum(h.numel() * 4 for h in host_up)), ("download", download, host_dn.numel() * 4)):
-        for h in host_up:
-            h.zero_()
+    for name, fn, nbytes in (("upload", upload, sum(t.numel() * 4 for t in ups)), ("download", download, fs.film_f.numel() * 4)):
         fn()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
+        times = []
+        for _ in range(7):
+            t0 = time.perf_counter()
             fn()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 3 * 1e3
-        out[name + "_ms"] = round(ms, 3)
-        out[name + "_GBs"] = round(nbytes / ms / 1e6, 1)
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1e3)
+        times.sort()
+        out[name + "_ms"] = round(times[0], 3)
+        out[name + "_ms_median"] = round(times[len(times) // 2], 3)
+        out[name + "_GBs"] = round(nbytes / times[0] / 1e6, 1)
         out[name + "_bytes_per_px"] = nbytes // (fs.width * fs.height)
+    for t, k in zip(ups, keep):
+        t.copy_(k)
+    torch.cuda.synchronize()
+    for h in host:
+        lib.statmc_free_host(h)
+    out["numa"] = numa_facts(dev.index or 0)
     return out
+
+
+def host_bracket(fs, args):
+    """The reference's own metric for this path: the `CUDA time [ns]` bracket = Upload + Denoise + Download +
+    Synchronize (statpath.cpp:409-417, 520-527), through the C++ host side (statmc::Estimator, the thing a pbrt build
+    links): the statistics are written as a dump and tools/bin/statmc_denoise runs the bracket on it (one warm-up,
+    four timed iterations).  Secondary: never part of `value`."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from statmc_amd import build, pfm
+    exe = build.build_tools()
+    rad = fs.state["radiance"]
+    d = tempfile.mkdtemp(prefix="statmc_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        stem = os.path.join(d, "scene")
+        dump = {"film": rad["film_mean"], "t0-b0-n": rad["n"], "t0-b0-mean": rad["mean"], "t0-b0-m2": rad["m2"],
+                "t0-b0-m3": rad["m3"], "t1-b0-film-mean": fs.g_buffer("normal"), "t2-b0-film-mean": fs.g_buffer("albedo")}
+        for name, img in dump.items():
+            pfm.write_pfm("%s-%d-%s.pfm" % (stem, args.spp, name), img.cpu().numpy())
+        out = subprocess.run([exe, "--stem", stem, "--spp", ",".join([str(args.spp)] * 4), "--filtersd", str(args.filtersd),
+                              "--filterradius", str(args.radius), "--warmup", "--output", "film-f"],
+                             capture_output=True, text=True, timeout=300)
+        if out.returncode != 0:
+            return {"error": out.stderr.strip()[-300:]}
+        ns = [int(v) for v in re.findall(r"HIP time \[ns\]: (\d+)", out.stdout)][1:]     # drop the warm-up
+        ns.sort()
+        return {"cuda_time_bracket_ms": round(ns[0] / 1e6, 3), "median_ms": round(ns[len(ns) // 2] / 1e6, 3),
+                "iterations": len(ns), "what": "Estimator::Upload (76 B/px) + Denoise + Download (12 B/px) + Synchronize, "
+                                               "C++ host side (tools/bin/statmc_denoise), page-locked host images"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def tile_fed_accumulate(fs, samples, types, spp_cap=64):
+    """The accumulation fed the way Render<T> produces samples: 16 x 16 tile blocks through statmc_accumulate_tiles
+    (Estimator::Merge[Transform]Tiles).  GB/s on the same byte count as the film-major kernel.  Secondary."""
+    from statmc_amd import api, film
+    W, H, dev = fs.width, fs.height, fs.device
+    if W % 16:
+        return {"skipped": "film width is not a multiple of the 16-pixel tile"}
+    S = min(spp_cap, next(iter(samples.values())).shape[0])
+    tiles = [(x, y, min(x + 16, W), min(y + 16, H)) for y in range(0, H, 16) for x in range(0, W, 16)]
+    bounds = torch.tensor(tiles, dtype=torch.int32, device=dev)
+    npx = torch.tensor([(x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in tiles], dtype=torch.int64)
+    offs = torch.cumsum(npx * S, 0) - npx * S
+    st2 = film.FilmStats(W, H, dev, types=types)
+    sts, keep = [], []
+    for t in types:
+        c = film.STAT_TYPES[t]["channels"]
+        src = samples[t][:S]
+        # [S, H, W, C] -> per tile [S, th, tw, C]: full 16-row bands by reshape, the ragged last band by hand
+        arena = torch.empty(int((npx * S).sum()) * c, device=dev)
+        pos = 0
+        for y in range(0, H, 16):
+            th = min(16, H - y)
+            band = src[:, y:y + th].reshape(S, th, W // 16, 16, c).permute(2, 0, 1, 3, 4).contiguous().reshape(-1)
+            arena[pos:pos + band.numel()] = band
+            pos += band.numel()
+        keep.append(arena)
+        sts.append(api.make_stat_type_arena(arena, c, st2.state[t], film.STAT_TYPES[t]["transform"], film.STAT_TYPES[t]["max_moment"]))
+    offs_d = offs.to(dev)
+    cnt = torch.full((len(tiles),), S, dtype=torch.int32, device=dev)
+    api.accumulate_tiles(W, H, sts, bounds, offs_d, cnt)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        api.accumulate_tiles(W, H, sts, bounds, offs_d, cnt)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    bpp = accumulate_bytes_per_px(S, types)
+    return {"spp": S, "avg_ms": round(ms, 4), "bytes_per_px": bpp, "achieved_GBs": round(bpp * W * H / ms / 1e6, 1),
+            "frac_hbm": round(bpp * W * H / ms / 1e6 / HBM_PEAK_GBS, 4)}
 
 
 def main():
@@ -216,9 +341,15 @@ def main():
     from statmc_amd import api, film, pipeline, sharding, synthetic
     api.setup(local_rank)
 
-    W, H, S, r = args.width, args.height, args.spp, args.radius
+    S, r = args.spp, args.radius
     types = list(synthetic.FEATURES) if args.channels == 11 else ["radiance", "normal", "albedo"]
     grid = sharding.row_strips(world) if args.grid == "rows" else sharding.grid_for(world)
+    if args.scaling == "strong":        # one film, N blocks
+        if args.width % grid[0] or args.height % grid[1]:
+            raise SystemExit("film %dx%d does not split into a %dx%d grid of equal blocks" % (args.width, args.height, *grid))
+        W, H = args.width // grid[0], args.height // grid[1]
+    else:                               # one film-sized block per rank
+        W, H = args.width, args.height
     layout = sharding.BlockLayout(rank, world, W, H, r, grid=grid)
     fw, fh = layout.film_size
     ox, oy = layout.origin
@@ -279,7 +410,7 @@ def main():
     ms = {k: (sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1)) for k, v in k_events.items()}
     px_block = W * H
     ms_per_step = elapsed * 1e3 / args.steps
-    value = world * px_block * args.steps / elapsed / 1e6
+    value = fw * fh * args.steps / elapsed / 1e6       # whole job: every block's pixels per step time
 
     result = None
     if rank == 0:
@@ -288,10 +419,12 @@ def main():
         acc_gbs = acc_bpp * px_block / (ms["accumulate"] * 1e-3) / 1e9
         pre_gbs = PREPASS_BYTES_PER_PX * px_block / (ms["prepass"] * 1e-3) / 1e9
         taps = (2 * r + 1) ** 2
-        # fp32 VALU work of the window filter: 20 instructions per (tap, pixel) pair, 9 of them
-        # packed (v_pk_*_f32 = 2 issue slots) and one v_exp_f32 (quarter rate): 33 slots
-        valu_slots = 33.0 * taps * px_block / 64.0
-        valu_rate = valu_slots / (ms["filter"] * 1e-3) / 1e12
+        # fp32 VALU work of the window filter in lane-operations (a packed op = 2, v_exp_f32 = 4: quarter rate).
+        # Pair-symmetric kernel: every unordered pair once, 29 for weight + gate and 4 + 4 for the two accumulations
+        # = 37 per pair; one-sided kernels: 33 per directed tap.
+        sym = variant.startswith("sym")
+        lane_ops = (37.0 * (taps - 1) / 2 + 33.0) if sym else 33.0 * taps
+        valu_rate = lane_ops * px_block / (ms["filter"] * 1e-3) / 1e12
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         # the committed PMC traffic figures were collected on the default workload only
@@ -304,12 +437,12 @@ def main():
         result = {
             "metric": "denoised_mpixels_per_s", "value": round(value, 3), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "StatMC accumulate+prepass+filter, %dx%d block/GPU, %d spp, %d-channel samples, "
+                "workload": "StatMC accumulate+prepass+filter, %dx%d film in %d block(s) of %dx%d, %d spp, %d-channel samples, "
                             "filterradius %d, filtersd %g, G-buffers normal(sd 0.1)+albedo(sd 0.02) "
-                            "[BASELINE.json configs[2] shape, synthetic stream]" % (W, H, S, args.channels, r, args.filtersd),
+                            "[BASELINE.json configs[2] shape, synthetic stream]" % (fw, fh, world, W, H, S, args.channels, r, args.filtersd),
                 "film": "%dx%d" % (fw, fh), "block_grid": "%dx%d" % (layout.gx, layout.gy),
                 "spp": S, "sample_channels": args.channels, "filter_variant": variant,
                 "parallelism": "film blocks x%d, RCCL halo exchange" % world if world > 1 else "single GPU",
@@ -327,15 +460,16 @@ def main():
             # (2r+1)^2-tap fp32 stencil -- bound by VALU issue, not by HBM -- so its fraction of the fp32
             # VALU peak is given next to the (necessarily small) HBM fraction.
             "roofline_filter": {
-                "kernel": "window_filter_lds<%d> + combine_parts_kernel (%s)" % (r, variant), "bound": "hbm",
+                "kernel": ("window_filter_sym + combine_sym_kernel (%s)" if sym else "window_filter_lds<%d> + combine_parts_kernel (%%s)" % r) % variant,
+                "bound": "hbm",
                 "achieved": round(flt_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(flt_gbs / HBM_PEAK_GBS, 5),
-                "traffic": traffic.get("window_filter_lds"),
+                "traffic": traffic.get("window_filter_sym" if sym else "window_filter_lds"),
                 "algorithmic_bytes_per_launch": FILTER_BYTES_PER_PX * px_block, "bytes_per_px": FILTER_BYTES_PER_PX,
                 "avg_launch_ms": round(ms["filter"], 4),
-                "valu": {"achieved": round(valu_rate, 2), "peak": VALU_PEAK_TOPS, "unit": "T wave-slots x64 lanes/s",
-                         "frac": round(valu_rate / VALU_PEAK_TOPS * 64.0, 4),
-                         "note": "33 issue slots per (tap, pixel) pair; peak = 256 CU x 4 SIMD x 1 slot / 2 cycles x 2.4 GHz x 64 lanes"},
+                "valu": {"achieved": round(valu_rate, 2), "peak": VALU_PEAK_TOPS, "unit": "T fp32 lane-ops/s",
+                         "frac": round(valu_rate / VALU_PEAK_TOPS, 4), "lane_ops_per_px": round(lane_ops, 1),
+                         "note": "peak = 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz; a packed op counts 2, v_exp_f32 4"},
             },
             "kernels": {
                 "accumulate": {"avg_ms": round(ms["accumulate"], 4), "bytes_per_px": acc_bpp,
@@ -346,7 +480,11 @@ def main():
                 "filter": {"avg_ms": round(ms["filter"], 4), "mpixels_per_s": round(px_block / ms["filter"] / 1e3, 2)},
             },
         }
-        if world == 1:
+        if world == 1 and not args.no_host_legs:
+            # secondary measurements, outside `value`: the reference's own `CUDA time` bracket through the C++ host
+            # side, the tile-fed accumulation, and the raw host <-> device copy rates
+            result["cuda_time_bracket"] = host_bracket(fs, args)
+            result["tile_fed_accumulate"] = tile_fed_accumulate(fs, samples, types)
             result["host_copies"] = host_copy_times(fs, dev)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, fs, samples, types)

@@ -69,13 +69,27 @@ inline int channelsOf(ImageType t) { return t == F32C3 ? 3 : 1; }
 class HostImage {
   public:
     HostImage() = default;
-    HostImage(int rows, int cols, ImageType type)
-        : rows(rows), cols(cols), type(type),
-          store(std::make_shared<std::vector<uint32_t>>((size_t)rows * cols * channelsOf(type), 0u)) {}
+    // Page-locked when the HIP runtime can provide it (Upload / Download then run at the full PCIe rate and stay
+    // asynchronous on the stream, which pageable cv::Mat storage does not); plain zeroed memory otherwise, e.g. when
+    // the buffer catalogue is inspected on a machine without a GPU.
+    HostImage(int rows, int cols, ImageType type) : rows(rows), cols(cols), type(type) {
+        const size_t n = (size_t)rows * cols * channelsOf(type) * 4;
+        void *p = nullptr;
+        if (n && statmc_malloc_host(&p, n) == STATMC_OK && p) {
+            std::memset(p, 0, n);
+            store = std::shared_ptr<void>(p, [](void *q) { statmc_free_host(q); });
+            pinned_ = true;
+        } else {
+            p = std::calloc(n ? n : 1, 1);
+            if (!p) throw std::bad_alloc();
+            store = std::shared_ptr<void>(p, [](void *q) { std::free(q); });
+        }
+    }
     int channels() const { return channelsOf(type); }
     size_t bytes() const { return (size_t)rows * cols * channels() * 4; }
     bool empty() const { return !store; }
-    void *ptr() const { return store ? store->data() : nullptr; }
+    bool pinned() const { return pinned_; }
+    void *ptr() const { return store.get(); }
     template <class T>
     T *ptr() const { return reinterpret_cast<T *>(ptr()); }
     bool sameStorage(const HostImage &o) const { return store == o.store; }
@@ -83,7 +97,8 @@ class HostImage {
     ImageType type = F32C1;
 
   private:
-    std::shared_ptr<std::vector<uint32_t>> store;
+    std::shared_ptr<void> store;
+    bool pinned_ = false;
 };
 
 class Stream {
