@@ -702,7 +702,21 @@ int statmc_debug_accumulate_resident_blocks(int n) {  // 0 large grid (default),
     g_accumulate_resident_blocks = n < 0 ? 0 : n;
     return STATMC_OK;
 }
-int statmc_debug_last_filter_parts(void) { return g_last_parts; }  // parts per tile of this thread's last window filter
+int statmc_debug_last_filter_parts(void) { return g_last_parts; }
+// the partial-sum / patch workspace of the calling thread's current device and stream 0 (diagnostic builds read it back)
+int statmc_debug_last_workspace(void **ptr, size_t *bytes) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    *ptr = nullptr;
+    *bytes = 0;
+    for (auto &kv : g_ws)
+        if (kv.first.dev == dev && kv.second.bytes > *bytes) {
+            *ptr = kv.second.ptr;
+            *bytes = kv.second.bytes;
+        }
+    return STATMC_OK;
+}  // parts per tile of this thread's last window filter
 int statmc_debug_force_filter_parts(int k) {  // 0 auto, k >= 1: window-sweep parts per tile
     statmc::set_filter_parts_override(k);
     return STATMC_OK;

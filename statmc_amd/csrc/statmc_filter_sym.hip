@@ -54,6 +54,24 @@
 namespace statmc {
 namespace sym {
 
+#ifndef STATMC_SYM_HK_END
+#define STATMC_SYM_HK_END 0
+#endif
+constexpr bool kHkAtEnd = STATMC_SYM_HK_END;   // experiment: per-step housekeeping after the sweep instead of before
+// diagnostic build (tools/experiments/stamps_sym.py): every wave sums the shader clocks it spends per step in
+// housekeeping / sweep / barrier and leaves them in the last float4s of its item's patch.  Never in the product.
+#ifndef STATMC_SYM_PIPE
+#define STATMC_SYM_PIPE 0
+#endif
+#ifndef STATMC_SYM_STAMPS
+#define STATMC_SYM_STAMPS 0
+#endif
+constexpr bool kStamps = STATMC_SYM_STAMPS;
+constexpr bool kPipe = STATMC_SYM_PIPE;
+#ifndef STATMC_SYM_SPLIT
+#define STATMC_SYM_SPLIT 0
+#endif
+constexpr int kSplit = STATMC_SYM_SPLIT;   // window half 0 sweeps dx <= kSplit, half 1 the rest   // hand-placed LDS reads one phase ahead of the arithmetic
 constexpr int kAblate = STATMC_SYM_ABLATE;  // 1 no q side, 2 no row staging, 4 no flush, 8 no sweep arithmetic, 16 no barrier
 constexpr int kR = 20;
 constexpr int kPx = 4;                    // pixels per lane
@@ -71,11 +89,16 @@ constexpr int kTabPad = 2 * (kTabW + 1);  // LDS copy: pairs (tab[t], tab[t+1])
 constexpr int kChunks = 2 * kR / 4 + 1;   // 11 read groups per window row
 constexpr int kMid = kChunks / 2;         // 5: the group that holds dx = 0
 constexpr int kPatchP = kRows * kW;       // float4 per patch: p-side piece
-// LDS-DMA staging: waves 0..6 each fetch and stage their own 24 of the 168 columns of a row, five RGB images (or
-// one 15-float AoS image) = 90 pieces of 16 B per wave and row, landing in a wave-private raw area
-constexpr int kWaveCols = 24;                               // 7 x 24 = 168 columns; wave 7 stages none
-constexpr int kRawFloats = kWaveCols * 15;                  // 360 floats = 90 pieces per wave
-constexpr int kRawTotal = 8 * kRawFloats;
+// LDS-DMA staging: the four waves of window half 0 each fetch and stage their own 44 / 44 / 40 / 40 of the 168 columns
+// of a row, five RGB images (or one 15-float AoS image) = 165 / 150 pieces of 16 B per wave and row, landing in a
+// wave-private raw area.  Half 0 because its waves are the older ones of every SIMD pair: they win the issue
+// arbitration, finish their sweep first and would otherwise idle at the barrier; while they wait for their fetches
+// and LDS reads the half-1 wave of the SIMD sweeps (tools/experiments/stamps_sym.py).
+constexpr int kWaveCols = 44;
+constexpr int kRawFloats = kWaveCols * 15;                  // 660 floats = 165 pieces per wave
+constexpr int kRawTotal = 4 * kRawFloats;
+__host__ __device__ inline int wave_col0(int wave) { return wave < 2 ? 44 * wave : 88 + 40 * (wave - 2); }
+__host__ __device__ inline int wave_cols(int wave) { return wave < 2 ? 44 : wave < 4 ? 40 : 0; }
 constexpr size_t kLdsBytes = (size_t)(kSlots * kSlotFloats + 2 * kTabPad + kRawTotal) * sizeof(float);
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 
@@ -151,6 +174,8 @@ __device__ __forceinline__ void range_exponent(const Lane &st, const v4f *g, con
 #pragma unroll
     for (int k = 0; k < kPx; k++) if (M::on(k)) tp[k] = *reinterpret_cast<const v2f *>(tab + 2 * (4 * j + 2 * H - k + 3));
 #pragma unroll
+    // (the spatial term as the first addend of the chain saves one packed add per pair and is 14 % SLOWER: the chain
+    // then starts behind the table read)
     for (int k = 0; k < kPx; k++) if (M::on(k)) { const v2f d = sub_bc(st.pg[k][0], 0, pair_of<H>(g[0])); e[k] = -d * d; }
 #pragma unroll
     for (int ch = 1; ch < 6; ch++) {
@@ -215,65 +240,197 @@ __device__ __forceinline__ void accumulate(Lane &st, const v4f *col, const v2f (
 // (6 feature planes), gates and weights (6 statistics planes), accumulation (3 colour planes + the 4 accumulator
 // planes of the taps) -- so that only one phase's operands are live at a time; the next phase's loads are issued
 // before the current phase's arithmetic.
-template <unsigned MASK, bool SYM>
+// LDS byte address of a pointer into the workgroup's shared array
+__device__ __forceinline__ unsigned lds_addr(const float *p) {
+    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) float *)p;
+}
+// ds_read_b128 placed by hand: the compiler sinks its own loads next to their first use, which leaves the LDS
+// latency of every phase exposed (a wave is mostly alone on its SIMD while it sweeps: the older wave of a pair wins
+// the issue arbitration, runs ahead and waits at the barrier -- tools/experiments/stamps_sym.py).  The register
+// is written when the data lands: every use sits behind an lds_wait that names it.
+template <int OFF>
+__device__ __forceinline__ v4f lds_read128(unsigned addr) {
+    v4f v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// wait until at most N LDS operations issued after the named registers' loads are outstanding (in-order return)
+template <int N>
+__device__ __forceinline__ void lds_wait(v4f &a, v4f &b, v4f &c) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(v4f &a, v4f &b, v4f &c, v4f &d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+
+// One read group (4 taps) against the lane's 4 pixels.  Every LDS operand is one ds_read_b128 of a channel plane
+// (consecutive lanes read consecutive 16 B: conflict-free); the group runs in three phases -- range exponents
+// (6 feature planes), gates and weights (6 statistics planes), accumulation (3 colour planes + the 4 accumulator
+// planes of the taps).  PIPE: the statistics planes are requested before the feature planes and the colour /
+// accumulator planes before the gates, by hand-placed reads, so that two of the three phases find their operands
+// in registers; otherwise the compiler's own loads (each phase waits for its operands).
+template <unsigned MASK, bool SYM, bool PIPE>
 __device__ __forceinline__ void chunk(Lane &st, const float *__restrict__ row, const float *__restrict__ tab, float *__restrict__ qrow, int j) {
     using M0 = Taps<0, MASK>;
     using M1 = Taps<1, MASK>;
     const float *r = row + 4 * j;
     v4f g[6], mcn[6], col[3], q4[4];
+    unsigned ra = 0, qa = 0;
+    if constexpr ((kAblate & 32) != 0) {   // timing only: operands from nowhere (no LDS reads in the sweep)
+#pragma unroll
+        for (int ch = 0; ch < 6; ch++) { asm volatile("" : "=v"(g[ch])); asm volatile("" : "=v"(mcn[ch])); }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) asm volatile("" : "=v"(col[ch]));
+#pragma unroll
+        for (int v = 0; v < 4; v++) asm volatile("" : "=v"(q4[v]));
+        v2f e0[kPx], e1[kPx], w0[kPx], w1[kPx];
+        if constexpr (M0::any()) range_exponent<0, MASK>(st, g, tab, j, e0);
+        if constexpr (M1::any()) range_exponent<1, MASK>(st, g, tab, j, e1);
+        if constexpr (M0::any()) gate_weight<0, MASK>(st, mcn, e0, w0);
+        if constexpr (M1::any()) gate_weight<1, MASK>(st, mcn, e1, w1);
+        v2f qa2[4], qb2[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) { qa2[v] = pair_of<0>(q4[v]); qb2[v] = pair_of<1>(q4[v]); }
+        if constexpr (M0::any()) accumulate<0, MASK, SYM>(st, col, w0, qa2);
+        if constexpr (M1::any()) accumulate<1, MASK, SYM>(st, col, w1, qb2);
+        if constexpr (SYM) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) asm volatile("" ::"v"(qa2[v]), "v"(qb2[v]));
+        }
+        return;
+    }
+    if constexpr (PIPE) {
+        ra = lds_addr(r);
+        qa = lds_addr(qrow + 4 * j);
+        mcn[0] = lds_read128<(C_MC + 0) * kP * 4>(ra);
+        mcn[1] = lds_read128<(C_MC + 1) * kP * 4>(ra);
+        mcn[2] = lds_read128<(C_MC + 2) * kP * 4>(ra);
+        mcn[3] = lds_read128<(C_MC + 3) * kP * 4>(ra);
+        mcn[4] = lds_read128<(C_MC + 4) * kP * 4>(ra);
+        mcn[5] = lds_read128<(C_MC + 5) * kP * 4>(ra);
+    }
 #pragma unroll
     for (int ch = 0; ch < 6; ch++) g[ch] = *reinterpret_cast<const v4f *>(r + (C_G0 + ch) * kP);
     v2f e0[kPx], e1[kPx], w0[kPx], w1[kPx];
     if constexpr (M0::any()) range_exponent<0, MASK>(st, g, tab, j, e0);
     if constexpr (M1::any()) range_exponent<1, MASK>(st, g, tab, j, e1);
+    if constexpr (PIPE) {
+        col[0] = lds_read128<(C_COL + 0) * kP * 4>(ra);
+        col[1] = lds_read128<(C_COL + 1) * kP * 4>(ra);
+        col[2] = lds_read128<(C_COL + 2) * kP * 4>(ra);
+        if constexpr (SYM) {
+            q4[0] = lds_read128<0 * kP * 4>(qa);
+            q4[1] = lds_read128<1 * kP * 4>(qa);
+            q4[2] = lds_read128<2 * kP * 4>(qa);
+            q4[3] = lds_read128<3 * kP * 4>(qa);
+        }
+        // the statistics planes were requested before the feature planes, which phase 1 has consumed
+        lds_wait<SYM ? 7 : 3>(mcn[0], mcn[1], mcn[2]);
+        lds_wait<SYM ? 7 : 3>(mcn[3], mcn[4], mcn[5]);
+    } else {
 #pragma unroll
-    for (int ch = 0; ch < 6; ch++) mcn[ch] = *reinterpret_cast<const v4f *>(r + (C_MC + ch) * kP);
+        for (int ch = 0; ch < 6; ch++) mcn[ch] = *reinterpret_cast<const v4f *>(r + (C_MC + ch) * kP);
+    }
     if constexpr (M0::any()) gate_weight<0, MASK>(st, mcn, e0, w0);
     if constexpr (M1::any()) gate_weight<1, MASK>(st, mcn, e1, w1);
+    if constexpr (PIPE) {
+        // ... and the colour / accumulator planes before the gates; the wait names the weights too, so that it stays
+        // behind the arithmetic that produced them (plain arithmetic may otherwise be scheduled after the wait)
+        if constexpr (M0::any()) asm volatile("" : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]));
+        if constexpr (M1::any()) asm volatile("" : "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]), "+v"(w1[3]));
+        lds_wait<0>(col[0], col[1], col[2]);
+        if constexpr (SYM) lds_wait<0>(q4[0], q4[1], q4[2], q4[3]);
+    } else {
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) col[ch] = *reinterpret_cast<const v4f *>(r + (C_COL + ch) * kP);
-    if constexpr (SYM) {
+        for (int ch = 0; ch < 3; ch++) col[ch] = *reinterpret_cast<const v4f *>(r + (C_COL + ch) * kP);
+        if constexpr (SYM) {
 #pragma unroll
-        for (int v = 0; v < 4; v++) q4[v] = *reinterpret_cast<const v4f *>(qrow + 4 * j + v * kP);
+            for (int v = 0; v < 4; v++) q4[v] = *reinterpret_cast<const v4f *>(qrow + 4 * j + v * kP);
+        }
     }
-    v2f qa[4], qb[4];
+    v2f qa2[4], qb2[4];
     if constexpr (SYM) {
 #pragma unroll
-        for (int v = 0; v < 4; v++) { qa[v] = pair_of<0>(q4[v]); qb[v] = pair_of<1>(q4[v]); }
+        for (int v = 0; v < 4; v++) { qa2[v] = pair_of<0>(q4[v]); qb2[v] = pair_of<1>(q4[v]); }
     }
-    if constexpr (M0::any()) accumulate<0, MASK, SYM>(st, col, w0, qa);
-    if constexpr (M1::any()) accumulate<1, MASK, SYM>(st, col, w1, qb);
+    if constexpr (M0::any()) accumulate<0, MASK, SYM>(st, col, w0, qa2);
+    if constexpr (M1::any()) accumulate<1, MASK, SYM>(st, col, w1, qb2);
     if constexpr (SYM) {
+        if constexpr ((kAblate & 64) != 0) {   // timing only: no write-back of the accumulators
 #pragma unroll
-        for (int v = 0; v < 4; v++)
-            *reinterpret_cast<v4f *>(qrow + 4 * j + v * kP) = v4f{qa[v].x, qa[v].y, qb[v].x, qb[v].y};
+            for (int v = 0; v < 4; v++) asm volatile("" ::"v"(qa2[v]), "v"(qb2[v]));
+        } else {
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+                *reinterpret_cast<v4f *>(qrow + 4 * j + v * kP) = v4f{qa2[v].x, qa2[v].y, qb2[v].x, qb2[v].y};
+        }
     }
 }
 
-// Half h of the window columns of one window row.  row / qrow point at the lane's first staged column
-// (column 4*lane of the slot); qrow at plane 0 of the wave's accumulator copy.
-// dy > 0: h = 0 sweeps dx in [-20, 0], h = 1 dx in [1, 20], every pair feeding both its pixels.
-// dy = 0: the pairs of a row are the taps dx in [1, 20] of half 1 (again feeding both pixels); half 0 is left with
-// the pixel's own tap dx = 0 (p side only).
+// Taps dx in [LO, HI] of one window row: the read groups that lie wholly inside the range run as a rolled loop, the
+// (at most two per side) groups cut by an end of the range get their static masks.
+template <int J, int LO, int HI>
+constexpr unsigned mask_of() { return (J >= 0 && J < kChunks) ? Mask<(J >= 0 && J < kChunks) ? J : 0, LO, HI>::value() : 0u; }
+template <int LO, int HI>
+struct Range {
+    static constexpr unsigned kFull = 0xFFFFu;
+    static constexpr unsigned m(int j) {
+        unsigned r = 0;
+        for (int i = 0; i < 4; i++)
+            for (int k = 0; k < 4; k++) {
+                const int dx = 4 * j - kR + i - k;
+                if (dx >= LO && dx <= HI) r |= 1u << (i * 4 + k);
+            }
+        return r;
+    }
+    static constexpr int first() { for (int j = 0; j < kChunks; j++) if (m(j)) return j; return kChunks; }
+    static constexpr int last() { for (int j = kChunks - 1; j >= 0; j--) if (m(j)) return j; return -1; }
+    static constexpr int first_full() { for (int j = 0; j < kChunks; j++) if (m(j) == kFull) return j; return kChunks; }
+    static constexpr int last_full() { for (int j = kChunks - 1; j >= 0; j--) if (m(j) == kFull) return j; return -1; }
+};
+
+template <int LO, int HI, bool SYM>
+__device__ __forceinline__ void sweep_range(Lane &st, const float *row, const float *tab, float *qrow) {
+    using R = Range<LO, HI>;
+    constexpr int j0 = R::first(), j1 = R::last(), f0 = R::first_full(), f1 = R::last_full();
+    static_assert(j0 <= j1, "empty range");
+    constexpr bool has_full = f0 <= f1;
+    constexpr int lo_end = has_full ? f0 : j1 + 1;      // masked groups j0 .. lo_end-1, full f0 .. f1, masked f1+1 .. j1
+    static_assert(lo_end - j0 <= 2 && (!has_full || j1 - f1 <= 2), "more than two cut groups at an end");
+    if constexpr (j0 < lo_end) chunk<R::m(j0), SYM, kPipe>(st, row, tab, qrow, j0);
+    if constexpr (j0 + 1 < lo_end) chunk<R::m(j0 + 1), SYM, kPipe>(st, row, tab, qrow, j0 + 1);
+    if constexpr (has_full) {
+#pragma unroll 1
+        for (int j = f0; j <= f1; j++) chunk<R::kFull, SYM, kPipe>(st, row, tab, qrow, j);
+        if constexpr (f1 + 1 <= j1) chunk<R::m(f1 + 1 <= j1 ? f1 + 1 : 0), SYM, kPipe>(st, row, tab, qrow, f1 + 1);
+        if constexpr (f1 + 2 <= j1) chunk<R::m(f1 + 2 <= j1 ? f1 + 2 : 0), SYM, kPipe>(st, row, tab, qrow, f1 + 2);
+    }
+}
+
+// The window columns of one window row, split between the two waves of a row at dx = kSplit: wave half 0 sweeps
+// dx in [-20, kSplit], half 1 dx in [kSplit + 1, 20], every pair feeding both its pixels.  kSplit = 0: the middle.
+// (The per-wave clocks -- tools/experiments/stamps_sym.py -- show the older wave of every SIMD pair finishing its
+// half well before the younger one and idling at the barrier, which suggests giving it more columns; measured, any
+// uneven split is slower: 1.42 ms at kSplit = 0, 1.62 at 7, 1.75 at 11.  The SIMD is busy either way.)
+// dy = 0: the pairs inside a row are the taps dx >= 1 (the accumulator row is the wave's own row); the pixel's own
+// tap dx = 0 feeds the p side only.
 template <int HF>
 __device__ __forceinline__ void eval_half_row(Lane &st, const float *row, const float *tab, float *qrow, bool dy0) {
-    constexpr unsigned kFull = 0xFFFFu;
     if constexpr (HF == 0) {
         if (dy0) {
-            chunk<Mask<kMid, 0, 0>::value(), false>(st, row, tab, qrow, kMid);
-            return;
+            sweep_range<0, 0, false>(st, row, tab, qrow);
+            if constexpr (kSplit >= 1) sweep_range<1, kSplit, true>(st, row, tab, qrow);
+        } else {
+            sweep_range<-kR, kSplit, true>(st, row, tab, qrow);
         }
-        static_assert(Mask<1, -kR, 0>::value() == kFull && Mask<kMid - 1, -kR, 0>::value() == kFull, "");
-        chunk<Mask<0, -kR, 0>::value(), true>(st, row, tab, qrow, 0);
-#pragma unroll 1
-        for (int j = 1; j < kMid; j++) chunk<kFull, true>(st, row, tab, qrow, j);
-        chunk<Mask<kMid, -kR, 0>::value(), true>(st, row, tab, qrow, kMid);
     } else {
-        static_assert(Mask<kMid + 1, 1, kR>::value() == kFull && Mask<kChunks - 2, 1, kR>::value() == kFull, "");
-        chunk<Mask<kMid, 1, kR>::value(), true>(st, row, tab, qrow, kMid);
-#pragma unroll 1
-        for (int j = kMid + 1; j < kChunks - 1; j++) chunk<kFull, true>(st, row, tab, qrow, j);
-        chunk<Mask<kChunks - 1, 1, kR>::value(), true>(st, row, tab, qrow, kChunks - 1);
+        if constexpr (kSplit >= 1) {
+            sweep_range<kSplit + 1, kR, true>(st, row, tab, qrow);
+        } else {
+            if (dy0) sweep_range<1, kR, true>(st, row, tab, qrow);
+            else sweep_range<kSplit + 1, kR, true>(st, row, tab, qrow);
+        }
     }
 }
 
@@ -318,7 +475,7 @@ __device__ __forceinline__ void dma_row(const FilterArgs &a, float *raw_w, int l
     if (yrow < 0 || yrow >= a.height) return;
     const int per_img = ncols * 3 / 4, total = 5 * per_img;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < 3; j++) {
         const int idx = 64 * j + lane;
         if (idx < total) {
             const float *src;
@@ -420,9 +577,9 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     }
 
     // wave-local staging geometry (DMA): this wave's columns of every staged row
-    float *raw_w = tab_lds + 2 * kTabPad + wave * kRawFloats;
-    const int wcol0 = kWaveCols * wave;                                // first staged column (0..295) of the wave
-    const int ncols = max(0, min(kWaveCols, kP - wcol0));             // 24, wave 7: 0
+    float *raw_w = tab_lds + 2 * kTabPad + (wave & 3) * kRawFloats;
+    const int wcol0 = wave_col0(wave);                                 // first staged column (0..167) of the wave
+    const int ncols = wave_cols(wave);                                 // 44, 44, 40, 40, then none
     if (s_a < s_b) {
         if constexpr (DMA) {   // the first row the sweep will need beyond the prologue: on its way during the prologue
             if (s_a + 1 < s_b && !(kAblate & 2)) dma_row(a, raw_w, lane, x0 - kR + wcol0, y0 + s_a + kRows, ncols);
@@ -441,7 +598,9 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
         __syncthreads();
 
         // ---- sweep
+        unsigned long long tk0 = 0, c_hk = 0, c_ev = 0, c_bar = 0;
         for (int s = s_a; s < s_b; s++) {
+            if constexpr (kStamps) tk0 = __builtin_amdgcn_s_memtime();
             const int i = DMA ? wcol0 + lane : (int)threadIdx.x;             // the staged column this thread looks after
             const bool mine = DMA ? lane < ncols : i < kP;
             const bool stage = s + 1 < s_b && mine && !(kAblate & 2);
@@ -450,25 +609,30 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             if constexpr (!DMA) {
                 if (stage) nxt = load_px(a, x0 - kR + i, y0 + s + kRows);
             }
-            // the row that went dead at the last barrier hands its accumulators to the patch
-            const int dead = s - 1;
-            if (mine && dead >= q_first && y0 + dead >= 0 && !(kAblate & 4))
-                flush_q(lds + (dead % kSlots) * kSlotFloats, i, patch_q + (long long)(dead - q_first) * kP);
-            if constexpr (DMA) {
-                // the row fetched during the last step: raw area -> its slot (the dead row's), accumulators cleared;
-                // then the fetch of the row after it starts and has this whole step to land
-                if (s + 1 < s_b && !(kAblate & 2)) {
-                    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's own transfers
-                    if (stage) {
-                        const StagedPixel sp = raw_pixel(a, raw_w, lane, ncols, x0 - kR + i, y0 + s + kRows);
-                        stage_store(lds + ((s + kRows) % kSlots) * kSlotFloats, i, sp, k0, k1);
-                    }
-                    if (s + 2 < s_b) {
-                        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the raw area has been read
-                        dma_row(a, raw_w, lane, x0 - kR + wcol0, y0 + s + 1 + kRows, ncols);
+            // Once per step every wave (a) hands the accumulators of the row that went dead at the last barrier to the
+            // patch, (b) turns the row fetched during the last step into a ring slot (the dead row's), and (c) starts
+            // the fetch of the row after it.  (Measured: doing it before the sweep in every wave beats both staggering
+            // the two waves of a SIMD -- 1.58 vs 1.51 ms -- and doing it after the sweep.)
+            auto housekeeping = [&]() {
+                const int dead = s - 1;
+                if (mine && dead >= q_first && y0 + dead >= 0 && !(kAblate & 4))
+                    flush_q(lds + (dead % kSlots) * kSlotFloats, i, patch_q + (long long)(dead - q_first) * kP);
+                if constexpr (DMA) {
+                    if (s + 1 < s_b && !(kAblate & 2)) {
+                        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's own transfers
+                        if (stage) {
+                            const StagedPixel sp = raw_pixel(a, raw_w, lane, ncols, x0 - kR + i, y0 + s + kRows);
+                            stage_store(lds + ((s + kRows) % kSlots) * kSlotFloats, i, sp, k0, k1);
+                        }
+                        if (s + 2 < s_b) {
+                            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the raw area has been read
+                            dma_row(a, raw_w, lane, x0 - kR + wcol0, y0 + s + 1 + kRows, ncols);
+                        }
                     }
                 }
-            }
+            };
+            if (!DMA || (!kHkAtEnd && half == 0)) housekeeping();
+            if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_hk += t - tk0; tk0 = t; }
             const int ti = (int)threadIdx.x - (kThreads - 64);
             const bool tstage = s + 1 < s_b && ti >= 0 && ti < tw;
             v2f tnext = v2f{0.f, 0.f};
@@ -488,11 +652,18 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
                 eval_half_row<1>(st, row, tab, qrow, s == 0);
             }
 
+            if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_ev += t - tk0; tk0 = t; }
+            if (DMA && kHkAtEnd && half == 0) housekeeping();
             if (tstage) *reinterpret_cast<v2f *>(tab_lds + ((s - s_a + 1) & 1) * kTabPad + 2 * ti) = tnext;
             if constexpr (!DMA) {
                 if (stage) stage_store(lds + ((s + kRows) % kSlots) * kSlotFloats, i, nxt, k0, k1);
             }
             if (!(kAblate & 16)) __syncthreads();
+            if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_bar += t - tk0; tk0 = t; }
+        }
+        if constexpr (kStamps) {
+            if (lane == 0)   // the last q-side row of the patch is never a target of a part-1 launch of a full film: scratch
+                patch[a.sym.item_stride4 - 8 + wave] = make_float4((float)c_hk, (float)c_ev, (float)c_bar, (float)(s_b - s_a));
         }
         // ---- the rows still in the ring: rel = s_b-1 .. s_b+6
         for (int idx2 = threadIdx.x; idx2 < kRows * kP; idx2 += kThreads) {
