@@ -902,6 +902,7 @@ class Estimator {
         PinnedFloats host;
         DeviceBytes dev;
         std::vector<uint32_t> slots;     // slots this (type, bounce) has merged since the last flush
+        std::vector<uint8_t> merged;     // merged[slot] != 0: the same, as a flag per slot (O(1) duplicate check)
     };
     struct Slot {
         int32_t x0, y0, x1, y1, samples;
@@ -990,8 +991,9 @@ class Estimator {
                     throw Error(STATMC_ERR_UNSUPPORTED, "Merge*Tile: the stat types of one tile hold different sample counts");
             }
             Arena &A = acc.arenas[ti][bj];
-            if (std::find(A.slots.begin(), A.slots.end(), slot) != A.slots.end())
-                throw Error(STATMC_ERR_INVALID, "Merge*Tile: tile merged twice");
+            if (A.merged.size() <= slot) A.merged.resize((size_t)slot + 1, 0);
+            if (A.merged[slot]) throw Error(STATMC_ERR_INVALID, "Merge*Tile: tile merged twice");
+            A.merged[slot] = 1;
             A.host.allocate((size_t)acc.capacity * C, !acc.dry);
             A.slots.push_back(slot);
             dst = A.host.ptr + (size_t)acc.slots[slot].offset * C;
@@ -1106,7 +1108,10 @@ class Estimator {
         acc.slotOf.clear();
         acc.nextOffset = 0;
         for (auto &per_type : acc.arenas)
-            for (Arena &a : per_type) a.slots.clear();
+            for (Arena &a : per_type) {
+                a.slots.clear();
+                a.merged.clear();
+            }
     }
 };
 

@@ -88,6 +88,9 @@ def load():
         raise RuntimeError(
             "libstatmc_hip.so is missing (%s). Build it with `python -m statmc_amd.build` or "
             "__graft_entry__.build(); statmc_amd has no CPU/PyTorch fallback." % _build.SO)
+    if _build.SO == _build.DEFAULT_SO and _build.stale():
+        raise RuntimeError("libstatmc_hip.so was built from other sources than the ones in statmc_amd/csrc "
+                           "(content hash mismatch): rebuild with `python -m statmc_amd.build` before using it")
     lib = C.CDLL(_build.SO)
     lib.statmc_last_error.restype = C.c_char_p
     lib.statmc_last_filter_variant.restype = C.c_char_p

@@ -7,6 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libstatmc_hip.so")
+DEFAULT_SO = SO
 SOURCES = ["statmc_pointwise.hip", "statmc_filter.hip", "statmc_filter_sym.hip", "statmc_abi.hip"]
 HEADERS = ["statmc_device.h", "statmc_filter_common.h", "t_quantiles.h", os.path.join("..", "..", "include", "statmc.h")]
 # -ffp-contract=off: every fp32 op rounds once, in source order, like the CPU oracle build.
@@ -25,10 +26,34 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libstatmc_hip.so cannot be built")
 
 
+STAMP = DEFAULT_SO + ".src"   # hash of the sources + flags the library was built from (git-ignored, ships with the .so)
+
+
+def source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for name in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    h.update(" ".join(FLAGS + KERNEL_FLAGS).encode())
+    return h.hexdigest()
+
+
+def stale():
+    """True when libstatmc_hip.so exists but was built from other sources than the ones in csrc/ (mtimes do not
+    survive a snapshot copy of the tree, a content hash does)."""
+    if not os.path.exists(SO):
+        return False
+    try:
+        return open(STAMP).read().strip() != source_hash()
+    except OSError:
+        return True
+
+
 def needs_build():
-    """Only a missing library triggers an implicit build (see build_tools for why mtimes are not
-    compared); after editing csrc/ run `python -m statmc_amd.build --force`."""
-    return not os.path.exists(SO)
+    """A missing library or one built from other sources.  The rebuild goes to a temporary file and is renamed into
+    place, so a process that has the old library mapped keeps a consistent image."""
+    return not os.path.exists(SO) or stale()
 
 
 def build(force=False, verbose=False):
@@ -51,8 +76,12 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
         if verbose and out:
             print(out.decode(), file=sys.stderr)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+    tmp = SO + ".tmp.%d" % os.getpid()
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     subprocess.check_call(cmd)
+    os.replace(tmp, SO)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return SO
 
 

@@ -36,6 +36,10 @@ class BlockLayout:
         assert self.gx * self.gy == world_size
         self.bx, self.by = rank % self.gx, rank // self.gx
         self.bw, self.bh, self.r = block_w, block_h, radius
+        # a halo comes from ONE ring of neighbours: a block narrower than the radius would need the next ring too
+        if (self.gx > 1 and block_w < radius) or (self.gy > 1 and block_h < radius):
+            raise ValueError("block %dx%d is smaller than the filter radius %d: the halo exchange reaches one "
+                             "ring of neighbours only" % (block_w, block_h, radius))
         self.left = self._nb(-1, 0)
         self.right = self._nb(1, 0)
         self.up = self._nb(0, -1)

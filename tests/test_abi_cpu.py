@@ -87,3 +87,55 @@ def test_product_does_not_import_oracle():
                     if re.search(r"(import|include|CDLL|dlopen).*oracle", code):
                         offenders.append((f, line.strip()))
     assert not offenders, offenders
+
+
+def test_per_device_state_needs_setup(lib):
+    """Every setting lives in the state of a device that statmc_setup() has prepared: without one, the setters refuse
+    (no process-global fallback that a second device would silently inherit)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from statmc_amd import api
+    spec = api.FilterSpec(gate=1)
+    assert lib.statmc_set_filter_spec(C.byref(spec)) == api.ERR_NO_DEVICE
+    assert lib.statmc_set_filter_spec(None) == api.ERR_INVALID
+    bad = api.FilterSpec(border=7)
+    assert lib.statmc_set_filter_spec(C.byref(bad)) == api.ERR_INVALID
+    assert lib.statmc_set_significance(1) == api.ERR_NO_DEVICE
+    assert lib.statmc_set_significance(9) == api.ERR_INVALID
+    assert lib.statmc_set_device(0) == api.ERR_NO_DEVICE          # never set up
+    got = api.FilterSpec(gate=1, border=1)
+    assert lib.statmc_get_filter_spec(C.byref(got)) == 0 and got.as_tuple() == (0,) * 6     # the default spec
+    assert lib.statmc_get_significance() == 0
+    q = (C.c_float * 4)(1, 2, 3, 4)
+    assert lib.statmc_set_t_quantiles(0, q, 4) == api.ERR_NO_DEVICE
+
+
+def test_filter_spec_struct_layout(lib):
+    import subprocess
+    import tempfile
+    from statmc_amd import api
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "statmc.h"
+int main(void) { printf("%zu %zu %zu %zu\n", sizeof(statmc_filter_spec), offsetof(statmc_filter_spec, small_n),
+                        offsetof(statmc_filter_args, film_x0), sizeof(statmc_filter_args)); return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        got = [int(x) for x in subprocess.check_output([os.path.join(d, "t")]).split()]
+    assert got == [C.sizeof(api.FilterSpec), api.FilterSpec.small_n.offset, api.FilterArgs.film_x0.offset, C.sizeof(api.FilterArgs)]
+
+
+def test_stale_library_is_refused(lib, tmp_path, monkeypatch):
+    """The library records a hash of the sources it was built from; a library from other sources is not loaded."""
+    from statmc_amd import api, build
+    assert not build.stale()
+    fake = tmp_path / "stamp"
+    fake.write_text("0" * 64 + "\n")
+    monkeypatch.setattr(build, "STAMP", str(fake))
+    assert build.stale() and build.needs_build()
+    monkeypatch.setattr(api, "_lib", None)
+    with pytest.raises(RuntimeError, match="other sources"):
+        api.load()

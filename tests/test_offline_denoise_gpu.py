@@ -70,3 +70,40 @@ def test_compare_against_reference_dumps_and_custom_quantiles(gpu, tmp_path):
     out = subprocess.run(base + ["--tquantiles", str(table)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert float(re.search(r"compare t0-b0-discriminator ch0 rel_l2 (\S+)", out.stdout).group(1)) > 0.5
+
+
+def test_fit_spec_finds_the_spec_that_wrote_the_dumps(gpu, tmp_path):
+    """tools/fit_spec.py: with output dumps of the CUDA denoiser in hand, pinning this build is one command.  Stand-in
+    for those dumps here: the oracle under a non-default spec (joint channel rule, one-sided quantiles, alpha 0.05).
+    The tool must rank exactly that spec first, within BASELINE's 1e-5."""
+    import re
+    import sys
+    from statmc_amd import build, pfm
+    from oracle import oracle
+    build.build_tools()
+    g = np.load(GOLDEN[1])                                    # caustics_r6: small window, quick to sweep
+    spp = int(g["spp"])
+    n = g["n"].copy()
+    n[3, 5] = 1                                               # one pixel where the n < 2 rule matters
+    spec = oracle.FilterSpec(channel_rule=oracle.CHANNELS_JOINT, sides=oracle.SIDES_ONE)
+    mc, dc = oracle.prepass(n, g["mean"], g["m2"], g["m3"], alpha_index=2, spec=spec)
+    film_f = oracle.filter_image(mc, dc, g["film_mean"], [g["normal_mean"], g["albedo_mean"]], [-50.0, -1250.0],
+                                 -0.5 / float(g["filter_sd"]) ** 2, int(g["radius"]), spec=spec, n=n, alpha_index=2)
+    stem, ref = str(tmp_path / "scene"), str(tmp_path / "cuda")
+    for name, img in {"film": g["film_mean"], "t0-b0-n": n, "t0-b0-mean": g["mean"], "t0-b0-m2": g["m2"], "t0-b0-m3": g["m3"],
+                      "t1-b0-film-mean": g["normal_mean"], "t2-b0-film-mean": g["albedo_mean"]}.items():
+        pfm.write_pfm("%s-%d-%s.pfm" % (stem, spp, name), img)
+    for name, img in {"film-f": film_f, "t0-b0-mean-corr": mc, "t0-b0-discriminator": dc}.items():
+        pfm.write_pfm("%s-%d-%s.pfm" % (ref, spp, name), img)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fit_spec.py"), "--stem", stem, "--ref", ref, "--spp", str(spp),
+                          "--filtersd", str(float(g["filter_sd"])), "--filterradius", str(int(g["radius"])), "--quick"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    best = re.search(r"best: significance (\d), --spec (\S+)\s+\(film-f worst channel (\S+);", out.stdout)
+    assert best, out.stdout
+    assert best.group(1) == "2" and best.group(2) == "gate=sym,channels=joint,sides=one", out.stdout
+    assert float(best.group(3)) <= 1e-5
+    rows = [l for l in out.stdout.splitlines() if re.match(r"^\d\.\d+e", l)]
+    assert len(rows) == 3 * 8                                                    # 3 levels x 2^3 specs
+    assert float(rows[1].split()[0]) > 1e-5 or "gate=asym,channels=joint,sides=one" in rows[1]   # only the rounding-twin gate form ties

@@ -90,3 +90,14 @@ def test_layouts():
     assert S.film_size == (1920, 8640) and S.origin == (0, 3240) and S.roi == (0, 20, 1920, 1100)
     one = sharding.BlockLayout(0, 1, 1920, 1080, 20)
     assert (one.pw, one.ph) == (1920, 1080) and one.roi == (0, 0, 1920, 1080)
+
+
+def test_blocks_smaller_than_the_radius_are_refused():
+    """The exchange fetches one ring of neighbours: a block narrower than the radius would need the next ring."""
+    from statmc_amd import sharding
+    with pytest.raises(ValueError, match="smaller than the filter radius"):
+        sharding.BlockLayout(0, 4, 64, 12, 20, grid=(1, 4))
+    with pytest.raises(ValueError, match="smaller than the filter radius"):
+        sharding.BlockLayout(1, 2, 16, 64, 20, grid=(2, 1))
+    sharding.BlockLayout(0, 1, 8, 8, 20)                     # a single block has no neighbours: any size
+    sharding.BlockLayout(0, 2, 20, 8, 20, grid=(2, 1))       # only the split direction counts

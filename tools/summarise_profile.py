@@ -41,7 +41,7 @@ def main(tag):
     traffic = {}
     for k, cs in agg.items():
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-            name = k.split("(")[0].replace("void statmc::", "").split("<")[0]
+            name = k.split("(")[0].replace("void ", "").replace("statmc::", "").replace("sym::", "").split("<")[0]
             fetch = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024.0
             write = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024.0
             traffic[name] = int(2.0 * fetch + write)
