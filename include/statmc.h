@@ -182,6 +182,27 @@ int statmc_pack_filter_inputs(const statmc_filter_args *args, const statmc_image
  * device images), and skipped when they are NULL. */
 int statmc_prepass_pack(const statmc_filter_args *args, const statmc_image *packed, int dst_x0, int dst_y0);
 
+/* ---- film blocks on several devices of ONE process (new capability: the reference is single-GPU).
+ * The Python side exchanges halos between processes with torch.distributed (RCCL send/recv); this is the same
+ * exchange for a C++ host that drives all devices itself -- one Estimator per device -- with device-to-device copies
+ * (peer access over xGMI, enabled on demand). */
+typedef struct statmc_block {
+    int32_t device;      /* HIP device that owns the block (statmc_setup must have run for it) */
+    statmc_image packed; /* [block_h + halo rows][block_w + halo columns][15] fp32 on that device: the block + halo image
+                            statmc_prepass_pack fills and statmc_window_filter reads; a side that lies on the film
+                            border has no halo */
+    void *stream;        /* the block's stream: its pack was enqueued there, the copies into it go there */
+} statmc_block;
+/* Fills the halo margins of every block's packed image from its neighbours.  blocks[by * gx + bx] = block (bx, by) of
+ * a gx x gy grid of equal block_w x block_h blocks; radius = halo width.  Two phases, as in statmc_amd/sharding.py:
+ * columns first, then rows over the widened blocks so that the corners ride along; every copy runs on the stream of
+ * its destination block and is ordered behind the source block's pack / first phase by events.  Asynchronous. */
+int statmc_halo_exchange(const statmc_block *blocks, int gx, int gy, int block_w, int block_h, int radius);
+/* Rectangle copy between device images of any two devices of the process (block cut / block paste of the sharded
+ * path).  elem_bytes = bytes per pixel; runs on `stream` (a stream of dst_device). */
+int statmc_copy_rect(const statmc_image *dst, int dst_device, int dst_x, int dst_y, const statmc_image *src,
+                     int src_device, int src_x, int src_y, int width, int height, int elem_bytes, void *stream);
+
 /* Replaces cv::cuda::stat_denoiser::calculateMeanVars<T> (commented-out call,
  * src/statistics/estimator.cpp:501-521) and its CPU stand-in (estimator.cpp:524-568):
  * film_var = film_m2 / ((n-1)*n).  row_n_quirk != 0 reproduces the CPU loop reading n once

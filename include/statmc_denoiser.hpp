@@ -733,6 +733,7 @@ class Estimator {
         }
     }
     void Synchronize() { stat_denoiser::synchronize(stream); }  // estimator.cpp:571-573
+    int deviceIndex() const { return device; }
 
     // ---- the accumulation side: tiles in, statistics images on the device ------------------
     // estimator.cpp:297-309.  (GetTilesF, the filter-weighted variant, is not used by Render.)
@@ -1113,6 +1114,132 @@ class Estimator {
                 a.merged.clear();
             }
     }
+};
+
+// ------------------------------------------------------------------------------------------
+// The RGB denoise pass of an Estimator cut into a gx x gy grid of film blocks, one per device of a list (new
+// capability: the reference is single-GPU).  Per block: cut the seven filter inputs out of the
+// Estimator's device images (device-to-device rectangle copies), pre-pass + pack into the block + halo image, fetch the
+// r-pixel halo from the neighbouring blocks (statmc_halo_exchange: two phases of peer copies ordered by events), window
+// filter of the owned pixels, paste into "film-f".  Everything is enqueued asynchronously on one stream per block; the
+// work tiles of the filter sit on a grid fixed in film coordinates, so the result is bit-identical to the unsharded
+// Estimator::Denoise().  With every block on the device of the Estimator this is the single-GPU emulation the tests
+// use; with blocks on different devices the copies cross xGMI.
+class FilmShards {
+  public:
+    FilmShards(Estimator &est, int gx, int gy, std::vector<int> devices = {}) : est(est), gx(gx), gy(gy) {
+        if (gx < 1 || gy < 1 || est.width % gx || est.height % gy)
+            throw Error(STATMC_ERR_INVALID, "FilmShards: the film does not split into equal blocks");
+        if (est.rgbBufferCounts[DenoiseGroup] != 1 || est.gBuffers.size() != 2 || est.gBufferChannelCounts[0] != 3 ||
+            est.gBufferChannelCounts[1] != 3)
+            throw Error(STATMC_ERR_UNSUPPORTED, "FilmShards: one RGB radiance buffer under two RGB G-buffers (the shipped denoise configuration)");
+        bw = est.width / gx;
+        bh = est.height / gy;
+        r = est.filterRadius;
+        if (devices.empty()) devices.push_back(est.deviceIndex());
+        blocks.resize((size_t)gx * gy);
+        for (int b = 0; b < gx * gy; b++) {
+            Block &B = blocks[b];
+            const int bx = b % gx, by = b / gx;
+            B.device = devices[b % devices.size()];
+            B.pl = bx > 0 ? r : 0; B.pr = bx + 1 < gx ? r : 0; B.pt = by > 0 ? r : 0; B.pb = by + 1 < gy ? r : 0;
+            B.x0 = bx * bw; B.y0 = by * bh;
+            check(statmc_setup(B.device));               // idempotent; makes the device current for the allocations
+            B.n = DeviceImage(bh, bw, I32C1);
+            for (DeviceImage *im : {&B.mean, &B.m2, &B.m3, &B.colour, &B.g0, &B.g1}) *im = DeviceImage(bh, bw, F32C3);
+            const int pw = bw + B.pl + B.pr, ph = bh + B.pt + B.pb;
+            void *p = nullptr;
+            check(statmc_malloc(&p, (size_t)pw * ph * 60));
+            B.packed = std::shared_ptr<void>(p, [](void *q) { statmc_free(q); });
+            B.packedDesc = statmc_image{p, (size_t)pw * 60, pw, ph};
+            B.out = DeviceImage(ph, pw, F32C3);
+            void *st = nullptr;
+            check(statmc_stream_create(&st));
+            B.stream = std::shared_ptr<void>(st, [](void *q) { statmc_stream_destroy(q); });
+        }
+        check(statmc_set_device(est.deviceIndex()));
+    }
+
+    // Estimator::Denoise() for the RGB buffer, sharded.  The inputs must be on the Estimator's device (after Upload()
+    // or a flush of the device accumulation); returns with the work enqueued and the Estimator's stream waiting for it.
+    void Denoise() {
+        est.Synchronize();   // the cuts below read what the Estimator's stream wrote
+        const Estimator::Tables &t = est.rgbTables[DenoiseGroup];
+        const DeviceImage &colour = est.denoiseFilm ? est.filmBuffer.gpuMat : t.film[0];
+        const DeviceImage &out = est.denoiseFilm ? est.filmFilteredBuffer.gpuMat : t.filmFiltered[0];
+        const int src = est.deviceIndex();
+        std::vector<statmc_block> desc(blocks.size());
+        for (size_t b = 0; b < blocks.size(); b++) {
+            Block &B = blocks[b];
+            check(statmc_set_device(B.device));
+            void *st = B.stream.get();
+            auto cut = [&](const DeviceImage &whole, DeviceImage &blk, int elem) {
+                const statmc_image d = blk.desc(), w = whole.desc();
+                check(statmc_copy_rect(&d, B.device, 0, 0, &w, src, B.x0, B.y0, bw, bh, elem, st));
+            };
+            cut(t.n[0], B.n, 4); cut(t.mean[0], B.mean, 12); cut(t.m2[0], B.m2, 12); cut(t.m3[0], B.m3, 12);
+            cut(colour, B.colour, 12); cut(est.gBufferImages[0], B.g0, 12); cut(est.gBufferImages[1], B.g1, 12);
+            statmc_filter_args a = args(B);
+            check(statmc_prepass_pack(&a, &B.packedDesc, B.pl, B.pt));
+            desc[b] = statmc_block{B.device, B.packedDesc, st};
+        }
+        check(statmc_halo_exchange(desc.data(), gx, gy, bw, bh, r));
+        for (Block &B : blocks) {
+            check(statmc_set_device(B.device));
+            statmc_filter_args a = args(B);
+            a.packed_inputs = B.packedDesc;
+            a.width = (uint16_t)B.packedDesc.cols;
+            a.height = (uint16_t)B.packedDesc.rows;
+            a.roi_x0 = B.pl; a.roi_y0 = B.pt; a.roi_x1 = B.pl + bw; a.roi_y1 = B.pt + bh;
+            a.film_x0 = B.x0 - B.pl; a.film_y0 = B.y0 - B.pt;
+            const statmc_image o = B.out.desc();
+            a.film_filtered = &o;
+            check(statmc_window_filter(&a, 3));
+            const statmc_image w = out.desc();
+            check(statmc_copy_rect(&w, src, B.x0, B.y0, &o, B.device, B.pl, B.pt, bw, bh, 12, B.stream.get()));
+        }
+        for (Block &B : blocks) {
+            check(statmc_set_device(B.device));
+            check(statmc_synchronize(B.stream.get()));
+        }
+        check(statmc_set_device(src));
+    }
+
+    int nBlocks() const { return (int)blocks.size(); }
+
+  private:
+    struct Block {
+        int device = 0, pl = 0, pr = 0, pt = 0, pb = 0, x0 = 0, y0 = 0;
+        DeviceImage n, mean, m2, m3, colour, g0, g1, out;
+        std::shared_ptr<void> packed, stream;
+        statmc_image packedDesc{};
+        // descriptor storage the argument block points into
+        statmc_image dn{}, dmean{}, dm2{}, dm3{}, dcol{}, dg[2]{};
+        uint8_t gch[2] = {3, 3};
+    };
+    // the argument block of filter<float3> for one block (reference order, estimator.cpp:465-487)
+    statmc_filter_args args(Block &B) {
+        statmc_filter_args a;
+        std::memset(&a, 0, sizeof(a));
+        B.dn = B.n.desc(); B.dmean = B.mean.desc(); B.dm2 = B.m2.desc(); B.dm3 = B.m3.desc(); B.dcol = B.colour.desc();
+        B.dg[0] = B.g0.desc(); B.dg[1] = B.g1.desc();
+        a.n_buffers = 1;
+        a.width = (uint16_t)bw;
+        a.height = (uint16_t)bh;
+        a.filter_ds_factor = est.filterDSFactor;
+        a.filter_radius = est.filterRadius;
+        a.denoise_film = 0;
+        a.n = &B.dn; a.mean = &B.dmean; a.m2 = &B.dm2; a.m3 = &B.dm3; a.film = &B.dcol;
+        a.g_buffers = B.dg;
+        a.g_channel_counts = B.gch;
+        a.g_dr_factors = est.gBufferDRFactors.data();
+        a.n_g_buffers = 2;
+        a.stream = B.stream.get();
+        return a;
+    }
+    Estimator &est;
+    int gx, gy, bw = 0, bh = 0, r = 0;
+    std::vector<Block> blocks;
 };
 
 }  // namespace statmc

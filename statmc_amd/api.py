@@ -68,7 +68,7 @@ EXPORTS = [
     "statmc_malloc", "statmc_free", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_download",
     "statmc_stream_create", "statmc_stream_destroy", "statmc_synchronize",
     "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs", "statmc_prepass_pack",
-    "statmc_calculate_mean_vars", "statmc_accumulate", "statmc_accumulate_tiles", "statmc_merge_tiles", "statmc_tile_moments", "statmc_film_update",
+    "statmc_halo_exchange", "statmc_copy_rect", "statmc_calculate_mean_vars", "statmc_accumulate", "statmc_accumulate_tiles", "statmc_merge_tiles", "statmc_tile_moments", "statmc_film_update",
     "statmc_last_filter_variant", "statmc_version",
 ]
 

@@ -558,6 +558,125 @@ int statmc_prepass_pack(const statmc_filter_args *a, const statmc_image *packed,
     return STATMC_OK;
 }
 
+// peer access src -> dst, once per ordered pair (an error other than "already enabled" is reported)
+static int enable_peer(int dst_device, int src_device) {
+    if (dst_device == src_device) return STATMC_OK;
+    static std::mutex mu;
+    static std::vector<std::pair<int, int>> done;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &p : done)
+        if (p.first == dst_device && p.second == src_device) return STATMC_OK;
+    int can = 0;
+    HIP_TRY(hipDeviceCanAccessPeer(&can, dst_device, src_device));
+    if (!can) return fail(STATMC_ERR_UNSUPPORTED, "device %d cannot access device %d", dst_device, src_device);
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    HIP_TRY(hipSetDevice(dst_device));
+    hipError_t e = hipDeviceEnablePeerAccess(src_device, 0);
+    (void)hipSetDevice(cur);
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(STATMC_ERR_HIP, "hipDeviceEnablePeerAccess: %s", hipGetErrorString(e));
+    (void)hipGetLastError();
+    done.emplace_back(dst_device, src_device);
+    return STATMC_OK;
+}
+
+int statmc_copy_rect(const statmc_image *dst, int dst_device, int dst_x, int dst_y, const statmc_image *src, int src_device,
+                     int src_x, int src_y, int width, int height, int elem_bytes, void *stream) {
+    if (!dst || !src || !dst->data || !src->data) return fail(STATMC_ERR_INVALID, "null image");
+    if (width <= 0 || height <= 0) return STATMC_OK;
+    if (elem_bytes <= 0 || dst_x < 0 || dst_y < 0 || src_x < 0 || src_y < 0 || dst_x + width > dst->cols || dst_y + height > dst->rows ||
+        src_x + width > src->cols || src_y + height > src->rows)
+        return fail(STATMC_ERR_INVALID, "rectangle outside an image");
+    if (int rc = enable_peer(dst_device, src_device)) return rc;
+    const char *s = static_cast<const char *>(src->data) + (size_t)src_y * src->step + (size_t)src_x * elem_bytes;
+    char *d = static_cast<char *>(dst->data) + (size_t)dst_y * dst->step + (size_t)dst_x * elem_bytes;
+    HIP_TRY(hipMemcpy2DAsync(d, dst->step, s, src->step, (size_t)width * elem_bytes, height, hipMemcpyDeviceToDevice, S(stream)));
+    return STATMC_OK;
+}
+
+int statmc_halo_exchange(const statmc_block *blocks, int gx, int gy, int block_w, int block_h, int radius) {
+    if (!blocks || gx < 1 || gy < 1 || block_w < 1 || block_h < 1 || radius < 0) return fail(STATMC_ERR_INVALID, "bad block grid");
+    if ((gx > 1 && block_w < radius) || (gy > 1 && block_h < radius))
+        return fail(STATMC_ERR_INVALID, "block %dx%d smaller than the radius %d: a halo comes from one ring of neighbours", block_w, block_h, radius);
+    const int n = gx * gy, r = radius;
+    if (n == 1 || r == 0) return STATMC_OK;
+    auto halo = [&](int bx, int by, int &pl, int &pr, int &pt, int &pb) {
+        pl = bx > 0 ? r : 0; pr = bx + 1 < gx ? r : 0; pt = by > 0 ? r : 0; pb = by + 1 < gy ? r : 0;
+    };
+    for (int b = 0; b < n; b++) {
+        int pl, pr, pt, pb;
+        halo(b % gx, b / gx, pl, pr, pt, pb);
+        const statmc_image &im = blocks[b].packed;
+        if (!im.data || im.cols != block_w + pl + pr || im.rows != block_h + pt + pb || im.step != (size_t)im.cols * 60)
+            return fail(STATMC_ERR_INVALID, "block %d: packed image is not the %dx%dx15 block + halo image", b, block_w + pl + pr, block_h + pt + pb);
+    }
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    std::vector<hipEvent_t> packed(n), phase1(n);
+    int rc = STATMC_OK;
+    auto hip = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == STATMC_OK) rc = fail(STATMC_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    for (int b = 0; b < n && rc == STATMC_OK; b++) {   // every block's pack is complete when its event fires
+        hip(hipSetDevice(blocks[b].device), "hipSetDevice");
+        hip(hipEventCreateWithFlags(&packed[b], hipEventDisableTiming), "hipEventCreate");
+        hip(hipEventCreateWithFlags(&phase1[b], hipEventDisableTiming), "hipEventCreate");
+        hip(hipEventRecord(packed[b], S(blocks[b].stream)), "hipEventRecord");
+    }
+    auto copy = [&](int dst, int dx, int dy, int src, int sx, int sy, int w, int h) {
+        if (rc != STATMC_OK) return;
+        rc = statmc_copy_rect(&blocks[dst].packed, blocks[dst].device, dx, dy, &blocks[src].packed, blocks[src].device, sx, sy, w, h, 60,
+                              blocks[dst].stream);
+    };
+    // phase 1: columns of the owned rows, from the left / right neighbour's interior
+    for (int b = 0; b < n && rc == STATMC_OK; b++) {
+        const int bx = b % gx, by = b / gx;
+        int pl, pr, pt, pb;
+        halo(bx, by, pl, pr, pt, pb);
+        hip(hipSetDevice(blocks[b].device), "hipSetDevice");
+        if (pl) {
+            int nl, nr, nt, nb;
+            halo(bx - 1, by, nl, nr, nt, nb);
+            hip(hipStreamWaitEvent(S(blocks[b].stream), packed[b - 1], 0), "hipStreamWaitEvent");
+            copy(b, 0, pt, b - 1, nl + block_w - r, nt, r, block_h);
+        }
+        if (pr) {
+            int nl, nr, nt, nb;
+            halo(bx + 1, by, nl, nr, nt, nb);
+            hip(hipStreamWaitEvent(S(blocks[b].stream), packed[b + 1], 0), "hipStreamWaitEvent");
+            copy(b, pl + block_w, pt, b + 1, nl, nt, r, block_h);
+        }
+        hip(hipEventRecord(phase1[b], S(blocks[b].stream)), "hipEventRecord");
+    }
+    // phase 2: rows over the full widened width (the vertical neighbour's columns were filled by ITS phase 1)
+    for (int b = 0; b < n && rc == STATMC_OK; b++) {
+        const int bx = b % gx, by = b / gx;
+        int pl, pr, pt, pb;
+        halo(bx, by, pl, pr, pt, pb);
+        hip(hipSetDevice(blocks[b].device), "hipSetDevice");
+        const int pw = block_w + pl + pr;
+        if (pt) {
+            int nl, nr, nt, nb;
+            halo(bx, by - 1, nl, nr, nt, nb);
+            hip(hipStreamWaitEvent(S(blocks[b].stream), phase1[b - gx], 0), "hipStreamWaitEvent");
+            copy(b, 0, 0, b - gx, 0, nt + block_h - r, pw, r);
+        }
+        if (pb) {
+            int nl, nr, nt, nb;
+            halo(bx, by + 1, nl, nr, nt, nb);
+            hip(hipStreamWaitEvent(S(blocks[b].stream), phase1[b + gx], 0), "hipStreamWaitEvent");
+            copy(b, 0, pt + block_h, b + gx, 0, nt, pw, r);
+        }
+    }
+    for (int b = 0; b < n; b++) {   // events may be destroyed while pending: HIP releases them when they complete
+        if (packed[b]) (void)hipEventDestroy(packed[b]);
+        if (phase1[b]) (void)hipEventDestroy(phase1[b]);
+    }
+    (void)hipSetDevice(cur);
+    return rc;
+}
+
 int statmc_filter_f32(const statmc_filter_args *a) {
     if (int rc = statmc_prepass(a, 1)) return rc;
     return statmc_window_filter(a, 1);

@@ -107,3 +107,28 @@ def test_fit_spec_finds_the_spec_that_wrote_the_dumps(gpu, tmp_path):
     rows = [l for l in out.stdout.splitlines() if re.match(r"^\d\.\d+e", l)]
     assert len(rows) == 3 * 8                                                    # 3 levels x 2^3 specs
     assert float(rows[1].split()[0]) > 1e-5 or "gate=asym,channels=joint,sides=one" in rows[1]   # only the rounding-twin gate form ties
+
+
+@pytest.mark.parametrize("grid", ["2x1", "2x2", "1x3"])
+def test_sharded_denoise_through_the_cpp_host(gpu, tmp_path, grid):
+    """The C++ host side without Python in the data path: statmc::FilmShards cuts the Estimator's images into film
+    blocks, runs pre-pass + pack per block, statmc_halo_exchange (device-to-device copies ordered by events), the
+    window filter per block, and pastes film-f together -- bit-identical to the unsharded Estimator::Denoise()."""
+    from conftest import make_case
+    from statmc_amd import build, pfm
+    exe = build.build_tools()
+    W, H, spp = 144, 96, 8
+    _, smp, st = make_case(W, H, spp, seed=9)
+    rad = st["radiance"]
+    stem = str(tmp_path / "scene")
+    for name, img in {"film": rad["film_mean"], "t0-b0-n": rad["n"], "t0-b0-mean": rad["mean"], "t0-b0-m2": rad["m2"],
+                      "t0-b0-m3": rad["m3"], "t1-b0-film-mean": st["normal"]["mean"], "t2-b0-film-mean": st["albedo"]["mean"]}.items():
+        pfm.write_pfm("%s-%d-%s.pfm" % (stem, spp, name), img)
+    outs = {}
+    for g in (None, grid):
+        cmd = [exe, "--stem", stem, "--spp", str(spp), "--output", "film-f", "--parts", "2"] + (["--grid", g] if g else [])
+        out = subprocess.run(cmd, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        outs[g] = pfm.read_pfm("%s-%d-film-f.pfm" % (stem, spp))
+    assert np.isfinite(outs[None]).all() and np.abs(outs[None] - rad["film_mean"]).max() > 0
+    assert np.array_equal(outs[grid], outs[None])

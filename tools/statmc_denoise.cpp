@@ -7,6 +7,7 @@
 //                  [--output 'film-f,t0-b0-mean-corr'] [--warmup]
 //                  [--significance 0|1|2] [--tquantiles table.txt] [--compare other/stem]
 //                  [--spec gate=sym|asym,channels=and|joint,sides=two|one,dof=pixel|welch,border=clip|clamp,small_n=accept|exclude]
+//                  [--grid GXxGY [--devices 0,1,..]]   the denoise pass over film blocks with a halo exchange (C++ only)
 //   statmc_denoise --catalogue [--config denoise|acrr|smis|proden|ours] [--width W --height H]
 //
 // Per iteration it reads "<stem>-<spp>-film.pfm" and every "<stem>-<spp>-t<i>-b<j>-<suffix>.pfm"
@@ -21,6 +22,7 @@
 // bound is stated in.  --tquantiles loads whitespace-separated t quantiles for dof 1..n into the
 // selected significance slot (for users who have the reference's own tables).
 #include <chrono>
+#include <memory>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +35,8 @@
 #include "statmc_pfm.hpp"
 
 using namespace statmc;
+
+extern "C" int statmc_debug_force_filter_parts(int k);   // test hook of the library: window-sweep parts per tile
 
 static std::vector<std::string> split(const std::string &s) {
     std::vector<std::string> out;
@@ -110,7 +114,8 @@ static StatPathParams shippedConfig(const std::string &name) {
 
 int main(int argc, char **argv) {
     try {
-        std::string stem, sppList, output = "film-f", config = "denoise", compareStem, tqFile, specText;
+        std::string stem, sppList, output = "film-f", config = "denoise", compareStem, tqFile, specText, gridText, devicesText;
+        int forceParts = 0;
         int significance = 0;
         StatPathParams params = shippedConfig("denoise");
         bool catalogue = false, warmup = false, configGiven = false;
@@ -137,6 +142,9 @@ int main(int argc, char **argv) {
             else if (a == "--significance") significance = std::stoi(next());
             else if (a == "--tquantiles") tqFile = next();
             else if (a == "--spec") specText = next();
+            else if (a == "--grid") gridText = next();          // GXxGY: the denoise pass sharded over film blocks
+            else if (a == "--devices") devicesText = next();    // devices the blocks go to, round robin (default: one)
+            else if (a == "--parts") forceParts = std::stoi(next());
             else if (a == "--width") width = std::stoi(next());
             else if (a == "--height") height = std::stoi(next());
             else throw std::runtime_error("unknown option " + a);
@@ -203,6 +211,15 @@ int main(int argc, char **argv) {
         stat_denoiser::setSignificance(significance);
         stat_denoiser::setFilterSpec(stat_denoiser::parseFilterSpec(specText));
         const std::vector<std::string> outputs = split(output);
+        if (forceParts > 0) statmc_debug_force_filter_parts(forceParts);
+        std::unique_ptr<FilmShards> shards;
+        if (!gridText.empty()) {
+            const size_t x = gridText.find('x');
+            if (x == std::string::npos) throw std::runtime_error("--grid wants GXxGY");
+            std::vector<int> devs;
+            for (const auto &d : split(devicesText)) devs.push_back(std::stoi(d));
+            shards.reset(new FilmShards(est, std::stoi(gridText.substr(0, x)), std::stoi(gridText.substr(x + 1)), devs));
+        }
 
         auto iteration = [&](const std::string &spp, bool write) {
             using clk = std::chrono::steady_clock;
@@ -224,7 +241,8 @@ int main(int argc, char **argv) {
             std::cout << "I/O time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count() << std::endl;
             t0 = clk::now();
             est.Upload();
-            est.Denoise();
+            if (shards) shards->Denoise();   // film blocks + halo exchange (statmc_halo_exchange), same result bit for bit
+            else est.Denoise();
             est.Download();
             est.Synchronize();
             t1 = clk::now();
