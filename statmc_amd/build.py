@@ -88,7 +88,9 @@ def build(force=False, verbose=False):
 ROOT = os.path.dirname(HERE)
 DENOISE_BIN = os.path.join(ROOT, "tools", "bin", "statmc_denoise")
 RENDER_SIM_BIN = os.path.join(ROOT, "tools", "bin", "statmc_render_sim")
-TOOLS = {DENOISE_BIN: "statmc_denoise.cpp", RENDER_SIM_BIN: "statmc_render_sim.cpp"}
+CV_ADAPTOR_BIN = os.path.join(ROOT, "tools", "bin", "test_cv_adaptor")   # tests/cpp/test_cv_adaptor.cpp: include/statmc_cv.hpp in use
+TOOLS = {DENOISE_BIN: "statmc_denoise.cpp", RENDER_SIM_BIN: "statmc_render_sim.cpp",
+         CV_ADAPTOR_BIN: os.path.join("..", "tests", "cpp", "test_cv_adaptor.cpp")}
 
 
 def build_tools(force=False):

@@ -156,3 +156,15 @@ def test_cpp_host_side_under_sanitizers(tmp_path, sanitizer):
     out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "host side ok" in out.stdout
+
+
+def test_patches_apply_to_the_reference():
+    """patches/000*.patch against the reference checkout (container only: the GPU box has no /root/reference)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.isdir("/root/reference/src/statistics"):
+        pytest.skip("no reference checkout here")
+    r = subprocess.run([os.path.join(root, "tools", "check_patches.sh")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("applied 000") == 3 and "patches apply" in r.stdout

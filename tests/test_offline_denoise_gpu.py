@@ -132,3 +132,24 @@ def test_sharded_denoise_through_the_cpp_host(gpu, tmp_path, grid):
         outs[g] = pfm.read_pfm("%s-%d-film-f.pfm" % (stem, spp))
     assert np.isfinite(outs[None]).all() and np.abs(outs[None] - rad["film_mean"]).max() > 0
     assert np.array_equal(outs[grid], outs[None])
+
+
+def test_cv_adaptor_matches_the_library(gpu, tmp_path):
+    """include/statmc_cv.hpp -- the cv:: names the reference's statistics path uses, on top of the C ABI -- driven the
+    way the reference's Estimator drives OpenCV (Buffers, uploaded PtrStepSzb tables, filter<float3> with the argument
+    list of estimator.cpp:465-487, PFM in BGR order): same film-f as the golden vector."""
+    from statmc_amd import build, pfm
+    build.build_tools()
+    g = np.load([p for p in GOLDEN if "default_r20" in p][0])     # the binary runs the shipped sd 10 / radius 20
+    spp = int(g["spp"])
+    stem = str(tmp_path / "scene")
+    for name, img in {"film": g["film_mean"], "t0-b0-n": g["n"], "t0-b0-mean": g["mean"], "t0-b0-m2": g["m2"], "t0-b0-m3": g["m3"],
+                      "t1-b0-film-mean": g["normal_mean"], "t2-b0-film-mean": g["albedo_mean"]}.items():
+        pfm.write_pfm("%s-%d-%s.pfm" % (stem, spp, name), img)
+    out_path = str(tmp_path / "film-f.pfm")
+    out = subprocess.run([build.CV_ADAPTOR_BIN, stem, str(spp), out_path], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stderr)
+    assert out.stdout.startswith("ok 40x28 dumps 7")
+    film_f = pfm.read_pfm(out_path)
+    for c in range(3):
+        assert rel_l2(film_f[..., c], g["film_f"][..., c]) <= 1e-5
