@@ -735,6 +735,23 @@ class Estimator {
     void Synchronize() { stat_denoiser::synchronize(stream); }  // estimator.cpp:571-573
     int deviceIndex() const { return device; }
 
+    // Tile-local pooled moments of a device image -- per tileSize x tileSize tile and channel {count, mean, M2}, by one
+    // wave per tile (Welford per lane, Chan merges through wave shuffles: statmc_tile_moments).  On the untransformed
+    // radiance mean (filmBuffers[type][bounce]) this is the local noise level of the estimate, tile by tile: what an
+    // adaptive sampler or a progress display reads instead of the full-resolution images.  Returns a host image of
+    // tiles_y rows and tiles_x * channels columns whose "pixels" are the three moments; blocks until it is there.
+    HostImage TileMoments(const Buffer &b, int tileSize = 16) {
+        const int C = b.gpuMat.channels();
+        const int tx = (width + tileSize - 1) / tileSize, ty = (height + tileSize - 1) / tileSize;
+        DeviceImage dev(ty, tx * C, F32C3);
+        HostImage host(ty, tx * C, F32C3);
+        check(statmc_tile_moments((uint16_t)width, (uint16_t)height, C, static_cast<const float *>(b.gpuMat.data()), tileSize,
+                                  static_cast<float *>(dev.data()), stream.handle()));
+        dev.download(host, stream);
+        Synchronize();
+        return host;
+    }
+
     // ---- the accumulation side: tiles in, statistics images on the device ------------------
     // estimator.cpp:297-309.  (GetTilesF, the filter-weighted variant, is not used by Render.)
     template <typename T>

@@ -68,6 +68,7 @@ def lib():
                                                 [C.c_int] * 5)
         _lib.oracle_film_update.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, f32p]
         _lib.oracle_num_threads.restype = C.c_int
+        _lib.oracle_tile_moments.argtypes = [C.c_int] * 3 + [f32p, C.c_int, f32p]
     return _lib
 
 
@@ -169,6 +170,16 @@ def film_update(pixels, splat_scale=1.0, scale=1.0):
     assert pixels.dtype == FILM_PIXEL_DTYPE and pixels.flags["C_CONTIGUOUS"]
     out = np.empty(pixels.shape + (3,), np.float32)
     lib().oracle_film_update(pixels.ctypes.data, pixels.size, float(splat_scale), float(scale), _f(out))
+    return out
+
+
+def tile_moments(values, tile_size):
+    """{count, mean, M2} per tile and channel: float32 [tiles_y, tiles_x, C, 3]."""
+    values = np.ascontiguousarray(values, dtype=np.float32)
+    h, w = values.shape[:2]
+    c = values.shape[2] if values.ndim == 3 else 1
+    out = np.zeros((-(-h // tile_size), -(-w // tile_size), c, 3), np.float32)
+    lib().oracle_tile_moments(w, h, c, _f(values), int(tile_size), _f(out))
     return out
 
 

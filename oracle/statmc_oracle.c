@@ -246,6 +246,55 @@ void oracle_film_update(const oracle_film_pixel *pixels, size_t n_pixels, float 
     }
 }
 
+/* ---------------------------- tile-local pooled moments ----------------------------------
+ * No reference function: BASELINE.json's north_star asks for "wavefront-level Welford reductions for tile-local
+ * variance"; the product's tile_moments_kernel (statmc_pointwise.hip) gives every lane of a 64-wide wave the pixels
+ * lane, lane + 64, ... of a tile (Welford, in that order) and merges the 64 partial (count, mean, M2) triples with
+ * Chan's formula in a butterfly of xor-shuffles (offsets 32, 16, ..., 1); lane 0 holds the tile's result.  Restated
+ * here lane by lane, level by level, so that the comparison is bit for bit. */
+static void chan_merge(float *na, float *ma, float *sa, float nb, float mb, float sb) {
+    const float n = *na + nb;
+    if (n > 0.f) {
+        const float d = mb - *ma;
+        const float f = nb / n;
+        *ma = *ma + d * f;
+        *sa = *sa + sb + d * d * *na * f;
+        *na = n;
+    }
+}
+
+void oracle_tile_moments(int width, int height, int channels, const float *values, int tile_size, float *out) {
+    const int tiles_x = (width + tile_size - 1) / tile_size, tiles_y = (height + tile_size - 1) / tile_size;
+    const int tpx = tile_size * tile_size;
+    for (int ty = 0; ty < tiles_y; ty++)
+        for (int tx = 0; tx < tiles_x; tx++)
+            for (int c = 0; c < channels; c++) {
+                float cnt[64], mean[64], m2[64];
+                for (int lane = 0; lane < 64; lane++) {
+                    cnt[lane] = mean[lane] = m2[lane] = 0.f;
+                    for (int i = lane; i < tpx; i += 64) {
+                        const int x = tx * tile_size + i % tile_size, y = ty * tile_size + i / tile_size;
+                        if (x < width && y < height) {
+                            const float v = values[((size_t)y * width + x) * channels + c];
+                            cnt[lane] += 1.f;
+                            const float d = v - mean[lane];
+                            mean[lane] += d / cnt[lane];
+                            m2[lane] += d * (v - mean[lane]);
+                        }
+                    }
+                }
+                for (int off = 32; off >= 1; off >>= 1) {
+                    float nb[64], mb[64], sb[64];
+                    for (int lane = 0; lane < 64; lane++) { nb[lane] = cnt[lane ^ off]; mb[lane] = mean[lane ^ off]; sb[lane] = m2[lane ^ off]; }
+                    for (int lane = 0; lane < 64; lane++) chan_merge(&cnt[lane], &mean[lane], &m2[lane], nb[lane], mb[lane], sb[lane]);
+                }
+                float *o = out + (((size_t)ty * tiles_x + tx) * channels + c) * 3;
+                o[0] = cnt[0];
+                o[1] = mean[0];
+                o[2] = m2[0];
+            }
+}
+
 /* ---------------------------- filter spec v2 -------------------------------------------
  * The reference's arithmetic for this half is not in the tree (header comment of statmc_oracle.h).  What the
  * tree leaves open (SURVEY.md App. B "Unknown") is carried by oracle_filter_spec; the all-zero spec is this

@@ -153,6 +153,10 @@ void oracle_filter_spec_run(int width, int height, int channels, float ds, int r
                             int n_g, const float *const *g_buffers, const int *g_channels, const float *g_dr,
                             float *out, int rx0, int ry0, int rx1, int ry1, int threads);
 
+/* Tile-local pooled moments {count, mean, M2} per tile_size x tile_size tile and channel (out: [tiles_y][tiles_x]
+ * [channels][3]); the lane order and merge tree of the product's wave-level kernel, restated (statmc_oracle.c). */
+void oracle_tile_moments(int width, int height, int channels, const float *values, int tile_size, float *out);
+
 int oracle_num_threads(void);
 
 #ifdef __cplusplus

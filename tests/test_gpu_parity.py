@@ -338,7 +338,9 @@ def test_mean_vars_matches_oracle(gpu, oracle, channels, quirk):
 
 
 @pytest.mark.parametrize("tile_size", [8, 16])
-def test_tile_moments(gpu, tile_size):
+def test_tile_moments(gpu, oracle, tile_size):
+    """Wave-level Welford + Chan merges against the oracle's lane-by-lane restatement of the same tree (bit for bit),
+    and both against float64 NumPy."""
     rng = np.random.default_rng(1)
     H, W, Cn = 37, 50, 3
     v = rng.lognormal(0, 1, (H, W, Cn)).astype(np.float32)
@@ -347,6 +349,7 @@ def test_tile_moments(gpu, tile_size):
     gpu.tile_moments(to_dev(v), tile_size, out)
     torch.cuda.synchronize()
     out = out.cpu().numpy()
+    assert np.array_equal(out, oracle.tile_moments(v, tile_size))
     for j in range(ty):
         for i in range(tx):
             blk = v[j * tile_size:(j + 1) * tile_size, i * tile_size:(i + 1) * tile_size].astype(np.float64)

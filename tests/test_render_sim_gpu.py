@@ -67,9 +67,11 @@ def test_render_loop_matches_oracle(gpu, oracle, tmp_path, W, H, stage_mb):
     stem = str(tmp_path / "sim")
     out = subprocess.run([build.RENDER_SIM_BIN, "--width", str(W), "--height", str(H), "--spp", str(spp),
                           "--iterations", str(iterations), "--threads", "4", "--seed", str(seed), "--stem", stem,
-                          "--filtersd", str(sd), "--filterradius", str(radius), "--stage-mb", str(stage_mb), "--warmup"],
+                          "--filtersd", str(sd), "--filterradius", str(radius), "--stage-mb", str(stage_mb), "--warmup",
+                          "--tilestats"],
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
+    assert out.stdout.count("Noisiest tile:") == iterations
     # --warmup: one throw-away iteration whose statistics must not survive into the real run
     assert out.stdout.count("CUDA time [ns]:") == iterations + 1 and "Iteration: 3" in out.stdout and "Warm-Up End" in out.stdout
 
@@ -101,6 +103,11 @@ def test_render_loop_matches_oracle(gpu, oracle, tmp_path, W, H, stage_mb):
         got = rd("t0-b0-film-mean-f")
         for c in range(3):
             assert rel_l2(got[..., c], ref[..., c]) <= 1e-5, (i, c)
+        # --tilestats: tile-local pooled mean / variance of the radiance mean (wave-level Welford + Chan merges) against
+        # the oracle's restatement of the same reduction tree on the same image: bit for bit
+        tm = oracle.tile_moments(r["film_mean"], 16)
+        assert np.array_equal(rd("t0-b0-tile-mean"), tm[..., 1])
+        assert np.array_equal(rd("t0-b0-tile-var"), np.where(tm[..., 0] > 1, tm[..., 2] / np.maximum(tm[..., 0] - 1, 1), 0).astype(np.float32))
 
 
 def test_render_loop_statistics_only(gpu, tmp_path):

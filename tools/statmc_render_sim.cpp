@@ -19,7 +19,7 @@
 //
 //   statmc_render_sim --width 96 --height 56 --spp 4 --iterations 3 --stem out/sim [--threads 4]
 //                     [--seed 1] [--filtersd 10] [--filterradius 20] [--stage-mb 2048] [--no-denoise]
-//                     [--config denoise|acrr|smis] [--trackedbounces 5] [--outputregex '.*'] [--warmup]
+//                     [--config denoise|acrr|smis] [--trackedbounces 5] [--outputregex '.*'] [--warmup] [--tilestats]
 // --config denoise: Render<Vec3>, RGB radiance + normal + albedo, filter<float3> (scenes/render-denoise.pbrt).
 // --config acrr:    Render<Float>, "multichannelstats" false: the luminance of the path prefix up to each
 //                   of the tracked bounces is one float stat buffer, filtered together by filter<float>
@@ -104,7 +104,7 @@ struct Options {
     unsigned seed = 1;
     float filterSD = 10.f;
     int filterRadius = 20;
-    bool denoise = true, acrr = false, smis = false, warmUp = false;
+    bool denoise = true, acrr = false, smis = false, warmUp = false, tileStats = false;
     std::string stem, outputRegex = ".*";
 };
 
@@ -245,6 +245,31 @@ static void Render(const Options &o) {
             estimator.Synchronize();
             outBufSel.PrepareOutput();
             outBufSel.Write(std::to_string(done));
+            if (o.tileStats && !estimator.filmBuffers.empty() && !estimator.filmBuffers[0].empty()) {
+                // --tilestats: the local noise level of the radiance estimate, one value per 16 x 16 tile (the tile
+                // size of the render loop): "<stem>-<spp>-t0-b0-tile-mean.pfm" and "-tile-var.pfm" (pooled sample
+                // variance M2 / (count - 1) of the per-pixel means inside the tile), from wave-level reductions
+                const Buffer &fm = estimator.filmBuffers[0][0];
+                const int C = fm.gpuMat.channels();
+                const HostImage tm = estimator.TileMoments(fm, 16);
+                const int ty = tm.rows, tx = tm.cols / C;
+                std::vector<float> mean((size_t)ty * tx * C), var((size_t)ty * tx * C);
+                float worst = -1.f;
+                int wx = 0, wy = 0;
+                for (int y = 0; y < ty; y++)
+                    for (int x = 0; x < tx; x++)
+                        for (int c = 0; c < C; c++) {
+                            const float *m = tm.ptr<float>() + (((size_t)y * tx + x) * C + c) * 3;
+                            const size_t k = ((size_t)y * tx + x) * C + c;
+                            mean[k] = m[1];
+                            var[k] = m[0] > 1.f ? m[2] / (m[0] - 1.f) : 0.f;
+                            if (var[k] > worst) { worst = var[k]; wx = x; wy = y; }
+                        }
+                const std::string prefix = o.stem + "-" + std::to_string(done) + "-" + fm.name + "-";
+                writePfm(prefix.substr(0, prefix.size() - std::string("film-mean-").size()) + "tile-mean.pfm", tx, ty, C, mean.data());
+                writePfm(prefix.substr(0, prefix.size() - std::string("film-mean-").size()) + "tile-var.pfm", tx, ty, C, var.data());
+                std::cout << "Noisiest tile: (" << wx << ", " << wy << ") variance " << worst << std::endl;
+            }
         }
         end = std::chrono::steady_clock::now();
         std::cout << "Output time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(end - begin).count() << std::endl;
@@ -287,6 +312,7 @@ int main(int argc, char **argv) {
         else if (a == "--outputregex") o.outputRegex = next();
         else if (a == "--no-denoise") o.denoise = false;
         else if (a == "--warmup") o.warmUp = true;
+        else if (a == "--tilestats") o.tileStats = true;
         else if (a == "--config") {
             const std::string c = next();
             if (c != "denoise" && c != "acrr" && c != "smis") {
