@@ -398,8 +398,8 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
         }
         if (!statmc::fast_path_eligible(k, 3))
             return fail(STATMC_ERR_UNSUPPORTED,
-                        "packed_inputs: radius must be 1..20, DR factors finite and <= 0, and the filter spec the default "
-                        "one (gate, channel rule, dof, border)");
+                        "packed_inputs: radius must be 1..20, DR factors finite and <= 0, and the discriminator's degrees "
+                        "of freedom per pixel (STATMC_DOF_PIXEL)");
         if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
         k.gscale0 = sqrtf(-k.g[0].dr * 1.44269504088896340736f);
         k.gscale1 = sqrtf(-k.g[1].dr * 1.44269504088896340736f);

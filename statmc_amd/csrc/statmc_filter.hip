@@ -290,25 +290,55 @@ __device__ __forceinline__ void range_exponent(const LaneState &st, const v2f *g
 
 // membership gate, weight and accumulation of a tap pair (mc / nd / col: corrected mean,
 // -discriminator, colour of the two taps, 3 channels each)
-template <int H, unsigned MASK, int K>
+// SPEC: the membership test of the filter spec (statmc_filter_spec, oracle pair_member).  0 = the default (symmetric
+// gate, every channel passes); kSpecAsym = one-sided gate fma(d, d, -D_q) <= D_p; kSpecJoint = channels pooled,
+// sum_c lhs_c <= sum_c rhs_c (an RGB buffer only: a float buffer has one channel, pooled == per channel).
+constexpr int kSpecAsym = 1, kSpecJoint = 2;
+
+template <int H, unsigned MASK, int K, int SPEC>
 __device__ __forceinline__ void gate_accumulate(LaneState &st, const v2f (&e)[kPx], const v2f *mc, const v2f *nd, const v2f *col) {
     using M = TapMask<H, MASK>;
     constexpr bool RGB = K == 0;
     constexpr int NB = RGB ? 3 : K;  // float mode: only the K real buffers of the launch are gated and summed
+    constexpr bool ASYM = (SPEC & kSpecAsym) != 0, JOINT = RGB && (SPEC & kSpecJoint) != 0;
     v2f u[kPx][3], w[kPx];
-    // membership statistic per channel: t_c = fma(d_c, d_c, -(D_p,c + D_q,c))  (the oracle's expression; nd = -D_q)
+    // membership statistic per channel: t_c = fma(d_c, d_c, -(D_p,c + D_q,c))  (the oracle's expression; nd = -D_q);
+    // one-sided gate: fma(d_c, d_c, -D_q,c), compared with D_p,c below
 #pragma unroll
     for (int ch = 0; ch < NB; ch++) {
 #pragma unroll
         for (int k = 0; k < kPx; k++) if (M::on(k)) {
             const v2f d = st.pmc[k][ch] - mc[ch];
-            const v2f s = nd[ch] - st.pd[k][ch];
+            const v2f s = ASYM ? nd[ch] : nd[ch] - st.pd[k][ch];
             u[k][ch] = __builtin_elementwise_fma(d, d, s);
         }
     }
 #pragma unroll
     for (int k = 0; k < kPx; k++) if (M::on(k)) w[k] = v2f{__builtin_amdgcn_exp2f(e[k].x), __builtin_amdgcn_exp2f(e[k].y)};
-    if constexpr (RGB) {
+    if constexpr (RGB && SPEC != 0) {
+        // the non-default tests as the oracle writes them: plain compares (a NaN statistic fails every one)
+#pragma unroll
+        for (int k = 0; k < kPx; k++) if (M::on(k)) {
+            bool m0, m1;
+            if constexpr (JOINT) {
+                const v2f lhs = (u[k][0] + u[k][1]) + u[k][2];
+                const float rhs = ASYM ? (st.pd[k][0] + st.pd[k][1]) + st.pd[k][2] : 0.f;
+                m0 = lhs.x <= rhs;
+                m1 = lhs.y <= rhs;
+            } else {
+                m0 = u[k][0].x <= st.pd[k][0] && u[k][1].x <= st.pd[k][1] && u[k][2].x <= st.pd[k][2];
+                m1 = u[k][0].y <= st.pd[k][0] && u[k][1].y <= st.pd[k][1] && u[k][2].y <= st.pd[k][2];
+            }
+            w[k] = v2f{M::in0(k) && m0 ? w[k].x : 0.f, M::in1(k) && m1 ? w[k].y : 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < kPx; k++) if (M::on(k)) st.sw[k][0] += w[k];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+#pragma unroll
+            for (int k = 0; k < kPx; k++) if (M::on(k)) st.acc[k][ch] = __builtin_elementwise_fma(w[k], col[ch], st.acc[k][ch]);
+        }
+    } else if constexpr (RGB) {
         // all three channels pass  <=>  max_c t_c <= 0; max3 + compare + select stays on the VALU, where 3
         // compares + 2 scalar ANDs send every pair through the scalar unit.  v_max3 drops NaN operands,
         // so a pixel that takes no part (NaN statistic, non-finite mean or colour) is staged with NaN in
@@ -331,8 +361,9 @@ __device__ __forceinline__ void gate_accumulate(LaneState &st, const v2f (&e)[kP
         for (int ch = 0; ch < NB; ch++) {
 #pragma unroll
             for (int k = 0; k < kPx; k++) if (M::on(k)) {
-                const v2f wc = v2f{M::in0(k) && u[k][ch].x <= 0.f ? w[k].x : 0.f,
-                                   M::in1(k) && u[k][ch].y <= 0.f ? w[k].y : 0.f};
+                const float rhs = ASYM ? st.pd[k][ch] : 0.f;
+                const v2f wc = v2f{M::in0(k) && u[k][ch].x <= rhs ? w[k].x : 0.f,
+                                   M::in1(k) && u[k][ch].y <= rhs ? w[k].y : 0.f};
                 st.sw[k][ch] += wc;
                 st.acc[k][ch] = __builtin_elementwise_fma(wc, col[ch], st.acc[k][ch]);
             }
@@ -340,17 +371,17 @@ __device__ __forceinline__ void gate_accumulate(LaneState &st, const v2f (&e)[kP
     }
 }
 
-template <int H, unsigned MASK, int K>
+template <int H, unsigned MASK, int K, int SPEC>
 __device__ __forceinline__ void compute_half(LaneState &st, const HalfChunk &c) {
     v2f e[kPx];
     range_exponent<H, MASK>(st, c.q + C_G0, c.tp, e);
-    gate_accumulate<H, MASK, K>(st, e, c.q + C_MC, c.q + C_ND, c.q + C_COL);
+    gate_accumulate<H, MASK, K, SPEC>(st, e, c.q + C_MC, c.q + C_ND, c.q + C_COL);
 }
 
 // Sweep one window row: 2*rp/4 + 1 read groups.  RT > 0 (compile-time radius, a multiple of 4):
 // the first and last groups hold (tap, pixel) pairs outside the window and get their static
 // masks; every group between is full and runs as a rolled loop.
-template <int RT, int K>
+template <int RT, int K, int SPEC>
 __device__ __forceinline__ void eval_row(LaneState &st, const float *row, int pitch, const float *tab, int n_chunks) {
     HalfChunk c;
     constexpr unsigned kFull = 0xFFFFu;
@@ -359,34 +390,34 @@ __device__ __forceinline__ void eval_row(LaneState &st, const float *row, int pi
         static_assert(RT % 4 == 0 && n >= 3, "static variant: radius multiple of 4");
         static_assert(ChunkMask<1, RT>::value() == kFull && ChunkMask<n - 2, RT>::value() == kFull, "");
         load_half<0>(c, row, pitch, tab, 0);
-        compute_half<0, ChunkMask<0, RT>::value(), K>(st, c);
+        compute_half<0, ChunkMask<0, RT>::value(), K, SPEC>(st, c);
         load_half<1>(c, row, pitch, tab, 0);
-        compute_half<1, ChunkMask<0, RT>::value(), K>(st, c);
+        compute_half<1, ChunkMask<0, RT>::value(), K, SPEC>(st, c);
 #pragma unroll 1
         for (int j = 1; j < n - 1; j++) {
             load_half<0>(c, row, pitch, tab, j);
-            compute_half<0, kFull, K>(st, c);
+            compute_half<0, kFull, K, SPEC>(st, c);
             load_half<1>(c, row, pitch, tab, j);
-            compute_half<1, kFull, K>(st, c);
+            compute_half<1, kFull, K, SPEC>(st, c);
         }
         load_half<0>(c, row, pitch, tab, n - 1);
-        compute_half<0, ChunkMask<n - 1, RT>::value(), K>(st, c);
+        compute_half<0, ChunkMask<n - 1, RT>::value(), K, SPEC>(st, c);
         load_half<1>(c, row, pitch, tab, n - 1);
-        compute_half<1, ChunkMask<n - 1, RT>::value(), K>(st, c);
+        compute_half<1, ChunkMask<n - 1, RT>::value(), K, SPEC>(st, c);
     } else {
 #pragma unroll 1
         for (int j = 0; j < n_chunks; j++) {
             load_half<0>(c, row, pitch, tab, j);
-            compute_half<0, kFull, K>(st, c);
+            compute_half<0, kFull, K, SPEC>(st, c);
             load_half<1>(c, row, pitch, tab, j);
-            compute_half<1, kFull, K>(st, c);
+            compute_half<1, kFull, K, SPEC>(st, c);
         }
     }
 }
 // RT > 0: compile-time radius (window edges resolved statically); RT == 0: runtime radius
 // a.radius <= 20, every pair of every read group evaluated, the table masks taps beyond r.
 // One work item: `part` of tile `tile` of the tile grid laid over columns [cx0, cx1) of the ROI.
-template <int RT, int K, bool DUAL>
+template <int RT, int K, int SPEC, bool DUAL>
 __device__ __forceinline__ void filter_tile(const FilterArgs &a, float *lds, int u, int cx0, int cx1) {
     using G = Geo<DUAL>;
     constexpr bool RGB = K == 0;  // K = 0: filter<float3>; K = 1..3: filter<float> with K real buffers in this launch
@@ -416,8 +447,10 @@ __device__ __forceinline__ void filter_tile(const FilterArgs &a, float *lds, int
     const int n_rows = 2 * r + 1;
     // ... clipped to the window rows that reach the image for at least one row of the tile (tiles at
     // the top and bottom of the film would otherwise sweep up to 13 rows of nothing but invalid taps)
-    const int s0 = max((n_rows * part) / a.n_parts, r - y0 - (G::ROWS - 1));
-    const int s1 = min((n_rows * (part + 1)) / a.n_parts, a.height + r - y0);
+    // (border rule "clamp": rows beyond the image repeat its first / last row, nothing to clip)
+    const bool clamp = a.border == STATMC_BORDER_CLAMP;
+    const int s0 = clamp ? (n_rows * part) / a.n_parts : max((n_rows * part) / a.n_parts, r - y0 - (G::ROWS - 1));
+    const int s1 = clamp ? (n_rows * (part + 1)) / a.n_parts : min((n_rows * (part + 1)) / a.n_parts, a.height + r - y0);
 
     // ---- the lane's own 4 pixels (clamped into the image so the loads stay in bounds)
     LaneState st;
@@ -484,7 +517,7 @@ __device__ __forceinline__ void filter_tile(const FilterArgs &a, float *lds, int
         }
 
         const float *row = lds + slot * slot_floats + kPx * lane;
-        eval_row<RT, K>(st, row, pitch, tab_lds + ((step - s0) & 1) * tw_pad, n_chunks);
+        eval_row<RT, K, SPEC>(st, row, pitch, tab_lds + ((step - s0) & 1) * tw_pad, n_chunks);
 
         if (tstage) *reinterpret_cast<v2f *>(tab_lds + ((step - s0 + 1) & 1) * tw_pad + 2 * ti) = tnext;
         if (stage) store_pixel(lds + fill * slot_floats, pitch, threadIdx.x, nxt, k0, k1, RGB);
@@ -545,14 +578,14 @@ __device__ __forceinline__ void filter_tile(const FilterArgs &a, float *lds, int
 // the parts of a tile and vertically adjacent tiles -- which stage the same image rows -- then hit in
 // the same L2 instead of each fetching its own copy over the fabric.  Placement only affects speed;
 // the remap is a bijection for any grid size.
-template <int RT, int K>
+template <int RT, int K, int SPEC>
 __global__ __launch_bounds__(kThreads, 2) void window_filter_lds(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n_items = gridDim.x, b = blockIdx.x;
     const int q8 = n_items >> 3, rem8 = n_items & 7, xcd = b & 7, idx = b >> 3;
     const int u = xcd < rem8 ? xcd * (q8 + 1) + idx : rem8 * (q8 + 1) + (xcd - rem8) * q8 + idx;
-    if (u < a.n_main_items) filter_tile<RT, K, false>(a, lds, u, a.rx0, a.rx_split);
-    else filter_tile<RT, K, true>(a, lds, u - a.n_main_items, a.rx_split, a.rx1);
+    if (u < a.n_main_items) filter_tile<RT, K, SPEC, false>(a, lds, u, a.rx0, a.rx_split);
+    else filter_tile<RT, K, SPEC, true>(a, lds, u - a.n_main_items, a.rx_split, a.rx1);
 }
 
 // Sums the per-part partial (acc, sum_w) of every ROI pixel in part order and normalises.
@@ -618,10 +651,9 @@ hipError_t launch_pack_inputs(const PackArgs &a, hipStream_t s) {
 // non-positive DR factors and radius 1..20.
 bool fast_path_eligible(const FilterArgs &a, int channels) {
     if (channels != 3 && channels != 1) return false;
-    // the LDS kernels implement the default spec; every other one runs the general kernel
-    if (a.gate != STATMC_GATE_SYMMETRIC || a.channel_rule != STATMC_CHANNELS_AND || a.dof != STATMC_DOF_PIXEL ||
-        a.border != STATMC_BORDER_CLIP)
-        return false;
+    // the LDS kernels know both gates, both channel rules and both border rules; a per-pair Welch lookup runs the
+    // general kernel
+    if (a.dof != STATMC_DOF_PIXEL) return false;
     int slots = 0;
     for (int g = 0; g < a.n_g; g++) {
         if (a.g[g].channels != 1 && a.g[g].channels != 3) return false;
@@ -719,7 +751,7 @@ static hipError_t allow_full_lds(const void *kernel) {
     return hipSuccess;
 }
 
-template <int RT, int K>
+template <int RT, int K, int SPEC = 0>
 static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
     if (a.partial == nullptr) a.n_parts = 1;
     if (a.rx1 <= a.rx0 || a.ry1 <= a.ry0) return hipSuccess;
@@ -730,8 +762,8 @@ static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
     const int dual_tiles = a.rx_split < a.rx1 ? (h + Geo<true>::ROWS - 1) / Geo<true>::ROWS : 0;
     a.n_main_items = main_tiles * a.n_parts;
     const size_t lds_bytes = std::max(main_tiles ? lds_bytes_for<false>(rp) : 0, dual_tiles ? lds_bytes_for<true>(rp) : 0);
-    if (hipError_t e = allow_full_lds(reinterpret_cast<const void *>(&window_filter_lds<RT, K>)); e != hipSuccess) return e;
-    hipLaunchKernelGGL((window_filter_lds<RT, K>), dim3((main_tiles + dual_tiles) * a.n_parts), dim3(kThreads), lds_bytes, s, a);
+    if (hipError_t e = allow_full_lds(reinterpret_cast<const void *>(&window_filter_lds<RT, K, SPEC>)); e != hipSuccess) return e;
+    hipLaunchKernelGGL((window_filter_lds<RT, K, SPEC>), dim3((main_tiles + dual_tiles) * a.n_parts), dim3(kThreads), lds_bytes, s, a);
     if (a.n_parts > 1) {
         const dim3 cgrid((a.rx1 - a.rx0 + 63) / 64, (a.ry1 - a.ry0 + 3) / 4);
         hipLaunchKernelGGL(combine_parts_kernel<K == 0>, cgrid, dim3(256), 0, s, a);
@@ -751,18 +783,42 @@ bool lds_path_selected(const FilterArgs &a, int channels) {
     return fast_path_eligible(a, channels) && a.spatial_tab != nullptr && g_variant_override != 1;
 }
 
-// Window filter reading the 15-channel block + halo image (multi-GPU path): LDS kernel only.
+// Launch of the one-sided LDS kernel for the arguments' spec.  The default membership test has a compile-time-radius
+// build for r = 20; the other tests (one-sided gate, pooled channels) run the runtime-radius build.
+static int lds_spec_of(const FilterArgs &a, bool rgb) {
+    return (a.gate == STATMC_GATE_ASYMMETRIC ? kSpecAsym : 0) | (rgb && a.channel_rule == STATMC_CHANNELS_JOINT ? kSpecJoint : 0);
+}
+
+template <int K>
+static hipError_t launch_lds_spec(const FilterArgs &a, hipStream_t s, const char **variant) {
+    constexpr bool rgb = K == 0;
+    switch (lds_spec_of(a, rgb)) {
+    case 0:
+        if (a.radius == 20 && g_variant_override != 2) {
+            *variant = rgb ? "lds_r20" : "lds_r20_f";
+            return launch_lds<20, K>(a, s);
+        }
+        *variant = rgb ? "lds_rt" : "lds_rt_f";
+        return launch_lds<0, K>(a, s);
+    case kSpecAsym:
+        *variant = rgb ? "lds_rt_asym" : "lds_rt_f_asym";
+        return launch_lds<0, K, kSpecAsym>(a, s);
+    case kSpecJoint:
+        *variant = "lds_rt_joint";
+        return launch_lds<0, K, rgb ? kSpecJoint : 0>(a, s);
+    default:
+        *variant = "lds_rt_asym_joint";
+        return launch_lds<0, K, rgb ? (kSpecAsym | kSpecJoint) : kSpecAsym>(a, s);
+    }
+}
+
+// Window filter reading the 15-channel block + halo image (multi-GPU path): LDS kernels only.
 hipError_t launch_lds_packed(const FilterArgs &a, hipStream_t s, const char **variant) {
     if (a.sym.patch != nullptr) {
         *variant = "sym_r20";
         return launch_sym(a, s);
     }
-    if (a.radius == 20 && g_variant_override != 2) {
-        *variant = "lds_r20";
-        return launch_lds<20, 0>(a, s);
-    }
-    *variant = "lds_rt";
-    return launch_lds<0, 0>(a, s);
+    return launch_lds_spec<0>(a, s, variant);
 }
 
 hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s, const char **variant) {
@@ -772,15 +828,8 @@ hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s
         return launch_sym(a, s);
     }
     if (fast) {
-        const bool rgb = channels == 3;
-        if (a.radius == 20 && g_variant_override != 2) {
-            *variant = rgb ? "lds_r20" : "lds_r20_f";
-            if (rgb) return launch_lds<20, 0>(a, s);
-            return a.f_active >= 3 ? launch_lds<20, 3>(a, s) : a.f_active == 2 ? launch_lds<20, 2>(a, s) : launch_lds<20, 1>(a, s);
-        }
-        *variant = rgb ? "lds_rt" : "lds_rt_f";
-        if (rgb) return launch_lds<0, 0>(a, s);
-        return a.f_active >= 3 ? launch_lds<0, 3>(a, s) : a.f_active == 2 ? launch_lds<0, 2>(a, s) : launch_lds<0, 1>(a, s);
+        if (channels == 3) return launch_lds_spec<0>(a, s, variant);
+        return a.f_active >= 3 ? launch_lds_spec<3>(a, s, variant) : a.f_active == 2 ? launch_lds_spec<2>(a, s, variant) : launch_lds_spec<1>(a, s, variant);
     }
     *variant = "generic";
     const dim3 grid((a.rx1 - a.rx0 + 31) / 32, (a.ry1 - a.ry0 + 7) / 8);

@@ -46,6 +46,10 @@ __device__ __forceinline__ void load_features(const FilterArgs &a, long long q, 
 template <bool RGB>
 __device__ __forceinline__ StagedPixel load_pixel(const FilterArgs &a, int x, int yrow) {
     StagedPixel s;
+    if (a.border == STATMC_BORDER_CLAMP) {  // taps beyond the image repeat its edge pixels
+        x = min(max(x, 0), a.width - 1);
+        yrow = min(max(yrow, 0), a.height - 1);
+    }
     s.valid = x >= 0 && x < a.width && yrow >= 0 && yrow < a.height;
     if (s.valid) {
         const long long q = (long long)yrow * a.width + x;

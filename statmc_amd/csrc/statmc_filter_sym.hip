@@ -190,26 +190,31 @@ __device__ __forceinline__ void range_exponent(const Lane &st, const v4f *g, con
 template <int H, unsigned MASK>
 __device__ __forceinline__ void gate_weight(const Lane &st, const v4f *mcn, const v2f (&e)[kPx], v2f (&w)[kPx]) {
     using M = Taps<H, MASK>;
-    v2f u[kPx][3];
-    // membership statistic per channel: fma(d, d, -(D_p + D_q))
+    // two pixels at a time: 6 independent chains are enough to keep the pipe busy and halve the live statistics
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) {
+    for (int k0 = 0; k0 < kPx; k0 += 2) {
+        v2f u[2][3];
+        // membership statistic per channel: fma(d, d, -(D_p + D_q))
 #pragma unroll
-        for (int k = 0; k < kPx; k++) if (M::on(k)) {
-            const v2f d = sub_bc(st.ms[k][ch], 0, pair_of<H>(mcn[ch]));
-            const v2f s = rsub_bc(pair_of<H>(mcn[3 + ch]), st.ms[k][ch], 1);
-            u[k][ch] = __builtin_elementwise_fma(d, d, s);
+        for (int ch = 0; ch < 3; ch++) {
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) if (M::on(k0 + kk)) {
+                const v2f d = sub_bc(st.ms[k0 + kk][ch], 0, pair_of<H>(mcn[ch]));
+                const v2f s = rsub_bc(pair_of<H>(mcn[3 + ch]), st.ms[k0 + kk][ch], 1);
+                u[kk][ch] = __builtin_elementwise_fma(d, d, s);
+            }
         }
-    }
 #pragma unroll
-    for (int k = 0; k < kPx; k++) if (M::on(k)) w[k] = v2f{__builtin_amdgcn_exp2f(e[k].x), __builtin_amdgcn_exp2f(e[k].y)};
-    // all three channels pass <=> max_c <= 0; v_max3 drops NaN operands, which is why a pixel that takes no
-    // part is staged with NaN in all three channels of its mean
+        for (int kk = 0; kk < 2; kk++) if (M::on(k0 + kk)) w[k0 + kk] = v2f{__builtin_amdgcn_exp2f(e[k0 + kk].x), __builtin_amdgcn_exp2f(e[k0 + kk].y)};
+        // all three channels pass <=> max_c <= 0; v_max3 drops NaN operands, which is why a pixel that takes no
+        // part is staged with NaN in all three channels of its mean
 #pragma unroll
-    for (int k = 0; k < kPx; k++) if (M::on(k)) {
-        const float m0 = __builtin_fmaxf(__builtin_fmaxf(u[k][0].x, u[k][1].x), u[k][2].x);
-        const float m1 = __builtin_fmaxf(__builtin_fmaxf(u[k][0].y, u[k][1].y), u[k][2].y);
-        w[k] = v2f{M::in0(k) && m0 <= 0.f ? w[k].x : 0.f, M::in1(k) && m1 <= 0.f ? w[k].y : 0.f};
+        for (int kk = 0; kk < 2; kk++) if (M::on(k0 + kk)) {
+            const int k = k0 + kk;
+            const float m0 = __builtin_fmaxf(__builtin_fmaxf(u[kk][0].x, u[kk][1].x), u[kk][2].x);
+            const float m1 = __builtin_fmaxf(__builtin_fmaxf(u[kk][0].y, u[kk][1].y), u[kk][2].y);
+            w[k] = v2f{M::in0(k) && m0 <= 0.f ? w[k].x : 0.f, M::in1(k) && m1 <= 0.f ? w[k].y : 0.f};
+        }
     }
 }
 
@@ -781,6 +786,8 @@ size_t sym_patch_floats(const FilterArgs &a, int n_parts) {
 // filter<float3>, radius 20, default spec, G-buffers = up to two RGB images (other sets: the one-sided kernel)
 bool sym_eligible(const FilterArgs &a, int channels) {
     if (channels != 3 || a.radius != sym::kR || !fast_path_eligible(a, channels)) return false;
+    // the pair-symmetric kernel implements the default membership test and border rule
+    if (a.gate != STATMC_GATE_SYMMETRIC || a.channel_rule != STATMC_CHANNELS_AND || a.border != STATMC_BORDER_CLIP) return false;
     if (a.n_g > 2) return false;
     for (int g = 0; g < a.n_g; g++)
         if (a.g[g].channels != 3) return false;

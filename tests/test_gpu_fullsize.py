@@ -105,14 +105,30 @@ def test_lds_kernel_vs_generic_vs_oracle_on_strip(gpu, oracle, film1080):
         assert rel_l2(a, ref) <= 1e-5
 
 
-def test_block_decomposition_equals_whole_film(gpu, film1080):
+@pytest.mark.parametrize("spec_kw,variant", [(dict(), "sym_r20"), (dict(border=1), "lds_r20"),
+                                             (dict(gate=1, channel_rule=1, border=1), "lds_rt_asym_joint")],
+                         ids=["default", "clamp", "asym+joint+clamp"])
+def test_block_decomposition_equals_whole_film(gpu, film1080, spec_kw, variant):
     """What 4 GPUs compute (2x2 blocks, each with its r-pixel halo) is bit-identical to the
-    single-GPU result: per-pixel tap order does not depend on the block origin."""
+    single-GPU result: per-pixel tap order does not depend on the block origin -- under the default spec (pair-symmetric
+    kernel, film-anchored tiles) and under specs the one-sided LDS kernel serves (a clamped border repeats the FILM's
+    edge pixels: the local image ends where the film does on exactly those sides)."""
     from statmc_amd import sharding
     fs, _ = film1080
     colour = fs.state["radiance"]["film_mean"]
+    gpu.set_filter_spec(**spec_kw)
     gpu.force_filter_parts(2)      # same window-row split for the film and for the blocks
+    try:
+        blocks_2x2_equal_whole(gpu, fs, colour, variant)
+    finally:
+        gpu.force_filter_parts(0)
+        gpu.set_filter_spec()
+
+
+def blocks_2x2_equal_whole(gpu, fs, colour, variant):
+    from statmc_amd import sharding
     whole = wf(gpu, fs, colour, torch.zeros_like(colour)).clone()
+    assert gpu.last_filter_variant() == variant
     imgs = dict(mean_corr=fs.mean_corr, disc=fs.disc, colour=colour, normal=fs.g_buffer("normal"), albedo=fs.g_buffer("albedo"))
     bw, bh = W // 2, H // 2
     for rank in range(4):
@@ -125,8 +141,8 @@ def test_block_decomposition_equals_whole_film(gpu, film1080):
                                        filter_sd=FILTER_SD, radius=RADIUS, roi=L.roi, film_origin=(ox - L.pl, oy - L.pt))
         gpu.window_filter(a, 3)
         torch.cuda.synchronize()
+        assert gpu.last_filter_variant() == variant
         assert torch.equal(L.interior(out), whole[oy:oy + bh, ox:ox + bw]), rank
-    gpu.force_filter_parts(0)
 
 
 # ====================================================================== every BASELINE.json config

@@ -982,6 +982,21 @@ def run_spec(gpu, oracle, st, spec_kw, radius, sd, channels=3, alpha_index=0, fo
     return mc.cpu().numpy(), dc.cpu().numpy(), out.cpu().numpy(), variant, (omc, odc, oout)
 
 
+def expected_lds_variant(spec_kw, channels, radius):
+    """Which kernel serves a spec: a per-pair Welch lookup runs the general kernel; the one-sided LDS kernel knows
+    both gates, channel rules and border rules (the non-default membership tests in its runtime-radius build); the
+    pair-symmetric kernel takes the default test and border at r = 20."""
+    gate, joint = spec_kw.get("gate", 0), spec_kw.get("channel_rule", 0) and channels == 3
+    if spec_kw.get("dof", 0):
+        return "generic"
+    f = "_f" if channels == 1 else ""
+    if gate or joint:
+        return "lds_rt" + f + ("_asym" if gate else "") + ("_joint" if joint else "")
+    if radius == 20:
+        return "sym_r20" if channels == 3 and not spec_kw.get("border", 0) else "lds_r20" + f
+    return "lds_rt" + f
+
+
 @pytest.mark.parametrize("spec_kw", SPEC_VARIANTS, ids=[spec_id(v) for v in SPEC_VARIANTS])
 def test_filter_spec_variants_match_oracle(gpu, oracle, spec_kw):
     """All 64 combinations of the six open choices (gate form, channel rule, quantile sides, dof, border,
@@ -992,22 +1007,26 @@ def test_filter_spec_variants_match_oracle(gpu, oracle, spec_kw):
     st["radiance"]["n"][20, 60:64] = 0
     mc, dc, out, variant, (omc, odc, oout) = run_spec(gpu, oracle, st, spec_kw, radius=7, sd=4.0, alpha_index=2)
     assert np.array_equal(mc, omc, equal_nan=True) and np.array_equal(dc, odc, equal_nan=True)
-    default_kernel_spec = not (spec_kw["gate"] or spec_kw["channel_rule"] or spec_kw["dof"] or spec_kw["border"])
-    assert variant == ("lds_rt" if default_kernel_spec else "generic"), variant
+    assert variant == expected_lds_variant(spec_kw, 3, 7), variant
     for c in range(3):
         assert rel_l2(out[..., c], oout[..., c]) <= TOL, c
+    if variant != "generic":       # the general kernel under the same spec: the two HIP paths agree as well
+        _, _, out_g, variant_g, _ = run_spec(gpu, oracle, st, spec_kw, radius=7, sd=4.0, alpha_index=2, force=1)
+        assert variant_g == "generic"
+        for c in range(3):
+            assert rel_l2(out[..., c], out_g[..., c]) <= TOL, c
 
 
-@pytest.mark.parametrize("spec_kw", [dict(), dict(gate=1), dict(dof=1), dict(border=1, channel_rule=1), dict(sides=1, small_n=1)],
-                         ids=["default", "asym", "welch", "clamp+joint", "one-sided+exclude"])
+@pytest.mark.parametrize("spec_kw", [dict(), dict(gate=1), dict(dof=1), dict(border=1, channel_rule=1), dict(sides=1, small_n=1),
+                                     dict(border=1), dict(gate=1, channel_rule=1, border=1)],
+                         ids=["default", "asym", "welch", "clamp+joint", "one-sided+exclude", "clamp", "asym+joint+clamp"])
 @pytest.mark.parametrize("channels", [1, 3])
 def test_filter_spec_r20_and_float(gpu, oracle, spec_kw, channels):
     """The shipped radius / sd under a few specs, RGB and float buffers; the default spec must stay on the LDS kernel."""
     _, smp, st = make_case(280, 26, 4, seed=23)
     mc, dc, out, variant, (omc, odc, oout) = run_spec(gpu, oracle, st, spec_kw, radius=RADIUS, sd=FILTER_SD, channels=channels)
     assert np.array_equal(dc, odc, equal_nan=True)
-    fast = not (spec_kw.get("gate") or spec_kw.get("channel_rule") or spec_kw.get("dof") or spec_kw.get("border"))
-    assert variant == (("sym_r20" if channels == 3 else "lds_r20_f") if fast else "generic")
+    assert variant == expected_lds_variant(spec_kw, channels, RADIUS), variant
     for c in range(channels):
         assert rel_l2(out[..., c], oout[..., c]) <= TOL, c
 
