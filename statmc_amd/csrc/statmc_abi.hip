@@ -152,14 +152,20 @@ void apply_spec(const DeviceState &d, statmc::FilterArgs &k, const statmc_filter
     (void)a;
 }
 // pair-symmetric kernel: tile range, parts and the patch workspace of this launch
-int prepare_sym(const DeviceState &d, statmc::FilterArgs &k, const statmc_filter_args *a) {
+// pair: filter<float> on the pair-symmetric kernel -- the workspace also holds the three RGB-shaped images every
+// launch packs its two buffers into (behind the patches, 16-byte aligned).
+int prepare_sym(const DeviceState &d, statmc::FilterArgs &k, const statmc_filter_args *a, bool pair = false) {
     k.sym.fx0 = a->film_x0;
     k.sym.fy0 = a->film_y0;
     statmc::sym_geometry(k);
     k.n_parts = statmc::sym_filter_parts(k, d.cus);
     float *ws = nullptr;
-    if (int rc = partial_workspace(statmc::sym_patch_floats(k, k.n_parts) * sizeof(float), a->stream, &ws)) return rc;
+    const size_t patch_floats = (statmc::sym_patch_floats(k, k.n_parts) + 3) & ~(size_t)3;
+    const size_t image_floats = pair ? (size_t)9 * k.width * k.height : 0;
+    if (int rc = partial_workspace((patch_floats + image_floats) * sizeof(float), a->stream, &ws)) return rc;
     k.sym.patch = reinterpret_cast<float4 *>(ws);
+    k.sym.pair = pair ? 1 : 0;
+    k.sym.pair_images = pair ? ws + patch_floats : nullptr;
     return STATMC_OK;
 }
 int prepass_table(const DeviceState &d) { return d.alpha_index + STATMC_TQ_N_ALPHAS * (d.spec.sides ? 1 : 0); }
@@ -435,19 +441,22 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
         k.n_parts = 1;
     }
     const bool fast = statmc::lds_path_selected(k, channels);
-    if (fast && statmc::sym_path_selected(k, channels)) {
-        if (int rc = prepare_sym(dstate, k, a)) return rc;
+    const bool sym = fast && statmc::sym_path_selected(k, channels);
+    if (sym) {
+        if (int rc = prepare_sym(dstate, k, a, channels == 1)) return rc;
     } else if (fast) {
         const int per_px = channels == 3 ? 4 : 8;
         if (k.n_parts > 1) {
             if (int rc = partial_workspace((size_t)k.n_parts * W * H * per_px * sizeof(float), a->stream, &k.partial)) return rc;
         }
     }
-    const int group = (fast && channels == 1) ? 3 : 1;  // float buffers go three per launch on the fast path
+    // float buffers share the range weight of a launch: two per launch on the pair-symmetric kernel, three on the
+    // one-sided LDS kernel
+    const int group = (fast && channels == 1) ? (sym ? 2 : 3) : 1;
     for (int b0 = 0; b0 < a->n_buffers; b0 += group) {
         const char *variant = "none";
-        if (group == 3) {
-            k.f_active = a->n_buffers - b0 < 3 ? a->n_buffers - b0 : 3;
+        if (group > 1) {
+            k.f_active = a->n_buffers - b0 < group ? a->n_buffers - b0 : group;
             if (!a->film || !a->film_filtered) return fail(STATMC_ERR_INVALID, "null film table");
             for (int j = 0; j < 3; j++) {
                 const int b = b0 + (j < k.f_active ? j : k.f_active - 1);

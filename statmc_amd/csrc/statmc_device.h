@@ -122,6 +122,8 @@ struct FilterArgs {
         int fx0, fy0;             // film coordinates of local pixel (0, 0)
         long long item_stride4;   // float4 per work item (tile, part) in the patch workspace
         float4 *patch;            // [items][p-side 4 x 256 | q-side rows x 296] (sum w*colour rgb, sum w)
+        int pair;                 // filter<float>: f_active (1 or 2) 1-channel buffers (f_mean_corr / f_disc / f_colour / f_out) per launch
+        float *pair_images;       // ... staged from three [height][width][3] images this launch packs them into
     } sym;
 };
 

@@ -823,8 +823,8 @@ hipError_t launch_lds_packed(const FilterArgs &a, hipStream_t s, const char **va
 
 hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s, const char **variant) {
     const bool fast = lds_path_selected(a, channels);
-    if (fast && channels == 3 && a.sym.patch != nullptr) {
-        *variant = "sym_r20";
+    if (fast && a.sym.patch != nullptr) {
+        *variant = channels == 3 ? "sym_r20" : "sym_r20_f";
         return launch_sym(a, s);
     }
     if (fast) {

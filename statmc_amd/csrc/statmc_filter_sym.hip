@@ -187,16 +187,19 @@ __device__ __forceinline__ void range_exponent(const Lane &st, const v4f *g, con
 }
 
 // membership gate and weight of tap pair H: w = member ? exp2(e) : 0   (mcn: corrected mean planes 0..2, -D planes 3..5)
-template <int H, unsigned MASK>
-__device__ __forceinline__ void gate_weight(const Lane &st, const v4f *mcn, const v2f (&e)[kPx], v2f (&w)[kPx]) {
+// PAIR (two float buffers in the (x, y) channels): one weight per buffer, w for buffer 0 and wb for buffer 1 -- the
+// buffers share the range weight and gate separately (filter<float>: every buffer is its own 1-channel test).
+template <int H, unsigned MASK, bool PAIR>
+__device__ __forceinline__ void gate_weight(const Lane &st, const v4f *mcn, const v2f (&e)[kPx], v2f (&w)[kPx], v2f (&wb)[kPx]) {
     using M = Taps<H, MASK>;
+    constexpr int NC = PAIR ? 2 : 3;
     // two pixels at a time: 6 independent chains are enough to keep the pipe busy and halve the live statistics
 #pragma unroll
     for (int k0 = 0; k0 < kPx; k0 += 2) {
         v2f u[2][3];
         // membership statistic per channel: fma(d, d, -(D_p + D_q))
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
+        for (int ch = 0; ch < NC; ch++) {
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) if (M::on(k0 + kk)) {
                 const v2f d = sub_bc(st.ms[k0 + kk][ch], 0, pair_of<H>(mcn[ch]));
@@ -206,22 +209,54 @@ __device__ __forceinline__ void gate_weight(const Lane &st, const v4f *mcn, cons
         }
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) if (M::on(k0 + kk)) w[k0 + kk] = v2f{__builtin_amdgcn_exp2f(e[k0 + kk].x), __builtin_amdgcn_exp2f(e[k0 + kk].y)};
-        // all three channels pass <=> max_c <= 0; v_max3 drops NaN operands, which is why a pixel that takes no
-        // part is staged with NaN in all three channels of its mean
+        if constexpr (PAIR) {
+            // a pixel that takes no part in a buffer is staged with NaN in that buffer's mean: the compare fails
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++) if (M::on(k0 + kk)) {
-            const int k = k0 + kk;
-            const float m0 = __builtin_fmaxf(__builtin_fmaxf(u[kk][0].x, u[kk][1].x), u[kk][2].x);
-            const float m1 = __builtin_fmaxf(__builtin_fmaxf(u[kk][0].y, u[kk][1].y), u[kk][2].y);
-            w[k] = v2f{M::in0(k) && m0 <= 0.f ? w[k].x : 0.f, M::in1(k) && m1 <= 0.f ? w[k].y : 0.f};
+            for (int kk = 0; kk < 2; kk++) if (M::on(k0 + kk)) {
+                const int k = k0 + kk;
+                const v2f x = w[k];
+                w[k] = v2f{M::in0(k) && u[kk][0].x <= 0.f ? x.x : 0.f, M::in1(k) && u[kk][0].y <= 0.f ? x.y : 0.f};
+                wb[k] = v2f{M::in0(k) && u[kk][1].x <= 0.f ? x.x : 0.f, M::in1(k) && u[kk][1].y <= 0.f ? x.y : 0.f};
+            }
+        } else {
+            // all three channels pass <=> max_c <= 0; v_max3 drops NaN operands, which is why a pixel that takes no
+            // part is staged with NaN in all three channels of its mean
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) if (M::on(k0 + kk)) {
+                const int k = k0 + kk;
+                const float m0 = __builtin_fmaxf(__builtin_fmaxf(u[kk][0].x, u[kk][1].x), u[kk][2].x);
+                const float m1 = __builtin_fmaxf(__builtin_fmaxf(u[kk][0].y, u[kk][1].y), u[kk][2].y);
+                w[k] = v2f{M::in0(k) && m0 <= 0.f ? w[k].x : 0.f, M::in1(k) && m1 <= 0.f ? w[k].y : 0.f};
+            }
         }
     }
 }
 
-// p side: the lane's pixels collect w * colour_q; q side (SYM): the taps' accumulators collect w * colour_p
-template <int H, unsigned MASK, bool SYM>
-__device__ __forceinline__ void accumulate(Lane &st, const v4f *col, const v2f (&w)[kPx], v2f (&qv)[4]) {
+// p side: the lane's pixels collect w * colour_q; q side (SYM): the taps' accumulators collect w * colour_p.
+// PAIR: the four sums per pixel are (sum w0 c0, sum w1 c1, sum w0, sum w1) -- acc[0], acc[1], acc[2], sw -- instead of
+// (sum w r, sum w g, sum w b, sum w); the same four packed operations per side.
+template <int H, unsigned MASK, bool SYM, bool PAIR>
+__device__ __forceinline__ void accumulate(Lane &st, const v4f *col, const v2f (&w)[kPx], const v2f (&wb)[kPx], v2f (&qv)[4]) {
     using M = Taps<H, MASK>;
+    if constexpr (PAIR) {
+#pragma unroll
+        for (int k = 0; k < kPx; k++) if (M::on(k)) { st.acc[k][2] += w[k]; st.sw[k] += wb[k]; }
+#pragma unroll
+        for (int k = 0; k < kPx; k++) if (M::on(k)) {
+            st.acc[k][0] = __builtin_elementwise_fma(w[k], pair_of<H>(col[0]), st.acc[k][0]);
+            st.acc[k][1] = __builtin_elementwise_fma(wb[k], pair_of<H>(col[1]), st.acc[k][1]);
+        }
+        if constexpr (SYM) {
+#pragma unroll
+            for (int k = 0; k < kPx; k++) if (M::on(k)) {
+                qv[0] = fma_bc(w[k], st.pc[k][0], 0, qv[0]);
+                qv[1] = fma_bc(wb[k], st.pc[k][0], 1, qv[1]);
+            }
+#pragma unroll
+            for (int k = 0; k < kPx; k++) if (M::on(k)) { qv[2] += w[k]; qv[3] += wb[k]; }
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < kPx; k++) if (M::on(k)) st.sw[k] += w[k];
 #pragma unroll
@@ -240,11 +275,6 @@ __device__ __forceinline__ void accumulate(Lane &st, const v4f *col, const v2f (
     }
 }
 
-// One read group (4 taps) against the lane's 4 pixels.  Every LDS operand is one ds_read_b128 of a channel plane
-// (consecutive lanes read consecutive 16 B: conflict-free); the group runs in three phases -- range exponents
-// (6 feature planes), gates and weights (6 statistics planes), accumulation (3 colour planes + the 4 accumulator
-// planes of the taps) -- so that only one phase's operands are live at a time; the next phase's loads are issued
-// before the current phase's arithmetic.
 // LDS byte address of a pointer into the workgroup's shared array
 __device__ __forceinline__ unsigned lds_addr(const float *p) {
     return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) float *)p;
@@ -275,12 +305,13 @@ __device__ __forceinline__ void lds_wait(v4f &a, v4f &b, v4f &c, v4f &d) {
 // planes of the taps).  PIPE: the statistics planes are requested before the feature planes and the colour /
 // accumulator planes before the gates, by hand-placed reads, so that two of the three phases find their operands
 // in registers; otherwise the compiler's own loads (each phase waits for its operands).
-template <unsigned MASK, bool SYM, bool PIPE>
+template <unsigned MASK, bool SYM, bool PIPE, bool PAIR>
 __device__ __forceinline__ void chunk(Lane &st, const float *__restrict__ row, const float *__restrict__ tab, float *__restrict__ qrow, int j) {
     using M0 = Taps<0, MASK>;
     using M1 = Taps<1, MASK>;
     const float *r = row + 4 * j;
     v4f g[6], mcn[6], col[3], q4[4];
+    v2f e0[kPx], e1[kPx], w0[kPx], w1[kPx], wb0[kPx], wb1[kPx];   // wb*: second buffer's weights (PAIR)
     unsigned ra = 0, qa = 0;
     if constexpr ((kAblate & 32) != 0) {   // timing only: operands from nowhere (no LDS reads in the sweep)
 #pragma unroll
@@ -289,16 +320,15 @@ __device__ __forceinline__ void chunk(Lane &st, const float *__restrict__ row, c
         for (int ch = 0; ch < 3; ch++) asm volatile("" : "=v"(col[ch]));
 #pragma unroll
         for (int v = 0; v < 4; v++) asm volatile("" : "=v"(q4[v]));
-        v2f e0[kPx], e1[kPx], w0[kPx], w1[kPx];
         if constexpr (M0::any()) range_exponent<0, MASK>(st, g, tab, j, e0);
         if constexpr (M1::any()) range_exponent<1, MASK>(st, g, tab, j, e1);
-        if constexpr (M0::any()) gate_weight<0, MASK>(st, mcn, e0, w0);
-        if constexpr (M1::any()) gate_weight<1, MASK>(st, mcn, e1, w1);
+        if constexpr (M0::any()) gate_weight<0, MASK, PAIR>(st, mcn, e0, w0, wb0);
+        if constexpr (M1::any()) gate_weight<1, MASK, PAIR>(st, mcn, e1, w1, wb1);
         v2f qa2[4], qb2[4];
 #pragma unroll
         for (int v = 0; v < 4; v++) { qa2[v] = pair_of<0>(q4[v]); qb2[v] = pair_of<1>(q4[v]); }
-        if constexpr (M0::any()) accumulate<0, MASK, SYM>(st, col, w0, qa2);
-        if constexpr (M1::any()) accumulate<1, MASK, SYM>(st, col, w1, qb2);
+        if constexpr (M0::any()) accumulate<0, MASK, SYM, PAIR>(st, col, w0, wb0, qa2);
+        if constexpr (M1::any()) accumulate<1, MASK, SYM, PAIR>(st, col, w1, wb1, qb2);
         if constexpr (SYM) {
 #pragma unroll
             for (int v = 0; v < 4; v++) asm volatile("" ::"v"(qa2[v]), "v"(qb2[v]));
@@ -317,7 +347,6 @@ __device__ __forceinline__ void chunk(Lane &st, const float *__restrict__ row, c
     }
 #pragma unroll
     for (int ch = 0; ch < 6; ch++) g[ch] = *reinterpret_cast<const v4f *>(r + (C_G0 + ch) * kP);
-    v2f e0[kPx], e1[kPx], w0[kPx], w1[kPx];
     if constexpr (M0::any()) range_exponent<0, MASK>(st, g, tab, j, e0);
     if constexpr (M1::any()) range_exponent<1, MASK>(st, g, tab, j, e1);
     if constexpr (PIPE) {
@@ -334,11 +363,13 @@ __device__ __forceinline__ void chunk(Lane &st, const float *__restrict__ row, c
         lds_wait<SYM ? 7 : 3>(mcn[0], mcn[1], mcn[2]);
         lds_wait<SYM ? 7 : 3>(mcn[3], mcn[4], mcn[5]);
     } else {
+        // (PAIR: the third channel's planes hold nothing and are not read)
 #pragma unroll
-        for (int ch = 0; ch < 6; ch++) mcn[ch] = *reinterpret_cast<const v4f *>(r + (C_MC + ch) * kP);
+        for (int ch = 0; ch < 6; ch++)
+            if (!(PAIR && ch % 3 == 2)) mcn[ch] = *reinterpret_cast<const v4f *>(r + (C_MC + ch) * kP);
     }
-    if constexpr (M0::any()) gate_weight<0, MASK>(st, mcn, e0, w0);
-    if constexpr (M1::any()) gate_weight<1, MASK>(st, mcn, e1, w1);
+    if constexpr (M0::any()) gate_weight<0, MASK, PAIR>(st, mcn, e0, w0, wb0);
+    if constexpr (M1::any()) gate_weight<1, MASK, PAIR>(st, mcn, e1, w1, wb1);
     if constexpr (PIPE) {
         // ... and the colour / accumulator planes before the gates; the wait names the weights too, so that it stays
         // behind the arithmetic that produced them (plain arithmetic may otherwise be scheduled after the wait)
@@ -348,7 +379,7 @@ __device__ __forceinline__ void chunk(Lane &st, const float *__restrict__ row, c
         if constexpr (SYM) lds_wait<0>(q4[0], q4[1], q4[2], q4[3]);
     } else {
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) col[ch] = *reinterpret_cast<const v4f *>(r + (C_COL + ch) * kP);
+        for (int ch = 0; ch < (PAIR ? 2 : 3); ch++) col[ch] = *reinterpret_cast<const v4f *>(r + (C_COL + ch) * kP);
         if constexpr (SYM) {
 #pragma unroll
             for (int v = 0; v < 4; v++) q4[v] = *reinterpret_cast<const v4f *>(qrow + 4 * j + v * kP);
@@ -359,8 +390,8 @@ __device__ __forceinline__ void chunk(Lane &st, const float *__restrict__ row, c
 #pragma unroll
         for (int v = 0; v < 4; v++) { qa2[v] = pair_of<0>(q4[v]); qb2[v] = pair_of<1>(q4[v]); }
     }
-    if constexpr (M0::any()) accumulate<0, MASK, SYM>(st, col, w0, qa2);
-    if constexpr (M1::any()) accumulate<1, MASK, SYM>(st, col, w1, qb2);
+    if constexpr (M0::any()) accumulate<0, MASK, SYM, PAIR>(st, col, w0, wb0, qa2);
+    if constexpr (M1::any()) accumulate<1, MASK, SYM, PAIR>(st, col, w1, wb1, qb2);
     if constexpr (SYM) {
         if constexpr ((kAblate & 64) != 0) {   // timing only: no write-back of the accumulators
 #pragma unroll
@@ -395,7 +426,7 @@ struct Range {
     static constexpr int last_full() { for (int j = kChunks - 1; j >= 0; j--) if (m(j) == kFull) return j; return -1; }
 };
 
-template <int LO, int HI, bool SYM>
+template <int LO, int HI, bool SYM, bool PAIR>
 __device__ __forceinline__ void sweep_range(Lane &st, const float *row, const float *tab, float *qrow) {
     using R = Range<LO, HI>;
     constexpr int j0 = R::first(), j1 = R::last(), f0 = R::first_full(), f1 = R::last_full();
@@ -403,13 +434,13 @@ __device__ __forceinline__ void sweep_range(Lane &st, const float *row, const fl
     constexpr bool has_full = f0 <= f1;
     constexpr int lo_end = has_full ? f0 : j1 + 1;      // masked groups j0 .. lo_end-1, full f0 .. f1, masked f1+1 .. j1
     static_assert(lo_end - j0 <= 2 && (!has_full || j1 - f1 <= 2), "more than two cut groups at an end");
-    if constexpr (j0 < lo_end) chunk<R::m(j0), SYM, kPipe>(st, row, tab, qrow, j0);
-    if constexpr (j0 + 1 < lo_end) chunk<R::m(j0 + 1), SYM, kPipe>(st, row, tab, qrow, j0 + 1);
+    if constexpr (j0 < lo_end) chunk<R::m(j0), SYM, kPipe, PAIR>(st, row, tab, qrow, j0);
+    if constexpr (j0 + 1 < lo_end) chunk<R::m(j0 + 1), SYM, kPipe, PAIR>(st, row, tab, qrow, j0 + 1);
     if constexpr (has_full) {
 #pragma unroll 1
-        for (int j = f0; j <= f1; j++) chunk<R::kFull, SYM, kPipe>(st, row, tab, qrow, j);
-        if constexpr (f1 + 1 <= j1) chunk<R::m(f1 + 1 <= j1 ? f1 + 1 : 0), SYM, kPipe>(st, row, tab, qrow, f1 + 1);
-        if constexpr (f1 + 2 <= j1) chunk<R::m(f1 + 2 <= j1 ? f1 + 2 : 0), SYM, kPipe>(st, row, tab, qrow, f1 + 2);
+        for (int j = f0; j <= f1; j++) chunk<R::kFull, SYM, kPipe, PAIR>(st, row, tab, qrow, j);
+        if constexpr (f1 + 1 <= j1) chunk<R::m(f1 + 1 <= j1 ? f1 + 1 : 0), SYM, kPipe, PAIR>(st, row, tab, qrow, f1 + 1);
+        if constexpr (f1 + 2 <= j1) chunk<R::m(f1 + 2 <= j1 ? f1 + 2 : 0), SYM, kPipe, PAIR>(st, row, tab, qrow, f1 + 2);
     }
 }
 
@@ -420,21 +451,21 @@ __device__ __forceinline__ void sweep_range(Lane &st, const float *row, const fl
 // uneven split is slower: 1.42 ms at kSplit = 0, 1.62 at 7, 1.75 at 11.  The SIMD is busy either way.)
 // dy = 0: the pairs inside a row are the taps dx >= 1 (the accumulator row is the wave's own row); the pixel's own
 // tap dx = 0 feeds the p side only.
-template <int HF>
+template <int HF, bool PAIR>
 __device__ __forceinline__ void eval_half_row(Lane &st, const float *row, const float *tab, float *qrow, bool dy0) {
     if constexpr (HF == 0) {
         if (dy0) {
-            sweep_range<0, 0, false>(st, row, tab, qrow);
-            if constexpr (kSplit >= 1) sweep_range<1, kSplit, true>(st, row, tab, qrow);
+            sweep_range<0, 0, false, PAIR>(st, row, tab, qrow);
+            if constexpr (kSplit >= 1) sweep_range<1, kSplit, true, PAIR>(st, row, tab, qrow);
         } else {
-            sweep_range<-kR, kSplit, true>(st, row, tab, qrow);
+            sweep_range<-kR, kSplit, true, PAIR>(st, row, tab, qrow);
         }
     } else {
         if constexpr (kSplit >= 1) {
-            sweep_range<kSplit + 1, kR, true>(st, row, tab, qrow);
+            sweep_range<kSplit + 1, kR, true, PAIR>(st, row, tab, qrow);
         } else {
-            if (dy0) sweep_range<1, kR, true>(st, row, tab, qrow);
-            else sweep_range<kSplit + 1, kR, true>(st, row, tab, qrow);
+            if (dy0) sweep_range<1, kR, true, PAIR>(st, row, tab, qrow);
+            else sweep_range<kSplit + 1, kR, true, PAIR>(st, row, tab, qrow);
         }
     }
 }
@@ -460,8 +491,8 @@ __device__ __forceinline__ StagedPixel load_px(const FilterArgs &a, int x, int y
 }
 
 // stage column i of a row: inputs as the one-sided kernel stages them, accumulators cleared
-__device__ __forceinline__ void stage_store(float *slot, int i, const StagedPixel &s, float k0, float k1) {
-    store_pixel(slot, kP, i, s, k0, k1, true);
+__device__ __forceinline__ void stage_store(float *slot, int i, const StagedPixel &s, float k0, float k1, bool rgb) {
+    store_pixel(slot, kP, i, s, k0, k1, rgb);
 #pragma unroll
     for (int v = 0; v < kQ; v++) slot[(kIn + v) * kP + i] = 0.f;
 }
@@ -518,7 +549,10 @@ __device__ __forceinline__ StagedPixel raw_pixel(const FilterArgs &a, const floa
 
 // DMA = rows are staged by LDS-DMA (two RGB G-buffers or the packed image, 16-byte aligned images whose width and
 // film x-origin are multiples of 4 pixels); otherwise through registers (any layout the one-sided kernel accepts).
-template <bool DMA>
+// PAIR = filter<float>, two 1-channel buffers per launch: the (x, y) channels of the three statistics / colour images
+// hold buffer 0 and buffer 1 (pack_pair_kernel), the third channel is empty; the buffers share the range weight, gate
+// and normalise separately.
+template <bool DMA, bool PAIR>
 __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // XCD-aware work mapping (as in the one-sided kernel): each XCD walks a contiguous range of items
@@ -565,7 +599,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             g1 = a.gscale1 != 0.f ? reinterpret_cast<const f3 *>(a.g[1].data)[p] : f3{0.f, 0.f, 0.f};
         }
         const bool inside = px >= 0 && px < a.width && py >= 0 && py < a.height;
-        const Validity ok = pixel_validity(mc, d, col, inside, true);
+        const Validity ok = pixel_validity(mc, d, col, inside, !PAIR);   // per pixel (RGB) / per buffer (PAIR)
         mc = canonical_mean(mc, ok);
         st.pg[k][0] = v2f{g0.x * k0, g0.y * k0};
         st.pg[k][1] = v2f{g0.z * k0, g1.x * k1};
@@ -574,8 +608,8 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
         st.ms[k][1] = v2f{mc.y, d.y};
         st.ms[k][2] = v2f{mc.z, d.z};
         // a pixel that takes no part adds nothing to its taps: weight 0, colour 0 (0 * NaN would poison them)
-        st.pc[k][0] = v2f{ok.x ? col.x : 0.f, ok.x ? col.y : 0.f};
-        st.pc[k][1] = v2f{ok.x ? col.z : 0.f, 0.f};
+        st.pc[k][0] = v2f{ok.x ? col.x : 0.f, ok.y ? col.y : 0.f};
+        st.pc[k][1] = v2f{ok.z ? col.z : 0.f, 0.f};
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) st.acc[k][ch] = v2f{0.f, 0.f};
         st.sw[k] = v2f{0.f, 0.f};
@@ -594,7 +628,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             const int rr = idx2 / kP, i = idx2 - rr * kP;
             const int rel = s_a + rr;
             const StagedPixel s = load_px(a, x0 - kR + i, y0 + rel);
-            stage_store(lds + (rel % kSlots) * kSlotFloats, i, s, k0, k1);
+            stage_store(lds + (rel % kSlots) * kSlotFloats, i, s, k0, k1, !PAIR);
         }
         if ((int)threadIdx.x < tw) {
             const float *t = a.spatial_tab + (s_a + kR) * tw + threadIdx.x;
@@ -627,7 +661,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
                         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's own transfers
                         if (stage) {
                             const StagedPixel sp = raw_pixel(a, raw_w, lane, ncols, x0 - kR + i, y0 + s + kRows);
-                            stage_store(lds + ((s + kRows) % kSlots) * kSlotFloats, i, sp, k0, k1);
+                            stage_store(lds + ((s + kRows) % kSlots) * kSlotFloats, i, sp, k0, k1, !PAIR);
                         }
                         if (s + 2 < s_b) {
                             __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the raw area has been read
@@ -652,16 +686,16 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             const float *tab = tab_lds + ((s - s_a) & 1) * kTabPad;
             if (kAblate & 8) {
             } else if (half == 0) {
-                eval_half_row<0>(st, row, tab, qrow, s == 0);
+                eval_half_row<0, PAIR>(st, row, tab, qrow, s == 0);
             } else {
-                eval_half_row<1>(st, row, tab, qrow, s == 0);
+                eval_half_row<1, PAIR>(st, row, tab, qrow, s == 0);
             }
 
             if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_ev += t - tk0; tk0 = t; }
             if (DMA && kHkAtEnd && half == 0) housekeeping();
             if (tstage) *reinterpret_cast<v2f *>(tab_lds + ((s - s_a + 1) & 1) * kTabPad + 2 * ti) = tnext;
             if constexpr (!DMA) {
-                if (stage) stage_store(lds + ((s + kRows) % kSlots) * kSlotFloats, i, nxt, k0, k1);
+                if (stage) stage_store(lds + ((s + kRows) % kSlots) * kSlotFloats, i, nxt, k0, k1, !PAIR);
             }
             if (!(kAblate & 16)) __syncthreads();
             if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_bar += t - tk0; tk0 = t; }
@@ -738,6 +772,11 @@ __global__ __launch_bounds__(256) void combine_sym_kernel(FilterArgs a) {
         }
     }
     const long long p = (long long)y * a.width + x;
+    if (a.sym.pair) {   // (sum w0 c0, sum w1 c1, sum w0, sum w1) of two float buffers
+        a.f_out[0][p] = t.z > 0.f ? t.x / t.z : a.f_colour[0][p];
+        if (a.f_active > 1) a.f_out[1][p] = t.w > 0.f ? t.y / t.w : a.f_colour[1][p];
+        return;
+    }
     f3 o;
     if (t.w > 0.f) {
         o.x = t.x / t.w; o.y = t.y / t.w; o.z = t.z / t.w;
@@ -745,6 +784,18 @@ __global__ __launch_bounds__(256) void combine_sym_kernel(FilterArgs a) {
         o = a.packed ? reinterpret_cast<const f3 *>(a.packed + p * 15)[2] : reinterpret_cast<const f3 *>(a.colour)[p];
     }
     reinterpret_cast<f3 *>(a.out)[p] = o;
+}
+
+// filter<float>: the statistics and colours of two 1-channel buffers -> the (x, y) channels of three RGB-shaped
+// images, so that rows stage exactly as for filter<float3>.  An absent second buffer gets a NaN mean: it takes no part.
+__global__ __launch_bounds__(256) void pack_pair_kernel(FilterArgs a, float *mc3, float *d3, float *c3) {
+    const long long n = (long long)a.width * a.height;
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const bool two = a.f_active > 1;
+    reinterpret_cast<f3 *>(mc3)[p] = f3{a.f_mean_corr[0][p], two ? a.f_mean_corr[1][p] : __builtin_nanf(""), 0.f};
+    reinterpret_cast<f3 *>(d3)[p] = f3{a.f_disc[0][p], two ? a.f_disc[1][p] : 0.f, 0.f};
+    reinterpret_cast<f3 *>(c3)[p] = f3{a.f_colour[0][p], two ? a.f_colour[1][p] : 0.f, 0.f};
 }
 
 static int floordiv_h(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
@@ -783,9 +834,10 @@ size_t sym_patch_floats(const FilterArgs &a, int n_parts) {
     return (size_t)sym_tiles(a) * n_parts * (sym::kPatchP + (size_t)sym::q_rows_max(n_parts) * sym::kP) * 4;
 }
 
-// filter<float3>, radius 20, default spec, G-buffers = up to two RGB images (other sets: the one-sided kernel)
+// filter<float3> and filter<float> (two buffers per launch), radius 20, default spec, G-buffers = up to two RGB images
+// (other sets: the one-sided kernel)
 bool sym_eligible(const FilterArgs &a, int channels) {
-    if (channels != 3 || a.radius != sym::kR || !fast_path_eligible(a, channels)) return false;
+    if (a.radius != sym::kR || !fast_path_eligible(a, channels)) return false;
     // the pair-symmetric kernel implements the default membership test and border rule
     if (a.gate != STATMC_GATE_SYMMETRIC || a.channel_rule != STATMC_CHANNELS_AND || a.border != STATMC_BORDER_CLIP) return false;
     if (a.n_g > 2) return false;
@@ -804,7 +856,19 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     if (a.packed) dma = dma && al16(a.packed);
     else dma = dma && al16(a.mean_corr) && al16(a.disc) && al16(a.colour) && (a.gscale0 == 0.f || al16(a.g[0].data)) &&
                (a.gscale1 == 0.f || al16(a.g[1].data));
-    const void *kernel = dma ? reinterpret_cast<const void *>(&window_filter_sym<true>) : reinterpret_cast<const void *>(&window_filter_sym<false>);
+    const bool pair = a.sym.pair != 0;
+    if (pair) {   // the launch's two float buffers -> the RGB-shaped images the rows are staged from
+        float *mc3 = a.sym.pair_images, *d3 = mc3 + (size_t)a.width * a.height * 3, *c3 = d3 + (size_t)a.width * a.height * 3;
+        const long long n = (long long)a.width * a.height;
+        hipLaunchKernelGGL(pack_pair_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, mc3, d3, c3);
+        a.mean_corr = mc3;
+        a.disc = d3;
+        a.colour = c3;
+        dma = a.width % 4 == 0 && a.sym.fx0 % 4 == 0 && al16(mc3) && al16(d3) && al16(c3) && (a.gscale0 == 0.f || al16(a.g[0].data)) &&
+              (a.gscale1 == 0.f || al16(a.g[1].data));
+    }
+    const void *kernel = pair ? (dma ? reinterpret_cast<const void *>(&window_filter_sym<true, true>) : reinterpret_cast<const void *>(&window_filter_sym<false, true>))
+                              : (dma ? reinterpret_cast<const void *>(&window_filter_sym<true, false>) : reinterpret_cast<const void *>(&window_filter_sym<false, false>));
     static std::mutex mu;
     static std::set<std::pair<int, const void *>> done;
     int dev = 0;
@@ -816,8 +880,11 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
             done.insert({dev, kernel});
         }
     }
-    if (dma) hipLaunchKernelGGL(window_filter_sym<true>, dim3(sym_tiles(a) * a.n_parts), dim3(kThreads), kLdsBytes, s, a);
-    else hipLaunchKernelGGL(window_filter_sym<false>, dim3(sym_tiles(a) * a.n_parts), dim3(kThreads), kLdsBytes, s, a);
+    const dim3 grid(sym_tiles(a) * a.n_parts);
+    if (pair && dma) hipLaunchKernelGGL((window_filter_sym<true, true>), grid, dim3(kThreads), kLdsBytes, s, a);
+    else if (pair) hipLaunchKernelGGL((window_filter_sym<false, true>), grid, dim3(kThreads), kLdsBytes, s, a);
+    else if (dma) hipLaunchKernelGGL((window_filter_sym<true, false>), grid, dim3(kThreads), kLdsBytes, s, a);
+    else hipLaunchKernelGGL((window_filter_sym<false, false>), grid, dim3(kThreads), kLdsBytes, s, a);
     const dim3 cgrid((a.rx1 - a.rx0 + 63) / 64, (a.ry1 - a.ry0 + 3) / 4);
     hipLaunchKernelGGL(combine_sym_kernel, cgrid, dim3(256), 0, s, a);
     return hipGetLastError();

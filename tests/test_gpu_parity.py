@@ -668,20 +668,25 @@ def test_filter_fewer_gbuffers_on_the_lds_kernel(gpu, oracle, channels, n_g):
     g_dr = [-0.5 / 0.2 ** 2][:n_g]
     ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / FILTER_SD ** 2, r)
     out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, FILTER_SD, r, channels=channels)
-    assert v == ("sym_r20" if channels == 3 else "lds_r20_f")
+    assert v == ("sym_r20" if channels == 3 else "sym_r20_f")
     for c in range(channels):
         assert rel_l2(out[..., c], ref[..., c]) <= TOL
+    out_1, v_1 = run_filter(gpu, mc, disc, colour, gbs, g_dr, FILTER_SD, r, channels=channels, force=3)   # one-sided LDS kernel
+    assert v_1 == ("lds_r20" if channels == 3 else "lds_r20_f")
+    for c in range(channels):
+        assert rel_l2(out_1[..., c], ref[..., c]) <= TOL
     out_g, v_g = run_filter(gpu, mc, disc, colour, gbs, g_dr, FILTER_SD, r, channels=channels, force=1)
     assert v_g == "generic"
     for c in range(channels):
         assert rel_l2(out_g[..., c], ref[..., c]) <= TOL
 
 
-@pytest.mark.parametrize("n_buffers,radius,variant", [(5, 20, "lds_r20_f"), (12, 20, "lds_r20_f"), (4, 7, "lds_rt_f"), (1, 20, "lds_r20_f")])
+@pytest.mark.parametrize("n_buffers,radius,variant", [(5, 20, "sym_r20_f"), (12, 20, "sym_r20_f"), (4, 7, "lds_rt_f"), (1, 20, "sym_r20_f"),
+                                                      (2, 20, "sym_r20_f")])
 def test_filter_float_multibuffer_fast_path(gpu, oracle, n_buffers, radius, variant):
     """filter<float> as ACRR (nBuffers = trackedbounces = 5) and SMIS (2 x 6 = 12) call it
     (estimator.cpp:437-459): 1-channel buffers with their own statistics and colour, shared RGB
-    G-buffers; the LDS kernel takes them three per launch."""
+    G-buffers; the pair-symmetric kernel takes them two per launch (r = 20), the one-sided LDS kernel three."""
     W, H = 276, 27
     _, smp, st = make_case(W, H, 8, seed=50 + n_buffers)
     rng = np.random.default_rng(n_buffers)
@@ -705,18 +710,19 @@ def test_filter_float_multibuffer_fast_path(gpu, oracle, n_buffers, radius, vari
     assert gpu.last_filter_variant() == variant
     for b in range(n_buffers):
         assert rel_l2(args["film_filtered"][b].cpu().numpy(), refs[b]) <= TOL, b
-    # same call through the generic kernel
-    gpu.force_filter_variant(1)
-    try:
-        for t in args["film_filtered"]:
-            t.zero_()
-        gpu.filter_f32(a)
-        torch.cuda.synchronize()
-    finally:
-        gpu.force_filter_variant(0)
-    assert gpu.last_filter_variant() == "generic"
-    for b in range(n_buffers):
-        assert rel_l2(args["film_filtered"][b].cpu().numpy(), refs[b]) <= TOL, b
+    # same call through the generic kernel and through the one-sided LDS kernel
+    for force, name in ((1, "generic"), (3, "lds_r20_f" if radius == 20 else "lds_rt_f")):
+        gpu.force_filter_variant(force)
+        try:
+            for t in args["film_filtered"]:
+                t.zero_()
+            gpu.filter_f32(a)
+            torch.cuda.synchronize()
+        finally:
+            gpu.force_filter_variant(0)
+        assert gpu.last_filter_variant() == name
+        for b in range(n_buffers):
+            assert rel_l2(args["film_filtered"][b].cpu().numpy(), refs[b]) <= TOL, (name, b)
 
 
 def test_filter_entry_point_reference_argument_order(gpu, oracle):
@@ -993,7 +999,7 @@ def expected_lds_variant(spec_kw, channels, radius):
     if gate or joint:
         return "lds_rt" + f + ("_asym" if gate else "") + ("_joint" if joint else "")
     if radius == 20:
-        return "sym_r20" if channels == 3 and not spec_kw.get("border", 0) else "lds_r20" + f
+        return "sym_r20" + f if not spec_kw.get("border", 0) else "lds_r20" + f
     return "lds_rt" + f
 
 
