@@ -116,12 +116,12 @@ struct FilterArgs {
     float *f_out[3];
     int f_active;
     const float *packed;         // optional [height][width][15] inputs: mc, disc, colour, g0, g1 (RGB each)
-    // pair-symmetric kernel (statmc_filter_sym.hip): tiles of 256 x 4 pixels on a grid fixed in film coordinates
+    // pair-symmetric kernel (statmc_filter_sym.hip): tiles of 128 x 8 pixels on a grid fixed in film coordinates
     struct SymGeom {
         int tx0, ty0, ntx, nty;   // tile range of the launch (film tile indices)
         int fx0, fy0;             // film coordinates of local pixel (0, 0)
         long long item_stride4;   // float4 per work item (tile, part) in the patch workspace
-        float4 *patch;            // [items][p-side 4 x 256 | q-side rows x 296] (sum w*colour rgb, sum w)
+        float4 *patch;            // [items][p-side 8 x 128 | q-side rows x 168] (sum w*colour rgb, sum w)
         int pair;                 // filter<float>: f_active (1 or 2) 1-channel buffers (f_mean_corr / f_disc / f_colour / f_out) per launch
         float *pair_images;       // ... staged from three [height][width][3] images this launch packs them into
     } sym;

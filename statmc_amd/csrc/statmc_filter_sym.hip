@@ -1,7 +1,8 @@
-// statmc_filter_sym.hip -- the pair-symmetric window filter (gfx950): filter<float3>, radius 20, default spec.
+// statmc_filter_sym.hip -- the pair-symmetric window filter (gfx950): filter<float3> and filter<float>, radius 20,
+// default spec.
 //
-// Replaces the window part of cv::cuda::stat_denoiser::filter<float3> (call site
-// src/statistics/estimator.cpp:465-487 of the reference; CUDA source not in the tree, arithmetic = this
+// Replaces the window part of cv::cuda::stat_denoiser::filter<float3> / filter<float> (call sites
+// src/statistics/estimator.cpp:465-487 and 437-459 of the reference; CUDA source not in the tree, arithmetic = this
 // build's spec v2, oracle/statmc_oracle.c:oracle_filter_spec_run).
 //
 // Why.  The filter is a (2r+1)^2 = 1681-tap stencil bound by VALU issue (33 fp32 lane-operations per
@@ -14,17 +15,18 @@
 // 29 operations for weight + gate and 4 + 4 for the two accumulations = 37 per pair = 18.5 per directed tap.
 //
 // Shape of the work.
-//   * Tile = 256 x 4 pixels on a grid fixed in FILM coordinates (so that block-decomposed multi-GPU runs
+//   * Tile = 128 x 8 pixels on a grid fixed in FILM coordinates (so that block-decomposed multi-GPU runs
 //     form every sum in the same order as a whole-film run: bit-identical results).  A 512-thread workgroup
-//     = 8 waves, TWO waves per tile row: wave (t, h) owns row t and half h of the window columns
-//     (h = 0: dx in [-20, 0], h = 1: dx in [1, 20]); a lane owns 4 adjacent pixels.  Both halves of a row keep
-//     the pixels' own data in registers; their partial sums meet in the epilogue.
-//   * Step s = window row dy = s, s = 0..20.  At step s the wave of tile row t sweeps image row y0 + t + s:
-//     4 live rows + 1 being staged = a ring of 5 LDS slots.  A slot holds the 15 input planes of a row
-//     (296 columns = tile + 2 x 20 halo) AND its 2 x 4 accumulator planes (Sigma w*colour, Sigma w; one copy
-//     per window half, because the two waves of a row hit the same columns at the same time).  Everything a
-//     row needs lives exactly as long as the row: 5 x 296 x 23 floats = 136 KB of the CU's 160 KB.
-//     (One wave per row and 8 rows -- the geometry of the one-sided kernel -- would need 202 KB.)
+//     = 8 waves; wave (t, h), t = 0..3, h = 0..1, owns tile rows t (lanes 0-31) and t + 4 (lanes 32-63) and
+//     half h of the window columns (h = 0: dx in [-20, 0], h = 1: dx in [1, 20]); a lane owns 4 adjacent
+//     pixels.  Both halves of a row keep the pixels' own data in registers; their partial sums meet in the
+//     epilogue.
+//   * Step s = window row dy = s, s = 0..20.  At step s tile row t sweeps image row y0 + t + s: 8 live rows
+//     + 1 being staged = a ring of 9 LDS slots.  A slot holds the 15 input planes of a row (168 columns =
+//     tile + 2 x 20 halo) AND its 2 x 4 accumulator planes (Sigma w*colour, Sigma w; one copy per window
+//     half, because the two waves of a row hit the same columns at the same time).  Everything a row needs
+//     lives exactly as long as the row: 9 x 168 x 23 floats = 139 KB, + the spatial table and the LDS-DMA
+//     landing area = 151 KB of the CU's 160 KB.
 //   * dy = 0: the pairs inside a row are the taps dx in [1, 20] of half 1 (the accumulator row is the wave's own
 //     row); half 0 only adds the pixel's own tap.
 //   * q-side scatter: per read group a lane reads the 4 x 2 accumulator values of its two taps, adds its four
@@ -34,10 +36,13 @@
 //     costs ~190 cycles per wave instruction on gfx950 -- tools/microbench/lds_scatter.hip -- 30x the RMW.)
 //   * When a row leaves the ring its two accumulator copies are added and written to the work item's PATCH in
 //     global memory; the p-side sums of the tile go there too.  combine_sym_kernel then gathers, for every
-//     output pixel, the patches that hold a share of it (its own tile's p-side, the q-side rows of the <= 6
-//     tile rows above it and of the horizontal neighbours whose halo covers it) in a fixed order, and
+//     output pixel, the patches that hold a share of it (its own tile's p-side, the q-side rows of the tile
+//     rows above it and of the horizontal neighbours whose halo covers it) in a fixed order, and
 //     normalises.  The sweep of a tile can be split over `parts` workgroups (steps [s_a, s_b) each) with no
 //     further mechanism: a part is just a patch.
+//   * filter<float> (PAIR): two 1-channel buffers per launch ride in the (x, y) channels of the same planes;
+//     they share the range weight, gate and normalise separately (the four sums per pixel become
+//     Sigma w0 c0, Sigma w1 c1, Sigma w0, Sigma w1).
 #include <algorithm>
 #include <mutex>
 #include <set>
@@ -747,15 +752,15 @@ __global__ __launch_bounds__(256) void combine_sym_kernel(FilterArgs a) {
     if (x >= a.rx1 || y >= a.ry1) return;
     const int X = x + a.sym.fx0, Y = y + a.sym.fy0;
     const int ty_own = floordiv(Y, kRows), tx_own = floordiv(X, kW);
-    const int ty_lo = max(floordiv(Y - (kSteps + kRows - 2) + kRows - 1, kRows), a.sym.ty0);  // 4 Ty + 23 >= Y
+    const int ty_lo = max(floordiv(Y - (kSteps + kRows - 2) + kRows - 1, kRows), a.sym.ty0);  // rows of tile row Ty: kRows Ty .. kRows Ty + kSteps + kRows - 2
     const int ty_hi = min(ty_own, a.sym.ty0 + a.sym.nty - 1);
-    const int tx_lo = max(floordiv(X + kR - (kP - 1) + kW - 1, kW), a.sym.tx0);              // X - 256 Tx + 20 <= 295
+    const int tx_lo = max(floordiv(X + kR - (kP - 1) + kW - 1, kW), a.sym.tx0);              // staged column X - kW Tx + kR <= kP - 1
     const int tx_hi = min(floordiv(X + kR, kW), a.sym.tx0 + a.sym.ntx - 1);
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int Ty = ty_lo; Ty <= ty_hi; Ty++) {
-        const int rel = Y - kRows * Ty;  // 0 .. 23
+        const int rel = Y - kRows * Ty;  // 0 .. kSteps + kRows - 2
         for (int Tx = tx_lo; Tx <= tx_hi; Tx++) {
-            const int c = X - kW * Tx + kR;  // 0 .. 295
+            const int c = X - kW * Tx + kR;  // 0 .. kP - 1
             const long long item0 = ((long long)(Ty - a.sym.ty0) * a.sym.ntx + (Tx - a.sym.tx0)) * a.n_parts;
             for (int k = 0; k < a.n_parts; k++) {
                 const float4 *patch = a.sym.patch + (item0 + k) * a.sym.item_stride4;
