@@ -454,9 +454,9 @@ def test_custom_t_quantile_table(gpu, oracle):
 
 
 # ------------------------------------------------------------------ window filter
-def run_filter(gpu, mc, disc, colour, gbs, g_dr, filter_sd, radius, roi=None, channels=3, force=0):
+def run_filter(gpu, mc, disc, colour, gbs, g_dr, filter_sd, radius, roi=None, channels=3, force=0, n=None):
     out = torch.zeros_like(to_dev(colour))
-    a, keep = gpu.make_filter_args([], [], [], [], [to_dev(colour)], [to_dev(mc)], [to_dev(disc)], [out],
+    a, keep = gpu.make_filter_args([to_dev(n)] if n is not None else [], [], [], [], [to_dev(colour)], [to_dev(mc)], [to_dev(disc)], [out],
                                    [to_dev(g) for g in gbs], g_dr=g_dr, filter_sd=filter_sd, radius=radius, roi=roi)
     gpu.force_filter_variant(force)
     try:

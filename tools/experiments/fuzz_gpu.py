@@ -12,6 +12,17 @@ import test_gpu_parity as T
 oracle.build(); gpu.setup(0)
 
 
+def random_spec(rng):
+    """Mostly the default spec; otherwise any combination of the options the window filter sees (the Welch lookup,
+    which runs the general kernel only, rarely)."""
+    if rng.random() < 0.5:
+        return {}
+    kw = dict(gate=int(rng.integers(0, 2)), channel_rule=int(rng.integers(0, 2)), border=int(rng.integers(0, 2)))
+    if rng.random() < 0.1:
+        kw["dof"] = 1
+    return kw
+
+
 def filter_case(case, verbose=False):
     rng = np.random.default_rng(1000003 * 17 + case)
     W = int(rng.choice([rng.integers(1, 12), rng.integers(12, 300), rng.integers(250, 800)]))
@@ -45,21 +56,29 @@ def filter_case(case, verbose=False):
     if rng.random() < 0.4 and W > 2 and H > 2:
         x0, y0 = int(rng.integers(0, W - 1)), int(rng.integers(0, H - 1))
         roi = (x0, y0, int(rng.integers(x0 + 1, W + 1)), int(rng.integers(y0 + 1, H + 1)))
-    ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / sd ** 2, radius, roi=roi)
-    force = int(rng.choice([0, 0, 0, 2, 1]))
+    if rng.random() < 0.3:   # a non-finite colour: the pixel takes no part, its own output passes it through
+        y, x = int(rng.integers(0, H)), int(rng.integers(0, W))
+        colour[y, x, rng.integers(0, 3)] = [np.nan, np.inf, -np.inf][int(rng.integers(0, 3))]
+        inj.append((9, x, y))
+    spec_kw = random_spec(rng)
+    n = rng.integers(2, 400, size=(H, W)).astype(np.int32) if spec_kw.get("dof") else None
+    ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / sd ** 2, radius, roi=roi, spec=oracle.FilterSpec(**spec_kw), n=n)
+    force = int(rng.choice([0, 0, 0, 2, 1, 3]))
     parts = int(rng.choice([0, 0, 1, 2, 3, 5, 41]))
     gpu.force_filter_parts(parts)
+    gpu.set_filter_spec(**spec_kw)
     try:
-        out, v = T.run_filter(gpu, mc, disc, colour, gbs, g_dr, sd, radius, roi=roi, force=force)
+        out, v = T.run_filter(gpu, mc, disc, colour, gbs, g_dr, sd, radius, roi=roi, force=force, n=n)
     finally:
         gpu.force_filter_parts(0)
+        gpu.set_filter_spec()
     mask = np.isfinite(ref)
     ok = np.array_equal(np.isfinite(out), mask)
     err = 0.0
     if ok and mask.any():
         err = max(T.rel_l2(np.where(mask[..., c], out[..., c], 0), np.where(mask[..., c], ref[..., c], 0)) for c in range(3))
     desc = dict(case=case, W=W, H=H, radius=radius, sd=round(sd, 3), g_sds=[round(g, 4) for g in g_sds], scale=scale, roi=roi,
-                force=force, parts=parts, variant=v, inj=inj, err=err, finite_ok=ok, layout=layout)
+                force=force, parts=parts, variant=v, inj=inj, err=err, finite_ok=ok, layout=layout, spec=spec_kw)
     if verbose:
         print(desc)
         d = np.abs(out.astype(np.float64) - ref) / (np.abs(ref) + 1e-30)
@@ -151,21 +170,35 @@ def float_filter_case(case):
             elif k == 1: mcs[b][y, x] = np.nan
             elif k == 2: mcs[b][y, x] = np.inf
             else: dcs[b][y, x] = np.nan
+        if rng.random() < 0.2:
+            y, x = int(rng.integers(0, H)), int(rng.integers(0, W))
+            cols[b][y, x] = [np.nan, np.inf][int(rng.integers(0, 2))]
     outs = [torch.zeros(H, W, 1, device=T.DEV) for _ in range(nb)]
     a, keep = gpu.make_filter_args([], [], [], [], [T.to_dev(c) for c in cols], [T.to_dev(m) for m in mcs], [T.to_dev(d) for d in dcs],
                                    outs, [T.to_dev(g) for g in gbs], g_dr=g_dr, filter_sd=sd, radius=radius)
-    force = int(rng.choice([0, 0, 2, 1]))
+    force = int(rng.choice([0, 0, 0, 2, 1, 3]))
+    parts = int(rng.choice([0, 0, 1, 2, 3, 7]))
+    spec_kw = {k: v for k, v in random_spec(rng).items() if k != "dof"}
     gpu.force_filter_variant(force)
+    gpu.force_filter_parts(parts)
+    gpu.set_filter_spec(**spec_kw)
     try:
         gpu.window_filter(a, 1)
         torch.cuda.synchronize()
     finally:
         gpu.force_filter_variant(0)
-    worst = 0.0
+        gpu.force_filter_parts(0)
+        gpu.set_filter_spec()
+    worst, finite_ok = 0.0, True
     for b in range(nb):
-        ref = oracle.filter_image(mcs[b], dcs[b], cols[b], gbs, g_dr, -0.5 / sd ** 2, radius)
-        worst = max(worst, T.rel_l2(outs[b].cpu().numpy(), ref))
-    return worst <= 1e-5, dict(case=case, W=W, H=H, nb=nb, radius=radius, force=force, variant=gpu.last_filter_variant(), err=worst)
+        ref = oracle.filter_image(mcs[b], dcs[b], cols[b], gbs, g_dr, -0.5 / sd ** 2, radius, spec=oracle.FilterSpec(**spec_kw))
+        out = outs[b].cpu().numpy()
+        mask = np.isfinite(ref)
+        finite_ok = finite_ok and np.array_equal(np.isfinite(out), mask)
+        if mask.any():
+            worst = max(worst, T.rel_l2(np.where(mask, out, 0), np.where(mask, ref, 0)))
+    return finite_ok and worst <= 1e-5, dict(case=case, W=W, H=H, nb=nb, radius=radius, force=force, parts=parts, spec=spec_kw,
+                                             variant=gpu.last_filter_variant(), err=worst, finite_ok=finite_ok)
 
 
 def tiles_case(case):
