@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <array>
 #include <condition_variable>
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -484,6 +485,11 @@ struct Bounds2i {  // pMax exclusive
     int Area() const { return (pMax.x - pMin.x) * (pMax.y - pMin.y); }
     Point2i pMin, pMax;
 };
+struct Vector2f {
+    Vector2f() = default;
+    Vector2f(float x, float y) : x(x), y(y) {}
+    float x = 0.f, y = 0.f;
+};
 using Vec3 = float3;  // statpbrt.h:22
 
 // StatTile<T> (estimator.h:147-239) with the reference's constructor and Add*Sample* names, so
@@ -499,6 +505,17 @@ class StatTile {
     explicit StatTile(const Bounds2i &pixelBounds)
         : pixelBounds(pixelBounds), tileWidth(std::max(0, pixelBounds.pMax.x - pixelBounds.pMin.x)),
           nPixels((size_t)tileWidth * std::max(0, pixelBounds.pMax.y - pixelBounds.pMin.y)), counts(nPixels, 0u) {}
+    // The tile GetTilesF hands out (estimator.h:152-161): it also carries the pixel reconstruction filter.  None of
+    // the reference's Add*Sample* methods reads it (estimator.h:162-232), so it is kept and not interpreted here either.
+    StatTile(const Bounds2i &pixelBounds, const Vector2f &filterRadius, const float *filterTable, int filterTableSize)
+        : StatTile(pixelBounds) {
+        this->filterRadius = filterRadius;
+        this->filterTable = filterTable;
+        this->filterTableSize = filterTableSize;
+    }
+    Vector2f GetFilterRadius() const { return filterRadius; }
+    const float *GetFilterTable() const { return filterTable; }
+    int GetFilterTableSize() const { return filterTableSize; }
     void AddSampleM1(const Point2i p, const T sample) { record(p, sample); }
     void AddSampleM2(const Point2i p, const T sample) { record(p, sample); }
     void AddSampleM3(const Point2i p, const T sample) { record(p, sample); }
@@ -521,6 +538,9 @@ class StatTile {
         planes[s][i] = sample;
     }
     Bounds2i pixelBounds;
+    Vector2f filterRadius;
+    const float *filterTable = nullptr;
+    int filterTableSize = 0;
     int tileWidth;
     size_t nPixels;
     // the merge interface is const in the reference (estimator.h:290-301); emptying the recorder is
@@ -753,7 +773,39 @@ class Estimator {
     }
 
     // ---- the accumulation side: tiles in, statistics images on the device ------------------
-    // estimator.cpp:297-309.  (GetTilesF, the filter-weighted variant, is not used by Render.)
+    // The reference's constructor also takes the film's cropped pixel bounds and its pixel reconstruction filter
+    // (estimator.h:253,264-265); only GetTilesF reads them, so here they are optional settings.  Defaults: the whole
+    // image, a box filter of radius 0.5 with no table.
+    void SetPixelFilter(const Vector2f &radius, const float *table, int tableWidth) {
+        pixelFilterRadius = radius;
+        filterTable = table;
+        filterTableWidth = tableWidth;
+    }
+    void SetCroppedPixelBounds(const Bounds2i &b) { croppedPixelBounds = b; }
+    // estimator.cpp:312-338: tiles over the pixels that samples inside sampleBounds contribute to under the pixel
+    // filter -- Ceil(pMin - 0.5 - radius) .. Floor(pMax - 0.5 + radius) + 1, cut to the cropped pixel bounds.
+    // (Not used by Render, which asks GetTiles for unfiltered tiles.)
+    Bounds2i FilteredTileBounds(const Bounds2i &sampleBounds) const {
+        const Bounds2i crop = croppedPixelBounds.Area() > 0 ? croppedPixelBounds : Bounds2i(Point2i(0, 0), Point2i(width, height));
+        const int x0 = (int)std::ceil((float)sampleBounds.pMin.x - 0.5f - pixelFilterRadius.x);
+        const int y0 = (int)std::ceil((float)sampleBounds.pMin.y - 0.5f - pixelFilterRadius.y);
+        const int x1 = (int)std::floor((float)sampleBounds.pMax.x - 0.5f + pixelFilterRadius.x) + 1;
+        const int y1 = (int)std::floor((float)sampleBounds.pMax.y - 0.5f + pixelFilterRadius.y) + 1;
+        Bounds2i b(Point2i(std::max(x0, crop.pMin.x), std::max(y0, crop.pMin.y)), Point2i(std::min(x1, crop.pMax.x), std::min(y1, crop.pMax.y)));
+        if (b.pMax.x < b.pMin.x || b.pMax.y < b.pMin.y) b = Bounds2i();   // pbrt's Intersect of disjoint boxes is degenerate too
+        return b;
+    }
+    template <typename T>
+    std::vector<StatTile<T>> GetTilesF(const Bounds2i &sampleBounds, const unsigned char bounceEnd) const {
+        return std::vector<StatTile<T>>(bounceEnd, StatTile<T>(FilteredTileBounds(sampleBounds), pixelFilterRadius, filterTable, filterTableWidth));
+    }
+    template <typename T>
+    std::vector<std::vector<StatTile<T>>> GetTilesF(const Bounds2i &sampleBounds, const unsigned char bounceEnd,
+                                                    const unsigned char n) const {
+        return std::vector<std::vector<StatTile<T>>>(
+            bounceEnd, std::vector<StatTile<T>>(n, StatTile<T>(FilteredTileBounds(sampleBounds), pixelFilterRadius, filterTable, filterTableWidth)));
+    }
+    // estimator.cpp:297-309
     template <typename T>
     std::vector<StatTile<T>> GetTiles(const Bounds2i &tilePixelBounds, const unsigned char bounceEnd) const {
         return std::vector<StatTile<T>>(bounceEnd, StatTile<T>(tilePixelBounds));
@@ -878,6 +930,10 @@ class Estimator {
     static void addUnique(std::vector<Buffer *> &v, Buffer *b) {
         if (std::find(v.begin(), v.end(), b) == v.end()) v.push_back(b);
     }
+    Vector2f pixelFilterRadius{0.5f, 0.5f};   // estimator.h:313 `filter` (pbrt's default box filter)
+    const float *filterTable = nullptr;       // film.cpp:56-65: the film's 16 x 16 table of filter weights
+    int filterTableWidth = 0;
+    Bounds2i croppedPixelBounds;              // empty = the whole image
     const bool allocateDevice;
     const int device;
 

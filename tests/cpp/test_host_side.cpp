@@ -61,6 +61,28 @@ int main(int argc, char **argv) {
         auto tiles = est.GetTiles<Vec3>(Bounds2i(Point2i(0, 0), Point2i(16, 16)), cfgs[Radiance].bounceEnd);
         REQUIRE(tiles.size() == 1);
         auto nested = est.GetTiles<Vec3>(Bounds2i(Point2i(0, 0), Point2i(16, 16)), 1, 2);
+        // GetTilesF (estimator.cpp:312-338): the pixels that samples of [16, 32)^2 reach under the pixel filter, cut to
+        // the cropped bounds (film 40 x 24).  Box filter of radius 0.5: Ceil(16 - 1) .. Floor(32) + 1 = [15, 33);
+        // radius 2: Ceil(13.5) .. Floor(33.5) + 1 = [14, 34).
+        {
+            auto f = est.GetTilesF<Vec3>(Bounds2i(Point2i(16, 16), Point2i(32, 32)), 2);
+            const Bounds2i b = f[0].GetPixelBounds();
+            REQUIRE(f.size() == 2 && b.pMin.x == 15 && b.pMin.y == 15 && b.pMax.x == 33 && b.pMax.y == 24);
+            static const float table[4] = {1.f, .5f, .5f, .25f};
+            est.SetPixelFilter(statmc::Vector2f(2.f, 2.f), table, 2);
+            auto g = est.GetTilesF<float>(Bounds2i(Point2i(16, 16), Point2i(32, 32)), 1, 3);
+            const Bounds2i c = g[0][2].GetPixelBounds();
+            REQUIRE(g.size() == 1 && g[0].size() == 3 && c.pMin.x == 14 && c.pMin.y == 14 && c.pMax.x == 34 && c.pMax.y == 24);
+            REQUIRE(g[0][0].GetFilterTable() == table && g[0][0].GetFilterTableSize() == 2 && g[0][0].GetFilterRadius().x == 2.f);
+            g[0][1].AddSampleM2(Point2i(14, 23), 1.5f);           // a filtered tile records like any other
+            REQUIRE(g[0][1].pending(Point2i(14, 23)) == 1);
+            est.SetCroppedPixelBounds(Bounds2i(Point2i(0, 0), Point2i(20, 20)));
+            const Bounds2i d = est.GetTilesF<float>(Bounds2i(Point2i(16, 16), Point2i(32, 32)), 1)[0].GetPixelBounds();
+            REQUIRE(d.pMin.x == 14 && d.pMin.y == 14 && d.pMax.x == 20 && d.pMax.y == 20);
+            REQUIRE(est.GetTilesF<float>(Bounds2i(Point2i(30, 30), Point2i(32, 32)), 1)[0].GetPixelBounds().Area() == 0);
+            est.SetCroppedPixelBounds(Bounds2i());
+            est.SetPixelFilter(statmc::Vector2f(.5f, .5f), nullptr, 0);
+        }
         REQUIRE(nested.size() == 1 && nested[0].size() == 2);
         tiles[0].AddTransformSampleM3(Point2i(3, 4), Vec3{1, 1, 1});
         REQUIRE(throwsError([&] { est.MergeTransformTiles(tiles, cfgs[Radiance]); }, STATMC_ERR_INVALID));   // not enabled
