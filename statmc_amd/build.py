@@ -93,25 +93,49 @@ TOOLS = {DENOISE_BIN: "statmc_denoise.cpp", RENDER_SIM_BIN: "statmc_render_sim.c
          CV_ADAPTOR_BIN: os.path.join("..", "tests", "cpp", "test_cv_adaptor.cpp")}
 
 
+TOOLS_STAMP = os.path.join(os.path.dirname(DENOISE_BIN), ".src")
+
+
+def tools_hash():
+    """Content hash of what the host tools are compiled from: their sources and every header under include/."""
+    import hashlib
+    h = hashlib.sha256()
+    inc = os.path.join(ROOT, "include")
+    files = [os.path.join(ROOT, "tools", src) for src in TOOLS.values()]
+    files += [os.path.join(inc, f) for f in sorted(os.listdir(inc))]
+    for path in files:
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def tools_stale():
+    try:
+        return open(TOOLS_STAMP).read().strip() != tools_hash()
+    except OSError:
+        return True
+
+
 def build_tools(force=False):
     """g++ build of the C++ host side (include/statmc_denoiser.hpp + tools/*.cpp: the offline
     denoise driver and the render-loop harness), linked against libstatmc_hip.so."""
-    # An existing binary is used as is (no mtime comparison: a snapshot copy of the tree does not
-    # keep a meaningful order of timestamps, and libstatmc_hip.so must never be rewritten while a
-    # test process has it loaded); __graft_entry__.build() rebuilds with force=True.
-    if not force and all(os.path.exists(b) for b in TOOLS):
+    # Binaries built from other sources than the ones in the tree are rebuilt (content hash: mtimes do not survive a
+    # snapshot copy of the tree); each goes to a temporary file and is renamed into place.
+    if not force and all(os.path.exists(b) for b in TOOLS) and not tools_stale():
         return DENOISE_BIN
     if not os.path.exists(SO):
         build()
     os.makedirs(os.path.dirname(DENOISE_BIN), exist_ok=True)
     rocm_lib = os.path.join(os.path.dirname(os.path.dirname(_hipcc())), "lib")
     for binary, src in TOOLS.items():
-        if not force and os.path.exists(binary):
-            continue
+        tmp = binary + ".tmp%d" % os.getpid()
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-ffp-contract=off", "-pthread",
-                               "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", src), "-o", binary,
+                               "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", src), "-o", tmp,
                                "-L", HERE, "-lstatmc_hip", "-L", rocm_lib, "-Wl,-rpath,$ORIGIN/../../statmc_amd",
                                "-Wl,-rpath," + rocm_lib])
+        os.replace(tmp, binary)
+    with open(TOOLS_STAMP, "w") as f:
+        f.write(tools_hash() + "\n")
     return DENOISE_BIN
 
 

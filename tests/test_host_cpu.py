@@ -168,3 +168,16 @@ def test_patches_apply_to_the_reference():
     r = subprocess.run([os.path.join(root, "tools", "check_patches.sh")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("applied 000") == 3 and "patches apply" in r.stdout
+
+
+def test_tools_built_from_other_sources_are_rebuilt(denoise_bin, tmp_path, monkeypatch):
+    """The host tools record a hash of the sources and headers they were compiled from (like the library): binaries
+    from another revision of the tree are not run."""
+    from statmc_amd import build
+    assert not build.tools_stale()
+    fake = tmp_path / "stamp"
+    fake.write_text("0" * 64 + "\n")
+    monkeypatch.setattr(build, "TOOLS_STAMP", str(fake))
+    assert build.tools_stale()
+    build.build_tools()                       # rebuilds and rewrites the stamp it was pointed at
+    assert not build.tools_stale()
