@@ -565,6 +565,8 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     const int q8 = n_items >> 3, rem8 = n_items & 7, xcd = b & 7, idx = b >> 3;
     const int u = xcd < rem8 ? xcd * (q8 + 1) + idx : rem8 * (q8 + 1) + (xcd - rem8) * q8 + idx;
 
+    unsigned long long t_start = 0, t_swept = 0, c_pro = 0, s_hk = 0, s_ev = 0, s_bar = 0;
+    if constexpr (kStamps) t_start = __builtin_amdgcn_s_memtime();
     const int part = u % a.n_parts, tile = u / a.n_parts;
     const int x0 = kW * (a.sym.tx0 + tile % a.sym.ntx) - a.sym.fx0;     // local coordinates of the tile
     const int y0 = kRows * (a.sym.ty0 + tile / a.sym.ntx) - a.sym.fy0;
@@ -628,12 +630,26 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
         if constexpr (DMA) {   // the first row the sweep will need beyond the prologue: on its way during the prologue
             if (s_a + 1 < s_b && !(kAblate & 2)) dma_row(a, raw_w, lane, x0 - kR + wcol0, y0 + s_a + kRows, ncols);
         }
-        // ---- prologue: rows rel = s_a .. s_a+7 (image rows y0 + rel) into slots rel % 9
-        for (int idx2 = threadIdx.x; idx2 < kRows * kP; idx2 += kThreads) {
-            const int rr = idx2 / kP, i = idx2 - rr * kP;
-            const int rel = s_a + rr;
-            const StagedPixel s = load_px(a, x0 - kR + i, y0 + rel);
-            stage_store(lds + (rel % kSlots) * kSlotFloats, i, s, k0, k1, !PAIR);
+        // ---- prologue: rows rel = s_a .. s_a+7 (image rows y0 + rel) into slots rel % 9.  All of a thread's fetches
+        // are issued before the first is staged: one memory latency per item instead of three.
+        constexpr int kProIters = (kRows * kP + kThreads - 1) / kThreads;
+        StagedPixel pro[kProIters];
+#pragma unroll
+        for (int it = 0; it < kProIters; it++) {
+            const int idx2 = (int)threadIdx.x + it * kThreads;
+            pro[it].valid = false;
+            if (idx2 < kRows * kP) {
+                const int rr = idx2 / kP, i = idx2 - rr * kP;
+                pro[it] = load_px(a, x0 - kR + i, y0 + s_a + rr);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < kProIters; it++) {
+            const int idx2 = (int)threadIdx.x + it * kThreads;
+            if (idx2 < kRows * kP) {
+                const int rr = idx2 / kP, i = idx2 - rr * kP;
+                stage_store(lds + ((s_a + rr) % kSlots) * kSlotFloats, i, pro[it], k0, k1, !PAIR);
+            }
         }
         if ((int)threadIdx.x < tw) {
             const float *t = a.spatial_tab + (s_a + kR) * tw + threadIdx.x;
@@ -643,6 +659,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
 
         // ---- sweep
         unsigned long long tk0 = 0, c_hk = 0, c_ev = 0, c_bar = 0;
+        if constexpr (kStamps) c_pro = __builtin_amdgcn_s_memtime() - t_start;
         for (int s = s_a; s < s_b; s++) {
             if constexpr (kStamps) tk0 = __builtin_amdgcn_s_memtime();
             const int i = DMA ? wcol0 + lane : (int)threadIdx.x;             // the staged column this thread looks after
@@ -706,8 +723,8 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_bar += t - tk0; tk0 = t; }
         }
         if constexpr (kStamps) {
-            if (lane == 0)   // the last q-side row of the patch is never a target of a part-1 launch of a full film: scratch
-                patch[a.sym.item_stride4 - 8 + wave] = make_float4((float)c_hk, (float)c_ev, (float)c_bar, (float)(s_b - s_a));
+            t_swept = __builtin_amdgcn_s_memtime();
+            s_hk = c_hk; s_ev = c_ev; s_bar = c_bar;
         }
         // ---- the rows still in the ring: rel = s_b-1 .. s_b+6
         for (int idx2 = threadIdx.x; idx2 < kRows * kP; idx2 += kThreads) {
@@ -739,6 +756,17 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             patch[trow * kW + kPx * lane32 + k] =
                 make_float4((st.acc[k][0].x + st.acc[k][0].y) + e[0 * kW], (st.acc[k][1].x + st.acc[k][1].y) + e[1 * kW],
                             (st.acc[k][2].x + st.acc[k][2].y) + e[2 * kW], (st.sw[k].x + st.sw[k].y) + e[3 * kW]);
+        }
+    }
+    if constexpr (kStamps) {
+        // the item's last 16 float4 (columns of its last accumulator row: the results of a stamps build are wrong):
+        // per wave (housekeeping, sweep, barrier clocks summed over the steps, steps) and (before the first step,
+        // after the last step, whole item)
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (lane == 0 && s_a < s_b) {
+            patch[a.sym.item_stride4 - 8 + wave] = make_float4((float)s_hk, (float)s_ev, (float)s_bar, (float)(s_b - s_a));
+            patch[a.sym.item_stride4 - 16 + wave] = make_float4((float)c_pro, (float)(t_end - t_swept), (float)(t_end - t_start), 0.f);
         }
     }
 }
@@ -821,7 +849,8 @@ void sym_geometry(FilterArgs &a) {
 int sym_tiles(const FilterArgs &a) { return a.sym.ntx * a.sym.nty; }
 
 // Parts per tile: the grid runs one workgroup per CU, so its makespan is ceil(items / CUs) rounds of 21 / parts steps
-// each, plus what an item pays before its first step (prologue: 8 rows staged, measured at about 2.5 steps).
+// each, plus what a further item costs: 0.95 steps before its first and after its last step (stamps_sym.py), 7 more
+// accumulator rows to flush and to gather in the combine -- fitted at 2.5 steps from runs with 1 .. 4 parts.
 int sym_choose_parts(int tiles, int n_cus) {
     int best = 1;
     double best_cost = 1e30;

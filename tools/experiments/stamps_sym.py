@@ -6,7 +6,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from statmc_amd import build
-build.SO = os.path.join(ROOT, "tools", "experiments", "variants", (sys.argv[1] if len(sys.argv) > 1 else "stamps") + ".so")
+build.SO = os.path.join(ROOT, "tools", "experiments", "variants", (sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "stamps") + ".so")
 import ctypes as C
 import torch
 from statmc_amd import api, film, synthetic
@@ -32,7 +32,12 @@ api.check(api.load().statmc_download(C.c_void_p(ws.data_ptr()), ptr, n4 * 16, ap
 torch.cuda.synchronize()
 tiles = (W // 128) * (H // 8)
 stride = n4 // tiles
-ws = ws[:tiles * stride].view(tiles, stride, 4)[:, stride - 8:, :].cpu()      # [tile][wave][hk, sweep, barrier, steps]
+full = ws[:tiles * stride].view(tiles, stride, 4)
+edge = full[:, stride - 16:stride - 8, :].cpu()                                # [tile][wave][before first step, after last, whole item]
+ws = full[:, stride - 8:, :].cpu()                                            # [tile][wave][hk, sweep, barrier, steps]
+e = edge.mean((0, 1))
+print("per item (clocks, mean over waves and workgroups): before the first step %.0f, after the last step %.0f, whole item %.0f"
+      % (e[0], e[1], e[2]))
 steps = ws[..., 3].clamp(min=1)
 per = ws[..., :3] / steps[..., None]
 print("tiles %d, stride %d float4" % (tiles, stride))
@@ -42,3 +47,7 @@ for w in range(8):
     print("  %d   %10.0f %10.0f %9.0f" % (w, m[0], m[1], m[2]))
 m = per.mean((0, 1))
 print("all   %10.0f %10.0f %9.0f   total %.0f clocks/step" % (m[0], m[1], m[2], m.sum()))
+if "--raw" in sys.argv:
+    for t in (0, 700, 2024):
+        print("tile", t, "step sums [hk, sweep, barrier, steps] wave 0:", ws[t, 0].tolist(), "wave 4:", ws[t, 4].tolist())
+        print("        edge [before, after, whole] wave 0:", edge[t, 0].tolist(), "wave 4:", edge[t, 4].tolist())
