@@ -14,6 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main(tag):
+    if tag.startswith("-"):
+        raise SystemExit("usage: summarise_profile.py TAG   (condenses gpurun_out/prof_TAG/ into profiles/TAG_*)")
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
