@@ -815,7 +815,7 @@ static hipError_t launch_lds_spec(const FilterArgs &a, hipStream_t s, const char
 // Window filter reading the 15-channel block + halo image (multi-GPU path): LDS kernels only.
 hipError_t launch_lds_packed(const FilterArgs &a, hipStream_t s, const char **variant) {
     if (a.sym.patch != nullptr) {
-        *variant = "sym_r20";
+        *variant = a.channel_rule == STATMC_CHANNELS_JOINT ? "sym_r20_joint" : "sym_r20";
         return launch_sym(a, s);
     }
     return launch_lds_spec<0>(a, s, variant);
@@ -824,7 +824,7 @@ hipError_t launch_lds_packed(const FilterArgs &a, hipStream_t s, const char **va
 hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s, const char **variant) {
     const bool fast = lds_path_selected(a, channels);
     if (fast && a.sym.patch != nullptr) {
-        *variant = channels == 3 ? "sym_r20" : "sym_r20_f";
+        *variant = channels == 1 ? "sym_r20_f" : a.channel_rule == STATMC_CHANNELS_JOINT ? "sym_r20_joint" : "sym_r20";
         return launch_sym(a, s);
     }
     if (fast) {

@@ -78,6 +78,10 @@ constexpr bool kPipe = STATMC_SYM_PIPE;
 #endif
 constexpr int kSplit = STATMC_SYM_SPLIT;   // window half 0 sweeps dx <= kSplit, half 1 the rest   // hand-placed LDS reads one phase ahead of the arithmetic
 constexpr int kAblate = STATMC_SYM_ABLATE;  // 1 no q side, 2 no row staging, 4 no flush, 8 no sweep arithmetic, 16 no barrier
+// membership / buffer mode of a launch: one RGB buffer, every channel passes (default spec) | two float buffers
+// (filter<float>) | one RGB buffer, channels pooled (STATMC_CHANNELS_JOINT: sum_c fma(d_c, d_c, -(D_p,c + D_q,c)) <= 0,
+// as symmetric in (p, q) as the default test)
+constexpr int kModeRgb = 0, kModePair = 1, kModeJoint = 2;
 constexpr int kR = 20;
 constexpr int kPx = 4;                    // pixels per lane
 constexpr int kW = 32 * kPx;              // 128 tile columns: half a wave per row
@@ -194,9 +198,10 @@ __device__ __forceinline__ void range_exponent(const Lane &st, const v4f *g, con
 // membership gate and weight of tap pair H: w = member ? exp2(e) : 0   (mcn: corrected mean planes 0..2, -D planes 3..5)
 // PAIR (two float buffers in the (x, y) channels): one weight per buffer, w for buffer 0 and wb for buffer 1 -- the
 // buffers share the range weight and gate separately (filter<float>: every buffer is its own 1-channel test).
-template <int H, unsigned MASK, bool PAIR>
+template <int H, unsigned MASK, int MODE>
 __device__ __forceinline__ void gate_weight(const Lane &st, const v4f *mcn, const v2f (&e)[kPx], v2f (&w)[kPx], v2f (&wb)[kPx]) {
     using M = Taps<H, MASK>;
+    constexpr bool PAIR = MODE == kModePair;
     constexpr int NC = PAIR ? 2 : 3;
     // two pixels at a time: 6 independent chains are enough to keep the pipe busy and halve the live statistics
 #pragma unroll
@@ -223,6 +228,14 @@ __device__ __forceinline__ void gate_weight(const Lane &st, const v4f *mcn, cons
                 w[k] = v2f{M::in0(k) && u[kk][0].x <= 0.f ? x.x : 0.f, M::in1(k) && u[kk][0].y <= 0.f ? x.y : 0.f};
                 wb[k] = v2f{M::in0(k) && u[kk][1].x <= 0.f ? x.x : 0.f, M::in1(k) && u[kk][1].y <= 0.f ? x.y : 0.f};
             }
+        } else if constexpr (MODE == kModeJoint) {
+            // pooled channels: (u_0 + u_1) + u_2 <= 0, the oracle's order; a NaN anywhere fails the compare
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) if (M::on(k0 + kk)) {
+                const int k = k0 + kk;
+                const v2f m = (u[kk][0] + u[kk][1]) + u[kk][2];
+                w[k] = v2f{M::in0(k) && m.x <= 0.f ? w[k].x : 0.f, M::in1(k) && m.y <= 0.f ? w[k].y : 0.f};
+            }
         } else {
             // all three channels pass <=> max_c <= 0; v_max3 drops NaN operands, which is why a pixel that takes no
             // part is staged with NaN in all three channels of its mean
@@ -240,9 +253,10 @@ __device__ __forceinline__ void gate_weight(const Lane &st, const v4f *mcn, cons
 // p side: the lane's pixels collect w * colour_q; q side (SYM): the taps' accumulators collect w * colour_p.
 // PAIR: the four sums per pixel are (sum w0 c0, sum w1 c1, sum w0, sum w1) -- acc[0], acc[1], acc[2], sw -- instead of
 // (sum w r, sum w g, sum w b, sum w); the same four packed operations per side.
-template <int H, unsigned MASK, bool SYM, bool PAIR>
+template <int H, unsigned MASK, bool SYM, int MODE>
 __device__ __forceinline__ void accumulate(Lane &st, const v4f *col, const v2f (&w)[kPx], const v2f (&wb)[kPx], v2f (&qv)[4]) {
     using M = Taps<H, MASK>;
+    constexpr bool PAIR = MODE == kModePair;
     if constexpr (PAIR) {
 #pragma unroll
         for (int k = 0; k < kPx; k++) if (M::on(k)) { st.acc[k][2] += w[k]; st.sw[k] += wb[k]; }
@@ -310,10 +324,11 @@ __device__ __forceinline__ void lds_wait(v4f &a, v4f &b, v4f &c, v4f &d) {
 // planes of the taps).  PIPE: the statistics planes are requested before the feature planes and the colour /
 // accumulator planes before the gates, by hand-placed reads, so that two of the three phases find their operands
 // in registers; otherwise the compiler's own loads (each phase waits for its operands).
-template <unsigned MASK, bool SYM, bool PIPE, bool PAIR>
+template <unsigned MASK, bool SYM, bool PIPE, int MODE>
 __device__ __forceinline__ void chunk(Lane &st, const float *__restrict__ row, const float *__restrict__ tab, float *__restrict__ qrow, int j) {
     using M0 = Taps<0, MASK>;
     using M1 = Taps<1, MASK>;
+    constexpr bool PAIR = MODE == kModePair;
     const float *r = row + 4 * j;
     v4f g[6], mcn[6], col[3], q4[4];
     v2f e0[kPx], e1[kPx], w0[kPx], w1[kPx], wb0[kPx], wb1[kPx];   // wb*: second buffer's weights (PAIR)
@@ -327,13 +342,13 @@ __device__ __forceinline__ void chunk(Lane &st, const float *__restrict__ row, c
         for (int v = 0; v < 4; v++) asm volatile("" : "=v"(q4[v]));
         if constexpr (M0::any()) range_exponent<0, MASK>(st, g, tab, j, e0);
         if constexpr (M1::any()) range_exponent<1, MASK>(st, g, tab, j, e1);
-        if constexpr (M0::any()) gate_weight<0, MASK, PAIR>(st, mcn, e0, w0, wb0);
-        if constexpr (M1::any()) gate_weight<1, MASK, PAIR>(st, mcn, e1, w1, wb1);
+        if constexpr (M0::any()) gate_weight<0, MASK, MODE>(st, mcn, e0, w0, wb0);
+        if constexpr (M1::any()) gate_weight<1, MASK, MODE>(st, mcn, e1, w1, wb1);
         v2f qa2[4], qb2[4];
 #pragma unroll
         for (int v = 0; v < 4; v++) { qa2[v] = pair_of<0>(q4[v]); qb2[v] = pair_of<1>(q4[v]); }
-        if constexpr (M0::any()) accumulate<0, MASK, SYM, PAIR>(st, col, w0, wb0, qa2);
-        if constexpr (M1::any()) accumulate<1, MASK, SYM, PAIR>(st, col, w1, wb1, qb2);
+        if constexpr (M0::any()) accumulate<0, MASK, SYM, MODE>(st, col, w0, wb0, qa2);
+        if constexpr (M1::any()) accumulate<1, MASK, SYM, MODE>(st, col, w1, wb1, qb2);
         if constexpr (SYM) {
 #pragma unroll
             for (int v = 0; v < 4; v++) asm volatile("" ::"v"(qa2[v]), "v"(qb2[v]));
@@ -373,8 +388,8 @@ __device__ __forceinline__ void chunk(Lane &st, const float *__restrict__ row, c
         for (int ch = 0; ch < 6; ch++)
             if (!(PAIR && ch % 3 == 2)) mcn[ch] = *reinterpret_cast<const v4f *>(r + (C_MC + ch) * kP);
     }
-    if constexpr (M0::any()) gate_weight<0, MASK, PAIR>(st, mcn, e0, w0, wb0);
-    if constexpr (M1::any()) gate_weight<1, MASK, PAIR>(st, mcn, e1, w1, wb1);
+    if constexpr (M0::any()) gate_weight<0, MASK, MODE>(st, mcn, e0, w0, wb0);
+    if constexpr (M1::any()) gate_weight<1, MASK, MODE>(st, mcn, e1, w1, wb1);
     if constexpr (PIPE) {
         // ... and the colour / accumulator planes before the gates; the wait names the weights too, so that it stays
         // behind the arithmetic that produced them (plain arithmetic may otherwise be scheduled after the wait)
@@ -395,8 +410,8 @@ __device__ __forceinline__ void chunk(Lane &st, const float *__restrict__ row, c
 #pragma unroll
         for (int v = 0; v < 4; v++) { qa2[v] = pair_of<0>(q4[v]); qb2[v] = pair_of<1>(q4[v]); }
     }
-    if constexpr (M0::any()) accumulate<0, MASK, SYM, PAIR>(st, col, w0, wb0, qa2);
-    if constexpr (M1::any()) accumulate<1, MASK, SYM, PAIR>(st, col, w1, wb1, qb2);
+    if constexpr (M0::any()) accumulate<0, MASK, SYM, MODE>(st, col, w0, wb0, qa2);
+    if constexpr (M1::any()) accumulate<1, MASK, SYM, MODE>(st, col, w1, wb1, qb2);
     if constexpr (SYM) {
         if constexpr ((kAblate & 64) != 0) {   // timing only: no write-back of the accumulators
 #pragma unroll
@@ -431,7 +446,7 @@ struct Range {
     static constexpr int last_full() { for (int j = kChunks - 1; j >= 0; j--) if (m(j) == kFull) return j; return -1; }
 };
 
-template <int LO, int HI, bool SYM, bool PAIR>
+template <int LO, int HI, bool SYM, int MODE>
 __device__ __forceinline__ void sweep_range(Lane &st, const float *row, const float *tab, float *qrow) {
     using R = Range<LO, HI>;
     constexpr int j0 = R::first(), j1 = R::last(), f0 = R::first_full(), f1 = R::last_full();
@@ -439,13 +454,13 @@ __device__ __forceinline__ void sweep_range(Lane &st, const float *row, const fl
     constexpr bool has_full = f0 <= f1;
     constexpr int lo_end = has_full ? f0 : j1 + 1;      // masked groups j0 .. lo_end-1, full f0 .. f1, masked f1+1 .. j1
     static_assert(lo_end - j0 <= 2 && (!has_full || j1 - f1 <= 2), "more than two cut groups at an end");
-    if constexpr (j0 < lo_end) chunk<R::m(j0), SYM, kPipe, PAIR>(st, row, tab, qrow, j0);
-    if constexpr (j0 + 1 < lo_end) chunk<R::m(j0 + 1), SYM, kPipe, PAIR>(st, row, tab, qrow, j0 + 1);
+    if constexpr (j0 < lo_end) chunk<R::m(j0), SYM, kPipe, MODE>(st, row, tab, qrow, j0);
+    if constexpr (j0 + 1 < lo_end) chunk<R::m(j0 + 1), SYM, kPipe, MODE>(st, row, tab, qrow, j0 + 1);
     if constexpr (has_full) {
 #pragma unroll 1
-        for (int j = f0; j <= f1; j++) chunk<R::kFull, SYM, kPipe, PAIR>(st, row, tab, qrow, j);
-        if constexpr (f1 + 1 <= j1) chunk<R::m(f1 + 1 <= j1 ? f1 + 1 : 0), SYM, kPipe, PAIR>(st, row, tab, qrow, f1 + 1);
-        if constexpr (f1 + 2 <= j1) chunk<R::m(f1 + 2 <= j1 ? f1 + 2 : 0), SYM, kPipe, PAIR>(st, row, tab, qrow, f1 + 2);
+        for (int j = f0; j <= f1; j++) chunk<R::kFull, SYM, kPipe, MODE>(st, row, tab, qrow, j);
+        if constexpr (f1 + 1 <= j1) chunk<R::m(f1 + 1 <= j1 ? f1 + 1 : 0), SYM, kPipe, MODE>(st, row, tab, qrow, f1 + 1);
+        if constexpr (f1 + 2 <= j1) chunk<R::m(f1 + 2 <= j1 ? f1 + 2 : 0), SYM, kPipe, MODE>(st, row, tab, qrow, f1 + 2);
     }
 }
 
@@ -456,21 +471,21 @@ __device__ __forceinline__ void sweep_range(Lane &st, const float *row, const fl
 // uneven split is slower: 1.42 ms at kSplit = 0, 1.62 at 7, 1.75 at 11.  The SIMD is busy either way.)
 // dy = 0: the pairs inside a row are the taps dx >= 1 (the accumulator row is the wave's own row); the pixel's own
 // tap dx = 0 feeds the p side only.
-template <int HF, bool PAIR>
+template <int HF, int MODE>
 __device__ __forceinline__ void eval_half_row(Lane &st, const float *row, const float *tab, float *qrow, bool dy0) {
     if constexpr (HF == 0) {
         if (dy0) {
-            sweep_range<0, 0, false, PAIR>(st, row, tab, qrow);
-            if constexpr (kSplit >= 1) sweep_range<1, kSplit, true, PAIR>(st, row, tab, qrow);
+            sweep_range<0, 0, false, MODE>(st, row, tab, qrow);
+            if constexpr (kSplit >= 1) sweep_range<1, kSplit, true, MODE>(st, row, tab, qrow);
         } else {
-            sweep_range<-kR, kSplit, true, PAIR>(st, row, tab, qrow);
+            sweep_range<-kR, kSplit, true, MODE>(st, row, tab, qrow);
         }
     } else {
         if constexpr (kSplit >= 1) {
-            sweep_range<kSplit + 1, kR, true, PAIR>(st, row, tab, qrow);
+            sweep_range<kSplit + 1, kR, true, MODE>(st, row, tab, qrow);
         } else {
-            if (dy0) sweep_range<1, kR, true, PAIR>(st, row, tab, qrow);
-            else sweep_range<kSplit + 1, kR, true, PAIR>(st, row, tab, qrow);
+            if (dy0) sweep_range<1, kR, true, MODE>(st, row, tab, qrow);
+            else sweep_range<kSplit + 1, kR, true, MODE>(st, row, tab, qrow);
         }
     }
 }
@@ -557,9 +572,10 @@ __device__ __forceinline__ StagedPixel raw_pixel(const FilterArgs &a, const floa
 // PAIR = filter<float>, two 1-channel buffers per launch: the (x, y) channels of the three statistics / colour images
 // hold buffer 0 and buffer 1 (pack_pair_kernel), the third channel is empty; the buffers share the range weight, gate
 // and normalise separately.
-template <bool DMA, bool PAIR>
+template <bool DMA, int MODE>
 __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr bool PAIR = MODE == kModePair;
     // XCD-aware work mapping (as in the one-sided kernel): each XCD walks a contiguous range of items
     const int n_items = gridDim.x, b = blockIdx.x;
     const int q8 = n_items >> 3, rem8 = n_items & 7, xcd = b & 7, idx = b >> 3;
@@ -708,9 +724,9 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             const float *tab = tab_lds + ((s - s_a) & 1) * kTabPad;
             if (kAblate & 8) {
             } else if (half == 0) {
-                eval_half_row<0, PAIR>(st, row, tab, qrow, s == 0);
+                eval_half_row<0, MODE>(st, row, tab, qrow, s == 0);
             } else {
-                eval_half_row<1, PAIR>(st, row, tab, qrow, s == 0);
+                eval_half_row<1, MODE>(st, row, tab, qrow, s == 0);
             }
 
             if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_ev += t - tk0; tk0 = t; }
@@ -872,8 +888,8 @@ size_t sym_patch_floats(const FilterArgs &a, int n_parts) {
 // (other sets: the one-sided kernel)
 bool sym_eligible(const FilterArgs &a, int channels) {
     if (a.radius != sym::kR || !fast_path_eligible(a, channels)) return false;
-    // the pair-symmetric kernel implements the default membership test and border rule
-    if (a.gate != STATMC_GATE_SYMMETRIC || a.channel_rule != STATMC_CHANNELS_AND || a.border != STATMC_BORDER_CLIP) return false;
+    // the pair-symmetric kernel implements the symmetric gate (channels tested one by one or pooled) and the clipped border
+    if (a.gate != STATMC_GATE_SYMMETRIC || a.border != STATMC_BORDER_CLIP) return false;
     if (a.n_g > 2) return false;
     for (int g = 0; g < a.n_g; g++)
         if (a.g[g].channels != 3) return false;
@@ -901,8 +917,14 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
         dma = a.width % 4 == 0 && a.sym.fx0 % 4 == 0 && al16(mc3) && al16(d3) && al16(c3) && (a.gscale0 == 0.f || al16(a.g[0].data)) &&
               (a.gscale1 == 0.f || al16(a.g[1].data));
     }
-    const void *kernel = pair ? (dma ? reinterpret_cast<const void *>(&window_filter_sym<true, true>) : reinterpret_cast<const void *>(&window_filter_sym<false, true>))
-                              : (dma ? reinterpret_cast<const void *>(&window_filter_sym<true, false>) : reinterpret_cast<const void *>(&window_filter_sym<false, false>));
+    // float buffers have one channel: pooled == per channel
+    const int mode = pair ? kModePair : a.channel_rule == STATMC_CHANNELS_JOINT ? kModeJoint : kModeRgb;
+    const void *kernels[2][3] = {
+        {reinterpret_cast<const void *>(&window_filter_sym<false, kModeRgb>), reinterpret_cast<const void *>(&window_filter_sym<false, kModePair>),
+         reinterpret_cast<const void *>(&window_filter_sym<false, kModeJoint>)},
+        {reinterpret_cast<const void *>(&window_filter_sym<true, kModeRgb>), reinterpret_cast<const void *>(&window_filter_sym<true, kModePair>),
+         reinterpret_cast<const void *>(&window_filter_sym<true, kModeJoint>)}};
+    const void *kernel = kernels[dma ? 1 : 0][mode];
     static std::mutex mu;
     static std::set<std::pair<int, const void *>> done;
     int dev = 0;
@@ -915,10 +937,8 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
         }
     }
     const dim3 grid(sym_tiles(a) * a.n_parts);
-    if (pair && dma) hipLaunchKernelGGL((window_filter_sym<true, true>), grid, dim3(kThreads), kLdsBytes, s, a);
-    else if (pair) hipLaunchKernelGGL((window_filter_sym<false, true>), grid, dim3(kThreads), kLdsBytes, s, a);
-    else if (dma) hipLaunchKernelGGL((window_filter_sym<true, false>), grid, dim3(kThreads), kLdsBytes, s, a);
-    else hipLaunchKernelGGL((window_filter_sym<false, false>), grid, dim3(kThreads), kLdsBytes, s, a);
+    void *kargs[] = {&a};
+    if (hipError_t e = hipLaunchKernel(kernel, grid, dim3(kThreads), kargs, kLdsBytes, s); e != hipSuccess) return e;
     const dim3 cgrid((a.rx1 - a.rx0 + 63) / 64, (a.ry1 - a.ry0 + 3) / 4);
     hipLaunchKernelGGL(combine_sym_kernel, cgrid, dim3(256), 0, s, a);
     return hipGetLastError();

@@ -991,15 +991,17 @@ def run_spec(gpu, oracle, st, spec_kw, radius, sd, channels=3, alpha_index=0, fo
 def expected_lds_variant(spec_kw, channels, radius):
     """Which kernel serves a spec: a per-pair Welch lookup runs the general kernel; the one-sided LDS kernel knows
     both gates, channel rules and border rules (the non-default membership tests in its runtime-radius build); the
-    pair-symmetric kernel takes the default test and border at r = 20."""
+    pair-symmetric kernel takes the symmetric gate (channels one by one or pooled) with the clipped border at r = 20."""
     gate, joint = spec_kw.get("gate", 0), spec_kw.get("channel_rule", 0) and channels == 3
     if spec_kw.get("dof", 0):
         return "generic"
     f = "_f" if channels == 1 else ""
+    if radius == 20 and not gate and not spec_kw.get("border", 0):
+        return "sym_r20" + f + ("_joint" if joint else "")
     if gate or joint:
         return "lds_rt" + f + ("_asym" if gate else "") + ("_joint" if joint else "")
     if radius == 20:
-        return "sym_r20" + f if not spec_kw.get("border", 0) else "lds_r20" + f
+        return "lds_r20" + f
     return "lds_rt" + f
 
 
@@ -1024,8 +1026,8 @@ def test_filter_spec_variants_match_oracle(gpu, oracle, spec_kw):
 
 
 @pytest.mark.parametrize("spec_kw", [dict(), dict(gate=1), dict(dof=1), dict(border=1, channel_rule=1), dict(sides=1, small_n=1),
-                                     dict(border=1), dict(gate=1, channel_rule=1, border=1)],
-                         ids=["default", "asym", "welch", "clamp+joint", "one-sided+exclude", "clamp", "asym+joint+clamp"])
+                                     dict(border=1), dict(gate=1, channel_rule=1, border=1), dict(channel_rule=1)],
+                         ids=["default", "asym", "welch", "clamp+joint", "one-sided+exclude", "clamp", "asym+joint+clamp", "joint"])
 @pytest.mark.parametrize("channels", [1, 3])
 def test_filter_spec_r20_and_float(gpu, oracle, spec_kw, channels):
     """The shipped radius / sd under a few specs, RGB and float buffers; the default spec must stay on the LDS kernel."""
