@@ -468,7 +468,8 @@ __device__ __forceinline__ void sweep_range(Lane &st, const float *row, const fl
 // dx in [-20, kSplit], half 1 dx in [kSplit + 1, 20], every pair feeding both its pixels.  kSplit = 0: the middle.
 // (The per-wave clocks -- tools/experiments/stamps_sym.py -- show the older wave of every SIMD pair finishing its
 // half well before the younger one and idling at the barrier, which suggests giving it more columns; measured, any
-// uneven split is slower: 1.42 ms at kSplit = 0, 1.62 at 7, 1.75 at 11.  The SIMD is busy either way.)
+// uneven split is slower: 1.43 ms at kSplit = 0; 1.46 at 4 and 1.48 at -4, which like 0 cut only one read group;
+// 1.56 at 7 and 1.75 at 11, which cut two.  The SIMD is busy either way.)
 // dy = 0: the pairs inside a row are the taps dx >= 1 (the accumulator row is the wave's own row); the pixel's own
 // tap dx = 0 feeds the p side only.
 template <int HF, int MODE>

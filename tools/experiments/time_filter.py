@@ -8,7 +8,7 @@ if "--lib" in sys.argv:      # a variant library (tools/experiments/build_varian
     k = sys.argv.index("--lib")
     build.SO = os.path.abspath(sys.argv[k + 1])
     del sys.argv[k:k + 2]
-    CASES = ((0, 1), (0, 2))
+    CASES = ((0, 1), (0, 1), (0, 1), (0, 2))
 import torch
 from statmc_amd import api, film, synthetic
 
