@@ -76,6 +76,12 @@ constexpr bool kPipe = STATMC_SYM_PIPE;
 #ifndef STATMC_SYM_SPLIT
 #define STATMC_SYM_SPLIT 0
 #endif
+#ifndef STATMC_SYM_PRIO
+#define STATMC_SYM_PRIO 0
+#endif
+// experiment (s_setprio): 1 = the half-1 waves run at raised issue priority (1.49 ms against 1.43), 2 = the half-0
+// waves during housekeeping (1.43: no change)
+constexpr int kPrio = STATMC_SYM_PRIO;
 constexpr int kSplit = STATMC_SYM_SPLIT;   // window half 0 sweeps dx <= kSplit, half 1 the rest   // hand-placed LDS reads one phase ahead of the arithmetic
 constexpr int kAblate = STATMC_SYM_ABLATE;  // 1 no q side, 2 no row staging, 4 no flush, 8 no sweep arithmetic, 16 no barrier
 // membership / buffer mode of a launch: one RGB buffer, every channel passes (default spec) | two float buffers
@@ -601,6 +607,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     const int half = wave >> 2;
     const float k0 = a.gscale0, k1 = a.gscale1;
     constexpr int tw = kTabW;
+    if constexpr (kPrio == 1) { if (half == 1) __builtin_amdgcn_s_setprio(2); }
 
     // ---- the lane's own 4 pixels (loads clamped into the image; outside it the pixel takes no part)
     Lane st;
@@ -709,7 +716,9 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
                     }
                 }
             };
+            if constexpr (kPrio == 2) { if (half == 0) __builtin_amdgcn_s_setprio(3); }
             if (!DMA || (!kHkAtEnd && half == 0)) housekeeping();
+            if constexpr (kPrio == 2) { if (half == 0) __builtin_amdgcn_s_setprio(0); }
             if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_hk += t - tk0; tk0 = t; }
             const int ti = (int)threadIdx.x - (kThreads - 64);
             const bool tstage = s + 1 < s_b && ti >= 0 && ti < tw;
