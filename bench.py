@@ -259,16 +259,22 @@ def host_bracket(fs, args):
                 "t0-b0-m3": rad["m3"], "t1-b0-film-mean": fs.g_buffer("normal"), "t2-b0-film-mean": fs.g_buffer("albedo")}
         for name, img in dump.items():
             pfm.write_pfm("%s-%d-%s.pfm" % (stem, args.spp, name), img.cpu().numpy())
-        out = subprocess.run([exe, "--stem", stem, "--spp", ",".join([str(args.spp)] * 4), "--filtersd", str(args.filtersd),
-                              "--filterradius", str(args.radius), "--warmup", "--output", "film-f"],
-                             capture_output=True, text=True, timeout=300)
-        if out.returncode != 0:
-            return {"error": out.stderr.strip()[-300:]}
-        ns = [int(v) for v in re.findall(r"HIP time \[ns\]: (\d+)", out.stdout)][1:]     # drop the warm-up
-        ns.sort()
-        return {"cuda_time_bracket_ms": round(ns[0] / 1e6, 3), "median_ms": round(ns[len(ns) // 2] / 1e6, 3),
-                "iterations": len(ns), "what": "Estimator::Upload (76 B/px) + Denoise + Download (12 B/px) + Synchronize, "
-                                               "C++ host side (tools/bin/statmc_denoise), page-locked host images"}
+        res = {}
+        for key, bands in (("pipelined", "0"), ("one_stream", "1")):
+            out = subprocess.run([exe, "--stem", stem, "--spp", ",".join([str(args.spp)] * 4), "--filtersd", str(args.filtersd),
+                                  "--filterradius", str(args.radius), "--warmup", "--bands", bands, "--output", "film-f"],
+                                 capture_output=True, text=True, timeout=300)
+            if out.returncode != 0:
+                return {"error": out.stderr.strip()[-300:]}
+            ns = [int(v) for v in re.findall(r"HIP time \[ns\]: (\d+)", out.stdout)][1:]     # drop the warm-up
+            ns.sort()
+            res[key] = (round(ns[0] / 1e6, 3), round(ns[len(ns) // 2] / 1e6, 3), len(ns),
+                        int(re.search(r"pipeline bands: (\d+)", out.stdout).group(1)))
+        return {"cuda_time_bracket_ms": res["pipelined"][0], "median_ms": res["pipelined"][1], "iterations": res["pipelined"][2],
+                "pipeline_bands": res["pipelined"][3], "one_stream_ms": res["one_stream"][0],
+                "what": "Estimator::Upload (76 B/px) + Denoise + Download (12 B/px) + Synchronize, C++ host side "
+                        "(tools/bin/statmc_denoise), page-locked host images; the three phases run as a pipeline of row "
+                        "bands on three streams (same bits), one_stream_ms: the same calls one after the other"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 

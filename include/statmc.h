@@ -105,6 +105,14 @@ int statmc_upload(void *dev_dst, const void *host_src, size_t bytes, void *strea
 int statmc_download(void *host_dst, const void *dev_src, size_t bytes, void *stream); /* Buffer::download */
 int statmc_stream_create(void **stream);
 int statmc_stream_destroy(void *stream);
+/* Events: order work across streams without blocking the host -- what lets Estimator::Upload / Denoise / Download
+ * (src/statistics/estimator.cpp:409-489) run as a pipeline of row bands on three streams (copies in, kernels, copies
+ * out) instead of one after the other.  statmc_stream_wait_event makes everything enqueued on `stream` afterwards
+ * wait for the work `event` was recorded behind. */
+int statmc_event_create(void **event);
+int statmc_event_destroy(void *event);
+int statmc_event_record(void *event, void *stream);
+int statmc_stream_wait_event(void *stream, void *event);
 /* Replaces cv::cuda::stat_denoiser::synchronize(stream)  (src/statistics/estimator.cpp:571-573). */
 int statmc_synchronize(void *stream);
 

@@ -204,8 +204,80 @@ template <>
 struct channels<float3> { static constexpr int value = 3; };
 }  // namespace detail
 
+// The argument block of one filter<T> call with the descriptor tables it points into.
+struct FilterCall {
+    std::vector<statmc_image> n, mean, m2, m3, film, g, mc, dc, ff;
+    statmc_filter_args a;
+    int channels = 3;
+    // rows [y0, y1) of an image as an image of its own (rows are contiguous: a band is a sub-array)
+    static statmc_image rows(const statmc_image &im, int y0, int y1) {
+        statmc_image r = im;
+        r.data = static_cast<char *>(im.data) + (size_t)y0 * im.step;
+        r.rows = y1 - y0;
+        return r;
+    }
+    // pre-pass of rows [y0, y1) only (per-pixel work: the band is passed as a shorter image)
+    void prepassRows(int y0, int y1) const {
+        std::vector<statmc_image> bn, bmean, bm2, bm3, bmc, bdc;
+        for (size_t b = 0; b < n.size(); b++) {
+            bn.push_back(rows(n[b], y0, y1)); bmean.push_back(rows(mean[b], y0, y1)); bm2.push_back(rows(m2[b], y0, y1));
+            bm3.push_back(rows(m3[b], y0, y1)); bmc.push_back(rows(mc[b], y0, y1)); bdc.push_back(rows(dc[b], y0, y1));
+        }
+        statmc_filter_args p = a;
+        p.height = (uint16_t)(y1 - y0);
+        p.n = bn.data(); p.mean = bmean.data(); p.m2 = bm2.data(); p.m3 = bm3.data();
+        p.mean_corr = bmc.data(); p.discriminator = bdc.data();
+        check(statmc_prepass(&p, channels));
+    }
+    // window filter of rows [y0, y1) (the window still reads the whole image)
+    void filterRows(int y0, int y1) const {
+        statmc_filter_args f = a;
+        f.roi_x0 = 0; f.roi_x1 = a.width; f.roi_y0 = y0; f.roi_y1 = y1;
+        check(statmc_window_filter(&f, channels));
+    }
+    void run() const { check(channels == 3 ? statmc_filter_f32x3(&a) : statmc_filter_f32(&a)); }
+};
+
 // Argument order of cv::cuda::stat_denoiser::filter<T> (estimator.cpp:437-459).  Where the
 // reference passes a GpuMat holding a device array of PtrStepSzb, this takes the images.
+template <class T>
+void fillFilterCall(FilterCall &c, unsigned char nBuffers, unsigned short width, unsigned short height, float filterDSFactor,
+                    unsigned char filterRadius, bool denoiseFilm, const std::vector<DeviceImage> &nPtrs,
+                    const std::vector<DeviceImage> &meanPtrs, const std::vector<DeviceImage> &m2Ptrs,
+                    const std::vector<DeviceImage> &m3Ptrs, const std::vector<DeviceImage> &filmPtrs,
+                    const DeviceImage &filmBuffer, const std::vector<DeviceImage> &gBufferPtrs,
+                    const std::vector<unsigned char> &gBufferChannelCounts, const std::vector<float> &gBufferDRFactors,
+                    size_t nGBuffers, const std::vector<DeviceImage> &meanCorrPtrs,
+                    const std::vector<DeviceImage> &discriminatorPtrs, const std::vector<DeviceImage> &filmFilteredPtrs,
+                    const DeviceImage &filmFilteredBuffer, Stream &stream) {
+    c.n = detail::descs(nPtrs); c.mean = detail::descs(meanPtrs); c.m2 = detail::descs(m2Ptrs);
+    c.m3 = detail::descs(m3Ptrs); c.film = detail::descs(filmPtrs); c.g = detail::descs(gBufferPtrs);
+    c.mc = detail::descs(meanCorrPtrs); c.dc = detail::descs(discriminatorPtrs); c.ff = detail::descs(filmFilteredPtrs);
+    c.channels = detail::channels<T>::value;
+    statmc_filter_args &a = c.a;
+    std::memset(&a, 0, sizeof(a));
+    a.n_buffers = nBuffers;
+    a.width = width;
+    a.height = height;
+    a.filter_ds_factor = filterDSFactor;
+    a.filter_radius = filterRadius;
+    a.denoise_film = denoiseFilm ? 1 : 0;
+    a.n = c.n.data();
+    a.mean = c.mean.data();
+    a.m2 = c.m2.data();
+    a.m3 = c.m3.data();
+    a.film = c.film.data();
+    a.film_buffer = filmBuffer.desc();
+    a.g_buffers = c.g.data();
+    a.g_channel_counts = gBufferChannelCounts.data();
+    a.g_dr_factors = gBufferDRFactors.data();
+    a.n_g_buffers = nGBuffers;
+    a.mean_corr = c.mc.data();
+    a.discriminator = c.dc.data();
+    a.film_filtered = c.ff.data();
+    a.film_filtered_buffer = filmFilteredBuffer.desc();
+    a.stream = stream.handle();
+}
 template <class T>
 void filter(unsigned char nBuffers, unsigned short width, unsigned short height, float filterDSFactor,
             unsigned char filterRadius, bool denoiseFilm, const std::vector<DeviceImage> &nPtrs,
@@ -216,34 +288,11 @@ void filter(unsigned char nBuffers, unsigned short width, unsigned short height,
             size_t nGBuffers, const std::vector<DeviceImage> &meanCorrPtrs,
             const std::vector<DeviceImage> &discriminatorPtrs, const std::vector<DeviceImage> &filmFilteredPtrs,
             const DeviceImage &filmFilteredBuffer, Stream &stream) {
-    const auto n = detail::descs(nPtrs), mean = detail::descs(meanPtrs), m2 = detail::descs(m2Ptrs),
-               m3 = detail::descs(m3Ptrs), film = detail::descs(filmPtrs), g = detail::descs(gBufferPtrs),
-               mc = detail::descs(meanCorrPtrs), dc = detail::descs(discriminatorPtrs),
-               ff = detail::descs(filmFilteredPtrs);
-    statmc_filter_args a;
-    std::memset(&a, 0, sizeof(a));
-    a.n_buffers = nBuffers;
-    a.width = width;
-    a.height = height;
-    a.filter_ds_factor = filterDSFactor;
-    a.filter_radius = filterRadius;
-    a.denoise_film = denoiseFilm ? 1 : 0;
-    a.n = n.data();
-    a.mean = mean.data();
-    a.m2 = m2.data();
-    a.m3 = m3.data();
-    a.film = film.data();
-    a.film_buffer = filmBuffer.desc();
-    a.g_buffers = g.data();
-    a.g_channel_counts = gBufferChannelCounts.data();
-    a.g_dr_factors = gBufferDRFactors.data();
-    a.n_g_buffers = nGBuffers;
-    a.mean_corr = mc.data();
-    a.discriminator = dc.data();
-    a.film_filtered = ff.data();
-    a.film_filtered_buffer = filmFilteredBuffer.desc();
-    a.stream = stream.handle();
-    check(detail::channels<T>::value == 3 ? statmc_filter_f32x3(&a) : statmc_filter_f32(&a));
+    FilterCall c;
+    fillFilterCall<T>(c, nBuffers, width, height, filterDSFactor, filterRadius, denoiseFilm, nPtrs, meanPtrs, m2Ptrs, m3Ptrs,
+                      filmPtrs, filmBuffer, gBufferPtrs, gBufferChannelCounts, gBufferDRFactors, nGBuffers, meanCorrPtrs,
+                      discriminatorPtrs, filmFilteredPtrs, filmFilteredBuffer, stream);
+    c.run();
 }
 
 // cv::cuda::stat_denoiser::calculateMeanVars<T> (estimator.cpp:501-521, commented-out call).
@@ -575,6 +624,7 @@ class Estimator {
         }
         if (allocateDevice) stat_denoiser::setup(device);
     }
+    ~Estimator() { destroyPipeline(); }
     Estimator(const Estimator &) = delete;
     Estimator &operator=(const Estimator &) = delete;
 
@@ -713,34 +763,108 @@ class Estimator {
         }
     }
 
+    // Upload / Denoise / Download / Synchronize (estimator.cpp:409-489, 571-573; the sequence StatPathIntegrator times
+    // as "CUDA time", statpath.cpp:409-417).  All four only enqueue.  With more than one pipeline band (SetPipelineBands;
+    // automatic: 6 bands for images of 512 rows and more) the image is cut into bands of rows and the three phases
+    // run on three streams ordered by events: band k travels with the r rows below it (its lower halo), is pre-passed
+    // and filtered as soon as it has arrived, and copied back as soon as it is filtered -- the PCIe copies in both
+    // directions and the kernels overlap instead of adding up; what is left after the last copy in is one band's
+    // filter.  Results are the same bits as without bands: the pre-pass is per pixel, and the window filter forms a
+    // pixel's sums in the same order for any output region.
+    void SetPipelineBands(int n) { bandsRequested = n; }   // 0 = automatic, 1 = off
+    int PipelineBands() const {
+        if (!allocateDevice || acc.dry) return 1;
+        int n = bandsRequested == 0 ? (height >= 512 ? 6 : 1) : bandsRequested;
+        const int minRows = std::max(64, ((int)filterRadius + 7) & ~7);   // a band holds the halo of the band above it
+        return std::max(1, std::min(n, (int)height / minRows));
+    }
     void Upload() {  // estimator.cpp:409-416
         if (acc.enabled) FlushSamples();  // statistics are produced on the device: only the rest moves
         if (acc.dry) return;
-        for (Buffer *b : uploadBuffers)
-            if (!acc.enabled || !acc.deviceProduced.count(b)) b->upload(stream);
+        const int nb = PipelineBands();
+        if (nb <= 1) {
+            for (Buffer *b : uploadBuffers)
+                if (!acc.enabled || !acc.deviceProduced.count(b)) b->upload(stream);
+            return;
+        }
+        ensurePipeline(nb);
+        // the copies overwrite images that earlier work on `stream` may still read
+        check(statmc_event_record(pipe.join, stream.handle()));
+        check(statmc_stream_wait_event(pipe.up, pipe.join));
+        for (int k = 0; k < nb; k++) {
+            const int y0 = arrivalEdge(k, nb), y1 = arrivalEdge(k + 1, nb);
+            for (Buffer *b : uploadBuffers) {
+                if (acc.enabled && acc.deviceProduced.count(b)) continue;
+                const size_t row = (size_t)b->mat.cols * b->mat.channels() * 4;
+                check(statmc_upload(static_cast<char *>(b->gpuMat.data()) + y0 * row, b->mat.ptr<char>() + y0 * row,
+                                    (size_t)(y1 - y0) * row, pipe.up));
+            }
+            check(statmc_event_record(pipe.arrived[k], pipe.up));
+        }
+        pipe.uploaded = pipe.pendingJoin = nb;
     }
     void Download() {  // estimator.cpp:418-425
-        for (Buffer *b : downloadBuffers) b->download(stream);
+        joinUploads();
+        const int nb = pipe.denoised;
+        pipe.denoised = 0;
+        for (Buffer *b : downloadBuffers) {
+            if (nb <= 1 || !pipe.outputs.count(b)) {
+                b->download(stream);   // behind everything enqueued on `stream`
+                continue;
+            }
+        }
+        if (nb <= 1) return;
+        for (int k = 0; k < nb; k++) {
+            const int y0 = bandEdge(k, nb), y1 = bandEdge(k + 1, nb);
+            check(statmc_stream_wait_event(pipe.down, pipe.filtered[k]));
+            for (Buffer *b : downloadBuffers) {
+                if (!pipe.outputs.count(b)) continue;
+                const size_t row = (size_t)b->mat.cols * b->mat.channels() * 4;
+                check(statmc_download(b->mat.ptr<char>() + y0 * row, static_cast<char *>(b->gpuMat.data()) + y0 * row,
+                                      (size_t)(y1 - y0) * row, pipe.down));
+            }
+        }
+        pipe.downloading = true;
     }
     void Denoise() {  // estimator.cpp:427-489
+        stat_denoiser::FilterCall calls[2];
+        int nCalls = 0;
         if (floatBufferCounts[DenoiseGroup] > 0) {
             const Tables &t = floatTables[DenoiseGroup];
-            stat_denoiser::filter<float>(floatBufferCounts[DenoiseGroup], width, height, filterDSFactor, filterRadius,
-                                         denoiseFilm, t.n, t.mean, t.m2, t.m3, t.film, filmBuffer.gpuMat, gBufferImages,
-                                         gBufferChannelCounts, gBufferDRFactors, gBuffers.size(), t.meanCorr,
-                                         t.discriminator, t.filmFiltered, filmFilteredBuffer.gpuMat, stream);
+            stat_denoiser::fillFilterCall<float>(calls[nCalls++], floatBufferCounts[DenoiseGroup], width, height, filterDSFactor,
+                                                 filterRadius, denoiseFilm, t.n, t.mean, t.m2, t.m3, t.film, filmBuffer.gpuMat,
+                                                 gBufferImages, gBufferChannelCounts, gBufferDRFactors, gBuffers.size(),
+                                                 t.meanCorr, t.discriminator, t.filmFiltered, filmFilteredBuffer.gpuMat, stream);
         }
         if (rgbBufferCounts[DenoiseGroup] > 0) {
             const Tables &t = rgbTables[DenoiseGroup];
-            stat_denoiser::filter<float3>(rgbBufferCounts[DenoiseGroup], width, height, filterDSFactor, filterRadius,
-                                          denoiseFilm, t.n, t.mean, t.m2, t.m3, t.film, filmBuffer.gpuMat, gBufferImages,
-                                          gBufferChannelCounts, gBufferDRFactors, gBuffers.size(), t.meanCorr,
-                                          t.discriminator, t.filmFiltered, filmFilteredBuffer.gpuMat, stream);
+            stat_denoiser::fillFilterCall<float3>(calls[nCalls++], rgbBufferCounts[DenoiseGroup], width, height, filterDSFactor,
+                                                  filterRadius, denoiseFilm, t.n, t.mean, t.m2, t.m3, t.film, filmBuffer.gpuMat,
+                                                  gBufferImages, gBufferChannelCounts, gBufferDRFactors, gBuffers.size(),
+                                                  t.meanCorr, t.discriminator, t.filmFiltered, filmFilteredBuffer.gpuMat, stream);
         }
+        const int nb = pipe.uploaded;
+        pipe.uploaded = 0;
+        if (nb <= 1) {
+            joinUploads();
+            for (int c = 0; c < nCalls; c++) calls[c].run();
+            return;
+        }
+        // transfer k brought rows [arrivalEdge(k), arrivalEdge(k + 1)): band k and its lower halo.  Pre-pass those rows,
+        // then filter band k (its upper halo came with the transfers before).
+        for (int k = 0; k < nb; k++) {
+            check(statmc_stream_wait_event(stream.handle(), pipe.arrived[k]));
+            for (int c = 0; c < nCalls; c++) calls[c].prepassRows(arrivalEdge(k, nb), arrivalEdge(k + 1, nb));
+            for (int c = 0; c < nCalls; c++) calls[c].filterRows(bandEdge(k, nb), bandEdge(k + 1, nb));
+            check(statmc_event_record(pipe.filtered[k], stream.handle()));
+        }
+        pipe.denoised = nb;
+        pipe.pendingJoin = 0;   // `stream` has waited for every band
     }
     // estimator.cpp:491-569.  The reference runs this loop on the CPU between rendering and
     // Upload(); here it is the device kernel, enqueued on the stream: call it after Upload().
     void CalculateMeanVars(bool rowNQuirk = true) {
+        joinUploads();
         if (floatBufferCounts[CalculateMeanVarianceGroup] > 0) {
             const Tables &t = floatTables[CalculateMeanVarianceGroup];
             stat_denoiser::calculateMeanVars<float>(floatBufferCounts[CalculateMeanVarianceGroup], width, height, t.n,
@@ -752,7 +876,14 @@ class Estimator {
                                                      t.filmM2, t.filmVar, stream, rowNQuirk);
         }
     }
-    void Synchronize() { stat_denoiser::synchronize(stream); }  // estimator.cpp:571-573
+    void Synchronize() {  // estimator.cpp:571-573
+        joinUploads();
+        stat_denoiser::synchronize(stream);
+        if (pipe.downloading) {
+            check(statmc_synchronize(pipe.down));
+            pipe.downloading = false;
+        }
+    }
     int deviceIndex() const { return device; }
 
     // Tile-local pooled moments of a device image -- per tileSize x tileSize tile and channel {count, mean, M2}, by one
@@ -761,6 +892,7 @@ class Estimator {
     // adaptive sampler or a progress display reads instead of the full-resolution images.  Returns a host image of
     // tiles_y rows and tiles_x * channels columns whose "pixels" are the three moments; blocks until it is there.
     HostImage TileMoments(const Buffer &b, int tileSize = 16) {
+        joinUploads();
         const int C = b.gpuMat.channels();
         const int tx = (width + tileSize - 1) / tileSize, ty = (height + tileSize - 1) / tileSize;
         DeviceImage dev(ty, tx * C, F32C3);
@@ -895,6 +1027,7 @@ class Estimator {
     size_t flushes() const { std::lock_guard<std::mutex> lk(acc.mu); return acc.nFlushes; }
     // Statistics images device -> host mats (dumps, OutputBufferSelection::Write); asynchronous.
     void DownloadStatistics() {
+        joinUploads();
         for (unsigned char i = 0; i < statTypeConfigs.nEnabled; i++)
             for (unsigned char j = 0; j < statTypeConfigs.configs[i].nBounces; j++)
                 for (auto *bufs : {&nBuffers, &meanBuffers, &m2Buffers, &m3Buffers, &filmBuffers, &filmM2Buffers})
@@ -929,6 +1062,58 @@ class Estimator {
   private:
     static void addUnique(std::vector<Buffer *> &v, Buffer *b) {
         if (std::find(v.begin(), v.end(), b) == v.end()) v.push_back(b);
+    }
+    // ---- the Upload / Denoise / Download pipeline (see Upload())
+    struct Pipeline {
+        void *up = nullptr, *down = nullptr;          // copy streams (non-blocking); the kernels run on `stream`
+        void *join = nullptr;
+        std::vector<void *> arrived, filtered;        // per band: uploaded / window-filtered
+        std::unordered_set<const Buffer *> outputs;   // what Denoise() writes: copied back band by band
+        int uploaded = 0, denoised = 0, pendingJoin = 0;
+        bool downloading = false;
+    } pipe;
+    int bandsRequested = 0;
+    // rows [bandEdge(k), bandEdge(k + 1)) are band k (edges at multiples of 8 rows: whole filter tiles, 16-byte aligned
+    // sub-images); transfer k carries rows [arrivalEdge(k), arrivalEdge(k + 1)) = the band shifted down by its halo
+    int bandEdge(int k, int n) const { return k >= n ? (int)height : (int)(((long long)height * k / n) & ~7LL); }
+    int arrivalEdge(int k, int n) const {
+        if (k <= 0) return 0;
+        if (k >= n) return (int)height;
+        return std::min((int)height, bandEdge(k, n) + (((int)filterRadius + 7) & ~7));
+    }
+    void ensurePipeline(int nb) {
+        if (!pipe.up) {
+            check(statmc_stream_create(&pipe.up));
+            check(statmc_stream_create(&pipe.down));
+            check(statmc_event_create(&pipe.join));
+            for (auto *bufs : {&meanCorrBuffers, &discriminatorBuffers, &filmFilteredBuffers})
+                for (auto &perType : *bufs)
+                    for (Buffer &b : perType) pipe.outputs.insert(&b);
+            pipe.outputs.insert(&filmFilteredBuffer);
+        }
+        while ((int)pipe.arrived.size() < nb) {
+            void *a = nullptr, *f = nullptr;
+            check(statmc_event_create(&a));
+            check(statmc_event_create(&f));
+            pipe.arrived.push_back(a);
+            pipe.filtered.push_back(f);
+        }
+    }
+    // everything enqueued on `stream` from here on sees the uploaded images
+    void joinUploads() {
+        for (int k = 0; k < pipe.pendingJoin; k++) check(statmc_stream_wait_event(stream.handle(), pipe.arrived[k]));
+        pipe.pendingJoin = 0;
+    }
+    void destroyPipeline() {
+        if (!pipe.up) return;
+        statmc_synchronize(pipe.up);
+        statmc_synchronize(pipe.down);
+        for (void *e : pipe.arrived) statmc_event_destroy(e);
+        for (void *e : pipe.filtered) statmc_event_destroy(e);
+        statmc_event_destroy(pipe.join);
+        statmc_stream_destroy(pipe.up);
+        statmc_stream_destroy(pipe.down);
+        pipe.up = pipe.down = nullptr;
     }
     Vector2f pixelFilterRadius{0.5f, 0.5f};   // estimator.h:313 `filter` (pbrt's default box filter)
     const float *filterTable = nullptr;       // film.cpp:56-65: the film's 16 x 16 table of filter weights

@@ -152,13 +152,27 @@ void apply_spec(const DeviceState &d, statmc::FilterArgs &k, const statmc_filter
     (void)a;
 }
 // pair-symmetric kernel: tile range, parts and the patch workspace of this launch
+// Window-sweep parts per tile are chosen for the whole local image, whatever output region a call asks for: the parts
+// decide how a pixel's sums are grouped, so a pixel filtered as part of a band of rows (Estimator's Upload / Denoise /
+// Download pipeline) gets the same bits as in a whole-image call.
+int parts_for_whole_image(const statmc::FilterArgs &k, int cus, bool sym) {
+    statmc::FilterArgs w = k;
+    w.rx0 = 0;
+    w.ry0 = 0;
+    w.rx1 = k.width;
+    w.ry1 = k.height;
+    if (!sym) return statmc::lds_filter_parts(w, cus);
+    statmc::sym_geometry(w);
+    return statmc::sym_filter_parts(w, cus);
+}
+
 // pair: filter<float> on the pair-symmetric kernel -- the workspace also holds the three RGB-shaped images every
 // launch packs its two buffers into (behind the patches, 16-byte aligned).
 int prepare_sym(const DeviceState &d, statmc::FilterArgs &k, const statmc_filter_args *a, bool pair = false) {
     k.sym.fx0 = a->film_x0;
     k.sym.fy0 = a->film_y0;
+    k.n_parts = parts_for_whole_image(k, d.cus, true);
     statmc::sym_geometry(k);
-    k.n_parts = statmc::sym_filter_parts(k, d.cus);
     float *ws = nullptr;
     const size_t patch_floats = (statmc::sym_patch_floats(k, k.n_parts) + 3) & ~(size_t)3;
     const size_t image_floats = pair ? (size_t)9 * k.width * k.height : 0;
@@ -324,6 +338,27 @@ int statmc_stream_destroy(void *stream) {
     HIP_TRY(hipStreamDestroy(S(stream)));
     return STATMC_OK;
 }
+int statmc_event_create(void **event) {
+    if (!event) return fail(STATMC_ERR_INVALID, "null event");
+    hipEvent_t e;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event = e;
+    return STATMC_OK;
+}
+int statmc_event_destroy(void *event) {
+    HIP_TRY(hipEventDestroy(static_cast<hipEvent_t>(event)));
+    return STATMC_OK;
+}
+int statmc_event_record(void *event, void *stream) {
+    if (!event) return fail(STATMC_ERR_INVALID, "null event");
+    HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), S(stream)));
+    return STATMC_OK;
+}
+int statmc_stream_wait_event(void *stream, void *event) {
+    if (!event) return fail(STATMC_ERR_INVALID, "null event");
+    HIP_TRY(hipStreamWaitEvent(S(stream), static_cast<hipEvent_t>(event), 0));
+    return STATMC_OK;
+}
 int statmc_synchronize(void *stream) {
     HIP_TRY(hipStreamSynchronize(S(stream)));
     return STATMC_OK;
@@ -412,7 +447,7 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
         if (statmc::sym_path_selected(k, 3)) {
             if (int rc = prepare_sym(dstate, k, a)) return rc;
         } else {
-            k.n_parts = statmc::lds_filter_parts(k, dstate.cus);
+            k.n_parts = parts_for_whole_image(k, dstate.cus, false);
             if (k.n_parts > 1) {
                 if (int rc = partial_workspace((size_t)k.n_parts * W * H * 4 * sizeof(float), a->stream, &k.partial)) return rc;
             }
@@ -436,7 +471,7 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
     if (statmc::fast_path_eligible(k, channels)) {
         if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
         statmc::set_feature_layout(k);
-        k.n_parts = statmc::lds_filter_parts(k, dstate.cus);
+        k.n_parts = parts_for_whole_image(k, dstate.cus, false);
     } else {
         k.n_parts = 1;
     }

@@ -7,7 +7,9 @@ sides, per-pixel / Welch dof, border policy, n < 2).  Given dumps written by the
 `<stem>-<spp>-{film,t0-b0-n,t0-b0-mean,t0-b0-m2,t0-b0-m3,t1-b0-film-mean,t2-b0-film-mean}.pfm` (inputs,
 scenes/render-for-ours.pbrt:24) and `<ref>-<spp>-{film-f,t0-b0-mean-corr,t0-b0-discriminator}.pfm` (its outputs) --
 this runs every spec x significance level through tools/bin/statmc_denoise --compare and prints the per-channel
-relative L2 table, best first.  BASELINE.json's bound is 1e-5 per channel.
+relative L2 table, best first.  BASELINE.json's bound is 1e-5 per channel.  Every candidate runs on the general
+kernel (--kernel general), whose sums are formed in one order for every spec: the differences in the table are the
+specs', not the kernels' (the fast kernels agree with it within 1e-6, which is more than rounding-twin specs differ by).
 
     python tools/fit_spec.py --stem dumps/scene --ref cuda/scene --spp 4,8,16 [--filtersd 10 --filterradius 20]
                              [--tquantiles table.txt]  [--quick]   (--quick: default dof / border / n<2 only)
@@ -46,7 +48,7 @@ def main():
     for sig in args.significance.split(","):
         for spec in variants(args.quick):
             cmd = [args.exe, "--stem", args.stem, "--spp", args.spp, "--filtersd", args.filtersd, "--filterradius",
-                   args.filterradius, "--significance", sig, "--spec", spec, "--compare", args.ref,
+                   args.filterradius, "--significance", sig, "--spec", spec, "--compare", args.ref, "--kernel", "general",
                    "--output", "film-f,t0-b0-mean-corr,t0-b0-discriminator"]
             if args.tquantiles:
                 cmd += ["--tquantiles", args.tquantiles]

@@ -37,6 +37,7 @@
 using namespace statmc;
 
 extern "C" int statmc_debug_force_filter_parts(int k);   // test hook of the library: window-sweep parts per tile
+extern "C" int statmc_debug_force_filter_variant(int v);  // test hook: 1 = the general kernel for every call
 
 static std::vector<std::string> split(const std::string &s) {
     std::vector<std::string> out;
@@ -115,7 +116,8 @@ static StatPathParams shippedConfig(const std::string &name) {
 int main(int argc, char **argv) {
     try {
         std::string stem, sppList, output = "film-f", config = "denoise", compareStem, tqFile, specText, gridText, devicesText;
-        int forceParts = 0;
+        int forceParts = 0, bands = 0;
+        std::string kernel;
         int significance = 0;
         StatPathParams params = shippedConfig("denoise");
         bool catalogue = false, warmup = false, configGiven = false;
@@ -145,6 +147,8 @@ int main(int argc, char **argv) {
             else if (a == "--grid") gridText = next();          // GXxGY: the denoise pass sharded over film blocks
             else if (a == "--devices") devicesText = next();    // devices the blocks go to, round robin (default: one)
             else if (a == "--parts") forceParts = std::stoi(next());
+            else if (a == "--kernel") kernel = next();   // "general": window_filter_generic for every call (one arithmetic for every spec)
+            else if (a == "--bands") bands = std::stoi(next());  // Upload / Denoise / Download as a pipeline of row bands (0 = automatic, 1 = off)
             else if (a == "--width") width = std::stoi(next());
             else if (a == "--height") height = std::stoi(next());
             else throw std::runtime_error("unknown option " + a);
@@ -198,6 +202,8 @@ int main(int argc, char **argv) {
         BufferRegistry reg(film);
         Estimator est(film, cfgs, params.filterSD, params.filterRadius, params.denoiseImage, params.acrr, params.smis, reg);
         est.AllocateBuffers(reg);
+        est.SetPipelineBands(bands);
+        std::cout << "pipeline bands: " << est.PipelineBands() << std::endl;
         if (!tqFile.empty()) {
             std::ifstream in(tqFile);
             if (!in) throw std::runtime_error("cannot open " + tqFile);
@@ -212,6 +218,8 @@ int main(int argc, char **argv) {
         stat_denoiser::setFilterSpec(stat_denoiser::parseFilterSpec(specText));
         const std::vector<std::string> outputs = split(output);
         if (forceParts > 0) statmc_debug_force_filter_parts(forceParts);
+        if (kernel == "general") statmc_debug_force_filter_variant(1);
+        else if (!kernel.empty()) throw std::runtime_error("--kernel general (or nothing)");
         std::unique_ptr<FilmShards> shards;
         if (!gridText.empty()) {
             const size_t x = gridText.find('x');
