@@ -1,0 +1,117 @@
+// statmc_bands.hpp -- Upload / Denoise / Download as a pipeline of row bands (shared by statmc::Estimator in
+// statmc_denoiser.hpp and by the cv::cuda adaptor in statmc_cv.hpp).
+//
+// The reference brackets Estimator::Upload(); Denoise(); Download(); Synchronize() as its "CUDA time"
+// (src/statistics/statpath.cpp:409-417; estimator.cpp:409-489, 571-573).  All four only enqueue work, so nothing
+// obliges them to run one after the other: the image is cut into bands of rows, a transfer carries one band plus the
+// r rows below it (its lower halo), the band is pre-passed and filtered as soon as that transfer has arrived and copied
+// back as soon as it is filtered.  Copies in, kernels and copies out sit on three streams ordered by events
+// (statmc_event_record / statmc_stream_wait_event); what is left after the last copy in is one band's filter.
+// The results are the same bits as with one stream: the pre-pass is per pixel, and the window filter forms a pixel's
+// sums in the same order for any output region (the library chooses its window-sweep parts for the whole image).
+#ifndef STATMC_BANDS_HPP
+#define STATMC_BANDS_HPP
+
+#include <algorithm>
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "statmc.h"
+
+namespace statmc {
+namespace bands {
+
+inline void ok(int rc, const char *what) {
+    if (rc != STATMC_OK) throw std::runtime_error(std::string(what) + ": " + statmc_last_error());
+}
+
+// halo rows of a transfer: the filter radius, rounded up to whole 8-row filter tiles
+inline int halo(int radius) { return (radius + 7) & ~7; }
+// Number of bands for an image of `height` rows: requested = 0 -> automatic (6 for 512 rows and more, else 1),
+// 1 -> off; never a band shorter than 64 rows or than its own halo.
+inline int count(int height, int radius, int requested) {
+    int n = requested == 0 ? (height >= 512 ? 6 : 1) : requested;
+    const int minRows = std::max(64, halo(radius));
+    return std::max(1, std::min(n, height / minRows));
+}
+// rows [edge(k), edge(k + 1)) are band k: edges at multiples of 8 rows (whole filter tiles, 16-byte aligned sub-images)
+inline int edge(int k, int n, int height) { return k >= n ? height : (int)(((long long)height * k / n) & ~7LL); }
+// transfer k carries rows [arrival(k), arrival(k + 1)): band k shifted down by its halo
+inline int arrival(int k, int n, int height, int radius) {
+    if (k <= 0) return 0;
+    if (k >= n) return height;
+    return std::min(height, edge(k, n, height) + halo(radius));
+}
+
+// rows [y0, y1) of an image as an image of its own (rows are contiguous: a band is a sub-array)
+inline statmc_image rows(const statmc_image &im, int y0, int y1) {
+    statmc_image r = im;
+    r.data = static_cast<char *>(im.data) + (size_t)y0 * im.step;
+    r.rows = y1 - y0;
+    return r;
+}
+// pre-pass of rows [y0, y1) of the buffers of `a` (per-pixel work: the band is passed as a shorter image)
+inline void prepassRows(const statmc_filter_args &a, int channels, int y0, int y1) {
+    const size_t nb = a.n_buffers;
+    std::vector<statmc_image> n(nb), mean(nb), m2(nb), m3(nb), mc(nb), dc(nb);
+    for (size_t b = 0; b < nb; b++) {
+        n[b] = rows(a.n[b], y0, y1); mean[b] = rows(a.mean[b], y0, y1); m2[b] = rows(a.m2[b], y0, y1);
+        m3[b] = rows(a.m3[b], y0, y1); mc[b] = rows(a.mean_corr[b], y0, y1); dc[b] = rows(a.discriminator[b], y0, y1);
+    }
+    statmc_filter_args p = a;
+    p.height = (uint16_t)(y1 - y0);
+    p.n = n.data(); p.mean = mean.data(); p.m2 = m2.data(); p.m3 = m3.data();
+    p.mean_corr = mc.data(); p.discriminator = dc.data();
+    ok(statmc_prepass(&p, channels), "statmc_prepass");
+}
+// window filter of rows [y0, y1) (the window still reads the whole image)
+inline void filterRows(const statmc_filter_args &a, int channels, int y0, int y1) {
+    statmc_filter_args f = a;
+    f.roi_x0 = 0; f.roi_x1 = a.width; f.roi_y0 = y0; f.roi_y1 = y1;
+    ok(statmc_window_filter(&f, channels), "statmc_window_filter");
+}
+
+// The two copy streams and the per-band events of one pipeline.
+struct Streams {
+    void *up = nullptr, *down = nullptr, *join = nullptr;
+    std::vector<void *> arrived, filtered;   // per band: transfer landed / band filtered
+    Streams() = default;
+    Streams(const Streams &) = delete;
+    Streams &operator=(const Streams &) = delete;
+    ~Streams() { destroy(); }
+    void ensure(int nb) {
+        if (!up) {
+            ok(statmc_stream_create(&up), "statmc_stream_create");
+            ok(statmc_stream_create(&down), "statmc_stream_create");
+            ok(statmc_event_create(&join), "statmc_event_create");
+        }
+        while ((int)arrived.size() < nb) {
+            void *a = nullptr, *f = nullptr;
+            ok(statmc_event_create(&a), "statmc_event_create");
+            ok(statmc_event_create(&f), "statmc_event_create");
+            arrived.push_back(a);
+            filtered.push_back(f);
+        }
+    }
+    void destroy() {
+        if (!up) return;
+        statmc_synchronize(up);
+        statmc_synchronize(down);
+        for (void *e : arrived) statmc_event_destroy(e);
+        for (void *e : filtered) statmc_event_destroy(e);
+        statmc_event_destroy(join);
+        statmc_stream_destroy(up);
+        statmc_stream_destroy(down);
+        up = down = join = nullptr;
+        arrived.clear();
+        filtered.clear();
+    }
+};
+
+}  // namespace bands
+}  // namespace statmc
+
+#endif  // STATMC_BANDS_HPP

@@ -29,7 +29,11 @@
 #include <string>
 #include <vector>
 
+#include <map>
+#include <set>
+
 #include "statmc.h"
+#include "statmc_bands.hpp"
 #include "statmc_pfm.hpp"
 
 typedef unsigned char uchar;
@@ -153,17 +157,61 @@ typedef Mat_<Vec3f> Mat3f;
 
 namespace cuda {
 
+// Upload / filter / download as a pipeline of row bands (statmc_bands.hpp): GpuMat::upload of an image only notes the
+// copy; filter<T> then issues the copies band by band on a copy stream and filters each band as soon as it has landed;
+// GpuMat::download of an image that filter wrote follows band by band on a second copy stream.  The reference's
+// Estimator::Upload / Denoise / Download / Synchronize (estimator.cpp:409-489) run unchanged and overlap.  Anything
+// else that touches the stream flushes the noted copies first.  STATMC_CV_BANDS=1 in the environment switches the
+// pipeline off (0 / unset: automatic, n: n bands).
+namespace detail {
+struct PendingUpload {
+    uchar *dst;
+    Mat src;          // keeps the host image alive until the copy has been enqueued and completed
+    size_t rowBytes;
+    int rows;
+};
+struct StreamState : statmc::bands::Streams {
+    std::vector<PendingUpload> pending;     // noted by GpuMat::upload, not yet enqueued
+    std::vector<Mat> inflight;              // host images of enqueued band copies (released at synchronisation)
+    std::set<const uchar *> outputs;        // images the last banded filter call wrote
+    int outBands = 0, outHeight = 0;
+    bool downloading = false;
+};
+inline int requestedBands() {
+    static const int v = [] { const char *e = std::getenv("STATMC_CV_BANDS"); return e ? std::atoi(e) : 0; }();
+    return v;
+}
+}  // namespace detail
+
 class Stream {   // one asynchronous queue (estimator.h:326)
   public:
-    Stream() {
+    Stream() : st_(std::make_shared<detail::StreamState>()) {
         void *s = nullptr;
         if (statmc_stream_create(&s) == STATMC_OK) h_ = std::shared_ptr<void>(s, [](void *q) { statmc_stream_destroy(q); });
     }
     void *handle() const { return h_.get(); }
-    void waitForCompletion() { statmcCheck(statmc_synchronize(h_.get()), "Stream::waitForCompletion"); }
+    detail::StreamState &state() const { return *st_; }
+    // the copies GpuMat::upload has noted go onto the stream itself
+    void flushUploads() {
+        for (auto &p : st_->pending) {
+            statmcCheck(statmc_upload(p.dst, p.src.ptr(), p.rowBytes * p.rows, h_.get()), "GpuMat::upload");
+            st_->inflight.push_back(p.src);
+        }
+        st_->pending.clear();
+    }
+    void waitForCompletion() {
+        flushUploads();
+        statmcCheck(statmc_synchronize(h_.get()), "Stream::waitForCompletion");
+        if (st_->downloading) {
+            statmcCheck(statmc_synchronize(st_->down), "Stream::waitForCompletion");
+            st_->downloading = false;
+        }
+        st_->inflight.clear();
+    }
 
   private:
     std::shared_ptr<void> h_;
+    std::shared_ptr<detail::StreamState> st_;
 };
 
 template <typename T>
@@ -199,13 +247,27 @@ class GpuMat {
         if (n <= 65536) {
             shadow_ = std::make_shared<std::vector<uchar>>(m.ptr(), m.ptr() + n);
             if (n) statmcCheck(statmc_upload(data, shadow_->data(), n, s.handle()), "GpuMat::upload");
-        } else {
+        } else {   // an image: noted, enqueued by filter<T> band by band (or by whatever touches the stream next)
             shadow_.reset();
-            statmcCheck(statmc_upload(data, m.ptr(), n, s.handle()), "GpuMat::upload");
+            auto &pending = s.state().pending;
+            for (auto &p : pending)
+                if (p.dst == data) { p.src = m; return; }
+            pending.push_back(detail::PendingUpload{data, m, step, rows});
         }
     }
     void download(Mat &m, Stream &s) const {
         m.create(rows, cols, type_);
+        detail::StreamState &st = s.state();
+        if (st.outBands > 1 && rows == st.outHeight && st.outputs.count(data)) {   // behind each band's filter
+            for (int k = 0; k < st.outBands; k++) {
+                const int y0 = statmc::bands::edge(k, st.outBands, rows), y1 = statmc::bands::edge(k + 1, st.outBands, rows);
+                statmcCheck(statmc_stream_wait_event(st.down, st.filtered[k]), "GpuMat::download");
+                statmcCheck(statmc_download(m.ptr(y0), data + (size_t)y0 * step, (size_t)(y1 - y0) * step, st.down), "GpuMat::download");
+            }
+            st.downloading = true;
+            return;
+        }
+        s.flushUploads();
         statmcCheck(statmc_download(m.ptr(), data, step * rows, s.handle()), "GpuMat::download");
     }
     template <typename T> operator PtrStepSz<T>() const { return PtrStepSz<T>{reinterpret_cast<T *>(data), step, cols, rows}; }
@@ -224,7 +286,7 @@ class GpuMat {
 namespace stat_denoiser {
 
 inline void setup() { statmcCheck(statmc_setup(0), "stat_denoiser::setup"); }
-inline void synchronize(Stream &s) { statmcCheck(statmc_synchronize(s.handle()), "stat_denoiser::synchronize"); }
+inline void synchronize(Stream &s) { s.waitForCompletion(); }
 
 namespace detail {
 // a table of n PtrStepSzb entries (uploaded by the caller, read back from the shadow) -> descriptors
@@ -282,7 +344,45 @@ void filter(uchar nBuffers, ushort width, ushort height, float filterDSFactor, u
     a.mean_corr = mc.data(); a.discriminator = dc.data(); a.film_filtered = ff.data();
     a.film_filtered_buffer = filmFilteredBuffer.desc();
     a.stream = stream.handle();
-    statmcCheck(C == 3 ? statmc_filter_f32x3(&a) : statmc_filter_f32(&a), "stat_denoiser::filter");
+    cuda::detail::StreamState &st = stream.state();
+    for (const auto *tab : {&mc, &dc, &ff})
+        for (const auto &im : *tab) st.outputs.erase(static_cast<const uchar *>(im.data));
+    st.outputs.erase(filmFilteredBuffer.data);
+    namespace B = statmc::bands;
+    const int nb = B::count(height, filterRadius, cuda::detail::requestedBands());
+    bool banded = nb > 1 && !st.pending.empty();
+    for (const auto &p : st.pending) banded = banded && p.rows == height;
+    if (!banded) {
+        stream.flushUploads();
+        statmcCheck(C == 3 ? statmc_filter_f32x3(&a) : statmc_filter_f32(&a), "stat_denoiser::filter");
+        return;
+    }
+    // the noted uploads travel band by band on the copy stream (a transfer = a band + the r rows below it) ...
+    st.ensure(nb);
+    statmcCheck(statmc_event_record(st.join, stream.handle()), "stat_denoiser::filter");   // earlier work may still read the images
+    statmcCheck(statmc_stream_wait_event(st.up, st.join), "stat_denoiser::filter");
+    for (int k = 0; k < nb; k++) {
+        const int y0 = B::arrival(k, nb, height, filterRadius), y1 = B::arrival(k + 1, nb, height, filterRadius);
+        for (const auto &p : st.pending)
+            statmcCheck(statmc_upload(p.dst + (size_t)y0 * p.rowBytes, p.src.ptr() + (size_t)y0 * p.rowBytes,
+                                      (size_t)(y1 - y0) * p.rowBytes, st.up), "GpuMat::upload");
+        statmcCheck(statmc_event_record(st.arrived[k], st.up), "stat_denoiser::filter");
+    }
+    for (auto &p : st.pending) st.inflight.push_back(p.src);
+    st.pending.clear();
+    // ... and every band is pre-passed and filtered as soon as its transfer has landed
+    for (int k = 0; k < nb; k++) {
+        statmcCheck(statmc_stream_wait_event(stream.handle(), st.arrived[k]), "stat_denoiser::filter");
+        B::prepassRows(a, C, B::arrival(k, nb, height, filterRadius), B::arrival(k + 1, nb, height, filterRadius));
+        B::filterRows(a, C, B::edge(k, nb, height), B::edge(k + 1, nb, height));
+        statmcCheck(statmc_event_record(st.filtered[k], stream.handle()), "stat_denoiser::filter");
+    }
+    st.outputs.clear();
+    for (const auto *tab : {&mc, &dc, &ff})
+        for (const auto &im : *tab) st.outputs.insert(static_cast<const uchar *>(im.data));
+    st.outputs.insert(filmFilteredBuffer.data);
+    st.outBands = nb;
+    st.outHeight = height;
 }
 
 // The dormant GPU form of Estimator::CalculateMeanVars (the call at estimator.cpp:501-521 is commented out in favour of
@@ -291,6 +391,7 @@ template <typename T>
 void calculateMeanVars(uchar nBuffers, ushort width, ushort height, const GpuMat &nPtrs, const GpuMat &filmM2Ptrs,
                        const GpuMat &filmVarPtrs, Stream &stream) {
     constexpr int C = sizeof(T) == 12 ? 3 : 1;
+    stream.flushUploads();
     const auto n = detail::table(nPtrs, nBuffers, 1), m2 = detail::table(filmM2Ptrs, nBuffers, C), var = detail::table(filmVarPtrs, nBuffers, C);
     statmcCheck(statmc_calculate_mean_vars(nBuffers, width, height, C, n.data(), m2.data(), var.data(), 0, stream.handle()),
                 "stat_denoiser::calculateMeanVars");

@@ -44,6 +44,7 @@
 #include <vector>
 
 #include "statmc.h"
+#include "statmc_bands.hpp"
 #include "statmc_pfm.hpp"
 
 namespace statmc {
@@ -209,32 +210,8 @@ struct FilterCall {
     std::vector<statmc_image> n, mean, m2, m3, film, g, mc, dc, ff;
     statmc_filter_args a;
     int channels = 3;
-    // rows [y0, y1) of an image as an image of its own (rows are contiguous: a band is a sub-array)
-    static statmc_image rows(const statmc_image &im, int y0, int y1) {
-        statmc_image r = im;
-        r.data = static_cast<char *>(im.data) + (size_t)y0 * im.step;
-        r.rows = y1 - y0;
-        return r;
-    }
-    // pre-pass of rows [y0, y1) only (per-pixel work: the band is passed as a shorter image)
-    void prepassRows(int y0, int y1) const {
-        std::vector<statmc_image> bn, bmean, bm2, bm3, bmc, bdc;
-        for (size_t b = 0; b < n.size(); b++) {
-            bn.push_back(rows(n[b], y0, y1)); bmean.push_back(rows(mean[b], y0, y1)); bm2.push_back(rows(m2[b], y0, y1));
-            bm3.push_back(rows(m3[b], y0, y1)); bmc.push_back(rows(mc[b], y0, y1)); bdc.push_back(rows(dc[b], y0, y1));
-        }
-        statmc_filter_args p = a;
-        p.height = (uint16_t)(y1 - y0);
-        p.n = bn.data(); p.mean = bmean.data(); p.m2 = bm2.data(); p.m3 = bm3.data();
-        p.mean_corr = bmc.data(); p.discriminator = bdc.data();
-        check(statmc_prepass(&p, channels));
-    }
-    // window filter of rows [y0, y1) (the window still reads the whole image)
-    void filterRows(int y0, int y1) const {
-        statmc_filter_args f = a;
-        f.roi_x0 = 0; f.roi_x1 = a.width; f.roi_y0 = y0; f.roi_y1 = y1;
-        check(statmc_window_filter(&f, channels));
-    }
+    void prepassRows(int y0, int y1) const { bands::prepassRows(a, channels, y0, y1); }   // rows [y0, y1) only
+    void filterRows(int y0, int y1) const { bands::filterRows(a, channels, y0, y1); }     // output rows [y0, y1)
     void run() const { check(channels == 3 ? statmc_filter_f32x3(&a) : statmc_filter_f32(&a)); }
 };
 
@@ -624,7 +601,6 @@ class Estimator {
         }
         if (allocateDevice) stat_denoiser::setup(device);
     }
-    ~Estimator() { destroyPipeline(); }
     Estimator(const Estimator &) = delete;
     Estimator &operator=(const Estimator &) = delete;
 
@@ -774,9 +750,7 @@ class Estimator {
     void SetPipelineBands(int n) { bandsRequested = n; }   // 0 = automatic, 1 = off
     int PipelineBands() const {
         if (!allocateDevice || acc.dry) return 1;
-        int n = bandsRequested == 0 ? (height >= 512 ? 6 : 1) : bandsRequested;
-        const int minRows = std::max(64, ((int)filterRadius + 7) & ~7);   // a band holds the halo of the band above it
-        return std::max(1, std::min(n, (int)height / minRows));
+        return bands::count(height, filterRadius, bandsRequested);
     }
     void Upload() {  // estimator.cpp:409-416
         if (acc.enabled) FlushSamples();  // statistics are produced on the device: only the rest moves
@@ -1064,56 +1038,27 @@ class Estimator {
         if (std::find(v.begin(), v.end(), b) == v.end()) v.push_back(b);
     }
     // ---- the Upload / Denoise / Download pipeline (see Upload())
-    struct Pipeline {
-        void *up = nullptr, *down = nullptr;          // copy streams (non-blocking); the kernels run on `stream`
-        void *join = nullptr;
-        std::vector<void *> arrived, filtered;        // per band: uploaded / window-filtered
+    struct Pipeline : bands::Streams {                // copy streams (non-blocking) + per-band events; the kernels run on `stream`
         std::unordered_set<const Buffer *> outputs;   // what Denoise() writes: copied back band by band
         int uploaded = 0, denoised = 0, pendingJoin = 0;
         bool downloading = false;
     } pipe;
     int bandsRequested = 0;
-    // rows [bandEdge(k), bandEdge(k + 1)) are band k (edges at multiples of 8 rows: whole filter tiles, 16-byte aligned
-    // sub-images); transfer k carries rows [arrivalEdge(k), arrivalEdge(k + 1)) = the band shifted down by its halo
-    int bandEdge(int k, int n) const { return k >= n ? (int)height : (int)(((long long)height * k / n) & ~7LL); }
-    int arrivalEdge(int k, int n) const {
-        if (k <= 0) return 0;
-        if (k >= n) return (int)height;
-        return std::min((int)height, bandEdge(k, n) + (((int)filterRadius + 7) & ~7));
-    }
+    int bandEdge(int k, int n) const { return bands::edge(k, n, height); }
+    int arrivalEdge(int k, int n) const { return bands::arrival(k, n, height, filterRadius); }
     void ensurePipeline(int nb) {
         if (!pipe.up) {
-            check(statmc_stream_create(&pipe.up));
-            check(statmc_stream_create(&pipe.down));
-            check(statmc_event_create(&pipe.join));
             for (auto *bufs : {&meanCorrBuffers, &discriminatorBuffers, &filmFilteredBuffers})
                 for (auto &perType : *bufs)
                     for (Buffer &b : perType) pipe.outputs.insert(&b);
             pipe.outputs.insert(&filmFilteredBuffer);
         }
-        while ((int)pipe.arrived.size() < nb) {
-            void *a = nullptr, *f = nullptr;
-            check(statmc_event_create(&a));
-            check(statmc_event_create(&f));
-            pipe.arrived.push_back(a);
-            pipe.filtered.push_back(f);
-        }
+        pipe.ensure(nb);
     }
     // everything enqueued on `stream` from here on sees the uploaded images
     void joinUploads() {
         for (int k = 0; k < pipe.pendingJoin; k++) check(statmc_stream_wait_event(stream.handle(), pipe.arrived[k]));
         pipe.pendingJoin = 0;
-    }
-    void destroyPipeline() {
-        if (!pipe.up) return;
-        statmc_synchronize(pipe.up);
-        statmc_synchronize(pipe.down);
-        for (void *e : pipe.arrived) statmc_event_destroy(e);
-        for (void *e : pipe.filtered) statmc_event_destroy(e);
-        statmc_event_destroy(pipe.join);
-        statmc_stream_destroy(pipe.up);
-        statmc_stream_destroy(pipe.down);
-        pipe.up = pipe.down = nullptr;
     }
     Vector2f pixelFilterRadius{0.5f, 0.5f};   // estimator.h:313 `filter` (pbrt's default box filter)
     const float *filterTable = nullptr;       // film.cpp:56-65: the film's 16 x 16 table of filter weights

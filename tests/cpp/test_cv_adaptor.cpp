@@ -3,6 +3,7 @@
 // argument list of src/statistics/estimator.cpp:465-487, PFM round trip in BGR order.  Prints the result so that the
 // Python test can compare it with the library called directly.
 //   test_cv_adaptor <stem> <spp> <out.pfm>      (dump files as written by tests: film, t0-b0-{n,mean,m2,m3}, t1/t2-b0-film-mean)
+#include <chrono>
 #include <cstdio>
 #include <iostream>
 
@@ -89,6 +90,26 @@ int main(int argc, char **argv) {
                                                 film.gpuMat, gPtrs, gCounts, gDR, gBuffers.size(), mcP, dcP, ffP, filmF.gpuMat, stream);
         filmF.download(stream);
         cv::cuda::stat_denoiser::synchronize(stream);
+        // the same bracket again, timed: Upload + Denoise + Download + Synchronize in the reference's call order
+        // (statpath.cpp:409-417); with STATMC_CV_BANDS unset the adaptor runs it as a pipeline of row bands
+        long long best_ns = -1;
+        for (int it = 0; it < 4; it++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (Buffer *bptr : {&film, &n, &mean, &m2, &m3, &normal, &albedo}) bptr->upload(stream);
+            cv::cuda::stat_denoiser::filter<float3>(1, (ushort)w, (ushort)h, -.5f / (sd * sd), 20, true, nP, meanP, m2P, m3P, filmP,
+                                                    film.gpuMat, gPtrs, gCounts, gDR, gBuffers.size(), mcP, dcP, ffP, filmF.gpuMat, stream);
+            filmF.download(stream);
+            meanCorr.download(stream);
+            cv::cuda::stat_denoiser::synchronize(stream);
+            const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (best_ns < 0 || ns < best_ns) best_ns = ns;
+        }
+        std::printf("bracket_ns %lld bands %d\n", best_ns, stream.state().outBands);
+        if (argc > 4) {   // the corrected means of the last iteration, for a bit-for-bit comparison between band counts
+            Mat mcOut;
+            cv::cvtColor(meanCorr.mat, mcOut, cv::COLOR_RGB2BGR);
+            cv::imwrite(argv[4], mcOut);
+        }
 
         Mat out;   // OutputBufferSelection::Write, buffer.cpp:40-53
         cv::cvtColor(filmF.mat, out, cv::COLOR_RGB2BGR);

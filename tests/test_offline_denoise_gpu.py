@@ -149,7 +149,7 @@ def test_cv_adaptor_matches_the_library(gpu, tmp_path):
     out_path = str(tmp_path / "film-f.pfm")
     out = subprocess.run([build.CV_ADAPTOR_BIN, stem, str(spp), out_path], capture_output=True, text=True)
     assert out.returncode == 0, (out.returncode, out.stderr)
-    assert out.stdout.startswith("ok 40x28 dumps 7")
+    assert "ok 40x28 dumps 7" in out.stdout and "bands 0" in out.stdout       # too small to cut into bands
     film_f = pfm.read_pfm(out_path)
     for c in range(3):
         assert rel_l2(film_f[..., c], g["film_f"][..., c]) <= 1e-5
@@ -204,3 +204,36 @@ def test_band_pipeline_gives_the_same_bits(gpu, tmp_path, config, W, H):
     for bands, (used, imgs) in results.items():
         for n, v in imgs.items():
             assert np.array_equal(v, base[n]), (bands, used, n)
+
+
+def test_cv_adaptor_band_pipeline_same_bits(gpu, tmp_path):
+    """The reference's call order -- Buffer::upload x 7, filter<float3>, Buffer::download, synchronize -- through
+    include/statmc_cv.hpp: the adaptor notes the uploads, filter<T> issues them band by band and filters each band as
+    it lands, the downloads follow band by band.  Same bits as the one-stream order (STATMC_CV_BANDS=1), for the
+    automatic band count and a forced one."""
+    import re
+    import torch
+    from statmc_amd import build, film, pfm, synthetic
+    build.build_tools()
+    W, H, spp = 640, 600, 8
+    scene = synthetic.Scene(W, H, seed=4, device=torch.device("cuda:0"))
+    fs = film.FilmStats(W, H, torch.device("cuda:0"))
+    fs.accumulate(scene.samples(spp, seed=6, features=("radiance", "normal", "albedo")))
+    torch.cuda.synchronize()
+    rad = fs.state["radiance"]
+    stem = str(tmp_path / "scene")
+    for name, img in {"film": rad["film_mean"], "t0-b0-n": rad["n"], "t0-b0-mean": rad["mean"], "t0-b0-m2": rad["m2"], "t0-b0-m3": rad["m3"],
+                      "t1-b0-film-mean": fs.g_buffer("normal"), "t2-b0-film-mean": fs.g_buffer("albedo")}.items():
+        pfm.write_pfm("%s-%d-%s.pfm" % (stem, spp, name), img.cpu().numpy())
+    outs = {}
+    for bands in ("1", "0", "3"):
+        f, m = str(tmp_path / ("film-f-%s.pfm" % bands)), str(tmp_path / ("mean-corr-%s.pfm" % bands))
+        out = subprocess.run([build.CV_ADAPTOR_BIN, stem, str(spp), f, m], capture_output=True, text=True,
+                             env=dict(os.environ, STATMC_CV_BANDS=bands))
+        assert out.returncode == 0, (out.returncode, out.stderr)
+        used = int(re.search(r"bracket_ns \d+ bands (\d+)", out.stdout).group(1))
+        assert used == {"1": 0, "0": 6, "3": 3}[bands], out.stdout
+        outs[bands] = (pfm.read_pfm(f), pfm.read_pfm(m))
+    assert np.isfinite(outs["1"][0]).all() and float(np.abs(outs["1"][0]).max()) > 0
+    for bands in ("0", "3"):
+        assert np.array_equal(outs[bands][0], outs["1"][0]) and np.array_equal(outs[bands][1], outs["1"][1]), bands
