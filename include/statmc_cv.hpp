@@ -348,6 +348,10 @@ void filter(uchar nBuffers, ushort width, ushort height, float filterDSFactor, u
     for (const auto *tab : {&mc, &dc, &ff})
         for (const auto &im : *tab) st.outputs.erase(static_cast<const uchar *>(im.data));
     st.outputs.erase(filmFilteredBuffer.data);
+    if (st.downloading) {   // band copies out of an earlier download still read the images this call rewrites
+        statmcCheck(statmc_event_record(st.join, st.down), "stat_denoiser::filter");
+        statmcCheck(statmc_stream_wait_event(stream.handle(), st.join), "stat_denoiser::filter");
+    }
     namespace B = statmc::bands;
     const int nb = B::count(height, filterRadius, cuda::detail::requestedBands());
     bool banded = nb > 1 && !st.pending.empty();

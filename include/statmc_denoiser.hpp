@@ -817,6 +817,10 @@ class Estimator {
                                                   gBufferImages, gBufferChannelCounts, gBufferDRFactors, gBuffers.size(),
                                                   t.meanCorr, t.discriminator, t.filmFiltered, filmFilteredBuffer.gpuMat, stream);
         }
+        if (pipe.downloading) {   // copies out of an earlier Download() still read the images this call rewrites
+            check(statmc_event_record(pipe.join, pipe.down));
+            check(statmc_stream_wait_event(stream.handle(), pipe.join));
+        }
         const int nb = pipe.uploaded;
         pipe.uploaded = 0;
         if (nb <= 1) {

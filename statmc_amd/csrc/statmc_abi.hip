@@ -335,6 +335,21 @@ int statmc_stream_create(void **stream) {
     return STATMC_OK;
 }
 int statmc_stream_destroy(void *stream) {
+    // the stream's filter workspace goes with it (a later stream may get the same handle)
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto it = g_ws.begin(); it != g_ws.end();) {
+            if (it->first.stream == stream && stream != nullptr) {
+                if (it->second.ptr) {
+                    (void)hipStreamSynchronize(S(stream));
+                    (void)hipFree(it->second.ptr);
+                }
+                it = g_ws.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
     HIP_TRY(hipStreamDestroy(S(stream)));
     return STATMC_OK;
 }

@@ -85,7 +85,7 @@ struct GBufferDesc {
 struct FilterArgs {
     const float *mean_corr, *disc, *colour;
     float *out;
-    // filter spec (statmc_filter_spec): the LDS kernels implement the all-default case only
+    // filter spec (statmc_filter_spec): every field but dof = Welch has an LDS kernel (statmc_filter.hip, statmc_filter_sym.hip)
     int gate, channel_rule, dof, border;
     const int32_t *n;            // Welch mode: sample counts
     const float *tq;             // Welch mode: this device's quantile table (4096 entries)
