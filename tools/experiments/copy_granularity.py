@@ -59,3 +59,6 @@ for nb in (4, 6, 8):
             assert rc == 0, rc
     ms = timed(run2d)
     print("%2d bands, 1 + one 2-D copy each: %.3f ms  (%.1f GB/s)" % (nb, ms, total / ms / 1e6), flush=True)
+
+# (hipMemcpyBatchAsync would take the seven pieces of a band in one call, but the HIP runtime PyTorch 2.10 ships --
+# the one a process that imports torch has loaded -- does not export it: not an option for the library.)
