@@ -874,15 +874,17 @@ void sym_geometry(FilterArgs &a) {
 }
 int sym_tiles(const FilterArgs &a) { return a.sym.ntx * a.sym.nty; }
 
-// Parts per tile: the grid runs one workgroup per CU, so its makespan is ceil(items / CUs) rounds of 21 / parts steps
-// each, plus what a further item costs: 0.95 steps before its first and after its last step (stamps_sym.py), 7 more
-// accumulator rows to flush and to gather in the combine -- fitted at 2.5 steps from runs with 1 .. 4 parts.
+// Parts per tile: the grid runs one workgroup per CU, so its makespan is ceil(items / CUs) rounds of the longest part,
+// ceil(21 / parts) steps, plus what a further item costs: 0.95 steps before its first and after its last step
+// (stamps_sym.py), 7 more accumulator rows to flush and to gather in the combine.  Fitted at 1.35 steps on 1080p runs
+// with 1 .. 4 parts (1.46 / 1.61 / 1.62 / 1.92 ms); the same model orders the parts of a 1920 x 135 / 270 / 540 block
+// (tools/experiments/block_parts.py: 3 parts best for all three).
 int sym_choose_parts(int tiles, int n_cus) {
     int best = 1;
     double best_cost = 1e30;
     for (int k = 1; k <= 8; k++) {
         const double rounds = (double)(((long long)tiles * k + n_cus - 1) / n_cus);
-        const double cost = rounds * ((double)sym::kSteps / k + 2.5);
+        const double cost = rounds * ((double)((sym::kSteps + k - 1) / k) + 1.35);
         if (cost < best_cost * 0.98) {
             best_cost = cost;
             best = k;
