@@ -5,7 +5,7 @@
 // (src/statistics/statpath.cpp:409-417; estimator.cpp:409-489, 571-573).  All four only enqueue work, so nothing
 // obliges them to run one after the other: the image is cut into bands of rows, a transfer carries one band plus the
 // r rows below it (its lower halo), the band is pre-passed and filtered as soon as that transfer has arrived and copied
-// back as soon as it is filtered.  Copies in, kernels and copies out sit on three streams ordered by events
+// back as soon as it is filtered.  Copies in (two queues), kernels and copies out sit on their own streams, ordered by events
 // (statmc_event_record / statmc_stream_wait_event); what is left after the last copy in is one band's filter.
 // The results are the same bits as with one stream: the pre-pass is per pixel, and the window filter forms a pixel's
 // sums in the same order for any output region (the library chooses its window-sweep parts for the whole image).
@@ -74,10 +74,52 @@ inline void filterRows(const statmc_filter_args &a, int channels, int y0, int y1
     ok(statmc_window_filter(&f, channels), "statmc_window_filter");
 }
 
-// The two copy streams and the per-band events of one pipeline.
+// The copy streams and the per-band events of one pipeline.  Copies in are dealt over TWO streams: behind one queue
+// every copy pays ~9.5 us between its predecessor's completion and its own start (42 pieces of the 157.6 MB of a
+// 1080p upload: 3.21 ms instead of 2.88 for 7 whole images); on two queues the gaps of one hide behind the other's
+// transfers (2.77 ms, 56.8 GB/s -- tools/experiments/copy_granularity.py).
 struct Streams {
-    void *up = nullptr, *down = nullptr, *join = nullptr;
-    std::vector<void *> arrived, filtered;   // per band: transfer landed / band filtered
+    void *up = nullptr, *up2 = nullptr, *down = nullptr, *join = nullptr;
+    std::vector<void *> arrived, arrived2, filtered;   // per band: transfer landed (per copy stream) / band filtered
+    // Which of the two copy streams carries each image of a transfer: bytes balanced (largest first onto the lighter
+    // queue), so that both queues finish a transfer together.
+    static std::vector<int> deal(const std::vector<size_t> &bytes, int queues = 2) {
+        if (queues < 2) return std::vector<int>(bytes.size(), 0);
+        std::vector<size_t> order(bytes.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return bytes[a] > bytes[b]; });
+        std::vector<int> q(bytes.size(), 0);
+        size_t load[2] = {0, 0};
+        for (size_t i : order) {
+            const int s = load[1] < load[0] ? 1 : 0;
+            q[i] = s;
+            load[s] += bytes[i];
+        }
+        return q;
+    }
+    void *upStream(int q) const { return q ? up2 : up; }
+    // transfer k starts on both queues only when transfer k - 1 has landed on both: the queues stay in step, a band is
+    // complete when it would have been on one queue (minus the gaps)
+    void beginTransfer(int k) const {
+        if (k <= 0) return;
+        ok(statmc_stream_wait_event(up, arrived2[k - 1]), "statmc_stream_wait_event");
+        ok(statmc_stream_wait_event(up2, arrived[k - 1]), "statmc_stream_wait_event");
+    }
+    // enqueue on `stream`: wait until transfer k has landed
+    void waitArrived(void *stream, int k) const {
+        ok(statmc_stream_wait_event(stream, arrived[k]), "statmc_stream_wait_event");
+        ok(statmc_stream_wait_event(stream, arrived2[k]), "statmc_stream_wait_event");
+    }
+    // the copies of a new round must not overtake what `stream` has been given so far
+    void beginUploads(void *stream) const {
+        ok(statmc_event_record(join, stream), "statmc_event_record");
+        ok(statmc_stream_wait_event(up, join), "statmc_stream_wait_event");
+        ok(statmc_stream_wait_event(up2, join), "statmc_stream_wait_event");
+    }
+    void markArrived(int k) const {
+        ok(statmc_event_record(arrived[k], up), "statmc_event_record");
+        ok(statmc_event_record(arrived2[k], up2), "statmc_event_record");
+    }
     Streams() = default;
     Streams(const Streams &) = delete;
     Streams &operator=(const Streams &) = delete;
@@ -85,28 +127,35 @@ struct Streams {
     void ensure(int nb) {
         if (!up) {
             ok(statmc_stream_create(&up), "statmc_stream_create");
+            ok(statmc_stream_create(&up2), "statmc_stream_create");
             ok(statmc_stream_create(&down), "statmc_stream_create");
             ok(statmc_event_create(&join), "statmc_event_create");
         }
         while ((int)arrived.size() < nb) {
-            void *a = nullptr, *f = nullptr;
+            void *a = nullptr, *a2 = nullptr, *f = nullptr;
             ok(statmc_event_create(&a), "statmc_event_create");
+            ok(statmc_event_create(&a2), "statmc_event_create");
             ok(statmc_event_create(&f), "statmc_event_create");
             arrived.push_back(a);
+            arrived2.push_back(a2);
             filtered.push_back(f);
         }
     }
     void destroy() {
         if (!up) return;
         statmc_synchronize(up);
+        statmc_synchronize(up2);
         statmc_synchronize(down);
         for (void *e : arrived) statmc_event_destroy(e);
+        for (void *e : arrived2) statmc_event_destroy(e);
         for (void *e : filtered) statmc_event_destroy(e);
         statmc_event_destroy(join);
         statmc_stream_destroy(up);
+        statmc_stream_destroy(up2);
         statmc_stream_destroy(down);
-        up = down = join = nullptr;
+        up = up2 = down = join = nullptr;
         arrived.clear();
+        arrived2.clear();
         filtered.clear();
     }
 };

@@ -363,20 +363,30 @@ void filter(uchar nBuffers, ushort width, ushort height, float filterDSFactor, u
     }
     // the noted uploads travel band by band on the copy stream (a transfer = a band + the r rows below it) ...
     st.ensure(nb);
-    statmcCheck(statmc_event_record(st.join, stream.handle()), "stat_denoiser::filter");   // earlier work may still read the images
-    statmcCheck(statmc_stream_wait_event(st.up, st.join), "stat_denoiser::filter");
+    st.beginUploads(stream.handle());   // earlier work may still read the images
+    std::vector<size_t> rowBytes;
+    for (const auto &p : st.pending) rowBytes.push_back(p.rowBytes);
+    // One copy queue by default: with two (STATMC_CV_UPLOAD_QUEUES=2) this call order runs at 4.0 instead of 4.35 ms
+    // at 1080p in three processes out of four and at 5.8 - 7.0 ms in the fourth (the two queues end up serialised behind
+    // each other for the life of the process; tools/experiments/time_cv_bracket.py).  statmc::Estimator, which issues
+    // its copies from Upload() and has the device's default stream for the kernels, has not shown that in a hundred runs.
+    static const int nQueues = [] { const char *e = std::getenv("STATMC_CV_UPLOAD_QUEUES"); return e ? std::atoi(e) : 1; }();
+    const std::vector<int> queue = B::Streams::deal(rowBytes, nQueues);
     for (int k = 0; k < nb; k++) {
         const int y0 = B::arrival(k, nb, height, filterRadius), y1 = B::arrival(k + 1, nb, height, filterRadius);
-        for (const auto &p : st.pending)
+        st.beginTransfer(k);
+        for (size_t i = 0; i < st.pending.size(); i++) {
+            const auto &p = st.pending[i];
             statmcCheck(statmc_upload(p.dst + (size_t)y0 * p.rowBytes, p.src.ptr() + (size_t)y0 * p.rowBytes,
-                                      (size_t)(y1 - y0) * p.rowBytes, st.up), "GpuMat::upload");
-        statmcCheck(statmc_event_record(st.arrived[k], st.up), "stat_denoiser::filter");
+                                      (size_t)(y1 - y0) * p.rowBytes, st.upStream(queue[i])), "GpuMat::upload");
+        }
+        st.markArrived(k);
     }
     for (auto &p : st.pending) st.inflight.push_back(p.src);
     st.pending.clear();
     // ... and every band is pre-passed and filtered as soon as its transfer has landed
     for (int k = 0; k < nb; k++) {
-        statmcCheck(statmc_stream_wait_event(stream.handle(), st.arrived[k]), "stat_denoiser::filter");
+        st.waitArrived(stream.handle(), k);
         B::prepassRows(a, C, B::arrival(k, nb, height, filterRadius), B::arrival(k + 1, nb, height, filterRadius));
         B::filterRows(a, C, B::edge(k, nb, height), B::edge(k + 1, nb, height));
         statmcCheck(statmc_event_record(st.filtered[k], stream.handle()), "stat_denoiser::filter");

@@ -742,7 +742,7 @@ class Estimator {
     // Upload / Denoise / Download / Synchronize (estimator.cpp:409-489, 571-573; the sequence StatPathIntegrator times
     // as "CUDA time", statpath.cpp:409-417).  All four only enqueue.  With more than one pipeline band (SetPipelineBands;
     // automatic: 6 bands for images of 512 rows and more) the image is cut into bands of rows and the three phases
-    // run on three streams ordered by events: band k travels with the r rows below it (its lower halo), is pre-passed
+    // run on their own streams (copies in on two) ordered by events: band k travels with the r rows below it (its lower halo), is pre-passed
     // and filtered as soon as it has arrived, and copied back as soon as it is filtered -- the PCIe copies in both
     // directions and the kernels overlap instead of adding up; what is left after the last copy in is one band's
     // filter.  Results are the same bits as without bands: the pre-pass is per pixel, and the window filter forms a
@@ -763,17 +763,25 @@ class Estimator {
         }
         ensurePipeline(nb);
         // the copies overwrite images that earlier work on `stream` may still read
-        check(statmc_event_record(pipe.join, stream.handle()));
-        check(statmc_stream_wait_event(pipe.up, pipe.join));
+        pipe.beginUploads(stream.handle());
+        std::vector<Buffer *> moving;
+        std::vector<size_t> rowBytes;
+        for (Buffer *b : uploadBuffers) {
+            if (acc.enabled && acc.deviceProduced.count(b)) continue;
+            moving.push_back(b);
+            rowBytes.push_back((size_t)b->mat.cols * b->mat.channels() * 4);
+        }
+        const std::vector<int> queue = bands::Streams::deal(rowBytes);
         for (int k = 0; k < nb; k++) {
             const int y0 = arrivalEdge(k, nb), y1 = arrivalEdge(k + 1, nb);
-            for (Buffer *b : uploadBuffers) {
-                if (acc.enabled && acc.deviceProduced.count(b)) continue;
-                const size_t row = (size_t)b->mat.cols * b->mat.channels() * 4;
+            pipe.beginTransfer(k);
+            for (size_t i = 0; i < moving.size(); i++) {
+                Buffer *b = moving[i];
+                const size_t row = rowBytes[i];
                 check(statmc_upload(static_cast<char *>(b->gpuMat.data()) + y0 * row, b->mat.ptr<char>() + y0 * row,
-                                    (size_t)(y1 - y0) * row, pipe.up));
+                                    (size_t)(y1 - y0) * row, pipe.upStream(queue[i])));
             }
-            check(statmc_event_record(pipe.arrived[k], pipe.up));
+            pipe.markArrived(k);
         }
         pipe.uploaded = pipe.pendingJoin = nb;
     }
@@ -831,7 +839,7 @@ class Estimator {
         // transfer k brought rows [arrivalEdge(k), arrivalEdge(k + 1)): band k and its lower halo.  Pre-pass those rows,
         // then filter band k (its upper halo came with the transfers before).
         for (int k = 0; k < nb; k++) {
-            check(statmc_stream_wait_event(stream.handle(), pipe.arrived[k]));
+            pipe.waitArrived(stream.handle(), k);
             for (int c = 0; c < nCalls; c++) calls[c].prepassRows(arrivalEdge(k, nb), arrivalEdge(k + 1, nb));
             for (int c = 0; c < nCalls; c++) calls[c].filterRows(bandEdge(k, nb), bandEdge(k + 1, nb));
             check(statmc_event_record(pipe.filtered[k], stream.handle()));
@@ -1061,7 +1069,7 @@ class Estimator {
     }
     // everything enqueued on `stream` from here on sees the uploaded images
     void joinUploads() {
-        for (int k = 0; k < pipe.pendingJoin; k++) check(statmc_stream_wait_event(stream.handle(), pipe.arrived[k]));
+        for (int k = 0; k < pipe.pendingJoin; k++) pipe.waitArrived(stream.handle(), k);
         pipe.pendingJoin = 0;
     }
     Vector2f pixelFilterRadius{0.5f, 0.5f};   // estimator.h:313 `filter` (pbrt's default box filter)

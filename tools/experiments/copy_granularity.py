@@ -62,3 +62,18 @@ for nb in (4, 6, 8):
 
 # (hipMemcpyBatchAsync would take the seven pieces of a band in one call, but the HIP runtime PyTorch 2.10 ships --
 # the one a process that imports torch has loaded -- does not export it: not an option for the library.)
+
+# the same pieces dealt over two or three copy streams (does the per-copy gap overlap?)
+for ns in (2, 3):
+    extra = [torch.cuda.Stream() for _ in range(ns)]
+    for nb in (6, 8):
+        def run_multi():
+            for k in range(nb):
+                for i, (o, s) in enumerate(zip(offs, sizes)):
+                    rows = H // nb
+                    row = s // H
+                    a, b = k * rows * row, ((k + 1) * rows if k < nb - 1 else H) * row
+                    st = C.c_void_p(extra[i % ns].cuda_stream)
+                    api.check(lib.statmc_upload(C.c_void_p(dev.data_ptr() + o + a), C.c_void_p(host.value + o + a), b - a, st))
+        ms = timed(run_multi)
+        print("%2d bands = %3d copies over %d streams: %.3f ms  (%.1f GB/s)" % (nb, nb * 7, ns, ms, total / ms / 1e6), flush=True)

@@ -26,10 +26,19 @@ try:
             "t0-b0-m3": rad["m3"], "t1-b0-film-mean": fs.g_buffer("normal"), "t2-b0-film-mean": fs.g_buffer("albedo")}
     for name, img in dump.items():
         pfm.write_pfm("%s-%d-%s.pfm" % (stem, spp, name), img.cpu().numpy())
+    config = sys.argv[1] if len(sys.argv) > 1 else "denoise"
+    if config == "acrr":   # five luminance buffers: 5 x (n, mean = film-mean, m2, m3) up, 5 x film-mean-f down
+        for b in range(5):
+            k = 1.0 / (1 + b)
+            lum = (rad["film_mean"].mean(dim=2, keepdim=True) * k).contiguous()
+            for name, img in (("n", rad["n"]), ("film-mean", lum), ("mean", lum), ("m2", (rad["m2"].mean(dim=2, keepdim=True) * k * k).contiguous()),
+                              ("m3", (rad["m3"].mean(dim=2, keepdim=True) * k ** 3).contiguous())):
+                pfm.write_pfm("%s-%d-t0-b%d-%s.pfm" % (stem, spp, b, name), img.cpu().numpy())
     del fs, scene
     torch.cuda.empty_cache()
-    for bands in (1, 2, 3, 4, 6, 8, 0):
-        out = subprocess.run([exe, "--stem", stem, "--spp", ",".join([str(spp)] * 6), "--warmup", "--bands", str(bands), "--output", "film-f"],
+    for bands in (1, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6):
+        out = subprocess.run([exe, "--stem", stem, "--spp", ",".join([str(spp)] * 6), "--warmup", "--bands", str(bands), "--config", config,
+                              "--output", "film-f" if config == "denoise" else "t0-b0-film-mean-f"],
                              capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr
         ns = sorted(int(v) for v in re.findall(r"HIP time \[ns\]: (\d+)", out.stdout)[1:])

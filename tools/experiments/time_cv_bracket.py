@@ -28,11 +28,14 @@ try:
         pfm.write_pfm("%s-%d-%s.pfm" % (stem, spp, name), img.cpu().numpy())
     del fs, scene
     torch.cuda.empty_cache()
-    for bands in ("1", "0", "4", "8"):
-        out = subprocess.run([build.CV_ADAPTOR_BIN, stem, str(spp), os.path.join(d, "f.pfm")], capture_output=True, text=True,
-                             env=dict(os.environ, STATMC_CV_BANDS=bands), timeout=300)
-        assert out.returncode == 0, out.stderr
-        m = re.search(r"bracket_ns (\d+) bands (\d+)", out.stdout)
-        print("STATMC_CV_BANDS=%s: %.3f ms (bands used %s)" % (bands, int(m.group(1)) / 1e6, m.group(2)), flush=True)
+    queues = sys.argv[1:] or ["2"]          # numbers of upload queues to try
+    for q in queues:
+        for bands in ("1", "6", "6", "6", "6", "6", "6", "6", "6", "6", "6", "6", "6"):
+            env = dict(os.environ, STATMC_CV_BANDS=bands, STATMC_CV_UPLOAD_QUEUES=q)
+            out = subprocess.run([build.CV_ADAPTOR_BIN, stem, str(spp), os.path.join(d, "f.pfm")], capture_output=True, text=True,
+                                 env=env, timeout=300)
+            assert out.returncode == 0, out.stderr
+            m = re.search(r"bracket_ns (\d+) bands (\d+)", out.stdout)
+            print("upload queues %s STATMC_CV_BANDS=%s: %.3f ms (bands used %s)" % (q, bands, int(m.group(1)) / 1e6, m.group(2)), flush=True)
 finally:
     shutil.rmtree(d, ignore_errors=True)
