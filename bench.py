@@ -489,11 +489,20 @@ def main():
         if world == 1 and not args.no_host_legs:
             # secondary measurements, outside `value`: the reference's own `CUDA time` bracket through the C++ host
             # side, the tile-fed accumulation, and the raw host <-> device copy rates
-            result["cuda_time_bracket"] = host_bracket(fs, args)
-            result["tile_fed_accumulate"] = tile_fed_accumulate(fs, samples, types)
-            result["host_copies"] = host_copy_times(fs, dev)
+            # (a failure in one of them must not cost the headline line: it is reported in place)
+            def leg(fn, *a):
+                try:
+                    return fn(*a)
+                except Exception as e:      # noqa: BLE001
+                    return {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
+            result["cuda_time_bracket"] = leg(host_bracket, fs, args)
+            result["tile_fed_accumulate"] = leg(tile_fed_accumulate, fs, samples, types)
+            result["host_copies"] = leg(host_copy_times, fs, dev)
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args, fs, samples, types)
+            try:
+                result["cpu_baseline"] = cpu_baseline(args, fs, samples, types)
+            except Exception as e:          # noqa: BLE001
+                result["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
