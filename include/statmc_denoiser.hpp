@@ -748,6 +748,9 @@ class Estimator {
     // filter.  Results are the same bits as without bands: the pre-pass is per pixel, and the window filter forms a
     // pixel's sums in the same order for any output region.
     void SetPipelineBands(int n) { bandsRequested = n; }   // 0 = automatic, 1 = off
+    // Copy queues the transfers of a band are dealt over (statmc_bands.hpp): 2 by default, 1 = a single queue (3.8
+    // instead of 3.5 ms for the 1080p bracket).  STATMC_UPLOAD_QUEUES in the environment overrides the default.
+    void SetUploadQueues(int n) { uploadQueues = n; }
     int PipelineBands() const {
         if (!allocateDevice || acc.dry) return 1;
         return bands::count(height, filterRadius, bandsRequested);
@@ -771,7 +774,7 @@ class Estimator {
             moving.push_back(b);
             rowBytes.push_back((size_t)b->mat.cols * b->mat.channels() * 4);
         }
-        const std::vector<int> queue = bands::Streams::deal(rowBytes);
+        const std::vector<int> queue = bands::Streams::deal(rowBytes, uploadQueues);
         for (int k = 0; k < nb; k++) {
             const int y0 = arrivalEdge(k, nb), y1 = arrivalEdge(k + 1, nb);
             pipe.beginTransfer(k);
@@ -1056,6 +1059,7 @@ class Estimator {
         bool downloading = false;
     } pipe;
     int bandsRequested = 0;
+    int uploadQueues = [] { const char *e = std::getenv("STATMC_UPLOAD_QUEUES"); return e ? std::atoi(e) : 2; }();
     int bandEdge(int k, int n) const { return bands::edge(k, n, height); }
     int arrivalEdge(int k, int n) const { return bands::arrival(k, n, height, filterRadius); }
     void ensurePipeline(int nb) {
