@@ -783,6 +783,12 @@ bool lds_path_selected(const FilterArgs &a, int channels) {
     return fast_path_eligible(a, channels) && a.spatial_tab != nullptr && g_variant_override != 1;
 }
 
+static const char *sym_variant_name(const FilterArgs &a) {
+    const bool joint = a.channel_rule == STATMC_CHANNELS_JOINT;
+    if (a.gate == STATMC_GATE_ASYMMETRIC) return joint ? "sym_r20_asym_joint" : "sym_r20_asym";
+    return joint ? "sym_r20_joint" : "sym_r20";
+}
+
 // Launch of the one-sided LDS kernel for the arguments' spec.  The default membership test has a compile-time-radius
 // build for r = 20; the other tests (one-sided gate, pooled channels) run the runtime-radius build.
 static int lds_spec_of(const FilterArgs &a, bool rgb) {
@@ -815,7 +821,7 @@ static hipError_t launch_lds_spec(const FilterArgs &a, hipStream_t s, const char
 // Window filter reading the 15-channel block + halo image (multi-GPU path): LDS kernels only.
 hipError_t launch_lds_packed(const FilterArgs &a, hipStream_t s, const char **variant) {
     if (a.sym.patch != nullptr) {
-        *variant = a.channel_rule == STATMC_CHANNELS_JOINT ? "sym_r20_joint" : "sym_r20";
+        *variant = sym_variant_name(a);
         return launch_sym(a, s);
     }
     return launch_lds_spec<0>(a, s, variant);
@@ -824,7 +830,7 @@ hipError_t launch_lds_packed(const FilterArgs &a, hipStream_t s, const char **va
 hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s, const char **variant) {
     const bool fast = lds_path_selected(a, channels);
     if (fast && a.sym.patch != nullptr) {
-        *variant = channels == 1 ? "sym_r20_f" : a.channel_rule == STATMC_CHANNELS_JOINT ? "sym_r20_joint" : "sym_r20";
+        *variant = channels == 1 ? "sym_r20_f" : sym_variant_name(a);
         return launch_sym(a, s);
     }
     if (fast) {

@@ -87,7 +87,12 @@ constexpr int kAblate = STATMC_SYM_ABLATE;  // 1 no q side, 2 no row staging, 4 
 // membership / buffer mode of a launch: one RGB buffer, every channel passes (default spec) | two float buffers
 // (filter<float>) | one RGB buffer, channels pooled (STATMC_CHANNELS_JOINT: sum_c fma(d_c, d_c, -(D_p,c + D_q,c)) <= 0,
 // as symmetric in (p, q) as the default test)
-constexpr int kModeRgb = 0, kModePair = 1, kModeJoint = 2;
+constexpr int kModeRgb = 0, kModePair = 1, kModeJoint = 2, kModeAsym = 3, kModeAsymJoint = 4;
+// kModeAsym / kModeAsymJoint: the one-sided gate (STATMC_GATE_ASYMMETRIC), channels one by one / pooled.  The pair is
+// still evaluated once, but its two directions are two tests -- fma(d, d, -D_q) <= D_p decides whether q enters p's
+// sums, fma(d, d, -D_p) <= D_q whether p enters q's -- so the pair carries two weights.
+constexpr int kModes = 5;
+constexpr bool mode_asym(int m) { return m == kModeAsym || m == kModeAsymJoint; }
 constexpr int kR = 20;
 constexpr int kPx = 4;                    // pixels per lane
 constexpr int kW = 32 * kPx;              // 128 tile columns: half a wave per row
@@ -152,6 +157,12 @@ __device__ __forceinline__ v2f fma_bc(const v2f &w, const v2f &pair, int half, c
     return d;
 }
 
+__device__ __forceinline__ v2f fma_sq_nbc(const v2f &d, const v2f &pair) {  // d * d - bc(pair.y)
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %1, %2 op_sel:[0,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(d), "v"(pair));
+    return r;
+}
+
 // bit (i*4+k): tap i of read group J lies at dx in [LO, HI] from pixel k
 template <int J, int LO, int HI>
 struct Mask {
@@ -209,6 +220,40 @@ __device__ __forceinline__ void gate_weight(const Lane &st, const v4f *mcn, cons
     using M = Taps<H, MASK>;
     constexpr bool PAIR = MODE == kModePair;
     constexpr int NC = PAIR ? 2 : 3;
+    if constexpr (mode_asym(MODE)) {
+        // one-sided gate: w decides q's membership in p's window (p side), wb p's membership in q's (q side); plain
+        // compares, as the oracle writes them (a NaN statistic fails every one)
+#pragma unroll
+        for (int k = 0; k < kPx; k++) if (M::on(k)) {
+            v2f upq[3], uqp[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const v2f d = sub_bc(st.ms[k][ch], 0, pair_of<H>(mcn[ch]));
+                upq[ch] = __builtin_elementwise_fma(d, d, pair_of<H>(mcn[3 + ch]));   // fma(d, d, -D_q)
+                uqp[ch] = fma_sq_nbc(d, st.ms[k][ch]);                                 // fma(d, d, -D_p)
+            }
+            const v2f x = v2f{__builtin_amdgcn_exp2f(e[k].x), __builtin_amdgcn_exp2f(e[k].y)};
+            bool p0, p1, q0, q1;
+            if constexpr (MODE == kModeAsymJoint) {
+                const v2f lp = (upq[0] + upq[1]) + upq[2], lq = (uqp[0] + uqp[1]) + uqp[2];
+                const float rp = (st.ms[k][0].y + st.ms[k][1].y) + st.ms[k][2].y;
+                const v2f rq = -((pair_of<H>(mcn[3]) + pair_of<H>(mcn[4])) + pair_of<H>(mcn[5]));   // (D_q0 + D_q1) + D_q2
+                p0 = lp.x <= rp; p1 = lp.y <= rp;
+                q0 = lq.x <= rq.x; q1 = lq.y <= rq.y;
+            } else {
+                p0 = p1 = q0 = q1 = true;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const v2f dq = -pair_of<H>(mcn[3 + ch]);
+                    p0 = p0 && upq[ch].x <= st.ms[k][ch].y; p1 = p1 && upq[ch].y <= st.ms[k][ch].y;
+                    q0 = q0 && uqp[ch].x <= dq.x; q1 = q1 && uqp[ch].y <= dq.y;
+                }
+            }
+            w[k] = v2f{M::in0(k) && p0 ? x.x : 0.f, M::in1(k) && p1 ? x.y : 0.f};
+            wb[k] = v2f{M::in0(k) && q0 ? x.x : 0.f, M::in1(k) && q1 ? x.y : 0.f};
+        }
+        return;
+    }
     // two pixels at a time: 6 independent chains are enough to keep the pipe busy and halve the live statistics
 #pragma unroll
     for (int k0 = 0; k0 < kPx; k0 += 2) {
@@ -290,13 +335,15 @@ __device__ __forceinline__ void accumulate(Lane &st, const v4f *col, const v2f (
         for (int k = 0; k < kPx; k++) if (M::on(k)) st.acc[k][ch] = __builtin_elementwise_fma(w[k], pair_of<H>(col[ch]), st.acc[k][ch]);
     }
     if constexpr (SYM) {
+        // the q side takes the weight of the pair's other direction under the one-sided gate
+        const v2f (&wq)[kPx] = mode_asym(MODE) ? wb : w;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
 #pragma unroll
-            for (int k = 0; k < kPx; k++) if (M::on(k)) qv[ch] = fma_bc(w[k], st.pc[k][ch >> 1], ch & 1, qv[ch]);
+            for (int k = 0; k < kPx; k++) if (M::on(k)) qv[ch] = fma_bc(wq[k], st.pc[k][ch >> 1], ch & 1, qv[ch]);
         }
 #pragma unroll
-        for (int k = 0; k < kPx; k++) if (M::on(k)) qv[3] += w[k];
+        for (int k = 0; k < kPx; k++) if (M::on(k)) qv[3] += wq[k];
     }
 }
 
@@ -900,8 +947,9 @@ size_t sym_patch_floats(const FilterArgs &a, int n_parts) {
 // (other sets: the one-sided kernel)
 bool sym_eligible(const FilterArgs &a, int channels) {
     if (a.radius != sym::kR || !fast_path_eligible(a, channels)) return false;
-    // the pair-symmetric kernel implements the symmetric gate (channels tested one by one or pooled) and the clipped border
-    if (a.gate != STATMC_GATE_SYMMETRIC || a.border != STATMC_BORDER_CLIP) return false;
+    // the pair-symmetric kernel implements both gates and both channel rules with the clipped border
+    if (a.border != STATMC_BORDER_CLIP) return false;
+    if (a.gate != STATMC_GATE_SYMMETRIC && channels != 3) return false;   // float buffers with the one-sided gate: one-sided kernel
     if (a.n_g > 2) return false;
     for (int g = 0; g < a.n_g; g++)
         if (a.g[g].channels != 3) return false;
@@ -930,12 +978,15 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
               (a.gscale1 == 0.f || al16(a.g[1].data));
     }
     // float buffers have one channel: pooled == per channel
-    const int mode = pair ? kModePair : a.channel_rule == STATMC_CHANNELS_JOINT ? kModeJoint : kModeRgb;
-    const void *kernels[2][3] = {
-        {reinterpret_cast<const void *>(&window_filter_sym<false, kModeRgb>), reinterpret_cast<const void *>(&window_filter_sym<false, kModePair>),
-         reinterpret_cast<const void *>(&window_filter_sym<false, kModeJoint>)},
-        {reinterpret_cast<const void *>(&window_filter_sym<true, kModeRgb>), reinterpret_cast<const void *>(&window_filter_sym<true, kModePair>),
-         reinterpret_cast<const void *>(&window_filter_sym<true, kModeJoint>)}};
+    const bool joint = a.channel_rule == STATMC_CHANNELS_JOINT, asym = a.gate == STATMC_GATE_ASYMMETRIC;
+    const int mode = pair ? kModePair : asym ? (joint ? kModeAsymJoint : kModeAsym) : joint ? kModeJoint : kModeRgb;
+#define STATMC_SYM_K(D, M) reinterpret_cast<const void *>(&window_filter_sym<D, M>)
+    const void *kernels[2][kModes] = {
+        {STATMC_SYM_K(false, kModeRgb), STATMC_SYM_K(false, kModePair), STATMC_SYM_K(false, kModeJoint), STATMC_SYM_K(false, kModeAsym),
+         STATMC_SYM_K(false, kModeAsymJoint)},
+        {STATMC_SYM_K(true, kModeRgb), STATMC_SYM_K(true, kModePair), STATMC_SYM_K(true, kModeJoint), STATMC_SYM_K(true, kModeAsym),
+         STATMC_SYM_K(true, kModeAsymJoint)}};
+#undef STATMC_SYM_K
     const void *kernel = kernels[dma ? 1 : 0][mode];
     static std::mutex mu;
     static std::set<std::pair<int, const void *>> done;
