@@ -70,10 +70,10 @@ int statmc_set_t_quantiles(int table, const float *quantiles, int n_dof);
  * only the call sites src/statistics/estimator.cpp:437-487 and the buffer meanings README.md:317-325
  * are in the tree).  Every open choice is a field, so that pinning this build to dumps of the CUDA
  * denoiser is a search over specs (tools/fit_spec.py), not a kernel rewrite.  All-zero = this build's
- * default ("spec v2").  Every combination runs on an LDS kernel (both gates and channel
- * rules with the clipped border on the pair-symmetric one, a clamped border on the one-sided one: 1.4 - 2.5 ms
- * per 1080p buffer) except Welch degrees of freedom, which take the general kernel (65 ms; same results as
- * the CPU oracle).  `sides` and `small_n` only change the pre-pass. */
+ * default ("spec v2").  Every combination runs on an LDS kernel (an RGB buffer at the
+ * shipped radius 20 on the pair-symmetric one: 1.4 - 1.9 ms per 1080p buffer) except Welch degrees of freedom,
+ * which take the general kernel (65 ms; same results as the CPU oracle).  `sides` and `small_n` only change
+ * the pre-pass. */
 #define STATMC_GATE_SYMMETRIC 0   /* member <=> fma(d, d, -(D_p + D_q)) <= 0, i.e. d^2 <= D_p + D_q        */
 #define STATMC_GATE_ASYMMETRIC 1  /* member <=> fma(d, d, -D_q) <= D_p      (this build's spec v1.x)       */
 #define STATMC_CHANNELS_AND 0     /* every channel of an RGB buffer must pass                              */

@@ -176,10 +176,12 @@ int prepare_sym(const DeviceState &d, statmc::FilterArgs &k, const statmc_filter
     float *ws = nullptr;
     const size_t patch_floats = (statmc::sym_patch_floats(k, k.n_parts) + 3) & ~(size_t)3;
     const size_t image_floats = pair ? (size_t)9 * k.width * k.height : 0;
-    if (int rc = partial_workspace((patch_floats + image_floats) * sizeof(float), a->stream, &ws)) return rc;
+    const size_t extra_floats = k.border == STATMC_BORDER_CLAMP ? (size_t)4 * k.width * k.height : 0;
+    if (int rc = partial_workspace((patch_floats + image_floats + extra_floats) * sizeof(float), a->stream, &ws)) return rc;
     k.sym.patch = reinterpret_cast<float4 *>(ws);
     k.sym.pair = pair ? 1 : 0;
     k.sym.pair_images = pair ? ws + patch_floats : nullptr;
+    k.sym.border_extra = extra_floats ? reinterpret_cast<float4 *>(ws + patch_floats + image_floats) : nullptr;
     return STATMC_OK;
 }
 int prepass_table(const DeviceState &d) { return d.alpha_index + STATMC_TQ_N_ALPHAS * (d.spec.sides ? 1 : 0); }

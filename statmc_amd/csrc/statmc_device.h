@@ -124,6 +124,7 @@ struct FilterArgs {
         float4 *patch;            // [items][p-side 8 x 128 | q-side rows x 168] (sum w*colour rgb, sum w)
         int pair;                 // filter<float>: f_active (1 or 2) 1-channel buffers (f_mean_corr / f_disc / f_colour / f_out) per launch
         float *pair_images;       // ... staged from three [height][width][3] images this launch packs them into
+        float4 *border_extra;     // border rule "clamp": per pixel, the sums over the taps beyond the image (border_virtual_kernel)
     } sym;
 };
 
@@ -178,6 +179,7 @@ int sym_choose_parts(int tiles, int n_cus);
 int sym_filter_parts(const FilterArgs &a, int n_cus);
 size_t sym_patch_floats(const FilterArgs &a, int n_parts);
 hipError_t launch_sym(FilterArgs a, hipStream_t s);
+hipError_t launch_border_virtual(const FilterArgs &a, hipStream_t s);   // the clamped border's taps beyond the image (RGB)
 int choose_parts(int tiles, int n_rows, int n_cus);
 int filter_parts_override();
 // parts per tile the LDS kernel would use for this ROI on a device with n_cus compute units

@@ -165,6 +165,81 @@ __global__ __launch_bounds__(256) void window_filter_generic(FilterArgs a) {
     for (int c = 0; c < C; c++) a.out[p * C + c] = sum_w > 0.f ? acc[c] / sum_w : a.colour[p * C + c];
 }
 
+// Border rule "clamp" on the pair-symmetric kernel: that kernel sums the taps inside the image; the taps beyond the
+// image, which the clamped border maps onto the edge pixels, exist for the pixels within r of an edge only (6 % of a
+// 1080p film) and have no mirror pair.  This kernel adds exactly those taps into one float4 per pixel
+// (sum w * colour, sum w) that combine_sym_kernel adds to the pixel's patches.  All the taps of one window column
+// that lie above the image land on the same pixel of row 0 with the same membership and range weight; they differ in
+// their spatial weight only, and that factorises: sum_dy exp(ds (dx^2 + dy^2)) = exp(ds dx^2) * sum_dy exp(ds dy^2).
+// So a pixel evaluates at most 4 x 41 (pixel, edge pixel) pairs instead of up to 1200 taps.
+__global__ __launch_bounds__(256) void border_virtual_kernel(FilterArgs a) {
+    constexpr int C = 3;
+    const int x = a.rx0 + blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = a.ry0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= a.rx1 || y >= a.ry1) return;
+    const int r = a.radius, W = a.width, H = a.height;
+    if (x >= r && x < W - r && y >= r && y < H - r) return;   // every tap of this pixel is inside the image
+    const long long p = (long long)y * W + x;
+    float pc[C], pd[C], acc[C] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        pc[c] = a.mean_corr[p * C + c];
+        pd[c] = a.disc[p * C + c];
+    }
+    float sum_w = 0.f;
+    if (pixel_valid<C>(a, p)) {
+        // summed spatial weights of the window rows above / below and of the window columns left / right of the image
+        float t_top = 0.f, t_bot = 0.f, t_left = 0.f, t_right = 0.f;
+        for (int d = 1; d <= r; d++) {
+            const float sw = __builtin_amdgcn_exp2f(a.ds * (float)(d * d) * kLog2e);
+            if (d > y) t_top += sw;
+            if (d > H - 1 - y) t_bot += sw;
+            if (d > x) t_left += sw;
+            if (d > W - 1 - x) t_right += sw;
+        }
+        // one (pixel, edge pixel) pair: membership, range weight, times the summed spatial weight of the taps it stands for
+        auto pair = [&](int qx, int qy, int d_along, float t_across) {
+            const long long q = (long long)qy * W + qx;
+            if (!pixel_valid<C>(a, q)) return;
+            if (!pair_member<C>(a, pc, pd, p, q)) return;
+            float e = a.ds * (float)(d_along * d_along);
+            for (int g = 0; g < a.n_g; g++) {
+                const int gc = a.g[g].channels;
+                const float *G = a.g[g].data;
+                const float d0 = G[p * gc] - G[q * gc];
+                float dist2 = d0 * d0;
+                for (int c = 1; c < gc; c++) {
+                    const float dc = G[p * gc + c] - G[q * gc + c];
+                    dist2 = __builtin_fmaf(dc, dc, dist2);
+                }
+                e = __builtin_fmaf(a.g[g].dr, dist2, e);
+            }
+            const float w = __builtin_amdgcn_exp2f(e * kLog2e) * t_across;
+            sum_w += w;
+#pragma unroll
+            for (int c = 0; c < C; c++) acc[c] = __builtin_fmaf(w, a.colour[q * C + c], acc[c]);
+        };
+        for (int dx = -r; dx <= r; dx++) {   // rows beyond the image (corners included): edge rows, clamped column
+            const int tx = x + dx, qx = tx < 0 ? 0 : tx >= W ? W - 1 : tx;
+            if (t_top > 0.f) pair(qx, 0, dx, t_top);
+            if (t_bot > 0.f) pair(qx, H - 1, dx, t_bot);
+        }
+        for (int dy = -r; dy <= r; dy++) {   // columns beyond the image, rows inside it: edge columns
+            const int ty = y + dy;
+            if (ty < 0 || ty >= H) continue;
+            if (t_left > 0.f) pair(0, ty, dy, t_left);
+            if (t_right > 0.f) pair(W - 1, ty, dy, t_right);
+        }
+    }
+    a.sym.border_extra[p] = make_float4(acc[0], acc[1], acc[2], sum_w);
+}
+
+hipError_t launch_border_virtual(const FilterArgs &a, hipStream_t s) {
+    const dim3 grid((a.rx1 - a.rx0 + 31) / 32, (a.ry1 - a.ry0 + 7) / 8);
+    hipLaunchKernelGGL(border_virtual_kernel, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 // ====================================================================== LDS kernel
 constexpr int kPx = 4;                 // pixels per lane
 constexpr int kTileW = 64 * kPx;       // 256 columns per wave-row
@@ -784,9 +859,10 @@ bool lds_path_selected(const FilterArgs &a, int channels) {
 }
 
 static const char *sym_variant_name(const FilterArgs &a) {
-    const bool joint = a.channel_rule == STATMC_CHANNELS_JOINT;
-    if (a.gate == STATMC_GATE_ASYMMETRIC) return joint ? "sym_r20_asym_joint" : "sym_r20_asym";
-    return joint ? "sym_r20_joint" : "sym_r20";
+    const bool joint = a.channel_rule == STATMC_CHANNELS_JOINT, clamp = a.border == STATMC_BORDER_CLAMP;
+    if (a.gate == STATMC_GATE_ASYMMETRIC)
+        return joint ? (clamp ? "sym_r20_asym_joint_clamp" : "sym_r20_asym_joint") : (clamp ? "sym_r20_asym_clamp" : "sym_r20_asym");
+    return joint ? (clamp ? "sym_r20_joint_clamp" : "sym_r20_joint") : (clamp ? "sym_r20_clamp" : "sym_r20");
 }
 
 // Launch of the one-sided LDS kernel for the arguments' spec.  The default membership test has a compile-time-radius

@@ -878,6 +878,10 @@ __global__ __launch_bounds__(256) void combine_sym_kernel(FilterArgs a) {
         }
     }
     const long long p = (long long)y * a.width + x;
+    if (a.sym.border_extra && (x < kR || x >= a.width - kR || y < kR || y >= a.height - kR)) {
+        const float4 v = a.sym.border_extra[p];   // clamped border: the taps beyond the image
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
     if (a.sym.pair) {   // (sum w0 c0, sum w1 c1, sum w0, sum w1) of two float buffers
         a.f_out[0][p] = t.z > 0.f ? t.x / t.z : a.f_colour[0][p];
         if (a.f_active > 1) a.f_out[1][p] = t.w > 0.f ? t.y / t.w : a.f_colour[1][p];
@@ -947,9 +951,11 @@ size_t sym_patch_floats(const FilterArgs &a, int n_parts) {
 // (other sets: the one-sided kernel)
 bool sym_eligible(const FilterArgs &a, int channels) {
     if (a.radius != sym::kR || !fast_path_eligible(a, channels)) return false;
-    // the pair-symmetric kernel implements both gates and both channel rules with the clipped border
-    if (a.border != STATMC_BORDER_CLIP) return false;
-    if (a.gate != STATMC_GATE_SYMMETRIC && channels != 3) return false;   // float buffers with the one-sided gate: one-sided kernel
+    // the pair-symmetric kernel implements both gates and both channel rules; the clamped border's taps beyond the image
+    // are added by border_virtual_kernel
+    // float buffers with the one-sided gate or the clamped border: one-sided kernel
+    if ((a.gate != STATMC_GATE_SYMMETRIC || a.border != STATMC_BORDER_CLIP) && channels != 3) return false;
+    if (a.border == STATMC_BORDER_CLAMP && a.packed) return false;   // the border kernel reads the five images, not the packed one
     if (a.n_g > 2) return false;
     for (int g = 0; g < a.n_g; g++)
         if (a.g[g].channels != 3) return false;
@@ -1002,6 +1008,9 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     const dim3 grid(sym_tiles(a) * a.n_parts);
     void *kargs[] = {&a};
     if (hipError_t e = hipLaunchKernel(kernel, grid, dim3(kThreads), kargs, kLdsBytes, s); e != hipSuccess) return e;
+    if (a.sym.border_extra) {
+        if (hipError_t e = launch_border_virtual(a, s); e != hipSuccess) return e;
+    }
     const dim3 cgrid((a.rx1 - a.rx0 + 63) / 64, (a.ry1 - a.ry0 + 3) / 4);
     hipLaunchKernelGGL(combine_sym_kernel, cgrid, dim3(256), 0, s, a);
     return hipGetLastError();

@@ -105,8 +105,8 @@ def test_lds_kernel_vs_generic_vs_oracle_on_strip(gpu, oracle, film1080):
         assert rel_l2(a, ref) <= 1e-5
 
 
-@pytest.mark.parametrize("spec_kw,variant", [(dict(), "sym_r20"), (dict(border=1), "lds_r20"),
-                                             (dict(gate=1, channel_rule=1, border=1), "lds_rt_asym_joint"), (dict(channel_rule=1), "sym_r20_joint"),
+@pytest.mark.parametrize("spec_kw,variant", [(dict(), "sym_r20"), (dict(border=1), "sym_r20_clamp"),
+                                             (dict(gate=1, channel_rule=1, border=1), "sym_r20_asym_joint_clamp"), (dict(channel_rule=1), "sym_r20_joint"),
                                              (dict(gate=1), "sym_r20_asym"), (dict(gate=1, channel_rule=1), "sym_r20_asym_joint")],
                          ids=["default", "clamp", "asym+joint+clamp", "joint", "asym", "asym+joint"])
 def test_block_decomposition_equals_whole_film(gpu, film1080, spec_kw, variant):
