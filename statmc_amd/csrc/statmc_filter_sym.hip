@@ -1,5 +1,5 @@
-// statmc_filter_sym.hip -- the pair-symmetric window filter (gfx950): filter<float3> and filter<float>, radius 20,
-// default spec.
+// statmc_filter_sym.hip -- the pair-symmetric window filter (gfx950): filter<float3> under every filter spec but Welch
+// degrees of freedom, filter<float> under the default gate and border; radius 20.
 //
 // Replaces the window part of cv::cuda::stat_denoiser::filter<float3> / filter<float> (call sites
 // src/statistics/estimator.cpp:465-487 and 437-459 of the reference; CUDA source not in the tree, arithmetic = this
@@ -43,6 +43,10 @@
 //   * filter<float> (PAIR): two 1-channel buffers per launch ride in the (x, y) channels of the same planes;
 //     they share the range weight, gate and normalise separately (the four sums per pixel become
 //     Sigma w0 c0, Sigma w1 c1, Sigma w0, Sigma w1).
+//   * Spec options as launch modes: pooled channels (a sum where the default has a max3, still symmetric); the
+//     one-sided gate (one evaluation per pair, but two tests and two weights -- one per direction); the clamped
+//     border (this kernel sums the taps inside the image, border_virtual_kernel in statmc_filter.hip adds the taps
+//     beyond it for the pixels next to an edge, combine_sym_kernel joins the two).
 #include <algorithm>
 #include <mutex>
 #include <set>
