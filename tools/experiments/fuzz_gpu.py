@@ -10,12 +10,15 @@ from oracle import oracle
 from statmc_amd import api as gpu
 import test_gpu_parity as T
 oracle.build(); gpu.setup(0)
+R20 = "--r20" in sys.argv
+if R20:
+    sys.argv.remove("--r20")
 
 
 def random_spec(rng):
     """Mostly the default spec; otherwise any combination of the options the window filter sees (the Welch lookup,
     which runs the general kernel only, rarely)."""
-    if rng.random() < 0.5:
+    if rng.random() < (0.25 if R20 else 0.5):
         return {}
     kw = dict(gate=int(rng.integers(0, 2)), channel_rule=int(rng.integers(0, 2)), border=int(rng.integers(0, 2)))
     if rng.random() < 0.1:
@@ -28,6 +31,8 @@ def filter_case(case, verbose=False):
     W = int(rng.choice([rng.integers(1, 12), rng.integers(12, 300), rng.integers(250, 800)]))
     H = int(rng.choice([rng.integers(1, 6), rng.integers(6, 70)]))
     radius = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 13, 19, 20, 20, 20, 21, 25]))
+    if R20:       # --r20: the shipped radius only, non-default specs three times out of four (the pair-symmetric kernel's modes)
+        radius = 20
     sd = float(rng.uniform(0.7, 15.0))
     g_sds = [float(10 ** rng.uniform(-2, 0)), float(10 ** rng.uniform(-2.3, 0))]
     g_dr = [-0.5 / s ** 2 for s in g_sds]
