@@ -80,6 +80,11 @@ constexpr bool kPipe = STATMC_SYM_PIPE;
 #ifndef STATMC_SYM_SPLIT
 #define STATMC_SYM_SPLIT 0
 #endif
+// diagnostic build (tools/experiments/count_sym.py): every wave counts its read groups and those in which no lane has
+// a member pair (what a wave-level "all rejected" skip in front of v_exp_f32 would save).  Never in the product.
+#ifndef STATMC_SYM_COUNT
+#define STATMC_SYM_COUNT 0
+#endif
 #ifndef STATMC_SYM_PRIO
 #define STATMC_SYM_PRIO 0
 #endif
@@ -138,6 +143,9 @@ struct Lane {
     v2f pc[kPx][2];    // colour (r, g), (b, -)
     v2f acc[kPx][3];   // .x even taps, .y odd taps of every read group
     v2f sw[kPx];
+#if STATMC_SYM_COUNT
+    unsigned n_groups = 0, n_empty = 0, n_empty_halves = 0;
+#endif
 };
 // The three packed instructions that take a broadcast half of a pair, spelled out: written as shuffles the
 // broadcasts are loop-invariant, get hoisted out of the sweep and come back as (x, x) register pairs of their own.
@@ -447,6 +455,20 @@ __device__ __forceinline__ void chunk(Lane &st, const float *__restrict__ row, c
     }
     if constexpr (M0::any()) gate_weight<0, MASK, MODE>(st, mcn, e0, w0, wb0);
     if constexpr (M1::any()) gate_weight<1, MASK, MODE>(st, mcn, e1, w1, wb1);
+#if STATMC_SYM_COUNT
+    if constexpr (MASK == 0xFFFFu && SYM && MODE == kModeRgb) {   // full read groups of the default mode
+        bool any0 = false, any1 = false;
+#pragma unroll
+        for (int k = 0; k < kPx; k++) {
+            any0 = any0 || w0[k].x != 0.f || w0[k].y != 0.f;
+            any1 = any1 || w1[k].x != 0.f || w1[k].y != 0.f;
+        }
+        const bool e0w = __builtin_amdgcn_ballot_w64(any0) == 0, e1w = __builtin_amdgcn_ballot_w64(any1) == 0;
+        st.n_groups++;
+        st.n_empty += (e0w && e1w) ? 1u : 0u;
+        st.n_empty_halves += (e0w ? 1u : 0u) + (e1w ? 1u : 0u);
+    }
+#endif
     if constexpr (PIPE) {
         // ... and the colour / accumulator planes before the gates; the wait names the weights too, so that it stays
         // behind the arithmetic that produced them (plain arithmetic may otherwise be scheduled after the wait)
@@ -835,6 +857,11 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
                             (st.acc[k][2].x + st.acc[k][2].y) + e[2 * kW], (st.sw[k].x + st.sw[k].y) + e[3 * kW]);
         }
     }
+#if STATMC_SYM_COUNT
+    __syncthreads();
+    if (lane == 0 && s_a < s_b)
+        patch[a.sym.item_stride4 - 8 + wave] = make_float4((float)st.n_groups, (float)st.n_empty, (float)st.n_empty_halves, 0.f);
+#endif
     if constexpr (kStamps) {
         // the item's last 16 float4 (columns of its last accumulator row: the results of a stamps build are wrong):
         // per wave (housekeeping, sweep, barrier clocks summed over the steps, steps) and (before the first step,
