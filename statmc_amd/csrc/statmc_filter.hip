@@ -64,26 +64,33 @@ void set_filter_variant_override(int v) { g_variant_override = v; }
 // ====================================================================== generic kernel
 // Every option of statmc_filter_spec, one lane per pixel, straight from global memory; the statements
 // follow oracle/statmc_oracle.c:oracle_filter_spec_run line by line (same operation order, no contraction).
+// (mc / dc / col: the buffer's corrected mean, discriminator and colour images -- a.mean_corr / a.disc / a.colour, or
+// one of the float buffers of a multi-buffer launch)
 template <int C>
-__device__ __forceinline__ bool pixel_valid(const FilterArgs &a, long long p) {
+__device__ __forceinline__ bool pixel_valid(const float *mc, const float *dc, const float *col, long long p) {
     bool v = true;
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        v = v && __builtin_isfinite(a.mean_corr[p * C + c]);
-        v = v && !__builtin_isnan(a.disc[p * C + c]);
-        v = v && __builtin_isfinite(a.colour[p * C + c]);
+        v = v && __builtin_isfinite(mc[p * C + c]);
+        v = v && !__builtin_isnan(dc[p * C + c]);
+        v = v && __builtin_isfinite(col[p * C + c]);
     }
     return v;
 }
+template <int C>
+__device__ __forceinline__ bool pixel_valid(const FilterArgs &a, long long p) {
+    return pixel_valid<C>(a.mean_corr, a.disc, a.colour, p);
+}
 
 template <int C>
-__device__ __forceinline__ bool pair_member(const FilterArgs &a, const float *pc, const float *pd, long long p, long long q) {
+__device__ __forceinline__ bool pair_member(const FilterArgs &a, const float *mc, const float *dc, const float *pc, const float *pd,
+                                            long long p, long long q) {
     bool all = true;
     float lhs_sum = 0.f, rhs_sum = 0.f;
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        const float d = pc[c] - a.mean_corr[q * C + c];
-        const float Dp = pd[c], Dq = a.disc[q * C + c];
+        const float d = pc[c] - mc[q * C + c];
+        const float Dp = pd[c], Dq = dc[q * C + c];
         float lhs, rhs;
         if (a.dof == STATMC_DOF_WELCH) {
             const float s = Dp + Dq;
@@ -108,6 +115,10 @@ __device__ __forceinline__ bool pair_member(const FilterArgs &a, const float *pc
         rhs_sum = c == 0 ? rhs : rhs_sum + rhs;
     }
     return a.channel_rule == STATMC_CHANNELS_JOINT ? (lhs_sum <= rhs_sum) : all;
+}
+template <int C>
+__device__ __forceinline__ bool pair_member(const FilterArgs &a, const float *pc, const float *pd, long long p, long long q) {
+    return pair_member<C>(a, a.mean_corr, a.disc, pc, pd, p, q);
 }
 
 template <int C>
@@ -172,71 +183,91 @@ __global__ __launch_bounds__(256) void window_filter_generic(FilterArgs a) {
 // that lie above the image land on the same pixel of row 0 with the same membership and range weight; they differ in
 // their spatial weight only, and that factorises: sum_dy exp(ds (dx^2 + dy^2)) = exp(ds dx^2) * sum_dy exp(ds dy^2).
 // So a pixel evaluates at most 4 x 41 (pixel, edge pixel) pairs instead of up to 1200 taps.
+// NB = 0: one RGB buffer (a.mean_corr / a.disc / a.colour).  NB = 2: the two float buffers of a filter<float> launch
+// (a.f_mean_corr[b] ...; the sums go to (x, z) and (y, w) of the float4, as combine_sym_kernel expects them).
+template <int NB>
 __global__ __launch_bounds__(256) void border_virtual_kernel(FilterArgs a) {
-    constexpr int C = 3;
+    constexpr int C = NB == 0 ? 3 : 1;
     const int x = a.rx0 + blockIdx.x * 32 + (threadIdx.x & 31);
     const int y = a.ry0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= a.rx1 || y >= a.ry1) return;
     const int r = a.radius, W = a.width, H = a.height;
     if (x >= r && x < W - r && y >= r && y < H - r) return;   // every tap of this pixel is inside the image
     const long long p = (long long)y * W + x;
-    float pc[C], pd[C], acc[C] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < C; c++) {
-        pc[c] = a.mean_corr[p * C + c];
-        pd[c] = a.disc[p * C + c];
+    // summed spatial weights of the window rows above / below and of the window columns left / right of the image
+    float t_top = 0.f, t_bot = 0.f, t_left = 0.f, t_right = 0.f;
+    for (int d = 1; d <= r; d++) {
+        const float sw = __builtin_amdgcn_exp2f(a.ds * (float)(d * d) * kLog2e);
+        if (d > y) t_top += sw;
+        if (d > H - 1 - y) t_bot += sw;
+        if (d > x) t_left += sw;
+        if (d > W - 1 - x) t_right += sw;
     }
-    float sum_w = 0.f;
-    if (pixel_valid<C>(a, p)) {
-        // summed spatial weights of the window rows above / below and of the window columns left / right of the image
-        float t_top = 0.f, t_bot = 0.f, t_left = 0.f, t_right = 0.f;
-        for (int d = 1; d <= r; d++) {
-            const float sw = __builtin_amdgcn_exp2f(a.ds * (float)(d * d) * kLog2e);
-            if (d > y) t_top += sw;
-            if (d > H - 1 - y) t_bot += sw;
-            if (d > x) t_left += sw;
-            if (d > W - 1 - x) t_right += sw;
+    float out[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int kBuffers = NB == 0 ? 1 : NB;
+#pragma unroll
+    for (int b = 0; b < kBuffers; b++) {
+        if (NB != 0 && b >= a.f_active) break;
+        const float *mc = NB == 0 ? a.mean_corr : a.f_mean_corr[b];
+        const float *dc = NB == 0 ? a.disc : a.f_disc[b];
+        const float *col = NB == 0 ? a.colour : a.f_colour[b];
+        float pc[C], pd[C], acc[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            pc[c] = mc[p * C + c];
+            pd[c] = dc[p * C + c];
+            acc[c] = 0.f;
         }
-        // one (pixel, edge pixel) pair: membership, range weight, times the summed spatial weight of the taps it stands for
-        auto pair = [&](int qx, int qy, int d_along, float t_across) {
-            const long long q = (long long)qy * W + qx;
-            if (!pixel_valid<C>(a, q)) return;
-            if (!pair_member<C>(a, pc, pd, p, q)) return;
-            float e = a.ds * (float)(d_along * d_along);
-            for (int g = 0; g < a.n_g; g++) {
-                const int gc = a.g[g].channels;
-                const float *G = a.g[g].data;
-                const float d0 = G[p * gc] - G[q * gc];
-                float dist2 = d0 * d0;
-                for (int c = 1; c < gc; c++) {
-                    const float dc = G[p * gc + c] - G[q * gc + c];
-                    dist2 = __builtin_fmaf(dc, dc, dist2);
+        float sum_w = 0.f;
+        if (pixel_valid<C>(mc, dc, col, p)) {
+            // one (pixel, edge pixel) pair: membership, range weight, times the summed spatial weight of the taps it stands for
+            auto pair = [&](int qx, int qy, int d_along, float t_across) {
+                const long long q = (long long)qy * W + qx;
+                if (!pixel_valid<C>(mc, dc, col, q)) return;
+                if (!pair_member<C>(a, mc, dc, pc, pd, p, q)) return;
+                float e = a.ds * (float)(d_along * d_along);
+                for (int g = 0; g < a.n_g; g++) {
+                    const int gc = a.g[g].channels;
+                    const float *G = a.g[g].data;
+                    const float d0 = G[p * gc] - G[q * gc];
+                    float dist2 = d0 * d0;
+                    for (int c = 1; c < gc; c++) {
+                        const float dcc = G[p * gc + c] - G[q * gc + c];
+                        dist2 = __builtin_fmaf(dcc, dcc, dist2);
+                    }
+                    e = __builtin_fmaf(a.g[g].dr, dist2, e);
                 }
-                e = __builtin_fmaf(a.g[g].dr, dist2, e);
-            }
-            const float w = __builtin_amdgcn_exp2f(e * kLog2e) * t_across;
-            sum_w += w;
+                const float w = __builtin_amdgcn_exp2f(e * kLog2e) * t_across;
+                sum_w += w;
 #pragma unroll
-            for (int c = 0; c < C; c++) acc[c] = __builtin_fmaf(w, a.colour[q * C + c], acc[c]);
-        };
-        for (int dx = -r; dx <= r; dx++) {   // rows beyond the image (corners included): edge rows, clamped column
-            const int tx = x + dx, qx = tx < 0 ? 0 : tx >= W ? W - 1 : tx;
-            if (t_top > 0.f) pair(qx, 0, dx, t_top);
-            if (t_bot > 0.f) pair(qx, H - 1, dx, t_bot);
+                for (int c = 0; c < C; c++) acc[c] = __builtin_fmaf(w, col[q * C + c], acc[c]);
+            };
+            for (int dx = -r; dx <= r; dx++) {   // rows beyond the image (corners included): edge rows, clamped column
+                const int tx = x + dx, qx = tx < 0 ? 0 : tx >= W ? W - 1 : tx;
+                if (t_top > 0.f) pair(qx, 0, dx, t_top);
+                if (t_bot > 0.f) pair(qx, H - 1, dx, t_bot);
+            }
+            for (int dy = -r; dy <= r; dy++) {   // columns beyond the image, rows inside it: edge columns
+                const int ty = y + dy;
+                if (ty < 0 || ty >= H) continue;
+                if (t_left > 0.f) pair(0, ty, dy, t_left);
+                if (t_right > 0.f) pair(W - 1, ty, dy, t_right);
+            }
         }
-        for (int dy = -r; dy <= r; dy++) {   // columns beyond the image, rows inside it: edge columns
-            const int ty = y + dy;
-            if (ty < 0 || ty >= H) continue;
-            if (t_left > 0.f) pair(0, ty, dy, t_left);
-            if (t_right > 0.f) pair(W - 1, ty, dy, t_right);
+        if (NB == 0) {
+            out[0] = acc[0]; out[1] = acc[C - 1 >= 1 ? 1 : 0]; out[2] = acc[C - 1 >= 2 ? 2 : 0]; out[3] = sum_w;
+        } else {
+            out[b] = acc[0];
+            out[2 + b] = sum_w;
         }
     }
-    a.sym.border_extra[p] = make_float4(acc[0], acc[1], acc[2], sum_w);
+    a.sym.border_extra[p] = make_float4(out[0], out[1], out[2], out[3]);
 }
 
 hipError_t launch_border_virtual(const FilterArgs &a, hipStream_t s) {
     const dim3 grid((a.rx1 - a.rx0 + 31) / 32, (a.ry1 - a.ry0 + 7) / 8);
-    hipLaunchKernelGGL(border_virtual_kernel, grid, dim3(256), 0, s, a);
+    if (a.sym.pair) hipLaunchKernelGGL(border_virtual_kernel<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(border_virtual_kernel<0>, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -906,7 +937,7 @@ hipError_t launch_lds_packed(const FilterArgs &a, hipStream_t s, const char **va
 hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s, const char **variant) {
     const bool fast = lds_path_selected(a, channels);
     if (fast && a.sym.patch != nullptr) {
-        *variant = channels == 1 ? "sym_r20_f" : sym_variant_name(a);
+        *variant = channels == 1 ? (a.border == STATMC_BORDER_CLAMP ? "sym_r20_f_clamp" : "sym_r20_f") : sym_variant_name(a);
         return launch_sym(a, s);
     }
     if (fast) {

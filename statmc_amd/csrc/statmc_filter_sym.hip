@@ -984,8 +984,8 @@ bool sym_eligible(const FilterArgs &a, int channels) {
     if (a.radius != sym::kR || !fast_path_eligible(a, channels)) return false;
     // the pair-symmetric kernel implements both gates and both channel rules; the clamped border's taps beyond the image
     // are added by border_virtual_kernel
-    // float buffers with the one-sided gate or the clamped border: one-sided kernel
-    if ((a.gate != STATMC_GATE_SYMMETRIC || a.border != STATMC_BORDER_CLIP) && channels != 3) return false;
+    // float buffers with the one-sided gate (four weights per pair for two buffers): one-sided kernel
+    if (a.gate != STATMC_GATE_SYMMETRIC && channels != 3) return false;
     if (a.border == STATMC_BORDER_CLAMP && a.packed) return false;   // the border kernel reads the five images, not the packed one
     if (a.n_g > 2) return false;
     for (int g = 0; g < a.n_g; g++)

@@ -991,13 +991,13 @@ def run_spec(gpu, oracle, st, spec_kw, radius, sd, channels=3, alpha_index=0, fo
 def expected_lds_variant(spec_kw, channels, radius):
     """Which kernel serves a spec: a per-pair Welch lookup runs the general kernel; at r = 20 the pair-symmetric kernel
     takes every other spec for an RGB buffer (the clamped border's taps beyond the image come from a second small
-    kernel) and the default gate / border for float buffers; the one-sided LDS kernel takes the rest (the non-default
+    kernel) and the symmetric gate for float buffers; the one-sided LDS kernel takes the rest (the non-default
     membership tests in its runtime-radius build)."""
     gate, joint, border = spec_kw.get("gate", 0), spec_kw.get("channel_rule", 0) and channels == 3, spec_kw.get("border", 0)
     if spec_kw.get("dof", 0):
         return "generic"
     f = "_f" if channels == 1 else ""
-    if radius == 20 and (channels == 3 or not (gate or border)):
+    if radius == 20 and (channels == 3 or not gate):
         return "sym_r20" + f + ("_asym" if gate else "") + ("_joint" if joint else "") + ("_clamp" if border else "")
     if gate or joint:
         return "lds_rt" + f + ("_asym" if gate else "") + ("_joint" if joint else "")
