@@ -27,8 +27,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+torch = None   # imported by main() AFTER the launch decision: the parent of a self-launched N > 1 run never touches the GPU
+dist = None
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TOPS = 78.6          # 10^12 fp32 lane-ops/s: 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz
@@ -70,6 +70,16 @@ def parse():
     ap.add_argument("--share-device", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--cpu-acc-rows", type=int, default=32, help="rows of the film the CPU baseline accumulates")
     ap.add_argument("--no-host-legs", action="store_true", help="skip the secondary host-side measurements (N = 1)")
+    ap.add_argument("--schedule", default="single", choices=("single", "reference"),
+                    help="single = one accumulate of --spp samples + one pre-pass + filter per step (default); reference = the "
+                         "reference's progressive schedule (statpath.cpp:272-279): iterations of 4, 4, 8, 16, ... samples up to "
+                         "--spp, the denoiser after every iteration, statistics reset at the start of a step")
+    ap.add_argument("--pool-spp", type=int, default=0,
+                    help="samples per pixel kept resident in HBM (0 = all of --spp if they fit in 60 %% of the free memory, else "
+                         "what fits); sample s of a step is pool sample s mod pool: every sample is still read from HBM")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: assemble film-f on rank 0 inside every step (default: measured after the timed region as gather_ms)")
+    ap.add_argument("--no-bind", action="store_true", help="do not bind the rank to the CPUs of its GPU's NUMA node")
     args = ap.parse_args()
     if args.film:
         args.width, args.height = (int(v) for v in args.film.lower().split("x"))
@@ -83,7 +93,8 @@ def cpu_baseline(args, fs, samples, types, budget_s=7.0):
     import numpy as np
     from oracle import oracle
     from statmc_amd.film import STAT_TYPES
-    W, H, S = args.width, args.height, args.spp
+    W, H = args.width, args.height
+    S = next(iter(samples.values())).shape[0]          # the resident samples (all of --spp unless a pool was needed)
     cores = oracle.num_threads()
 
     # ---- accumulate: a strip of rows, all spp, all channels, repeated on fresh state
@@ -322,27 +333,94 @@ def tile_fed_accumulate(fs, samples, types, spp_cap=64):
             "frac_hbm": round(bpp * W * H / ms / 1e6 / HBM_PEAK_GBS, 4)}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as FRESH child processes
+    (python -m torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) before this process has made any GPU
+    call -- it never does -- and relay rank 0's JSON line and the exit code.  Nothing is exec'ed."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for l in proc.stdout:
+        if l.startswith("{") and '"metric"' in l:
+            line = l.strip()
+        else:
+            sys.stderr.write(l)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    sys.exit(rc if rc else (0 if line is not None else 1))
+
+
+def bind_to_gpu_numa(dev_index):
+    """Keep the rank on the CPUs of the NUMA node its GPU hangs off (host-side issue latency, pinned staging buffers)."""
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip())
+        if node < 0:
+            return {"pci": bdf, "numa_node": node, "bound": False}
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return {"pci": bdf, "numa_node": node, "bound": False}
+        os.sched_setaffinity(0, cpus)
+        return {"pci": bdf, "numa_node": node, "bound": True, "cpus": len(cpus)}
+    except Exception as e:      # noqa: BLE001  (diagnostic convenience only)
+        return {"bound": False, "error": repr(e)[:120]}
+
+
+def pool_slices(start, count, pool):
+    """Samples [start, start + count) of a step as slices of the resident pool (sample s = pool sample s mod pool)."""
+    out = []
+    while count > 0:
+        a = start % pool
+        b = min(pool, a + count)
+        out.append((a, b))
+        count -= b - a
+        start += b - a
+    return out
+
+
 def main():
+    global torch, dist
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        launch_ranks(args)                       # does not return
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
-                             "--nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d started with WORLD_SIZE=%d" % (args.gpus, world))
+    import torch as _torch
+    import torch.distributed as _dist
+    torch, dist = _torch, _dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a gfx950 GPU (no CPU fallback exists for the product path)")
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    binding = {"bound": False} if args.no_bind else bind_to_gpu_numa(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_ranks_seen = dist.get_world_size() if world > 1 else 1
 
     from statmc_amd import api, film, pipeline, sharding, synthetic
     api.setup(local_rank)
@@ -363,35 +441,60 @@ def main():
     # ---- synthetic inputs, generated in place in HBM (seeded; same generator as the tests)
     scene = synthetic.Scene(W, H, n_regions=min(12 * world, 32), seed=1, device=dev, x_offset=ox, y_offset=oy,
                             full_width=fw, full_height=fh)
-    samples = {t: [] for t in types}
-    chunk = 32
-    for s0 in range(0, S, chunk):
-        part = scene.samples(min(chunk, S - s0), seed=1000 * (rank + 1) + s0, features=types)
-        for t in types:
-            samples[t].append(part[t])
-    samples = {t: torch.cat(v, dim=0) for t, v in samples.items()}
     pipe = pipeline.BlockPipeline(layout, dev, types, filter_sd=args.filtersd, radius=r,
                                   via_host=args.backend == "gloo")
     fs = pipe.fs
+    chunk = 32
+    bytes_per_spp = 4 * args.channels * W * H
+    pool = args.pool_spp
+    if pool <= 0:
+        free_b = torch.cuda.mem_get_info(dev)[0]
+        fit = int(0.6 * free_b / bytes_per_spp)
+        pool = S if fit >= S else max(chunk, fit // chunk * chunk)
+    pool = min(pool, S)
+    samples = {t: torch.empty((pool, H, W, synthetic.CHANNELS[t]), dtype=torch.float32, device=dev) for t in types}
+    for s0 in range(0, pool, chunk):
+        part = scene.samples(min(chunk, pool - s0), seed=1000 * (rank + 1) + s0, features=types)
+        for t in types:
+            samples[t][s0:s0 + part[t].shape[0]] = part[t]
+        del part
+    batches = synthetic.sample_schedule(S) if args.schedule == "reference" else [S]
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    k_events = {"accumulate": [], "prepass": [], "halo": [], "filter": []}
+    k_events = {"accumulate": [], "prepass": [], "halo": [], "filter": [], "gather": []}
+    film_f = torch.empty(fh, fw, 3, dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
 
-    def step(record):
-        e = [ev() for _ in range(5)] if record else None
-        if record: e[0].record()
-        pipe.accumulate(samples)
-        if record: e[1].record()
-        pipe.prepass()
-        if record: e[2].record()
-        if world > 1:
-            pipe.exchange()
-        if record: e[3].record()
-        pipe.window_filter()
-        if record:
-            e[4].record()
-            for name, i in (("accumulate", 0), ("prepass", 1), ("halo", 2), ("filter", 3)):
-                k_events[name].append((e[i], e[i + 1]))
+    def timed(name, record, fn, *a):
+        if not record:
+            return fn(*a)
+        e0, e1 = ev(), ev()
+        e0.record()
+        out = fn(*a)
+        e1.record()
+        k_events[name].append((e0, e1))
+        return out
+
+    def accumulate_range(start, count):
+        for a, b in pool_slices(start, count, pool):
+            pipe.accumulate(samples if (a, b) == (0, pool) else {t: v[a:b] for t, v in samples.items()})
+
+    def step(record, probe=None):
+        if args.schedule == "reference":
+            fs.reset()                  # a progressive render starts from empty statistics (statpath.cpp:173-190)
+        pos = 0
+        for b in batches:
+            timed("accumulate", record, accumulate_range, pos, b)
+            pos += b
+            if probe is not None:
+                probe("accumulate")
+            timed("prepass", record, pipe.prepass)
+            if world > 1:
+                timed("halo", record, pipe.exchange)
+            block = timed("filter", record, pipe.window_filter)
+            if probe is not None:
+                probe("filter")
+            if world > 1 and args.gather:
+                timed("gather", record, pipe.gather_film, block, film_f)
 
     def barrier():
         torch.cuda.synchronize()
@@ -413,45 +516,122 @@ def main():
         elapsed = float(t.item())
 
     variant = api.last_filter_variant()
-    ms = {k: (sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1)) for k, v in k_events.items()}
+    n_iter = len(batches)
+    # per-STEP totals of every stage (a reference-schedule step launches each stage n_iter times)
+    ms = {k: (sum(a.elapsed_time(b) for a, b in v) / args.steps) for k, v in k_events.items()}
     px_block = W * H
     ms_per_step = elapsed * 1e3 / args.steps
     value = fw * fh * args.steps / elapsed / 1e6       # whole job: every block's pixels per step time
 
+    # ---- outside the timed region: film-f assembled on rank 0 (SURVEY 8e "final gather", 12 B/px), and the shader
+    # clock the chip holds right behind the two big kernels (one wave counting shader cycles against the 100 MHz clock)
+    gather_ms = None
+    if world > 1:
+        block = pipe.window_filter()
+        times = []
+        for _ in range(5):
+            barrier()
+            g0 = time.perf_counter()
+            pipe.gather_film(block, film_f)
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - g0) * 1e3)
+        t = torch.tensor([sorted(times)[len(times) // 2]], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gather_ms = float(t.item())
+    clocks = {}
+    if rank == 0:
+        try:
+            slots = torch.zeros(2 * 16, 2, dtype=torch.int64, device=dev)
+            idx = {"accumulate": 0, "filter": 0}
+
+            def probe(name):
+                i = idx[name]
+                if i < 16:
+                    api.clock_probe(slots[(0 if name == "accumulate" else 16) + i])
+                    idx[name] = i + 1
+            for _ in range(max(1, 16 // n_iter)):
+                step(False, probe)
+            torch.cuda.synchronize()
+            sl = slots.cpu().numpy().astype("float64")
+            for name, base in (("accumulate", 0), ("filter", 16)):
+                rows = sl[base:base + idx[name]]
+                rows = rows[rows[:, 1] > 0]
+                if len(rows):
+                    ghz = rows[:, 0] / rows[:, 1] * 0.1       # cycles per 10 ns tick
+                    clocks["after_" + name + "_GHz"] = round(float(sorted(ghz)[len(ghz) // 2]), 3)
+        except Exception as e:      # noqa: BLE001
+            clocks = {"error": repr(e)[:200]}
+    if world > 1:
+        barrier()
+
     result = None
     if rank == 0:
-        flt_gbs = FILTER_BYTES_PER_PX * px_block / (ms["filter"] * 1e-3) / 1e9
+        n_flt = n_iter
+        flt_gbs = FILTER_BYTES_PER_PX * px_block * n_flt / (ms["filter"] * 1e-3) / 1e9
+        acc_bytes_px = sum(accumulate_bytes_per_px(b, types) for b in batches)     # every launch re-reads and re-writes the state
+        n_acc_launches = sum(len(pool_slices(sum(batches[:i]), b, pool)) for i, b in enumerate(batches))
         acc_bpp = accumulate_bytes_per_px(S, types)
-        acc_gbs = acc_bpp * px_block / (ms["accumulate"] * 1e-3) / 1e9
-        pre_gbs = PREPASS_BYTES_PER_PX * px_block / (ms["prepass"] * 1e-3) / 1e9
+        acc_gbs = acc_bytes_px * px_block / (ms["accumulate"] * 1e-3) / 1e9
+        pre_gbs = PREPASS_BYTES_PER_PX * px_block * n_iter / (ms["prepass"] * 1e-3) / 1e9
         taps = (2 * r + 1) ** 2
         # fp32 VALU work of the window filter in lane-operations (a packed op = 2, v_exp_f32 = 4: quarter rate).
         # Pair-symmetric kernel: every unordered pair once, 29 for weight + gate and 4 + 4 for the two accumulations
         # = 37 per pair; one-sided kernels: 33 per directed tap.
         sym = variant.startswith("sym")
         lane_ops = (37.0 * (taps - 1) / 2 + 33.0) if sym else 33.0 * taps
-        valu_rate = lane_ops * px_block / (ms["filter"] * 1e-3) / 1e12
+        valu_rate = lane_ops * px_block * n_flt / (ms["filter"] * 1e-3) / 1e12
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        # the committed PMC traffic figures were collected on the default workload only
-        default_cfg = (W, H, S, args.channels, r) == (1920, 1080, 256, 11, 20)
+        # the committed PMC figures were collected on the default workload only
+        default_cfg = (W, H, S, args.channels, r, args.schedule) == (1920, 1080, 256, 11, 20, "single")
         if default_cfg and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath))
             except Exception:
                 traffic = {}
+        # counter-based VALU figure (profiles/: SQ_INSTS_VALU per launch of the same command, and the instruction mix of
+        # the compiled loop): SIMD issue cycles the instructions need at the 2.4 GHz peak clock / the measured time
+        valu_counter = None
+        vc = traffic.get("window_filter_valu") if isinstance(traffic, dict) else None
+        if vc and sym:
+            cyc = vc["SQ_INSTS_VALU"] * vc["cycles_per_inst"] / (256 * 4)
+            bound_ms = cyc / 2.4e6
+            valu_counter = {"SQ_INSTS_VALU_per_launch": vc["SQ_INSTS_VALU"], "issue_cycles_per_inst": vc["cycles_per_inst"],
+                            "alu_pass_bound_ms": round(bound_ms, 4), "frac": round(bound_ms / (ms["filter"] / n_flt), 4),
+                            "source": vc.get("source")}
+        pred = None
+        ppath = os.path.join(ROOT, "profiles", "block_step.json")
+        if world > 1 and os.path.exists(ppath) and (fw, fh, S, args.channels, r, args.schedule, args.grid) == (1920, 1080, 256, 11, 20, "single", "rows"):
+            try:
+                bs = json.load(open(ppath))
+                row = bs["per_rank_step_ms"].get(str(world))
+                if row is not None:
+                    pred = {"per_rank_step_ms_without_exchange": row, "n1_step_ms": bs["per_rank_step_ms"]["1"],
+                            "fraction_of_ideal": round(bs["per_rank_step_ms"]["1"] / world / row, 3), "source": bs.get("source")}
+            except Exception:
+                pred = None
         result = {
             "metric": "denoised_mpixels_per_s", "value": round(value, 3), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "n_ranks_seen": n_ranks_seen,
             "config": {
                 "workload": "StatMC accumulate+prepass+filter, %dx%d film in %d block(s) of %dx%d, %d spp, %d-channel samples, "
                             "filterradius %d, filtersd %g, G-buffers normal(sd 0.1)+albedo(sd 0.02) "
-                            "[BASELINE.json configs[2] shape, synthetic stream]" % (fw, fh, world, W, H, S, args.channels, r, args.filtersd),
+                            "[BASELINE.json %s shape, synthetic stream]%s"
+                            % (fw, fh, world, W, H, S, args.channels, r, args.filtersd,
+                               "configs[4]" if (fw, fh, S) == (3840, 2160, 1024) else "configs[2]",
+                               "" if args.schedule == "single" else
+                               "; reference schedule: %d iterations of %s samples, pre-pass + filter after each, statistics reset per step"
+                               % (n_iter, ",".join(str(b) for b in batches))),
                 "film": "%dx%d" % (fw, fh), "block_grid": "%dx%d" % (layout.gx, layout.gy),
                 "spp": S, "sample_channels": args.channels, "filter_variant": variant,
+                "schedule": args.schedule, "iterations_per_step": n_iter,
+                "resident_pool_spp": pool, "accumulate_launches_per_step": n_acc_launches,
+                "gather_in_step": bool(args.gather and world > 1),
                 "parallelism": "film blocks x%d, RCCL halo exchange" % world if world > 1 else "single GPU",
+                "rank0_binding": binding,
             },
             # the kernel that dominates the step: the sample-stream accumulation (HBM-bound)
             "roofline": {
@@ -459,33 +639,42 @@ def main():
                 "achieved": round(acc_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(acc_gbs / HBM_PEAK_GBS, 4),
                 "traffic": traffic.get("accumulate_kernel"),
-                "algorithmic_bytes_per_launch": acc_bpp * px_block, "bytes_per_px": acc_bpp,
-                "avg_launch_ms": round(ms["accumulate"], 4),
+                "algorithmic_bytes_per_launch": acc_bytes_px * px_block // n_acc_launches, "bytes_per_px": acc_bpp,
+                "avg_launch_ms": round(ms["accumulate"] / n_acc_launches, 4), "launches_per_step": n_acc_launches,
             },
-            # the kernel BASELINE.json's metric names: HBM GB/s of the window filter.  It is a
-            # (2r+1)^2-tap fp32 stencil -- bound by VALU issue, not by HBM -- so its fraction of the fp32
-            # VALU peak is given next to the (necessarily small) HBM fraction.
+            # the kernel BASELINE.json's metric names.  It is a (2r+1)^2-tap fp32 stencil: three orders of magnitude above
+            # the machine balance, bound by the fp32 VALU issue rate -- no MFMA, it is not a contraction -- so the
+            # fraction that means something is the VALU one; the (necessarily tiny) HBM figures the metric asks for
+            # ride along under "hbm".
             "roofline_filter": {
                 "kernel": ("window_filter_sym + combine_sym_kernel (%s)" if sym else "window_filter_lds<%d> + combine_parts_kernel (%%s)" % r) % variant,
-                "bound": "hbm",
-                "achieved": round(flt_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(flt_gbs / HBM_PEAK_GBS, 5),
-                "traffic": traffic.get("window_filter_sym" if sym else "window_filter_lds"),
-                "algorithmic_bytes_per_launch": FILTER_BYTES_PER_PX * px_block, "bytes_per_px": FILTER_BYTES_PER_PX,
-                "avg_launch_ms": round(ms["filter"], 4),
-                "valu": {"achieved": round(valu_rate, 2), "peak": VALU_PEAK_TOPS, "unit": "T fp32 lane-ops/s",
-                         "frac": round(valu_rate / VALU_PEAK_TOPS, 4), "lane_ops_per_px": round(lane_ops, 1),
-                         "note": "peak = 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz; a packed op counts 2, v_exp_f32 4"},
+                "bound": "valu",
+                "achieved": round(valu_rate, 2), "peak": VALU_PEAK_TOPS, "unit": "T fp32 lane-ops/s",
+                "frac": round(valu_rate / VALU_PEAK_TOPS, 4), "lane_ops_per_px": round(lane_ops, 1),
+                "note": "peak = 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz; a packed op counts 2, v_exp_f32 4",
+                "counter": valu_counter,
+                "avg_launch_ms": round(ms["filter"] / n_flt, 4), "launches_per_step": n_flt,
+                "hbm": {"achieved": round(flt_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(flt_gbs / HBM_PEAK_GBS, 5),
+                        "traffic": traffic.get("window_filter_sym" if sym else "window_filter_lds"),
+                        "algorithmic_bytes_per_launch": FILTER_BYTES_PER_PX * px_block, "bytes_per_px": FILTER_BYTES_PER_PX},
             },
+            "shader_clock": clocks,
             "kernels": {
-                "accumulate": {"avg_ms": round(ms["accumulate"], 4), "bytes_per_px": acc_bpp,
+                "accumulate": {"ms_per_step": round(ms["accumulate"], 4), "bytes_per_px": acc_bytes_px,
                                "achieved_GBs": round(acc_gbs, 1), "frac_hbm": round(acc_gbs / HBM_PEAK_GBS, 4)},
-                "prepass": {"avg_ms": round(ms["prepass"], 4), "bytes_per_px": PREPASS_BYTES_PER_PX,
+                "prepass": {"ms_per_step": round(ms["prepass"], 4), "bytes_per_px": PREPASS_BYTES_PER_PX,
                             "achieved_GBs": round(pre_gbs, 1), "frac_hbm": round(pre_gbs / HBM_PEAK_GBS, 4)},
-                "halo_exchange": {"avg_ms": round(ms["halo"], 4)},
-                "filter": {"avg_ms": round(ms["filter"], 4), "mpixels_per_s": round(px_block / ms["filter"] / 1e3, 2)},
+                "halo_exchange": {"ms_per_step": round(ms["halo"], 4)},
+                "filter": {"ms_per_step": round(ms["filter"], 4), "mpixels_per_s": round(px_block * n_flt / ms["filter"] / 1e3, 2)},
             },
         }
+        if world > 1:
+            result["gather_ms"] = round(gather_ms, 4)
+            result["gather"] = {"ms": round(gather_ms, 4), "in_step": bool(args.gather), "bytes": 12 * fw * fh,
+                                "what": "film-f blocks assembled on rank 0 (median of 5, max over ranks)"}
+            if args.gather:
+                result["kernels"]["gather"] = {"ms_per_step": round(ms["gather"], 4)}
+            result["block_step_prediction"] = pred
         if world == 1 and not args.no_host_legs:
             # secondary measurements, outside `value`: the reference's own `CUDA time` bracket through the C++ host
             # side, the tile-fed accumulation, and the raw host <-> device copy rates

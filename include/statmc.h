@@ -279,6 +279,12 @@ int statmc_tile_moments(uint16_t width, uint16_t height, int channels, const flo
 const char *statmc_last_filter_variant(void);
 int statmc_version(void);
 
+/* Measurement aid (bench.py "shader_clock"; no counterpart in the reference): one wave counts `cycles` shader clocks
+ * (s_memtime) against the constant 100 MHz clock (s_memrealtime) and writes {shader clocks, 10 ns ticks} to
+ * out[0..1] (device, int64).  Enqueued right behind a kernel it reports the clock the power manager held for that
+ * kernel.  The loop ends after `cycles` shader clocks (1 .. 2^24). */
+int statmc_clock_probe(int64_t *out, int cycles, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

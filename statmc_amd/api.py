@@ -70,7 +70,7 @@ EXPORTS = [
     "statmc_event_create", "statmc_event_destroy", "statmc_event_record", "statmc_stream_wait_event",
     "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs", "statmc_prepass_pack",
     "statmc_halo_exchange", "statmc_copy_rect", "statmc_calculate_mean_vars", "statmc_accumulate", "statmc_accumulate_tiles", "statmc_merge_tiles", "statmc_tile_moments", "statmc_film_update",
-    "statmc_last_filter_variant", "statmc_version",
+    "statmc_last_filter_variant", "statmc_version", "statmc_clock_probe",
 ]
 
 _lib = None
@@ -131,6 +131,7 @@ def load():
     lib.statmc_tile_moments.argtypes = [C.c_uint16, C.c_uint16, C.c_int, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_void_p]
     lib.statmc_film_update.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    lib.statmc_clock_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.statmc_debug_force_filter_variant.argtypes = [C.c_int]
     lib.statmc_debug_force_filter_parts.argtypes = [C.c_int]
     lib.statmc_debug_last_filter_parts.restype = C.c_int
@@ -362,3 +363,9 @@ def tile_moments(values, tile_size, out, stream=None):
     c = values.shape[2] if values.dim() == 3 else 1
     check(load().statmc_tile_moments(w, h, c, values.data_ptr(), tile_size, out.data_ptr(),
                                      stream if stream is not None else current_stream_handle()))
+
+
+def clock_probe(out, cycles=200000, stream=None):
+    """out: int64 device tensor of 2 elements <- {shader clocks counted, 10 ns ticks they took}."""
+    assert out.is_cuda and out.numel() >= 2 and out.element_size() == 8
+    check(load().statmc_clock_probe(out.data_ptr(), int(cycles), stream if stream is not None else current_stream_handle()))

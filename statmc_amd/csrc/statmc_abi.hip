@@ -212,6 +212,17 @@ int check_common(const statmc_filter_args *a, int channels) {
     return STATMC_OK;
 }
 
+// one wave: `cycles` shader clocks against the constant-rate clock (statmc_clock_probe)
+__global__ void clock_probe_kernel(long long *out, long long cycles) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long w0 = wall_clock64(), c0 = clock64();
+    unsigned long long c = c0;
+    while (c - c0 < (unsigned long long)cycles) c = clock64();   // ends: the shader clock advances
+    const unsigned long long w1 = wall_clock64();
+    out[0] = (long long)(c - c0);
+    out[1] = (long long)(w1 - w0);
+}
+
 }  // namespace
 
 extern "C" {
@@ -461,6 +472,10 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
         if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
         k.gscale0 = sqrtf(-k.g[0].dr * 1.44269504088896340736f);
         k.gscale1 = sqrtf(-k.g[1].dr * 1.44269504088896340736f);
+        // before the kernel is chosen: sym_eligible looks at k.packed (the clamped border's taps beyond the image are read
+        // from the five separate images, which a block + halo call does not have -> one-sided kernel)
+        k.packed = static_cast<const float *>(a->packed_inputs.data);
+        k.out = static_cast<float *>(a->film_filtered[0].data);
         if (statmc::sym_path_selected(k, 3)) {
             if (int rc = prepare_sym(dstate, k, a)) return rc;
         } else {
@@ -469,8 +484,6 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
                 if (int rc = partial_workspace((size_t)k.n_parts * W * H * 4 * sizeof(float), a->stream, &k.partial)) return rc;
             }
         }
-        k.packed = static_cast<const float *>(a->packed_inputs.data);
-        k.out = static_cast<float *>(a->film_filtered[0].data);
         const char *variant = "none";
         HIP_TRY(statmc::launch_lds_packed(k, S(a->stream), &variant));
         g_variant = variant;
@@ -870,6 +883,15 @@ int statmc_tile_moments(uint16_t width, uint16_t height, int channels, const flo
     statmc::TileMomentsArgs k{values, out, width, height, channels, tile_size,
                               (width + tile_size - 1) / tile_size, (height + tile_size - 1) / tile_size};
     HIP_TRY(statmc::launch_tile_moments(k, S(stream)));
+    return STATMC_OK;
+}
+
+int statmc_clock_probe(int64_t *out, int cycles, void *stream) {
+    NEED_READY();
+    if (!out) return fail(STATMC_ERR_INVALID, "null out");
+    if (cycles < 1 || cycles > (1 << 24)) return fail(STATMC_ERR_INVALID, "cycles must be in 1 .. 2^24");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, S(stream), reinterpret_cast<long long *>(out), (long long)cycles);
+    HIP_TRY(hipGetLastError());
     return STATMC_OK;
 }
 

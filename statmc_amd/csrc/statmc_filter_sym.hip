@@ -996,6 +996,9 @@ bool sym_eligible(const FilterArgs &a, int channels) {
 hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     using namespace sym;
     if (a.rx1 <= a.rx0 || a.ry1 <= a.ry0) return hipSuccess;
+    // the border kernel reads the five separate images: never launch it on a block + halo call (sym_eligible excludes
+    // that combination; this is the guard behind it)
+    if (a.sym.border_extra && a.packed) return hipErrorInvalidValue;
     a.sym.item_stride4 = kPatchP + (long long)q_rows_max(a.n_parts) * kP;
     // LDS-DMA staging needs whole 16-byte pieces: images 16-byte aligned, width and film x-origin multiples of 4 pixels
     auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };

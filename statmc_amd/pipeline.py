@@ -59,3 +59,7 @@ class BlockPipeline:
         if self.multi:
             self.exchange()
         return self.window_filter()
+
+    def gather_film(self, block, film_f=None, dst=0):
+        """The "final gather" of SURVEY 8e: every rank's filtered block -> the whole film-f image on rank `dst`."""
+        return sharding.gather_blocks(self.layout, block, film_f, dst=dst, via_host=self.via_host)

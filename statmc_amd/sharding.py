@@ -120,3 +120,34 @@ def exchange_halo(layout, padded, group=None, via_host=False):
         (L.up, padded[y0:y0 + r, :], padded[0:y0, :]),
         (L.down, padded[y1 - r:y1, :], padded[y1:y1 + L.pb, :]),
     ])
+
+
+def gather_blocks(layout, block, film_f=None, dst=0, group=None, via_host=False):
+    """Assemble the ranks' filtered blocks ([bh, bw, C] each) into the whole film on rank `dst`: SURVEY 8e's final
+    gather of film-f (12 B/px).  Row strips land in place -- a strip is a contiguous slab of the film -- and 2-D blocks
+    go through one staging tensor per block.  Returns the film on rank dst (film_f if given), None elsewhere."""
+    L = layout
+    if L.world == 1:
+        return block
+    dev = block.device
+    src = block.contiguous()
+    if via_host:
+        src = src.cpu()
+    if L.rank != dst:
+        dist.gather(src, None, dst=dst, group=group)
+        return None
+    fw, fh = L.film_size
+    c = block.shape[2]
+    if film_f is None:
+        film_f = torch.empty(fh, fw, c, dtype=block.dtype, device=dev)
+    in_place = L.gx == 1 and not via_host
+    if in_place:
+        parts = [film_f[r * L.bh:(r + 1) * L.bh] for r in range(L.world)]
+    else:
+        parts = [torch.empty(L.bh, L.bw, c, dtype=block.dtype, device=src.device) for _ in range(L.world)]
+    dist.gather(src, parts, dst=dst, group=group)
+    if not in_place:
+        for r, p in enumerate(parts):
+            bx, by = r % L.gx, r // L.gx
+            film_f[by * L.bh:(by + 1) * L.bh, bx * L.bw:(bx + 1) * L.bw].copy_(p)
+    return film_f

@@ -28,8 +28,13 @@ def test_single_gpu_line(gpu):
     assert r["value"] > 0 and r["dtype"] == "f32" and r["data"] == "synthetic" and r["vs_baseline"] is None
     assert r["config"]["film"] == "512x256" and r["config"]["filter_variant"] == "sym_r20"
     assert abs(r["value"] - 512 * 256 / r["ms_per_step"] / 1e3) < 1e-2 * r["value"]
-    for k in ("roofline", "roofline_filter"):
-        assert r[k]["bound"] == "hbm" and r[k]["unit"] == "GB/s" and abs(r[k]["frac"] - r[k]["achieved"] / r[k]["peak"]) < 1e-3
+    rl, rf = r["roofline"], r["roofline_filter"]
+    assert rl["bound"] == "hbm" and rl["unit"] == "GB/s" and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3
+    # the window filter is a VALU-bound stencil: its roofline is the fp32 issue rate, the HBM figures ride along
+    assert rf["bound"] == "valu" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["hbm"]["unit"] == "GB/s" and abs(rf["hbm"]["frac"] - rf["hbm"]["achieved"] / rf["hbm"]["peak"]) < 1e-3
+    assert r["n_ranks_seen"] == 1 and r["config"]["schedule"] == "single" and r["config"]["resident_pool_spp"] == 8
+    assert 0.5 < r["shader_clock"]["after_filter_GHz"] < 3.0 and 0.5 < r["shader_clock"]["after_accumulate_GHz"] < 3.0
     assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["cores"] >= 1 and r["cpu_baseline"]["value"] > 0
     # secondary legs: the reference's own bracket through the C++ host side, tile-fed accumulation, copy rates
     assert r["cuda_time_bracket"]["cuda_time_bracket_ms"] > 0 and r["cuda_time_bracket"]["iterations"] == 4
@@ -39,18 +44,48 @@ def test_single_gpu_line(gpu):
 
 @pytest.mark.parametrize("grid,blocks", [("rows", "1x2"), ("blocks", "2x1")])
 def test_strong_scaling_two_ranks_share_the_device(gpu, grid, blocks):
+    """`python bench.py --gpus 2` with NO launcher around it: bench.py starts its own ranks (fresh processes, before
+    any GPU call in the parent) and relays rank 0's line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device",
+           "--grid", grid] + COMMON
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = _line(out)
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["n_ranks_seen"] == 2
+    assert r["config"]["film"] == "512x256" and r["config"]["block_grid"] == blocks      # one film, two blocks
+    assert abs(r["value"] - 512 * 256 / r["ms_per_step"] / 1e3) < 1e-2 * r["value"]      # film pixels per step time
+    assert r["kernels"]["halo_exchange"]["ms_per_step"] > 0
+    assert r["gather_ms"] > 0 and r["gather"]["bytes"] == 12 * 512 * 256 and not r["gather"]["in_step"]
+    assert "cpu_baseline" not in r
+
+
+def test_launched_under_torchrun_and_gather_in_step(gpu):
+    """The driver's N > 1 launch form (python -m torch.distributed.run ... bench.py --gpus N) still works, and --gather
+    puts the assembly of film-f on rank 0 inside the step."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device",
-           "--grid", grid] + COMMON
+           "--gather"] + COMMON
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     r = _line(out)
-    assert r["n_gpus"] == 2 and r["scaling"] == "strong"
-    assert r["config"]["film"] == "512x256" and r["config"]["block_grid"] == blocks      # one film, two blocks
-    assert abs(r["value"] - 512 * 256 / r["ms_per_step"] / 1e3) < 1e-2 * r["value"]      # film pixels per step time
-    assert r["kernels"]["halo_exchange"]["avg_ms"] > 0
-    assert "cpu_baseline" not in r
+    assert r["n_gpus"] == 2 and r["n_ranks_seen"] == 2 and r["gather"]["in_step"] and r["kernels"]["gather"]["ms_per_step"] > 0
+
+
+def test_reference_schedule_with_a_sample_pool(gpu):
+    """configs[4]'s shape in small: the reference's 4, 4, 8, 16 schedule (statpath.cpp:272-279) with the denoiser after every
+    iteration, samples drawn from a resident pool smaller than the sample count."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--film", "512x256", "--spp", "32", "--steps", "2",
+                          "--warmup", "1", "--schedule", "reference", "--pool-spp", "12", "--no-host-legs", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = _line(out)
+    c = r["config"]
+    assert c["schedule"] == "reference" and c["iterations_per_step"] == 4 and c["resident_pool_spp"] == 12
+    # 4 | 4 | 8 (wraps the pool: 8..12, 0..4) | 16 (4..12, 0..8): 1 + 1 + 2 + 2 launches
+    assert c["accumulate_launches_per_step"] == 6 and r["roofline_filter"]["launches_per_step"] == 4
+    assert abs(r["value"] - 512 * 256 / r["ms_per_step"] / 1e3) < 1e-2 * r["value"]

@@ -57,6 +57,13 @@ def _worker(rank, world, port, bw, bh, r, rows, q):
                                   roi=(ox, oy, ox + bw, oy + bh), threads=1)
         x0, y0, x1, y1 = L.roi
         ok_filter = np.array_equal(out[y0:y1, x0:x1], ref[oy:oy + bh, ox:ox + bw])
+        # final gather: the blocks assembled on rank 0 are the whole-film filter output
+        whole = sharding.gather_blocks(L, torch.from_numpy(np.ascontiguousarray(out[y0:y1, x0:x1])))
+        if rank == 0:
+            full = oracle.filter_image(film["mc"], film["disc"], film["colour"], [film["g0"], film["g1"]], drs, ds, r, threads=1)
+            ok_filter = ok_filter and whole.shape == full.shape and np.array_equal(whole.numpy(), full)
+        else:
+            ok_filter = ok_filter and whole is None
         q.put((rank, ok_halo, ok_filter))
     finally:
         dist.destroy_process_group()

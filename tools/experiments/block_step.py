@@ -21,6 +21,7 @@ def ev():
 
 
 base = None
+res, detail = {}, {}
 for world in (1, 2, 4, 8):
     grid = sharding.row_strips(world)
     W, H = FW // grid[0], FH // grid[1]
@@ -63,5 +64,14 @@ for world in (1, 2, 4, 8):
     print("N=%d block %dx%d (+halo %dx%d): step %.3f ms (1/N of N=1: %.3f, efficiency %.2f)  host issue %.3f ms | accumulate %.3f  prepass %.3f  filter %.3f  parts %d"
           % (world, W, H, L.pw, L.ph, wall, base / world, base / world / wall, host, acc, pre, flt,
              api.load().statmc_debug_last_filter_parts()), flush=True)
+    res[str(world)] = round(wall, 4)
+    detail[str(world)] = {"accumulate_ms": round(acc, 4), "prepass_ms": round(pre, 4), "filter_ms": round(flt, 4), "host_issue_ms": round(host, 4),
+                          "block": "%dx%d" % (W, H), "filter_parts": api.load().statmc_debug_last_filter_parts()}
     del pipe, samples
     torch.cuda.empty_cache()
+
+import json
+out = {"per_rank_step_ms": res, "detail": detail, "spp": spp, "film": "%dx%d" % (FW, FH),
+       "source": "tools/experiments/block_step.py on one MI355X: the middle rank's block of an N-strip grid, halo exchange left out"}
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/block_step.json", "w"), indent=1)
