@@ -137,6 +137,9 @@ class Mat {
         else throw std::runtime_error("statmc_cv: convertTo supports int32 <-> float32 only");
         dst = out;
     }
+    // OpenCV takes the destination as an OutputArray, which binds to a const Mat as well (a Mat is a handle to shared
+    // pixels): buffer.cpp:34-38 converts into the outMat of a `const Buffer &`
+    void convertTo(const Mat &dst, int rtype) const { convertTo(const_cast<Mat &>(dst), rtype); }
     int rows = 0, cols = 0;
 
   private:

@@ -820,6 +820,33 @@ def test_packed_inputs_path(gpu, oracle):
     assert e.value.code == gpu.ERR_INVALID
 
 
+@pytest.mark.parametrize("spec_kw,variant", [(dict(border=1), "lds_r20"), (dict(border=1, gate=1), "lds_rt_asym"), (dict(gate=1), "sym_r20_asym")])
+def test_packed_inputs_under_non_default_specs(gpu, oracle, spec_kw, variant):
+    """Block + halo image at r = 20 under a clamped border (this combination once selected the pair-symmetric
+    kernel, whose border pass reads the five separate images a packed call does not have): the one-sided LDS kernel must
+    take it; the result equals the oracle's on the same local image under the same spec."""
+    W, H, m = 300, 56, 20
+    mc, disc, colour, gbs = stats_case(oracle, W, H, 8, seed=405)
+    ospec = oracle.FilterSpec(**spec_kw)
+    roi = (m, 0, W - m, H)                                           # ROI touches the top and bottom image border
+    ref = oracle.filter_image(mc, disc, colour, gbs, G_DR, -0.5 / FILTER_SD ** 2, RADIUS, roi=roi, spec=ospec)
+    packed = to_dev(np.concatenate([mc, disc, colour, gbs[0], gbs[1]], axis=2))
+    out = torch.zeros(H, W, 3, device=DEV)
+    a, keep = gpu.make_filter_args([], [], [], [], [], [], [], [out], [], g_sds=[SD_NORMAL, SD_ALBEDO],
+                                   filter_sd=FILTER_SD, radius=RADIUS, roi=roi, packed=packed)
+    gpu.set_filter_spec(**spec_kw)
+    try:
+        gpu.window_filter(a, 3)
+        torch.cuda.synchronize()
+        assert gpu.last_filter_variant() == variant, gpu.last_filter_variant()
+    finally:
+        gpu.set_filter_spec()
+    got = out.cpu().numpy()
+    x0, y0, x1, y1 = roi
+    for c in range(3):
+        assert rel_l2(got[y0:y1, x0:x1, c], ref[y0:y1, x0:x1, c]) <= TOL, c
+
+
 def test_prepass_pack_equals_prepass_then_pack(gpu, oracle):
     """statmc_prepass_pack (the multi-GPU path's single pass) writes the same bits as statmc_prepass
     followed by statmc_pack_filter_inputs, with and without the mean_corr / discriminator by-products."""
