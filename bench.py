@@ -394,6 +394,34 @@ def pool_slices(start, count, pool):
     return out
 
 
+def eight_channel_filter(fs, args, reps=20):
+    """The window filter with all four feature images of the 11-channel stream as G-buffers -- normal, albedo, depth,
+    material id: eight feature channels (statpath.cpp:828-835, 1096-1130) -- on the statistics the timed loop left.
+    Secondary: never part of `value`."""
+    from statmc_amd import api
+    if "depth" not in fs.state or "materialid" not in fs.state:
+        return {"skipped": "needs the 11-channel stream"}
+    rad = fs.state["radiance"]
+    names, sds = ["normal", "albedo", "depth", "materialid"], [0.1, 0.02, 1.0, 0.5]
+    out = torch.zeros_like(fs.film_f)
+    a, keep = api.make_filter_args(n=[rad["n"]], mean=[rad["mean"]], m2=[rad["m2"]], m3=[rad["m3"]], film=[rad["film_mean"]],
+                                   mean_corr=[fs.mean_corr], disc=[fs.disc], film_filtered=[out],
+                                   g_buffers=[fs.g_buffer(g) for g in names], g_sds=sds, filter_sd=args.filtersd, radius=args.radius)
+    for _ in range(3):
+        api.window_filter(a, 3)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        api.window_filter(a, 3)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return {"g_buffers": names, "g_sds": sds, "feature_channels": 8, "filter_variant": api.last_filter_variant(), "avg_ms": round(ms, 4),
+            "mpixels_per_s": round(fs.width * fs.height / ms / 1e3, 1), "bytes_per_px": FILTER_BYTES_PER_PX + 8,
+            "what": "back-to-back launches of the window filter (pre-pass not included) with normal, albedo, depth and material id as G-buffers"}
+
+
 def main():
     global torch, dist
     args = parse()
@@ -539,19 +567,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         gather_ms = float(t.item())
     clocks = {}
+    slots = torch.zeros(2 * 16, 2, dtype=torch.int64, device=dev)
+    idx = {"accumulate": 0, "filter": 0}
+
+    def probe(name):
+        i = idx[name]
+        if rank == 0 and i < 16:
+            api.clock_probe(slots[(0 if name == "accumulate" else 16) + i])
+            idx[name] = i + 1
+    for _ in range(max(1, 16 // n_iter)):     # every rank steps (the halo exchange is collective); rank 0 probes
+        step(False, probe)
+    torch.cuda.synchronize()
     if rank == 0:
         try:
-            slots = torch.zeros(2 * 16, 2, dtype=torch.int64, device=dev)
-            idx = {"accumulate": 0, "filter": 0}
-
-            def probe(name):
-                i = idx[name]
-                if i < 16:
-                    api.clock_probe(slots[(0 if name == "accumulate" else 16) + i])
-                    idx[name] = i + 1
-            for _ in range(max(1, 16 // n_iter)):
-                step(False, probe)
-            torch.cuda.synchronize()
             sl = slots.cpu().numpy().astype("float64")
             for name, base in (("accumulate", 0), ("filter", 16)):
                 rows = sl[base:base + idx[name]]
@@ -687,6 +715,7 @@ def main():
             result["cuda_time_bracket"] = leg(host_bracket, fs, args)
             result["tile_fed_accumulate"] = leg(tile_fed_accumulate, fs, samples, types)
             result["host_copies"] = leg(host_copy_times, fs, dev)
+            result["filter_8_feature_channels"] = leg(eight_channel_filter, fs, args)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(args, fs, samples, types)

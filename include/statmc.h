@@ -65,6 +65,11 @@ int statmc_get_significance(void);
  * (a repeated statmc_setup of the same device keeps what was loaded). */
 int statmc_set_t_quantiles(int table, const float *quantiles, int n_dof);
 
+/* Copies significance level, filter spec and the quantile tables (built-in or caller-supplied) of `src_device` to
+ * `dst_device`; both must have been set up.  All of these are per-device state: a host that spreads one Estimator's
+ * film over several devices (statmc::FilmShards) calls this so that every block is filtered under the same rules. */
+int statmc_copy_device_settings(int src_device, int dst_device);
+
 /* ---- filter spec: everything about cv::cuda::stat_denoiser::filter<T> that the reference tree does
  * not fix (its CUDA source is in the un-vendored submodule src/ext/opencv_contrib, .gitmodules:19-21;
  * only the call sites src/statistics/estimator.cpp:437-487 and the buffer meanings README.md:317-325

@@ -166,12 +166,19 @@ namespace cuda {
 // Estimator::Upload / Denoise / Download / Synchronize (estimator.cpp:409-489) run unchanged and overlap.  Anything
 // else that touches the stream flushes the noted copies first.  STATMC_CV_BANDS=1 in the environment switches the
 // pipeline off (0 / unset: automatic, n: n bands).
+// Contract that differs from OpenCV's pageable cudaMemcpyAsync: the host image is read when its copy is ENQUEUED (at the
+// next filter<T> / download / waitForCompletion on the stream), not inside upload() -- the pixels of a Mat handed to
+// upload() must stay unchanged until the stream has been synchronised.  The reference's render loop satisfies this
+// (statpath.cpp:397-417: Upload .. Synchronize with no host write in between).  The noted copy holds a reference to both
+// the host Mat and the device allocation, so destroying or re-creating either side before the flush is safe.
 namespace detail {
 struct PendingUpload {
     uchar *dst;
     Mat src;          // keeps the host image alive until the copy has been enqueued and completed
     size_t rowBytes;
     int rows;
+    std::shared_ptr<void> dstMem;   // ... and the device image: a GpuMat destroyed or re-created before the copy is enqueued
+                                    // must not leave a dangling destination
 };
 struct StreamState : statmc::bands::Streams {
     std::vector<PendingUpload> pending;     // noted by GpuMat::upload, not yet enqueued
@@ -255,7 +262,7 @@ class GpuMat {
             auto &pending = s.state().pending;
             for (auto &p : pending)
                 if (p.dst == data) { p.src = m; return; }
-            pending.push_back(detail::PendingUpload{data, m, step, rows});
+            pending.push_back(detail::PendingUpload{data, m, step, rows, mem_});
         }
     }
     void download(Mat &m, Stream &s) const {

@@ -1383,6 +1383,10 @@ class FilmShards {
     // or a flush of the device accumulation); returns with the work enqueued and the Estimator's stream waiting for it.
     void Denoise() {
         est.Synchronize();   // the cuts below read what the Estimator's stream wrote
+        // filter spec, significance level and quantile tables are per-device state: every block device filters under the
+        // Estimator's device's rules (a seam between blocks under different specs would not be the unsharded result)
+        for (const Block &B : blocks)
+            if (B.device != est.deviceIndex()) check(statmc_copy_device_settings(est.deviceIndex(), B.device));
         const Estimator::Tables &t = est.rgbTables[DenoiseGroup];
         const DeviceImage &colour = est.denoiseFilm ? est.filmBuffer.gpuMat : t.film[0];
         const DeviceImage &out = est.denoiseFilm ? est.filmFilteredBuffer.gpuMat : t.filmFiltered[0];

@@ -64,7 +64,7 @@ class StatType(C.Structure):
 
 EXPORTS = [
     "statmc_last_error", "statmc_setup", "statmc_set_device", "statmc_set_significance", "statmc_get_significance", "statmc_set_t_quantiles",
-    "statmc_set_filter_spec", "statmc_get_filter_spec",
+    "statmc_set_filter_spec", "statmc_get_filter_spec", "statmc_copy_device_settings",
     "statmc_malloc", "statmc_free", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_download",
     "statmc_stream_create", "statmc_stream_destroy", "statmc_synchronize",
     "statmc_event_create", "statmc_event_destroy", "statmc_event_record", "statmc_stream_wait_event",
@@ -100,6 +100,7 @@ def load():
     lib.statmc_set_t_quantiles.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_int]
     lib.statmc_set_filter_spec.argtypes = [C.POINTER(FilterSpec)]
     lib.statmc_get_filter_spec.argtypes = [C.POINTER(FilterSpec)]
+    lib.statmc_copy_device_settings.argtypes = [C.c_int, C.c_int]
     lib.statmc_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     lib.statmc_free.argtypes = [C.c_void_p]
     lib.statmc_malloc_host.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]

@@ -174,7 +174,13 @@ int prepare_sym(const DeviceState &d, statmc::FilterArgs &k, const statmc_filter
     k.n_parts = parts_for_whole_image(k, d.cus, true);
     statmc::sym_geometry(k);
     float *ws = nullptr;
-    const size_t patch_floats = (statmc::sym_patch_floats(k, k.n_parts) + 3) & ~(size_t)3;
+    // sized for the whole local image whatever region this call filters: the bands of the Upload / Denoise / Download
+    // pipeline then share one allocation (growing it mid-pipeline means a stream synchronisation and a hipFree between
+    // two bands)
+    statmc::FilterArgs whole = k;
+    whole.rx0 = 0; whole.ry0 = 0; whole.rx1 = k.width; whole.ry1 = k.height;
+    statmc::sym_geometry(whole);
+    const size_t patch_floats = (statmc::sym_patch_floats(whole, k.n_parts) + 3) & ~(size_t)3;
     const size_t image_floats = pair ? (size_t)9 * k.width * k.height : 0;
     const size_t extra_floats = k.border == STATMC_BORDER_CLAMP ? (size_t)4 * k.width * k.height : 0;
     if (int rc = partial_workspace((patch_floats + image_floats + extra_floats) * sizeof(float), a->stream, &ws)) return rc;
@@ -242,6 +248,10 @@ int statmc_setup(int device) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(STATMC_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
                     prop.gcnArchName);
+    // check, table upload and `ready` under one lock: two threads setting up the same device must not both upload (the
+    // second upload would overwrite quantiles a concurrent statmc_set_t_quantiles has just loaded)
+    static std::mutex setup_mu;
+    std::lock_guard<std::mutex> setup_lk(setup_mu);
     {
         std::lock_guard<std::mutex> lk(g_mu);
         if (g_dev[device].ready) return STATMC_OK;  // idempotent: settings and loaded tables of the device stay
@@ -307,6 +317,33 @@ int statmc_set_t_quantiles(int table, const float *quantiles, int n_dof) {
     std::vector<float> t(4096);
     for (int i = 0; i < 4096; i++) t[i] = quantiles[i < n_dof ? i : n_dof - 1];
     HIP_TRY(statmc::upload_t_table(table, t.data()));
+    return STATMC_OK;
+}
+
+// significance level, filter spec and the six quantile tables of `src_device` -> `dst_device` (both set up): what a host
+// that shards one Estimator's film over several devices calls before it filters blocks there (FilmShards).
+int statmc_copy_device_settings(int src_device, int dst_device) {
+    DeviceState src;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto a = g_dev.find(src_device), b = g_dev.find(dst_device);
+        if (a == g_dev.end() || !a->second.ready || b == g_dev.end() || !b->second.ready)
+            return fail(STATMC_ERR_NO_DEVICE, "statmc_setup() has not been called for device %d or %d", src_device, dst_device);
+        src = a->second;
+    }
+    if (src_device == dst_device) return STATMC_OK;
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    std::vector<float> tables((size_t)STATMC_TQ_N_TABLES * STATMC_TQ_N_DOF);
+    hipError_t e = hipSetDevice(src_device);
+    if (e == hipSuccess) e = hipMemcpy(tables.data(), statmc::t_table_device_ptr(0), tables.size() * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipSetDevice(dst_device);
+    for (int t = 0; t < STATMC_TQ_N_TABLES && e == hipSuccess; t++) e = statmc::upload_t_table(t, tables.data() + (size_t)t * STATMC_TQ_N_DOF);
+    (void)hipSetDevice(cur);
+    if (e != hipSuccess) return fail(STATMC_ERR_HIP, "copying the quantile tables: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_dev[dst_device].alpha_index = src.alpha_index;
+    g_dev[dst_device].spec = src.spec;
     return STATMC_OK;
 }
 
@@ -498,16 +535,24 @@ int statmc_window_filter(const statmc_filter_args *a, int channels) {
         k.g[g].channels = gc;
         k.g[g].dr = a->g_dr_factors[g];
     }
-    if (statmc::fast_path_eligible(k, channels)) {
+    const bool lds_ok = statmc::fast_path_eligible(k, channels);   // one-sided LDS kernel: at most six feature channels
+    if (lds_ok || statmc::sym_eligible(k, channels)) {
         if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
-        statmc::set_feature_layout(k);
-        k.n_parts = parts_for_whole_image(k, dstate.cus, false);
+        if (lds_ok) {
+            statmc::set_feature_layout(k);
+            k.n_parts = parts_for_whole_image(k, dstate.cus, false);
+        } else {
+            k.n_parts = 1;
+        }
     } else {
         k.n_parts = 1;
     }
-    const bool fast = statmc::lds_path_selected(k, channels);
-    const bool sym = fast && statmc::sym_path_selected(k, channels);
+    // the pair-symmetric kernel (r = 20) also takes G-buffer sets the one-sided kernel has no slots for: two RGB + two
+    // 1-channel images (normal, albedo, depth, material id)
+    const bool sym = statmc::sym_path_selected(k, channels);
+    const bool fast = sym || statmc::lds_path_selected(k, channels);
     if (sym) {
+        statmc::sym_feature_slots(k);
         if (int rc = prepare_sym(dstate, k, a, channels == 1)) return rc;
     } else if (fast) {
         const int per_px = channels == 3 ? 4 : 8;

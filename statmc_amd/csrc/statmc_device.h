@@ -125,6 +125,11 @@ struct FilterArgs {
         int pair;                 // filter<float>: f_active (1 or 2) 1-channel buffers (f_mean_corr / f_disc / f_colour / f_out) per launch
         float *pair_images;       // ... staged from three [height][width][3] images this launch packs them into
         float4 *border_extra;     // border rule "clamp": per pixel, the sums over the taps beyond the image (border_virtual_kernel)
+        // eight feature planes (NG = 8 build): up to two RGB and up to two 1-channel G-buffers of the argument list, sorted
+        // into slots by sym_feature_slots(); scale = sqrt(-dr * log2 e), 0 = empty slot (never read)
+        int g8;
+        const float *rgb[2], *sc[2];
+        float rgb_scale[2], sc_scale[2];
     } sym;
 };
 
@@ -172,6 +177,7 @@ bool lds_path_selected(const FilterArgs &a, int channels);
 void set_filter_variant_override(int v);
 // pair-symmetric kernel
 bool sym_eligible(const FilterArgs &a, int channels);
+void sym_feature_slots(FilterArgs &a);                       // fills a.sym.g8 / rgb / sc from a.g[] (eligible sets only)
 bool sym_path_selected(const FilterArgs &a, int channels);   // eligible and not overridden
 void sym_geometry(FilterArgs &a);                            // fills a.sym.tx0 .. nty from the ROI and film origin
 int sym_tiles(const FilterArgs &a);

@@ -52,6 +52,8 @@
 #include <set>
 #include <utility>
 
+#include <stdio.h>
+
 #include "statmc_device.h"
 #include "statmc_filter_common.h"
 
@@ -889,11 +891,13 @@ bool lds_path_selected(const FilterArgs &a, int channels) {
     return fast_path_eligible(a, channels) && a.spatial_tab != nullptr && g_variant_override != 1;
 }
 
-static const char *sym_variant_name(const FilterArgs &a) {
-    const bool joint = a.channel_rule == STATMC_CHANNELS_JOINT, clamp = a.border == STATMC_BORDER_CLAMP;
-    if (a.gate == STATMC_GATE_ASYMMETRIC)
-        return joint ? (clamp ? "sym_r20_asym_joint_clamp" : "sym_r20_asym_joint") : (clamp ? "sym_r20_asym_clamp" : "sym_r20_asym");
-    return joint ? (clamp ? "sym_r20_joint_clamp" : "sym_r20_joint") : (clamp ? "sym_r20_clamp" : "sym_r20");
+// "sym_r20[_f][_g8][_asym][_joint][_clamp]": float buffers, eight feature planes, then the spec's non-default choices
+static const char *sym_variant_name(const FilterArgs &a, int channels) {
+    static thread_local char name[64];
+    const bool joint = a.channel_rule == STATMC_CHANNELS_JOINT && channels == 3;
+    snprintf(name, sizeof(name), "sym_r20%s%s%s%s%s", channels == 1 ? "_f" : "", a.sym.g8 ? "_g8" : "",
+             a.gate == STATMC_GATE_ASYMMETRIC ? "_asym" : "", joint ? "_joint" : "", a.border == STATMC_BORDER_CLAMP ? "_clamp" : "");
+    return name;
 }
 
 // Launch of the one-sided LDS kernel for the arguments' spec.  The default membership test has a compile-time-radius
@@ -928,18 +932,18 @@ static hipError_t launch_lds_spec(const FilterArgs &a, hipStream_t s, const char
 // Window filter reading the 15-channel block + halo image (multi-GPU path): LDS kernels only.
 hipError_t launch_lds_packed(const FilterArgs &a, hipStream_t s, const char **variant) {
     if (a.sym.patch != nullptr) {
-        *variant = sym_variant_name(a);
+        *variant = sym_variant_name(a, 3);
         return launch_sym(a, s);
     }
     return launch_lds_spec<0>(a, s, variant);
 }
 
 hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s, const char **variant) {
-    const bool fast = lds_path_selected(a, channels);
-    if (fast && a.sym.patch != nullptr) {
-        *variant = channels == 1 ? (a.border == STATMC_BORDER_CLAMP ? "sym_r20_f_clamp" : "sym_r20_f") : sym_variant_name(a);
+    if (a.sym.patch != nullptr) {   // the C-ABI layer prepared the pair-symmetric kernel's workspace: that kernel was chosen
+        *variant = sym_variant_name(a, channels);
         return launch_sym(a, s);
     }
+    const bool fast = lds_path_selected(a, channels);
     if (fast) {
         if (channels == 3) return launch_lds_spec<0>(a, s, variant);
         return a.f_active >= 3 ? launch_lds_spec<3>(a, s, variant) : a.f_active == 2 ? launch_lds_spec<2>(a, s, variant) : launch_lds_spec<1>(a, s, variant);

@@ -48,6 +48,7 @@
 //     border (this kernel sums the taps inside the image, border_virtual_kernel in statmc_filter.hip adds the taps
 //     beyond it for the pixels next to an edge, combine_sym_kernel joins the two).
 #include <algorithm>
+#include <cmath>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -108,9 +109,7 @@ constexpr int kW = 32 * kPx;              // 128 tile columns: half a wave per r
 constexpr int kRows = 8;                  // tile rows: wave (t, h) owns rows t (lanes 0-31) and t + 4 (lanes 32-63)
 constexpr int kSlots = kRows + 1;         // LDS row ring
 constexpr int kP = kW + 2 * kR;           // 296 staged columns per row
-constexpr int kIn = 15;                   // input planes per row
 constexpr int kQ = 8;                     // accumulator planes per row: 2 copies x (r, g, b, w)
-constexpr int kSlotFloats = (kIn + kQ) * kP;
 constexpr int kThreads = 512;
 constexpr int kSteps = kR + 1;            // dy = 0 .. 20
 constexpr int kTabW = 2 * kR + 7;         // entries per window row of the spatial table: index dx + kR + 3
@@ -124,12 +123,22 @@ constexpr int kPatchP = kRows * kW;       // float4 per patch: p-side piece
 // arbitration, finish their sweep first and would otherwise idle at the barrier; while they wait for their fetches
 // and LDS reads the half-1 wave of the SIMD sweeps (tools/experiments/stamps_sym.py).
 constexpr int kWaveCols = 44;
-constexpr int kRawFloats = kWaveCols * 15;                  // 660 floats = 165 pieces per wave
-constexpr int kRawTotal = 4 * kRawFloats;
 __host__ __device__ inline int wave_col0(int wave) { return wave < 2 ? 44 * wave : 88 + 40 * (wave - 2); }
 __host__ __device__ inline int wave_cols(int wave) { return wave < 2 ? 44 : wave < 4 ? 40 : 0; }
-constexpr size_t kLdsBytes = (size_t)(kSlots * kSlotFloats + 2 * kTabPad + kRawTotal) * sizeof(float);
-static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+// NG = feature planes per staged row.  6: up to two RGB G-buffers (the shipped normal + albedo).  8: the same plus up to
+// two 1-channel G-buffers (depth, material id: statpath.cpp:828-835, 1096-1130) -- 17 input + 8 accumulator planes per
+// row: 9 x 25 x 168 floats = 151 200 B of ring, and the LDS-DMA landing area shrinks to exactly the 168 columns a row
+// has (wave w's columns at wave_col0(w) x 17 floats) so that the lot still fits the CU's 160 KiB: 163 392 B.
+template <int NG>
+struct Planes {
+    static constexpr int kIn = NG + 9;                       // input planes per row: features, mean, -D, colour
+    static constexpr int cMC = NG, cND = NG + 3, cCOL = NG + 6;
+    static constexpr int kSlotFloats = (kIn + kQ) * kP;
+    static constexpr int kRawTotal = NG == 6 ? 4 * kWaveCols * 15 : kP * kIn;
+    static constexpr size_t kLdsBytes = (size_t)(kSlots * kSlotFloats + 2 * kTabPad + kRawTotal) * sizeof(float);
+    __host__ __device__ static inline int raw_off(int wave) { return NG == 6 ? (wave & 3) * kWaveCols * 15 : wave_col0(wave & 3) * kIn; }
+};
+static_assert(Planes<6>::kLdsBytes <= 160 * 1024 && Planes<8>::kLdsBytes <= 160 * 1024, "LDS budget");
 
 __host__ __device__ inline int step_lo(int part, int n_parts) { return (kSteps * part) / n_parts; }
 __host__ __device__ inline int q_rows_max(int n_parts) { return (kSteps + n_parts - 1) / n_parts + kRows - 1; }  // rows s_a .. s_b+6
@@ -137,8 +146,9 @@ __host__ __device__ inline int q_rows_max(int n_parts) { return (kSteps + n_part
 // The lane's own 4 pixels.  Their values enter the packed instructions as broadcasts of ONE half of a register
 // pair (op_sel), so two different scalars share every pair: 6 + 6 + 4 pairs per pixel instead of 15 + 15
 // registers holding (x, x) duplicates -- which is what a `v2f{x, x}` splat of a scalar compiles to.
+template <int NG>
 struct Lane {
-    v2f pg[kPx][3];    // scaled features: (n.x, n.y), (n.z, a.x), (a.y, a.z)
+    v2f pg[kPx][NG / 2];   // scaled features: (n.x, n.y), (n.z, a.x), (a.y, a.z)[, (depth, material id)]
     v2f ms[kPx][3];    // per channel (corrected mean, discriminator)
     v2f pc[kPx][2];    // colour (r, g), (b, -)
     v2f acc[kPx][3];   // .x even taps, .y odd taps of every read group
@@ -205,8 +215,8 @@ __device__ __forceinline__ v2f pair_of(const v4f &v) {
 }
 
 // range weight exponent of tap pair H against the lane's 4 pixels: tab - |k_n dn|^2 - |k_a da|^2 (log2 domain)
-template <int H, unsigned MASK>
-__device__ __forceinline__ void range_exponent(const Lane &st, const v4f *g, const float *__restrict__ tab, int j, v2f (&e)[kPx]) {
+template <int H, unsigned MASK, int NG>
+__device__ __forceinline__ void range_exponent(const Lane<NG> &st, const v4f *g, const float *__restrict__ tab, int j, v2f (&e)[kPx]) {
     using M = Taps<H, MASK>;
     v2f tp[kPx];
 #pragma unroll
@@ -216,7 +226,7 @@ __device__ __forceinline__ void range_exponent(const Lane &st, const v4f *g, con
     // then starts behind the table read)
     for (int k = 0; k < kPx; k++) if (M::on(k)) { const v2f d = sub_bc(st.pg[k][0], 0, pair_of<H>(g[0])); e[k] = -d * d; }
 #pragma unroll
-    for (int ch = 1; ch < 6; ch++) {
+    for (int ch = 1; ch < NG; ch++) {
 #pragma unroll
         for (int k = 0; k < kPx; k++) if (M::on(k)) { const v2f d = sub_bc(st.pg[k][ch >> 1], ch & 1, pair_of<H>(g[ch])); e[k] = __builtin_elementwise_fma(-d, d, e[k]); }
     }
@@ -227,8 +237,8 @@ __device__ __forceinline__ void range_exponent(const Lane &st, const v4f *g, con
 // membership gate and weight of tap pair H: w = member ? exp2(e) : 0   (mcn: corrected mean planes 0..2, -D planes 3..5)
 // PAIR (two float buffers in the (x, y) channels): one weight per buffer, w for buffer 0 and wb for buffer 1 -- the
 // buffers share the range weight and gate separately (filter<float>: every buffer is its own 1-channel test).
-template <int H, unsigned MASK, int MODE>
-__device__ __forceinline__ void gate_weight(const Lane &st, const v4f *mcn, const v2f (&e)[kPx], v2f (&w)[kPx], v2f (&wb)[kPx]) {
+template <int H, unsigned MASK, int MODE, int NG>
+__device__ __forceinline__ void gate_weight(const Lane<NG> &st, const v4f *mcn, const v2f (&e)[kPx], v2f (&w)[kPx], v2f (&wb)[kPx]) {
     using M = Taps<H, MASK>;
     constexpr bool PAIR = MODE == kModePair;
     constexpr int NC = PAIR ? 2 : 3;
@@ -316,8 +326,8 @@ __device__ __forceinline__ void gate_weight(const Lane &st, const v4f *mcn, cons
 // p side: the lane's pixels collect w * colour_q; q side (SYM): the taps' accumulators collect w * colour_p.
 // PAIR: the four sums per pixel are (sum w0 c0, sum w1 c1, sum w0, sum w1) -- acc[0], acc[1], acc[2], sw -- instead of
 // (sum w r, sum w g, sum w b, sum w); the same four packed operations per side.
-template <int H, unsigned MASK, bool SYM, int MODE>
-__device__ __forceinline__ void accumulate(Lane &st, const v4f *col, const v2f (&w)[kPx], const v2f (&wb)[kPx], v2f (&qv)[4]) {
+template <int H, unsigned MASK, bool SYM, int MODE, int NG>
+__device__ __forceinline__ void accumulate(Lane<NG> &st, const v4f *col, const v2f (&w)[kPx], const v2f (&wb)[kPx], v2f (&qv)[4]) {
     using M = Taps<H, MASK>;
     constexpr bool PAIR = MODE == kModePair;
     if constexpr (PAIR) {
@@ -389,31 +399,34 @@ __device__ __forceinline__ void lds_wait(v4f &a, v4f &b, v4f &c, v4f &d) {
 // planes of the taps).  PIPE: the statistics planes are requested before the feature planes and the colour /
 // accumulator planes before the gates, by hand-placed reads, so that two of the three phases find their operands
 // in registers; otherwise the compiler's own loads (each phase waits for its operands).
-template <unsigned MASK, bool SYM, bool PIPE, int MODE>
-__device__ __forceinline__ void chunk(Lane &st, const float *__restrict__ row, const float *__restrict__ tab, float *__restrict__ qrow, int j) {
+template <unsigned MASK, bool SYM, bool PIPE, int MODE, int NG>
+__device__ __forceinline__ void chunk(Lane<NG> &st, const float *__restrict__ row, const float *__restrict__ tab, float *__restrict__ qrow, int j) {
     using M0 = Taps<0, MASK>;
     using M1 = Taps<1, MASK>;
     constexpr bool PAIR = MODE == kModePair;
+    constexpr int C_MC = Planes<NG>::cMC, C_COL = Planes<NG>::cCOL;
     const float *r = row + 4 * j;
-    v4f g[6], mcn[6], col[3], q4[4];
+    v4f g[NG], mcn[6], col[3], q4[4];
     v2f e0[kPx], e1[kPx], w0[kPx], w1[kPx], wb0[kPx], wb1[kPx];   // wb*: second buffer's weights (PAIR)
     unsigned ra = 0, qa = 0;
     if constexpr ((kAblate & 32) != 0) {   // timing only: operands from nowhere (no LDS reads in the sweep)
 #pragma unroll
-        for (int ch = 0; ch < 6; ch++) { asm volatile("" : "=v"(g[ch])); asm volatile("" : "=v"(mcn[ch])); }
+        for (int ch = 0; ch < NG; ch++) asm volatile("" : "=v"(g[ch]));
+#pragma unroll
+        for (int ch = 0; ch < 6; ch++) asm volatile("" : "=v"(mcn[ch]));
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) asm volatile("" : "=v"(col[ch]));
 #pragma unroll
         for (int v = 0; v < 4; v++) asm volatile("" : "=v"(q4[v]));
-        if constexpr (M0::any()) range_exponent<0, MASK>(st, g, tab, j, e0);
-        if constexpr (M1::any()) range_exponent<1, MASK>(st, g, tab, j, e1);
-        if constexpr (M0::any()) gate_weight<0, MASK, MODE>(st, mcn, e0, w0, wb0);
-        if constexpr (M1::any()) gate_weight<1, MASK, MODE>(st, mcn, e1, w1, wb1);
+        if constexpr (M0::any()) range_exponent<0, MASK, NG>(st, g, tab, j, e0);
+        if constexpr (M1::any()) range_exponent<1, MASK, NG>(st, g, tab, j, e1);
+        if constexpr (M0::any()) gate_weight<0, MASK, MODE, NG>(st, mcn, e0, w0, wb0);
+        if constexpr (M1::any()) gate_weight<1, MASK, MODE, NG>(st, mcn, e1, w1, wb1);
         v2f qa2[4], qb2[4];
 #pragma unroll
         for (int v = 0; v < 4; v++) { qa2[v] = pair_of<0>(q4[v]); qb2[v] = pair_of<1>(q4[v]); }
-        if constexpr (M0::any()) accumulate<0, MASK, SYM, MODE>(st, col, w0, wb0, qa2);
-        if constexpr (M1::any()) accumulate<1, MASK, SYM, MODE>(st, col, w1, wb1, qb2);
+        if constexpr (M0::any()) accumulate<0, MASK, SYM, MODE, NG>(st, col, w0, wb0, qa2);
+        if constexpr (M1::any()) accumulate<1, MASK, SYM, MODE, NG>(st, col, w1, wb1, qb2);
         if constexpr (SYM) {
 #pragma unroll
             for (int v = 0; v < 4; v++) asm volatile("" ::"v"(qa2[v]), "v"(qb2[v]));
@@ -431,9 +444,9 @@ __device__ __forceinline__ void chunk(Lane &st, const float *__restrict__ row, c
         mcn[5] = lds_read128<(C_MC + 5) * kP * 4>(ra);
     }
 #pragma unroll
-    for (int ch = 0; ch < 6; ch++) g[ch] = *reinterpret_cast<const v4f *>(r + (C_G0 + ch) * kP);
-    if constexpr (M0::any()) range_exponent<0, MASK>(st, g, tab, j, e0);
-    if constexpr (M1::any()) range_exponent<1, MASK>(st, g, tab, j, e1);
+    for (int ch = 0; ch < NG; ch++) g[ch] = *reinterpret_cast<const v4f *>(r + ch * kP);
+    if constexpr (M0::any()) range_exponent<0, MASK, NG>(st, g, tab, j, e0);
+    if constexpr (M1::any()) range_exponent<1, MASK, NG>(st, g, tab, j, e1);
     if constexpr (PIPE) {
         col[0] = lds_read128<(C_COL + 0) * kP * 4>(ra);
         col[1] = lds_read128<(C_COL + 1) * kP * 4>(ra);
@@ -453,8 +466,8 @@ __device__ __forceinline__ void chunk(Lane &st, const float *__restrict__ row, c
         for (int ch = 0; ch < 6; ch++)
             if (!(PAIR && ch % 3 == 2)) mcn[ch] = *reinterpret_cast<const v4f *>(r + (C_MC + ch) * kP);
     }
-    if constexpr (M0::any()) gate_weight<0, MASK, MODE>(st, mcn, e0, w0, wb0);
-    if constexpr (M1::any()) gate_weight<1, MASK, MODE>(st, mcn, e1, w1, wb1);
+    if constexpr (M0::any()) gate_weight<0, MASK, MODE, NG>(st, mcn, e0, w0, wb0);
+    if constexpr (M1::any()) gate_weight<1, MASK, MODE, NG>(st, mcn, e1, w1, wb1);
 #if STATMC_SYM_COUNT
     if constexpr (MASK == 0xFFFFu && SYM && MODE == kModeRgb) {   // full read groups of the default mode
         bool any0 = false, any1 = false;
@@ -489,8 +502,8 @@ __device__ __forceinline__ void chunk(Lane &st, const float *__restrict__ row, c
 #pragma unroll
         for (int v = 0; v < 4; v++) { qa2[v] = pair_of<0>(q4[v]); qb2[v] = pair_of<1>(q4[v]); }
     }
-    if constexpr (M0::any()) accumulate<0, MASK, SYM, MODE>(st, col, w0, wb0, qa2);
-    if constexpr (M1::any()) accumulate<1, MASK, SYM, MODE>(st, col, w1, wb1, qb2);
+    if constexpr (M0::any()) accumulate<0, MASK, SYM, MODE, NG>(st, col, w0, wb0, qa2);
+    if constexpr (M1::any()) accumulate<1, MASK, SYM, MODE, NG>(st, col, w1, wb1, qb2);
     if constexpr (SYM) {
         if constexpr ((kAblate & 64) != 0) {   // timing only: no write-back of the accumulators
 #pragma unroll
@@ -525,21 +538,21 @@ struct Range {
     static constexpr int last_full() { for (int j = kChunks - 1; j >= 0; j--) if (m(j) == kFull) return j; return -1; }
 };
 
-template <int LO, int HI, bool SYM, int MODE>
-__device__ __forceinline__ void sweep_range(Lane &st, const float *row, const float *tab, float *qrow) {
+template <int LO, int HI, bool SYM, int MODE, int NG>
+__device__ __forceinline__ void sweep_range(Lane<NG> &st, const float *row, const float *tab, float *qrow) {
     using R = Range<LO, HI>;
     constexpr int j0 = R::first(), j1 = R::last(), f0 = R::first_full(), f1 = R::last_full();
     static_assert(j0 <= j1, "empty range");
     constexpr bool has_full = f0 <= f1;
     constexpr int lo_end = has_full ? f0 : j1 + 1;      // masked groups j0 .. lo_end-1, full f0 .. f1, masked f1+1 .. j1
     static_assert(lo_end - j0 <= 2 && (!has_full || j1 - f1 <= 2), "more than two cut groups at an end");
-    if constexpr (j0 < lo_end) chunk<R::m(j0), SYM, kPipe, MODE>(st, row, tab, qrow, j0);
-    if constexpr (j0 + 1 < lo_end) chunk<R::m(j0 + 1), SYM, kPipe, MODE>(st, row, tab, qrow, j0 + 1);
+    if constexpr (j0 < lo_end) chunk<R::m(j0), SYM, kPipe, MODE, NG>(st, row, tab, qrow, j0);
+    if constexpr (j0 + 1 < lo_end) chunk<R::m(j0 + 1), SYM, kPipe, MODE, NG>(st, row, tab, qrow, j0 + 1);
     if constexpr (has_full) {
 #pragma unroll 1
-        for (int j = f0; j <= f1; j++) chunk<R::kFull, SYM, kPipe, MODE>(st, row, tab, qrow, j);
-        if constexpr (f1 + 1 <= j1) chunk<R::m(f1 + 1 <= j1 ? f1 + 1 : 0), SYM, kPipe, MODE>(st, row, tab, qrow, f1 + 1);
-        if constexpr (f1 + 2 <= j1) chunk<R::m(f1 + 2 <= j1 ? f1 + 2 : 0), SYM, kPipe, MODE>(st, row, tab, qrow, f1 + 2);
+        for (int j = f0; j <= f1; j++) chunk<R::kFull, SYM, kPipe, MODE, NG>(st, row, tab, qrow, j);
+        if constexpr (f1 + 1 <= j1) chunk<R::m(f1 + 1 <= j1 ? f1 + 1 : 0), SYM, kPipe, MODE, NG>(st, row, tab, qrow, f1 + 1);
+        if constexpr (f1 + 2 <= j1) chunk<R::m(f1 + 2 <= j1 ? f1 + 2 : 0), SYM, kPipe, MODE, NG>(st, row, tab, qrow, f1 + 2);
     }
 }
 
@@ -551,65 +564,108 @@ __device__ __forceinline__ void sweep_range(Lane &st, const float *row, const fl
 // 1.56 at 7 and 1.75 at 11, which cut two.  The SIMD is busy either way.)
 // dy = 0: the pairs inside a row are the taps dx >= 1 (the accumulator row is the wave's own row); the pixel's own
 // tap dx = 0 feeds the p side only.
-template <int HF, int MODE>
-__device__ __forceinline__ void eval_half_row(Lane &st, const float *row, const float *tab, float *qrow, bool dy0) {
+template <int HF, int MODE, int NG>
+__device__ __forceinline__ void eval_half_row(Lane<NG> &st, const float *row, const float *tab, float *qrow, bool dy0) {
     if constexpr (HF == 0) {
         if (dy0) {
-            sweep_range<0, 0, false, MODE>(st, row, tab, qrow);
-            if constexpr (kSplit >= 1) sweep_range<1, kSplit, true, MODE>(st, row, tab, qrow);
+            sweep_range<0, 0, false, MODE, NG>(st, row, tab, qrow);
+            if constexpr (kSplit >= 1) sweep_range<1, kSplit, true, MODE, NG>(st, row, tab, qrow);
         } else {
-            sweep_range<-kR, kSplit, true, MODE>(st, row, tab, qrow);
+            sweep_range<-kR, kSplit, true, MODE, NG>(st, row, tab, qrow);
         }
     } else {
         if constexpr (kSplit >= 1) {
-            sweep_range<kSplit + 1, kR, true, MODE>(st, row, tab, qrow);
+            sweep_range<kSplit + 1, kR, true, MODE, NG>(st, row, tab, qrow);
         } else {
-            if (dy0) sweep_range<1, kR, true, MODE>(st, row, tab, qrow);
-            else sweep_range<kSplit + 1, kR, true, MODE>(st, row, tab, qrow);
+            if (dy0) sweep_range<1, kR, true, MODE, NG>(st, row, tab, qrow);
+            else sweep_range<kSplit + 1, kR, true, MODE, NG>(st, row, tab, qrow);
         }
     }
 }
 
-// pixel (x, yrow) of the five input images (two RGB G-buffers at most; an absent one has factor 0 and is not read)
-__device__ __forceinline__ StagedPixel load_px(const FilterArgs &a, int x, int yrow) {
-    StagedPixel s;
+// Where a launch's features come from.  NG = 6: the first two G-buffers of the argument list (RGB, factor k0 / k1; an
+// absent one has factor 0 and is never read).  NG = 8: up to two RGB and up to two 1-channel G-buffers in any order of the
+// argument list, sorted into slots by the host (FilterArgs::SymGeom::rgb / sc).
+struct Feat {
+    const float *g0, *g1, *s0, *s1;
+    float k0, k1, k2, k3;
+};
+template <int NG>
+__device__ __forceinline__ Feat features_of(const FilterArgs &a) {
+    if constexpr (NG == 6) return Feat{a.g[0].data, a.g[1].data, nullptr, nullptr, a.gscale0, a.gscale1, 0.f, 0.f};
+    else return Feat{a.sym.rgb[0], a.sym.rgb[1], a.sym.sc[0], a.sym.sc[1], a.sym.rgb_scale[0], a.sym.rgb_scale[1], a.sym.sc_scale[0], a.sym.sc_scale[1]};
+}
+struct Staged {   // one staged pixel: the 15 values of the common layout + the two 1-channel features (NG = 8)
+    StagedPixel p;
+    float s0, s1;
+};
+
+// pixel (x, yrow) of the input images (an absent G-buffer has factor 0 and is not read)
+template <int NG>
+__device__ __forceinline__ Staged load_px(const FilterArgs &a, const Feat &F, int x, int yrow) {
+    Staged r;
+    StagedPixel &s = r.p;
+    r.s0 = r.s1 = 0.f;
     s.valid = x >= 0 && x < a.width && yrow >= 0 && yrow < a.height;
     if (s.valid) {
         const long long q = (long long)yrow * a.width + x;
         if (a.packed) {
             const f3 *px = reinterpret_cast<const f3 *>(a.packed + q * 15);
             s.mc = px[0]; s.d = px[1]; s.col = px[2]; s.g0 = px[3]; s.g1 = px[4];
-            return s;
+            return r;
         }
         s.mc = reinterpret_cast<const f3 *>(a.mean_corr)[q];
         s.d = reinterpret_cast<const f3 *>(a.disc)[q];
         s.col = reinterpret_cast<const f3 *>(a.colour)[q];
-        s.g0 = a.gscale0 != 0.f ? reinterpret_cast<const f3 *>(a.g[0].data)[q] : f3{0.f, 0.f, 0.f};
-        s.g1 = a.gscale1 != 0.f ? reinterpret_cast<const f3 *>(a.g[1].data)[q] : f3{0.f, 0.f, 0.f};
+        s.g0 = F.k0 != 0.f ? reinterpret_cast<const f3 *>(F.g0)[q] : f3{0.f, 0.f, 0.f};
+        s.g1 = F.k1 != 0.f ? reinterpret_cast<const f3 *>(F.g1)[q] : f3{0.f, 0.f, 0.f};
+        if constexpr (NG == 8) {
+            r.s0 = F.k2 != 0.f ? F.s0[q] : 0.f;
+            r.s1 = F.k3 != 0.f ? F.s1[q] : 0.f;
+        }
     }
-    return s;
+    return r;
 }
 
-// stage column i of a row: inputs as the one-sided kernel stages them, accumulators cleared
-__device__ __forceinline__ void stage_store(float *slot, int i, const StagedPixel &s, float k0, float k1, bool rgb) {
-    store_pixel(slot, kP, i, s, k0, k1, rgb);
+// stage column i of a row: inputs (NG = 6: exactly as the one-sided kernel stages them), accumulators cleared
+template <int NG>
+__device__ __forceinline__ void stage_store(float *slot, int i, const Staged &r, const Feat &F, bool rgb) {
+    const StagedPixel &s = r.p;
+    if constexpr (NG == 6) {
+        store_pixel(slot, kP, i, s, F.k0, F.k1, rgb);
+    } else {
+        const bool v = s.valid;
+        const Validity ok = pixel_validity(s.mc, s.d, s.col, v, rgb);
+        const f3 mc = canonical_mean(s.mc, ok);
+        float *p = slot + i;
+        p[0 * kP] = v ? s.g0.x * F.k0 : 0.f; p[1 * kP] = v ? s.g0.y * F.k0 : 0.f; p[2 * kP] = v ? s.g0.z * F.k0 : 0.f;
+        p[3 * kP] = v ? s.g1.x * F.k1 : 0.f; p[4 * kP] = v ? s.g1.y * F.k1 : 0.f; p[5 * kP] = v ? s.g1.z * F.k1 : 0.f;
+        p[6 * kP] = v ? r.s0 * F.k2 : 0.f;   p[7 * kP] = v ? r.s1 * F.k3 : 0.f;
+        p[8 * kP] = mc.x; p[9 * kP] = mc.y; p[10 * kP] = mc.z;
+        p[11 * kP] = ok.x ? -s.d.x : 0.f; p[12 * kP] = ok.y ? -s.d.y : 0.f; p[13 * kP] = ok.z ? -s.d.z : 0.f;
+        p[14 * kP] = ok.x ? s.col.x : 0.f; p[15 * kP] = ok.y ? s.col.y : 0.f; p[16 * kP] = ok.z ? s.col.z : 0.f;
+    }
 #pragma unroll
-    for (int v = 0; v < kQ; v++) slot[(kIn + v) * kP + i] = 0.f;
+    for (int v = 0; v < kQ; v++) slot[(Planes<NG>::kIn + v) * kP + i] = 0.f;
 }
 
 // the accumulators of row `rel` (tile-relative) leave the ring: copy A + copy B -> patch
+template <int NG>
 __device__ __forceinline__ void flush_q(const float *slot, int i, float4 *patch_q_row) {
-    const float *q = slot + kIn * kP + i;
+    const float *q = slot + Planes<NG>::kIn * kP + i;
     patch_q_row[i] = make_float4(q[0 * kP] + q[4 * kP], q[1 * kP] + q[5 * kP], q[2 * kP] + q[6 * kP], q[3 * kP] + q[7 * kP]);
 }
 
 // Issue the LDS-DMA transfers of image row `yrow`, columns [xw0, xw0 + ncols) -> the wave's raw area.  Nothing
 // passes through registers and nothing waits: the data is used one step later.  Pieces never straddle the image
-// border (xw0 and the image width are multiples of 4 pixels = 3 or 15 pieces); pieces outside the image are skipped
-// and their stale bytes are never looked at (validity is decided from coordinates).
-__device__ __forceinline__ void dma_row(const FilterArgs &a, float *raw_w, int lane, int xw0, int yrow, int ncols) {
+// border (xw0 and the image width are multiples of 4 pixels = 3 or 15 pieces, or 1 piece of a 1-channel image); pieces
+// outside the image are skipped and their stale bytes are never looked at (validity is decided from coordinates).
+// Raw area of a wave: the five RGB images' pieces one after the other (ncols x 3 floats each), then (NG = 8) the two
+// 1-channel images' (ncols floats each).
+template <int NG>
+__device__ __forceinline__ void dma_row(const FilterArgs &a, const Feat &F, float *raw_w, int lane, int xw0, int yrow, int ncols) {
     if (yrow < 0 || yrow >= a.height) return;
-    const int per_img = ncols * 3 / 4, total = 5 * per_img;
+    const int per_img = ncols * 3 / 4, per_sc = ncols / 4, total = 5 * per_img + (NG == 8 ? 2 * per_sc : 0);
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const int idx = 64 * j + lane;
@@ -620,9 +676,15 @@ __device__ __forceinline__ void dma_row(const FilterArgs &a, float *raw_w, int l
                 const long long f = (long long)xw0 * 15 + 4 * idx;   // float offset inside the AoS row
                 inside = f >= 0 && f + 4 <= (long long)a.width * 15;
                 src = a.packed + (long long)yrow * a.width * 15 + f;
+            } else if (NG == 8 && idx >= 5 * per_img) {
+                const int i2 = idx - 5 * per_img, m = i2 / per_sc, p = i2 - m * per_sc;
+                const float *img = m == 0 ? F.s0 : F.s1;
+                const long long f = (long long)xw0 + 4 * p;
+                inside = f >= 0 && f + 4 <= (long long)a.width && img != nullptr;
+                src = img + (long long)yrow * a.width + f;
             } else {
                 const int m = idx / per_img, p = idx - m * per_img;
-                const float *img = m == 0 ? a.mean_corr : m == 1 ? a.disc : m == 2 ? a.colour : m == 3 ? a.g[0].data : a.g[1].data;
+                const float *img = m == 0 ? a.mean_corr : m == 1 ? a.disc : m == 2 ? a.colour : m == 3 ? F.g0 : F.g1;
                 const long long f = (long long)xw0 * 3 + 4 * p;
                 inside = f >= 0 && f + 4 <= (long long)a.width * 3 && img != nullptr;
                 src = img + (long long)yrow * a.width * 3 + f;
@@ -633,18 +695,25 @@ __device__ __forceinline__ void dma_row(const FilterArgs &a, float *raw_w, int l
     }
 }
 
-// column c of the wave's raw area -> the staged pixel (image order in the raw area: mean, discriminator, colour, g0, g1)
-__device__ __forceinline__ StagedPixel raw_pixel(const FilterArgs &a, const float *raw_w, int c, int ncols, int x, int yrow) {
-    StagedPixel s;
+// column c of the wave's raw area -> the staged pixel (image order in the raw area: mean, discriminator, colour, g0, g1[, s0, s1])
+template <int NG>
+__device__ __forceinline__ Staged raw_pixel(const FilterArgs &a, const Feat &F, const float *raw_w, int c, int ncols, int x, int yrow) {
+    Staged out;
+    StagedPixel &s = out.p;
     s.valid = x >= 0 && x < a.width && yrow >= 0 && yrow < a.height;
     const int im = a.packed ? 3 : ncols * 3, px = a.packed ? 15 : 3;   // float stride between images / pixels
     const float *r = raw_w + c * px;
     s.mc = f3{r[0], r[1], r[2]};
     s.d = f3{r[im], r[im + 1], r[im + 2]};
     s.col = f3{r[2 * im], r[2 * im + 1], r[2 * im + 2]};
-    s.g0 = a.gscale0 != 0.f ? f3{r[3 * im], r[3 * im + 1], r[3 * im + 2]} : f3{0.f, 0.f, 0.f};
-    s.g1 = a.gscale1 != 0.f ? f3{r[4 * im], r[4 * im + 1], r[4 * im + 2]} : f3{0.f, 0.f, 0.f};
-    return s;
+    s.g0 = F.k0 != 0.f ? f3{r[3 * im], r[3 * im + 1], r[3 * im + 2]} : f3{0.f, 0.f, 0.f};
+    s.g1 = F.k1 != 0.f ? f3{r[4 * im], r[4 * im + 1], r[4 * im + 2]} : f3{0.f, 0.f, 0.f};
+    out.s0 = out.s1 = 0.f;
+    if constexpr (NG == 8) {
+        out.s0 = F.k2 != 0.f ? raw_w[15 * ncols + c] : 0.f;
+        out.s1 = F.k3 != 0.f ? raw_w[16 * ncols + c] : 0.f;
+    }
+    return out;
 }
 
 // DMA = rows are staged by LDS-DMA (two RGB G-buffers or the packed image, 16-byte aligned images whose width and
@@ -652,10 +721,12 @@ __device__ __forceinline__ StagedPixel raw_pixel(const FilterArgs &a, const floa
 // PAIR = filter<float>, two 1-channel buffers per launch: the (x, y) channels of the three statistics / colour images
 // hold buffer 0 and buffer 1 (pack_pair_kernel), the third channel is empty; the buffers share the range weight, gate
 // and normalise separately.
-template <bool DMA, int MODE>
+template <bool DMA, int MODE, int NG>
 __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool PAIR = MODE == kModePair;
+    constexpr int kSlotFloats = Planes<NG>::kSlotFloats, kIn = Planes<NG>::kIn;
+    const Feat F = features_of<NG>(a);
     // XCD-aware work mapping (as in the one-sided kernel): each XCD walks a contiguous range of items
     const int n_items = gridDim.x, b = blockIdx.x;
     const int q8 = n_items >> 3, rem8 = n_items & 7, xcd = b & 7, idx = b >> 3;
@@ -678,12 +749,11 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     const int lane32 = lane & 31;                       // 4-pixel column group of the lane inside its row
     const int trow = (wave & 3) + 4 * (lane >> 5);      // lower / upper half of the wave: rows t and t + 4
     const int half = wave >> 2;
-    const float k0 = a.gscale0, k1 = a.gscale1;
     constexpr int tw = kTabW;
     if constexpr (kPrio == 1) { if (half == 1) __builtin_amdgcn_s_setprio(2); }
 
     // ---- the lane's own 4 pixels (loads clamped into the image; outside it the pixel takes no part)
-    Lane st;
+    Lane<NG> st;
     const int py = y0 + trow;
     const int pyc = min(max(py, 0), a.height - 1);
 #pragma unroll
@@ -692,6 +762,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
         const int pxc = min(max(px, 0), a.width - 1);
         const long long p = (long long)pyc * a.width + pxc;
         f3 mc, d, g0, g1, col;
+        float sc0 = 0.f, sc1 = 0.f;
         if (a.packed) {
             const f3 *q = reinterpret_cast<const f3 *>(a.packed + p * 15);
             mc = q[0]; d = q[1]; col = q[2]; g0 = q[3]; g1 = q[4];
@@ -699,15 +770,20 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             mc = reinterpret_cast<const f3 *>(a.mean_corr)[p];
             d = reinterpret_cast<const f3 *>(a.disc)[p];
             col = reinterpret_cast<const f3 *>(a.colour)[p];
-            g0 = a.gscale0 != 0.f ? reinterpret_cast<const f3 *>(a.g[0].data)[p] : f3{0.f, 0.f, 0.f};
-            g1 = a.gscale1 != 0.f ? reinterpret_cast<const f3 *>(a.g[1].data)[p] : f3{0.f, 0.f, 0.f};
+            g0 = F.k0 != 0.f ? reinterpret_cast<const f3 *>(F.g0)[p] : f3{0.f, 0.f, 0.f};
+            g1 = F.k1 != 0.f ? reinterpret_cast<const f3 *>(F.g1)[p] : f3{0.f, 0.f, 0.f};
+            if constexpr (NG == 8) {
+                sc0 = F.k2 != 0.f ? F.s0[p] : 0.f;
+                sc1 = F.k3 != 0.f ? F.s1[p] : 0.f;
+            }
         }
         const bool inside = px >= 0 && px < a.width && py >= 0 && py < a.height;
         const Validity ok = pixel_validity(mc, d, col, inside, !PAIR);   // per pixel (RGB) / per buffer (PAIR)
         mc = canonical_mean(mc, ok);
-        st.pg[k][0] = v2f{g0.x * k0, g0.y * k0};
-        st.pg[k][1] = v2f{g0.z * k0, g1.x * k1};
-        st.pg[k][2] = v2f{g1.y * k1, g1.z * k1};
+        st.pg[k][0] = v2f{g0.x * F.k0, g0.y * F.k0};
+        st.pg[k][1] = v2f{g0.z * F.k0, g1.x * F.k1};
+        st.pg[k][2] = v2f{g1.y * F.k1, g1.z * F.k1};
+        if constexpr (NG == 8) st.pg[k][3] = v2f{sc0 * F.k2, sc1 * F.k3};
         st.ms[k][0] = v2f{mc.x, d.x};
         st.ms[k][1] = v2f{mc.y, d.y};
         st.ms[k][2] = v2f{mc.z, d.z};
@@ -720,24 +796,24 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     }
 
     // wave-local staging geometry (DMA): this wave's columns of every staged row
-    float *raw_w = tab_lds + 2 * kTabPad + (wave & 3) * kRawFloats;
+    float *raw_w = tab_lds + 2 * kTabPad + Planes<NG>::raw_off(wave);
     const int wcol0 = wave_col0(wave);                                 // first staged column (0..167) of the wave
     const int ncols = wave_cols(wave);                                 // 44, 44, 40, 40, then none
     if (s_a < s_b) {
         if constexpr (DMA) {   // the first row the sweep will need beyond the prologue: on its way during the prologue
-            if (s_a + 1 < s_b && !(kAblate & 2)) dma_row(a, raw_w, lane, x0 - kR + wcol0, y0 + s_a + kRows, ncols);
+            if (s_a + 1 < s_b && !(kAblate & 2)) dma_row<NG>(a, F, raw_w, lane, x0 - kR + wcol0, y0 + s_a + kRows, ncols);
         }
         // ---- prologue: rows rel = s_a .. s_a+7 (image rows y0 + rel) into slots rel % 9.  All of a thread's fetches
         // are issued before the first is staged: one memory latency per item instead of three.
         constexpr int kProIters = (kRows * kP + kThreads - 1) / kThreads;
-        StagedPixel pro[kProIters];
+        Staged pro[kProIters];
 #pragma unroll
         for (int it = 0; it < kProIters; it++) {
             const int idx2 = (int)threadIdx.x + it * kThreads;
-            pro[it].valid = false;
+            pro[it].p.valid = false;
             if (idx2 < kRows * kP) {
                 const int rr = idx2 / kP, i = idx2 - rr * kP;
-                pro[it] = load_px(a, x0 - kR + i, y0 + s_a + rr);
+                pro[it] = load_px<NG>(a, F, x0 - kR + i, y0 + s_a + rr);
             }
         }
 #pragma unroll
@@ -745,7 +821,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             const int idx2 = (int)threadIdx.x + it * kThreads;
             if (idx2 < kRows * kP) {
                 const int rr = idx2 / kP, i = idx2 - rr * kP;
-                stage_store(lds + ((s_a + rr) % kSlots) * kSlotFloats, i, pro[it], k0, k1, !PAIR);
+                stage_store<NG>(lds + ((s_a + rr) % kSlots) * kSlotFloats, i, pro[it], F, !PAIR);
             }
         }
         if ((int)threadIdx.x < tw) {
@@ -762,10 +838,10 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             const int i = DMA ? wcol0 + lane : (int)threadIdx.x;             // the staged column this thread looks after
             const bool mine = DMA ? lane < ncols : i < kP;
             const bool stage = s + 1 < s_b && mine && !(kAblate & 2);
-            StagedPixel nxt;
-            nxt.valid = false;
+            Staged nxt;
+            nxt.p.valid = false;
             if constexpr (!DMA) {
-                if (stage) nxt = load_px(a, x0 - kR + i, y0 + s + kRows);
+                if (stage) nxt = load_px<NG>(a, F, x0 - kR + i, y0 + s + kRows);
             }
             // Once per step every wave (a) hands the accumulators of the row that went dead at the last barrier to the
             // patch, (b) turns the row fetched during the last step into a ring slot (the dead row's), and (c) starts
@@ -774,17 +850,17 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             auto housekeeping = [&]() {
                 const int dead = s - 1;
                 if (mine && dead >= q_first && y0 + dead >= 0 && !(kAblate & 4))
-                    flush_q(lds + (dead % kSlots) * kSlotFloats, i, patch_q + (long long)(dead - q_first) * kP);
+                    flush_q<NG>(lds + (dead % kSlots) * kSlotFloats, i, patch_q + (long long)(dead - q_first) * kP);
                 if constexpr (DMA) {
                     if (s + 1 < s_b && !(kAblate & 2)) {
                         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's own transfers
                         if (stage) {
-                            const StagedPixel sp = raw_pixel(a, raw_w, lane, ncols, x0 - kR + i, y0 + s + kRows);
-                            stage_store(lds + ((s + kRows) % kSlots) * kSlotFloats, i, sp, k0, k1, !PAIR);
+                            const Staged sp = raw_pixel<NG>(a, F, raw_w, lane, ncols, x0 - kR + i, y0 + s + kRows);
+                            stage_store<NG>(lds + ((s + kRows) % kSlots) * kSlotFloats, i, sp, F, !PAIR);
                         }
                         if (s + 2 < s_b) {
                             __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the raw area has been read
-                            dma_row(a, raw_w, lane, x0 - kR + wcol0, y0 + s + 1 + kRows, ncols);
+                            dma_row<NG>(a, F, raw_w, lane, x0 - kR + wcol0, y0 + s + 1 + kRows, ncols);
                         }
                     }
                 }
@@ -807,16 +883,16 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             const float *tab = tab_lds + ((s - s_a) & 1) * kTabPad;
             if (kAblate & 8) {
             } else if (half == 0) {
-                eval_half_row<0, MODE>(st, row, tab, qrow, s == 0);
+                eval_half_row<0, MODE, NG>(st, row, tab, qrow, s == 0);
             } else {
-                eval_half_row<1, MODE>(st, row, tab, qrow, s == 0);
+                eval_half_row<1, MODE, NG>(st, row, tab, qrow, s == 0);
             }
 
             if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_ev += t - tk0; tk0 = t; }
             if (DMA && kHkAtEnd && half == 0) housekeeping();
             if (tstage) *reinterpret_cast<v2f *>(tab_lds + ((s - s_a + 1) & 1) * kTabPad + 2 * ti) = tnext;
             if constexpr (!DMA) {
-                if (stage) stage_store(lds + ((s + kRows) % kSlots) * kSlotFloats, i, nxt, k0, k1, !PAIR);
+                if (stage) stage_store<NG>(lds + ((s + kRows) % kSlots) * kSlotFloats, i, nxt, F, !PAIR);
             }
             if (!(kAblate & 16)) __syncthreads();
             if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_bar += t - tk0; tk0 = t; }
@@ -830,7 +906,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             const int rr = idx2 / kP, i = idx2 - rr * kP;
             const int rel = s_b - 1 + rr;
             if (rel >= q_first && y0 + rel >= 0 && y0 + rel < a.height)
-                flush_q(lds + (rel % kSlots) * kSlotFloats, i, patch_q + (long long)(rel - q_first) * kP);
+                flush_q<NG>(lds + (rel % kSlots) * kSlotFloats, i, patch_q + (long long)(rel - q_first) * kP);
         }
         __syncthreads();
     }
@@ -929,10 +1005,9 @@ __global__ __launch_bounds__(256) void combine_sym_kernel(FilterArgs a) {
 
 // filter<float>: the statistics and colours of two 1-channel buffers -> the (x, y) channels of three RGB-shaped
 // images, so that rows stage exactly as for filter<float3>.  An absent second buffer gets a NaN mean: it takes no part.
-__global__ __launch_bounds__(256) void pack_pair_kernel(FilterArgs a, float *mc3, float *d3, float *c3) {
-    const long long n = (long long)a.width * a.height;
-    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
+__global__ __launch_bounds__(256) void pack_pair_kernel(FilterArgs a, float *mc3, float *d3, float *c3, long long p0, long long p1) {
+    const long long p = p0 + (long long)blockIdx.x * 256 + threadIdx.x;   // pixels [p0, p1): the rows the launch's tiles stage
+    if (p >= p1) return;
     const bool two = a.f_active > 1;
     reinterpret_cast<f3 *>(mc3)[p] = f3{a.f_mean_corr[0][p], two ? a.f_mean_corr[1][p] : __builtin_nanf(""), 0.f};
     reinterpret_cast<f3 *>(d3)[p] = f3{a.f_disc[0][p], two ? a.f_disc[1][p] : 0.f, 0.f};
@@ -978,19 +1053,42 @@ size_t sym_patch_floats(const FilterArgs &a, int n_parts) {
     return (size_t)sym_tiles(a) * n_parts * (sym::kPatchP + (size_t)sym::q_rows_max(n_parts) * sym::kP) * 4;
 }
 
-// filter<float3> and filter<float> (two buffers per launch), radius 20, default spec, G-buffers = up to two RGB images
-// (other sets: the one-sided kernel)
+// filter<float3> and filter<float> (two buffers per launch), radius 20, every spec but Welch degrees of freedom.
+// G-buffers: up to two RGB images (six feature planes, the shipped normal + albedo), or up to two RGB and up to two
+// 1-channel images in any order (eight feature planes: + depth + material id; not for block + halo calls, whose packed
+// image has 15 channels)
 bool sym_eligible(const FilterArgs &a, int channels) {
-    if (a.radius != sym::kR || !fast_path_eligible(a, channels)) return false;
+    if (a.radius != sym::kR || (channels != 1 && channels != 3) || a.dof != STATMC_DOF_PIXEL) return false;
     // the pair-symmetric kernel implements both gates and both channel rules; the clamped border's taps beyond the image
     // are added by border_virtual_kernel
     // float buffers with the one-sided gate (four weights per pair for two buffers): one-sided kernel
     if (a.gate != STATMC_GATE_SYMMETRIC && channels != 3) return false;
     if (a.border == STATMC_BORDER_CLAMP && a.packed) return false;   // the border kernel reads the five images, not the packed one
-    if (a.n_g > 2) return false;
-    for (int g = 0; g < a.n_g; g++)
-        if (a.g[g].channels != 3) return false;
+    int n_rgb = 0, n_sc = 0;
+    for (int g = 0; g < a.n_g; g++) {
+        if (a.g[g].channels == 3) n_rgb++;
+        else if (a.g[g].channels == 1) n_sc++;
+        else return false;
+        if (!(a.g[g].dr <= 0.f) || !std::isfinite(a.g[g].dr)) return false;
+    }
+    if (n_rgb > 2 || n_sc > 2) return false;
+    if (n_sc > 0 && a.packed) return false;
     return true;
+}
+
+void sym_feature_slots(FilterArgs &a) {
+    a.sym.g8 = 0;
+    for (int i = 0; i < 2; i++) {
+        a.sym.rgb[i] = a.sym.sc[i] = nullptr;
+        a.sym.rgb_scale[i] = a.sym.sc_scale[i] = 0.f;
+    }
+    int n_rgb = 0, n_sc = 0;
+    for (int g = 0; g < a.n_g; g++) {
+        const float scale = sqrtf(-a.g[g].dr * kLog2e);
+        if (a.g[g].channels == 3 && n_rgb < 2) { a.sym.rgb[n_rgb] = a.g[g].data; a.sym.rgb_scale[n_rgb++] = scale; }
+        else if (a.g[g].channels == 1 && n_sc < 2) { a.sym.sc[n_sc] = a.g[g].data; a.sym.sc_scale[n_sc++] = scale; }
+    }
+    a.sym.g8 = n_sc > 0;
 }
 
 hipError_t launch_sym(FilterArgs a, hipStream_t s) {
@@ -1002,32 +1100,37 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     a.sym.item_stride4 = kPatchP + (long long)q_rows_max(a.n_parts) * kP;
     // LDS-DMA staging needs whole 16-byte pieces: images 16-byte aligned, width and film x-origin multiples of 4 pixels
     auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool g8 = a.sym.g8 != 0;
+    // the feature images the kernel will read (NG = 6: the argument list's first two; NG = 8: the sorted slots)
+    const float *f_img[4] = {g8 ? a.sym.rgb[0] : (a.gscale0 != 0.f ? a.g[0].data : nullptr), g8 ? a.sym.rgb[1] : (a.gscale1 != 0.f ? a.g[1].data : nullptr),
+                             g8 ? a.sym.sc[0] : nullptr, g8 ? a.sym.sc[1] : nullptr};
+    const bool f_al = al16(f_img[0]) && al16(f_img[1]) && al16(f_img[2]) && al16(f_img[3]);
     bool dma = a.width % 4 == 0 && a.sym.fx0 % 4 == 0;
     if (a.packed) dma = dma && al16(a.packed);
-    else dma = dma && al16(a.mean_corr) && al16(a.disc) && al16(a.colour) && (a.gscale0 == 0.f || al16(a.g[0].data)) &&
-               (a.gscale1 == 0.f || al16(a.g[1].data));
+    else dma = dma && al16(a.mean_corr) && al16(a.disc) && al16(a.colour) && f_al;
     const bool pair = a.sym.pair != 0;
     if (pair) {   // the launch's two float buffers -> the RGB-shaped images the rows are staged from
         float *mc3 = a.sym.pair_images, *d3 = mc3 + (size_t)a.width * a.height * 3, *c3 = d3 + (size_t)a.width * a.height * 3;
-        const long long n = (long long)a.width * a.height;
-        hipLaunchKernelGGL(pack_pair_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, mc3, d3, c3);
+        // only the rows this launch's tiles read (ROI rows, the window above and below, rounded out to whole tiles): a
+        // band of the Upload / Denoise / Download pipeline neither repacks the whole image nor touches rows whose copies
+        // are still in flight
+        const int y_lo = std::max(0, a.ry0 - kR - (kRows - 1)), y_hi = std::min(a.height, a.ry1 + kR);
+        const long long p0 = (long long)y_lo * a.width, p1 = (long long)y_hi * a.width;
+        hipLaunchKernelGGL(pack_pair_kernel, dim3((unsigned)((p1 - p0 + 255) / 256)), dim3(256), 0, s, a, mc3, d3, c3, p0, p1);
         a.mean_corr = mc3;
         a.disc = d3;
         a.colour = c3;
-        dma = a.width % 4 == 0 && a.sym.fx0 % 4 == 0 && al16(mc3) && al16(d3) && al16(c3) && (a.gscale0 == 0.f || al16(a.g[0].data)) &&
-              (a.gscale1 == 0.f || al16(a.g[1].data));
+        dma = a.width % 4 == 0 && a.sym.fx0 % 4 == 0 && al16(mc3) && al16(d3) && al16(c3) && f_al;
     }
     // float buffers have one channel: pooled == per channel
     const bool joint = a.channel_rule == STATMC_CHANNELS_JOINT, asym = a.gate == STATMC_GATE_ASYMMETRIC;
     const int mode = pair ? kModePair : asym ? (joint ? kModeAsymJoint : kModeAsym) : joint ? kModeJoint : kModeRgb;
-#define STATMC_SYM_K(D, M) reinterpret_cast<const void *>(&window_filter_sym<D, M>)
-    const void *kernels[2][kModes] = {
-        {STATMC_SYM_K(false, kModeRgb), STATMC_SYM_K(false, kModePair), STATMC_SYM_K(false, kModeJoint), STATMC_SYM_K(false, kModeAsym),
-         STATMC_SYM_K(false, kModeAsymJoint)},
-        {STATMC_SYM_K(true, kModeRgb), STATMC_SYM_K(true, kModePair), STATMC_SYM_K(true, kModeJoint), STATMC_SYM_K(true, kModeAsym),
-         STATMC_SYM_K(true, kModeAsymJoint)}};
+#define STATMC_SYM_K(D, M, G) reinterpret_cast<const void *>(&window_filter_sym<D, M, G>)
+#define STATMC_SYM_ROW(D, G) {STATMC_SYM_K(D, kModeRgb, G), STATMC_SYM_K(D, kModePair, G), STATMC_SYM_K(D, kModeJoint, G), STATMC_SYM_K(D, kModeAsym, G), STATMC_SYM_K(D, kModeAsymJoint, G)}
+    const void *kernels[2][2][kModes] = {{STATMC_SYM_ROW(false, 6), STATMC_SYM_ROW(true, 6)}, {STATMC_SYM_ROW(false, 8), STATMC_SYM_ROW(true, 8)}};
+#undef STATMC_SYM_ROW
 #undef STATMC_SYM_K
-    const void *kernel = kernels[dma ? 1 : 0][mode];
+    const void *kernel = kernels[g8 ? 1 : 0][dma ? 1 : 0][mode];
     static std::mutex mu;
     static std::set<std::pair<int, const void *>> done;
     int dev = 0;
@@ -1041,7 +1144,7 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     }
     const dim3 grid(sym_tiles(a) * a.n_parts);
     void *kargs[] = {&a};
-    if (hipError_t e = hipLaunchKernel(kernel, grid, dim3(kThreads), kargs, kLdsBytes, s); e != hipSuccess) return e;
+    if (hipError_t e = hipLaunchKernel(kernel, grid, dim3(kThreads), kargs, g8 ? Planes<8>::kLdsBytes : Planes<6>::kLdsBytes, s); e != hipSuccess) return e;
     if (a.sym.border_extra) {
         if (hipError_t e = launch_border_virtual(a, s); e != hipSuccess) return e;
     }

@@ -641,7 +641,10 @@ def test_filter_generic_gbuffer_sets(gpu, oracle, channels):
     gbs2, dr2 = [gbs[1], gbs[0]], [g_dr[1], g_dr[0]]
     ref2 = oracle.filter_image(mc, disc, colour, gbs2, dr2, -0.5 / 100.0, 20)
     out2, v2 = run_filter(gpu, mc, disc, colour, gbs2, dr2, 10.0, 20, channels=channels)
-    assert v2 == ("lds_r20" if channels == 3 else "lds_r20_f") and rel_l2(out2, ref2) <= TOL   # slot layout: one-sided kernel
+    # at r = 20 a set with 1-channel images runs the pair-symmetric kernel's eight-feature-plane build
+    assert v2 == ("sym_r20_g8" if channels == 3 else "sym_r20_f_g8") and rel_l2(out2, ref2) <= TOL
+    out2b, v2b = run_filter(gpu, mc, disc, colour, gbs2, dr2, 10.0, 20, channels=channels, force=3)
+    assert v2b == ("lds_r20" if channels == 3 else "lds_r20_f") and rel_l2(out2b, ref2) <= TOL  # slot layout of the one-sided kernel
     # seven channels do not fit
     gbs7 = [gbs[0], rng.random((H, W, 3), dtype=np.float32), gbs[1]]
     ref7 = oracle.filter_image(mc, disc, colour, gbs7, g_dr, -0.5 / 16.0, r)
@@ -651,6 +654,46 @@ def test_filter_generic_gbuffer_sets(gpu, oracle, channels):
     ref0 = oracle.filter_image(mc, disc, colour, [], [], -0.5 / 16.0, r)
     out0, _ = run_filter(gpu, mc, disc, colour, [], [], 4.0, r, channels=channels)
     assert rel_l2(out0, ref0) <= TOL
+
+
+@pytest.mark.parametrize("channels,order,spec_kw,W", [
+    (3, ("normal", "albedo", "depth", "materialid"), dict(), 300),
+    (3, ("depth", "albedo", "materialid", "normal"), dict(), 300),           # any order of the argument list
+    (3, ("albedo", "normal", "depth"), dict(), 300),                          # one 1-channel image
+    (3, ("normal", "albedo", "depth", "materialid"), dict(), 301),            # width not a multiple of 4: register staging
+    (3, ("normal", "albedo", "depth", "materialid"), dict(border=1), 300),
+    (3, ("normal", "albedo", "depth", "materialid"), dict(gate=1, channel_rule=1), 300),
+    (1, ("normal", "albedo", "depth", "materialid"), dict(), 300),            # filter<float>, two buffers per launch
+], ids=["nadm", "danm-order", "three", "unaligned", "clamp", "asym+joint", "float"])
+def test_filter_eight_feature_channels(gpu, oracle, channels, order, spec_kw, W):
+    """normal + albedo + depth + material id as G-buffers (statpath.cpp:828-835, 1096-1130: `filterbuffers` may name all
+    four) at the shipped radius: eight feature channels run the pair-symmetric kernel's eight-plane build, not the
+    global-memory kernel; same result as the oracle and as the general kernel."""
+    H = 44
+    feats = ("radiance", "normal", "albedo", "depth", "materialid")
+    _, smp, st = make_case(W, H, 6, seed=321, features=feats)
+    rad = st["radiance"]
+    pick = (lambda a: a) if channels == 3 else (lambda a: np.ascontiguousarray(a[..., :1]))
+    ospec = oracle.FilterSpec(**spec_kw)
+    mc, disc = oracle.prepass(rad["n"], pick(rad["mean"]), pick(rad["m2"]), pick(rad["m3"]), spec=ospec)
+    colour = pick(rad["film_mean"])
+    sds = dict(normal=SD_NORMAL, albedo=SD_ALBEDO, depth=2.0, materialid=0.5)
+    gbs = [st[g]["mean"] for g in order]
+    g_dr = [-0.5 / sds[g] ** 2 for g in order]
+    ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / FILTER_SD ** 2, RADIUS, spec=ospec)
+    gpu.set_filter_spec(**spec_kw)
+    try:
+        out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, FILTER_SD, RADIUS, channels=channels)
+        out_g, v_g = run_filter(gpu, mc, disc, colour, gbs, g_dr, FILTER_SD, RADIUS, channels=channels, force=1)
+    finally:
+        gpu.set_filter_spec()
+    want = "sym_r20" + ("_f" if channels == 1 else "") + "_g8" + ("_asym" if spec_kw.get("gate") else "") + \
+        ("_joint" if spec_kw.get("channel_rule") and channels == 3 else "") + ("_clamp" if spec_kw.get("border") else "")
+    assert v == want, v
+    assert v_g == "generic"
+    for c in range(channels):
+        assert rel_l2(out[..., c], ref[..., c]) <= TOL, c
+        assert rel_l2(out_g[..., c], ref[..., c]) <= TOL, c
 
 
 @pytest.mark.parametrize("channels", [1, 3])
