@@ -82,18 +82,20 @@ struct TabHash {
 };
 std::unordered_map<TabKey, float *, TabHash> g_tabs;
 
-int spatial_table(int radius, float ds, const float **out) {
+// sym_rt: the table of the pair-symmetric kernel's runtime-radius build (cached under the key (dev, -radius, ds))
+int spatial_table(int radius, float ds, const float **out, bool sym_rt = false) {
     *out = nullptr;
-    const size_t n = statmc::spatial_table_floats(radius);
+    const size_t n = sym_rt ? statmc::sym_rt_table_floats(radius) : statmc::spatial_table_floats(radius);
     if (n == 0) return STATMC_OK;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_mu);
-    const TabKey key{dev, radius, ds};
+    const TabKey key{dev, sym_rt ? -radius : radius, ds};
     auto it = g_tabs.find(key);
     if (it == g_tabs.end()) {
         std::vector<float> host(n);
-        statmc::fill_spatial_table(host.data(), radius, ds);
+        if (sym_rt) statmc::fill_sym_rt_table(host.data(), radius, ds);
+        else statmc::fill_spatial_table(host.data(), radius, ds);
         float *d = nullptr;
         HIP_TRY(hipMalloc(&d, n * sizeof(float)));
         // synchronous copy: the table must be resident before any stream uses it
@@ -171,6 +173,10 @@ int parts_for_whole_image(const statmc::FilterArgs &k, int cus, bool sym) {
 int prepare_sym(const DeviceState &d, statmc::FilterArgs &k, const statmc_filter_args *a, bool pair = false) {
     k.sym.fx0 = a->film_x0;
     k.sym.fy0 = a->film_y0;
+    k.sym.tab_rt = nullptr;
+    if (k.radius != 20) {
+        if (int rc = spatial_table(k.radius, k.ds, &k.sym.tab_rt, true)) return rc;
+    }
     k.n_parts = parts_for_whole_image(k, d.cus, true);
     statmc::sym_geometry(k);
     float *ws = nullptr;

@@ -127,6 +127,8 @@ struct FilterArgs {
         float4 *border_extra;     // border rule "clamp": per pixel, the sums over the taps beyond the image (border_virtual_kernel)
         // eight feature planes (NG = 8 build): up to two RGB and up to two 1-channel G-buffers of the argument list, sorted
         // into slots by sym_feature_slots(); scale = sqrt(-dr * log2 e), 0 = empty slot (never read)
+        int steps;                // window rows a tile sweeps: radius + 1
+        const float *tab_rt;      // runtime-radius build (radius < 20): [radius + 1][47] spatial exponents, row = dy, -inf beyond the radius
         int g8;
         const float *rgb[2], *sc[2];
         float rgb_scale[2], sc_scale[2];
@@ -167,6 +169,8 @@ hipError_t launch_window_filter(const FilterArgs &a, int channels, hipStream_t s
 hipError_t launch_lds_packed(const FilterArgs &a, hipStream_t s, const char **variant);
 // Size in floats of the spatial table the fast path wants for radius r (0 if r unsupported).
 size_t spatial_table_floats(int radius);
+size_t sym_rt_table_floats(int radius);                   // pair-symmetric kernel, radius < 20
+void fill_sym_rt_table(float *host_tab, int radius, float ds);
 void fill_spatial_table(float *host_tab, int radius, float ds);
 bool fast_path_eligible(const FilterArgs &a, int channels);
 void set_feature_layout(FilterArgs &a);   // gscale0/1, feat[] of an eligible G-buffer set
@@ -181,7 +185,7 @@ void sym_feature_slots(FilterArgs &a);                       // fills a.sym.g8 /
 bool sym_path_selected(const FilterArgs &a, int channels);   // eligible and not overridden
 void sym_geometry(FilterArgs &a);                            // fills a.sym.tx0 .. nty from the ROI and film origin
 int sym_tiles(const FilterArgs &a);
-int sym_choose_parts(int tiles, int n_cus);
+int sym_choose_parts(int tiles, int n_cus, int steps);
 int sym_filter_parts(const FilterArgs &a, int n_cus);
 size_t sym_patch_floats(const FilterArgs &a, int n_parts);
 hipError_t launch_sym(FilterArgs a, hipStream_t s);

@@ -322,6 +322,19 @@ void fill_spatial_table(float *tab, int radius, float ds) {
         }
 }
 
+// The pair-symmetric kernel's runtime-radius build keeps the r = 20 staging geometry: tab[dy][dx + 23] for dy = 0 .. r,
+// 47 entries per row, -inf for |dx| > r (those taps get weight 0).
+size_t sym_rt_table_floats(int radius) { return radius < 1 || radius >= kMaxR ? 0 : (size_t)(radius + 1) * tab_width(kMaxR); }
+void fill_sym_rt_table(float *tab, int radius, float ds) {
+    const int tw = tab_width(kMaxR);
+    for (int dy = 0; dy <= radius; dy++)
+        for (int i = 0; i < tw; i++) {
+            const int dx = i - kMaxR - 3;
+            const float e = ds * (float)(dx * dx + dy * dy);  // same product as the oracle
+            tab[dy * tw + i] = (dx >= -radius && dx <= radius) ? e * kLog2e : -INFINITY;
+        }
+}
+
 template <int J, int RT>
 struct ChunkMask {
     // bit (i*4+k) set when tap i of chunk J is inside the window of pixel k (compile-time R)
@@ -822,8 +835,8 @@ bool sym_path_selected(const FilterArgs &a, int channels) {
 }
 int sym_filter_parts(const FilterArgs &a, int n_cus) {
     const int forced = g_parts_override;
-    if (forced > 0) return forced < 21 ? forced : 21;
-    return sym_choose_parts(sym_tiles(a), n_cus);
+    if (forced > 0) return forced < a.radius + 1 ? forced : a.radius + 1;
+    return sym_choose_parts(sym_tiles(a), n_cus, a.radius + 1);
 }
 
 // Where the ROI is cut: columns [rx0, split) go to regular 256-wide tiles, [split, rx1) -- at most half
@@ -891,11 +904,11 @@ bool lds_path_selected(const FilterArgs &a, int channels) {
     return fast_path_eligible(a, channels) && a.spatial_tab != nullptr && g_variant_override != 1;
 }
 
-// "sym_r20[_f][_g8][_asym][_joint][_clamp]": float buffers, eight feature planes, then the spec's non-default choices
+// "sym_r20|sym_rt[_f][_g8][_asym][_joint][_clamp]": compile-time / runtime radius, float buffers, eight feature planes, then the spec's non-default choices
 static const char *sym_variant_name(const FilterArgs &a, int channels) {
     static thread_local char name[64];
     const bool joint = a.channel_rule == STATMC_CHANNELS_JOINT && channels == 3;
-    snprintf(name, sizeof(name), "sym_r20%s%s%s%s%s", channels == 1 ? "_f" : "", a.sym.g8 ? "_g8" : "",
+    snprintf(name, sizeof(name), "%s%s%s%s%s%s", a.radius == 20 ? "sym_r20" : "sym_rt", channels == 1 ? "_f" : "", a.sym.g8 ? "_g8" : "",
              a.gate == STATMC_GATE_ASYMMETRIC ? "_asym" : "", joint ? "_joint" : "", a.border == STATMC_BORDER_CLAMP ? "_clamp" : "");
     return name;
 }

@@ -140,8 +140,9 @@ struct Planes {
 };
 static_assert(Planes<6>::kLdsBytes <= 160 * 1024 && Planes<8>::kLdsBytes <= 160 * 1024, "LDS budget");
 
-__host__ __device__ inline int step_lo(int part, int n_parts) { return (kSteps * part) / n_parts; }
-__host__ __device__ inline int q_rows_max(int n_parts) { return (kSteps + n_parts - 1) / n_parts + kRows - 1; }  // rows s_a .. s_b+6
+// steps = window rows dy = 0 .. r a tile sweeps: kSteps in the r = 20 builds, radius + 1 in the runtime-radius ones
+__host__ __device__ inline int step_lo(int part, int n_parts, int steps) { return (steps * part) / n_parts; }
+__host__ __device__ inline int q_rows_max(int n_parts, int steps) { return (steps + n_parts - 1) / n_parts + kRows - 1; }  // rows s_a .. s_b+6
 
 // The lane's own 4 pixels.  Their values enter the packed instructions as broadcasts of ONE half of a register
 // pair (op_sel), so two different scalars share every pair: 6 + 6 + 4 pairs per pixel instead of 15 + 15
@@ -564,8 +565,29 @@ __device__ __forceinline__ void sweep_range(Lane<NG> &st, const float *row, cons
 // 1.56 at 7 and 1.75 at 11, which cut two.  The SIMD is busy either way.)
 // dy = 0: the pairs inside a row are the taps dx >= 1 (the accumulator row is the wave's own row); the pixel's own
 // tap dx = 0 feeds the p side only.
-template <int HF, int MODE, int NG>
-__device__ __forceinline__ void eval_half_row(Lane<NG> &st, const float *row, const float *tab, float *qrow, bool dy0) {
+// RT (runtime radius r < 20): the same staging geometry (20 halo columns) and the same split of the window at dx = 0; the
+// read groups a half sweeps are groups [j_lo, 4] + the cut group 5 (half 0) and the cut group 5 + groups [6, j_hi] (half 1),
+// where j_lo / j_hi are the outermost groups that hold a tap with |dx| <= r; taps of those groups beyond r carry a
+// spatial exponent of -inf in the table (weight 0).
+template <int HF, int MODE, int NG, bool RT>
+__device__ __forceinline__ void eval_half_row(Lane<NG> &st, const float *row, const float *tab, float *qrow, bool dy0, int j_lo, int j_hi) {
+    if constexpr (RT) {
+        static_assert(kSplit == 0, "the runtime-radius build splits the window in the middle");
+        if constexpr (HF == 0) {
+            if (dy0) {
+                sweep_range<0, 0, false, MODE, NG>(st, row, tab, qrow);
+            } else {
+#pragma unroll 1
+                for (int j = j_lo; j < kMid; j++) chunk<0xFFFFu, true, kPipe, MODE, NG>(st, row, tab, qrow, j);
+                chunk<Range<-kR, 0>::m(kMid), true, kPipe, MODE, NG>(st, row, tab, qrow, kMid);
+            }
+        } else {
+            chunk<Range<1, kR>::m(kMid), true, kPipe, MODE, NG>(st, row, tab, qrow, kMid);
+#pragma unroll 1
+            for (int j = kMid + 1; j <= j_hi; j++) chunk<0xFFFFu, true, kPipe, MODE, NG>(st, row, tab, qrow, j);
+        }
+        return;
+    }
     if constexpr (HF == 0) {
         if (dy0) {
             sweep_range<0, 0, false, MODE, NG>(st, row, tab, qrow);
@@ -721,7 +743,7 @@ __device__ __forceinline__ Staged raw_pixel(const FilterArgs &a, const Feat &F, 
 // PAIR = filter<float>, two 1-channel buffers per launch: the (x, y) channels of the three statistics / colour images
 // hold buffer 0 and buffer 1 (pack_pair_kernel), the third channel is empty; the buffers share the range weight, gate
 // and normalise separately.
-template <bool DMA, int MODE, int NG>
+template <bool DMA, int MODE, int NG, bool RT>
 __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool PAIR = MODE == kModePair;
@@ -737,8 +759,12 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     const int part = u % a.n_parts, tile = u / a.n_parts;
     const int x0 = kW * (a.sym.tx0 + tile % a.sym.ntx) - a.sym.fx0;     // local coordinates of the tile
     const int y0 = kRows * (a.sym.ty0 + tile / a.sym.ntx) - a.sym.fy0;
-    const int s_a = step_lo(part, a.n_parts);
-    const int s_b = min(step_lo(part + 1, a.n_parts), a.height - y0);  // window rows below the image are not swept
+    const int steps = RT ? a.sym.steps : kSteps;
+    const int s_a = step_lo(part, a.n_parts, steps);
+    const int s_b = min(step_lo(part + 1, a.n_parts, steps), a.height - y0);  // window rows below the image are not swept
+    // spatial exponents: [dy + 20][..] of the (2r+1)-row table (r = 20) / [dy][..] of the runtime-radius table
+    const float *stab = RT ? a.sym.tab_rt : a.spatial_tab + kR * kTabW;
+    const int j_lo = RT ? (kR - a.radius) / 4 : 0, j_hi = RT ? min(kChunks - 1, (a.radius + kR + 3) / 4) : kChunks - 1;
     const int q_first = s_a;   // accumulator rows the item flushes: tile-relative rows s_a .. s_b+2
     float4 *patch = a.sym.patch + (long long)u * a.sym.item_stride4;
     float4 *patch_q = patch + kPatchP;
@@ -825,7 +851,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             }
         }
         if ((int)threadIdx.x < tw) {
-            const float *t = a.spatial_tab + (s_a + kR) * tw + threadIdx.x;
+            const float *t = stab + s_a * tw + threadIdx.x;
             *reinterpret_cast<v2f *>(tab_lds + 2 * threadIdx.x) = v2f{t[0], (int)threadIdx.x + 1 < tw ? t[1] : 0.f};
         }
         __syncthreads();
@@ -873,7 +899,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             const bool tstage = s + 1 < s_b && ti >= 0 && ti < tw;
             v2f tnext = v2f{0.f, 0.f};
             if (tstage) {
-                const float *t = a.spatial_tab + (s + 1 + kR) * tw + ti;
+                const float *t = stab + (s + 1) * tw + ti;
                 tnext = v2f{t[0], ti + 1 < tw ? t[1] : 0.f};
             }
 
@@ -883,9 +909,9 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             const float *tab = tab_lds + ((s - s_a) & 1) * kTabPad;
             if (kAblate & 8) {
             } else if (half == 0) {
-                eval_half_row<0, MODE, NG>(st, row, tab, qrow, s == 0);
+                eval_half_row<0, MODE, NG, RT>(st, row, tab, qrow, s == 0, j_lo, j_hi);
             } else {
-                eval_half_row<1, MODE, NG>(st, row, tab, qrow, s == 0);
+                eval_half_row<1, MODE, NG, RT>(st, row, tab, qrow, s == 0, j_lo, j_hi);
             }
 
             if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_ev += t - tk0; tk0 = t; }
@@ -960,10 +986,11 @@ __global__ __launch_bounds__(256) void combine_sym_kernel(FilterArgs a) {
     if (x >= a.rx1 || y >= a.ry1) return;
     const int X = x + a.sym.fx0, Y = y + a.sym.fy0;
     const int ty_own = floordiv(Y, kRows), tx_own = floordiv(X, kW);
-    const int ty_lo = max(floordiv(Y - (kSteps + kRows - 2) + kRows - 1, kRows), a.sym.ty0);  // rows of tile row Ty: kRows Ty .. kRows Ty + kSteps + kRows - 2
+    const int steps = a.sym.steps, r = a.radius;
+    const int ty_lo = max(floordiv(Y - (steps + kRows - 2) + kRows - 1, kRows), a.sym.ty0);  // rows of tile row Ty: kRows Ty .. kRows Ty + steps + kRows - 2
     const int ty_hi = min(ty_own, a.sym.ty0 + a.sym.nty - 1);
-    const int tx_lo = max(floordiv(X + kR - (kP - 1) + kW - 1, kW), a.sym.tx0);              // staged column X - kW Tx + kR <= kP - 1
-    const int tx_hi = min(floordiv(X + kR, kW), a.sym.tx0 + a.sym.ntx - 1);
+    const int tx_lo = max(floordiv(X - r, kW), a.sym.tx0);              // tiles whose pixels lie within r columns of X: X - kW Tx in [-r, kW - 1 + r]
+    const int tx_hi = min(floordiv(X + r, kW), a.sym.tx0 + a.sym.ntx - 1);
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int Ty = ty_lo; Ty <= ty_hi; Ty++) {
         const int rel = Y - kRows * Ty;  // 0 .. kSteps + kRows - 2
@@ -972,7 +999,7 @@ __global__ __launch_bounds__(256) void combine_sym_kernel(FilterArgs a) {
             const long long item0 = ((long long)(Ty - a.sym.ty0) * a.sym.ntx + (Tx - a.sym.tx0)) * a.n_parts;
             for (int k = 0; k < a.n_parts; k++) {
                 const float4 *patch = a.sym.patch + (item0 + k) * a.sym.item_stride4;
-                const int s_a = step_lo(k, a.n_parts), s_b = step_lo(k + 1, a.n_parts), q_first = s_a;
+                const int s_a = step_lo(k, a.n_parts, steps), s_b = step_lo(k + 1, a.n_parts, steps), q_first = s_a;
                 if (Ty == ty_own && Tx == tx_own) {
                     const float4 v = patch[rel * kW + (X - kW * Tx)];
                     t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
@@ -985,7 +1012,7 @@ __global__ __launch_bounds__(256) void combine_sym_kernel(FilterArgs a) {
         }
     }
     const long long p = (long long)y * a.width + x;
-    if (a.sym.border_extra && (x < kR || x >= a.width - kR || y < kR || y >= a.height - kR)) {
+    if (a.sym.border_extra && (x < r || x >= a.width - r || y < r || y >= a.height - r)) {
         const float4 v = a.sym.border_extra[p];   // clamped border: the taps beyond the image
         t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
@@ -1022,8 +1049,10 @@ static int floordiv_h(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b
 // ROI (rows ry0-20 .. ry1-1, columns rx0-20 .. rx1+19, clipped to the local image).
 void sym_geometry(FilterArgs &a) {
     using namespace sym;
-    const int ex0 = std::max(0, a.rx0 - kR), ex1 = std::min(a.width, a.rx1 + kR);
-    const int ey0 = std::max(0, a.ry0 - kR), ey1 = a.ry1;
+    const int r = a.radius;
+    const int ex0 = std::max(0, a.rx0 - r), ex1 = std::min(a.width, a.rx1 + r);
+    const int ey0 = std::max(0, a.ry0 - r), ey1 = a.ry1;
+    a.sym.steps = r + 1;
     a.sym.tx0 = floordiv_h(ex0 + a.sym.fx0, kW);
     a.sym.ty0 = floordiv_h(ey0 + a.sym.fy0, kRows);
     a.sym.ntx = floordiv_h(ex1 - 1 + a.sym.fx0, kW) - a.sym.tx0 + 1;
@@ -1036,12 +1065,12 @@ int sym_tiles(const FilterArgs &a) { return a.sym.ntx * a.sym.nty; }
 // (stamps_sym.py), 7 more accumulator rows to flush and to gather in the combine.  Fitted at 1.35 steps on 1080p runs
 // with 1 .. 4 parts (1.46 / 1.61 / 1.62 / 1.92 ms); the same model orders the parts of a 1920 x 135 / 270 / 540 block
 // (tools/experiments/block_parts.py: 3 parts best for all three).
-int sym_choose_parts(int tiles, int n_cus) {
+int sym_choose_parts(int tiles, int n_cus, int steps) {
     int best = 1;
     double best_cost = 1e30;
-    for (int k = 1; k <= 8; k++) {
+    for (int k = 1; k <= 8 && k <= steps; k++) {
         const double rounds = (double)(((long long)tiles * k + n_cus - 1) / n_cus);
-        const double cost = rounds * ((double)((sym::kSteps + k - 1) / k) + 1.35);
+        const double cost = rounds * ((double)((steps + k - 1) / k) + 1.35);
         if (cost < best_cost * 0.98) {
             best_cost = cost;
             best = k;
@@ -1050,7 +1079,7 @@ int sym_choose_parts(int tiles, int n_cus) {
     return best;
 }
 size_t sym_patch_floats(const FilterArgs &a, int n_parts) {
-    return (size_t)sym_tiles(a) * n_parts * (sym::kPatchP + (size_t)sym::q_rows_max(n_parts) * sym::kP) * 4;
+    return (size_t)sym_tiles(a) * n_parts * (sym::kPatchP + (size_t)sym::q_rows_max(n_parts, a.radius + 1) * sym::kP) * 4;
 }
 
 // filter<float3> and filter<float> (two buffers per launch), radius 20, every spec but Welch degrees of freedom.
@@ -1058,7 +1087,7 @@ size_t sym_patch_floats(const FilterArgs &a, int n_parts) {
 // 1-channel images in any order (eight feature planes: + depth + material id; not for block + halo calls, whose packed
 // image has 15 channels)
 bool sym_eligible(const FilterArgs &a, int channels) {
-    if (a.radius != sym::kR || (channels != 1 && channels != 3) || a.dof != STATMC_DOF_PIXEL) return false;
+    if (a.radius < 1 || a.radius > sym::kR || (channels != 1 && channels != 3) || a.dof != STATMC_DOF_PIXEL) return false;
     // the pair-symmetric kernel implements both gates and both channel rules; the clamped border's taps beyond the image
     // are added by border_virtual_kernel
     // float buffers with the one-sided gate (four weights per pair for two buffers): one-sided kernel
@@ -1073,6 +1102,7 @@ bool sym_eligible(const FilterArgs &a, int channels) {
     }
     if (n_rgb > 2 || n_sc > 2) return false;
     if (n_sc > 0 && a.packed) return false;
+    if (n_sc > 0 && a.radius != sym::kR) return false;   // the eight-plane build exists for the shipped radius only
     return true;
 }
 
@@ -1097,7 +1127,10 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     // the border kernel reads the five separate images: never launch it on a block + halo call (sym_eligible excludes
     // that combination; this is the guard behind it)
     if (a.sym.border_extra && a.packed) return hipErrorInvalidValue;
-    a.sym.item_stride4 = kPatchP + (long long)q_rows_max(a.n_parts) * kP;
+    a.sym.steps = a.radius + 1;
+    a.sym.item_stride4 = kPatchP + (long long)q_rows_max(a.n_parts, a.sym.steps) * kP;
+    const bool rt = a.radius != kR;
+    if (rt && a.sym.tab_rt == nullptr) return hipErrorInvalidValue;
     // LDS-DMA staging needs whole 16-byte pieces: images 16-byte aligned, width and film x-origin multiples of 4 pixels
     auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool g8 = a.sym.g8 != 0;
@@ -1125,12 +1158,14 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     // float buffers have one channel: pooled == per channel
     const bool joint = a.channel_rule == STATMC_CHANNELS_JOINT, asym = a.gate == STATMC_GATE_ASYMMETRIC;
     const int mode = pair ? kModePair : asym ? (joint ? kModeAsymJoint : kModeAsym) : joint ? kModeJoint : kModeRgb;
-#define STATMC_SYM_K(D, M, G) reinterpret_cast<const void *>(&window_filter_sym<D, M, G>)
-#define STATMC_SYM_ROW(D, G) {STATMC_SYM_K(D, kModeRgb, G), STATMC_SYM_K(D, kModePair, G), STATMC_SYM_K(D, kModeJoint, G), STATMC_SYM_K(D, kModeAsym, G), STATMC_SYM_K(D, kModeAsymJoint, G)}
-    const void *kernels[2][2][kModes] = {{STATMC_SYM_ROW(false, 6), STATMC_SYM_ROW(true, 6)}, {STATMC_SYM_ROW(false, 8), STATMC_SYM_ROW(true, 8)}};
+#define STATMC_SYM_K(D, M, G, R) reinterpret_cast<const void *>(&window_filter_sym<D, M, G, R>)
+#define STATMC_SYM_ROW(D, G, R) {STATMC_SYM_K(D, kModeRgb, G, R), STATMC_SYM_K(D, kModePair, G, R), STATMC_SYM_K(D, kModeJoint, G, R), STATMC_SYM_K(D, kModeAsym, G, R), STATMC_SYM_K(D, kModeAsymJoint, G, R)}
+    // [eight feature planes | runtime radius (six planes)][LDS-DMA staging][mode]
+    const void *kernels[3][2][kModes] = {{STATMC_SYM_ROW(false, 6, false), STATMC_SYM_ROW(true, 6, false)}, {STATMC_SYM_ROW(false, 8, false), STATMC_SYM_ROW(true, 8, false)},
+                                         {STATMC_SYM_ROW(false, 6, true), STATMC_SYM_ROW(true, 6, true)}};
 #undef STATMC_SYM_ROW
 #undef STATMC_SYM_K
-    const void *kernel = kernels[g8 ? 1 : 0][dma ? 1 : 0][mode];
+    const void *kernel = kernels[rt ? 2 : g8 ? 1 : 0][dma ? 1 : 0][mode];
     static std::mutex mu;
     static std::set<std::pair<int, const void *>> done;
     int dev = 0;

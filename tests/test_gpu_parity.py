@@ -479,9 +479,15 @@ def stats_case(oracle, W, H, spp, seed):
     (300, 41, 20, 10.0, 3, "lds_r20"),     # the one-sided r = 20 kernel
     (300, 41, 20, 10.0, 2, "lds_rt"),
     (300, 41, 20, 10.0, 1, "generic"),
-    (37, 21, 6, 3.0, 0, "lds_rt"),         # glass-caustics config; image smaller than one tile
-    (259, 9, 3, 2.0, 0, "lds_rt"),         # radius not a multiple of 4, width 4k+3
-    (64, 50, 1, 1.0, 0, "lds_rt"),
+    (37, 21, 6, 3.0, 0, "sym_rt"),         # glass-caustics config (filterradius 6); image smaller than one tile
+    (37, 21, 6, 3.0, 2, "lds_rt"),         # ... on the one-sided runtime-radius kernel
+    (420, 70, 6, 3.0, 0, "sym_rt"),        # ... four tile columns, nine tile rows, LDS-DMA staging
+    (259, 9, 3, 2.0, 0, "sym_rt"),         # radius not a multiple of 4, width 4k+3 (register staging)
+    (64, 50, 1, 1.0, 0, "sym_rt"),
+    (300, 41, 19, 9.0, 0, "sym_rt"),       # every read group in play, the outermost ones cut by the table
+    (300, 41, 16, 8.0, 0, "sym_rt"),       # j_lo = 1: group 0 skipped
+    (300, 41, 13, 6.0, 0, "sym_rt"),
+    (132, 30, 7, 4.0, 0, "sym_rt"),
     (45, 33, 24, 12.0, 0, "generic"),      # radius beyond the LDS kernel's range
 ])
 def test_filter_matches_oracle(gpu, oracle, W, H, radius, sd, force, variant):
@@ -633,7 +639,7 @@ def test_filter_generic_gbuffer_sets(gpu, oracle, channels):
     g_dr = [-0.5 / 0.3 ** 2, -0.5 / 0.2 ** 2, -0.5 / 0.1 ** 2]
     ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / 16.0, r)
     out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, 4.0, r, channels=channels)
-    assert v == ("lds_rt" if channels == 3 else "lds_rt_f")           # 3 + 1 + 1 channels: slot layout
+    assert v == ("lds_rt" if channels == 3 else "lds_rt_f")           # 3 + 1 + 1 channels at r = 7: slot layout of the one-sided kernel
     assert rel_l2(out, ref) <= TOL
     out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, 4.0, r, channels=channels, force=1)
     assert v == "generic" and rel_l2(out, ref) <= TOL
@@ -724,7 +730,7 @@ def test_filter_fewer_gbuffers_on_the_lds_kernel(gpu, oracle, channels, n_g):
         assert rel_l2(out_g[..., c], ref[..., c]) <= TOL
 
 
-@pytest.mark.parametrize("n_buffers,radius,variant", [(5, 20, "sym_r20_f"), (12, 20, "sym_r20_f"), (4, 7, "lds_rt_f"), (1, 20, "sym_r20_f"),
+@pytest.mark.parametrize("n_buffers,radius,variant", [(5, 20, "sym_r20_f"), (12, 20, "sym_r20_f"), (4, 7, "sym_rt_f"), (1, 20, "sym_r20_f"),
                                                       (2, 20, "sym_r20_f")])
 def test_filter_float_multibuffer_fast_path(gpu, oracle, n_buffers, radius, variant):
     """filter<float> as ACRR (nBuffers = trackedbounces = 5) and SMIS (2 x 6 = 12) call it
@@ -754,7 +760,7 @@ def test_filter_float_multibuffer_fast_path(gpu, oracle, n_buffers, radius, vari
     for b in range(n_buffers):
         assert rel_l2(args["film_filtered"][b].cpu().numpy(), refs[b]) <= TOL, b
     # same call through the generic kernel and through the one-sided LDS kernel
-    for force, name in ((1, "generic"), (3, "lds_r20_f" if radius == 20 else "lds_rt_f")):
+    for force, name in ((1, "generic"), (3 if radius == 20 else 2, "lds_r20_f" if radius == 20 else "lds_rt_f")):
         gpu.force_filter_variant(force)
         try:
             for t in args["film_filtered"]:
@@ -1067,13 +1073,9 @@ def expected_lds_variant(spec_kw, channels, radius):
     if spec_kw.get("dof", 0):
         return "generic"
     f = "_f" if channels == 1 else ""
-    if radius == 20 and (channels == 3 or not gate):
-        return "sym_r20" + f + ("_asym" if gate else "") + ("_joint" if joint else "") + ("_clamp" if border else "")
-    if gate or joint:
-        return "lds_rt" + f + ("_asym" if gate else "") + ("_joint" if joint else "")
-    if radius == 20:
-        return "lds_r20" + f
-    return "lds_rt" + f
+    if channels == 3 or not gate:       # the pair-symmetric kernel: compile-time radius 20, runtime radius below
+        return ("sym_r20" if radius == 20 else "sym_rt") + f + ("_asym" if gate else "") + ("_joint" if joint else "") + ("_clamp" if border else "")
+    return "lds_rt" + f + ("_asym" if gate else "") + ("_joint" if joint else "")
 
 
 @pytest.mark.parametrize("spec_kw", SPEC_VARIANTS, ids=[spec_id(v) for v in SPEC_VARIANTS])
@@ -1094,6 +1096,12 @@ def test_filter_spec_variants_match_oracle(gpu, oracle, spec_kw):
         assert variant_g == "generic"
         for c in range(3):
             assert rel_l2(out[..., c], out_g[..., c]) <= TOL, c
+        # ... and the one-sided LDS kernel's build for the spec
+        _, _, out_l, variant_l, _ = run_spec(gpu, oracle, st, spec_kw, radius=7, sd=4.0, alpha_index=2, force=2)
+        gate, joint = spec_kw.get("gate", 0), spec_kw.get("channel_rule", 0)
+        assert variant_l == "lds_rt" + ("_asym" if gate else "") + ("_joint" if joint else ""), variant_l
+        for c in range(3):
+            assert rel_l2(out_l[..., c], oout[..., c]) <= TOL, c
 
 
 @pytest.mark.parametrize("spec_kw", [dict(), dict(gate=1), dict(dof=1), dict(border=1, channel_rule=1), dict(sides=1, small_n=1),
