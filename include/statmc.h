@@ -98,6 +98,11 @@ typedef struct statmc_filter_spec {
 /* Acts on the current device; applies to every later pre-pass / window-filter call on it. */
 int statmc_set_filter_spec(const statmc_filter_spec *spec);
 int statmc_get_filter_spec(statmc_filter_spec *spec);
+/* The spec and significance level a device has after statmc_setup: include/statmc_pinned_spec.h, which
+ * tools/pin_from_dumps.sh rewrites from dumps of the CUDA build (all zero until then).  statmc_reset_filter_spec puts
+ * the current device back to it; statmc_pinned_from says where it came from. */
+int statmc_reset_filter_spec(void);
+const char *statmc_pinned_from(void);
 
 /* Device memory + copies: the GpuMat role inside Buffer (src/statistics/buffer.h:25,57-63). */
 int statmc_malloc(void **dev_ptr, size_t bytes);

@@ -183,19 +183,31 @@ def tile_moments(values, tile_size):
     return out
 
 
-def prepass(n, mean, m2, m3, alpha_index=0, spec=None):
+def default_spec():
+    """The pinned spec (include/statmc_pinned_spec.h; all zero = spec v2 until tools/pin_from_dumps.sh has run)."""
+    s = FilterSpec()
+    lib().oracle_default_spec(C.byref(s))
+    return s
+
+
+def default_significance():
+    return int(lib().oracle_default_significance())
+
+
+def prepass(n, mean, m2, m3, alpha_index=None, spec=None):
     h, w = n.shape
     c = mean.shape[2] if mean.ndim == 3 else 1
     mc, disc = np.empty_like(mean), np.empty_like(mean)
-    spec = spec if spec is not None else FilterSpec()
+    spec = spec if spec is not None else default_spec()
+    alpha_index = default_significance() if alpha_index is None else alpha_index
     lib().oracle_prepass_spec(w, h, c, alpha_index, C.byref(spec), _i(n), _f(mean), _f(m2), _f(m3), _f(mc), _f(disc))
     return mc, disc
 
 
 def filter_image(mean_corr, disc, colour, g_buffers, g_dr, ds, radius, roi=None, threads=0, spec=None, n=None,
-                 alpha_index=0):
+                 alpha_index=None):
     """g_buffers: list of [H, W, Cg] (or [H, W]) float32 arrays; g_dr: list of -0.5/sd^2.
-    spec: FilterSpec (default: spec v2); n: the int32 sample counts, needed in Welch mode only."""
+    spec: FilterSpec (default: the pinned spec); n: the int32 sample counts, needed in Welch mode only."""
     h, w = mean_corr.shape[:2]
     c = mean_corr.shape[2] if mean_corr.ndim == 3 else 1
     gs = [np.ascontiguousarray(g, dtype=np.float32) for g in g_buffers]
@@ -205,7 +217,8 @@ def filter_image(mean_corr, disc, colour, g_buffers, g_dr, ds, radius, roi=None,
     gdr = np.asarray(list(g_dr) + ([] if ng else [0.0]), dtype=np.float32)
     out = np.zeros_like(colour)
     x0, y0, x1, y1 = roi if roi is not None else (0, 0, w, h)
-    spec = spec if spec is not None else FilterSpec()
+    spec = spec if spec is not None else default_spec()
+    alpha_index = default_significance() if alpha_index is None else alpha_index
     assert spec.dof == DOF_PIXEL or n is not None, "Welch mode reads the sample counts"
     lib().oracle_filter_spec_run(w, h, c, float(ds), int(radius), int(alpha_index), C.byref(spec),
                                  _i(n) if n is not None else None, _f(mean_corr), _f(disc), _f(colour),

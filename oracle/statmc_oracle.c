@@ -5,6 +5,7 @@
  * kernels are built the same way, which is what makes the integer/compare parts of the path
  * (membership decisions) bit-identical between the two.
  */
+#include "../include/statmc_pinned_spec.h"
 #include "statmc_oracle.h"
 #include "t_quantiles_oracle.h"
 
@@ -300,7 +301,11 @@ void oracle_tile_moments(int width, int height, int channels, const float *value
  * tree leaves open (SURVEY.md App. B "Unknown") is carried by oracle_filter_spec; the all-zero spec is this
  * build's default. */
 
-void oracle_default_spec(oracle_filter_spec *s) { memset(s, 0, sizeof(*s)); }
+void oracle_default_spec(oracle_filter_spec *s) {   /* include/statmc_pinned_spec.h: all zero until tools/pin_from_dumps.sh has run */
+    static const oracle_filter_spec pinned = STATMC_PINNED_SPEC;
+    *s = pinned;
+}
+int oracle_default_significance(void) { return STATMC_PINNED_SIGNIFICANCE; }
 
 static float tq_override[ORACLE_TQ_N_TABLES][ORACLE_TQ_N_DOF];
 static int tq_overridden[ORACLE_TQ_N_TABLES];

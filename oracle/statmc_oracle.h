@@ -114,7 +114,8 @@ typedef struct {
     int32_t border;       /* CLIP: taps outside the image are skipped;  CLAMP: their coordinates are clamped */
     int32_t small_n;      /* ACCEPT: n < 2 -> D = +inf (passes every test);  EXCLUDE: the pixel takes no part */
 } oracle_filter_spec;
-void oracle_default_spec(oracle_filter_spec *spec);
+void oracle_default_spec(oracle_filter_spec *spec);   /* the pinned spec (include/statmc_pinned_spec.h) */
+int oracle_default_significance(void);
 
 /* tq(dof) = Student-t quantile of table `table` = alpha_index + 3 * sides (alpha_index in {0: 0.005, 1: 0.002,
  * 2: 0.05}); dof < 1 -> +inf; dof clamped to the last table entry. */

@@ -64,7 +64,7 @@ class StatType(C.Structure):
 
 EXPORTS = [
     "statmc_last_error", "statmc_setup", "statmc_set_device", "statmc_set_significance", "statmc_get_significance", "statmc_set_t_quantiles",
-    "statmc_set_filter_spec", "statmc_get_filter_spec", "statmc_copy_device_settings",
+    "statmc_set_filter_spec", "statmc_get_filter_spec", "statmc_reset_filter_spec", "statmc_pinned_from", "statmc_copy_device_settings",
     "statmc_malloc", "statmc_free", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_download",
     "statmc_stream_create", "statmc_stream_destroy", "statmc_synchronize",
     "statmc_event_create", "statmc_event_destroy", "statmc_event_record", "statmc_stream_wait_event",
@@ -95,6 +95,7 @@ def load():
     lib = C.CDLL(_build.SO)
     lib.statmc_last_error.restype = C.c_char_p
     lib.statmc_last_filter_variant.restype = C.c_char_p
+    lib.statmc_pinned_from.restype = C.c_char_p
     lib.statmc_setup.argtypes = [C.c_int]
     lib.statmc_set_significance.argtypes = [C.c_int]
     lib.statmc_set_t_quantiles.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_int]
@@ -157,7 +158,11 @@ def setup(device=0):
 
 
 def set_filter_spec(spec=None, **fields):
-    """Filter spec of the current device: a FilterSpec, or its fields by keyword; no argument = default."""
+    """Filter spec of the current device: a FilterSpec, or its fields by keyword; no argument = the pinned default
+    (and the pinned significance level)."""
+    if spec is None and not fields:     # what a freshly set-up device has (include/statmc_pinned_spec.h)
+        check(load().statmc_reset_filter_spec())
+        return
     spec = spec if spec is not None else FilterSpec(**fields)
     check(load().statmc_set_filter_spec(C.byref(spec)))
 

@@ -9,7 +9,8 @@ CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libstatmc_hip.so")
 DEFAULT_SO = SO
 SOURCES = ["statmc_pointwise.hip", "statmc_filter.hip", "statmc_filter_sym.hip", "statmc_abi.hip"]
-HEADERS = ["statmc_device.h", "statmc_filter_common.h", "t_quantiles.h", os.path.join("..", "..", "include", "statmc.h")]
+HEADERS = ["statmc_device.h", "statmc_filter_common.h", "t_quantiles.h", os.path.join("..", "..", "include", "statmc.h"),
+           os.path.join("..", "..", "include", "statmc_pinned_spec.h")]
 # -ffp-contract=off: every fp32 op rounds once, in source order, like the CPU oracle build.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]

@@ -14,6 +14,7 @@
 #include <atomic>
 
 #include "t_quantiles.h"
+#include "../../include/statmc_pinned_spec.h"
 
 namespace {
 
@@ -21,6 +22,8 @@ thread_local char g_err[512] = "";
 thread_local const char *g_variant = "none";
 thread_local int g_last_parts = 0;
 std::atomic<int> g_accumulate_resident_blocks{0};
+std::atomic<int> g_tiles_umul{2}, g_tiles_order{0}, g_tiles_wg_per_cu{0};   // tile-fed path: deeper prefetch of the mean-only types by default
+std::atomic<int> g_accumulate_umul{1};
 std::mutex g_mu;
 
 // Everything the library remembers is kept per device (one Estimator per device in a process that drives
@@ -28,8 +31,8 @@ std::mutex g_mu;
 // quantile tables are a per-device __device__ symbol), significance level, filter spec, CU count.
 struct DeviceState {
     bool ready = false;
-    int alpha_index = 0;
-    statmc_filter_spec spec = {0, 0, 0, 0, 0, 0};
+    int alpha_index = STATMC_PINNED_SIGNIFICANCE;   // include/statmc_pinned_spec.h (tools/pin_from_dumps.sh)
+    statmc_filter_spec spec = STATMC_PINNED_SPEC;
     int cus = 0;
 };
 std::unordered_map<int, DeviceState> g_dev;  // guarded by g_mu
@@ -306,6 +309,16 @@ int statmc_set_filter_spec(const statmc_filter_spec *spec) {
     g_dev[dev].spec = *spec;
     return STATMC_OK;
 }
+int statmc_reset_filter_spec(void) {   // back to what a freshly set-up device has: the pinned spec and significance level
+    int dev = 0;
+    NEED_READY();
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_dev[dev].spec = statmc_filter_spec STATMC_PINNED_SPEC;
+    g_dev[dev].alpha_index = STATMC_PINNED_SIGNIFICANCE;
+    return STATMC_OK;
+}
+const char *statmc_pinned_from(void) { return STATMC_PINNED_FROM; }
 int statmc_get_filter_spec(statmc_filter_spec *spec) {
     if (!spec) return fail(STATMC_ERR_INVALID, "null spec");
     *spec = current_state().spec;
@@ -869,6 +882,7 @@ int statmc_accumulate(uint16_t width, uint16_t height, const statmc_stat_type *t
     for (int i = 0; i < n_types; i++)
         if (int rc = fill_stat_type(types[i], i, width, height, true, k.t[i])) return rc;
     k.resident_blocks = g_accumulate_resident_blocks;
+    k.umul = g_accumulate_umul;
     HIP_TRY(statmc::launch_accumulate(k, S(stream)));
     return STATMC_OK;
 }
@@ -894,6 +908,9 @@ int statmc_accumulate_tiles(uint16_t width, uint16_t height, const statmc_stat_t
     k.n_tiles = n_tiles;
     k.width = width;
     k.height = height;
+    k.umul = g_tiles_umul;
+    k.order = g_tiles_order;
+    k.wg_per_cu = g_tiles_wg_per_cu;
     HIP_TRY(statmc::launch_accumulate_tiles(k, S(stream)));
     return STATMC_OK;
 }
@@ -953,6 +970,16 @@ int statmc_debug_force_filter_variant(int v) {  // 0 auto, 1 generic, 2 runtime-
 }
 int statmc_debug_accumulate_resident_blocks(int n) {  // 0 large grid (default), n > 0: n resident workgroups
     g_accumulate_resident_blocks = n < 0 ? 0 : n;
+    return STATMC_OK;
+}
+int statmc_debug_accumulate_umul(int umul) {   // film-major kernel: 2 = the mean-only feature types prefetch twice as deep
+    g_accumulate_umul = umul == 2 ? 2 : 1;
+    return STATMC_OK;
+}
+int statmc_debug_accumulate_tiles_variant(int umul, int order, int wg_per_cu) {  // experiments (time_accumulate_tiles.py)
+    g_tiles_umul = umul == 2 ? 2 : 1;
+    g_tiles_order = order ? 1 : 0;
+    g_tiles_wg_per_cu = wg_per_cu < 0 ? 0 : wg_per_cu;
     return STATMC_OK;
 }
 int statmc_debug_last_filter_parts(void) { return g_last_parts; }

@@ -246,7 +246,8 @@ __device__ __forceinline__ void add_sample(ElemState &st, float nf, float r, flo
 // state, fold S samples in order, store.  Sample s of the lane's elements is at sp + s * stride
 // (4*C consecutive floats): stride = n_elems for sample-major film planes, = tile pixels * C for
 // the tile-major arena of accumulate_tiles.
-template <int C, int MAXM, bool TRANSFORM>
+// UMUL: prefetch depth multiplier (tile-fed path, types whose state is small enough to afford the registers)
+template <int C, int MAXM, bool TRANSFORM, int UMUL = 1>
 __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long long p0, const float *sp,
                                                 long long stride, int S) {
     constexpr int NE = 4 * C;  // elements per lane
@@ -278,7 +279,7 @@ __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long lo
     // they only coalesce through the cache, so they must be plain loads (non-temporal ones
     // re-fetch the shared lines: 4.8 vs 6.4 TB/s, tools/microbench/hbm_read.hip).  C = 1
     // streams with non-temporal loads.
-    constexpr int U = C == 3 ? (TRANSFORM ? STATMC_ACC_U_RGB_T : STATMC_ACC_U_RGB) : STATMC_ACC_U_F;
+    constexpr int U = UMUL * (C == 3 ? (TRANSFORM ? STATMC_ACC_U_RGB_T : STATMC_ACC_U_RGB) : STATMC_ACC_U_F);
     auto load_sample = [&](vfloat4 (&dst)[C], const float *src) {
 #pragma unroll
         for (int k = 0; k < C; k++)
@@ -378,14 +379,14 @@ __device__ __forceinline__ void accumulate_pixel(const AccumulateType &t, long l
 
 // Film-major batch: one lane owns 4 consecutive PIXELS of one stat type and walks the batch's
 // samples in order (sample s of pixel p, channel c is at samples[s*n_elems + p*C + c]).
-template <int C, int MAXM, bool TRANSFORM, bool VEC>
+template <int C, int MAXM, bool TRANSFORM, bool VEC, int UMUL>
 __device__ __forceinline__ void accumulate_type(const AccumulateType &t, long long blk, long long nblk) {
     const long long n_px = t.n_elems / C;
     const long long n_groups = (n_px + 3) >> 2;
     for (long long g = blk * kBlock + threadIdx.x; g < n_groups; g += nblk * kBlock) {
         const long long p0 = g << 2;
         if (VEC && p0 + 4 <= n_px) {
-            accumulate_lane<C, MAXM, TRANSFORM>(t, p0, t.samples + p0 * C, t.n_elems, t.n_samples);
+            accumulate_lane<C, MAXM, TRANSFORM, (!TRANSFORM && MAXM == 1) ? UMUL : 1>(t, p0, t.samples + p0 * C, t.n_elems, t.n_samples);
         } else {
             for (long long p = p0; p < n_px && p < p0 + 4; p++)
                 accumulate_pixel<C, MAXM, TRANSFORM>(t, p, t.samples + p * C, t.n_elems, t.n_samples);
@@ -393,16 +394,16 @@ __device__ __forceinline__ void accumulate_type(const AccumulateType &t, long lo
     }
 }
 
-template <int C, bool VEC>
+template <int C, bool VEC, int UMUL>
 __device__ __forceinline__ void accumulate_dispatch(const AccumulateType &t, long long blk, long long nblk) {
     if (t.transform) {
-        if (t.max_moment >= 3) accumulate_type<C, 3, true, VEC>(t, blk, nblk);
-        else if (t.max_moment == 2) accumulate_type<C, 2, true, VEC>(t, blk, nblk);
-        else accumulate_type<C, 1, true, VEC>(t, blk, nblk);
+        if (t.max_moment >= 3) accumulate_type<C, 3, true, VEC, UMUL>(t, blk, nblk);
+        else if (t.max_moment == 2) accumulate_type<C, 2, true, VEC, UMUL>(t, blk, nblk);
+        else accumulate_type<C, 1, true, VEC, UMUL>(t, blk, nblk);
     } else {
-        if (t.max_moment >= 3) accumulate_type<C, 3, false, VEC>(t, blk, nblk);
-        else if (t.max_moment == 2) accumulate_type<C, 2, false, VEC>(t, blk, nblk);
-        else accumulate_type<C, 1, false, VEC>(t, blk, nblk);
+        if (t.max_moment >= 3) accumulate_type<C, 3, false, VEC, UMUL>(t, blk, nblk);
+        else if (t.max_moment == 2) accumulate_type<C, 2, false, VEC, UMUL>(t, blk, nblk);
+        else accumulate_type<C, 1, false, VEC, UMUL>(t, blk, nblk);
     }
 }
 
@@ -414,13 +415,13 @@ __device__ __forceinline__ void accumulate_dispatch(const AccumulateType &t, lon
 // running this bandwidth-bound kernel beside the VALU-bound window filter of the previous
 // iteration on a second stream gains <= 15 % (the two contend for VALU issue), so bench.py
 // keeps the kernels back to back.
-template <bool VEC>
+template <bool VEC, int UMUL>
 __global__ __launch_bounds__(kBlock) void accumulate_kernel(AccumulateArgs a) {
     if (a.resident_blocks > 0) {
         for (int i = 0; i < a.n_types; i++) {
             const AccumulateType &t = a.t[(blockIdx.x + i) % a.n_types];
-            if (t.channels == 3) accumulate_dispatch<3, VEC>(t, blockIdx.x, gridDim.x);
-            else accumulate_dispatch<1, VEC>(t, blockIdx.x, gridDim.x);
+            if (t.channels == 3) accumulate_dispatch<3, VEC, UMUL>(t, blockIdx.x, gridDim.x);
+            else accumulate_dispatch<1, VEC, UMUL>(t, blockIdx.x, gridDim.x);
         }
         return;
     }
@@ -432,8 +433,8 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(AccumulateArgs a) {
     const AccumulateType &t = a.t[ti];
     const long long blk = (long long)round * a.type_slots[ti] + a.slot_rank[slot];
     const long long nblk = (long long)n_rounds * a.type_slots[ti];
-    if (t.channels == 3) accumulate_dispatch<3, VEC>(t, blk, nblk);
-    else accumulate_dispatch<1, VEC>(t, blk, nblk);
+    if (t.channels == 3) accumulate_dispatch<3, VEC, UMUL>(t, blk, nblk);
+    else accumulate_dispatch<1, VEC, UMUL>(t, blk, nblk);
 }
 
 hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
@@ -473,10 +474,12 @@ hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
     }
     const int rounds = (grid_for(max_groups, 256 * 8) * a.n_types + a.n_slots - 1) / a.n_slots;
     const dim3 grid(a.resident_blocks > 0 ? a.resident_blocks : rounds * a.n_slots);
-    if (vec)
-        hipLaunchKernelGGL(accumulate_kernel<true>, grid, dim3(kBlock), 0, s, a);
+    if (vec && a.umul == 2)
+        hipLaunchKernelGGL((accumulate_kernel<true, 2>), grid, dim3(kBlock), 0, s, a);
+    else if (vec)
+        hipLaunchKernelGGL((accumulate_kernel<true, 1>), grid, dim3(kBlock), 0, s, a);
     else
-        hipLaunchKernelGGL(accumulate_kernel<false>, grid, dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL((accumulate_kernel<false, 1>), grid, dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 
@@ -486,7 +489,7 @@ hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
 // block [S_tile][tile_h][tile_w][C] of a per-type arena, S_tile the same for every pixel of the
 // tile but free to differ between tiles.  One wave per (tile, type): a 16 x 16 tile is exactly
 // 64 lanes x 4 pixels, a sample plane of the block is one contiguous 1 / 3 KiB read of the wave.
-template <int C, int MAXM, bool TRANSFORM>
+template <int C, int MAXM, bool TRANSFORM, int UMUL>
 __device__ __forceinline__ void accumulate_tile(const AccumulateType &t, const AccumulateTilesArgs &a, int x0, int y0,
                                                 int tw, int th, long long off, int S) {
     const int lane = threadIdx.x & 63;
@@ -500,7 +503,8 @@ __device__ __forceinline__ void accumulate_tile(const AccumulateType &t, const A
         for (int g = lane; g < (npx >> 2); g += 64) {
             const int i = g << 2, row = i / tw, col = i - row * tw;
             const long long p0 = (long long)(y0 + row) * a.width + x0 + col;
-            accumulate_lane<C, MAXM, TRANSFORM>(t, p0, base + (long long)i * C, stride, S);
+            // deeper prefetch only where the state is one plane (mean-only feature types): the registers are there
+            accumulate_lane<C, MAXM, TRANSFORM, (!TRANSFORM && MAXM == 1) ? UMUL : 1>(t, p0, base + (long long)i * C, stride, S);
         }
     } else {
         for (int i = lane; i < npx; i += 64) {
@@ -511,35 +515,37 @@ __device__ __forceinline__ void accumulate_tile(const AccumulateType &t, const A
     }
 }
 
-template <int C>
+template <int C, int UMUL>
 __device__ __forceinline__ void accumulate_tile_dispatch(const AccumulateType &t, const AccumulateTilesArgs &a, int x0,
                                                          int y0, int tw, int th, long long off, int S) {
     if (t.transform) {
-        if (t.max_moment >= 3) accumulate_tile<C, 3, true>(t, a, x0, y0, tw, th, off, S);
-        else if (t.max_moment == 2) accumulate_tile<C, 2, true>(t, a, x0, y0, tw, th, off, S);
-        else accumulate_tile<C, 1, true>(t, a, x0, y0, tw, th, off, S);
+        if (t.max_moment >= 3) accumulate_tile<C, 3, true, UMUL>(t, a, x0, y0, tw, th, off, S);
+        else if (t.max_moment == 2) accumulate_tile<C, 2, true, UMUL>(t, a, x0, y0, tw, th, off, S);
+        else accumulate_tile<C, 1, true, UMUL>(t, a, x0, y0, tw, th, off, S);
     } else {
-        if (t.max_moment >= 3) accumulate_tile<C, 3, false>(t, a, x0, y0, tw, th, off, S);
-        else if (t.max_moment == 2) accumulate_tile<C, 2, false>(t, a, x0, y0, tw, th, off, S);
-        else accumulate_tile<C, 1, false>(t, a, x0, y0, tw, th, off, S);
+        if (t.max_moment >= 3) accumulate_tile<C, 3, false, UMUL>(t, a, x0, y0, tw, th, off, S);
+        else if (t.max_moment == 2) accumulate_tile<C, 2, false, UMUL>(t, a, x0, y0, tw, th, off, S);
+        else accumulate_tile<C, 1, false, UMUL>(t, a, x0, y0, tw, th, off, S);
     }
 }
 
+template <int UMUL>
 __global__ __launch_bounds__(kBlock) void accumulate_tiles_kernel(AccumulateTilesArgs a) {
     const long long n_items = (long long)a.n_tiles * a.n_types;
     const long long n_waves = (long long)gridDim.x * (kBlock / 64);
     // item = (tile, type), types innermost: the waves of a workgroup work on the types of one
     // tile, so ALU-heavy radiance items and bandwidth-only feature items share every CU
+    // (a.order = 1, experiment: tiles innermost -- neighbouring waves read neighbouring blocks of one type's arena)
     for (long long item = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); item < n_items; item += n_waves) {
-        const int tile = __builtin_amdgcn_readfirstlane((int)(item / a.n_types));
-        const int ti = __builtin_amdgcn_readfirstlane((int)(item % a.n_types));
+        const int tile = __builtin_amdgcn_readfirstlane(a.order ? (int)(item % a.n_tiles) : (int)(item / a.n_types));
+        const int ti = __builtin_amdgcn_readfirstlane(a.order ? (int)(item / a.n_tiles) : (int)(item % a.n_types));
         const int x0 = a.tile_bounds[4 * tile], y0 = a.tile_bounds[4 * tile + 1];
         const int x1 = a.tile_bounds[4 * tile + 2], y1 = a.tile_bounds[4 * tile + 3];
         const int S = a.tile_samples[tile];
         if (S <= 0 || x1 <= x0 || y1 <= y0) continue;
         const AccumulateType &t = a.t[ti];
-        if (t.channels == 3) accumulate_tile_dispatch<3>(t, a, x0, y0, x1 - x0, y1 - y0, a.tile_offsets[tile], S);
-        else accumulate_tile_dispatch<1>(t, a, x0, y0, x1 - x0, y1 - y0, a.tile_offsets[tile], S);
+        if (t.channels == 3) accumulate_tile_dispatch<3, UMUL>(t, a, x0, y0, x1 - x0, y1 - y0, a.tile_offsets[tile], S);
+        else accumulate_tile_dispatch<1, UMUL>(t, a, x0, y0, x1 - x0, y1 - y0, a.tile_offsets[tile], S);
     }
 }
 
@@ -554,8 +560,9 @@ hipError_t launch_accumulate_tiles(const AccumulateTilesArgs &a_in, hipStream_t 
     }
     a.vec = vec ? 1 : 0;
     const long long items = (long long)a.n_tiles * a.n_types;
-    const int grid = grid_for(items * 64, 256 * 8);  // one wave per item, at most 8 workgroups per CU
-    hipLaunchKernelGGL(accumulate_tiles_kernel, dim3(grid), dim3(kBlock), 0, s, a);
+    const int grid = grid_for(items * 64, 256 * (a.wg_per_cu > 0 ? a.wg_per_cu : 8));  // one wave per item, at most 8 workgroups per CU
+    if (a.umul == 2) hipLaunchKernelGGL(accumulate_tiles_kernel<2>, dim3(grid), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL(accumulate_tiles_kernel<1>, dim3(grid), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 

@@ -34,7 +34,7 @@ def test_single_gpu_line(gpu):
     assert rf["bound"] == "valu" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["hbm"]["unit"] == "GB/s" and abs(rf["hbm"]["frac"] - rf["hbm"]["achieved"] / rf["hbm"]["peak"]) < 1e-3
     assert r["n_ranks_seen"] == 1 and r["config"]["schedule"] == "single" and r["config"]["resident_pool_spp"] == 8
-    assert 0.5 < r["shader_clock"]["after_filter_GHz"] < 3.0 and 0.5 < r["shader_clock"]["after_accumulate_GHz"] < 3.0
+    assert 0.5 < r["shader_clock"]["during_filter_GHz"] < 3.0 and 0.5 < r["shader_clock"]["during_accumulate_GHz"] < 3.0
     assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["cores"] >= 1 and r["cpu_baseline"]["value"] > 0
     # secondary legs: the reference's own bracket through the C++ host side, tile-fed accumulation, copy rates
     assert r["cuda_time_bracket"]["cuda_time_bracket_ms"] > 0 and r["cuda_time_bracket"]["iterations"] == 4

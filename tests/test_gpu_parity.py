@@ -819,7 +819,7 @@ def test_maximum_width_and_empty_calls(gpu, oracle):
     mc, dc = oracle.prepass(ref["n"], ref["mean"], ref["m2"], ref["m3"])
     g_dr = [-0.5 / 0.5 ** 2, -0.5 / 0.4 ** 2]
     want = oracle.filter_image(mc, dc, ref["film_mean"], gb, g_dr, -0.5 / 25.0, 8)
-    for force, variant in ((0, "lds_rt"), (1, "generic")):
+    for force, variant in ((0, "sym_rt"), (2, "lds_rt"), (1, "generic")):
         out, v = run_filter(gpu, mc, dc, ref["film_mean"], gb, g_dr, 5.0, 8, force=force)
         assert v == variant
         assert max(rel_l2(out[..., c], want[..., c]) for c in range(3)) <= TOL, v

@@ -21,6 +21,10 @@ def timeit(fn, n=5):
 bpp = sum(4 * film.STAT_TYPES[t]["channels"] * S + 2 * (4 + 4 * film.STAT_TYPES[t]["channels"] * (film.STAT_TYPES[t]["max_moment"] + (2 if film.STAT_TYPES[t]["transform"] else 0))) for t in types)
 fs = film.FilmStats(W, H, dev, types=types)
 t_film = min(timeit(lambda: fs.accumulate(smp)) for _ in range(2))
+api.load().statmc_debug_accumulate_umul(2)
+t_film2 = min(timeit(lambda: fs.accumulate(smp)) for _ in range(2))
+api.load().statmc_debug_accumulate_umul(1)
+print("S=%d film-major umul 1: %.3f ms | umul 2: %.3f ms" % (S, t_film, t_film2), flush=True)
 # the same samples as tile blocks [tile][S][16][16][C] (1080 = 67.5 tiles: the last tile row is 8 high)
 tiles = [(x, y, min(x + 16, W), min(y + 16, H)) for y in range(0, H, 16) for x in range(0, W, 16)]
 bounds = torch.tensor(tiles, dtype=torch.int32, device=dev)
@@ -37,6 +41,14 @@ for t in types:
 fs2 = film.FilmStats(W, H, dev, types=types)
 sts = [api.make_stat_type_arena(arenas[t], film.STAT_TYPES[t]["channels"], fs2.state[t], film.STAT_TYPES[t]["transform"], film.STAT_TYPES[t]["max_moment"]) for t in types]
 offs_d = offs.to(dev); cnt = torch.full((len(tiles),), S, dtype=torch.int32, device=dev)
+import ctypes
+lib = api.load()
+lib.statmc_debug_accumulate_tiles_variant.argtypes = [ctypes.c_int] * 3
+for umul, order, wg in ((1, 0, 0), (2, 0, 0), (2, 0, 2)):
+    lib.statmc_debug_accumulate_tiles_variant(umul, order, wg)
+    tt = min(timeit(lambda: api.accumulate_tiles(W, H, sts, bounds, offs_d, cnt)) for _ in range(2))
+    print("S=%d tiles umul %d order %d wg/cu %2d: %.3f ms (%.0f GB/s, %.3f of 8 TB/s)" % (S, umul, order, wg, tt, bpp * W * H / tt / 1e6, bpp * W * H / tt / 8e9), flush=True)
+lib.statmc_debug_accumulate_tiles_variant(2, 0, 0)
 t_tiles = min(timeit(lambda: api.accumulate_tiles(W, H, sts, bounds, offs_d, cnt)) for _ in range(2))
 fs3 = film.FilmStats(W, H, dev, types=types); fs3.accumulate(smp)
 fs4 = film.FilmStats(W, H, dev, types=types)
