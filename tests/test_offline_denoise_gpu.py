@@ -109,6 +109,53 @@ def test_fit_spec_finds_the_spec_that_wrote_the_dumps(gpu, tmp_path):
     assert float(rows[1].split()[0]) > 1e-5 or "gate=asym,channels=joint,sides=one" in rows[1]   # only the rounding-twin gate form ties
 
 
+def test_pin_from_dumps_end_to_end(gpu, tmp_path):
+    """tools/pin_from_dumps.sh on a directory of dumps: the oracle under a non-default spec (pooled channels, clamped
+    border, n < 2 excluded, alpha 0.002) stands in for the CUDA build.  Two stems; the tool must print the table, find
+    exactly that spec over the full 64 x 3 grid and write it as the pinned default (to a scratch header: the tree's
+    own default is not touched, nothing is rebuilt)."""
+    import re
+    import sys
+    from statmc_amd import build, pfm
+    from oracle import oracle
+    build.build_tools()
+    spec = oracle.FilterSpec(channel_rule=oracle.CHANNELS_JOINT, border=oracle.BORDER_CLAMP, small_n=oracle.SMALL_N_EXCLUDE)
+    for stem, gi in (("sceneA", 1), ("sceneB", 1)):
+        g = np.load(GOLDEN[gi])
+        spp = int(g["spp"])
+        n = g["n"].copy()
+        n[3, 5] = 1
+        if stem == "sceneB":
+            n[10, 2:6] = 0
+        mc, dc = oracle.prepass(n, g["mean"], g["m2"], g["m3"], alpha_index=1, spec=spec)
+        film_f = oracle.filter_image(mc, dc, g["film_mean"], [g["normal_mean"], g["albedo_mean"]], [-50.0, -1250.0],
+                                     -0.5 / float(g["filter_sd"]) ** 2, int(g["radius"]), spec=spec, n=n, alpha_index=1)
+        for name, img in {"film": g["film_mean"], "t0-b0-n": n, "t0-b0-mean": g["mean"], "t0-b0-m2": g["m2"], "t0-b0-m3": g["m3"],
+                          "t1-b0-film-mean": g["normal_mean"], "t2-b0-film-mean": g["albedo_mean"], "film-f": film_f,
+                          "t0-b0-mean-corr": mc, "t0-b0-discriminator": dc}.items():
+            pfm.write_pfm(str(tmp_path / ("%s-%d-%s.pfm" % (stem, spp, name))), img)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = tmp_path / "pinned.h"
+    out = subprocess.run([os.path.join(root, "tools", "pin_from_dumps.sh"), str(tmp_path), "--filtersd", str(float(g["filter_sd"])),
+                          "--filterradius", str(int(g["radius"])), "--header", str(header), "--no-rebuild"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    win = re.search(r"winner: significance (\d), spec (\S+): film-f (\S+) ", out.stdout)
+    assert win and win.group(1) == "1" and float(win.group(3)) <= 1e-5, out.stdout
+    # (the two forms of the gate differ by one rounding of a threshold: either may come out on top)
+    assert win.group(2) in ("gate=sym,channels=joint,sides=two,dof=pixel,border=clamp,small_n=exclude",
+                            "gate=asym,channels=joint,sides=two,dof=pixel,border=clamp,small_n=exclude"), out.stdout
+    h = header.read_text()
+    assert re.search(r"#define STATMC_PINNED_SPEC \{[01], 1, 0, 0, 1, 1\}", h) and "#define STATMC_PINNED_SIGNIFICANCE 1" in h
+    table = (tmp_path / "pin_table.txt").read_text()
+    assert table.count("==== scene") == 2 and len([l for l in table.splitlines() if re.match(r"^\d\.\d+e", l)]) == 2 * 3 * 64
+    # a directory whose outputs no spec reproduces is reported, not pinned
+    pfm.write_pfm(str(tmp_path / ("sceneA-%d-film-f.pfm" % spp)), film_f * 1.01)
+    out = subprocess.run([os.path.join(root, "tools", "pin_from_dumps.sh"), str(tmp_path), "--filtersd", str(float(g["filter_sd"])),
+                          "--filterradius", str(int(g["radius"])), "--header", str(tmp_path / "other.h"), "--no-rebuild", "--quick"],
+                         capture_output=True, text=True)
+    assert out.returncode == 3 and "NOT pinned" in out.stdout and not (tmp_path / "other.h").exists()
+
+
 @pytest.mark.parametrize("grid", ["2x1", "2x2", "1x3"])
 def test_sharded_denoise_through_the_cpp_host(gpu, tmp_path, grid):
     """The C++ host side without Python in the data path: statmc::FilmShards cuts the Estimator's images into film

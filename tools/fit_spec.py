@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--tquantiles", default=None)
     ap.add_argument("--significance", default="0,1,2")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--json", default=None, help="also write the table as JSON (tools/pin_from_dumps.py reads it)")
     ap.add_argument("--exe", default=os.path.join(ROOT, "tools", "bin", "statmc_denoise"))
     args = ap.parse_args()
     rows = []
@@ -66,6 +67,9 @@ def main():
     for w, sig, spec, worst in rows:
         print("%-12.3e %-3s %-80s %.3e / %.3e" % (w, sig, spec, worst.get("t0-b0-mean-corr", float("nan")),
                                                   worst.get("t0-b0-discriminator", float("nan"))))
+    if args.json:
+        import json
+        json.dump([{"significance": sig, "spec": spec, "worst": worst} for _, sig, spec, worst in rows], open(args.json, "w"))
     if rows:
         print("\nbest: significance %s, --spec %s  (film-f worst channel %.3e; bound 1e-5)" % (rows[0][1], rows[0][2], rows[0][0]))
     return 0
