@@ -138,6 +138,10 @@ def load():
     lib.statmc_debug_force_filter_parts.argtypes = [C.c_int]
     lib.statmc_debug_last_filter_parts.restype = C.c_int
     lib.statmc_debug_accumulate_resident_blocks.argtypes = [C.c_int]
+    if lib.statmc_debug_diagnostic_build() and os.environ.get("STATMC_ALLOW_DIAGNOSTIC_BUILD") != "1":
+        raise RuntimeError("%s was built with STATMC_SYM_* experiment switches (bits %#x): its filter results are not the "
+                           "product's.  Set STATMC_ALLOW_DIAGNOSTIC_BUILD=1 to load it anyway (tools/experiments only)."
+                           % (_build.SO, lib.statmc_debug_diagnostic_build()))
     _lib = lib
     return lib
 

@@ -9,11 +9,12 @@ CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libstatmc_hip.so")
 DEFAULT_SO = SO
 SOURCES = ["statmc_pointwise.hip", "statmc_filter.hip", "statmc_filter_sym.hip", "statmc_abi.hip"]
-HEADERS = ["statmc_device.h", "statmc_filter_common.h", "t_quantiles.h", os.path.join("..", "..", "include", "statmc.h"),
+HEADERS = ["statmc_device.h", "statmc_filter_common.h", "statmc_sym_experiments.h", "t_quantiles.h", os.path.join("..", "..", "include", "statmc.h"),
            os.path.join("..", "..", "include", "statmc_pinned_spec.h")]
 # -ffp-contract=off: every fp32 op rounds once, in source order, like the CPU oracle build.
+# -DSTATMC_PRODUCT_BUILD: any STATMC_SYM_* experiment switch next to it is a compile error (statmc_sym_experiments.h).
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
+         "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-DSTATMC_PRODUCT_BUILD=1"]
 # The hot loops are written in the order they should issue (stage by stage across a lane's pixels,
 # loads ahead of the folds); the pre-RA machine scheduler only loses against that order: window filter
 # 2.44 -> 2.40 ms, radiance accumulation 1.40 -> 1.30 ms in A/B builds on one box.

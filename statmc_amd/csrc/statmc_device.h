@@ -191,6 +191,7 @@ int sym_choose_parts(int tiles, int n_cus, int steps);
 int sym_filter_parts(const FilterArgs &a, int n_cus);
 size_t sym_patch_floats(const FilterArgs &a, int n_parts);
 hipError_t launch_sym(FilterArgs a, hipStream_t s);
+int sym_diagnostic_bits();   // non-zero: built with a STATMC_SYM_* experiment switch (statmc_sym_experiments.h)
 hipError_t launch_border_virtual(const FilterArgs &a, hipStream_t s);   // the clamped border's taps beyond the image (RGB)
 int choose_parts(int tiles, int n_rows, int n_cus);
 int filter_parts_override();

@@ -56,44 +56,17 @@
 #include "statmc_device.h"
 #include "statmc_filter_common.h"
 
-// timing-only ablation builds (tools/experiments/ablate_sym.sh); results are wrong with any bit set
-#ifndef STATMC_SYM_ABLATE
-#define STATMC_SYM_ABLATE 0
-#endif
+#include "statmc_sym_experiments.h"   // the STATMC_SYM_* diagnostic / experiment switches: all zero in the product build
 
 namespace statmc {
 namespace sym {
 
-#ifndef STATMC_SYM_HK_END
-#define STATMC_SYM_HK_END 0
-#endif
 constexpr bool kHkAtEnd = STATMC_SYM_HK_END;   // experiment: per-step housekeeping after the sweep instead of before
-// diagnostic build (tools/experiments/stamps_sym.py): every wave sums the shader clocks it spends per step in
-// housekeeping / sweep / barrier and leaves them in the last float4s of its item's patch.  Never in the product.
-#ifndef STATMC_SYM_PIPE
-#define STATMC_SYM_PIPE 0
-#endif
-#ifndef STATMC_SYM_STAMPS
-#define STATMC_SYM_STAMPS 0
-#endif
-constexpr bool kStamps = STATMC_SYM_STAMPS;
-constexpr bool kPipe = STATMC_SYM_PIPE;
-#ifndef STATMC_SYM_SPLIT
-#define STATMC_SYM_SPLIT 0
-#endif
-// diagnostic build (tools/experiments/count_sym.py): every wave counts its read groups and those in which no lane has
-// a member pair (what a wave-level "all rejected" skip in front of v_exp_f32 would save).  Never in the product.
-#ifndef STATMC_SYM_COUNT
-#define STATMC_SYM_COUNT 0
-#endif
-#ifndef STATMC_SYM_PRIO
-#define STATMC_SYM_PRIO 0
-#endif
-// experiment (s_setprio): 1 = the half-1 waves run at raised issue priority (1.49 ms against 1.43), 2 = the half-0
-// waves during housekeeping (1.43: no change)
-constexpr int kPrio = STATMC_SYM_PRIO;
-constexpr int kSplit = STATMC_SYM_SPLIT;   // window half 0 sweeps dx <= kSplit, half 1 the rest   // hand-placed LDS reads one phase ahead of the arithmetic
-constexpr int kAblate = STATMC_SYM_ABLATE;  // 1 no q side, 2 no row staging, 4 no flush, 8 no sweep arithmetic, 16 no barrier
+constexpr bool kStamps = STATMC_SYM_STAMPS;    // diagnostic: per-wave clock sums per step (tools/experiments/stamps_sym.py)
+constexpr bool kPipe = STATMC_SYM_PIPE;        // experiment: hand-placed LDS reads one phase ahead of the arithmetic
+constexpr int kPrio = STATMC_SYM_PRIO;         // experiment (s_setprio)
+constexpr int kSplit = STATMC_SYM_SPLIT;       // window half 0 sweeps dx <= kSplit, half 1 the rest
+constexpr int kAblate = STATMC_SYM_ABLATE;     // timing only: 1 no q side, 2 no row staging, 4 no flush, 8 no sweep arithmetic, 16 no barrier
 // membership / buffer mode of a launch: one RGB buffer, every channel passes (default spec) | two float buffers
 // (filter<float>) | one RGB buffer, channels pooled (STATMC_CHANNELS_JOINT: sum_c fma(d_c, d_c, -(D_p,c + D_q,c)) <= 0,
 // as symmetric in (p, q) as the default test)
@@ -1044,6 +1017,8 @@ __global__ __launch_bounds__(256) void pack_pair_kernel(FilterArgs a, float *mc3
 static int floordiv_h(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
 }  // namespace sym
+
+int sym_diagnostic_bits() { return STATMC_SYM_DIAGNOSTIC_BITS; }
 
 // Tile range of a launch: every tile of the film grid that holds a pixel whose upper half-window reaches the
 // ROI (rows ry0-20 .. ry1-1, columns rx0-20 .. rx1+19, clipped to the local image).

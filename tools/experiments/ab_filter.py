@@ -6,7 +6,7 @@ CHILD = r'''
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(sys.argv[2])))
 from statmc_amd import build
-build.SO = os.path.abspath(sys.argv[1])
+os.environ.setdefault("STATMC_ALLOW_DIAGNOSTIC_BUILD", "1"); build.SO = os.path.abspath(sys.argv[1])
 import torch
 from statmc_amd import api, film, synthetic
 dev = torch.device("cuda:0"); api.setup(0)

@@ -7,7 +7,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from statmc_amd import build
-build.SO = os.path.join(ROOT, "tools", "experiments", "variants", "count.so")
+os.environ.setdefault("STATMC_ALLOW_DIAGNOSTIC_BUILD", "1"); build.SO = os.path.join(ROOT, "tools", "experiments", "variants", "count.so")
 import ctypes as C
 import torch
 from statmc_amd import api, film, synthetic

@@ -3,7 +3,7 @@ variant library.  usage: overlap_variant.py path/to/variant.so [spp] [grid_overr
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from statmc_amd import build
-build.SO = os.path.abspath(sys.argv[1])
+os.environ.setdefault("STATMC_ALLOW_DIAGNOSTIC_BUILD", "1"); build.SO = os.path.abspath(sys.argv[1])
 import torch
 from statmc_amd import api, film, synthetic
 dev = torch.device("cuda:0"); api.setup(0)

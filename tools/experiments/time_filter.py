@@ -6,7 +6,7 @@ from statmc_amd import build
 CASES = ((3, 0), (0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (3, 0), (0, 0))
 if "--lib" in sys.argv:      # a variant library (tools/experiments/build_variant.sh): sym kernel only, two part counts
     k = sys.argv.index("--lib")
-    build.SO = os.path.abspath(sys.argv[k + 1])
+    os.environ.setdefault("STATMC_ALLOW_DIAGNOSTIC_BUILD", "1"); build.SO = os.path.abspath(sys.argv[k + 1])
     del sys.argv[k:k + 2]
     CASES = ((0, 1), (0, 1), (0, 1), (0, 2))
 import torch
