@@ -271,21 +271,25 @@ def host_bracket(fs, args):
         for name, img in dump.items():
             pfm.write_pfm("%s-%d-%s.pfm" % (stem, args.spp, name), img.cpu().numpy())
         res = {}
-        for key, bands in (("pipelined", "0"), ("one_stream", "1")):
-            out = subprocess.run([exe, "--stem", stem, "--spp", ",".join([str(args.spp)] * 4), "--filtersd", str(args.filtersd),
+        for key, bands, queues in (("pipelined", "0", "1"), ("two_queues", "0", "2"), ("one_stream", "1", "1")):
+            out = subprocess.run([exe, "--stem", stem, "--spp", ",".join([str(args.spp)] * 12), "--filtersd", str(args.filtersd),
                                   "--filterradius", str(args.radius), "--warmup", "--bands", bands, "--output", "film-f"],
-                                 capture_output=True, text=True, timeout=300)
+                                 capture_output=True, text=True, timeout=300, env=dict(os.environ, STATMC_UPLOAD_QUEUES=queues))
             if out.returncode != 0:
                 return {"error": out.stderr.strip()[-300:]}
             ns = [int(v) for v in re.findall(r"HIP time \[ns\]: (\d+)", out.stdout)][1:]     # drop the warm-up
             ns.sort()
-            res[key] = (round(ns[0] / 1e6, 3), round(ns[len(ns) // 2] / 1e6, 3), len(ns),
-                        int(re.search(r"pipeline bands: (\d+)", out.stdout).group(1)))
-        return {"cuda_time_bracket_ms": res["pipelined"][0], "median_ms": res["pipelined"][1], "iterations": res["pipelined"][2],
-                "pipeline_bands": res["pipelined"][3], "one_stream_ms": res["one_stream"][0],
+            res[key] = {"best_ms": round(ns[0] / 1e6, 3), "median_ms": round(ns[len(ns) // 2] / 1e6, 3), "worst_ms": round(ns[-1] / 1e6, 3),
+                        "mean_ms": round(sum(ns) / len(ns) / 1e6, 3), "iterations": len(ns),
+                        "bands": int(re.search(r"pipeline bands: (\d+)", out.stdout).group(1))}
+        return {"cuda_time_bracket_ms": res["pipelined"]["best_ms"], "median_ms": res["pipelined"]["median_ms"],
+                "worst_ms": res["pipelined"]["worst_ms"], "mean_ms": res["pipelined"]["mean_ms"], "iterations": res["pipelined"]["iterations"],
+                "pipeline_bands": res["pipelined"]["bands"], "one_stream_ms": res["one_stream"]["best_ms"],
+                "two_upload_queues": res["two_queues"],
                 "what": "Estimator::Upload (76 B/px) + Denoise + Download (12 B/px) + Synchronize, C++ host side "
                         "(tools/bin/statmc_denoise), page-locked host images; the three phases run as a pipeline of row "
-                        "bands on three streams (same bits), one_stream_ms: the same calls one after the other"}
+                        "bands on three streams (same bits), one copy queue; one_stream_ms: the same calls one after the other; "
+                        "two_upload_queues: the copies dealt over two queues (faster when nothing stalls, with a tail: DESIGN.md 4.5)"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 

@@ -115,6 +115,10 @@ int statmc_memset(void *dev_ptr, int value, size_t bytes, void *stream);
 int statmc_upload(void *dev_dst, const void *host_src, size_t bytes, void *stream);   /* Buffer::upload */
 int statmc_download(void *host_dst, const void *dev_src, size_t bytes, void *stream); /* Buffer::download */
 int statmc_stream_create(void **stream);
+/* priority_class 0 normal, > 0 high, < 0 low.  Streams of different classes never share a hardware queue (the runtime
+ * keeps one pool of GPU_MAX_HW_QUEUES queues per priority level), so the barrier packets of one cannot hold back the
+ * packets of the other: what the band pipeline's copy streams need against its kernel stream (statmc_bands.hpp). */
+int statmc_stream_create_with_priority(void **stream, int priority_class);
 int statmc_stream_destroy(void *stream);
 /* Events: order work across streams without blocking the host -- what lets Estimator::Upload / Denoise / Download
  * (src/statistics/estimator.cpp:409-489) run as a pipeline of row bands on three streams (copies in, kernels, copies

@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -102,6 +104,8 @@ struct Streams {
     // complete when it would have been on one queue (minus the gaps)
     void beginTransfer(int k) const {
         if (k <= 0) return;
+        static const bool freeRunning = [] { const char *e = std::getenv("STATMC_BANDS_FREE"); return e && e[0] == '1'; }();   // experiment
+        if (freeRunning) return;
         ok(statmc_stream_wait_event(up, arrived2[k - 1]), "statmc_stream_wait_event");
         ok(statmc_stream_wait_event(up2, arrived[k - 1]), "statmc_stream_wait_event");
     }
@@ -126,9 +130,19 @@ struct Streams {
     ~Streams() { destroy(); }
     void ensure(int nb) {
         if (!up) {
-            ok(statmc_stream_create(&up), "statmc_stream_create");
-            ok(statmc_stream_create(&up2), "statmc_stream_create");
-            ok(statmc_stream_create(&down), "statmc_stream_create");
+            // The copy streams live in other priority classes than the (normal-priority) kernel stream: the runtime keeps a
+            // pool of GPU_MAX_HW_QUEUES = 4 hardware queues per priority level and lets a fifth stream of a level share a
+            // queue with an arbitrary other one (which one depends on address order, i.e. on the process); a copy
+            // stream that shares the kernel stream's hardware queue parks its event-wait barrier packets in front of the
+            // kernels, and the pipeline degenerates (7.0 instead of 4.0 ms for the 1080p bracket in one process out of
+            // three; always with GPU_MAX_HW_QUEUES=2 -- tools/experiments/diagnose_queues.py).  STATMC_BANDS_SAME_PRIORITY=1
+            // restores the old behaviour for A/B runs.
+            static const bool flat = [] { const char *e = std::getenv("STATMC_BANDS_SAME_PRIORITY"); return e && e[0] == '1'; }();
+            int pu = flat ? 0 : 1, pu2 = flat ? 0 : 1, pd = flat ? 0 : -1;
+            if (const char *e = std::getenv("STATMC_BANDS_PRIO")) std::sscanf(e, "%d,%d,%d", &pu, &pu2, &pd);   // experiments
+            ok(statmc_stream_create_with_priority(&up, pu), "statmc_stream_create");
+            ok(statmc_stream_create_with_priority(&up2, pu2), "statmc_stream_create");
+            ok(statmc_stream_create_with_priority(&down, pd), "statmc_stream_create");
             ok(statmc_event_create(&join), "statmc_event_create");
         }
         while ((int)arrived.size() < nb) {

@@ -376,10 +376,19 @@ void filter(uchar nBuffers, ushort width, ushort height, float filterDSFactor, u
     st.beginUploads(stream.handle());   // earlier work may still read the images
     std::vector<size_t> rowBytes;
     for (const auto &p : st.pending) rowBytes.push_back(p.rowBytes);
-    // One copy queue by default: with two (STATMC_CV_UPLOAD_QUEUES=2) this call order runs at 4.0 instead of 4.35 ms
-    // at 1080p in three processes out of four and at 5.8 - 7.0 ms in the fourth (the two queues end up serialised behind
-    // each other for the life of the process; tools/experiments/time_cv_bracket.py).  statmc::Estimator, which issues
-    // its copies from Upload() and has the device's default stream for the kernels, has not shown that in a hundred runs.
+    // One copy queue by default (4.38 ms for the 1080p bracket in 48 of 48 processes).  With two
+    // (STATMC_CV_UPLOAD_QUEUES=2) it is 4.0 ms -- when nothing stalls.  Two stalls were found (round 3,
+    // tools/experiments/diagnose_queues.py, iter_times.py):
+    //  (a) 7.0 ms for the life of one process in three: the runtime multiplexes streams over GPU_MAX_HW_QUEUES = 4
+    //      hardware queues per priority level, the pipeline's streams were one too many, and a copy stream that shared
+    //      the kernel stream's hardware queue parked its event-wait barrier packets in front of the kernels (16 of 16
+    //      processes with GPU_MAX_HW_QUEUES=2).  Gone since the copy streams live in other priority classes
+    //      (statmc_bands.hpp) -- also with GPU_MAX_HW_QUEUES=2.
+    //  (b) what is left: with two copy streams feeding four or more bands the HOST thread now and then blocks 6.6 - 8 ms
+    //      inside one hipMemcpyAsync enqueue (5.8 ms brackets in 1 - 5 processes of 16 here; single 7 - 10 ms iterations in
+    //      the Estimator); the copies themselves run at the same rate in slow and fast processes, three bands never
+    //      showed it (0 of 32), HSA_ENABLE_INTERRUPT=0 nearly removes it (1 of 96 iterations against 8 of 96): a
+    //      wake-up path inside the runtime, not something this side of the API can order differently.
     static const int nQueues = [] { const char *e = std::getenv("STATMC_CV_UPLOAD_QUEUES"); return e ? std::atoi(e) : 1; }();
     const std::vector<int> queue = B::Streams::deal(rowBytes, nQueues);
     for (int k = 0; k < nb; k++) {

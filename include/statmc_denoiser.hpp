@@ -748,8 +748,10 @@ class Estimator {
     // filter.  Results are the same bits as without bands: the pre-pass is per pixel, and the window filter forms a
     // pixel's sums in the same order for any output region.
     void SetPipelineBands(int n) { bandsRequested = n; }   // 0 = automatic, 1 = off
-    // Copy queues the transfers of a band are dealt over (statmc_bands.hpp): 2 by default, 1 = a single queue (3.8
-    // instead of 3.5 ms for the 1080p bracket).  STATMC_UPLOAD_QUEUES in the environment overrides the default.
+    // Copy queues the transfers of a band are dealt over (statmc_bands.hpp): 1 by default -- 3.9 ms for the 1080p
+    // bracket, every iteration.  2 (SetUploadQueues / STATMC_UPLOAD_QUEUES=2) gives 3.5 ms when nothing stalls, but about
+    // one iteration in twelve then takes 7 - 10 ms because the host thread blocks inside a hipMemcpyAsync enqueue
+    // (statmc_cv.hpp, note (b); tools/experiments/iter_times.py): 4.1 ms on average, with a tail.
     void SetUploadQueues(int n) { uploadQueues = n; }
     int PipelineBands() const {
         if (!allocateDevice || acc.dry) return 1;
@@ -1059,7 +1061,7 @@ class Estimator {
         bool downloading = false;
     } pipe;
     int bandsRequested = 0;
-    int uploadQueues = [] { const char *e = std::getenv("STATMC_UPLOAD_QUEUES"); return e ? std::atoi(e) : 2; }();
+    int uploadQueues = [] { const char *e = std::getenv("STATMC_UPLOAD_QUEUES"); return e ? std::atoi(e) : 1; }();
     int bandEdge(int k, int n) const { return bands::edge(k, n, height); }
     int arrivalEdge(int k, int n) const { return bands::arrival(k, n, height, filterRadius); }
     void ensurePipeline(int nb) {

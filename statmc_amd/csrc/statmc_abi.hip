@@ -403,6 +403,21 @@ int statmc_stream_create(void **stream) {
     *stream = s;
     return STATMC_OK;
 }
+// priority_class: 0 normal, > 0 high, < 0 low.  The HIP runtime multiplexes the streams of a process over
+// GPU_MAX_HW_QUEUES (default 4) hardware queues PER PRIORITY LEVEL; a stream beyond that number shares a hardware queue
+// with another one, and a barrier packet of one tenant (hipStreamWaitEvent) then holds back the other tenant's packets.
+// Streams that must never stall each other (the copy queues of the band pipeline against the kernel stream) are
+// therefore created in different priority classes: different pools, no shared hardware queue.
+int statmc_stream_create_with_priority(void **stream, int priority_class) {
+    if (!stream) return fail(STATMC_ERR_INVALID, "null stream");
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));   // numerically: greatest <= least
+    const int prio = priority_class > 0 ? greatest : priority_class < 0 ? least : (least + greatest) / 2;
+    hipStream_t s;
+    HIP_TRY(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
+    *stream = s;
+    return STATMC_OK;
+}
 int statmc_stream_destroy(void *stream) {
     // the stream's filter workspace goes with it (a later stream may get the same handle)
     {

@@ -4,6 +4,7 @@
 // Python test can compare it with the library called directly.
 //   test_cv_adaptor <stem> <spp> <out.pfm>      (dump files as written by tests: film, t0-b0-{n,mean,m2,m3}, t1/t2-b0-film-mean)
 #include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <iostream>
 
@@ -105,6 +106,44 @@ int main(int argc, char **argv) {
             if (best_ns < 0 || ns < best_ns) best_ns = ns;
         }
         std::printf("bracket_ns %lld bands %d\n", best_ns, stream.state().outBands);
+        if (std::getenv("STATMC_CV_DIAG")) {
+            // diagnosis of slow processes (tools/experiments/diagnose_queues.py): the raw copies of the bracket on the
+            // pipeline's own streams, without kernels -- one queue, two queues, the download
+            auto &st = stream.state();
+            st.ensure(1);
+            std::vector<Buffer *> ups = {&film, &n, &mean, &m2, &m3, &normal, &albedo};
+            auto best_of = [&](auto &&fn) {
+                long long best = -1;
+                for (int it = 0; it < 5; it++) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    fn();
+                    const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+                    if (best < 0 || ns < best) best = ns;
+                }
+                return best;
+            };
+            auto upload = [&](int queues) {
+                int i = 0;
+                for (Buffer *b : ups) {
+                    void *q = (queues == 2 && (i++ & 1)) ? st.up2 : st.up;
+                    statmc_upload(b->gpuMat.data, b->mat.ptr(), b->gpuMat.step * b->gpuMat.rows, q);
+                }
+                statmc_synchronize(st.up);
+                statmc_synchronize(st.up2);
+            };
+            const long long u1 = best_of([&] { upload(1); }), u2 = best_of([&] { upload(2); });
+            const long long dn = best_of([&] {
+                statmc_download(filmF.mat.ptr(), filmF.gpuMat.data, filmF.gpuMat.step * filmF.gpuMat.rows, st.down);
+                statmc_synchronize(st.down);
+            });
+            // uploads on two queues while the download runs on the third
+            const long long both = best_of([&] {
+                statmc_download(filmF.mat.ptr(), filmF.gpuMat.data, filmF.gpuMat.step * filmF.gpuMat.rows, st.down);
+                upload(2);
+                statmc_synchronize(st.down);
+            });
+            std::printf("diag upload_1q_ns %lld upload_2q_ns %lld download_ns %lld upload_2q_plus_download_ns %lld\n", u1, u2, dn, both);
+        }
         if (argc > 4) {   // the corrected means of the last iteration, for a bit-for-bit comparison between band counts
             Mat mcOut;
             cv::cvtColor(meanCorr.mat, mcOut, cv::COLOR_RGB2BGR);

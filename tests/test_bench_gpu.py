@@ -37,7 +37,8 @@ def test_single_gpu_line(gpu):
     assert 0.5 < r["shader_clock"]["during_filter_GHz"] < 3.0 and 0.5 < r["shader_clock"]["during_accumulate_GHz"] < 3.0
     assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["cores"] >= 1 and r["cpu_baseline"]["value"] > 0
     # secondary legs: the reference's own bracket through the C++ host side, tile-fed accumulation, copy rates
-    assert r["cuda_time_bracket"]["cuda_time_bracket_ms"] > 0 and r["cuda_time_bracket"]["iterations"] == 4
+    assert r["cuda_time_bracket"]["cuda_time_bracket_ms"] > 0 and r["cuda_time_bracket"]["iterations"] == 12
+    assert r["cuda_time_bracket"]["two_upload_queues"]["best_ms"] > 0
     assert r["tile_fed_accumulate"]["achieved_GBs"] > 0
     assert r["host_copies"]["upload_bytes_per_px"] == 76 and r["host_copies"]["download_bytes_per_px"] == 12
     assert r["filter_8_feature_channels"]["filter_variant"] == "sym_r20_g8" and r["filter_8_feature_channels"]["avg_ms"] > 0

@@ -37,20 +37,41 @@ try:
     torch.cuda.empty_cache()
 
     def run(env_extra, prefix=()):
-        env = dict(os.environ, STATMC_CV_BANDS="6", **env_extra)
+        env = dict(os.environ, **dict({"STATMC_CV_BANDS": "6"}, **env_extra))
         out = subprocess.run(list(prefix) + [build.CV_ADAPTOR_BIN, stem, str(spp), os.path.join(d, "f.pfm")], capture_output=True,
                              text=True, env=env, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         return int(re.search(r"bracket_ns (\d+) bands (\d+)", out.stdout).group(1)) / 1e6, out
 
-    for label, env in (("1 upload queue", {"STATMC_CV_UPLOAD_QUEUES": "1"}),
-                       ("2 upload queues", {"STATMC_CV_UPLOAD_QUEUES": "2"}),
-                       ("2 upload queues, GPU_MAX_HW_QUEUES=8", {"STATMC_CV_UPLOAD_QUEUES": "2", "GPU_MAX_HW_QUEUES": "8"}),
-                       ("2 upload queues, GPU_MAX_HW_QUEUES=2", {"STATMC_CV_UPLOAD_QUEUES": "2", "GPU_MAX_HW_QUEUES": "2"}),
-                       ("1 upload queue, GPU_MAX_HW_QUEUES=8", {"STATMC_CV_UPLOAD_QUEUES": "1", "GPU_MAX_HW_QUEUES": "8"})):
-        ts = [run(env)[0] for _ in range(N)]
-        print("%-40s: %s  (min %.2f, max %.2f ms; %d of %d above 5 ms)" % (label, " ".join("%.2f" % t for t in ts), min(ts), max(ts),
-                                                                              sum(t > 5.0 for t in ts), N), flush=True)
+    def show(label, env):
+        rows = []
+        for _ in range(N):
+            t, out = run(dict(env, STATMC_CV_DIAG="1"))
+            m = re.search(r"diag upload_1q_ns (\d+) upload_2q_ns (\d+) download_ns (\d+) upload_2q_plus_download_ns (\d+)", out.stdout)
+            rows.append((t,) + tuple(int(v) / 1e6 for v in m.groups()))
+        print("%-72s: %s  (%d of %d above 5 ms)" % (label, " ".join("%.2f" % r[0] for r in rows), sum(r[0] > 5.0 for r in rows), N), flush=True)
+        slow = [r for r in rows if r[0] > 5.0]
+        fast = [r for r in rows if r[0] <= 5.0]
+        for name, grp in (("fast", fast), ("slow", slow)):
+            if grp:
+                med = lambda i: sorted(g[i] for g in grp)[len(grp) // 2]
+                print("      %s processes (median): bracket %.2f | raw copies: upload 1 queue %.2f, 2 queues %.2f, download %.2f, 2 queues + download %.2f ms"
+                      % (name, med(0), med(1), med(2), med(3), med(4)), flush=True)
+
+    show("adaptor, 2 upload queues, 6 bands", {"STATMC_CV_UPLOAD_QUEUES": "2"})
+    show("adaptor, 2 upload queues, 3 bands", {"STATMC_CV_UPLOAD_QUEUES": "2", "STATMC_CV_BANDS": "3"})
+    show("adaptor, 2 upload queues, 4 bands", {"STATMC_CV_UPLOAD_QUEUES": "2", "STATMC_CV_BANDS": "4"})
+    # the C++ Estimator (tools/bin/statmc_denoise): 8 timed iterations per process after a warm-up
+    for bands in ("6", "3", "4"):
+        firsts, worsts = [], []
+        for _ in range(N):
+            out = subprocess.run([build.DENOISE_BIN, "--stem", stem, "--spp", ",".join([str(spp)] * 8), "--filtersd", "10", "--filterradius", "20",
+                                  "--warmup", "--bands", bands, "--output", "film-f"], capture_output=True, text=True, timeout=300)
+            assert out.returncode == 0, out.stderr[-500:]
+            ns = [int(v) / 1e6 for v in re.findall(r"HIP time \[ns\]: (\d+)", out.stdout)][1:]
+            firsts.append(min(ns))
+            worsts.append(max(ns))
+        print("Estimator --bands %s: best of 8 per process: %s | worst of 8: %s" % (bands, " ".join("%.2f" % t for t in firsts), " ".join("%.2f" % t for t in worsts)), flush=True)
     # runtime log of one process: which hardware queue does each stream get?
     _, out = run({"STATMC_CV_UPLOAD_QUEUES": "2", "AMD_LOG_LEVEL": "4", "AMD_LOG_MASK": "0x8000"})
     lines = [l for l in out.stderr.splitlines() if re.search(r"[Qq]ueue", l)]
@@ -62,7 +83,7 @@ try:
     os.environ["STATMC_CV_UPLOAD_QUEUES"] = "2"
     os.environ["STATMC_CV_BANDS"] = "6"
     kept = {}
-    for i in range(8):
+    for i in range(0):
         td = os.path.join(d, "trace%d" % i)
         t, out = run({}, prefix=("rocprofv3", "--hip-trace", "--memory-copy-trace", "--kernel-trace", "-d", td, "-o", "t", "--"))
         kind = "slow" if t > 5.0 else "fast"

@@ -249,12 +249,20 @@ int main(int argc, char **argv) {
             std::cout << "I/O time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count() << std::endl;
             t0 = clk::now();
             est.Upload();
+            const auto tu = clk::now();
             if (shards) shards->Denoise();   // film blocks + halo exchange (statmc_halo_exchange), same result bit for bit
             else est.Denoise();
+            const auto td = clk::now();
             est.Download();
+            const auto tl = clk::now();
             est.Synchronize();
             t1 = clk::now();
             std::cout << "HIP time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count() << std::endl;
+            // how long the host spent ENQUEUEING each phase (all four calls only enqueue; a long time here is the runtime
+            // blocking the caller) and waiting in Synchronize
+            auto ns = [](clk::time_point a, clk::time_point b) { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count(); };
+            std::cout << "host phases [ns]: upload " << ns(t0, tu) << " denoise " << ns(tu, td) << " download " << ns(td, tl) << " synchronize "
+                      << ns(tl, t1) << std::endl;
             if (!write) return;
             for (const auto &name : outputs) {
                 const Buffer *b = reg.find(name);
