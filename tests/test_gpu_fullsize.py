@@ -294,6 +294,48 @@ def test_config3_1080p_64spp_2x2_blocks(gpu):
     blocks_equal_whole(gpu, fs, 2, 2)
 
 
+def test_block_decomposition_at_the_shipped_small_radius(gpu, oracle):
+    """scenes/render-denoise-glass-caustics.pbrt (filterradius 6, filtersd 3) on the pair-symmetric kernel's runtime-radius
+    build: strips against the oracle, and 2 x 2 / 1 x 4 block decompositions (block + 6-pixel halo each) == the whole
+    film bit for bit -- the film-anchored tile grid and the fixed gather order do not depend on the radius."""
+    from statmc_amd import sharding
+    r, sd = 6, 3.0
+    fs = make_film(gpu, 1280, 720, 16, seed=11)
+    colour = fs.state["radiance"]["film_mean"]
+
+    def run(imgs, roi=None, origin=None, parts=0):
+        out = torch.zeros_like(imgs["colour"])
+        a, keep = gpu.make_filter_args([], [], [], [], [imgs["colour"]], [imgs["mean_corr"]], [imgs["disc"]], [out],
+                                       [imgs["normal"], imgs["albedo"]], g_sds=[SD_NORMAL, SD_ALBEDO], filter_sd=sd, radius=r,
+                                       roi=roi, film_origin=origin)
+        gpu.force_filter_parts(parts)
+        try:
+            gpu.window_filter(a, 3)
+            torch.cuda.synchronize()
+        finally:
+            gpu.force_filter_parts(0)
+        assert gpu.last_filter_variant() == "sym_rt", gpu.last_filter_variant()
+        return out
+
+    imgs = dict(mean_corr=fs.mean_corr, disc=fs.disc, colour=colour, normal=fs.g_buffer("normal"), albedo=fs.g_buffer("albedo"))
+    whole = run(imgs, parts=2)
+    for roi in ((0, 352, 1280, 360), (0, 0, 300, 8), (1280 - 300, 720 - 8, 1280, 720)):
+        x0, y0, x1, y1 = roi
+        ref = oracle.filter_image(fs.mean_corr.cpu().numpy(), fs.disc.cpu().numpy(), colour.cpu().numpy(),
+                                  [imgs["normal"].cpu().numpy(), imgs["albedo"].cpu().numpy()], G_DR, -0.5 / sd ** 2, r, roi=roi)[y0:y1, x0:x1]
+        got = whole[y0:y1, x0:x1].cpu().numpy()
+        for c in range(3):
+            assert rel_l2(got[..., c], ref[..., c]) <= 1e-5, (roi, c)
+    for gx, gy in ((2, 2), (1, 4)):
+        bw, bh = 1280 // gx, 720 // gy
+        for rank in range(gx * gy):
+            L = sharding.BlockLayout(rank, gx * gy, bw, bh, r, grid=(gx, gy))
+            ox, oy = L.origin
+            loc = {k: v[oy - L.pt:oy + bh + L.pb, ox - L.pl:ox + bw + L.pr].contiguous() for k, v in imgs.items()}
+            out = run(loc, roi=L.roi, origin=(ox - L.pl, oy - L.pt), parts=2)
+            assert torch.equal(L.interior(out), whole[oy:oy + bh, ox:ox + bw]), (gx, gy, rank)
+
+
 def test_config4_4k_strips_and_4x2_blocks(gpu, oracle):
     """configs[4]: 3840x2160.  Strip + corners against the oracle, and the 8-GPU partition (4x2 blocks of
     960x1080) against the whole film."""

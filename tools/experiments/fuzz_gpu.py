@@ -50,7 +50,7 @@ def filter_case(case, verbose=False):
         elif kind == 3: mc[y, x] = np.inf
         else: disc[y, x, rng.integers(0, 3)] = np.nan
     colour = (rng.random((H, W, 3), dtype=np.float32) * 3 * float(10 ** rng.uniform(-2, 3))).astype(np.float32)
-    layouts = [[3, 3]] * 6 + [[3], [], [3, 1, 1], [1, 3], [1, 1, 1, 1, 1, 1], [3, 3, 1], [1]]
+    layouts = [[3, 3]] * 6 + [[3], [], [3, 1, 1], [1, 3], [1, 1, 1, 1, 1, 1], [3, 3, 1], [1], [3, 3, 1, 1], [1, 3, 1, 3], [3, 1, 3]]
     layout = layouts[int(rng.integers(0, len(layouts)))]
     gbs = [(rng.random((H, W, c), dtype=np.float32) * 2 - (i % 2)).astype(np.float32) for i, c in enumerate(layout)]
     g_sds = (g_sds + [float(10 ** rng.uniform(-1.5, 0)) for _ in layout])[:len(layout)]
@@ -262,18 +262,28 @@ case = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 t_end = time.time() + budget
 n = fails = 0
 worst = 0.0
+import collections
+seen = collections.Counter()
+last_print = time.time()
 while time.time() < t_end:
     ok, d = filter_case(case)
     worst = max(worst, d["err"])
+    seen[d["variant"]] += 1
+    if time.time() - last_print > 60:
+        print("... %d cases, %d failures" % (n, fails), flush=True)
+        last_print = time.time()
     if not ok:
         fails += 1
         print("FAIL filter", d, flush=True)
     for name, fn in (("accumulate", accumulate_case), ("prepass", prepass_case), ("float_filter", float_filter_case),
                      ("tiles", tiles_case)):
         ok, d = fn(case)
+        if name == "float_filter":
+            seen[d["variant"]] += 1
         if not ok:
             fails += 1
             print("FAIL", name, d, flush=True)
     case += 1
     n += 1
 print("cases %d (next %d), worst filter rel L2 %.3g, failures %d" % (n, case, worst, fails))
+print("filter variants exercised:", dict(sorted(seen.items())))

@@ -49,7 +49,7 @@ def main():
     for sig in args.significance.split(","):
         for spec in variants(args.quick):
             cmd = [args.exe, "--stem", args.stem, "--spp", args.spp, "--filtersd", args.filtersd, "--filterradius",
-                   args.filterradius, "--significance", sig, "--spec", spec, "--compare", args.ref, "--kernel", "general",
+                   args.filterradius, "--significance", sig, "--spec", spec, "--compare", args.ref, "--no-write", "--kernel", "general",
                    "--output", "film-f,t0-b0-mean-corr,t0-b0-discriminator"]
             if args.tquantiles:
                 cmd += ["--tquantiles", args.tquantiles]

@@ -5,7 +5,7 @@
 //   statmc_denoise --stem out/scene --spp 4,8,16 [--filtersd 10] [--filterradius 20]
 //                  [--filterbuffers albedo,normal --filterbuffersds 0.02,0.1]
 //                  [--output 'film-f,t0-b0-mean-corr'] [--warmup]
-//                  [--significance 0|1|2] [--tquantiles table.txt] [--compare other/stem]
+//                  [--significance 0|1|2] [--tquantiles table.txt] [--compare other/stem] [--no-write]
 //                  [--spec gate=sym|asym,channels=and|joint,sides=two|one,dof=pixel|welch,border=clip|clamp,small_n=accept|exclude]
 //                  [--grid GXxGY [--devices 0,1,..]]   the denoise pass over film blocks with a halo exchange (C++ only)
 //   statmc_denoise --catalogue [--config denoise|acrr|smis|proden|ours] [--width W --height H]
@@ -116,6 +116,7 @@ static StatPathParams shippedConfig(const std::string &name) {
 int main(int argc, char **argv) {
     try {
         std::string stem, sppList, output = "film-f", config = "denoise", compareStem, tqFile, specText, gridText, devicesText;
+        bool noWrite = false;
         int forceParts = 0, bands = 0;
         std::string kernel;
         int significance = 0;
@@ -141,6 +142,7 @@ int main(int argc, char **argv) {
             else if (a == "--catalogue") catalogue = true;
             else if (a == "--warmup") warmup = true;
             else if (a == "--compare") compareStem = next();
+            else if (a == "--no-write") noWrite = true;   // compare / time only: no output dumps
             else if (a == "--significance") significance = std::stoi(next());
             else if (a == "--tquantiles") tqFile = next();
             else if (a == "--spec") specText = next();
@@ -281,10 +283,12 @@ int main(int argc, char **argv) {
                     for (size_t i = 0; i < tmp.size(); i++) tmp[i] = (float)host.ptr<int32_t>()[i];
                     pixels = tmp.data();
                 }
-                writePfm(prefix + name + ".pfm", width, height, host.channels(), pixels);
-                const std::string other = compareStem + "-" + spp + "-" + name + ".pfm";
-                if (!compareStem.empty() && fileExists(other))
-                    compareImages(name, readPfm(other), width, height, host.channels(), pixels);
+                // compare first, and never write over the file a comparison reads (--compare with the dumps' own stem: the
+                // CUDA build's outputs sit next to its inputs, tools/pin_from_dumps.sh)
+                const std::string mine = prefix + name + ".pfm", other = compareStem + "-" + spp + "-" + name + ".pfm";
+                const bool comparing = !compareStem.empty() && fileExists(other);
+                if (comparing) compareImages(name, readPfm(other), width, height, host.channels(), pixels);
+                if (!noWrite && !(comparing && other == mine)) writePfm(mine, width, height, host.channels(), pixels);
             }
         };
         if (warmup) {  // --warmup (statpath.cpp:543-547)
