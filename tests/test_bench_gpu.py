@@ -36,6 +36,8 @@ def test_single_gpu_line(gpu):
     assert r["n_ranks_seen"] == 1 and r["config"]["schedule"] == "single" and r["config"]["resident_pool_spp"] == 8
     assert 0.5 < r["shader_clock"]["during_filter_GHz"] < 3.0 and 0.5 < r["shader_clock"]["during_accumulate_GHz"] < 3.0
     assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["cores"] >= 1 and r["cpu_baseline"]["value"] > 0
+    par = r["cpu_baseline"]["parity_of_the_same_run"]
+    assert par["prepass_bit_exact"] and max(par["rel_l2_per_channel"]) <= 1e-5
     # secondary legs: the reference's own bracket through the C++ host side, tile-fed accumulation, copy rates
     assert r["cuda_time_bracket"]["cuda_time_bracket_ms"] > 0 and r["cuda_time_bracket"]["iterations"] == 12
     assert r["cuda_time_bracket"]["two_upload_queues"]["best_ms"] > 0
