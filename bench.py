@@ -428,6 +428,67 @@ def pool_slices(start, count, pool):
     return out
 
 
+def pcie_inclusive(fs, samples, types, args, chunk_spp=32, rounds=6):
+    """What the step costs when the samples are NOT resident: the renderer's samples sit in page-locked host memory and
+    cross PCIe on their way to the accumulation (statmc::Estimator's device-side accumulation, FlushSamples).  Two device
+    chunks of `chunk_spp` samples per pixel in flight: chunk k + 1 is copied on a copy stream while chunk k is
+    accumulated.  Reports the steady-state rate and what it makes of a whole step (spp / chunk copies + pre-pass +
+    filter, copies hiding the kernels).  Secondary; `value` is defined with the inputs resident."""
+    import ctypes as C
+    from statmc_amd import api, film
+    lib = api.load()
+    W, H, dev = fs.width, fs.height, fs.device
+    S = min(chunk_spp, next(iter(samples.values())).shape[0])
+    nbytes = {t: samples[t][:S].numel() * 4 for t in types}
+    host = {}
+    for t in types:
+        p = C.c_void_p()
+        api.check(lib.statmc_malloc_host(C.byref(p), nbytes[t]))
+        C.memset(p, 0, nbytes[t])                                   # touch every page before timing
+        host[t] = p
+    dchunks = [{t: torch.empty_like(samples[t][:S]) for t in types} for _ in range(2)]
+    st2 = film.FilmStats(W, H, dev, types=types)
+    copy_stream = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream()
+    landed = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
+
+    def upload(k):
+        copy_stream.wait_event(consumed[k])
+        for t in types:
+            api.check(lib.statmc_upload(C.c_void_p(dchunks[k][t].data_ptr()), host[t], nbytes[t], C.c_void_p(copy_stream.cuda_stream)))
+        landed[k].record(copy_stream)
+
+    def run(n):
+        for k in range(2):
+            consumed[k].record(main)
+        upload(0)
+        for i in range(n):
+            k = i & 1
+            if i + 1 < n:
+                upload(k ^ 1)
+            main.wait_event(landed[k])
+            st2.accumulate(dchunks[k])
+            consumed[k].record(main)
+        torch.cuda.synchronize()
+
+    try:
+        run(2)
+        t0 = time.perf_counter()
+        run(rounds)
+        dt = (time.perf_counter() - t0) / rounds
+    finally:
+        for p in host.values():
+            lib.statmc_free_host(p)
+    per_chunk_bytes = sum(nbytes.values())
+    n_chunks = (args.spp + S - 1) // S
+    step_ms = n_chunks * dt * 1e3 + 0.03 + 1.7          # + pre-pass + filter behind the last chunk
+    return {"chunk_spp": S, "chunk_bytes": per_chunk_bytes, "ms_per_chunk": round(dt * 1e3, 3), "GBs": round(per_chunk_bytes / dt / 1e9, 1),
+            "step_ms_if_samples_cross_pcie": round(step_ms, 1), "mpixels_per_s_if_samples_cross_pcie": round(W * H / step_ms / 1e3, 2),
+            "what": "samples of a step streamed from page-locked host memory in %d-spp chunks, copy of chunk k + 1 beside the accumulation of "
+                    "chunk k (the accumulation hides behind the copies: the link is the bound); step = %d chunks + pre-pass + filter" % (S, n_chunks)}
+
+
 def eight_channel_filter(fs, args, reps=20):
     """The window filter with all four feature images of the 11-channel stream as G-buffers -- normal, albedo, depth,
     material id: eight feature channels (statpath.cpp:828-835, 1096-1130) -- on the statistics the timed loop left.
@@ -780,6 +841,7 @@ def main():
             result["tile_fed_accumulate"] = leg(tile_fed_accumulate, fs, samples, types)
             result["host_copies"] = leg(host_copy_times, fs, dev)
             result["filter_8_feature_channels"] = leg(eight_channel_filter, fs, args)
+            result["pcie_inclusive"] = leg(pcie_inclusive, fs, samples, types, args)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(args, fs, samples, types)

@@ -44,6 +44,7 @@ def test_single_gpu_line(gpu):
     assert r["tile_fed_accumulate"]["achieved_GBs"] > 0
     assert r["host_copies"]["upload_bytes_per_px"] == 76 and r["host_copies"]["download_bytes_per_px"] == 12
     assert r["filter_8_feature_channels"]["filter_variant"] == "sym_r20_g8" and r["filter_8_feature_channels"]["avg_ms"] > 0
+    assert r["pcie_inclusive"]["GBs"] > 0 and r["pcie_inclusive"]["mpixels_per_s_if_samples_cross_pcie"] < r["value"]
 
 
 @pytest.mark.parametrize("grid,blocks", [("rows", "1x2"), ("blocks", "2x1")])
