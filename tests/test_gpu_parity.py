@@ -896,6 +896,28 @@ def test_packed_inputs_under_non_default_specs(gpu, oracle, spec_kw, variant):
         assert rel_l2(got[y0:y1, x0:x1, c], ref[y0:y1, x0:x1, c]) <= TOL, c
 
 
+@pytest.mark.parametrize("radius,sd,variant,origin", [(6, 3.0, "sym_rt", (128, 40)), (6, 3.0, "sym_rt", (122, 34)), (13, 6.0, "sym_rt", (256, 8))])
+def test_packed_inputs_at_small_radii(gpu, oracle, radius, sd, variant, origin):
+    """The block + halo image of the multi-GPU path at the glass-caustics radius: the pair-symmetric kernel's
+    runtime-radius build stages from the 15-channel image (LDS-DMA) like the r = 20 build."""
+    W, H, m = 300, 56, radius
+    mc, disc, colour, gbs = stats_case(oracle, W, H, 8, seed=406)
+    roi = (m, m, W - m, H - m)
+    ref = oracle.filter_image(mc, disc, colour, gbs, G_DR, -0.5 / sd ** 2, radius, roi=roi)
+    packed = to_dev(np.concatenate([mc, disc, colour, gbs[0], gbs[1]], axis=2))
+    out = torch.zeros(H, W, 3, device=DEV)
+    a, keep = gpu.make_filter_args([], [], [], [], [], [], [], [out], [], g_sds=[SD_NORMAL, SD_ALBEDO],
+                                   filter_sd=sd, radius=radius, roi=roi, packed=packed, film_origin=origin)
+    gpu.window_filter(a, 3)
+    torch.cuda.synchronize()
+    assert gpu.last_filter_variant() == variant
+    got = out.cpu().numpy()
+    x0, y0, x1, y1 = roi
+    for c in range(3):
+        assert rel_l2(got[y0:y1, x0:x1, c], ref[y0:y1, x0:x1, c]) <= TOL, c
+    assert not got[:m].any() and not got[:, :m].any()
+
+
 def test_prepass_pack_equals_prepass_then_pack(gpu, oracle):
     """statmc_prepass_pack (the multi-GPU path's single pass) writes the same bits as statmc_prepass
     followed by statmc_pack_filter_inputs, with and without the mean_corr / discriminator by-products."""
