@@ -24,6 +24,7 @@ thread_local int g_last_parts = 0;
 std::atomic<int> g_accumulate_resident_blocks{0};
 std::atomic<int> g_tiles_umul{2}, g_tiles_order{0}, g_tiles_wg_per_cu{0};   // tile-fed path: deeper prefetch of the mean-only types by default
 std::atomic<int> g_accumulate_umul{1};
+std::atomic<int> g_accumulate_dma{0};   // RGB sample planes by LDS-DMA (statmc_debug_accumulate_dma(1)); A/B: no gain inside the full type mix
 std::mutex g_mu;
 
 // Everything the library remembers is kept per device (one Estimator per device in a process that drives
@@ -898,6 +899,7 @@ int statmc_accumulate(uint16_t width, uint16_t height, const statmc_stat_type *t
         if (int rc = fill_stat_type(types[i], i, width, height, true, k.t[i])) return rc;
     k.resident_blocks = g_accumulate_resident_blocks;
     k.umul = g_accumulate_umul;
+    k.dma = g_accumulate_dma;
     HIP_TRY(statmc::launch_accumulate(k, S(stream)));
     return STATMC_OK;
 }
@@ -923,6 +925,7 @@ int statmc_accumulate_tiles(uint16_t width, uint16_t height, const statmc_stat_t
     k.n_tiles = n_tiles;
     k.width = width;
     k.height = height;
+    k.dma = g_accumulate_dma;
     k.umul = g_tiles_umul;
     k.order = g_tiles_order;
     k.wg_per_cu = g_tiles_wg_per_cu;
@@ -985,6 +988,10 @@ int statmc_debug_force_filter_variant(int v) {  // 0 auto, 1 generic, 2 runtime-
 }
 int statmc_debug_accumulate_resident_blocks(int n) {  // 0 large grid (default), n > 0: n resident workgroups
     g_accumulate_resident_blocks = n < 0 ? 0 : n;
+    return STATMC_OK;
+}
+int statmc_debug_accumulate_dma(int on) {   // 1 (default): RGB sample planes stream through LDS-DMA; 0: loads into registers
+    g_accumulate_dma = on ? 1 : 0;
     return STATMC_OK;
 }
 int statmc_debug_accumulate_umul(int umul) {   // film-major kernel: 2 = the mean-only feature types prefetch twice as deep

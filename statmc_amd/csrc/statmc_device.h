@@ -42,6 +42,7 @@ struct AccumulateArgs {
     int n_types;
     int resident_blocks;  // 0: large interleaved grid; > 0: that many workgroups walk all types
     int umul;             // 2: the mean-only feature types prefetch twice as deep (statmc_debug_accumulate_umul; A/B)
+    int dma;              // RGB sample planes arrive by LDS-DMA (default 1; 0: loads into registers, A/B)
     // large grid: workgroup b serves slot b % n_slots; slots are dealt to types in proportion to cost
     int n_slots;
     int type_slots[kMaxStatTypes];
@@ -58,6 +59,7 @@ struct AccumulateTilesArgs {
     const long long *tile_offsets;   // device, in pixel-samples
     const int32_t *tile_samples;     // device
     int n_tiles, width, height, vec;
+    int dma;                         // RGB sample planes arrive by LDS-DMA (default 1)
     int umul, order, wg_per_cu;      // experiment knobs (statmc_debug_accumulate_tiles_variant): prefetch depth x2, item order, grid size
 };
 

@@ -33,9 +33,26 @@
 #ifndef STATMC_ACC_U_F
 #define STATMC_ACC_U_F 6
 #endif
+// RGB sample planes stream through LDS-DMA (global_load_lds_dwordx4, non-temporal): a wave's sample row is 3 KiB of
+// contiguous memory, three 1-KiB transfers land it in a wave-private ring of STATMC_ACC_DMA_D rows, every lane reads its own
+// 48 B back.  tools/microbench/hbm_read_ldsdma.hip: 7.0 TB/s against 6.26 for the same walk with loads into registers
+// (which for a 48-B lane stride coalesce only through the cache and must not be non-temporal); 1-channel planes keep
+// their non-temporal register loads (6.8 TB/s against 6.3 - 6.6 through LDS-DMA).
+// element pairs folded stage by stage together (RGB types: 6 pairs per lane and sample)
+#ifndef STATMC_ACC_PAIR_GROUP
+#define STATMC_ACC_PAIR_GROUP 3
+#endif
+#ifndef STATMC_ACC_DMA_D
+#define STATMC_ACC_DMA_D 5
+#endif
 #include "t_quantiles.h"
 
 namespace statmc {
+
+constexpr int kAccDmaD = STATMC_ACC_DMA_D;                 // sample rows in flight per wave (RGB types)
+constexpr int kAccRingFloats = kAccDmaD * 3 * 256;          // per wave: D rows of 64 lanes x 12 floats
+constexpr size_t kAccLdsBytes = (size_t)4 * kAccRingFloats * sizeof(float);   // four waves per workgroup
+template <int N> __device__ __forceinline__ void acc_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Student-t tables, uploaded once by statmc_setup() (hipMemcpyToSymbol).
 __device__ float g_tq[STATMC_TQ_N_TABLES][STATMC_TQ_N_DOF];
@@ -242,17 +259,90 @@ __device__ __forceinline__ void add_sample(ElemState &st, float nf, float r, flo
     }
 }
 
+// The same update on two elements at once (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: one issue slot for two lanes'
+// worth of IEEE fp32 arithmetic, each component rounded exactly like the scalar instruction, so the bits are those of
+// add_sample).  The kernel holds ~250 VGPRs, i.e. two waves per SIMD, and while one of them waits for memory the other
+// issues one vector instruction per 4 cycles: the radiance type (Box-Cox + three moments + the raw-sample chain, 27
+// instructions per element and sample) was bound by exactly that issue rate (5.1 TB/s on its own); paired, it is
+// bound by the memory like the feature types.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct PairState {
+    v2f mean, m2, m3, fmean, fm2;
+};
+__device__ __forceinline__ v2f div_by_count2(v2f d, v2f nf, v2f r) {
+    const v2f q0 = d * r;
+    const v2f rem = __builtin_elementwise_fma(-q0, nf, d);
+    return __builtin_elementwise_fma(rem, r, q0);
+}
+// G pairs at a time, stage by stage: consecutive instructions belong to different pairs, so none waits for the one
+// before it (a dependent packed instruction costs a wait state, and the kernel is compiled without the machine scheduler:
+// the source order is the issue order).
+#define STATMC_PAIRS(i) _Pragma("unroll") for (int i = 0; i < G; i++)
+template <int G, int MAXM, bool TRANSFORM>
+__device__ __forceinline__ void add_sample2(PairState *st, const v2f *nf, const v2f *r, const v2f *smp) {
+    v2f v[G], d[G], q0[G], dN[G];
+    if (TRANSFORM) {   // estimator.h:215 -- boxCox(sample, .5f), as in add_sample
+        STATMC_PAIRS(i) v[i] = v2f{__builtin_amdgcn_sqrtf(smp[i].x), __builtin_amdgcn_sqrtf(smp[i].y)};
+        STATMC_PAIRS(i) v[i] = v[i] - 1.f;
+        STATMC_PAIRS(i) v[i] = v[i] / .5f;
+    } else {
+        STATMC_PAIRS(i) v[i] = smp[i];
+    }
+    STATMC_PAIRS(i) d[i] = v[i] - st[i].mean;
+    STATMC_PAIRS(i) q0[i] = d[i] * r[i];                                         // div_by_count, three stages
+    STATMC_PAIRS(i) dN[i] = __builtin_elementwise_fma(-q0[i], nf[i], d[i]);
+    STATMC_PAIRS(i) dN[i] = __builtin_elementwise_fma(dN[i], r[i], q0[i]);
+    STATMC_PAIRS(i) st[i].mean += dN[i];
+    if (MAXM >= 2) {
+        v2f t[G];
+        STATMC_PAIRS(i) t[i] = d[i] - dN[i];
+        STATMC_PAIRS(i) t[i] = d[i] * t[i];
+        STATMC_PAIRS(i) st[i].m2 += t[i];
+    }
+    if (MAXM >= 3) {   // m3 += -3 dN m2 + d (d^2 - dN^2), with the m2 already updated (estimator.h:178-180)
+        v2f a[G], b[G];
+        STATMC_PAIRS(i) a[i] = -3.f * dN[i];
+        STATMC_PAIRS(i) b[i] = d[i] * d[i];
+        STATMC_PAIRS(i) dN[i] = dN[i] * dN[i];
+        STATMC_PAIRS(i) a[i] = a[i] * st[i].m2;
+        STATMC_PAIRS(i) b[i] = b[i] - dN[i];
+        STATMC_PAIRS(i) b[i] = d[i] * b[i];
+        STATMC_PAIRS(i) a[i] = a[i] + b[i];
+        STATMC_PAIRS(i) st[i].m3 += a[i];
+    }
+    if (TRANSFORM) {   // the raw-sample chain (estimator.h:217-225)
+        STATMC_PAIRS(i) d[i] = smp[i] - st[i].fmean;
+        STATMC_PAIRS(i) q0[i] = d[i] * r[i];
+        STATMC_PAIRS(i) dN[i] = __builtin_elementwise_fma(-q0[i], nf[i], d[i]);
+        STATMC_PAIRS(i) dN[i] = __builtin_elementwise_fma(dN[i], r[i], q0[i]);
+        STATMC_PAIRS(i) st[i].fmean += dN[i];
+        STATMC_PAIRS(i) dN[i] = d[i] - dN[i];
+        STATMC_PAIRS(i) dN[i] = d[i] * dN[i];
+        STATMC_PAIRS(i) st[i].fm2 += dN[i];
+    }
+}
+#undef STATMC_PAIRS
+
 // The lane's 4 consecutive pixels starting at film pixel p0 (16-B aligned planes): load the
 // state, fold S samples in order, store.  Sample s of the lane's elements is at sp + s * stride
 // (4*C consecutive floats): stride = n_elems for sample-major film planes, = tile pixels * C for
 // the tile-major arena of accumulate_tiles.
 // UMUL: prefetch depth multiplier (tile-fed path, types whose state is small enough to afford the registers)
-template <int C, int MAXM, bool TRANSFORM, int UMUL = 1>
-__device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long long p0, const float *sp,
-                                                long long stride, int S) {
+// DMA (C == 3 only): the sample rows arrive by LDS-DMA in the wave's ring.  That walk is COOPERATIVE -- the 16-byte piece a
+// lane fetches belongs to another lane's pixels -- so the whole wave calls in: lane l owns the 4-pixel group at
+// sp_wave + 12 l floats, `active` says whether that group exists, `n_active` (wave-uniform) how many lanes' groups do
+// (they are the first n_active lanes).  Without DMA an inactive lane returns at once.
+template <int C, int MAXM, bool TRANSFORM, int UMUL = 1, bool DMA = false>
+__device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long long p0_in, const float *sp,
+                                                long long stride, int S, float *ring = nullptr, bool active = true, int n_active = 64) {
+    constexpr bool kDma = DMA && C == 3;
+    if constexpr (!kDma) {
+        if (!active) return;
+    }
+    const long long p0 = active ? p0_in : 0;   // an inactive lane of the cooperative walk touches no state: its loads read group 0, it stores nothing
     constexpr int NE = 4 * C;  // elements per lane
     const long long e0 = p0 * C;
-    ElemState st[NE];
+    PairState st[NE / 2];   // element pairs (2 i, 2 i + 1) of the lane's 4 C consecutive elements
     float tmp[NE];
     const int4 n4 = *reinterpret_cast<const int4 *>(t.n + p0);
     const int n0[4] = {n4.x, n4.y, n4.z, n4.w};
@@ -265,7 +355,7 @@ __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long lo
     } else {                                                                     \
         _Pragma("unroll") for (int j = 0; j < NE; j++) tmp[j] = 0.f;             \
     }                                                                            \
-    _Pragma("unroll") for (int j = 0; j < NE; j++) st[j].field = tmp[j];
+    _Pragma("unroll") for (int j = 0; j < NE / 2; j++) st[j].field = v2f{tmp[2 * j], tmp[2 * j + 1]};
     STATMC_LOAD_PLANE(t.mean, mean, true)
     STATMC_LOAD_PLANE(t.m2, m2, MAXM >= 2)
     STATMC_LOAD_PLANE(t.m3, m3, MAXM >= 3)
@@ -290,21 +380,37 @@ __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long lo
     // same number of samples, i.e. all but adaptively sampled ones) -> one count conversion and
     // one refined reciprocal per sample instead of four (a fifth of the kernel's VALU work).
     auto fold_sample = [&](const vfloat4 (&q)[C], int s, auto same) {
-        float nf[4], rc[4];
         if constexpr (decltype(same)::value) {
             const float nf0 = (float)(n0[0] + s + 1);
             const float rc0 = refined_rcp(nf0);
+            v2f nf2[NE / 2], rc2[NE / 2], smp2[NE / 2];
 #pragma unroll
-            for (int p = 0; p < 4; p++) { nf[p] = nf0; rc[p] = rc0; }
+            for (int i = 0; i < NE / 2; i++) {   // elements 2 i and 2 i + 1
+                nf2[i] = v2f{nf0, nf0};
+                rc2[i] = v2f{rc0, rc0};
+                smp2[i] = v2f{q[i >> 1][2 * (i & 1)], q[i >> 1][2 * (i & 1) + 1]};
+            }
+            constexpr int G = C == 3 ? STATMC_ACC_PAIR_GROUP : 2;
+#pragma unroll
+            for (int g = 0; g < NE / 2; g += G) add_sample2<G, MAXM, TRANSFORM>(st + g, nf2 + g, rc2 + g, smp2 + g);
         } else {
+            // ragged counts (adaptively sampled films): element by element, one reciprocal per pixel
+            float nf[4], rc[4];
 #pragma unroll
             for (int p = 0; p < 4; p++) {
                 nf[p] = (float)(n0[p] + s + 1);
                 rc[p] = refined_rcp(nf[p]);
             }
-        }
 #pragma unroll
-        for (int j = 0; j < NE; j++) add_sample<MAXM, TRANSFORM>(st[j], nf[j / C], rc[j / C], q[j >> 2][j & 3]);
+            for (int j = 0; j < NE; j++) {
+                ElemState e = {st[j >> 1].mean[j & 1], st[j >> 1].m2[j & 1], st[j >> 1].m3[j & 1], st[j >> 1].fmean[j & 1], st[j >> 1].fm2[j & 1]};
+                add_sample<MAXM, TRANSFORM>(e, nf[j / C], rc[j / C], q[j >> 2][j & 3]);
+                st[j >> 1].mean[j & 1] = e.mean;
+                if (MAXM >= 2) st[j >> 1].m2[j & 1] = e.m2;
+                if (MAXM >= 3) st[j >> 1].m3[j & 1] = e.m3;
+                if (TRANSFORM) { st[j >> 1].fmean[j & 1] = e.fmean; st[j >> 1].fm2[j & 1] = e.fm2; }
+            }
+        }
     };
     auto walk_samples = [&](auto same) {
         vfloat4 cur[U][C], nxt[U][C];
@@ -332,15 +438,74 @@ __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long lo
             fold_sample(q, s, same);
         }
     };
+    // The same walk with the sample rows arriving by LDS-DMA (C == 3): D rows in flight in the wave's ring; row s has
+    // landed when at most 3 (D - 1) transfers issued after it are outstanding (VMEM operations of a wave complete in
+    // order; nothing else touches memory inside the walk).  A slot is refilled once every lane has read its 48 B.
+    auto walk_samples_dma = [&](auto same) {
+        constexpr int D = kAccDmaD;
+        const int lane = threadIdx.x & 63;
+        const float *row0 = sp - 12 * lane;                 // the wave's row of sample 0 (lane l sits 12 l floats in; the same value in every lane)
+        const int row_floats = 12 * n_active;               // the part of the wave's row that exists
+        // Every lane issues all three transfers of a row, whatever part of the row exists: the waits below COUNT transfers
+        // (vmcnt), so their number per row must not depend on n_active.  A piece beyond the row's end re-reads the row's first
+        // 16 bytes (memory that exists) into a part of the slot nobody reads.
+        int piece[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) piece[k] = 256 * k + 4 * lane < row_floats ? 256 * k + 4 * lane : 0;
+        auto issue = [&](int s, int slot) {
+            const float *src = row0 + (long long)s * stride;
+            float *dst = ring + slot * 768;
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                __builtin_amdgcn_global_load_lds(src + piece[k], (__attribute__((address_space(3))) void *)(dst + 256 * k), 16, 0, 2);
+        };
+        auto take = [&](vfloat4 (&q)[C], int slot) {
+            const float *mine = ring + slot * 768 + 12 * lane;
+#pragma unroll
+            for (int k = 0; k < C; k++) q[k] = *reinterpret_cast<const vfloat4 *>(mine + 4 * k);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read before the slot is refilled
+        };
+        // every earlier access of the wave to memory (the state loads above) has completed before the counted waits start
+        acc_wait_vmcnt<0>();
+#pragma unroll
+        for (int d = 0; d < D; d++)
+            if (d < S) issue(d, d);
+        const int S_full = S >= D ? S - D + 1 : 0;          // samples s < S_full have D - 1 later rows in flight behind them
+        int s = 0;
+        for (; s + D <= S_full; s += D) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                vfloat4 q[C];
+                acc_wait_vmcnt<3 * (D - 1)>();
+                take(q, d);
+                if (s + d + D < S) issue(s + d + D, d);
+                fold_sample(q, s + d, same);
+            }
+        }
+        for (; s < S; s++) {                                 // the last rows (and batches shorter than the ring)
+            vfloat4 q[C];
+            const int slot = s % D;
+            if (s < S_full) acc_wait_vmcnt<3 * (D - 1)>(); else acc_wait_vmcnt<0>();
+            take(q, slot);
+            if (s + D < S) issue(s + D, slot);
+            fold_sample(q, s, same);
+        }
+    };
     // wave-uniform choice: the fast walk only when every active lane qualifies
-    const bool lane_same = n0[0] == n0[1] && n0[1] == n0[2] && n0[2] == n0[3];
-    if (__builtin_amdgcn_ballot_w64(!lane_same) == 0) walk_samples(std::true_type{});
-    else walk_samples(std::false_type{});
+    const bool lane_same = !active || (n0[0] == n0[1] && n0[1] == n0[2] && n0[2] == n0[3]);
+    if constexpr (kDma) {
+        if (__builtin_amdgcn_ballot_w64(!lane_same) == 0) walk_samples_dma(std::true_type{});
+        else walk_samples_dma(std::false_type{});
+        if (!active) return;                                // nothing of an inactive lane is stored
+    } else {
+        if (__builtin_amdgcn_ballot_w64(!lane_same) == 0) walk_samples(std::true_type{});
+        else walk_samples(std::false_type{});
+    }
 #define STATMC_STORE_PLANE(ptr, field, enabled)                                  \
     if (enabled) {                                                               \
         _Pragma("unroll") for (int k = 0; k < C; k++)                            \
             *reinterpret_cast<float4 *>((ptr) + e0 + 4 * k) =                    \
-                make_float4(st[4 * k].field, st[4 * k + 1].field, st[4 * k + 2].field, st[4 * k + 3].field); \
+                make_float4(st[2 * k].field.x, st[2 * k].field.y, st[2 * k + 1].field.x, st[2 * k + 1].field.y); \
     }
     STATMC_STORE_PLANE(t.mean, mean, true)
     STATMC_STORE_PLANE(t.m2, m2, MAXM >= 2)
@@ -379,31 +544,39 @@ __device__ __forceinline__ void accumulate_pixel(const AccumulateType &t, long l
 
 // Film-major batch: one lane owns 4 consecutive PIXELS of one stat type and walks the batch's
 // samples in order (sample s of pixel p, channel c is at samples[s*n_elems + p*C + c]).
-template <int C, int MAXM, bool TRANSFORM, bool VEC, int UMUL>
-__device__ __forceinline__ void accumulate_type(const AccumulateType &t, long long blk, long long nblk) {
+template <int C, int MAXM, bool TRANSFORM, bool VEC, int UMUL, bool DMA>
+__device__ __forceinline__ void accumulate_type(const AccumulateType &t, long long blk, long long nblk, float *ring) {
     const long long n_px = t.n_elems / C;
     const long long n_groups = (n_px + 3) >> 2;
-    for (long long g = blk * kBlock + threadIdx.x; g < n_groups; g += nblk * kBlock) {
-        const long long p0 = g << 2;
-        if (VEC && p0 + 4 <= n_px) {
-            accumulate_lane<C, MAXM, TRANSFORM, (!TRANSFORM && MAXM == 1) ? UMUL : 1>(t, p0, t.samples + p0 * C, t.n_elems, t.n_samples);
-        } else {
+    const long long n_full = VEC ? (n_px >> 2) : 0;          // complete 4-pixel groups: the vector path's share
+    const int lane = threadIdx.x & 63;
+    // wave-uniform walk over the groups: the waves of a workgroup take 64 consecutive groups each (the LDS-DMA walk of the
+    // RGB types is cooperative: every lane of a wave with at least one complete group calls in)
+    for (long long gw = blk * kBlock + (threadIdx.x & ~63); gw < n_groups; gw += nblk * kBlock) {
+        const long long g = gw + lane, p0 = g << 2;
+        const bool active = g < n_full;
+        const long long left = n_full - gw;
+        const int n_active = left >= 64 ? 64 : left > 0 ? (int)left : 0;
+        if (n_active > 0)
+            accumulate_lane<C, MAXM, TRANSFORM, (!TRANSFORM && MAXM == 1) ? UMUL : 1, DMA>(t, p0, t.samples + p0 * C, t.n_elems, t.n_samples,
+                                                                                            ring, active, n_active);
+        if (!active && g < n_groups) {   // unaligned images, the ragged last group
             for (long long p = p0; p < n_px && p < p0 + 4; p++)
                 accumulate_pixel<C, MAXM, TRANSFORM>(t, p, t.samples + p * C, t.n_elems, t.n_samples);
         }
     }
 }
 
-template <int C, bool VEC, int UMUL>
-__device__ __forceinline__ void accumulate_dispatch(const AccumulateType &t, long long blk, long long nblk) {
+template <int C, bool VEC, int UMUL, bool DMA>
+__device__ __forceinline__ void accumulate_dispatch(const AccumulateType &t, long long blk, long long nblk, float *ring) {
     if (t.transform) {
-        if (t.max_moment >= 3) accumulate_type<C, 3, true, VEC, UMUL>(t, blk, nblk);
-        else if (t.max_moment == 2) accumulate_type<C, 2, true, VEC, UMUL>(t, blk, nblk);
-        else accumulate_type<C, 1, true, VEC, UMUL>(t, blk, nblk);
+        if (t.max_moment >= 3) accumulate_type<C, 3, true, VEC, UMUL, DMA>(t, blk, nblk, ring);
+        else if (t.max_moment == 2) accumulate_type<C, 2, true, VEC, UMUL, DMA>(t, blk, nblk, ring);
+        else accumulate_type<C, 1, true, VEC, UMUL, DMA>(t, blk, nblk, ring);
     } else {
-        if (t.max_moment >= 3) accumulate_type<C, 3, false, VEC, UMUL>(t, blk, nblk);
-        else if (t.max_moment == 2) accumulate_type<C, 2, false, VEC, UMUL>(t, blk, nblk);
-        else accumulate_type<C, 1, false, VEC, UMUL>(t, blk, nblk);
+        if (t.max_moment >= 3) accumulate_type<C, 3, false, VEC, UMUL, DMA>(t, blk, nblk, ring);
+        else if (t.max_moment == 2) accumulate_type<C, 2, false, VEC, UMUL, DMA>(t, blk, nblk, ring);
+        else accumulate_type<C, 1, false, VEC, UMUL, DMA>(t, blk, nblk, ring);
     }
 }
 
@@ -415,13 +588,16 @@ __device__ __forceinline__ void accumulate_dispatch(const AccumulateType &t, lon
 // running this bandwidth-bound kernel beside the VALU-bound window filter of the previous
 // iteration on a second stream gains <= 15 % (the two contend for VALU issue), so bench.py
 // keeps the kernels back to back.
-template <bool VEC, int UMUL>
+template <bool VEC, int UMUL, bool DMA>
 __global__ __launch_bounds__(kBlock) void accumulate_kernel(AccumulateArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float acc_lds[];
+    // the wave's LDS-DMA ring (RGB types, vector path); DMA = false (debug hook, A/B) keeps every type on register loads
+    float *ring = DMA ? acc_lds + (threadIdx.x >> 6) * kAccRingFloats : nullptr;
     if (a.resident_blocks > 0) {
         for (int i = 0; i < a.n_types; i++) {
             const AccumulateType &t = a.t[(blockIdx.x + i) % a.n_types];
-            if (t.channels == 3) accumulate_dispatch<3, VEC, UMUL>(t, blockIdx.x, gridDim.x);
-            else accumulate_dispatch<1, VEC, UMUL>(t, blockIdx.x, gridDim.x);
+            if (t.channels == 3) accumulate_dispatch<3, VEC, UMUL, DMA>(t, blockIdx.x, gridDim.x, ring);
+            else accumulate_dispatch<1, VEC, UMUL, DMA>(t, blockIdx.x, gridDim.x, ring);
         }
         return;
     }
@@ -433,8 +609,8 @@ __global__ __launch_bounds__(kBlock) void accumulate_kernel(AccumulateArgs a) {
     const AccumulateType &t = a.t[ti];
     const long long blk = (long long)round * a.type_slots[ti] + a.slot_rank[slot];
     const long long nblk = (long long)n_rounds * a.type_slots[ti];
-    if (t.channels == 3) accumulate_dispatch<3, VEC, UMUL>(t, blk, nblk);
-    else accumulate_dispatch<1, VEC, UMUL>(t, blk, nblk);
+    if (t.channels == 3) accumulate_dispatch<3, VEC, UMUL, DMA>(t, blk, nblk, ring);
+    else accumulate_dispatch<1, VEC, UMUL, DMA>(t, blk, nblk, ring);
 }
 
 hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
@@ -474,12 +650,14 @@ hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
     }
     const int rounds = (grid_for(max_groups, 256 * 8) * a.n_types + a.n_slots - 1) / a.n_slots;
     const dim3 grid(a.resident_blocks > 0 ? a.resident_blocks : rounds * a.n_slots);
-    if (vec && a.umul == 2)
-        hipLaunchKernelGGL((accumulate_kernel<true, 2>), grid, dim3(kBlock), 0, s, a);
+    if (vec && a.dma)
+        hipLaunchKernelGGL((accumulate_kernel<true, 1, true>), grid, dim3(kBlock), kAccLdsBytes, s, a);
+    else if (vec && a.umul == 2)
+        hipLaunchKernelGGL((accumulate_kernel<true, 2, false>), grid, dim3(kBlock), 0, s, a);
     else if (vec)
-        hipLaunchKernelGGL((accumulate_kernel<true, 1>), grid, dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL((accumulate_kernel<true, 1, false>), grid, dim3(kBlock), 0, s, a);
     else
-        hipLaunchKernelGGL((accumulate_kernel<false, 1>), grid, dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL((accumulate_kernel<false, 1, false>), grid, dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 
@@ -489,9 +667,9 @@ hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
 // block [S_tile][tile_h][tile_w][C] of a per-type arena, S_tile the same for every pixel of the
 // tile but free to differ between tiles.  One wave per (tile, type): a 16 x 16 tile is exactly
 // 64 lanes x 4 pixels, a sample plane of the block is one contiguous 1 / 3 KiB read of the wave.
-template <int C, int MAXM, bool TRANSFORM, int UMUL>
+template <int C, int MAXM, bool TRANSFORM, int UMUL, bool DMA>
 __device__ __forceinline__ void accumulate_tile(const AccumulateType &t, const AccumulateTilesArgs &a, int x0, int y0,
-                                                int tw, int th, long long off, int S) {
+                                                int tw, int th, long long off, int S, float *ring) {
     const int lane = threadIdx.x & 63;
     const int npx = tw * th;
     const float *base = t.samples + off * C;
@@ -500,11 +678,15 @@ __device__ __forceinline__ void accumulate_tile(const AccumulateType &t, const A
     // block's offset are all multiples of 4 (and the images themselves 16-B aligned: a.vec)
     const bool fast = a.vec && ((tw | x0 | a.width) & 3) == 0 && (off & 3) == 0;
     if (fast) {
-        for (int g = lane; g < (npx >> 2); g += 64) {
+        const int n_g = npx >> 2;
+        for (int gw = 0; gw < n_g; gw += 64) {   // wave-uniform: the LDS-DMA walk of the RGB types is cooperative
+            const int g = gw + lane;
+            const bool active = g < n_g;
             const int i = g << 2, row = i / tw, col = i - row * tw;
             const long long p0 = (long long)(y0 + row) * a.width + x0 + col;
             // deeper prefetch only where the state is one plane (mean-only feature types): the registers are there
-            accumulate_lane<C, MAXM, TRANSFORM, (!TRANSFORM && MAXM == 1) ? UMUL : 1>(t, p0, base + (long long)i * C, stride, S);
+            accumulate_lane<C, MAXM, TRANSFORM, (!TRANSFORM && MAXM == 1) ? UMUL : 1, DMA>(t, p0, base + (long long)i * C, stride, S, ring, active,
+                                                                                            n_g - gw >= 64 ? 64 : n_g - gw);
         }
     } else {
         for (int i = lane; i < npx; i += 64) {
@@ -515,22 +697,24 @@ __device__ __forceinline__ void accumulate_tile(const AccumulateType &t, const A
     }
 }
 
-template <int C, int UMUL>
+template <int C, int UMUL, bool DMA>
 __device__ __forceinline__ void accumulate_tile_dispatch(const AccumulateType &t, const AccumulateTilesArgs &a, int x0,
-                                                         int y0, int tw, int th, long long off, int S) {
+                                                         int y0, int tw, int th, long long off, int S, float *ring) {
     if (t.transform) {
-        if (t.max_moment >= 3) accumulate_tile<C, 3, true, UMUL>(t, a, x0, y0, tw, th, off, S);
-        else if (t.max_moment == 2) accumulate_tile<C, 2, true, UMUL>(t, a, x0, y0, tw, th, off, S);
-        else accumulate_tile<C, 1, true, UMUL>(t, a, x0, y0, tw, th, off, S);
+        if (t.max_moment >= 3) accumulate_tile<C, 3, true, UMUL, DMA>(t, a, x0, y0, tw, th, off, S, ring);
+        else if (t.max_moment == 2) accumulate_tile<C, 2, true, UMUL, DMA>(t, a, x0, y0, tw, th, off, S, ring);
+        else accumulate_tile<C, 1, true, UMUL, DMA>(t, a, x0, y0, tw, th, off, S, ring);
     } else {
-        if (t.max_moment >= 3) accumulate_tile<C, 3, false, UMUL>(t, a, x0, y0, tw, th, off, S);
-        else if (t.max_moment == 2) accumulate_tile<C, 2, false, UMUL>(t, a, x0, y0, tw, th, off, S);
-        else accumulate_tile<C, 1, false, UMUL>(t, a, x0, y0, tw, th, off, S);
+        if (t.max_moment >= 3) accumulate_tile<C, 3, false, UMUL, DMA>(t, a, x0, y0, tw, th, off, S, ring);
+        else if (t.max_moment == 2) accumulate_tile<C, 2, false, UMUL, DMA>(t, a, x0, y0, tw, th, off, S, ring);
+        else accumulate_tile<C, 1, false, UMUL, DMA>(t, a, x0, y0, tw, th, off, S, ring);
     }
 }
 
-template <int UMUL>
+template <int UMUL, bool DMA>
 __global__ __launch_bounds__(kBlock) void accumulate_tiles_kernel(AccumulateTilesArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float acc_lds[];
+    float *ring = DMA ? acc_lds + (threadIdx.x >> 6) * kAccRingFloats : nullptr;
     const long long n_items = (long long)a.n_tiles * a.n_types;
     const long long n_waves = (long long)gridDim.x * (kBlock / 64);
     // item = (tile, type), types innermost: the waves of a workgroup work on the types of one
@@ -544,8 +728,8 @@ __global__ __launch_bounds__(kBlock) void accumulate_tiles_kernel(AccumulateTile
         const int S = a.tile_samples[tile];
         if (S <= 0 || x1 <= x0 || y1 <= y0) continue;
         const AccumulateType &t = a.t[ti];
-        if (t.channels == 3) accumulate_tile_dispatch<3, UMUL>(t, a, x0, y0, x1 - x0, y1 - y0, a.tile_offsets[tile], S);
-        else accumulate_tile_dispatch<1, UMUL>(t, a, x0, y0, x1 - x0, y1 - y0, a.tile_offsets[tile], S);
+        if (t.channels == 3) accumulate_tile_dispatch<3, UMUL, DMA>(t, a, x0, y0, x1 - x0, y1 - y0, a.tile_offsets[tile], S, ring);
+        else accumulate_tile_dispatch<1, UMUL, DMA>(t, a, x0, y0, x1 - x0, y1 - y0, a.tile_offsets[tile], S, ring);
     }
 }
 
@@ -561,8 +745,11 @@ hipError_t launch_accumulate_tiles(const AccumulateTilesArgs &a_in, hipStream_t 
     a.vec = vec ? 1 : 0;
     const long long items = (long long)a.n_tiles * a.n_types;
     const int grid = grid_for(items * 64, 256 * (a.wg_per_cu > 0 ? a.wg_per_cu : 8));  // one wave per item, at most 8 workgroups per CU
-    if (a.umul == 2) hipLaunchKernelGGL(accumulate_tiles_kernel<2>, dim3(grid), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL(accumulate_tiles_kernel<1>, dim3(grid), dim3(kBlock), 0, s, a);
+    // (the DMA walk needs the vector path: a.vec; the scalar path of unaligned images never touches the ring)
+    if (a.vec && a.dma && a.umul == 2) hipLaunchKernelGGL((accumulate_tiles_kernel<2, true>), dim3(grid), dim3(kBlock), kAccLdsBytes, s, a);
+    else if (a.vec && a.dma) hipLaunchKernelGGL((accumulate_tiles_kernel<1, true>), dim3(grid), dim3(kBlock), kAccLdsBytes, s, a);
+    else if (a.umul == 2) hipLaunchKernelGGL((accumulate_tiles_kernel<2, false>), dim3(grid), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((accumulate_tiles_kernel<1, false>), dim3(grid), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 

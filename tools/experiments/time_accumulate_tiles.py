@@ -21,10 +21,11 @@ def timeit(fn, n=5):
 bpp = sum(4 * film.STAT_TYPES[t]["channels"] * S + 2 * (4 + 4 * film.STAT_TYPES[t]["channels"] * (film.STAT_TYPES[t]["max_moment"] + (2 if film.STAT_TYPES[t]["transform"] else 0))) for t in types)
 fs = film.FilmStats(W, H, dev, types=types)
 t_film = min(timeit(lambda: fs.accumulate(smp)) for _ in range(2))
-api.load().statmc_debug_accumulate_umul(2)
-t_film2 = min(timeit(lambda: fs.accumulate(smp)) for _ in range(2))
-api.load().statmc_debug_accumulate_umul(1)
-print("S=%d film-major umul 1: %.3f ms | umul 2: %.3f ms" % (S, t_film, t_film2), flush=True)
+api.load().statmc_debug_accumulate_dma(0)
+t_film_reg = min(timeit(lambda: fs.accumulate(smp)) for _ in range(2))
+api.load().statmc_debug_accumulate_dma(1)
+print("S=%d film-major: RGB planes by LDS-DMA %.3f ms (%.0f GB/s) | loads into registers %.3f ms (%.0f GB/s)"
+      % (S, t_film, bpp * W * H / t_film / 1e6, t_film_reg, bpp * W * H / t_film_reg / 1e6), flush=True)
 # the same samples as tile blocks [tile][S][16][16][C] (1080 = 67.5 tiles: the last tile row is 8 high)
 tiles = [(x, y, min(x + 16, W), min(y + 16, H)) for y in range(0, H, 16) for x in range(0, W, 16)]
 bounds = torch.tensor(tiles, dtype=torch.int32, device=dev)
@@ -44,10 +45,12 @@ offs_d = offs.to(dev); cnt = torch.full((len(tiles),), S, dtype=torch.int32, dev
 import ctypes
 lib = api.load()
 lib.statmc_debug_accumulate_tiles_variant.argtypes = [ctypes.c_int] * 3
-for umul, order, wg in ((1, 0, 0), (2, 0, 0), (2, 0, 2)):
+for umul, order, wg, dma in ((2, 0, 0, 1), (2, 0, 0, 0), (1, 0, 0, 1), (2, 0, 4, 1)):
+    lib.statmc_debug_accumulate_dma(dma)
     lib.statmc_debug_accumulate_tiles_variant(umul, order, wg)
     tt = min(timeit(lambda: api.accumulate_tiles(W, H, sts, bounds, offs_d, cnt)) for _ in range(2))
-    print("S=%d tiles umul %d order %d wg/cu %2d: %.3f ms (%.0f GB/s, %.3f of 8 TB/s)" % (S, umul, order, wg, tt, bpp * W * H / tt / 1e6, bpp * W * H / tt / 8e9), flush=True)
+    print("S=%d tiles dma %d umul %d order %d wg/cu %2d: %.3f ms (%.0f GB/s, %.3f of 8 TB/s)" % (S, dma, umul, order, wg, tt, bpp * W * H / tt / 1e6, bpp * W * H / tt / 8e9), flush=True)
+lib.statmc_debug_accumulate_dma(1)
 lib.statmc_debug_accumulate_tiles_variant(2, 0, 0)
 t_tiles = min(timeit(lambda: api.accumulate_tiles(W, H, sts, bounds, offs_d, cnt)) for _ in range(2))
 fs3 = film.FilmStats(W, H, dev, types=types); fs3.accumulate(smp)

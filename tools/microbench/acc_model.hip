@@ -1,0 +1,218 @@
+// Step-by-step model of the accumulate kernel's RGB walk on gfx950: what separates the bare LDS-DMA stream
+// (hbm_read_ldsdma.hip: 7.0 TB/s on zero-filled memory) from the kernel (6.1 - 6.4 TB/s)?  One feature is added per mode:
+//   data        zero-filled or random sample memory
+//   mode 0      LDS-DMA ring, persistent waves (grid-stride over the wave-groups)
+//   mode 1      LDS-DMA ring, one workgroup per 256 lanes' groups (the kernel's large grid)
+//   mode 2      mode 1 + the mean-only fold (count -> reciprocal, Markstein quotient) + state planes read and written
+//   mode 3      register loads (plain, 3 + 3 rows in flight) + the same fold, large grid (the kernel as shipped)
+//   arrays      1 or 2 sample arrays walked by alternate workgroups (normal + albedo)
+// hipcc -O3 --offload-arch=gfx950 -ffp-contract=off acc_model.hip -o acc_model
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__global__ void fill_random(float *p, size_t n, unsigned seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u ^ (unsigned)(i >> 32) * 40503u ^ seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = (h >> 8) * (1.f / 16777216.f);
+    }
+}
+
+struct Args {
+    const float *src[2];
+    float *mean[2];
+    int *n[2];
+    long long n_px;
+    int S, arrays;
+};
+
+__device__ __forceinline__ void fold(float (&mean)[12], const vfloat4 (&q)[3], float nf, float rc) {
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        const float d = q[j >> 2][j & 3] - mean[j];
+        const float q0 = d * rc;
+        const float rem = __builtin_fmaf(-q0, nf, d);
+        mean[j] += __builtin_fmaf(rem, rc, q0);
+    }
+}
+
+template <int MODE, int D, int F = 0>
+__global__ __launch_bounds__(256) void walk(Args a, float *out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *ring = lds + wave * (D * 768);
+    const long long n_wave_groups = a.n_px / 256;
+    const long long n_elems = a.n_px * 3;
+    const int S = a.S;
+    float acc = 0.f;
+    const long long w0 = (long long)blockIdx.x * 4 + wave, wstep = (long long)gridDim.x * 4;
+    for (long long wi = w0; wi < n_wave_groups * a.arrays; wi += wstep) {
+        const int arr = a.arrays == 2 ? (int)((wi >> 2) & 1) : 0;                      // alternate workgroups take the other array
+        const long long wg = a.arrays == 2 ? ((wi >> 3) << 2) + (wi & 3) : wi;
+        const float *base = a.src[arr] + wg * 768;
+        float mean[12];
+        int n0 = 0;
+#pragma unroll
+        for (int j = 0; j < 12; j++) mean[j] = 0.f;
+        if (MODE >= 2 && !(F & 1) && !(F & 16)) {
+            n0 = a.n[arr][wg * 256 + lane * 4];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const vfloat4 v = *reinterpret_cast<const vfloat4 *>(a.mean[arr] + wg * 768 + lane * 12 + 4 * k);
+                mean[4 * k] = v.x; mean[4 * k + 1] = v.y; mean[4 * k + 2] = v.z; mean[4 * k + 3] = v.w;
+            }
+        }
+        if (MODE <= 2) {
+            auto issue = [&](int s) {
+                const float *p = base + (long long)s * n_elems + lane * 4;
+                float *slot = ring + (s % D) * 768;
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    __builtin_amdgcn_global_load_lds(p + k * 256, (__attribute__((address_space(3))) void *)(slot + k * 256), 16, 0, 2);
+            };
+            if (!(F & 4)) wait_vm<0>();
+#pragma unroll
+            for (int s = 0; s < D; s++) if (s < S) issue(s);
+            for (int s = 0; s < S; s++) {
+                if (s + D <= S) wait_vm<3 * (D - 1)>(); else wait_vm<0>();
+                const float *slot = ring + (s % D) * 768;
+                vfloat4 v[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) v[k] = *reinterpret_cast<const vfloat4 *>(slot + lane * 12 + 4 * k);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (s + D < S) issue(s + D);
+                if (MODE >= 2 && !(F & 2)) {
+                    const float nf = (float)(n0 + s + 1);
+                    const float y0 = __builtin_amdgcn_rcpf(nf);
+                    const float rc = __builtin_fmaf(__builtin_fmaf(-nf, y0, 1.f), y0, y0);
+                    fold(mean, v, nf, rc);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) acc += v[k].x + v[k].y + v[k].z + v[k].w;
+                }
+            }
+        } else {
+            constexpr int U = 3;
+            const float *sp = base + lane * 12;
+            vfloat4 cur[U][3], nxt[U][3];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) cur[u][k] = *reinterpret_cast<const vfloat4 *>(sp + (long long)u * n_elems + 4 * k);
+            for (int s = 0; s + U <= S; s += U) {
+                if (s + 2 * U <= S) {
+#pragma unroll
+                    for (int u = 0; u < U; u++)
+#pragma unroll
+                        for (int k = 0; k < 3; k++) nxt[u][k] = *reinterpret_cast<const vfloat4 *>(sp + (long long)(s + U + u) * n_elems + 4 * k);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const float nf = (float)(n0 + s + u + 1);
+                    const float y0 = __builtin_amdgcn_rcpf(nf);
+                    const float rc = __builtin_fmaf(__builtin_fmaf(-nf, y0, 1.f), y0, y0);
+                    fold(mean, cur[u], nf, rc);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) cur[u][k] = nxt[u][k];
+            }
+        }
+        if (MODE >= 2 && !(F & 1) && !(F & 8) && !(F & 512)) {
+            if (F & 128) {   // through the wave's LDS ring: every store instruction writes 1 KiB of consecutive memory
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    vfloat4 v = {mean[4 * k], mean[4 * k + 1], mean[4 * k + 2], mean[4 * k + 3]};
+                    *reinterpret_cast<vfloat4 *>(ring + lane * 12 + 4 * k) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const vfloat4 v = *reinterpret_cast<const vfloat4 *>(ring + 256 * k + 4 * lane);
+                    if (F & 32) __builtin_nontemporal_store(v, reinterpret_cast<vfloat4 *>(a.mean[arr] + wg * 768 + 256 * k + 4 * lane));
+                    else *reinterpret_cast<vfloat4 *>(a.mean[arr] + wg * 768 + 256 * k + 4 * lane) = v;
+                }
+            } else
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                vfloat4 v = {mean[4 * k], mean[4 * k + 1], mean[4 * k + 2], mean[4 * k + 3]};
+                if (F & 256) *reinterpret_cast<vfloat4 *>(a.mean[arr] + (wg & 15) * 768 + lane * 12 + 4 * k) = v;
+                else if (F & 32) __builtin_nontemporal_store(v, reinterpret_cast<vfloat4 *>(a.mean[arr] + wg * 768 + lane * 12 + 4 * k));
+                else *reinterpret_cast<vfloat4 *>(a.mean[arr] + wg * 768 + lane * 12 + 4 * k) = v;
+            }
+            if (!(F & 64)) a.n[arr][wg * 256 + lane * 4] = n0;   // (the model keeps the count: repeated launches stay comparable)
+        }
+        if (MODE >= 2 && (F & (8 | 512))) acc += mean[0] + mean[5] + mean[11];
+        if (MODE >= 2 && (F & 1)) acc += mean[0] + mean[5] + mean[11];
+    }
+    if (F & 512) {   // the same stores, all of them at the end of the wave's life (the last group's values stand in for every group's)
+        float mean_last[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) mean_last[j] = acc + j;
+        for (long long wi = w0; wi < n_wave_groups * a.arrays; wi += wstep) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                vfloat4 v = {mean_last[4 * k], mean_last[4 * k + 1], mean_last[4 * k + 2], mean_last[4 * k + 3]};
+                *reinterpret_cast<vfloat4 *>(a.mean[0] + wi * 768 + lane * 12 + 4 * k) = v;
+            }
+        }
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+
+template <int MODE, int D, int F = 0>
+void run(const Args &a, float *out, int grid_req, const char *what) {
+    const size_t lds = MODE <= 2 ? (size_t)4 * D * 768 * 4 : 0;
+    const long long n_wg = a.n_px / 1024 * a.arrays;
+    const int grid = grid_req > 0 ? grid_req : (int)n_wg;
+    CHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&walk<MODE, D, F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0));
+    CHK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((walk<MODE, D, F>), dim3(grid), dim3(256), lds, 0, a, out);
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; rep++) {
+        CHK(hipEventRecord(e0));
+        for (int r = 0; r < 3; r++) hipLaunchKernelGGL((walk<MODE, D, F>), dim3(grid), dim3(256), lds, 0, a, out);
+        CHK(hipEventRecord(e1));
+        CHK(hipEventSynchronize(e1));
+        float ms;
+        CHK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms / 3 < best) best = ms / 3;
+    }
+    const double bytes = (double)a.n_px * 12 * a.S * a.arrays;
+    printf("%-14s F=%d mode %d D=%d arrays=%d grid=%5d: %.3f ms  %.0f GB/s\n", what, F, MODE, D, a.arrays, grid, best, bytes / best / 1e6);
+    fflush(stdout);
+}
+
+int main() {
+    const long long n_px = 1920LL * 1080;
+    const int S = 256;
+    Args a;
+    a.n_px = n_px; a.S = S;
+    float *out;
+    CHK(hipMalloc(&out, 64));
+    for (int i = 0; i < 2; i++) {
+        CHK(hipMalloc((void **)&a.src[i], (size_t)n_px * 12 * S));
+        CHK(hipMalloc((void **)&a.mean[i], (size_t)n_px * 12));
+        CHK(hipMalloc((void **)&a.n[i], (size_t)n_px * 4));
+        CHK(hipMemset(a.mean[i], 0, (size_t)n_px * 12));
+        CHK(hipMemset(a.n[i], 0, (size_t)n_px * 4));
+    }
+    for (int i = 0; i < 2; i++) hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, (float *)a.src[i], (size_t)n_px * 3 * S, 17u + i);
+    CHK(hipDeviceSynchronize());
+    const char *what = "random data";
+    a.arrays = 1;
+    for (int rep = 0; rep < 2; rep++) {
+        run<1, 5>(a, out, 512, what);
+        run<2, 5, 64>(a, out, 512, "no n store");
+        run<2, 5, 64 + 512>(a, out, 512, "stores at the end");
+        run<2, 5, 64 + 8>(a, out, 512, "no stores");
+    }
+    return 0;
+}
