@@ -24,7 +24,7 @@ thread_local int g_last_parts = 0;
 std::atomic<int> g_accumulate_resident_blocks{0};
 std::atomic<int> g_tiles_umul{2}, g_tiles_order{0}, g_tiles_wg_per_cu{0};   // tile-fed path: deeper prefetch of the mean-only types by default
 std::atomic<int> g_accumulate_umul{1};
-std::atomic<int> g_accumulate_dma{0};   // RGB sample planes by LDS-DMA (statmc_debug_accumulate_dma(1)); A/B: no gain inside the full type mix
+std::atomic<int> g_accumulate_dma{1};   // RGB sample planes by LDS-DMA (statmc_debug_accumulate_dma(0): loads into registers, A/B)
 std::mutex g_mu;
 
 // Everything the library remembers is kept per device (one Estimator per device in a process that drives
@@ -991,7 +991,7 @@ int statmc_debug_accumulate_resident_blocks(int n) {  // 0 large grid (default),
     return STATMC_OK;
 }
 int statmc_debug_accumulate_dma(int on) {   // 1 (default): RGB sample planes stream through LDS-DMA; 0: loads into registers
-    g_accumulate_dma = on ? 1 : 0;
+    g_accumulate_dma = on;
     return STATMC_OK;
 }
 int statmc_debug_accumulate_umul(int umul) {   // film-major kernel: 2 = the mean-only feature types prefetch twice as deep

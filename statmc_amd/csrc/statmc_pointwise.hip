@@ -42,8 +42,14 @@
 #ifndef STATMC_ACC_PAIR_GROUP
 #define STATMC_ACC_PAIR_GROUP 3
 #endif
+// the state planes are written once per launch and not read again before the next one: non-temporal stores
+// (tools/microbench/acc_model.hip: the stores are 1 % of the bytes and 9 % of the time of a one-type walk, streaming ones cost a
+// quarter less there; in the kernel the radiance type alone gains 3 %, the full mix nothing: off)
+#ifndef STATMC_ACC_NT_STORES
+#define STATMC_ACC_NT_STORES 0
+#endif
 #ifndef STATMC_ACC_DMA_D
-#define STATMC_ACC_DMA_D 5
+#define STATMC_ACC_DMA_D 3
 #endif
 #include "t_quantiles.h"
 
@@ -503,9 +509,11 @@ __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long lo
     }
 #define STATMC_STORE_PLANE(ptr, field, enabled)                                  \
     if (enabled) {                                                               \
-        _Pragma("unroll") for (int k = 0; k < C; k++)                            \
-            *reinterpret_cast<float4 *>((ptr) + e0 + 4 * k) =                    \
-                make_float4(st[2 * k].field.x, st[2 * k].field.y, st[2 * k + 1].field.x, st[2 * k + 1].field.y); \
+        _Pragma("unroll") for (int k = 0; k < C; k++) {                          \
+            const vfloat4 v = {st[2 * k].field.x, st[2 * k].field.y, st[2 * k + 1].field.x, st[2 * k + 1].field.y}; \
+            if (STATMC_ACC_NT_STORES) __builtin_nontemporal_store(v, reinterpret_cast<vfloat4 *>((ptr) + e0 + 4 * k)); \
+            else *reinterpret_cast<vfloat4 *>((ptr) + e0 + 4 * k) = v;            \
+        }                                                                        \
     }
     STATMC_STORE_PLANE(t.mean, mean, true)
     STATMC_STORE_PLANE(t.m2, m2, MAXM >= 2)
@@ -514,7 +522,10 @@ __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long lo
     STATMC_STORE_PLANE(t.film_m2, fm2, TRANSFORM)
 #undef STATMC_STORE_PLANE
     // Merge*Tile casts the tile's uint64 count to int32 (estimator.cpp:347,380)
-    *reinterpret_cast<int4 *>(t.n + p0) = make_int4(n0[0] + S, n0[1] + S, n0[2] + S, n0[3] + S);
+    typedef int vint4 __attribute__((ext_vector_type(4)));
+    const vint4 n_out = {n0[0] + S, n0[1] + S, n0[2] + S, n0[3] + S};
+    if (STATMC_ACC_NT_STORES) __builtin_nontemporal_store(n_out, reinterpret_cast<vint4 *>(t.n + p0));
+    else *reinterpret_cast<vint4 *>(t.n + p0) = n_out;
 }
 
 // One pixel, scalar accesses: unaligned images, ragged ends, tiles whose rows do not split into
@@ -650,7 +661,9 @@ hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
     }
     const int rounds = (grid_for(max_groups, 256 * 8) * a.n_types + a.n_slots - 1) / a.n_slots;
     const dim3 grid(a.resident_blocks > 0 ? a.resident_blocks : rounds * a.n_slots);
-    if (vec && a.dma)
+    if (vec && a.dma == 2)   // experiment: the register-load kernel holding the DMA kernel's LDS
+        hipLaunchKernelGGL((accumulate_kernel<true, 1, false>), grid, dim3(kBlock), kAccLdsBytes, s, a);
+    else if (vec && a.dma)
         hipLaunchKernelGGL((accumulate_kernel<true, 1, true>), grid, dim3(kBlock), kAccLdsBytes, s, a);
     else if (vec && a.umul == 2)
         hipLaunchKernelGGL((accumulate_kernel<true, 2, false>), grid, dim3(kBlock), 0, s, a);

@@ -3,6 +3,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
+from statmc_amd import build
+if os.environ.get("STATMC_VARIANT"):
+    os.environ.setdefault("STATMC_ALLOW_DIAGNOSTIC_BUILD", "1"); build.SO = os.path.abspath(os.environ["STATMC_VARIANT"])
 from statmc_amd import api, film, synthetic
 dev = torch.device("cuda:0"); api.setup(0)
 lib = api.load()
@@ -22,7 +25,8 @@ def bpp(t):
     planes = cfg["max_moment"] + (2 if cfg["transform"] else 0)
     return 4 * c * S + 2 * (4 + 4 * c * planes)
 RESIDENT = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
-for types in (["radiance"], ["normal"], ["depth", "materialid"], ["normal", "albedo"], ["normal", "albedo", "depth", "materialid"], list(synthetic.FEATURES)):
+MODES = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 0]
+for types in (["radiance"], ["normal"], ["depth", "materialid"], ["normal", "albedo"], ["radiance", "normal", "albedo"], ["normal", "albedo", "depth", "materialid"], list(synthetic.FEATURES)):
     sub = {t: smp[t] for t in types}
     b = sum(bpp(x) for x in types) * W * H
     states = {}
@@ -35,12 +39,12 @@ for types in (["radiance"], ["normal"], ["depth", "materialid"], ["normal", "alb
     fs = film.FilmStats(W, H, dev, types=types)
     for resident in RESIDENT:
         lib.statmc_debug_accumulate_resident_blocks(resident)
-        best = {1: 1e9, 0: 1e9}
+        best = {1: 1e9, 0: 1e9, 2: 1e9}
         for rep in range(3):
-            for dma in (1, 0):
+            for dma in (1, 0, 2):
                 lib.statmc_debug_accumulate_dma(dma)
                 best[dma] = min(best[dma], timeit(lambda: fs.accumulate(sub)))
         lib.statmc_debug_accumulate_dma(1)
-        print("%-42s resident %4d LDS-DMA %.3f ms %5.0f GB/s | registers %.3f ms %5.0f GB/s | same bits: %s"
-              % ("+".join(types), resident, best[1], b / best[1] / 1e6, best[0], b / best[0] / 1e6, same), flush=True)
+        print("%-42s resident %4d LDS-DMA %.3f ms %5.0f GB/s | registers %.3f ms %5.0f GB/s | registers + idle LDS %.3f ms | same bits: %s"
+              % ("+".join(types), resident, best[1], b / best[1] / 1e6, best[0], b / best[0] / 1e6, best[2], same), flush=True)
     lib.statmc_debug_accumulate_resident_blocks(0)
