@@ -42,11 +42,20 @@
 #ifndef STATMC_ACC_PAIR_GROUP
 #define STATMC_ACC_PAIR_GROUP 3
 #endif
+// timing experiment only (variant builds): the walk without its state stores -- what the stores cost
+#ifndef STATMC_ACC_SKIP_STORES
+#define STATMC_ACC_SKIP_STORES 0
+#elif defined(STATMC_PRODUCT_BUILD) && STATMC_ACC_SKIP_STORES
+#error "STATMC_ACC_SKIP_STORES is a timing experiment: the results are wrong"
+#endif
 // the state planes are written once per launch and not read again before the next one: non-temporal stores
 // (tools/microbench/acc_model.hip: the stores are 1 % of the bytes and 9 % of the time of a one-type walk, streaming ones cost a
 // quarter less there; in the kernel the radiance type alone gains 3 %, the full mix nothing: off)
 #ifndef STATMC_ACC_NT_STORES
 #define STATMC_ACC_NT_STORES 0
+#endif
+#ifndef STATMC_ACC_WAVES
+#define STATMC_ACC_WAVES 2   // waves per SIMD the film-major kernel is compiled for
 #endif
 #ifndef STATMC_ACC_DMA_D
 #define STATMC_ACC_DMA_D 3
@@ -289,8 +298,9 @@ __device__ __forceinline__ void add_sample2(PairState *st, const v2f *nf, const 
     v2f v[G], d[G], q0[G], dN[G];
     if (TRANSFORM) {   // estimator.h:215 -- boxCox(sample, .5f), as in add_sample
         STATMC_PAIRS(i) v[i] = v2f{__builtin_amdgcn_sqrtf(smp[i].x), __builtin_amdgcn_sqrtf(smp[i].y)};
-        STATMC_PAIRS(i) v[i] = v[i] - 1.f;
-        STATMC_PAIRS(i) v[i] = v[i] / .5f;
+        // (root - 1) / .5 in one instruction: fma(root, 2, -2) rounds 2 root - 2 = 2 (root - 1) once, and doubling commutes with
+        // rounding (no overflow: root < 2^64; no underflow: |root - 1| is 0 or at least 2^-24) -- the bits of the two-step form
+        STATMC_PAIRS(i) v[i] = __builtin_elementwise_fma(v[i], v2f{2.f, 2.f}, v2f{-2.f, -2.f});
     } else {
         STATMC_PAIRS(i) v[i] = smp[i];
     }
@@ -511,6 +521,7 @@ __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long lo
     if (enabled) {                                                               \
         _Pragma("unroll") for (int k = 0; k < C; k++) {                          \
             const vfloat4 v = {st[2 * k].field.x, st[2 * k].field.y, st[2 * k + 1].field.x, st[2 * k + 1].field.y}; \
+            if (STATMC_ACC_SKIP_STORES && v.x != 12345.678f) continue;  /* the arithmetic stays alive, the store never happens */ \
             if (STATMC_ACC_NT_STORES) __builtin_nontemporal_store(v, reinterpret_cast<vfloat4 *>((ptr) + e0 + 4 * k)); \
             else *reinterpret_cast<vfloat4 *>((ptr) + e0 + 4 * k) = v;            \
         }                                                                        \
@@ -600,7 +611,7 @@ __device__ __forceinline__ void accumulate_dispatch(const AccumulateType &t, lon
 // iteration on a second stream gains <= 15 % (the two contend for VALU issue), so bench.py
 // keeps the kernels back to back.
 template <bool VEC, int UMUL, bool DMA>
-__global__ __launch_bounds__(kBlock) void accumulate_kernel(AccumulateArgs a) {
+__global__ __launch_bounds__(kBlock, STATMC_ACC_WAVES) void accumulate_kernel(AccumulateArgs a) {
     extern __shared__ __attribute__((aligned(16))) float acc_lds[];
     // the wave's LDS-DMA ring (RGB types, vector path); DMA = false (debug hook, A/B) keeps every type on register loads
     float *ring = DMA ? acc_lds + (threadIdx.x >> 6) * kAccRingFloats : nullptr;

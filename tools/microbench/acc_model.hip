@@ -45,7 +45,7 @@ __device__ __forceinline__ void fold(float (&mean)[12], const vfloat4 (&q)[3], f
     }
 }
 
-template <int MODE, int D, int F = 0>
+template <int MODE, int D, int F = 0, int AUX = 2>
 __global__ __launch_bounds__(256) void walk(Args a, float *out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void walk(Args a, float *out) {
                 float *slot = ring + (s % D) * 768;
 #pragma unroll
                 for (int k = 0; k < 3; k++)
-                    __builtin_amdgcn_global_load_lds(p + k * 256, (__attribute__((address_space(3))) void *)(slot + k * 256), 16, 0, 2);
+                    __builtin_amdgcn_global_load_lds(p + k * 256, (__attribute__((address_space(3))) void *)(slot + k * 256), 16, 0, AUX);
             };
             if (!(F & 4)) wait_vm<0>();
 #pragma unroll
@@ -173,20 +173,20 @@ __global__ __launch_bounds__(256) void walk(Args a, float *out) {
     if (acc == 12345.678f) out[0] = acc;
 }
 
-template <int MODE, int D, int F = 0>
+template <int MODE, int D, int F = 0, int AUX = 2>
 void run(const Args &a, float *out, int grid_req, const char *what) {
     const size_t lds = MODE <= 2 ? (size_t)4 * D * 768 * 4 : 0;
     const long long n_wg = a.n_px / 1024 * a.arrays;
     const int grid = grid_req > 0 ? grid_req : (int)n_wg;
-    CHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&walk<MODE, D, F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&walk<MODE, D, F, AUX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0));
     CHK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((walk<MODE, D, F>), dim3(grid), dim3(256), lds, 0, a, out);
+    hipLaunchKernelGGL((walk<MODE, D, F, AUX>), dim3(grid), dim3(256), lds, 0, a, out);
     float best = 1e9f;
     for (int rep = 0; rep < 3; rep++) {
         CHK(hipEventRecord(e0));
-        for (int r = 0; r < 3; r++) hipLaunchKernelGGL((walk<MODE, D, F>), dim3(grid), dim3(256), lds, 0, a, out);
+        for (int r = 0; r < 3; r++) hipLaunchKernelGGL((walk<MODE, D, F, AUX>), dim3(grid), dim3(256), lds, 0, a, out);
         CHK(hipEventRecord(e1));
         CHK(hipEventSynchronize(e1));
         float ms;
@@ -194,7 +194,7 @@ void run(const Args &a, float *out, int grid_req, const char *what) {
         if (ms / 3 < best) best = ms / 3;
     }
     const double bytes = (double)a.n_px * 12 * a.S * a.arrays;
-    printf("%-14s F=%d mode %d D=%d arrays=%d grid=%5d: %.3f ms  %.0f GB/s\n", what, F, MODE, D, a.arrays, grid, best, bytes / best / 1e6);
+    printf("%-14s aux=%2d F=%d mode %d D=%d arrays=%d grid=%5d: %.3f ms  %.0f GB/s\n", what, AUX, F, MODE, D, a.arrays, grid, best, bytes / best / 1e6);
     fflush(stdout);
 }
 
@@ -217,29 +217,22 @@ int main() {
     const char *what = "random data";
     a.arrays = 1;
     for (int rep = 0; rep < 2; rep++) {
-        run<1, 5>(a, out, 0, what);
-        run<2, 5, 64>(a, out, 0, "plain stores");
-        run<2, 5, 64 + 32>(a, out, 0, "nt");
-        run<2, 5, 64 + 1024>(a, out, 0, "sc0 sc1");
-        run<2, 5, 64 + 2048>(a, out, 0, "sc1");
-        run<2, 5, 64 + 4096>(a, out, 0, "sc0 sc1 nt");
-        {   // the bare stream followed by the same 25 MB written by a kernel of its own
-            hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-            CHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&walk<1, 5, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            float best = 1e9f, bestw = 1e9f;
-            for (int r = 0; r < 4; r++) {
-                CHK(hipEventRecord(e0));
-                hipLaunchKernelGGL((walk<1, 5, 0>), dim3(2025), dim3(256), 61440, 0, a, out);
-                hipLaunchKernelGGL(dense_write, dim3(2048), dim3(256), 0, 0, a.mean[0], (size_t)n_px * 3 / 4);
-                CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
-                float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
-                CHK(hipEventRecord(e0));
-                hipLaunchKernelGGL(dense_write, dim3(2048), dim3(256), 0, 0, a.mean[0], (size_t)n_px * 3 / 4);
-                CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
-                CHK(hipEventElapsedTime(&ms, e0, e1)); if (ms < bestw) bestw = ms;
-            }
-            printf("bare stream + a kernel writing the 25 MB: %.3f ms (the writing kernel alone %.4f ms)\n", best, bestw);
-        }
+        run<1, 5, 0, 2>(a, out, 0, "bare");
+        run<1, 5, 0, 0>(a, out, 0, "bare");
+        run<1, 5, 0, 1>(a, out, 0, "bare");
+        run<1, 5, 0, 3>(a, out, 0, "bare");
+        run<1, 5, 0, 16>(a, out, 0, "bare");
+        run<1, 5, 0, 17>(a, out, 0, "bare");
+        run<1, 5, 0, 18>(a, out, 0, "bare");
+        run<1, 5, 0, 19>(a, out, 0, "bare");
+        run<2, 5, 64, 2>(a, out, 0, "plain stores");
+        run<2, 5, 64, 0>(a, out, 0, "plain stores");
+        run<2, 5, 64, 1>(a, out, 0, "plain stores");
+        run<2, 5, 64, 3>(a, out, 0, "plain stores");
+        run<2, 5, 64, 16>(a, out, 0, "plain stores");
+        run<2, 5, 64, 17>(a, out, 0, "plain stores");
+        run<2, 5, 64, 18>(a, out, 0, "plain stores");
+        run<2, 5, 64, 19>(a, out, 0, "plain stores");
     }
     return 0;
 }
