@@ -139,6 +139,7 @@ def load():
     lib.statmc_debug_force_filter_parts.argtypes = [C.c_int]
     lib.statmc_debug_last_filter_parts.restype = C.c_int
     lib.statmc_debug_accumulate_resident_blocks.argtypes = [C.c_int]
+    lib.statmc_debug_accumulate_dma.argtypes = [C.c_int]
     if lib.statmc_debug_diagnostic_build() and os.environ.get("STATMC_ALLOW_DIAGNOSTIC_BUILD") != "1":
         raise RuntimeError("%s was built with STATMC_SYM_* experiment switches (bits %#x): its filter results are not the "
                            "product's.  Set STATMC_ALLOW_DIAGNOSTIC_BUILD=1 to load it anyway (tools/experiments only)."
@@ -190,6 +191,11 @@ def force_filter_variant(v):
 def accumulate_resident_blocks(n):
     """0: default large grid; n > 0: the accumulate kernel runs as n resident workgroups."""
     load().statmc_debug_accumulate_resident_blocks(int(n))
+
+
+def accumulate_dma(on):
+    """1 (default): the RGB sample planes of the accumulation stream through LDS-DMA; 0: loads into registers (A/B, tests)."""
+    load().statmc_debug_accumulate_dma(int(on))
 
 
 def force_filter_parts(k):

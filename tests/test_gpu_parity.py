@@ -268,6 +268,53 @@ def test_accumulate_resident_grid(gpu, oracle):
             assert np.array_equal(fs.state[t]["mean"].cpu().numpy(), ref[t]["mean"]), t
 
 
+@pytest.mark.parametrize("transform,max_moment", [(False, 1), (True, 3), (False, 3)])
+def test_accumulate_lds_dma_walk(gpu, oracle, transform, max_moment):
+    """The LDS-DMA walk of the RGB types (rows of a wave's samples land in a ring, counted waits) at its edges: batches
+    shorter than, equal to and longer than the ring, waves whose last lanes have no pixel group (the transfers of a row
+    are counted, so every row issues all of them), a ragged last group, uniform and ragged counts -- against the oracle
+    and, bit for bit, against the walk with loads into registers."""
+    rng = np.random.default_rng(31 + max_moment)
+    for W, H in ((4, 1), (36, 5), (260, 3), (1028, 2), (254, 7)):         # 1, 45, 195, 514 and 444.5 four-pixel groups
+        for S, ragged in ((0, False), (1, False), (2, True), (3, False), (4, False), (5, True), (7, False), (16, True)):
+            smp = rng.lognormal(0, 1, size=(S, H, W, 3)).astype(np.float32)
+            smp[rng.random(smp.shape) < 0.2] = 0.0
+            ref = oracle.new_state(H, W, 3)
+            if ragged:
+                n0 = rng.integers(0, 9, size=(H, W)).astype(np.int32)
+                ref["n"][...] = n0
+                for k in ("mean", "m2", "m3", "film_mean", "film_m2"):
+                    ref[k][...] = (rng.random(ref[k].shape) * (n0[..., None] > 0)).astype(np.float32)
+                if not transform:
+                    ref["film_mean"][...] = ref["mean"]
+                    ref["film_m2"][...] = ref["m2"]
+            st_dma, st_reg = dev_state(ref), dev_state(ref)
+            oracle.accumulate(ref, smp, transform, max_moment)
+            d_smp = to_dev(smp)
+            try:
+                gpu.accumulate_dma(1)
+                gpu.accumulate(W, H, [gpu.make_stat_type(d_smp, st_dma, transform, max_moment)])
+                gpu.accumulate_dma(0)
+                gpu.accumulate(W, H, [gpu.make_stat_type(d_smp, st_reg, transform, max_moment)])
+                torch.cuda.synchronize()
+            finally:
+                gpu.accumulate_dma(1)
+            what = (W, H, S, ragged)
+            for k in st_dma:
+                assert torch.equal(st_dma[k].view(torch.int32), st_reg[k].view(torch.int32)), (what, k)
+            got = {k: v.cpu().numpy() for k, v in st_dma.items()}
+            assert np.array_equal(got["n"], ref["n"]), what
+            keys = ("mean", "m2", "m3")[:max_moment]
+            if transform:
+                assert np.array_equal(got["film_mean"], ref["film_mean"]), what
+                assert np.array_equal(got["film_m2"], ref["film_m2"]), what
+                for k in keys:
+                    assert rel_l2(got[k], ref[k]) <= TOL, (what, k)
+            else:
+                for k in keys:
+                    assert np.array_equal(got[k], ref[k]), (what, k)
+
+
 def test_accumulate_empty_and_errors(gpu, oracle):
     st = dev_state(oracle.new_state(4, 4, 3))
     empty = torch.zeros(0, 4, 4, 3, device=DEV)
