@@ -1005,7 +1005,7 @@ int statmc_debug_accumulate_tiles_variant(int umul, int order, int wg_per_cu) { 
     return STATMC_OK;
 }
 // non-zero: the library was built with an experiment switch of statmc_sym_experiments.h (never the product build)
-int statmc_debug_diagnostic_build(void) { return statmc::sym_diagnostic_bits(); }
+int statmc_debug_diagnostic_build(void) { return statmc::sym_diagnostic_bits() | statmc::acc_diagnostic_bits(); }
 int statmc_debug_last_filter_parts(void) { return g_last_parts; }
 // the partial-sum / patch workspace of the calling thread's current device and stream 0 (diagnostic builds read it back)
 int statmc_debug_last_workspace(void **ptr, size_t *bytes) {

@@ -194,6 +194,7 @@ int sym_filter_parts(const FilterArgs &a, int n_cus);
 size_t sym_patch_floats(const FilterArgs &a, int n_parts);
 hipError_t launch_sym(FilterArgs a, hipStream_t s);
 int sym_diagnostic_bits();   // non-zero: built with a STATMC_SYM_* experiment switch (statmc_sym_experiments.h)
+int acc_diagnostic_bits();   // non-zero: the accumulation was built with a timing-only switch (STATMC_ACC_SKIP_STORES: bit 7)
 hipError_t launch_border_virtual(const FilterArgs &a, hipStream_t s);   // the clamped border's taps beyond the image (RGB)
 int choose_parts(int tiles, int n_rows, int n_cus);
 int filter_parts_override();

@@ -635,6 +635,8 @@ __global__ __launch_bounds__(kBlock, STATMC_ACC_WAVES) void accumulate_kernel(Ac
     else accumulate_dispatch<1, VEC, UMUL, DMA>(t, blk, nblk, ring);
 }
 
+int acc_diagnostic_bits() { return STATMC_ACC_SKIP_STORES ? 128 : 0; }
+
 hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
     AccumulateArgs a = a_in;
     // slots per type ~ relative cost: 4 B x channels per sample, x1.3 for transform types
