@@ -991,7 +991,7 @@ int statmc_debug_accumulate_resident_blocks(int n) {  // 0 large grid (default),
     return STATMC_OK;
 }
 int statmc_debug_accumulate_dma(int on) {   // 1 (default): RGB sample planes stream through LDS-DMA; 0: loads into registers
-    g_accumulate_dma = on;
+    g_accumulate_dma = on ? 1 : 0;
     return STATMC_OK;
 }
 int statmc_debug_accumulate_umul(int umul) {   // film-major kernel: 2 = the mean-only feature types prefetch twice as deep

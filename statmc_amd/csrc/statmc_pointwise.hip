@@ -674,9 +674,7 @@ hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
     }
     const int rounds = (grid_for(max_groups, 256 * 8) * a.n_types + a.n_slots - 1) / a.n_slots;
     const dim3 grid(a.resident_blocks > 0 ? a.resident_blocks : rounds * a.n_slots);
-    if (vec && a.dma == 2)   // experiment: the register-load kernel holding the DMA kernel's LDS
-        hipLaunchKernelGGL((accumulate_kernel<true, 1, false>), grid, dim3(kBlock), kAccLdsBytes, s, a);
-    else if (vec && a.dma)
+    if (vec && a.dma)
         hipLaunchKernelGGL((accumulate_kernel<true, 1, true>), grid, dim3(kBlock), kAccLdsBytes, s, a);
     else if (vec && a.umul == 2)
         hipLaunchKernelGGL((accumulate_kernel<true, 2, false>), grid, dim3(kBlock), 0, s, a);
