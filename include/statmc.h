@@ -135,7 +135,8 @@ int statmc_synchronize(void *stream);
  * tables carries (src/statistics/estimator.cpp:35-84). */
 typedef struct statmc_image {
     void *data;   /* device pointer */
-    size_t step;  /* bytes per row */
+    size_t step;  /* bytes per row: cols * channels * 4 (packed; what the library allocates), or more (a pitched image of the
+                   * caller's: filter<T>, pre-pass, window filter and mean-vars run it through a packed twin) */
     int32_t cols; /* width  */
     int32_t rows; /* height */
 } statmc_image;

@@ -214,12 +214,14 @@ def current_stream_handle():
 
 
 def image_of(t):
-    """Describe a packed [H, W] or [H, W, C] device tensor as a statmc_image."""
-    assert t.is_cuda and t.is_contiguous(), "device images must be contiguous CUDA(HIP) tensors"
-    assert t.element_size() == 4
+    """Describe a [H, W] or [H, W, C] device tensor as a statmc_image: packed, or with a row pitch (a view such as
+    padded[:, :W] of a wider tensor -- what a cv::cuda::GpuMat allocated with a pitch looks like)."""
+    assert t.is_cuda and t.element_size() == 4
     h, w = t.shape[0], t.shape[1]
     c = t.shape[2] if t.dim() == 3 else 1
-    return Image(C.c_void_p(t.data_ptr()), w * c * 4, w, h)
+    inner = (t.stride(1) == c and t.stride(2) == 1) if t.dim() == 3 else t.stride(1) == 1
+    assert inner and t.stride(0) >= w * c, "device images must have packed pixels and a row pitch of at least one row"
+    return Image(C.c_void_p(t.data_ptr()), t.stride(0) * 4, w, h)
 
 
 def _img_array(tensors):

@@ -125,6 +125,7 @@ struct WsHash {
     size_t operator()(const WsKey &k) const { return std::hash<void *>()(k.stream) ^ ((size_t)k.dev * 0x9e3779b97f4a7c15ull); }
 };
 std::unordered_map<WsKey, Workspace, WsHash> g_ws;
+void free_dense_arenas(void *stream);   // packed twins of pitched images (below); caller holds g_mu
 
 int partial_workspace(size_t bytes, void *stream, float **out) {
     int dev = 0;
@@ -206,8 +207,11 @@ int check_image(const statmc_image &im, int w, int h, int channels, const char *
     if (!im.data) return fail(STATMC_ERR_INVALID, "%s[%d]: null device pointer", what, idx);
     if (im.cols != w || im.rows != h)
         return fail(STATMC_ERR_INVALID, "%s[%d]: %dx%d image, expected %dx%d", what, idx, im.cols, im.rows, w, h);
-    if (im.step != (size_t)w * channels * 4)
-        return fail(STATMC_ERR_UNSUPPORTED, "%s[%d]: row pitch %zu, this build needs packed rows (%zu)", what, idx,
+    if (im.step < (size_t)w * channels * 4)
+        return fail(STATMC_ERR_INVALID, "%s[%d]: row pitch %zu is shorter than a row (%zu)", what, idx, im.step,
+                    (size_t)w * channels * 4);
+    if (im.step != (size_t)w * channels * 4)   // filter<T>, pre-pass, window filter and mean-vars take pitched images (packed twins)
+        return fail(STATMC_ERR_UNSUPPORTED, "%s[%d]: row pitch %zu, this entry point needs packed rows (%zu)", what, idx,
                     im.step, (size_t)w * channels * 4);
     return STATMC_OK;
 }
@@ -434,6 +438,7 @@ int statmc_stream_destroy(void *stream) {
                 ++it;
             }
         }
+        free_dense_arenas(stream);
     }
     HIP_TRY(hipStreamDestroy(S(stream)));
     return STATMC_OK;
@@ -464,7 +469,7 @@ int statmc_synchronize(void *stream) {
     return STATMC_OK;
 }
 
-int statmc_prepass(const statmc_filter_args *a, int channels) {
+static int prepass_impl(const statmc_filter_args *a, int channels) {
     NEED_READY();
     if (int rc = check_common(a, channels)) return rc;
     const int W = a->width, H = a->height;
@@ -494,7 +499,7 @@ int statmc_prepass(const statmc_filter_args *a, int channels) {
     return STATMC_OK;
 }
 
-int statmc_window_filter(const statmc_filter_args *a, int channels) {
+static int window_filter_impl(const statmc_filter_args *a, int channels) {
     NEED_READY();
     if (int rc = check_common(a, channels)) return rc;
     const int W = a->width, H = a->height;
@@ -831,18 +836,158 @@ int statmc_halo_exchange(const statmc_block *blocks, int gx, int gy, int block_w
     return rc;
 }
 
-int statmc_filter_f32(const statmc_filter_args *a) {
-    if (int rc = statmc_prepass(a, 1)) return rc;
-    return statmc_window_filter(a, 1);
+}  // extern "C"
+
+// ---------------------------------------------------------------- pitched device images
+// cv::cuda::GpuMat allocates its rows with a pitch (buffer.h:25 keeps one per Buffer), so a caller that binds the C ABI to
+// images it allocated itself may hand over rows longer than width x channels x 4 bytes.  The kernels walk packed rows.
+// A call that names such an image runs on packed twins: every pitched image is copied (device to device, on the call's
+// stream) into a packed image of a per-stream arena, the call runs on those, and the images it writes are copied back.
+// Images of the adaptor and of statmc::Estimator are packed and never come this way.
+namespace {
+struct DenseTwin {
+    statmc_image orig;
+    void *dense;
+    size_t row_bytes;
+    bool copy_back;
+};
+struct PackedRowsCall {
+    statmc_filter_args args;
+    std::vector<statmc_image> n, mean, m2, m3, film, g, mc, disc, ff;
+    std::vector<DenseTwin> twins;
+};
+std::unordered_map<WsKey, Workspace, WsHash> g_dense;   // arena of the packed twins, one per (device, stream)
+
+int dense_arena(size_t bytes, void *stream, char **out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    Workspace &w = g_dense[WsKey{dev, stream}];
+    if (w.bytes < bytes) {
+        if (w.ptr) {
+            HIP_TRY(hipStreamSynchronize(S(stream)));
+            HIP_TRY(hipFree(w.ptr));
+        }
+        w.ptr = nullptr;
+        w.bytes = 0;
+        HIP_TRY(hipMalloc(&w.ptr, bytes));
+        w.bytes = bytes;
+    }
+    *out = reinterpret_cast<char *>(w.ptr);
+    return STATMC_OK;
 }
-int statmc_filter_f32x3(const statmc_filter_args *a) {
-    if (int rc = statmc_prepass(a, 3)) return rc;
-    return statmc_window_filter(a, 3);
+void free_dense_arenas(void *stream) {
+    for (auto it = g_dense.begin(); it != g_dense.end();) {
+        if (it->first.stream == stream && stream != nullptr) {
+            if (it->second.ptr) {
+                (void)hipStreamSynchronize(S(stream));
+                (void)hipFree(it->second.ptr);
+            }
+            it = g_dense.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+inline bool pitched(const statmc_image &im, int channels) {
+    return im.data && im.cols > 0 && im.rows > 0 && im.step > (size_t)im.cols * channels * 4;
+}
+inline size_t twin_bytes(const statmc_image &im, int channels) {
+    return ((size_t)im.cols * channels * 4 * im.rows + 255) & ~(size_t)255;
 }
 
-int statmc_calculate_mean_vars(uint8_t n_buffers, uint16_t width, uint16_t height, int channels,
-                               const statmc_image *n, const statmc_image *film_m2, const statmc_image *film_var,
-                               int row_n_quirk, void *stream) {
+// Runs fn on `a` with every pitched image replaced by a packed twin.  writes_stats: mean_corr / discriminator are outputs
+// of the call (else inputs only); writes_filtered: film_filtered / film_filtered_buffer are outputs.
+template <class Fn>
+int with_packed_rows(const statmc_filter_args *a, int channels, bool writes_stats, bool writes_filtered, Fn fn) {
+    if (!a || (channels != 1 && channels != 3) || a->n_buffers > STATMC_MAX_BUFFERS || a->n_g_buffers > STATMC_MAX_GBUFFERS)
+        return fn(a);   // the entry point's own checks report it
+    const int nb = a->n_buffers, ng = (int)a->n_g_buffers;
+    PackedRowsCall c;
+    c.args = *a;
+    size_t total = 0;
+    bool g_counts_ok = ng == 0 || (a->g_buffers && a->g_channel_counts);
+    auto table = [&](const statmc_image *src, std::vector<statmc_image> &dst, const statmc_image *&slot, int ch) {
+        if (!src || nb == 0) return;
+        dst.assign(src, src + nb);
+        slot = dst.data();
+        for (auto &im : dst)
+            if (pitched(im, ch)) total += twin_bytes(im, ch);
+    };
+    table(a->n, c.n, c.args.n, 1);
+    table(a->mean, c.mean, c.args.mean, channels);
+    table(a->m2, c.m2, c.args.m2, channels);
+    table(a->m3, c.m3, c.args.m3, channels);
+    table(a->film, c.film, c.args.film, channels);
+    table(a->mean_corr, c.mc, c.args.mean_corr, channels);
+    table(a->discriminator, c.disc, c.args.discriminator, channels);
+    table(a->film_filtered, c.ff, c.args.film_filtered, channels);
+    if (g_counts_ok && ng) {
+        c.g.assign(a->g_buffers, a->g_buffers + ng);
+        c.args.g_buffers = c.g.data();
+        for (int g = 0; g < ng; g++)
+            if (pitched(c.g[g], a->g_channel_counts[g] == 1 ? 1 : 3)) total += twin_bytes(c.g[g], a->g_channel_counts[g] == 1 ? 1 : 3);
+    }
+    if (pitched(a->film_buffer, 3)) total += twin_bytes(a->film_buffer, 3);
+    if (pitched(a->film_filtered_buffer, 3)) total += twin_bytes(a->film_filtered_buffer, 3);
+    if (total == 0) return fn(a);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));   // (NEED_READY of the entry point runs inside fn; an arena needs no library state)
+    char *arena = nullptr;
+    if (int rc = dense_arena(total, a->stream, &arena)) return rc;
+    size_t off = 0;
+    auto twin = [&](statmc_image &im, int ch, bool copy_back) -> int {
+        if (!pitched(im, ch)) return STATMC_OK;
+        const size_t row = (size_t)im.cols * ch * 4;
+        void *dense = arena + off;
+        off += twin_bytes(im, ch);
+        // copied in even when the call writes it: a call with a region of interest leaves the rest of the image as it was
+        HIP_TRY(hipMemcpy2DAsync(dense, row, im.data, im.step, row, im.rows, hipMemcpyDeviceToDevice, S(a->stream)));
+        c.twins.push_back(DenseTwin{im, dense, row, copy_back});
+        im.data = dense;
+        im.step = row;
+        return STATMC_OK;
+    };
+    for (auto &im : c.n) if (int rc = twin(im, 1, false)) return rc;
+    for (auto &im : c.mean) if (int rc = twin(im, channels, false)) return rc;
+    for (auto &im : c.m2) if (int rc = twin(im, channels, false)) return rc;
+    for (auto &im : c.m3) if (int rc = twin(im, channels, false)) return rc;
+    for (auto &im : c.film) if (int rc = twin(im, channels, false)) return rc;
+    for (auto &im : c.mc) if (int rc = twin(im, channels, writes_stats)) return rc;
+    for (auto &im : c.disc) if (int rc = twin(im, channels, writes_stats)) return rc;
+    for (auto &im : c.ff) if (int rc = twin(im, channels, writes_filtered)) return rc;
+    for (int g = 0; g < (int)c.g.size(); g++)
+        if (int rc = twin(c.g[g], a->g_channel_counts[g] == 1 ? 1 : 3, false)) return rc;
+    if (int rc = twin(c.args.film_buffer, 3, false)) return rc;
+    if (int rc = twin(c.args.film_filtered_buffer, 3, writes_filtered)) return rc;
+    if (int rc = fn(&c.args)) return rc;
+    for (const DenseTwin &t : c.twins)
+        if (t.copy_back)
+            HIP_TRY(hipMemcpy2DAsync(t.orig.data, t.orig.step, t.dense, t.row_bytes, t.row_bytes, t.orig.rows,
+                                     hipMemcpyDeviceToDevice, S(a->stream)));
+    return STATMC_OK;
+}
+}  // namespace
+
+extern "C" {
+int statmc_prepass(const statmc_filter_args *a, int channels) {
+    return with_packed_rows(a, channels, true, false, [&](const statmc_filter_args *p) { return prepass_impl(p, channels); });
+}
+int statmc_window_filter(const statmc_filter_args *a, int channels) {
+    return with_packed_rows(a, channels, false, true, [&](const statmc_filter_args *p) { return window_filter_impl(p, channels); });
+}
+static int filter_both(const statmc_filter_args *a, int channels) {
+    return with_packed_rows(a, channels, true, true, [&](const statmc_filter_args *p) {
+        if (int rc = prepass_impl(p, channels)) return rc;
+        return window_filter_impl(p, channels);
+    });
+}
+int statmc_filter_f32(const statmc_filter_args *a) { return filter_both(a, 1); }
+int statmc_filter_f32x3(const statmc_filter_args *a) { return filter_both(a, 3); }
+
+static int mean_vars_impl(uint8_t n_buffers, uint16_t width, uint16_t height, int channels,
+                          const statmc_image *n, const statmc_image *film_m2, const statmc_image *film_var,
+                          int row_n_quirk, void *stream) {
     NEED_READY();
     if (channels != 1 && channels != 3) return fail(STATMC_ERR_INVALID, "channels must be 1 or 3");
     if (width == 0 || height == 0) return fail(STATMC_ERR_INVALID, "empty image");
@@ -857,6 +1002,24 @@ int statmc_calculate_mean_vars(uint8_t n_buffers, uint16_t width, uint16_t heigh
         HIP_TRY(statmc::launch_mean_vars(k, S(stream)));
     }
     return STATMC_OK;
+}
+
+int statmc_calculate_mean_vars(uint8_t n_buffers, uint16_t width, uint16_t height, int channels,
+                               const statmc_image *n, const statmc_image *film_m2, const statmc_image *film_var,
+                               int row_n_quirk, void *stream) {
+    // pitched images: the three tables ride through the packed-twin helper in the slots of a filter call
+    statmc_filter_args f;
+    memset(&f, 0, sizeof(f));
+    f.n_buffers = n_buffers;
+    f.width = width;
+    f.height = height;
+    f.n = n;
+    f.mean = film_m2;
+    f.mean_corr = film_var;
+    f.stream = stream;
+    return with_packed_rows(&f, channels, true, false, [&](const statmc_filter_args *p) {
+        return mean_vars_impl(n_buffers, width, height, channels, p->n, p->mean, p->mean_corr, row_n_quirk, stream);
+    });
 }
 
 // validates one statmc_stat_type and translates it for the kernels (shared by both accumulate entries)

@@ -1009,10 +1009,74 @@ def test_filter_argument_errors(gpu):
     with pytest.raises(gpu.StatmcError):                               # in-place filtering is refused
         gpu.window_filter(a, 3)
     a, keep = gpu.make_filter_args([], [], [], [], [z()], [z()], [z()], [z()], [], g_sds=[], radius=2)
-    a.mean_corr[0].step = 8 * 3 * 4 + 64                               # pitched rows are not supported
+    a.mean_corr[0].step = 8 * 3 * 4 - 16                               # a row pitch shorter than a row
     with pytest.raises(gpu.StatmcError) as e:
         gpu.window_filter(a, 3)
-    assert e.value.code == gpu.ERR_UNSUPPORTED
+    assert e.value.code == gpu.ERR_INVALID
+
+
+@pytest.mark.parametrize("radius,roi", [(20, None), (3, None), (20, (8, 4, 60, 21))])
+def test_pitched_device_images(gpu, oracle, radius, roi):
+    """Device images with a row pitch (what cv::cuda::GpuMat allocates; buffer.h:25): filter<float3> with the reference's
+    two-buffer argument block, filter<float> and mean-vars give the bits of the same calls on packed images, and the
+    bytes between the rows are neither read as pixels nor written."""
+    W, H = 68, 25
+    _, smp, st = make_case(W, H, 8, seed=77)
+    rad = st["radiance"]
+    rng = np.random.default_rng(5)
+
+    def pitched(t, pad):
+        wide = torch.full((t.shape[0], t.shape[1] + pad) + tuple(t.shape[2:]), float("nan"), device=DEV).to(t.dtype)
+        if t.dtype == torch.int32:
+            wide.fill_(-7)
+        wide[:, :t.shape[1]] = t
+        return wide[:, :t.shape[1]], wide
+
+    def run(make):
+        wides = []
+
+        def m(t, pad):                                                  # the image the call sees: t itself, or a pitched twin of it
+            if not make:
+                return t
+            v, wide = pitched(t, pad)
+            wides.append((wide, t.shape[1]))
+            return v
+        z3 = lambda fill=0.0: torch.full((H, W, 3), fill, device=DEV)
+        z1 = lambda fill=0.0: torch.full((H, W), fill, device=DEV)
+        d = {k: to_dev(v) for k, v in rad.items()}
+        film_img = to_dev((rad["film_mean"] * 1.5).astype(np.float32))
+        gb = [to_dev(st["normal"]["mean"]), to_dev(st["albedo"]["mean"])]
+        # filter<float3> with the reference's two-buffer block, denoiseFilm set
+        mc, dc = [m(z3(), 2) for _ in range(2)], [m(z3(), 5) for _ in range(2)]
+        ff, film_f = [m(z3(5.0), 1) for _ in range(2)], m(z3(5.0), 4)
+        ins = {k: m(d[k], 3 + i) for i, k in enumerate(("n", "mean", "m2", "m3", "film_mean"))}
+        a, keep = gpu.make_filter_args([ins["n"]] * 2, [ins["mean"]] * 2, [ins["m2"]] * 2, [ins["m3"]] * 2, [ins["film_mean"]] * 2,
+                                       mc, dc, ff, [m(gb[0], 6), m(gb[1], 7)], g_sds=[SD_NORMAL, SD_ALBEDO], filter_sd=FILTER_SD,
+                                       radius=radius, denoise_film=True, film_buffer=m(film_img, 2), film_filtered_buffer=film_f, roi=roi)
+        gpu.filter_f32x3(a)
+        # filter<float>: the channels of the radiance statistics as three float buffers
+        chan = lambda t, c: t[..., c].contiguous()
+        fmc, fdc, fff = [m(z1(), 3) for _ in range(3)], [m(z1(), 2) for _ in range(3)], [m(z1(5.0), 1) for _ in range(3)]
+        a1, keep1 = gpu.make_filter_args([m(d["n"], 9)] * 3, [m(chan(d["mean"], c), 1 + c) for c in range(3)],
+                                         [m(chan(d["m2"], c), 2 + c) for c in range(3)], [m(chan(d["m3"], c), 3 + c) for c in range(3)],
+                                         [m(chan(d["film_mean"], c), 4 + c) for c in range(3)], fmc, fdc, fff, [m(gb[0], 6), m(gb[1], 7)],
+                                         g_sds=[SD_NORMAL, SD_ALBEDO], filter_sd=FILTER_SD, radius=radius, roi=roi)
+        gpu.filter_f32(a1)
+        var = m(z3(), 4)
+        gpu.calculate_mean_vars([m(d["n"], 2)], [m(d["film_m2"], 3)], [var], row_n_quirk=True)
+        torch.cuda.synchronize()
+        for wide, w in wides:                                           # the bytes between the rows are as they were
+            pad = wide[:, w:]
+            assert bool((pad == -7).all()) if wide.dtype == torch.int32 else bool(torch.isnan(pad).all())
+        return [t.contiguous().clone() for t in mc + dc + ff + [film_f] + fmc + fdc + fff + [var]]
+
+    packed_res, pitched_res = run(False), run(True)
+    for i, (x, y) in enumerate(zip(packed_res, pitched_res)):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32)), i
+    film_f = packed_res[6]
+    assert bool(film_f.isfinite().all()) and (roi is None) == bool((film_f != 5.0).all())
+    mcr, dr = oracle.prepass(rad["n"], rad["mean"], rad["m2"], rad["m3"])
+    assert np.array_equal(pitched_res[1].cpu().numpy(), mcr) and np.array_equal(pitched_res[2].cpu().numpy(), dr)
 
 
 def test_film_update_matches_oracle(gpu, oracle):
