@@ -9,7 +9,7 @@ if os.environ.get("STATMC_VARIANT"):
 from statmc_amd import api, film, synthetic
 dev = torch.device("cuda:0"); api.setup(0)
 lib = api.load()
-W, H = 1920, 1080
+W, H = int(os.environ.get("W", 1920)), int(os.environ.get("H", 1080))
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 sc = synthetic.Scene(W, H, seed=1, device=dev)
 smp = sc.samples(S, seed=2)
