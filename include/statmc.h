@@ -114,6 +114,10 @@ int statmc_free_host(void *host_ptr);
 int statmc_memset(void *dev_ptr, int value, size_t bytes, void *stream);
 int statmc_upload(void *dev_dst, const void *host_src, size_t bytes, void *stream);   /* Buffer::upload */
 int statmc_download(void *host_dst, const void *dev_src, size_t bytes, void *stream); /* Buffer::download */
+/* statmc_upload by a small kernel that pulls page-locked (statmc_malloc_host) memory over PCIe instead of by the copy
+ * engine: same result, same rate (57 GB/s), another queue -- the second transport of the Upload / Denoise / Download band
+ * pipeline (include/statmc_bands.hpp).  Host memory the device cannot address goes through statmc_upload. */
+int statmc_upload_by_kernel(void *dev_dst, const void *host_src, size_t bytes, void *stream);
 int statmc_stream_create(void **stream);
 /* priority_class 0 normal, > 0 high, < 0 low.  Streams of different classes never share a hardware queue (the runtime
  * keeps one pool of GPU_MAX_HW_QUEUES queues per priority level), so the barrier packets of one cannot hold back the

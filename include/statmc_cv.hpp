@@ -391,13 +391,13 @@ void filter(uchar nBuffers, ushort width, ushort height, float filterDSFactor, u
     //      wake-up path inside the runtime, not something this side of the API can order differently.
     static const int nQueues = [] { const char *e = std::getenv("STATMC_CV_UPLOAD_QUEUES"); return e ? std::atoi(e) : 1; }();
     const std::vector<int> queue = B::Streams::deal(rowBytes, nQueues);
+    st.pullSecond = nQueues == 3;   // 3: the second queue is a pulling kernel (statmc_upload_by_kernel), not a copy-engine stream
     for (int k = 0; k < nb; k++) {
         const int y0 = B::arrival(k, nb, height, filterRadius), y1 = B::arrival(k + 1, nb, height, filterRadius);
         st.beginTransfer(k);
         for (size_t i = 0; i < st.pending.size(); i++) {
             const auto &p = st.pending[i];
-            statmcCheck(statmc_upload(p.dst + (size_t)y0 * p.rowBytes, p.src.ptr() + (size_t)y0 * p.rowBytes,
-                                      (size_t)(y1 - y0) * p.rowBytes, st.upStream(queue[i])), "GpuMat::upload");
+            st.upload(queue[i], p.dst + (size_t)y0 * p.rowBytes, p.src.ptr() + (size_t)y0 * p.rowBytes, (size_t)(y1 - y0) * p.rowBytes);
         }
         st.markArrived(k);
     }

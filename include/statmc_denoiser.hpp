@@ -777,14 +777,15 @@ class Estimator {
             rowBytes.push_back((size_t)b->mat.cols * b->mat.channels() * 4);
         }
         const std::vector<int> queue = bands::Streams::deal(rowBytes, uploadQueues);
+        pipe.pullSecond = uploadQueues == 3;   // 3: two queues, the second one a pulling kernel instead of a copy-engine stream
         for (int k = 0; k < nb; k++) {
             const int y0 = arrivalEdge(k, nb), y1 = arrivalEdge(k + 1, nb);
             pipe.beginTransfer(k);
             for (size_t i = 0; i < moving.size(); i++) {
                 Buffer *b = moving[i];
                 const size_t row = rowBytes[i];
-                check(statmc_upload(static_cast<char *>(b->gpuMat.data()) + y0 * row, b->mat.ptr<char>() + y0 * row,
-                                    (size_t)(y1 - y0) * row, pipe.upStream(queue[i])));
+                pipe.upload(queue[i], static_cast<char *>(b->gpuMat.data()) + y0 * row, b->mat.ptr<char>() + y0 * row,
+                            (size_t)(y1 - y0) * row);
             }
             pipe.markArrived(k);
         }

@@ -232,6 +232,11 @@ int check_common(const statmc_filter_args *a, int channels) {
     return STATMC_OK;
 }
 
+// statmc_upload_by_kernel: 64 workgroups walk the image in 16-byte pieces (host memory mapped into the device's address space)
+__global__ __launch_bounds__(256) void pull_host_kernel(const uint4 *__restrict__ host, uint4 *__restrict__ dev, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dev[i] = host[i];
+}
+
 // one wave: `cycles` shader clocks against the constant-rate clock (statmc_clock_probe)
 __global__ void clock_probe_kernel(long long *out, long long cycles) {
     if (threadIdx.x != 0) return;
@@ -395,6 +400,30 @@ int statmc_memset(void *dev_ptr, int value, size_t bytes, void *stream) {
 }
 int statmc_upload(void *dev_dst, const void *host_src, size_t bytes, void *stream) {
     HIP_TRY(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, S(stream)));
+    return STATMC_OK;
+}
+int statmc_upload_by_kernel(void *dev_dst, const void *host_src, size_t bytes, void *stream) {
+    // The second transport of the band pipeline's copies in: a small kernel pulls page-locked host memory over PCIe at the
+    // copy engine's rate (tools/microbench/pcie_read.hip: 57 GB/s from 64 workgroups, and 57 GB/s in total beside a
+    // hipMemcpyAsync), so a transfer dealt over the copy engine AND this kernel keeps the link busy through the ~9.5 us
+    // a queue pays between two copies -- without a second hipMemcpyAsync stream, whose enqueue path occasionally blocks
+    // the host thread for milliseconds.  Memory the device cannot address (pageable, or not 16-byte
+    // aligned) goes through the copy engine.
+    void *mapped = nullptr;
+    const bool aligned = (((uintptr_t)dev_dst | (uintptr_t)host_src) & 15) == 0;
+    if (bytes == 0) return STATMC_OK;
+    if (!aligned || bytes < 4096 || hipHostGetDevicePointer(&mapped, const_cast<void *>(host_src), 0) != hipSuccess || !mapped) {
+        (void)hipGetLastError();
+        HIP_TRY(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, S(stream)));
+        return STATMC_OK;
+    }
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(pull_host_kernel, dim3(64), dim3(256), 0, S(stream), static_cast<const uint4 *>(mapped),
+                       static_cast<uint4 *>(dev_dst), n16);
+    HIP_TRY(hipGetLastError());
+    if (bytes & 15)
+        HIP_TRY(hipMemcpyAsync(static_cast<char *>(dev_dst) + n16 * 16, static_cast<const char *>(host_src) + n16 * 16, bytes & 15,
+                               hipMemcpyHostToDevice, S(stream)));
     return STATMC_OK;
 }
 int statmc_download(void *host_dst, const void *dev_src, size_t bytes, void *stream) {

@@ -237,9 +237,11 @@ def test_band_pipeline_gives_the_same_bits(gpu, tmp_path, config, W, H):
     for name, img in dump.items():
         pfm.write_pfm("%s-%d-%s.pfm" % (stem, spp, name), img)
     results = {}
-    for bands in (1, 0, 2, 3, 8):
-        out = subprocess.run([exe, "--stem", stem, "--spp", str(spp), "--config", config, "--bands", str(bands), "--output", outputs],
-                             capture_output=True, text=True)
+    # (bands, transport of the copies in: 1 one copy-engine queue, 2 two, 3 one copy-engine queue + the pulling kernel)
+    for bands, queues in ((1, 1), (0, 1), (2, 1), (3, 1), (8, 1), ((0, 2), 2), ((0, 3), 3), ((3, 3), 3)):
+        n_bands = bands[0] if isinstance(bands, tuple) else bands
+        out = subprocess.run([exe, "--stem", stem, "--spp", str(spp), "--config", config, "--bands", str(n_bands), "--output", outputs],
+                             capture_output=True, text=True, env=dict(os.environ, STATMC_UPLOAD_QUEUES=str(queues)))
         assert out.returncode == 0, out.stderr
         used = int(re.search(r"pipeline bands: (\d+)", out.stdout).group(1))
         results[bands] = (used, {n: pfm.read_pfm("%s-%d-%s.pfm" % (stem, spp, n)) for n in outputs.split(",")})
