@@ -6,7 +6,8 @@
 // obliges them to run one after the other: the image is cut into bands of rows, a transfer carries one band plus the
 // r rows below it (its lower halo), the band is pre-passed and filtered as soon as that transfer has arrived and copied
 // back as soon as it is filtered.  Copies in (two queues), kernels and copies out sit on their own streams, ordered by events
-// (statmc_event_record / statmc_stream_wait_event); what is left after the last copy in is one band's filter.
+// (statmc_event_record / statmc_stream_wait_event); what is left after the last copy in is one band's filter.  Where the
+// bands lie is a Plan (below): by default fitted to the window filter's rounds, the last band the short one.
 // The results are the same bits as with one stream: the pre-pass is per pixel, and the window filter forms a pixel's
 // sums in the same order for any output region (the library chooses its window-sweep parts for the whole image).
 #ifndef STATMC_BANDS_HPP
@@ -32,20 +33,75 @@ inline void ok(int rc, const char *what) {
 
 // halo rows of a transfer: the filter radius, rounded up to whole 8-row filter tiles
 inline int halo(int radius) { return (radius + 7) & ~7; }
-// Number of bands for an image of `height` rows: requested = 0 -> automatic (6 for 512 rows and more, else 1),
-// 1 -> off; never a band shorter than 64 rows or than its own halo.
+// Number of bands for an image of `height` rows when the caller asks for a count: 1 -> off; never a band shorter than 64
+// rows or than its own halo.
 inline int count(int height, int radius, int requested) {
-    int n = requested == 0 ? (height >= 512 ? 6 : 1) : requested;
+    const int n = std::max(1, requested);
     const int minRows = std::max(64, halo(radius));
     return std::max(1, std::min(n, height / minRows));
 }
-// rows [edge(k), edge(k + 1)) are band k: edges at multiples of 8 rows (whole filter tiles, 16-byte aligned sub-images)
-inline int edge(int k, int n, int height) { return k >= n ? height : (int)(((long long)height * k / n) & ~7LL); }
-// transfer k carries rows [arrival(k), arrival(k + 1)): band k shifted down by its halo
-inline int arrival(int k, int n, int height, int radius) {
-    if (k <= 0) return 0;
-    if (k >= n) return height;
-    return std::min(height, edge(k, n, height) + halo(radius));
+
+// Where the bands of an image lie.  Edges are multiples of 8 rows (whole filter tiles, 16-byte aligned sub-images).
+//   requested > 1: that many bands of equal height (as far as the minimum height allows).
+//   requested = 1: no bands.
+//   requested = 0: automatic -- none below 512 rows; above, bands FITTED TO THE FILTER'S ROUNDS.  The window filter runs
+//     one workgroup per 128 x 8 tile and CU, and to filter rows [y0, y1) the pair-symmetric kernel also sweeps the
+//     ceil(r / 8) tile rows above y0 (their taps reach into the band), so a band of b tile rows costs
+//     ceil((b + ceil(r / 8)) * tiles_per_row / CUs) rounds of ~0.2 ms whatever it produces: six equal bands of a 1080p film
+//     are 345 + 45 workgroups each = two rounds for 22.5 tile rows, where two rounds hold 31 (+ 3).  The automatic plan
+//     picks the number of rounds per band that gives at most six bands and makes every band but the last exactly as
+//     tall as those rounds hold; the last band takes the rest and is the short one -- it is what remains after the last copy
+//     in.  (1080p: 248, 248, 248, 248, 88 rows: the bracket 3.88 -> 3.72 ms; tools/experiments/upload_modes.py.)
+struct Plan {
+    std::vector<int> edges{0, 0};   // edges[k] .. edges[k + 1]: band k
+    int height = 0, radius = 0;
+    int count() const { return (int)edges.size() - 1; }
+    int edge(int k) const { return k <= 0 ? 0 : k >= count() ? height : edges[k]; }
+    // transfer k carries rows [arrival(k), arrival(k + 1)): band k shifted down by its halo
+    int arrival(int k) const {
+        if (k <= 0) return 0;
+        if (k >= count()) return height;
+        return std::min(height, edge(k) + halo(radius));
+    }
+};
+constexpr int kFilterCUs = 256, kTileW = 128, kTileH = 8, kAutoBandsMax = 6;   // MI355X; the pair-symmetric kernel's tile
+inline Plan plan(int width, int height, int radius, int requested) {
+    Plan p;
+    p.height = height;
+    p.radius = radius;
+    p.edges = {0, height};
+    const int minRows = std::max(64, halo(radius));
+    if (requested == 1 || height < 2 * minRows || (requested == 0 && height < 512)) return p;
+    p.edges.clear();
+    if (requested > 1) {
+        const int n = count(height, radius, requested);
+        for (int k = 0; k < n; k++) p.edges.push_back((int)(((long long)height * k / n) & ~7LL));
+        p.edges.push_back(height);
+        return p;
+    }
+    if (const char *s = std::getenv("STATMC_BANDS_EDGES")) {   // experiment: "y1,y2,..." places the edges by hand
+        p.edges.push_back(0);
+        for (const char *q = s; *q;) {
+            const int y = std::atoi(q) & ~7;
+            if (y > p.edges.back() && y < height) p.edges.push_back(y);
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+        p.edges.push_back(height);
+        return p;
+    }
+    const int tilesPerRow = (width + kTileW - 1) / kTileW, tileRows = (height + kTileH - 1) / kTileH;
+    const int above = (radius + kTileH - 1) / kTileH;
+    int rounds = std::max(1, (int)(((long long)tileRows * tilesPerRow + (long long)kFilterCUs * kAutoBandsMax - 1) / ((long long)kFilterCUs * kAutoBandsMax)));
+    int bandTileRows = 0;
+    for (;; rounds++) {   // the tallest band those rounds hold; more rounds while that is less than the minimum or gives too many bands
+        bandTileRows = rounds * kFilterCUs / tilesPerRow - above;
+        if (bandTileRows * kTileH >= minRows && (tileRows + bandTileRows - 1) / bandTileRows <= kAutoBandsMax) break;
+    }
+    for (int y = 0; y < height; y += bandTileRows * kTileH) p.edges.push_back(y);
+    if (p.edges.size() > 1 && height - p.edges.back() < minRows) p.edges.pop_back();   // a last band below the minimum joins the one before
+    p.edges.push_back(height);
+    return p;
 }
 
 // rows [y0, y1) of an image as an image of its own (rows are contiguous: a band is a sub-array)

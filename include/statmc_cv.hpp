@@ -185,6 +185,7 @@ struct StreamState : statmc::bands::Streams {
     std::vector<Mat> inflight;              // host images of enqueued band copies (released at synchronisation)
     std::set<const uchar *> outputs;        // images the last banded filter call wrote
     int outBands = 0, outHeight = 0;
+    statmc::bands::Plan outPlan;            // the bands of that call (the copies out follow them)
     bool downloading = false;
 };
 inline int requestedBands() {
@@ -270,7 +271,7 @@ class GpuMat {
         detail::StreamState &st = s.state();
         if (st.outBands > 1 && rows == st.outHeight && st.outputs.count(data)) {   // behind each band's filter
             for (int k = 0; k < st.outBands; k++) {
-                const int y0 = statmc::bands::edge(k, st.outBands, rows), y1 = statmc::bands::edge(k + 1, st.outBands, rows);
+                const int y0 = st.outPlan.edge(k), y1 = st.outPlan.edge(k + 1);
                 statmcCheck(statmc_stream_wait_event(st.down, st.filtered[k]), "GpuMat::download");
                 statmcCheck(statmc_download(m.ptr(y0), data + (size_t)y0 * step, (size_t)(y1 - y0) * step, st.down), "GpuMat::download");
             }
@@ -363,7 +364,8 @@ void filter(uchar nBuffers, ushort width, ushort height, float filterDSFactor, u
         statmcCheck(statmc_stream_wait_event(stream.handle(), st.join), "stat_denoiser::filter");
     }
     namespace B = statmc::bands;
-    const int nb = B::count(height, filterRadius, cuda::detail::requestedBands());
+    const B::Plan plan = B::plan(width, height, filterRadius, cuda::detail::requestedBands());
+    const int nb = plan.count();
     bool banded = nb > 1 && !st.pending.empty();
     for (const auto &p : st.pending) banded = banded && p.rows == height;
     if (!banded) {
@@ -393,7 +395,7 @@ void filter(uchar nBuffers, ushort width, ushort height, float filterDSFactor, u
     const std::vector<int> queue = B::Streams::deal(rowBytes, nQueues);
     st.pullSecond = nQueues == 3;   // 3: the second queue is a pulling kernel (statmc_upload_by_kernel), not a copy-engine stream
     for (int k = 0; k < nb; k++) {
-        const int y0 = B::arrival(k, nb, height, filterRadius), y1 = B::arrival(k + 1, nb, height, filterRadius);
+        const int y0 = plan.arrival(k), y1 = plan.arrival(k + 1);
         st.beginTransfer(k);
         for (size_t i = 0; i < st.pending.size(); i++) {
             const auto &p = st.pending[i];
@@ -406,8 +408,8 @@ void filter(uchar nBuffers, ushort width, ushort height, float filterDSFactor, u
     // ... and every band is pre-passed and filtered as soon as its transfer has landed
     for (int k = 0; k < nb; k++) {
         st.waitArrived(stream.handle(), k);
-        B::prepassRows(a, C, B::arrival(k, nb, height, filterRadius), B::arrival(k + 1, nb, height, filterRadius));
-        B::filterRows(a, C, B::edge(k, nb, height), B::edge(k + 1, nb, height));
+        B::prepassRows(a, C, plan.arrival(k), plan.arrival(k + 1));
+        B::filterRows(a, C, plan.edge(k), plan.edge(k + 1));
         statmcCheck(statmc_event_record(st.filtered[k], stream.handle()), "stat_denoiser::filter");
     }
     st.outputs.clear();
@@ -415,6 +417,7 @@ void filter(uchar nBuffers, ushort width, ushort height, float filterDSFactor, u
         for (const auto &im : *tab) st.outputs.insert(static_cast<const uchar *>(im.data));
     st.outputs.insert(filmFilteredBuffer.data);
     st.outBands = nb;
+    st.outPlan = plan;
     st.outHeight = height;
 }
 

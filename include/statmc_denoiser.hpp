@@ -755,7 +755,7 @@ class Estimator {
     void SetUploadQueues(int n) { uploadQueues = n; }
     int PipelineBands() const {
         if (!allocateDevice || acc.dry) return 1;
-        return bands::count(height, filterRadius, bandsRequested);
+        return bandPlan().count();
     }
     void Upload() {  // estimator.cpp:409-416
         if (acc.enabled) FlushSamples();  // statistics are produced on the device: only the rest moves
@@ -1063,8 +1063,11 @@ class Estimator {
     } pipe;
     int bandsRequested = 0;
     int uploadQueues = [] { const char *e = std::getenv("STATMC_UPLOAD_QUEUES"); return e ? std::atoi(e) : 1; }();
-    int bandEdge(int k, int n) const { return bands::edge(k, n, height); }
-    int arrivalEdge(int k, int n) const { return bands::arrival(k, n, height, filterRadius); }
+    // where the bands lie (statmc_bands.hpp: automatic = fitted to the window filter's rounds); the same plan serves Upload,
+    // Denoise and Download of an iteration because it depends on the image, the radius and the request only
+    bands::Plan bandPlan() const { return bands::plan(width, height, filterRadius, bandsRequested); }
+    int bandEdge(int k, int) const { return bandPlan().edge(k); }
+    int arrivalEdge(int k, int) const { return bandPlan().arrival(k); }
     void ensurePipeline(int nb) {
         if (!pipe.up) {
             for (auto *bufs : {&meanCorrBuffers, &discriminatorBuffers, &filmFilteredBuffers})

@@ -24,7 +24,7 @@ try:
         allt = []
         for p in range(procs):
             out = subprocess.run([build.DENOISE_BIN, "--stem", stem, "--spp", ",".join([str(spp)] * 17), "--filtersd", "10", "--filterradius", "20",
-                                  "--warmup", "--bands", "6", "--output", "film-f"], capture_output=True, text=True, timeout=300,
+                                  "--warmup", "--bands", os.environ.get("BANDS", "6"), "--output", "film-f"], capture_output=True, text=True, timeout=300,
                                  env=dict(os.environ, STATMC_UPLOAD_QUEUES=mode))
             assert out.returncode == 0, out.stderr
             ns = [int(v) / 1e6 for v in re.findall(r"HIP time \[ns\]: (\d+)", out.stdout)][1:]
