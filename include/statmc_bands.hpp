@@ -79,7 +79,7 @@ inline Plan plan(int width, int height, int radius, int requested) {
         p.edges.push_back(height);
         return p;
     }
-    if (const char *s = std::getenv("STATMC_BANDS_EDGES")) {   // experiment: "y1,y2,..." places the edges by hand
+    if (const char *s = std::getenv("STATMC_BANDS_EDGES"); s && *s) {   // experiment: "y1,y2,..." places the edges by hand
         p.edges.push_back(0);
         for (const char *q = s; *q;) {
             const int y = std::atoi(q) & ~7;
@@ -98,6 +98,8 @@ inline Plan plan(int width, int height, int radius, int requested) {
         bandTileRows = rounds * kFilterCUs / tilesPerRow - above;
         if (bandTileRows * kTileH >= minRows && (tileRows + bandTileRows - 1) / bandTileRows <= kAutoBandsMax) break;
     }
+    // (the end of the image in one-round bands -- 248, 248, 248, 112, 112, 112 -- was tried: best iterations 3.63 ms, but a
+    // bimodal 3.63 / 3.85 and the same mean as the plain plan's steady 3.74)
     for (int y = 0; y < height; y += bandTileRows * kTileH) p.edges.push_back(y);
     if (p.edges.size() > 1 && height - p.edges.back() < minRows) p.edges.pop_back();   // a last band below the minimum joins the one before
     p.edges.push_back(height);

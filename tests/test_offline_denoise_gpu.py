@@ -249,7 +249,7 @@ def test_band_pipeline_gives_the_same_bits(gpu, tmp_path, config, W, H):
         used = int(re.search(r"pipeline bands: (\d+)", out.stdout).group(1))
         results[bands] = (used, {n: pfm.read_pfm("%s-%d-%s.pfm" % (stem, spp, n)) for n in outputs.split(",")})
     assert results[1][0] == 1
-    # automatic: bands fitted to the window filter's rounds of 256 workgroups (statmc_bands.hpp): 1080p is 5 x 248 rows (+ 88),
+    # automatic: bands fitted to the window filter's rounds of 256 workgroups (statmc_bands.hpp): 1080p is 4 x 248 rows + 88,
     # 640 x 600 two bands (384 + 216), the others fit one round and stay whole
     assert results[0][0] == {(640, 600): 2, (328, 520): 1, (200, 130): 1, (1920, 1080): 5}[(W, H)]
     assert results[8][0] == min(8, H // 64)                              # no band shorter than 64 rows
