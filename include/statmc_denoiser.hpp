@@ -741,7 +741,7 @@ class Estimator {
 
     // Upload / Denoise / Download / Synchronize (estimator.cpp:409-489, 571-573; the sequence StatPathIntegrator times
     // as "CUDA time", statpath.cpp:409-417).  All four only enqueue.  With more than one pipeline band (SetPipelineBands;
-    // automatic: 6 bands for images of 512 rows and more) the image is cut into bands of rows and the three phases
+    // automatic: for images of 512 rows and more, bands fitted to the window filter's rounds -- bands::plan) the image is cut into bands of rows and the three phases
     // run on their own streams (copies in on two) ordered by events: band k travels with the r rows below it (its lower halo), is pre-passed
     // and filtered as soon as it has arrived, and copied back as soon as it is filtered -- the PCIe copies in both
     // directions and the kernels overlap instead of adding up; what is left after the last copy in is one band's
