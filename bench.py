@@ -307,7 +307,8 @@ def host_bracket(fs, args):
                 "two_upload_queues": res["two_queues"],
                 "what": "Estimator::Upload (76 B/px) + Denoise + Download (12 B/px) + Synchronize, C++ host side "
                         "(tools/bin/statmc_denoise), page-locked host images; the three phases run as a pipeline of row "
-                        "bands on three streams (same bits), one copy queue; one_stream_ms: the same calls one after the other; "
+                        "bands on three streams (same bits; bands fitted to the window filter's rounds of 256 workgroups), one copy queue; "
+                        "one_stream_ms: the same calls one after the other; "
                         "two_upload_queues: the copies dealt over two queues (faster when nothing stalls, with a tail: DESIGN.md 4.5)"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
