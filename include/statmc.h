@@ -118,6 +118,13 @@ int statmc_download(void *host_dst, const void *dev_src, size_t bytes, void *str
  * engine: same result, same rate (57 GB/s), another queue -- the second transport of the Upload / Denoise / Download band
  * pipeline (include/statmc_bands.hpp).  Host memory the device cannot address goes through statmc_upload. */
 int statmc_upload_by_kernel(void *dev_dst, const void *host_src, size_t bytes, void *stream);
+/* Several images in one launch (all images of one transfer of the band pipeline: no gap between them). */
+typedef struct statmc_copy_segment {
+    void *dev_dst;
+    const void *host_src;
+    size_t bytes;
+} statmc_copy_segment;
+int statmc_upload_segments_by_kernel(const statmc_copy_segment *segs, int n_segs, void *stream);
 int statmc_stream_create(void **stream);
 /* priority_class 0 normal, > 0 high, < 0 low.  Streams of different classes never share a hardware queue (the runtime
  * keeps one pool of GPU_MAX_HW_QUEUES queues per priority level), so the barrier packets of one cannot hold back the

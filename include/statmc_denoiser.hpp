@@ -752,6 +752,11 @@ class Estimator {
     // bracket, every iteration.  2 (SetUploadQueues / STATMC_UPLOAD_QUEUES=2) gives 3.5 ms when nothing stalls, but about
     // one iteration in twelve then takes 7 - 10 ms because the host thread blocks inside a hipMemcpyAsync enqueue
     // (statmc_cv.hpp, note (b); tools/experiments/iter_times.py): 4.1 ms on average, with a tail.
+    // 3: the second queue is a pulling kernel (statmc_upload_by_kernel) instead of a copy-engine stream; 4: no copy engine, one
+    // pulling kernel per transfer (statmc_upload_segments_by_kernel: the link's rate without a gap between the images,
+    // the copies in done 0.3 ms earlier -- but its eight workgroups hold eight CUs, a band's filter then needs a third
+    // round, and the bracket ends where it did: 3.65 against 3.73 ms).  Both give the same bits; both need page-locked
+    // host images.  DESIGN.md 4.5.
     void SetUploadQueues(int n) { uploadQueues = n; }
     int PipelineBands() const {
         if (!allocateDevice || acc.dry) return 1;
@@ -778,6 +783,23 @@ class Estimator {
         }
         const std::vector<int> queue = bands::Streams::deal(rowBytes, uploadQueues);
         pipe.pullSecond = uploadQueues == 3;   // 3: two queues, the second one a pulling kernel instead of a copy-engine stream
+        if (uploadQueues == 4) {
+            // 4: no copy engine at all -- ONE pulling kernel per transfer moves the rows of every image (statmc_upload_segments_by_kernel:
+            // no gap between the images of a transfer), the transfers queue up behind each other on one stream and each
+            // marks its band as arrived on both events
+            for (int k = 0; k < nb; k++) {
+                const int y0 = arrivalEdge(k, nb), y1 = arrivalEdge(k + 1, nb);
+                std::vector<statmc_copy_segment> segs;
+                for (size_t i = 0; i < moving.size(); i++)
+                    segs.push_back({static_cast<char *>(moving[i]->gpuMat.data()) + y0 * rowBytes[i], moving[i]->mat.ptr<char>() + y0 * rowBytes[i],
+                                    (size_t)(y1 - y0) * rowBytes[i]});
+                check(statmc_upload_segments_by_kernel(segs.data(), (int)segs.size(), pipe.up2));
+                check(statmc_event_record(pipe.arrived[k], pipe.up2));
+                check(statmc_event_record(pipe.arrived2[k], pipe.up2));
+            }
+            pipe.uploaded = pipe.pendingJoin = nb;
+            return;
+        }
         for (int k = 0; k < nb; k++) {
             const int y0 = arrivalEdge(k, nb), y1 = arrivalEdge(k + 1, nb);
             pipe.beginTransfer(k);

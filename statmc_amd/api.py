@@ -65,7 +65,7 @@ class StatType(C.Structure):
 EXPORTS = [
     "statmc_last_error", "statmc_setup", "statmc_set_device", "statmc_set_significance", "statmc_get_significance", "statmc_set_t_quantiles",
     "statmc_set_filter_spec", "statmc_get_filter_spec", "statmc_reset_filter_spec", "statmc_pinned_from", "statmc_copy_device_settings",
-    "statmc_malloc", "statmc_free", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_upload_by_kernel", "statmc_download",
+    "statmc_malloc", "statmc_free", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_upload_by_kernel", "statmc_upload_segments_by_kernel", "statmc_download",
     "statmc_stream_create", "statmc_stream_create_with_priority", "statmc_stream_destroy", "statmc_synchronize",
     "statmc_event_create", "statmc_event_destroy", "statmc_event_record", "statmc_stream_wait_event",
     "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs", "statmc_prepass_pack",

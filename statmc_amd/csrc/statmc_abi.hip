@@ -233,8 +233,40 @@ int check_common(const statmc_filter_args *a, int channels) {
 }
 
 // statmc_upload_by_kernel: 64 workgroups walk the image in 16-byte pieces (host memory mapped into the device's address space)
-__global__ __launch_bounds__(256) void pull_host_kernel(const uint4 *__restrict__ host, uint4 *__restrict__ dev, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dev[i] = host[i];
+// Few, large workgroups: the pulling waves sit on their CUs for the whole transfer, and a CU that holds one of them cannot
+// take a window-filter workgroup (151 KB of LDS, the whole register file).  64 workgroups of 256 threads spread over 64 CUs
+// and cost a concurrent band filter a third round (0.42 -> 0.59 ms: rocprofv3 timeline); kPullGroups workgroups of 1024
+// threads with four 16-byte loads in flight per thread keep the link as busy from kPullGroups CUs.
+constexpr int kPullThreads = 1024, kPullUnroll = 4;
+#ifndef STATMC_PULL_GROUPS
+#define STATMC_PULL_GROUPS 8
+#endif
+constexpr int kPullGroups = STATMC_PULL_GROUPS;
+__device__ __forceinline__ void pull_range(const uint4 *__restrict__ host, uint4 *__restrict__ dev, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * kPullThreads;
+    size_t i = (size_t)blockIdx.x * kPullThreads + threadIdx.x;
+    for (; i + (kPullUnroll - 1) * stride < n16; i += kPullUnroll * stride) {
+        uint4 v[kPullUnroll];
+#pragma unroll
+        for (int u = 0; u < kPullUnroll; u++) v[u] = host[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < kPullUnroll; u++) dev[i + u * stride] = v[u];
+    }
+    for (; i < n16; i += stride) dev[i] = host[i];
+}
+__global__ __launch_bounds__(kPullThreads) void pull_host_kernel(const uint4 *__restrict__ host, uint4 *__restrict__ dev, size_t n16) {
+    pull_range(host, dev, n16);
+}
+
+// statmc_upload_segments_by_kernel: the same for up to 8 images in one launch (a whole transfer of the band pipeline)
+struct PullSegments {
+    const uint4 *src[8];
+    uint4 *dst[8];
+    size_t n16[8];
+    int n;
+};
+__global__ __launch_bounds__(kPullThreads) void pull_segments_kernel(PullSegments p) {
+    for (int s = 0; s < p.n; s++) pull_range(p.src[s], p.dst[s], p.n16[s]);
 }
 
 // one wave: `cycles` shader clocks against the constant-rate clock (statmc_clock_probe)
@@ -418,13 +450,42 @@ int statmc_upload_by_kernel(void *dev_dst, const void *host_src, size_t bytes, v
         return STATMC_OK;
     }
     const size_t n16 = bytes / 16;
-    hipLaunchKernelGGL(pull_host_kernel, dim3(64), dim3(256), 0, S(stream), static_cast<const uint4 *>(mapped),
+    hipLaunchKernelGGL(pull_host_kernel, dim3(kPullGroups), dim3(kPullThreads), 0, S(stream), static_cast<const uint4 *>(mapped),
                        static_cast<uint4 *>(dev_dst), n16);
     HIP_TRY(hipGetLastError());
     if (bytes & 15)
         HIP_TRY(hipMemcpyAsync(static_cast<char *>(dev_dst) + n16 * 16, static_cast<const char *>(host_src) + n16 * 16, bytes & 15,
                                hipMemcpyHostToDevice, S(stream)));
     return STATMC_OK;
+}
+int statmc_upload_segments_by_kernel(const statmc_copy_segment *segs, int n_segs, void *stream) {
+    if (n_segs < 0 || (n_segs && !segs)) return fail(STATMC_ERR_INVALID, "null segment table");
+    PullSegments p;
+    p.n = 0;
+    auto flush = [&]() -> int {
+        if (p.n == 0) return STATMC_OK;
+        hipLaunchKernelGGL(pull_segments_kernel, dim3(kPullGroups), dim3(kPullThreads), 0, S(stream), p);
+        HIP_TRY(hipGetLastError());
+        p.n = 0;
+        return STATMC_OK;
+    };
+    for (int i = 0; i < n_segs; i++) {
+        const statmc_copy_segment &g = segs[i];
+        if (g.bytes == 0) continue;
+        void *mapped = nullptr;
+        const bool aligned = (((uintptr_t)g.dev_dst | (uintptr_t)g.host_src | g.bytes) & 15) == 0;
+        if (!aligned || hipHostGetDevicePointer(&mapped, const_cast<void *>(g.host_src), 0) != hipSuccess || !mapped) {
+            (void)hipGetLastError();   // memory the device cannot address (or an odd size): the copy engine, in stream order
+            HIP_TRY(hipMemcpyAsync(g.dev_dst, g.host_src, g.bytes, hipMemcpyHostToDevice, S(stream)));
+            continue;
+        }
+        p.src[p.n] = static_cast<const uint4 *>(mapped);
+        p.dst[p.n] = static_cast<uint4 *>(g.dev_dst);
+        p.n16[p.n] = g.bytes / 16;
+        if (++p.n == 8)
+            if (int rc = flush()) return rc;
+    }
+    return flush();
 }
 int statmc_download(void *host_dst, const void *dev_src, size_t bytes, void *stream) {
     HIP_TRY(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, S(stream)));
