@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--film", default=None, help="WxH of the film (default 1920x1080; 3840x2160 = BASELINE configs[4])")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-overlap-halo", dest="overlap_halo", action="store_false",
+                    help="N > 1: accumulate the whole block, then exchange the halo (default: border rows first, the exchange behind the rest of the accumulation)")
     ap.add_argument("--scaling", default="strong", choices=("strong", "weak"),
                     help="N > 1: strong = one film cut into N blocks (default); weak = one film-sized block per rank")
     ap.add_argument("--spp", type=int, default=256)
@@ -598,22 +600,37 @@ def main():
         k_events[name].append((e0, e1))
         return out
 
-    def accumulate_range(start, count):
+    def accumulate_range(start, count, rows=None):
         for a, b in pool_slices(start, count, pool):
-            pipe.accumulate(samples if (a, b) == (0, pool) else {t: v[a:b] for t, v in samples.items()})
+            pipe.accumulate(samples if (a, b) == (0, pool) else {t: v[a:b] for t, v in samples.items()}, rows=rows)
+
+    # Row-strip grids: the rows a neighbour needs are accumulated, pre-passed and sent first, the rest of the block is
+    # accumulated while they travel (BlockPipeline.border_rows; same bits).  On one GPU the split costs 0.04 - 0.06 ms per
+    # step (tools/experiments/halo_overlap_cost.py) and leaves the exchange 0.4 - 1.9 ms to hide in.
+    border = pipe.border_rows() if (world > 1 and args.overlap_halo) else []
 
     def step(record, probe=None):
         if args.schedule == "reference":
             fs.reset()                  # a progressive render starts from empty statistics (statpath.cpp:173-190)
         pos = 0
         for b in batches:
-            timed("accumulate", record, accumulate_range, pos, b)
-            pos += b
-            if probe is not None:
-                probe("accumulate")
-            timed("prepass", record, pipe.prepass)
-            if world > 1:
-                timed("halo", record, pipe.exchange)
+            if border:
+                timed("accumulate", record, accumulate_range, pos, b, border)
+                for rows in border:
+                    timed("prepass", record, pipe.prepass, rows)
+                in_flight = timed("halo", record, pipe.exchange_start)
+                timed("accumulate", record, accumulate_range, pos, b, pipe.interior_rows())
+                pos += b
+                timed("prepass", record, pipe.prepass, pipe.interior_rows())
+                timed("halo", record, in_flight.wait)        # what of the exchange is still exposed
+            else:
+                timed("accumulate", record, accumulate_range, pos, b)
+                pos += b
+                if probe is not None:
+                    probe("accumulate")
+                timed("prepass", record, pipe.prepass)
+                if world > 1:
+                    timed("halo", record, pipe.exchange)
             block = timed("filter", record, pipe.window_filter)
             if probe is not None:
                 probe("filter")
@@ -818,7 +835,10 @@ def main():
                                "achieved_GBs": round(acc_gbs, 1), "frac_hbm": round(acc_gbs / HBM_PEAK_GBS, 4)},
                 "prepass": {"ms_per_step": round(ms["prepass"], 4), "bytes_per_px": PREPASS_BYTES_PER_PX,
                             "achieved_GBs": round(pre_gbs, 1), "frac_hbm": round(pre_gbs / HBM_PEAK_GBS, 4)},
-                "halo_exchange": {"ms_per_step": round(ms["halo"], 4)},
+                "halo_exchange": {"ms_per_step": round(ms["halo"], 4),
+                                  "order": ("border rows accumulated and sent first, the exchange behind the rest of the accumulation: "
+                                            "ms_per_step is what of it stays exposed" if border else "after the whole block's accumulation")
+                                  if world > 1 else "single GPU"},
                 "filter": {"ms_per_step": round(ms["filter"], 4), "mpixels_per_s": round(px_block * n_flt / ms["filter"] / 1e3, 2)},
             },
         }

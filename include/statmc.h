@@ -13,8 +13,9 @@
  *     sites -- OpenCV throws)
  *   - images are row-major with interleaved channels, exactly the cv::Mat / GpuMat layout of
  *     src/statistics/buffer.h:19-71: int32 x1 for "n", float32 x1 or x3 otherwise.  `step` is
- *     the row pitch in bytes.  This build requires tightly packed rows
- *     (step == cols * channels * 4) and returns STATMC_ERR_UNSUPPORTED otherwise.
+ *     the row pitch in bytes.  The kernels walk tightly packed rows (step == cols * channels * 4), which is what
+ *     the library allocates; filter<T>, pre-pass, window filter and mean-vars also take images with a longer pitch
+ *     (a foreign GpuMat: they run on packed twins), the other entry points return STATMC_ERR_UNSUPPORTED for them.
  */
 #ifndef STATMC_H
 #define STATMC_H
@@ -263,6 +264,15 @@ typedef struct statmc_stat_type {
 
 int statmc_accumulate(uint16_t width, uint16_t height, const statmc_stat_type *types, int n_types,
                       void *stream);
+/* The same for rows [y0, y1) of the film only (the descriptors still describe the whole film: samples
+ * [n_samples][height][width][channels], whole state images).  Per-pixel work, so any split of a batch into row ranges
+ * leaves the same bits; the multi-GPU step accumulates the rows next to a neighbour first and the rest while their
+ * halo exchange runs. */
+int statmc_accumulate_rows(uint16_t width, uint16_t height, const statmc_stat_type *types, int n_types, int y0, int y1,
+                           void *stream);
+/* ... and for n_ranges disjoint row ranges {y0, y1} in one launch (n_types x n_ranges <= 16). */
+int statmc_accumulate_row_ranges(uint16_t width, uint16_t height, const statmc_stat_type *types, int n_types,
+                                 const int32_t *ranges, int n_ranges, void *stream);
 
 /* The same accumulation fed tile by tile, the way StatPathIntegrator::Render produces samples
  * (src/statistics/statpath.cpp:132-190: 16 x 16 tiles; 355-371: every sample of a pixel is handed to

@@ -69,7 +69,7 @@ EXPORTS = [
     "statmc_stream_create", "statmc_stream_create_with_priority", "statmc_stream_destroy", "statmc_synchronize",
     "statmc_event_create", "statmc_event_destroy", "statmc_event_record", "statmc_stream_wait_event",
     "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs", "statmc_prepass_pack",
-    "statmc_halo_exchange", "statmc_copy_rect", "statmc_calculate_mean_vars", "statmc_accumulate", "statmc_accumulate_tiles", "statmc_merge_tiles", "statmc_tile_moments", "statmc_film_update",
+    "statmc_halo_exchange", "statmc_copy_rect", "statmc_calculate_mean_vars", "statmc_accumulate", "statmc_accumulate_rows", "statmc_accumulate_row_ranges", "statmc_accumulate_tiles", "statmc_merge_tiles", "statmc_tile_moments", "statmc_film_update",
     "statmc_last_filter_variant", "statmc_version", "statmc_clock_probe",
 ]
 
@@ -128,6 +128,8 @@ def load():
                                                C.POINTER(Image), C.POINTER(Image), C.POINTER(Image),
                                                C.c_int, C.c_void_p]
     lib.statmc_accumulate.argtypes = [C.c_uint16, C.c_uint16, C.POINTER(StatType), C.c_int, C.c_void_p]
+    lib.statmc_accumulate_rows.argtypes = [C.c_uint16, C.c_uint16, C.POINTER(StatType), C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.statmc_accumulate_row_ranges.argtypes = [C.c_uint16, C.c_uint16, C.POINTER(StatType), C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p]
     lib.statmc_accumulate_tiles.argtypes = [C.c_uint16, C.c_uint16, C.POINTER(StatType), C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_int, C.c_void_p]
     lib.statmc_merge_tiles.argtypes = [C.c_uint16, C.c_uint16, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -337,10 +339,18 @@ def make_stat_type_arena(arena, channels, state, transform, max_moment):
     return t
 
 
-def accumulate(width, height, stat_types, stream=None):
+def accumulate(width, height, stat_types, stream=None, rows=None):
+    """rows = (y0, y1): only those rows of the film (statmc_accumulate_rows); rows = [(y0, y1), ...]: several disjoint
+    ranges in one launch (statmc_accumulate_row_ranges)."""
     arr = (StatType * max(len(stat_types), 1))(*stat_types)
-    check(load().statmc_accumulate(width, height, arr, len(stat_types),
-                                   stream if stream is not None else current_stream_handle()))
+    st = stream if stream is not None else current_stream_handle()
+    if rows is None:
+        check(load().statmc_accumulate(width, height, arr, len(stat_types), st))
+    elif len(rows) == 2 and not hasattr(rows[0], "__len__"):
+        check(load().statmc_accumulate_rows(width, height, arr, len(stat_types), int(rows[0]), int(rows[1]), st))
+    else:
+        flat = (C.c_int32 * (2 * len(rows)))(*[int(v) for r in rows for v in r])
+        check(load().statmc_accumulate_row_ranges(width, height, arr, len(stat_types), flat, len(rows), st))
 
 
 def accumulate_tiles(width, height, stat_types, tile_bounds, tile_offsets, tile_samples, stream=None):

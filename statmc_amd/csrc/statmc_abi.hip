@@ -1131,6 +1131,7 @@ static int fill_stat_type(const statmc_stat_type &t, int i, uint16_t width, uint
     d.film_mean = t.film_mean;
     d.film_m2 = t.film_m2;
     d.n_elems = (long long)width * height * t.channels;
+    d.stride = d.n_elems;
     d.channels = t.channels;
     d.n_samples = t.n_samples;
     d.transform = t.transform ? 1 : 0;
@@ -1139,17 +1140,50 @@ static int fill_stat_type(const statmc_stat_type &t, int i, uint16_t width, uint
 }
 
 int statmc_accumulate(uint16_t width, uint16_t height, const statmc_stat_type *types, int n_types, void *stream) {
+    return statmc_accumulate_rows(width, height, types, n_types, 0, height, stream);
+}
+// Rows [y0, y1) of the film only (per-pixel work: any split into row ranges leaves the same bits).  The multi-GPU step
+// accumulates the r rows next to a neighbour first, hands them to the halo exchange and accumulates the rest while the
+// exchange runs (statmc_amd/pipeline.py).
+int statmc_accumulate_rows(uint16_t width, uint16_t height, const statmc_stat_type *types, int n_types, int y0, int y1, void *stream) {
+    const int32_t range[2] = {y0, y1};
+    return statmc_accumulate_row_ranges(width, height, types, n_types, range, 1, stream);
+}
+// Several disjoint row ranges in ONE launch (the two border strips of a block: a 20-row launch on its own is bound by the
+// latency of its few waves, two of them together cost what one costs).
+int statmc_accumulate_row_ranges(uint16_t width, uint16_t height, const statmc_stat_type *types, int n_types, const int32_t *ranges,
+                                 int n_ranges, void *stream) {
     NEED_READY();
     if (width == 0 || height == 0) return fail(STATMC_ERR_INVALID, "empty image");
-    if (n_types < 0 || n_types > statmc::kMaxStatTypes)
-        return fail(STATMC_ERR_INVALID, "n_types must be in [0,%d]", statmc::kMaxStatTypes);
-    if (n_types == 0) return STATMC_OK;
-    if (!types) return fail(STATMC_ERR_INVALID, "null types");
+    if (n_types < 0 || n_ranges < 0 || (long long)n_types * n_ranges > statmc::kMaxStatTypes)
+        return fail(STATMC_ERR_INVALID, "stat types x row ranges must be in [0,%d]", statmc::kMaxStatTypes);
+    if (n_types == 0 || n_ranges == 0) return STATMC_OK;
+    if (!types || !ranges) return fail(STATMC_ERR_INVALID, "null types or ranges");
     statmc::AccumulateArgs k;
     memset(&k, 0, sizeof(k));
-    k.n_types = n_types;
-    for (int i = 0; i < n_types; i++)
-        if (int rc = fill_stat_type(types[i], i, width, height, true, k.t[i])) return rc;
+    k.n_types = 0;
+    for (int r = 0; r < n_ranges; r++) {
+        const int y0 = ranges[2 * r], y1 = ranges[2 * r + 1];
+        if (y0 < 0 || y1 > height || y0 > y1) return fail(STATMC_ERR_INVALID, "rows [%d,%d) outside the %d-row image", y0, y1, (int)height);
+        for (int q = 0; q < r; q++)
+            if (y0 < ranges[2 * q + 1] && ranges[2 * q] < y1) return fail(STATMC_ERR_INVALID, "row ranges %d and %d overlap", q, r);
+        if (y0 == y1) continue;
+        for (int i = 0; i < n_types; i++) {
+            statmc::AccumulateType &d = k.t[k.n_types];
+            if (int rc = fill_stat_type(types[i], i, width, height, true, d)) return rc;
+            const long long px0 = (long long)y0 * width, e0 = px0 * d.channels;
+            if (d.samples) d.samples += e0;
+            d.n += px0;
+            d.mean += e0;
+            if (d.m2) d.m2 += e0;
+            if (d.m3) d.m3 += e0;
+            if (d.film_mean) d.film_mean += e0;
+            if (d.film_m2) d.film_m2 += e0;
+            d.n_elems = (long long)(y1 - y0) * width * d.channels;   // d.stride stays the whole film's plane
+            k.n_types++;
+        }
+    }
+    if (k.n_types == 0) return STATMC_OK;
     k.resident_blocks = g_accumulate_resident_blocks;
     k.umul = g_accumulate_umul;
     k.dma = g_accumulate_dma;

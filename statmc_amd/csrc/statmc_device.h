@@ -28,15 +28,16 @@ struct MeanVarsArgs {
     int width, height, channels, row_n_quirk;
 };
 
-constexpr int kMaxStatTypes = 8;
+constexpr int kMaxStatTypes = 16;   // stat types of a call x row ranges of a call (statmc_accumulate_row_ranges)
 struct AccumulateType {
     const float *samples;
     int32_t *n;
     float *mean, *m2, *m3, *film_mean, *film_m2;
-    long long n_elems;  // width*height*channels
+    long long n_elems;  // elements this launch updates: width * rows * channels
+    long long stride;   // floats between consecutive samples of an element: width * height * channels (> n_elems when the launch covers a range of rows)
     int channels, n_samples, transform, max_moment;
 };
-constexpr int kMaxSlots = 32;
+constexpr int kMaxSlots = 64;
 struct AccumulateArgs {
     AccumulateType t[kMaxStatTypes];
     int n_types;

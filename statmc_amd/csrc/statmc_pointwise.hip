@@ -580,11 +580,11 @@ __device__ __forceinline__ void accumulate_type(const AccumulateType &t, long lo
         const long long left = n_full - gw;
         const int n_active = left >= 64 ? 64 : left > 0 ? (int)left : 0;
         if (n_active > 0)
-            accumulate_lane<C, MAXM, TRANSFORM, (!TRANSFORM && MAXM == 1) ? UMUL : 1, DMA>(t, p0, t.samples + p0 * C, t.n_elems, t.n_samples,
+            accumulate_lane<C, MAXM, TRANSFORM, (!TRANSFORM && MAXM == 1) ? UMUL : 1, DMA>(t, p0, t.samples + p0 * C, t.stride, t.n_samples,
                                                                                             ring, active, n_active);
         if (!active && g < n_groups) {   // unaligned images, the ragged last group
             for (long long p = p0; p < n_px && p < p0 + 4; p++)
-                accumulate_pixel<C, MAXM, TRANSFORM>(t, p, t.samples + p * C, t.n_elems, t.n_samples);
+                accumulate_pixel<C, MAXM, TRANSFORM>(t, p, t.samples + p * C, t.stride, t.n_samples);
         }
     }
 }
@@ -668,7 +668,7 @@ hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
         vec = vec && aligned16(t.samples) && aligned16(t.n) && aligned16(t.mean) &&
               (t.max_moment < 2 || aligned16(t.m2)) && (t.max_moment < 3 || aligned16(t.m3)) &&
               (!t.transform || (aligned16(t.film_mean) && aligned16(t.film_m2))) &&
-              (t.n_elems % 4 == 0);  // sample planes stay 16-B aligned
+              (t.n_elems % 4 == 0) && (t.stride % 4 == 0);  // sample planes stay 16-B aligned
         const long long groups = (t.n_elems / t.channels + 3) / 4;
         if (groups > max_groups) max_groups = groups;
     }

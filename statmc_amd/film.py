@@ -50,23 +50,25 @@ class FilmStats:
                 if v is not None:
                     v.zero_()
 
-    def accumulate(self, samples):
-        """samples: {type: [S, H, W, C]}; one kernel launch covers every stat type."""
+    def accumulate(self, samples, rows=None):
+        """samples: {type: [S, H, W, C]}; one kernel launch covers every stat type.  rows = (y0, y1): only those rows."""
         sts = [api.make_stat_type(samples[t], self.state[t], STAT_TYPES[t]["transform"],
                                   STAT_TYPES[t]["max_moment"]) for t in self.types if t in samples]
-        api.accumulate(self.width, self.height, sts)
+        api.accumulate(self.width, self.height, sts, rows=rows)
 
     def g_buffer(self, name):
         return self.state[name]["mean"]  # film-mean == mean for non-transform types
 
-    def filter_args(self, roi=None, colour=None, out=None):
+    def filter_args(self, roi=None, colour=None, out=None, rows=None):
+        """rows = (y0, y1): the call sees those rows of every image as images of their own (per-pixel stages only)."""
         rad = self.state["radiance"]
         colour = colour if colour is not None else rad["film_mean"]
         out = out if out is not None else self.film_f
+        cut = (lambda t: t) if rows is None else (lambda t: t[rows[0]:rows[1]])
         args, keep = api.make_filter_args(
-            n=[rad["n"]], mean=[rad["mean"]], m2=[rad["m2"]], m3=[rad["m3"]], film=[colour],
-            mean_corr=[self.mean_corr], disc=[self.disc], film_filtered=[out],
-            g_buffers=[self.g_buffer(g) for g in self.g_names], g_sds=self.g_sds,
+            n=[cut(rad["n"])], mean=[cut(rad["mean"])], m2=[cut(rad["m2"])], m3=[cut(rad["m3"])], film=[cut(colour)],
+            mean_corr=[cut(self.mean_corr)], disc=[cut(self.disc)], film_filtered=[cut(out)],
+            g_buffers=[cut(self.g_buffer(g)) for g in self.g_names], g_sds=self.g_sds,
             filter_sd=self.filter_sd, radius=self.radius, denoise_film=False, roi=roi)
         return args, keep
 

@@ -20,23 +20,63 @@ class BlockPipeline:
             self.packed = layout.new_padded(15, device)
             self.out_pad = layout.new_padded(3, device)
 
-    def accumulate(self, samples):
-        self.fs.accumulate(samples)
+    def accumulate(self, samples, rows=None):
+        self.fs.accumulate(samples, rows=rows)
 
-    def prepass(self):
-        """Single GPU: the pre-pass.  Multi-GPU: pre-pass and pack of the owned block in one HIP pass --
-        the five filter inputs go straight into the block + halo image, mean-corr / discriminator are
+    def prepass(self, rows=None):
+        """Single GPU: the pre-pass.  Multi-GPU: pre-pass and pack of the owned block (or of its rows [y0, y1)) in one
+        HIP pass -- the five filter inputs go straight into the block + halo image, mean-corr / discriminator are
         still written out as the reference's device images."""
         if not self.multi:
             self.fs.prepass()
             return
         L = self.layout
-        args, keep = self.fs.filter_args()
-        api.prepass_pack(args, self.packed, L.pl, L.pt)
+        args, keep = self.fs.filter_args(rows=rows)
+        api.prepass_pack(args, self.packed, L.pl, L.pt + (rows[0] if rows is not None else 0))
 
     def exchange(self):
         """Fetch the r-pixel border of the block + halo image from the neighbours (RCCL send/recv)."""
         sharding.exchange_halo(self.layout, self.packed, via_host=self.via_host)
+
+    # ---- the halo exchange behind the accumulation (row-strip grids): the rows a neighbour needs are accumulated,
+    # pre-passed and sent first; the rest of the block is accumulated while they travel.  Per-pixel stages, so the bits are
+    # those of the one-piece order.
+    def border_rows(self):
+        """Row ranges of the owned block that go to a neighbour: [(0, r)] and / or [(bh - r, bh)]."""
+        L = self.layout
+        out = []
+        if self.multi and L.gx == 1 and L.bh >= 2 * L.r + 8:
+            if L.up is not None:
+                out.append((0, L.r))
+            if L.down is not None:
+                out.append((L.bh - L.r, L.bh))
+        return out
+
+    def interior_rows(self):
+        b = self.border_rows()
+        lo = self.layout.r if any(y0 == 0 for y0, _ in b) else 0
+        hi = self.layout.bh - (self.layout.r if any(y1 == self.layout.bh for _, y1 in b) else 0)
+        return (lo, hi)
+
+    def accumulate_and_denoise(self, samples, overlap=True):
+        """One iteration on this rank's block: accumulate -> pre-pass -> halo exchange -> window filter.  With `overlap`
+        (row-strip grids) the rows a neighbour needs go first and travel while the rest is accumulated."""
+        border = self.border_rows() if overlap else []
+        if not border:
+            self.accumulate(samples)
+            return self.denoise()
+        self.accumulate(samples, rows=border)          # both strips in one launch
+        for rows in border:
+            self.prepass(rows=rows)
+        in_flight = self.exchange_start()
+        rows = self.interior_rows()
+        self.accumulate(samples, rows=rows)
+        self.prepass(rows=rows)
+        in_flight.wait()
+        return self.window_filter()
+
+    def exchange_start(self):
+        return sharding.exchange_halo_start(self.layout, self.packed, via_host=self.via_host)
 
     def window_filter(self):
         """Returns the filtered owned block ([bh, bw, 3] view)."""

@@ -122,6 +122,42 @@ def exchange_halo(layout, padded, group=None, via_host=False):
     ])
 
 
+class HaloInFlight:
+    """A halo exchange that has been started (exchange_halo_start); wait() makes the current stream wait for it."""
+
+    def __init__(self, reqs=()):
+        self.reqs = list(reqs)
+
+    def wait(self):
+        for req in self.reqs:
+            req.wait()
+        self.reqs = []
+
+
+def exchange_halo_start(layout, padded, group=None, via_host=False):
+    """exchange_halo in two halves for row-strip grids: the border rows of `padded` must be written, the sends and
+    receives are issued and the call returns; whatever is enqueued next (the accumulation of the rows that need no
+    halo) runs beside the transfers; HaloInFlight.wait() orders the current stream behind them.  Whole rows of the
+    padded image travel in place (no staging copies).  2-D grids and host-staged test setups (gloo) finish the exchange
+    here and return a handle with nothing to wait for."""
+    L, r = layout, layout.r
+    if L.world == 1 or r == 0:
+        return HaloInFlight()
+    if L.gx > 1 or via_host:
+        exchange_halo(layout, padded, group=group, via_host=via_host)
+        return HaloInFlight()
+    y0, y1 = L.pt, L.pt + L.bh
+    ops = []
+    for peer, send_view, recv_view in ((L.up, padded[y0:y0 + r, :], padded[0:y0, :]),
+                                       (L.down, padded[y1 - r:y1, :], padded[y1:y1 + L.pb, :])):
+        if peer is None:
+            continue
+        assert send_view.is_contiguous() and recv_view.is_contiguous()
+        ops.append(dist.P2POp(dist.isend, send_view, peer, group=group))
+        ops.append(dist.P2POp(dist.irecv, recv_view, peer, group=group))
+    return HaloInFlight(dist.batch_isend_irecv(ops) if ops else ())
+
+
 def gather_blocks(layout, block, film_f=None, dst=0, group=None, via_host=False):
     """Assemble the ranks' filtered blocks ([bh, bw, C] each) into the whole film on rank `dst`: SURVEY 8e's final
     gather of film-f (12 B/px).  Row strips land in place -- a strip is a contiguous slab of the film -- and 2-D blocks

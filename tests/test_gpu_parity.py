@@ -315,6 +315,34 @@ def test_accumulate_lds_dma_walk(gpu, oracle, transform, max_moment):
                     assert np.array_equal(got[k], ref[k]), (what, k)
 
 
+@pytest.mark.parametrize("W,H,cuts", [(36, 13, (0, 5, 6, 13)), (260, 9, (0, 2, 9)), (37, 6, (0, 3, 6))], ids=["36x13", "260x9", "37x6-scalar"])
+def test_accumulate_rows_same_bits(gpu, oracle, W, H, cuts):
+    """statmc_accumulate_rows: a batch folded in over any split of the film into row ranges (the multi-GPU step does the
+    rows next to a neighbour first) leaves the bits of the one-launch call -- every stat type of the shipped set in one
+    launch, row offsets that keep and that break the 16-byte alignment of the vector / LDS-DMA paths."""
+    from statmc_amd import film, synthetic
+    S = 5
+    scene, smp, ref = make_case(W, H, S, seed=19, features=synthetic.FEATURES)
+    dsmp = {k: to_dev(v) for k, v in smp.items()}
+    whole = film.FilmStats(W, H, DEV, types=synthetic.FEATURES)
+    whole.accumulate(dsmp)
+    split = film.FilmStats(W, H, DEV, types=synthetic.FEATURES)
+    ranges = list(zip(cuts[:-1], cuts[1:]))
+    if len(ranges) >= 3:                                                 # first and last range in ONE launch, then the middle
+        split.accumulate(dsmp, rows=[ranges[-1], ranges[0]])
+        ranges = ranges[1:-1]
+    for y0, y1 in reversed(ranges):                                      # any order
+        split.accumulate(dsmp, rows=(y0, y1))
+    torch.cuda.synchronize()
+    for t in synthetic.FEATURES:
+        for k, v in whole.state[t].items():
+            if v is not None:
+                assert torch.equal(v.view(torch.int32), split.state[t][k].view(torch.int32)), (t, k)
+        assert np.array_equal(split.state[t]["n"].cpu().numpy(), ref[t]["n"]), t
+    with pytest.raises(gpu.StatmcError):
+        split.accumulate(dsmp, rows=(2, H + 1))
+
+
 def test_accumulate_empty_and_errors(gpu, oracle):
     st = dev_state(oracle.new_state(4, 4, 3))
     empty = torch.zeros(0, 4, 4, 3, device=DEV)

@@ -30,7 +30,7 @@ def _grid(world, rows):
     return sharding.row_strips(world) if rows else sharding.grid_for(world)
 
 
-def _film_samples(world, rows):
+def _film_samples(world, rows, BH=BH):
     """Whole-film sample stream, identical in every process (CPU generator, fixed seed)."""
     from statmc_amd import synthetic
     gx, gy = _grid(world, rows)
@@ -38,7 +38,7 @@ def _film_samples(world, rows):
     return scene.samples(SPP, seed=22, features=TYPES)
 
 
-def _worker(rank, world, rows, port, q):
+def _worker(rank, world, rows, port, q, BH=BH):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch.distributed as dist
@@ -47,7 +47,7 @@ def _worker(rank, world, rows, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        _run(rank, world, rows, q, dist, api, pipeline, sharding)
+        _run(rank, world, rows, q, dist, api, pipeline, sharding, BH)
     except Exception as e:                      # report instead of leaving the parent waiting
         q.put((rank, "error", repr(e), None))
         raise
@@ -55,28 +55,32 @@ def _worker(rank, world, rows, port, q):
         dist.destroy_process_group()
 
 
-def _run(rank, world, rows, q, dist, api, pipeline, sharding):
+def _run(rank, world, rows, q, dist, api, pipeline, sharding, BH=BH):
     if True:
         dev = torch.device("cuda:0")
         api.setup(0)
         api.force_filter_parts(2)            # same window-row split as the single-process run
         L = sharding.BlockLayout(rank, world, BW, BH, RADIUS, grid=_grid(world, rows))
         ox, oy = L.origin
-        smp = {k: v[:, oy:oy + BH, ox:ox + BW].contiguous().to(dev) for k, v in _film_samples(world, rows).items()}
+        smp = {k: v[:, oy:oy + BH, ox:ox + BW].contiguous().to(dev) for k, v in _film_samples(world, rows, BH).items()}
         pipe = pipeline.BlockPipeline(L, dev, TYPES, radius=RADIUS, via_host=True)
-        pipe.accumulate(smp)
-        out = pipe.denoise().clone()
+        # row strips tall enough for it take the overlapped order: the rows a neighbour needs first, the exchange started,
+        # the rest accumulated behind it (BlockPipeline.accumulate_and_denoise); everything else the plain order
+        overlapped = bool(pipe.border_rows())
+        out = pipe.accumulate_and_denoise(smp).clone()
         torch.cuda.synchronize()
+        assert overlapped == (rows and BH >= 2 * RADIUS + 8)
         q.put((rank, ox, oy, out.cpu().numpy()))
         dist.barrier()
 
 
-@pytest.mark.parametrize("world,rows", [(2, False), (4, False), (3, True)], ids=["2x1", "2x2", "1x3-rows"])
-def test_blocks_equal_whole_film(gpu, world, rows):
+@pytest.mark.parametrize("world,rows,BH", [(2, False, 40), (4, False, 40), (3, True, 40), (3, True, 56), (2, True, 64)],
+                         ids=["2x1", "2x2", "1x3-rows", "1x3-rows-overlapped", "1x2-rows-overlapped"])
+def test_blocks_equal_whole_film(gpu, world, rows, BH):
     from statmc_amd import pipeline, sharding
     dev = torch.device("cuda:0")
     gx, gy = _grid(world, rows)
-    whole = _film_samples(world, rows)
+    whole = _film_samples(world, rows, BH)
     gpu.force_filter_parts(2)
     try:
         one = pipeline.BlockPipeline(sharding.BlockLayout(0, 1, gx * BW, gy * BH, RADIUS), dev, TYPES, radius=RADIUS)
@@ -87,7 +91,7 @@ def test_blocks_equal_whole_film(gpu, world, rows):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(rk, world, rows, port, q)) for rk in range(world)]
+    procs = [ctx.Process(target=_worker, args=(rk, world, rows, port, q, BH)) for rk in range(world)]
     for p in procs:
         p.start()
     got = []

@@ -43,7 +43,13 @@ def _worker(rank, world, port, bw, bh, r, rows, q):
         inner = L.interior(packed)
         for i, k in enumerate(("mc", "disc", "colour", "g0", "g1")):
             inner[..., 3 * i:3 * i + 3] = torch.from_numpy(film[k][oy:oy + bh, ox:ox + bw])
-        sharding.exchange_halo(L, packed)
+        if rows:   # row strips: the exchange in two halves (started, something else done, waited for) as the multi-GPU step runs it
+            in_flight = sharding.exchange_halo_start(L, packed)
+            busy = float(torch.ones(1000).sum())          # (what the rank does meanwhile: the rest of its accumulation)
+            in_flight.wait()
+            assert busy == 1000.0 and not in_flight.reqs
+        else:
+            sharding.exchange_halo(L, packed)
         # the padded block must now equal the film window around the block
         want = np.concatenate([film[k] for k in ("mc", "disc", "colour", "g0", "g1")], axis=2)[
             oy - L.pt:oy + bh + L.pb, ox - L.pl:ox + bw + L.pr]
@@ -69,7 +75,7 @@ def _worker(rank, world, port, bw, bh, r, rows, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,bw,bh,r,rows", [(2, 24, 18, 5, False), (4, 16, 14, 6, False), (3, 20, 9, 4, True)])
+@pytest.mark.parametrize("world,bw,bh,r,rows", [(2, 24, 18, 5, False), (4, 16, 14, 6, False), (3, 20, 9, 4, True), (4, 12, 10, 5, True)])
 def test_halo_exchange_and_block_filter(world, bw, bh, r, rows):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

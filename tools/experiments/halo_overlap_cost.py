@@ -10,6 +10,7 @@ import torch
 from statmc_amd import api, pipeline, sharding, synthetic
 
 FW, FH, spp, R = 1920, 1080, 16, 20
+SPP_ACC = 256
 dev = torch.device("cuda:0")
 api.setup(0)
 types = ["radiance", "normal", "albedo"]
@@ -61,3 +62,37 @@ for world in (2, 4, 8):
     same = torch.equal(one.view(torch.int32), three.view(torch.int32))
     print("N=%d block %dx%d (+%d halo rows): one launch %.3f ms | interior %.3f + two strips = %.3f ms (+%.3f) | same bits: %s"
           % (world, W, H, L.pt + L.pb, t_one, t_interior, t_three, t_three - t_one, same), flush=True)
+
+
+# ---- the other way of hiding the exchange: the rows a neighbour needs accumulated, pre-passed and sent first, the rest of
+# the block accumulated while they travel (BlockPipeline.accumulate_and_denoise).  Compute-side cost: the accumulation +
+# pre-pass of a middle rank's block in one piece against border rows + interior (three + three launches).
+for world in (2, 4, 8):
+    grid = sharding.row_strips(world)
+    W, H = FW // grid[0], FH // grid[1]
+    L = sharding.BlockLayout(world // 2, world, W, H, R, grid=grid)
+    ox, oy = L.origin
+    scene = synthetic.Scene(W, H, n_regions=12, seed=1, device=dev, x_offset=ox, y_offset=oy, full_width=FW, full_height=FH)
+    pipe = pipeline.BlockPipeline(L, dev, list(synthetic.FEATURES))
+    smp = {t: torch.cat([scene.samples(32, seed=5 + i, features=synthetic.FEATURES)[t] for i in range(SPP_ACC // 32)]) for t in synthetic.FEATURES}
+
+    def one_piece():
+        pipe.accumulate(smp)
+        pipe.prepass()
+
+    def split():
+        pipe.accumulate(smp, rows=pipe.border_rows())
+        for rows in pipe.border_rows():
+            pipe.prepass(rows=rows)
+        rows = pipe.interior_rows()
+        pipe.accumulate(smp, rows=rows)
+        pipe.prepass(rows=rows)
+
+    def borders_only():
+        pipe.accumulate(smp, rows=pipe.border_rows())
+        for rows in pipe.border_rows():
+            pipe.prepass(rows=rows)
+
+    t_one, t_split, t_b = timed(one_piece, 10), timed(split, 10), timed(borders_only, 10)
+    print("N=%d block %dx%d, %d spp, 11 channels: accumulate + pre-pass in one piece %.3f ms | border rows %s first %.3f ms, then the rest: %.3f ms (+%.3f); the exchange has %.3f ms to hide in"
+          % (world, W, H, SPP_ACC, t_one, pipe.border_rows(), t_b, t_split, t_split - t_one, t_split - t_b), flush=True)
