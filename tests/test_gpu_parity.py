@@ -1147,6 +1147,44 @@ def test_device_memory_and_streams_roundtrip(gpu):
     assert lib.statmc_setup(99) == gpu.ERR_INVALID and b"out of range" in lib.statmc_last_error()
 
 
+def test_upload_by_kernel(gpu):
+    """statmc_upload_by_kernel / statmc_upload_segments_by_kernel: a kernel pulls page-locked host memory over PCIe (the second
+    transport of the band pipeline's copies in); pageable, unaligned or odd-sized memory goes through the copy engine.  Same
+    bytes as statmc_upload either way."""
+    lib = gpu.load()
+
+    class Seg(C.Structure):
+        _fields_ = [("dev_dst", C.c_void_p), ("host_src", C.c_void_p), ("bytes", C.c_size_t)]
+    lib.statmc_upload_segments_by_kernel.argtypes = [C.POINTER(Seg), C.c_int, C.c_void_p]
+    n = 3 * 1000 * 1000 + 5                                              # not a multiple of 16 bytes: a tail through the copy engine
+    pinned = C.c_void_p()
+    gpu.check(lib.statmc_malloc_host(C.byref(pinned), 4 * n))
+    try:
+        host = np.ctypeslib.as_array(C.cast(pinned, C.POINTER(C.c_float)), shape=(n,))
+        host[:] = np.random.default_rng(3).random(n, dtype=np.float32)
+        pageable = host.copy()
+        for src, what in ((host, "page-locked"), (pageable, "pageable"), (host[1:], "unaligned")):
+            dev = torch.zeros(src.size, device=DEV)
+            gpu.check(lib.statmc_upload_by_kernel(dev.data_ptr(), src.ctypes.data, src.nbytes, None))
+            torch.cuda.synchronize()
+            assert np.array_equal(dev.cpu().numpy(), src), what
+        # ten segments (two launches of up to eight), one of them pageable, one empty
+        cuts = np.linspace(0, n - 5, 11).astype(np.int64) // 4 * 4
+        dev = torch.zeros(n, device=DEV)
+        segs = (Seg * 11)()
+        for i in range(10):
+            a, b = int(cuts[i]), int(cuts[i + 1])
+            src = pageable if i == 4 else host
+            segs[i] = Seg(dev.data_ptr() + 4 * a, src.ctypes.data + 4 * a, 4 * (b - a))
+        segs[10] = Seg(dev.data_ptr(), host.ctypes.data, 0)
+        gpu.check(lib.statmc_upload_segments_by_kernel(segs, 11, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(dev.cpu().numpy()[:int(cuts[-1])], host[:int(cuts[-1])])
+        assert lib.statmc_upload_segments_by_kernel(None, 2, None) == gpu.ERR_INVALID
+    finally:
+        gpu.check(lib.statmc_free_host(pinned))
+
+
 def test_filter_randomised_configurations(gpu, oracle):
     """40 seeded random configurations: image size, radius, filter sds, ROI, window-sweep parts,
     kernel variant -- every one against the oracle."""
