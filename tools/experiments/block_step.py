@@ -34,9 +34,19 @@ for world in (1, 2, 4, 8):
     del parts
     pipe = pipeline.BlockPipeline(L, dev, types)
 
+    # the order bench.py --gpus N runs on row strips: border rows first, (the exchange started), the rest, the filter
+    border, interior = pipe.border_rows(), pipe.interior_rows()
+
     def step():
-        pipe.accumulate(samples)
-        pipe.prepass()
+        if border:
+            pipe.accumulate(samples, rows=border)
+            for rows in border:
+                pipe.prepass(rows=rows)
+            pipe.accumulate(samples, rows=interior)
+            pipe.prepass(rows=interior)
+        else:
+            pipe.accumulate(samples)
+            pipe.prepass()
         pipe.window_filter()
 
     for _ in range(3):
@@ -72,6 +82,6 @@ for world in (1, 2, 4, 8):
 
 import json
 out = {"per_rank_step_ms": res, "detail": detail, "spp": spp, "film": "%dx%d" % (FW, FH),
-       "source": "tools/experiments/block_step.py on one MI355X: the middle rank's block of an N-strip grid, halo exchange left out"}
+       "source": "tools/experiments/block_step.py on one MI355X: the middle rank's block of an N-strip grid in the order bench.py runs (border rows first, then the rest, then the filter; detail: the one-piece kernels), halo exchange left out"}
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/block_step.json", "w"), indent=1)
