@@ -615,14 +615,14 @@ def main():
         pos = 0
         for b in batches:
             if border:
-                timed("accumulate", record, accumulate_range, pos, b, border)
-                for rows in border:
-                    timed("prepass", record, pipe.prepass, rows)
-                in_flight = timed("halo", record, pipe.exchange_start)
-                timed("accumulate", record, accumulate_range, pos, b, pipe.interior_rows())
+                # border chain (both strips in one launch, pre-pass + pack, sends and receives) on this stream; the rest of the
+                # block beside it on the pipeline's side stream (the kernel events of the step then cover: "accumulate" = the
+                # border chain, "halo" = what of the interior's accumulation and of the exchange stays exposed behind it)
+                acc = lambda rows, pos=pos, b=b: accumulate_range(pos, b, rows)
+                in_flight = timed("accumulate", record, pipe.border_first, acc)     # border strips + their pre-pass, exchange started
+                pipe.interior_beside(acc, timed=lambda name, fn, *a: timed(name, record, fn, *a))   # the rest of the block, on the side stream
                 pos += b
-                timed("prepass", record, pipe.prepass, pipe.interior_rows())
-                timed("halo", record, in_flight.wait)        # what of the exchange is still exposed
+                timed("halo", record, pipe.join_interior, in_flight)                # what of the interior and the exchange is still exposed
             else:
                 timed("accumulate", record, accumulate_range, pos, b)
                 pos += b
@@ -743,7 +743,7 @@ def main():
         acc_bytes_px = sum(accumulate_bytes_per_px(b, types) for b in batches)     # every launch re-reads and re-writes the state
         acc_bpp = accumulate_bytes_per_px(S, types)
         acc_gbs = acc_bytes_px * px_block / (ms["accumulate"] * 1e-3) / 1e9
-        pre_gbs = PREPASS_BYTES_PER_PX * px_block * n_iter / (ms["prepass"] * 1e-3) / 1e9
+        pre_gbs = PREPASS_BYTES_PER_PX * px_block * n_iter / (max(ms["prepass"], 1e-6) * 1e-3) / 1e9
         taps = (2 * r + 1) ** 2
         # fp32 VALU work of the window filter in lane-operations (a packed op = 2, v_exp_f32 = 4: quarter rate).
         # Pair-symmetric kernel: every unordered pair once, 29 for weight + gate and 4 + 4 for the two accumulations

@@ -14,6 +14,7 @@ class BlockPipeline:
         self.fs = film.FilmStats(layout.bw, layout.bh, device, types=types, filter_sd=filter_sd, radius=radius)
         self.filter_sd, self.radius = filter_sd, radius
         self.multi = layout.world > 1
+        self.side = None   # stream of the interior's accumulation in the overlapped order
         if self.multi:
             # block + halo: one 15-channel image (mean-corr, discriminator, colour, normal, albedo per
             # pixel) is what the pack kernel writes, the halo exchange moves and the filter reads
@@ -65,15 +66,55 @@ class BlockPipeline:
         if not border:
             self.accumulate(samples)
             return self.denoise()
-        self.accumulate(samples, rows=border)          # both strips in one launch
+        in_flight = self.border_first(samples)
+        self.interior_beside(samples)
+        self.join_interior(in_flight)
+        return self.window_filter()
+
+    # The border chain -- both strips accumulated in one launch (a few hundred waves, bound by their own latency: 0.13 ms
+    # for 30 % of an N = 8 block), pre-passed and packed, the sends and receives issued -- goes first on the current
+    # stream.  The rest of the block is accumulated on a side stream that waits only for what preceded the border chain, so
+    # it starts a few microseconds behind the border launch, takes the part of the machine that launch leaves free and all
+    # of it when the strips are done.  (The other way round -- interior on the main stream, border chain on a high-priority
+    # side stream, forked from the same event or not -- lets the interior's workgroups occupy every slot first: stream
+    # priority does not reorder the dispatch, the strips finish WITH the interior and nothing is hidden; rocprofv3
+    # timelines, tools/experiments/block_step_trace.py.  N = 8, middle rank, per step without the exchange E: one piece
+    # 0.78 ms + E; strips first, then the rest 0.87 + max(0, E - 0.37); this order 0.83 + max(0, E - 0.10).)
+    def border_first(self, samples_or_fn, exchange=True):
+        """samples_or_fn: the samples of this batch, or a callable(rows) that accumulates them (bench.py's pooled slices).
+        exchange=False leaves the sends and receives out (one-process timing scripts that stand in for one rank)."""
+        main = torch.cuda.current_stream(self.device)
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=self.device)
+            self.fork = torch.cuda.Event()
+        self.fork.record(main)                          # what both chains have to wait for: the previous iteration
+        border = self.border_rows()
+
+        if callable(samples_or_fn):
+            samples_or_fn(border)
+        else:
+            self.accumulate(samples_or_fn, rows=border)
         for rows in border:
             self.prepass(rows=rows)
-        in_flight = self.exchange_start()
+        return self.exchange_start() if exchange else sharding.HaloInFlight()
+
+    def interior_beside(self, samples_or_fn, timed=None):
+        """Accumulation and pre-pass of the rows that need no neighbour, on the side stream.  timed(name, fn, *args): the
+        caller's per-kernel event timing (bench.py), applied on the side stream."""
+        self.side.wait_event(self.fork)
         rows = self.interior_rows()
-        self.accumulate(samples, rows=rows)
-        self.prepass(rows=rows)
+        run = timed if timed is not None else (lambda name, fn, *a: fn(*a))
+        with torch.cuda.stream(self.side):
+            if callable(samples_or_fn):
+                run("accumulate", samples_or_fn, rows)
+            else:
+                run("accumulate", self.accumulate, samples_or_fn, rows)
+            run("prepass", self.prepass, rows)
+
+    def join_interior(self, in_flight):
+        """Orders the current stream behind the interior's chain and the receives."""
+        torch.cuda.current_stream(self.device).wait_stream(self.side)
         in_flight.wait()
-        return self.window_filter()
 
     def exchange_start(self):
         return sharding.exchange_halo_start(self.layout, self.packed, via_host=self.via_host)

@@ -39,11 +39,9 @@ for world in (1, 2, 4, 8):
 
     def step():
         if border:
-            pipe.accumulate(samples, rows=border)
-            for rows in border:
-                pipe.prepass(rows=rows)
-            pipe.accumulate(samples, rows=interior)
-            pipe.prepass(rows=interior)
+            in_flight = pipe.border_first(samples, exchange=False)       # (world of its own here: nothing is sent)
+            pipe.interior_beside(samples)
+            pipe.join_interior(in_flight)
         else:
             pipe.accumulate(samples)
             pipe.prepass()
