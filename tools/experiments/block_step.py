@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from statmc_amd import api, pipeline, sharding, synthetic
 
-FW, FH = 1920, 1080
+FW, FH = int(os.environ.get("FW", 1920)), int(os.environ.get("FH", 1080))
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 dev = torch.device("cuda:0")
 api.setup(0)
