@@ -37,7 +37,9 @@
 // contiguous memory, three 1-KiB transfers land it in a wave-private ring of STATMC_ACC_DMA_D rows, every lane reads its own
 // 48 B back.  tools/microbench/hbm_read_ldsdma.hip: 7.0 TB/s against 6.26 for the same walk with loads into registers
 // (which for a 48-B lane stride coalesce only through the cache and must not be non-temporal); 1-channel planes keep
-// their non-temporal register loads (6.8 TB/s against 6.3 - 6.6 through LDS-DMA).
+// their non-temporal register loads (6.8 TB/s against 6.3 - 6.6 through LDS-DMA).  Ring depth (STATMC_ACC_DMA_D, below): 3 rows --
+// 240 VGPRs, two waves per SIMD; with 5 the compiler hoists all five row reads (256 VGPRs + AGPR copies), occupancy
+// drops to one wave per SIMD and every type loses.
 // element pairs folded stage by stage together (RGB types: 6 pairs per lane and sample)
 #ifndef STATMC_ACC_PAIR_GROUP
 #define STATMC_ACC_PAIR_GROUP 3
@@ -55,7 +57,7 @@
 #define STATMC_ACC_NT_STORES 0
 #endif
 #ifndef STATMC_ACC_WAVES
-#define STATMC_ACC_WAVES 2   // waves per SIMD the film-major kernel is compiled for
+#define STATMC_ACC_WAVES 2   // waves per SIMD the film-major kernel is compiled for (3: 168 VGPRs, 346 spills, slower)
 #endif
 #ifndef STATMC_ACC_DMA_D
 #define STATMC_ACC_DMA_D 3
