@@ -217,6 +217,9 @@ int statmc_pack_filter_inputs(const statmc_filter_args *args, const statmc_image
  * discriminator[0] are written as well when those tables are given (the reference keeps them as
  * device images), and skipped when they are NULL. */
 int statmc_prepass_pack(const statmc_filter_args *args, const statmc_image *packed, int dst_x0, int dst_y0);
+/* ... for n_ranges = 1 or 2 disjoint ascending row ranges {y0, y1} of the block only, in one launch (0 = the whole block). */
+int statmc_prepass_pack_rows(const statmc_filter_args *args, const statmc_image *packed, int dst_x0, int dst_y0,
+                             const int32_t *ranges, int n_ranges);
 
 /* ---- film blocks on several devices of ONE process (new capability: the reference is single-GPU).
  * The Python side exchanges halos between processes with torch.distributed (RCCL send/recv); this is the same

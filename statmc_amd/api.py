@@ -68,7 +68,7 @@ EXPORTS = [
     "statmc_malloc", "statmc_free", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_upload_by_kernel", "statmc_upload_segments_by_kernel", "statmc_download",
     "statmc_stream_create", "statmc_stream_create_with_priority", "statmc_stream_destroy", "statmc_synchronize",
     "statmc_event_create", "statmc_event_destroy", "statmc_event_record", "statmc_stream_wait_event",
-    "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs", "statmc_prepass_pack",
+    "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs", "statmc_prepass_pack", "statmc_prepass_pack_rows",
     "statmc_halo_exchange", "statmc_copy_rect", "statmc_calculate_mean_vars", "statmc_accumulate", "statmc_accumulate_rows", "statmc_accumulate_row_ranges", "statmc_accumulate_tiles", "statmc_merge_tiles", "statmc_tile_moments", "statmc_film_update",
     "statmc_last_filter_variant", "statmc_version", "statmc_clock_probe",
 ]
@@ -124,6 +124,7 @@ def load():
     lib.statmc_window_filter.argtypes = [C.POINTER(FilterArgs), C.c_int]
     lib.statmc_pack_filter_inputs.argtypes = [C.POINTER(FilterArgs), C.POINTER(Image), C.c_int, C.c_int]
     lib.statmc_prepass_pack.argtypes = [C.POINTER(FilterArgs), C.POINTER(Image), C.c_int, C.c_int]
+    lib.statmc_prepass_pack_rows.argtypes = [C.POINTER(FilterArgs), C.POINTER(Image), C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int]
     lib.statmc_calculate_mean_vars.argtypes = [C.c_uint8, C.c_uint16, C.c_uint16, C.c_int,
                                                C.POINTER(Image), C.POINTER(Image), C.POINTER(Image),
                                                C.c_int, C.c_void_p]
@@ -301,11 +302,16 @@ def pack_filter_inputs(args, packed, dst_x0, dst_y0):
     check(load().statmc_pack_filter_inputs(C.byref(args), C.byref(img), dst_x0, dst_y0))
 
 
-def prepass_pack(args, packed, dst_x0, dst_y0):
+def prepass_pack(args, packed, dst_x0, dst_y0, rows=None):
     """Pre-pass of buffer 0 + pack of the five filter inputs in one pass (mean_corr / discriminator are
-    also written to their own images when the args carry them)."""
+    also written to their own images when the args carry them).  rows: one or two (y0, y1) ranges of the block -- only
+    those rows, in one launch."""
     img = image_of(packed)
-    check(load().statmc_prepass_pack(C.byref(args), C.byref(img), dst_x0, dst_y0))
+    if rows is None:
+        check(load().statmc_prepass_pack(C.byref(args), C.byref(img), dst_x0, dst_y0))
+    else:
+        flat = (C.c_int32 * (2 * len(rows)))(*[int(v) for r in rows for v in r])
+        check(load().statmc_prepass_pack_rows(C.byref(args), C.byref(img), dst_x0, dst_y0, flat, len(rows)))
 
 
 def filter_f32x3(args):

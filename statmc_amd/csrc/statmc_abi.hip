@@ -770,6 +770,12 @@ int statmc_pack_filter_inputs(const statmc_filter_args *a, const statmc_image *p
 }
 
 int statmc_prepass_pack(const statmc_filter_args *a, const statmc_image *packed, int dst_x0, int dst_y0) {
+    return statmc_prepass_pack_rows(a, packed, dst_x0, dst_y0, nullptr, 0);
+}
+// ranges: n_ranges (0 = the whole block, else 1 or 2) disjoint ascending row ranges {y0, y1} of the block: only those rows, in
+// one launch (the multi-GPU step pre-passes and packs the two strips its neighbours need before anything else)
+int statmc_prepass_pack_rows(const statmc_filter_args *a, const statmc_image *packed, int dst_x0, int dst_y0, const int32_t *ranges,
+                             int n_ranges) {
     NEED_READY();
     if (int rc = check_common(a, 3)) return rc;
     if (!packed || !packed->data) return fail(STATMC_ERR_INVALID, "null packed image");
@@ -802,7 +808,22 @@ int statmc_prepass_pack(const statmc_filter_args *a, const statmc_image *packed,
                               static_cast<const float *>(colour.data), static_cast<const float *>(a->g_buffers[0].data),
                               static_cast<const float *>(a->g_buffers[1].data), mc, dc, static_cast<float *>(packed->data),
                               W, H, packed->cols, dst_x0, dst_y0, prepass_table(dstate),
-                              dstate.spec.dof == STATMC_DOF_WELCH, dstate.spec.small_n == STATMC_SMALL_N_EXCLUDE};
+                              dstate.spec.dof == STATMC_DOF_WELCH, dstate.spec.small_n == STATMC_SMALL_N_EXCLUDE, H, 0};
+    if (n_ranges < 0 || n_ranges > 2 || (n_ranges && !ranges)) return fail(STATMC_ERR_INVALID, "0, 1 or 2 row ranges");
+    if (n_ranges) {
+        const int a0 = ranges[0], a1 = ranges[1], b0 = n_ranges == 2 ? ranges[2] : a1, b1 = n_ranges == 2 ? ranges[3] : a1;
+        if (a0 < 0 || a0 > a1 || a1 > b0 || b0 > b1 || b1 > H) return fail(STATMC_ERR_INVALID, "row ranges must be ascending and inside the %d-row block", H);
+        if (a1 - a0 + b1 - b0 == 0) return STATMC_OK;
+        // the launch walks (a1 - a0) + (b1 - b0) rows of images that start at row a0; its rows from a1 - a0 on sit b0 - a1 further down
+        const long long px0 = (long long)a0 * W;
+        k.n += px0;
+        k.mean += 3 * px0; k.m2 += 3 * px0; k.m3 += 3 * px0; k.colour += 3 * px0; k.g0 += 3 * px0; k.g1 += 3 * px0;
+        if (k.mean_corr) { k.mean_corr += 3 * px0; k.disc += 3 * px0; }
+        k.dst_y0 = dst_y0 + a0;
+        k.src_h = (a1 - a0) + (b1 - b0);
+        k.split_row = a1 - a0;
+        k.skip_rows = b0 - a1;
+    }
     HIP_TRY(statmc::launch_prepass_pack(k, S(a->stream)));
     return STATMC_OK;
 }

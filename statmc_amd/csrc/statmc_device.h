@@ -155,6 +155,7 @@ struct PrepassPackArgs {
     float *mean_corr, *disc;   // optional
     float *packed;             // [dst_h][dst_w][15]
     int src_w, src_h, dst_w, dst_x0, dst_y0, table, welch, small_n_exclude;
+    int split_row, skip_rows;   // rows >= split_row of the launch's src_h rows sit skip_rows further down in every image (two row ranges in one launch)
 };
 hipError_t launch_prepass_pack(const PrepassPackArgs &a, hipStream_t s);
 

@@ -179,8 +179,10 @@ struct f3p {
 };
 __global__ __launch_bounds__(kBlock) void prepass_pack_kernel(PrepassPackArgs a) {
     const long long n_px = (long long)a.src_w * a.src_h;
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n_px; i += (long long)gridDim.x * kBlock) {
-        const int y = (int)(i / a.src_w), x = (int)(i - (long long)y * a.src_w);
+    for (long long i0 = (long long)blockIdx.x * kBlock + threadIdx.x; i0 < n_px; i0 += (long long)gridDim.x * kBlock) {
+        const int y0 = (int)(i0 / a.src_w), x = (int)(i0 - (long long)y0 * a.src_w);
+        const int y = y0 + (y0 >= a.split_row ? a.skip_rows : 0);   // the second of two row ranges
+        const long long i = (long long)y * a.src_w + x;
         const int ni = a.n[i];
         const float t = a.welch ? 1.f : t_quantile(a.table, ni - 1);
         const f3p mu = reinterpret_cast<const f3p *>(a.mean)[i], s2 = reinterpret_cast<const f3p *>(a.m2)[i],

@@ -32,8 +32,10 @@ class BlockPipeline:
             self.fs.prepass()
             return
         L = self.layout
-        args, keep = self.fs.filter_args(rows=rows)
-        api.prepass_pack(args, self.packed, L.pl, L.pt + (rows[0] if rows is not None else 0))
+        args, keep = self.fs.filter_args()
+        if rows is not None and not hasattr(rows[0], "__len__"):
+            rows = [rows]                                  # one (y0, y1) range; a list holds one or two of them: one launch
+        api.prepass_pack(args, self.packed, L.pl, L.pt, rows=rows)
 
     def exchange(self):
         """Fetch the r-pixel border of the block + halo image from the neighbours (RCCL send/recv)."""
@@ -94,8 +96,7 @@ class BlockPipeline:
             samples_or_fn(border)
         else:
             self.accumulate(samples_or_fn, rows=border)
-        for rows in border:
-            self.prepass(rows=rows)
+        self.prepass(rows=border)                       # both strips in one launch, too
         return self.exchange_start() if exchange else sharding.HaloInFlight()
 
     def interior_beside(self, samples_or_fn, timed=None):

@@ -1023,6 +1023,24 @@ def test_prepass_pack_equals_prepass_then_pack(gpu, oracle):
     with pytest.raises(gpu.StatmcError) as e:
         gpu.prepass_pack(a, packed, W, 0)
     assert e.value.code == gpu.ERR_INVALID
+    # statmc_prepass_pack_rows: the block in row ranges -- the two outer strips in one launch (what the multi-GPU step sends
+    # first), then the middle -- leaves the bits of the one-launch call, and a range on its own touches nothing else
+    mc, dc = torch.zeros(H, W, 3, device=DEV), torch.zeros(H, W, 3, device=DEV)
+    packed = torch.full((H + 2 * my, W + 2 * mx, 15), -7.0, device=DEV)
+    a, keep = gpu.make_filter_args([dev["n"]], [dev["mean"]], [dev["m2"]], [dev["m3"]], [dev["film_mean"]], [mc], [dc],
+                                   [torch.zeros(H, W, 3, device=DEV)], [g0, g1], g_sds=[SD_NORMAL, SD_ALBEDO], radius=RADIUS)
+    gpu.prepass_pack(a, packed, mx, my, rows=[(0, 5), (H - 9, H)])
+    torch.cuda.synchronize()
+    part = packed.cpu().numpy()
+    assert np.array_equal(part[my:my + 5], want[my:my + 5], equal_nan=True) and np.array_equal(part[my + H - 9:], want[my + H - 9:], equal_nan=True)
+    assert (part[my + 5:my + H - 9] == -7.0).all() and not mc[5:H - 9].any()
+    gpu.prepass_pack(a, packed, mx, my, rows=[(5, H - 9)])
+    gpu.prepass_pack(a, packed, mx, my, rows=[(3, 3)])                 # an empty range
+    torch.cuda.synchronize()
+    assert np.array_equal(packed.cpu().numpy(), want, equal_nan=True)
+    assert np.array_equal(mc.cpu().numpy(), mc_ref) and np.array_equal(dc.cpu().numpy(), dc_ref)
+    with pytest.raises(gpu.StatmcError):
+        gpu.prepass_pack(a, packed, mx, my, rows=[(4, 9), (8, 12)])    # overlapping
 
 
 def test_filter_argument_errors(gpu):

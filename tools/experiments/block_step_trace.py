@@ -22,8 +22,7 @@ for _ in range(12):
     else:
         pipe.accumulate(samples, rows=border)
         pipe.accumulate(samples, rows=interior)
-        for rows in border:
-            pipe.prepass(rows=rows)
+        pipe.prepass(rows=border)
         pipe.prepass(rows=interior)
     pipe.window_filter()
 torch.cuda.synchronize()

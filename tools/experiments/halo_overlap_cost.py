@@ -82,16 +82,14 @@ for world in (2, 4, 8):
 
     def split():
         pipe.accumulate(smp, rows=pipe.border_rows())
-        for rows in pipe.border_rows():
-            pipe.prepass(rows=rows)
+        pipe.prepass(rows=pipe.border_rows())
         rows = pipe.interior_rows()
         pipe.accumulate(smp, rows=rows)
         pipe.prepass(rows=rows)
 
     def borders_only():
         pipe.accumulate(smp, rows=pipe.border_rows())
-        for rows in pipe.border_rows():
-            pipe.prepass(rows=rows)
+        pipe.prepass(rows=pipe.border_rows())
 
     t_one, t_split, t_b = timed(one_piece, 10), timed(split, 10), timed(borders_only, 10)
     print("N=%d block %dx%d, %d spp, 11 channels: accumulate + pre-pass in one piece %.3f ms | border rows %s first %.3f ms, then the rest: %.3f ms (+%.3f); the exchange has %.3f ms to hide in"
