@@ -16,6 +16,14 @@ default -- 1920x540, 1920x270, 1920x135 -- or --grid blocks for 2x1 / 2x2 / 4x2:
 480x540), one per rank: strong scaling, value = film pixels / step time ("1920x1080 @1/2/4/8 GPU").
 --film 3840x2160 is configs[4]'s film; --scaling weak gives every rank its own --film-sized block instead.
 
+Two ways to run N > 1, same step order, same JSON line (`backend` says which):
+    --backend nccl   one process per GPU (torch.distributed; the driver's launch form, or self-launched), halo rows by
+                     RCCL send/recv.  The bring-up is checked under a watchdog; if the leg gives no result, a FRESH
+                     process runs the peer leg and the line carries `fallback_from` / `nccl_error`.
+    --backend peer   ONE process drives all N devices through the C ABI: statmc_accumulate_row_ranges ->
+                     statmc_prepass_pack_rows -> statmc_halo_exchange (device-to-device copies, peer access over
+                     xGMI) -> statmc_window_filter.  No torch.distributed, no RCCL.
+
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -67,8 +75,16 @@ def parse():
                     help="N > 1: rows = 1xN strips of full-width blocks (contiguous halo rows, default); "
                          "blocks = 2x1 / 2x2 / 4x2 grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
-                    help="gloo (+ --share-device) exercises the N > 1 code path on a 1-GPU box; halos go via the host")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo", "peer"),
+                    help="N > 1: nccl = one process per GPU, halo exchange over torch.distributed / RCCL (default; if it gives no "
+                         "result, the peer leg runs in a fresh process and the line says so); peer = ONE process drives all N devices "
+                         "through the C ABI, statmc_halo_exchange's device-to-device copies -- no torch.distributed, no RCCL; "
+                         "gloo (+ --share-device) exercises the per-rank code path on a 1-GPU box, halos via the host")
+    ap.add_argument("--no-fallback", action="store_true", help="nccl: do not fall back to the peer leg")
+    ap.add_argument("--rank-timeout", type=int, default=900, help="self-launched ranks: seconds before the leg is ended (and the peer leg tried)")
+    ap.add_argument("--bringup-timeout", type=int, default=150, help="seconds the process-group bring-up (init, first all-reduce, first "
+                                                                      "neighbour exchange) may take before it counts as hung")
+    ap.add_argument("--dump-film-f", default=None, help="write film-f of a fresh run (empty statistics, three steps) to this .npy (tests: legs against each other)")
     ap.add_argument("--share-device", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--cpu-acc-rows", type=int, default=32, help="rows of the film the CPU baseline accumulates")
     ap.add_argument("--no-host-legs", action="store_true", help="skip the secondary host-side measurements (N = 1)")
@@ -316,86 +332,97 @@ def host_bracket(fs, args):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def _tile_fed_measure(W, H, dev, samples, types, S, reps=5):
+    """statmc_accumulate_tiles over the whole film with S samples per 16 x 16 tile (median of three `reps`-launch averages)."""
+    from statmc_amd import api, film
+    tiles = [(x, y, min(x + 16, W), min(y + 16, H)) for y in range(0, H, 16) for x in range(0, W, 16)]
+    bounds = torch.tensor(tiles, dtype=torch.int32, device=dev)
+    npx = torch.tensor([(x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in tiles], dtype=torch.int64)
+    offs = torch.cumsum(npx * S, 0) - npx * S
+    st2 = film.FilmStats(W, H, dev, types=types)
+    sts, keep = [], []
+    for t in types:
+        c = film.STAT_TYPES[t]["channels"]
+        src = samples[t][:S]
+        # [S, H, W, C] -> per tile [S, th, tw, C]: full 16-row bands by reshape, the ragged last band by hand
+        arena = torch.empty(int((npx * S).sum()) * c, device=dev)
+        pos = 0
+        for y in range(0, H, 16):
+            th = min(16, H - y)
+            band = src[:, y:y + th].reshape(S, th, W // 16, 16, c).permute(2, 0, 1, 3, 4).contiguous().reshape(-1)
+            arena[pos:pos + band.numel()] = band
+            pos += band.numel()
+        keep.append(arena)
+        sts.append(api.make_stat_type_arena(arena, c, st2.state[t], film.STAT_TYPES[t]["transform"], film.STAT_TYPES[t]["max_moment"]))
+    offs_d = offs.to(dev)
+    cnt = torch.full((len(tiles),), S, dtype=torch.int32, device=dev)
+    api.accumulate_tiles(W, H, sts, bounds, offs_d, cnt)
+    torch.cuda.synchronize()
+    runs = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            api.accumulate_tiles(W, H, sts, bounds, offs_d, cnt)
+        e1.record()
+        torch.cuda.synchronize()
+        runs.append(e0.elapsed_time(e1) / reps)
+    ms = sorted(runs)[1]              # median of three averages
+    bpp = accumulate_bytes_per_px(S, types)
+    return {"spp": S, "avg_ms": round(ms, 4), "best_ms": round(min(runs), 4), "bytes_per_px": bpp,
+            "achieved_GBs": round(bpp * W * H / ms / 1e6, 1), "frac_hbm": round(bpp * W * H / ms / 1e6 / HBM_PEAK_GBS, 4)}
+
+
 def tile_fed_accumulate(fs, samples, types):
     """The accumulation fed the way Render<T> produces samples: 16 x 16 tile blocks through statmc_accumulate_tiles
     (Estimator::Merge[Transform]Tiles).  GB/s on the same byte count as the film-major kernel, at the step's sample count
     (the figure the film-major roofline line is compared with) and at 64 samples per tile.  Secondary."""
-    from statmc_amd import api, film
     W, H, dev = fs.width, fs.height, fs.device
     if W % 16:
         return {"skipped": "film width is not a multiple of the 16-pixel tile"}
-    tiles = [(x, y, min(x + 16, W), min(y + 16, H)) for y in range(0, H, 16) for x in range(0, W, 16)]
-    bounds = torch.tensor(tiles, dtype=torch.int32, device=dev)
-    npx = torch.tensor([(x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in tiles], dtype=torch.int64)
     S_all = next(iter(samples.values())).shape[0]
+    out = _tile_fed_measure(W, H, dev, samples, types, S_all)
+    if S_all > 64:
+        out["at_64_spp"] = _tile_fed_measure(W, H, dev, samples, types, 64)
+    return out
 
-    def measure(S):
-        offs = torch.cumsum(npx * S, 0) - npx * S
+
+def accumulate_by_batch(fs, samples, types, batch_sizes=(4, 8, 16, 32, 64), reps=10):
+    """The accumulation at the batch sizes the reference's progressive schedule launches (statpath.cpp:272-279: 4, 4, 8, 16,
+    ... samples per iteration): one launch of S samples per pixel moves 44 S + 224 B/px (11 channels), so at small S the
+    224 B/px read-modify-write of the state dominates.  Film-major (statmc_accumulate) and tile-fed
+    (statmc_accumulate_tiles) launches, `reps` back to back, median of three averages.  Secondary."""
+    from statmc_amd import film
+    W, H, dev = fs.width, fs.height, fs.device
+    S_all = next(iter(samples.values())).shape[0]
+    rows = []
+    for S in batch_sizes:
+        if S > S_all:
+            continue
         st2 = film.FilmStats(W, H, dev, types=types)
-        sts, keep = [], []
-        for t in types:
-            c = film.STAT_TYPES[t]["channels"]
-            src = samples[t][:S]
-            # [S, H, W, C] -> per tile [S, th, tw, C]: full 16-row bands by reshape, the ragged last band by hand
-            arena = torch.empty(int((npx * S).sum()) * c, device=dev)
-            pos = 0
-            for y in range(0, H, 16):
-                th = min(16, H - y)
-                band = src[:, y:y + th].reshape(S, th, W // 16, 16, c).permute(2, 0, 1, 3, 4).contiguous().reshape(-1)
-                arena[pos:pos + band.numel()] = band
-                pos += band.numel()
-            keep.append(arena)
-            sts.append(api.make_stat_type_arena(arena, c, st2.state[t], film.STAT_TYPES[t]["transform"], film.STAT_TYPES[t]["max_moment"]))
-        offs_d = offs.to(dev)
-        cnt = torch.full((len(tiles),), S, dtype=torch.int32, device=dev)
-        api.accumulate_tiles(W, H, sts, bounds, offs_d, cnt)
+        part = {t: v[:S] for t, v in samples.items()}
+        st2.accumulate(part)
         torch.cuda.synchronize()
         runs = []
         for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(5):
-                api.accumulate_tiles(W, H, sts, bounds, offs_d, cnt)
+            for _ in range(reps):
+                st2.accumulate(part)
             e1.record()
             torch.cuda.synchronize()
-            runs.append(e0.elapsed_time(e1) / 5)
-        ms = sorted(runs)[1]              # median of three 5-launch averages
+            runs.append(e0.elapsed_time(e1) / reps)
+        ms = sorted(runs)[1]
         bpp = accumulate_bytes_per_px(S, types)
-        return {"spp": S, "avg_ms": round(ms, 4), "best_ms": round(min(runs), 4), "bytes_per_px": bpp,
-                "achieved_GBs": round(bpp * W * H / ms / 1e6, 1), "frac_hbm": round(bpp * W * H / ms / 1e6 / HBM_PEAK_GBS, 4)}
-
-    out = measure(S_all)
-    if S_all > 64:
-        out["at_64_spp"] = measure(64)
-    return out
-
-
-def launch_ranks(args):
-    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as FRESH child processes
-    (python -m torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) before this process has made any GPU
-    call -- it never does -- and relay rank 0's JSON line and the exit code.  Nothing is exec'ed."""
-    import socket
-    import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    line = None
-    for l in proc.stdout:
-        if l.startswith("{") and '"metric"' in l:
-            line = l.strip()
-        else:
-            sys.stderr.write(l)
-    rc = proc.wait()
-    if line is not None:
-        print(line, flush=True)
-    sys.exit(rc if rc else (0 if line is not None else 1))
+        row = {"spp": S, "bytes_per_px": bpp, "film_major_ms": round(ms, 4), "film_major_GBs": round(bpp * W * H / ms / 1e6, 1),
+               "film_major_frac_hbm": round(bpp * W * H / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        if W % 16 == 0:
+            tf = _tile_fed_measure(W, H, dev, samples, types, S, reps=reps)
+            row.update({"tile_fed_ms": tf["avg_ms"], "tile_fed_GBs": tf["achieved_GBs"], "tile_fed_frac_hbm": tf["frac_hbm"]})
+        rows.append(row)
+        del st2
+    return {"film": "%dx%d" % (W, H), "launches": rows,
+            "what": "one launch of S samples per pixel, all stat types (bytes = samples + read-modify-write of the state), %d launches back to back" % reps}
 
 
 def bind_to_gpu_numa(dev_index):
@@ -520,12 +547,186 @@ def eight_channel_filter(fs, args, reps=20):
             "what": "back-to-back launches of the window filter (pre-pass not included) with normal, albedo, depth and material id as G-buffers"}
 
 
+def _relay_child(cmd, env, timeout_s):
+    """Runs a child to its end (or to the time limit: its whole process group is then ended), relays everything but the
+    JSON line to stderr; returns (rc, line, last stderr lines, timed_out).  Nothing is exec'ed in this process."""
+    import collections
+    import signal
+    import subprocess
+    import threading
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    tail = collections.deque(maxlen=12)
+
+    def pump_err():
+        for l in proc.stderr:
+            tail.append(l.rstrip()[-300:])
+            sys.stderr.write(l)
+    t = threading.Thread(target=pump_err, daemon=True)
+    t.start()
+    line = [None]
+
+    def pump_out():
+        for l in proc.stdout:
+            if l.startswith("{") and '"metric"' in l:
+                line[0] = l.strip()
+            else:
+                sys.stderr.write(l)
+    t2 = threading.Thread(target=pump_out, daemon=True)
+    t2.start()
+    timed_out = False
+    try:
+        rc = proc.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        try:
+            os.killpg(proc.pid, signal.SIGTERM)          # the group this call started, nothing else
+            rc = proc.wait(timeout=20)
+        except Exception:                                # noqa: BLE001
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except Exception:                            # noqa: BLE001
+                pass
+            rc = proc.wait()
+    t.join(5)
+    t2.join(5)
+    return rc, line[0], list(tail), timed_out
+
+
+def _child_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "LOCAL_WORLD_SIZE",
+                                                           "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    # dmabuf IPC: the host driver of this pool supports no other kind -- without it RCCL (and any sharing of device
+    # memory across processes) fails in hipIpcGetMemHandle.  The image exports it already; a launcher that builds its
+    # own environment must keep it (the task's environment notes say so), hence setdefault rather than a guess.
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def run_peer_child(args, why, error_lines, timeout_s=900):
+    """The RCCL-independent leg as a FRESH process (this one may hold a half-initialised communicator): one process drives
+    all N devices through the C ABI.  Returns (rc, line) with the fallback recorded in the line."""
+    argv = [a for a in sys.argv[1:]]
+    # drop a --backend given on the command line, then ask for the peer leg
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a == "--backend":
+            skip = True
+            continue
+        if a.startswith("--backend="):
+            continue
+        out.append(a)
+    cmd = [sys.executable, os.path.abspath(__file__)] + out + ["--backend", "peer"]
+    rc, line, tail, timed_out = _relay_child(cmd, _child_env(), timeout_s)
+    if line is not None:
+        try:
+            d = json.loads(line)
+            d["fallback_from"] = "nccl"
+            d["nccl_error"] = {"why": why, "last_stderr_lines": error_lines[-8:]}
+            line = json.dumps(d)
+        except Exception:                                # noqa: BLE001
+            pass
+    return rc, line
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as FRESH child processes
+    (python -m torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) before this process has made any GPU
+    call -- it never does -- and relay rank 0's JSON line and the exit code.  If the nccl leg ends without a line (RCCL
+    bring-up failed, a rank died, the time limit passed), a fresh child runs the peer leg instead and the line says so
+    (`fallback_from`, `nccl_error`).  Nothing is exec'ed."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = _child_env()
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    env["STATMC_BENCH_NO_FALLBACK"] = "1"          # the ranks report a failure to this parent, which owns the fallback
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc, line, tail, timed_out = _relay_child(cmd, env, args.rank_timeout)
+    if line is None and args.backend == "nccl" and not args.no_fallback:
+        why = "time limit of %d s" % args.rank_timeout if timed_out else "exit code %d without a result line" % rc
+        sys.stderr.write("bench.py: the nccl leg gave no result (%s); running the peer leg in a fresh process\n" % why)
+        rc, line = run_peer_child(args, why, tail)
+    if line is not None:
+        print(line, flush=True)
+    sys.exit(rc if rc else (0 if line is not None else 1))
+
+
+def bring_up(args, rank, world, dev):
+    """Initialises the process group and proves the primitive the halo exchange uses (grouped isend / irecv between strip
+    neighbours) plus the all-reduce of the timing, under a watchdog: a bring-up that hangs ends the process instead of the
+    run.  Returns None on success, a short description of the failure otherwise."""
+    import datetime
+    import threading
+    done = threading.Event()
+    state = {"stage": "init_process_group"}
+
+    def watchdog():
+        if not done.wait(args.bringup_timeout):
+            sys.stderr.write("bench.py rank %d: %s bring-up stuck in %s for %d s\n" % (rank, args.backend, state["stage"], args.bringup_timeout))
+            sys.stderr.flush()
+            state["hung"] = True
+            if rank == 0 and args.backend == "nccl" and not os.environ.get("STATMC_BENCH_NO_FALLBACK") and not args.no_fallback:
+                rc, line = run_peer_child(args, "bring-up stuck in %s for %d s" % (state["stage"], args.bringup_timeout), [])
+                if line is not None:
+                    print(line, flush=True)
+                os._exit(0 if line is not None else 1)
+            os._exit(0 if (rank != 0 and not os.environ.get("STATMC_BENCH_NO_FALLBACK")) else 3)
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        to = datetime.timedelta(seconds=max(60, args.bringup_timeout))
+        if args.backend == "nccl":
+            if os.environ.get("STATMC_BENCH_FAIL_NCCL") == "1":          # tests: the forced-failure path
+                raise RuntimeError("STATMC_BENCH_FAIL_NCCL=1 (forced failure of the nccl bring-up)")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=to)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=to)
+        cdev = dev if args.backend == "nccl" else "cpu"
+        state["stage"] = "all_reduce"
+        t = torch.ones(1, device=cdev)
+        dist.all_reduce(t)
+        assert int(t.item()) == world
+        state["stage"] = "batch_isend_irecv"
+        ops, bufs = [], []
+        for peer in (rank - 1, rank + 1):
+            if 0 <= peer < world:
+                sb, rb = torch.full((1024,), float(rank), device=cdev), torch.empty(1024, device=cdev)
+                bufs.append((peer, rb))
+                ops += [dist.P2POp(dist.isend, sb, peer), dist.P2POp(dist.irecv, rb, peer)]
+        for req in (dist.batch_isend_irecv(ops) if ops else []):
+            req.wait()
+        if args.backend == "nccl":
+            torch.cuda.synchronize()
+        for peer, rb in bufs:
+            assert float(rb[0].item()) == float(peer)
+        return None
+    except Exception as e:      # noqa: BLE001
+        return "%s in %s: %s" % (type(e).__name__, state["stage"], str(e)[-400:])
+    finally:
+        done.set()
+
+
 def main():
     global torch, dist
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.backend == "peer":
+        if world > 1:           # started under a launcher: one process does it all, the others have nothing to do
+            if rank != 0:
+                return
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                os.environ.pop(k, None)
+        import torch as _torch
+        torch = _torch
+        return main_peer(args)
     if world == 1 and args.gpus > 1:
         launch_ranks(args)                       # does not return
     if world != args.gpus:
@@ -541,11 +742,20 @@ def main():
     dev = torch.device("cuda", local_rank)
     binding = {"bound": False} if args.no_bind else bind_to_gpu_numa(local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        err = bring_up(args, rank, world, dev)
+        if err is not None:
+            # every rank sees a failed bring-up (it is collective).  Under the self-launcher the parent owns the fallback;
+            # under a foreign launcher (the driver's torch.distributed.run form) rank 0 does, in a fresh child process.
+            sys.stderr.write("bench.py rank %d: %s bring-up failed: %s\n" % (rank, args.backend, err))
+            own = args.backend == "nccl" and not os.environ.get("STATMC_BENCH_NO_FALLBACK") and not args.no_fallback
+            if not own:
+                sys.exit(3)
+            if rank != 0:
+                sys.exit(0)
+            rc, line = run_peer_child(args, err, [])
+            if line is not None:
+                print(line, flush=True)
+            sys.exit(rc if rc else (0 if line is not None else 1))
     n_ranks_seen = dist.get_world_size() if world > 1 else 1
 
     from statmc_amd import api, film, pipeline, sharding, synthetic
@@ -562,32 +772,17 @@ def main():
         W, H = args.width, args.height
     layout = sharding.BlockLayout(rank, world, W, H, r, grid=grid)
     fw, fh = layout.film_size
-    ox, oy = layout.origin
 
     # ---- synthetic inputs, generated in place in HBM (seeded; same generator as the tests)
-    scene = synthetic.Scene(W, H, n_regions=min(12 * world, 32), seed=1, device=dev, x_offset=ox, y_offset=oy,
-                            full_width=fw, full_height=fh)
     pipe = pipeline.BlockPipeline(layout, dev, types, filter_sd=args.filtersd, radius=r,
                                   via_host=args.backend == "gloo")
     fs = pipe.fs
-    chunk = 32
-    bytes_per_spp = 4 * args.channels * W * H
-    pool = args.pool_spp
-    if pool <= 0:
-        free_b = torch.cuda.mem_get_info(dev)[0]
-        fit = int(0.6 * free_b / bytes_per_spp)
-        pool = S if fit >= S else max(chunk, fit // chunk * chunk)
-    pool = min(pool, S)
-    samples = {t: torch.empty((pool, H, W, synthetic.CHANNELS[t]), dtype=torch.float32, device=dev) for t in types}
-    for s0 in range(0, pool, chunk):
-        part = scene.samples(min(chunk, pool - s0), seed=1000 * (rank + 1) + s0, features=types)
-        for t in types:
-            samples[t][s0:s0 + part[t].shape[0]] = part[t]
-        del part
+    samples, pool = block_samples(args, layout, dev, types, rank, world, share=world if args.share_device else 1)
     batches = synthetic.sample_schedule(S) if args.schedule == "reference" else [S]
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    k_events = {"accumulate": [], "prepass": [], "halo": [], "filter": [], "gather": []}
+    k_events = {k: [] for k in ("accumulate", "prepass", "halo", "filter", "gather", "border_chain", "interior_accumulate",
+                                "interior_prepass", "interior_exposed", "exchange_exposed")}
     film_f = torch.empty(fh, fw, 3, dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
 
     def timed(name, record, fn, *a):
@@ -609,20 +804,24 @@ def main():
     # step (tools/experiments/halo_overlap_cost.py) and leaves the exchange 0.4 - 1.9 ms to hide in.
     border = pipe.border_rows() if (world > 1 and args.overlap_halo) else []
 
-    def step(record, probe=None):
+    def step(record, probe=None, overlapped=True):
         if args.schedule == "reference":
             fs.reset()                  # a progressive render starts from empty statistics (statpath.cpp:173-190)
         pos = 0
+        block = None
         for b in batches:
-            if border:
-                # border chain (both strips in one launch, pre-pass + pack, sends and receives) on this stream; the rest of the
-                # block beside it on the pipeline's side stream (the kernel events of the step then cover: "accumulate" = the
-                # border chain, "halo" = what of the interior's accumulation and of the exchange stays exposed behind it)
+            if border and overlapped:
+                # border chain (both strips in one launch, pre-pass + pack, sends and receives issued) on this stream; the
+                # rest of the block beside it on the pipeline's side stream.  Keys of the overlapped order: border_chain,
+                # interior_accumulate / interior_prepass (side stream), interior_exposed (how long this stream still waits for
+                # the side stream once the border chain is done), exchange_exposed (... and then for the receives).
                 acc = lambda rows, pos=pos, b=b: accumulate_range(pos, b, rows)
-                in_flight = timed("accumulate", record, pipe.border_first, acc)     # border strips + their pre-pass, exchange started
-                pipe.interior_beside(acc, timed=lambda name, fn, *a: timed(name, record, fn, *a))   # the rest of the block, on the side stream
+                in_flight = timed("border_chain", record, pipe.border_first, acc)
+                names = {"accumulate": "interior_accumulate", "prepass": "interior_prepass"}
+                pipe.interior_beside(acc, timed=lambda name, fn, *a: timed(names[name], record, fn, *a))
                 pos += b
-                timed("halo", record, pipe.join_interior, in_flight)                # what of the interior and the exchange is still exposed
+                timed("interior_exposed", record, pipe.join_side)
+                timed("exchange_exposed", record, in_flight.wait)
             else:
                 timed("accumulate", record, accumulate_range, pos, b)
                 pos += b
@@ -636,6 +835,7 @@ def main():
                 probe("filter")
             if world > 1 and args.gather:
                 timed("gather", record, pipe.gather_film, block, film_f)
+        return block
 
     def barrier():
         torch.cuda.synchronize()
@@ -651,8 +851,9 @@ def main():
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
+    cdev = dev if args.backend == "nccl" else "cpu"
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -660,9 +861,6 @@ def main():
     n_iter = len(batches)
     # per-STEP totals of every stage (a reference-schedule step launches each stage n_iter times)
     ms = {k: (sum(a.elapsed_time(b) for a, b in v) / args.steps) for k, v in k_events.items()}
-    px_block = W * H
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = fw * fh * args.steps / elapsed / 1e6       # whole job: every block's pixels per step time
 
     # ---- outside the timed region: film-f assembled on rank 0 (SURVEY 8e "final gather", 12 B/px), and the shader
     # clock the chip holds right behind the two big kernels (one wave counting shader cycles against the 100 MHz clock)
@@ -676,7 +874,7 @@ def main():
             pipe.gather_film(block, film_f)
             torch.cuda.synchronize()
             times.append((time.perf_counter() - g0) * 1e3)
-        t = torch.tensor([sorted(times)[len(times) // 2]], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        t = torch.tensor([sorted(times)[len(times) // 2]], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         gather_ms = float(t.item())
     # The shader clock the chip HOLDS while a kernel runs: one wave on a side stream counts shader clocks (s_memtime) against
@@ -689,7 +887,10 @@ def main():
     side = torch.cuda.Stream(device=dev)
     main_stream = torch.cuda.current_stream()
     n_acc_launches = sum(len(pool_slices(sum(batches[:i]), b, pool)) for i, b in enumerate(batches))
-    est_ms = {"accumulate": ms["accumulate"] / max(1, n_acc_launches), "filter": ms["filter"] / n_iter}
+    acc_ms_total = ms["interior_accumulate"] if border else ms["accumulate"]
+    est_ms = {"accumulate": acc_ms_total / max(1, n_acc_launches), "filter": ms["filter"] / n_iter}
+    import ctypes
+    C_void = ctypes.c_void_p
 
     def probed(name, fn, *a):
         i = idx[name]
@@ -716,139 +917,90 @@ def main():
             block = probed("filter", pipe.window_filter)
             if world > 1 and args.gather:
                 pipe.gather_film(block, film_f)
-    import ctypes
-    C_void = ctypes.c_void_p
     for _ in range(max(1, 8 // n_iter)):     # every rank steps (the halo exchange is collective); rank 0 probes
         probe_step()
     torch.cuda.synchronize()
     if rank == 0:
-        try:
-            sl = slots.cpu().numpy().astype("float64")
-            for name, base in (("accumulate", 0), ("filter", 8)):
-                rows = sl[base:base + idx[name]]
-                rows = rows[rows[:, 1] > 0]
-                if len(rows):
-                    ghz = rows[:, 0] / rows[:, 1] * 0.1       # cycles per 10 ns tick
-                    clocks["during_" + name + "_GHz"] = round(float(sorted(ghz)[len(ghz) // 2]), 3)
-            clocks["how"] = "one wave on a side stream counting s_memtime against s_memrealtime beside the kernel (median of %d)" % idx["filter"]
-        except Exception as e:      # noqa: BLE001
-            clocks = {"error": repr(e)[:200]}
+        clocks = read_clock_slots(slots, idx)
     if world > 1:
         barrier()
 
+    # ---- the overlapped order against the plain one, on this run's own backend (the asynchronous nccl branch
+    # -- border chain on this stream, interior on the side stream, sends and receives in flight until the join -- is
+    # otherwise never compared with anything): from empty statistics, three steps each way, the filtered blocks must be
+    # the same bits on every rank.
+    self_check = None
+    dump_block = None
+    if world > 1:
+        outs = []
+        for overlapped in (True, False):
+            fs.reset()
+            blk = None
+            for _ in range(1 if args.schedule == "reference" else 3):
+                blk = step(False, overlapped=overlapped)
+            torch.cuda.synchronize()
+            outs.append(blk.clone())
+            if overlapped:
+                dump_block = outs[0]
+        same = torch.tensor([1.0 if torch.equal(outs[0], outs[1]) else 0.0], device=cdev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        self_check = {"overlapped_vs_plain_order": "bit-identical" if float(same.item()) == 1.0 else "DIFFERENT",
+                      "ranks": world, "backend": args.backend, "overlapped_order_used": bool(border),
+                      "steps_each": 1 if args.schedule == "reference" else 3}
+    # secondary, N > 1: the block's window filter with all four feature types as G-buffers (eight feature planes: a
+    # 17-channel block + halo image through the same pack / exchange / filter path), on 8 samples of the pool
+    eight = None
+    if world > 1 and args.channels == 11 and not args.no_host_legs:
+        try:
+            names = ("materialid", "depth", "normal", "albedo")
+            pipe8 = pipeline.BlockPipeline(layout, dev, types, filter_sd=args.filtersd, radius=r, via_host=args.backend == "gloo", g_buffers=names)
+            pipe8.accumulate({t: v[:min(8, pool)] for t, v in samples.items()})
+            pipe8.prepass()
+            pipe8.exchange()
+            for _ in range(2):
+                pipe8.window_filter()
+            torch.cuda.synchronize()
+            e0, e1 = ev(), ev()
+            e0.record()
+            for _ in range(10):
+                pipe8.window_filter()
+            e1.record()
+            torch.cuda.synchronize()
+            t8 = torch.tensor([e0.elapsed_time(e1) / 10], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t8, op=dist.ReduceOp.MAX)
+            eight = {"g_buffers": list(names), "feature_channels": 8, "packed_channels": int(pipe8.packed.shape[2]),
+                     "filter_variant": api.last_filter_variant(), "avg_ms": round(float(t8.item()), 4), "block": "%dx%d" % (W, H),
+                     "what": "window filter of one block + halo image with eight feature planes, back to back (max over ranks)"}
+            del pipe8
+        except Exception as e:      # noqa: BLE001
+            eight = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
+    if args.dump_film_f:
+        if world == 1:
+            fs.reset()
+            blk = None
+            for _ in range(1 if args.schedule == "reference" else 3):
+                blk = step(False)
+            torch.cuda.synchronize()
+            import numpy as np
+            np.save(args.dump_film_f, blk.cpu().numpy())
+        else:
+            whole = pipe.gather_film(dump_block, film_f)
+            torch.cuda.synchronize()
+            if rank == 0:
+                import numpy as np
+                np.save(args.dump_film_f, whole.cpu().numpy())
+
     result = None
     if rank == 0:
-        n_flt = n_iter
-        flt_gbs = FILTER_BYTES_PER_PX * px_block * n_flt / (ms["filter"] * 1e-3) / 1e9
-        acc_bytes_px = sum(accumulate_bytes_per_px(b, types) for b in batches)     # every launch re-reads and re-writes the state
-        acc_bpp = accumulate_bytes_per_px(S, types)
-        acc_gbs = acc_bytes_px * px_block / (ms["accumulate"] * 1e-3) / 1e9
-        pre_gbs = PREPASS_BYTES_PER_PX * px_block * n_iter / (max(ms["prepass"], 1e-6) * 1e-3) / 1e9
-        taps = (2 * r + 1) ** 2
-        # fp32 VALU work of the window filter in lane-operations (a packed op = 2, v_exp_f32 = 4: quarter rate).
-        # Pair-symmetric kernel: every unordered pair once, 29 for weight + gate and 4 + 4 for the two accumulations
-        # = 37 per pair; one-sided kernels: 33 per directed tap.
-        sym = variant.startswith("sym")
-        lane_ops = (37.0 * (taps - 1) / 2 + 33.0) if sym else 33.0 * taps
-        valu_rate = lane_ops * px_block * n_flt / (ms["filter"] * 1e-3) / 1e12
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        # the committed PMC figures were collected on the default workload only
-        default_cfg = (W, H, S, args.channels, r, args.schedule) == (1920, 1080, 256, 11, 20, "single")
-        if default_cfg and os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath))
-            except Exception:
-                traffic = {}
-        # counter-based VALU figure (profiles/: SQ_INSTS_VALU per launch of the same command, and the instruction mix of
-        # the compiled loop): SIMD issue cycles the instructions need at the 2.4 GHz peak clock / the measured time
-        valu_counter = None
-        vc = traffic.get("window_filter_valu") if isinstance(traffic, dict) else None
-        if vc and sym:
-            cyc = vc["SQ_INSTS_VALU"] * vc["cycles_per_inst"] / (256 * 4)
-            bound_ms = cyc / 2.4e6
-            valu_counter = {"SQ_INSTS_VALU_per_launch": vc["SQ_INSTS_VALU"], "issue_cycles_per_inst": vc["cycles_per_inst"],
-                            "alu_pass_bound_ms": round(bound_ms, 4), "frac": round(bound_ms / (ms["filter"] / n_flt), 4),
-                            "source": vc.get("source")}
-        pred = None
-        ppath = os.path.join(ROOT, "profiles", "block_step.json")
-        if world > 1 and os.path.exists(ppath) and (fw, fh, S, args.channels, r, args.schedule, args.grid) == (1920, 1080, 256, 11, 20, "single", "rows"):
-            try:
-                bs = json.load(open(ppath))
-                row = bs["per_rank_step_ms"].get(str(world))
-                if row is not None:
-                    pred = {"per_rank_step_ms_without_exchange": row, "n1_step_ms": bs["per_rank_step_ms"]["1"],
-                            "fraction_of_ideal": round(bs["per_rank_step_ms"]["1"] / world / row, 3), "source": bs.get("source")}
-            except Exception:
-                pred = None
-        result = {
-            "metric": "denoised_mpixels_per_s", "value": round(value, 3), "unit": "Mpixels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "n_ranks_seen": n_ranks_seen,
-            "config": {
-                "workload": "StatMC accumulate+prepass+filter, %dx%d film in %d block(s) of %dx%d, %d spp, %d-channel samples, "
-                            "filterradius %d, filtersd %g, G-buffers normal(sd 0.1)+albedo(sd 0.02) "
-                            "[BASELINE.json %s shape, synthetic stream]%s"
-                            % (fw, fh, world, W, H, S, args.channels, r, args.filtersd,
-                               "configs[4]" if (fw, fh, S) == (3840, 2160, 1024) else "configs[2]",
-                               "" if args.schedule == "single" else
-                               "; reference schedule: %d iterations of %s samples, pre-pass + filter after each, statistics reset per step"
-                               % (n_iter, ",".join(str(b) for b in batches))),
-                "film": "%dx%d" % (fw, fh), "block_grid": "%dx%d" % (layout.gx, layout.gy),
-                "spp": S, "sample_channels": args.channels, "filter_variant": variant,
-                "schedule": args.schedule, "iterations_per_step": n_iter,
-                "resident_pool_spp": pool, "accumulate_launches_per_step": n_acc_launches,
-                "gather_in_step": bool(args.gather and world > 1),
-                "parallelism": "film blocks x%d, RCCL halo exchange" % world if world > 1 else "single GPU",
-                "rank0_binding": binding,
-            },
-            # the kernel that dominates the step: the sample-stream accumulation (HBM-bound)
-            "roofline": {
-                "kernel": "accumulate_kernel", "bound": "hbm",
-                "achieved": round(acc_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(acc_gbs / HBM_PEAK_GBS, 4),
-                "traffic": traffic.get("accumulate_kernel"),
-                "algorithmic_bytes_per_launch": acc_bytes_px * px_block // n_acc_launches, "bytes_per_px": acc_bpp,
-                "avg_launch_ms": round(ms["accumulate"] / n_acc_launches, 4), "launches_per_step": n_acc_launches,
-            },
-            # the kernel BASELINE.json's metric names.  It is a (2r+1)^2-tap fp32 stencil: three orders of magnitude above
-            # the machine balance, bound by the fp32 VALU issue rate -- no MFMA, it is not a contraction -- so the
-            # fraction that means something is the VALU one; the (necessarily tiny) HBM figures the metric asks for
-            # ride along under "hbm".
-            "roofline_filter": {
-                "kernel": ("window_filter_sym + combine_sym_kernel (%s)" if sym else "window_filter_lds<%d> + combine_parts_kernel (%%s)" % r) % variant,
-                "bound": "valu",
-                "achieved": round(valu_rate, 2), "peak": VALU_PEAK_TOPS, "unit": "T fp32 lane-ops/s",
-                "frac": round(valu_rate / VALU_PEAK_TOPS, 4), "lane_ops_per_px": round(lane_ops, 1),
-                "note": "peak = 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz; a packed op counts 2, v_exp_f32 4",
-                "counter": valu_counter,
-                "avg_launch_ms": round(ms["filter"] / n_flt, 4), "launches_per_step": n_flt,
-                "hbm": {"achieved": round(flt_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(flt_gbs / HBM_PEAK_GBS, 5),
-                        "traffic": traffic.get("window_filter_sym" if sym else "window_filter_lds"),
-                        "algorithmic_bytes_per_launch": FILTER_BYTES_PER_PX * px_block, "bytes_per_px": FILTER_BYTES_PER_PX},
-            },
-            "shader_clock": clocks,
-            "kernels": {
-                "accumulate": {"ms_per_step": round(ms["accumulate"], 4), "bytes_per_px": acc_bytes_px,
-                               "achieved_GBs": round(acc_gbs, 1), "frac_hbm": round(acc_gbs / HBM_PEAK_GBS, 4)},
-                "prepass": {"ms_per_step": round(ms["prepass"], 4), "bytes_per_px": PREPASS_BYTES_PER_PX,
-                            "achieved_GBs": round(pre_gbs, 1), "frac_hbm": round(pre_gbs / HBM_PEAK_GBS, 4)},
-                "halo_exchange": {"ms_per_step": round(ms["halo"], 4),
-                                  "order": ("border rows accumulated and sent first, the exchange behind the rest of the accumulation: "
-                                            "ms_per_step is what of it stays exposed" if border else "after the whole block's accumulation")
-                                  if world > 1 else "single GPU"},
-                "filter": {"ms_per_step": round(ms["filter"], 4), "mpixels_per_s": round(px_block * n_flt / ms["filter"] / 1e3, 2)},
-            },
-        }
-        if world > 1:
-            result["gather_ms"] = round(gather_ms, 4)
-            result["gather"] = {"ms": round(gather_ms, 4), "in_step": bool(args.gather), "bytes": 12 * fw * fh,
-                                "what": "film-f blocks assembled on rank 0 (median of 5, max over ranks)"}
-            if args.gather:
-                result["kernels"]["gather"] = {"ms_per_step": round(ms["gather"], 4)}
-            result["block_step_prediction"] = pred
+        ctx = dict(args=args, world=world, W=W, H=H, fw=fw, fh=fh, gx=layout.gx, gy=layout.gy, S=S, r=r, types=types,
+                   batches=batches, pool=pool, n_acc_launches=n_acc_launches, ms=ms, elapsed=elapsed, variant=variant,
+                   binding=binding, n_ranks_seen=n_ranks_seen, clocks=clocks, overlapped=bool(border), gather_ms=gather_ms,
+                   backend=args.backend, border_rows=sum(y1 - y0 for y0, y1 in border), self_check=self_check,
+                   parallelism="film blocks x%d, one process per GPU, halo exchange over torch.distributed (%s%s)"
+                               % (world, args.backend, " = RCCL" if args.backend == "nccl" else ", halos via the host") if world > 1 else "single GPU")
+        result = build_result(ctx)
+        if eight is not None:
+            result["filter_8_feature_channels"] = eight
         if world == 1 and not args.no_host_legs:
             # secondary measurements, outside `value`: the reference's own `CUDA time` bracket through the C++ host
             # side, the tile-fed accumulation, and the raw host <-> device copy rates
@@ -860,6 +1012,7 @@ def main():
                     return {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
             result["cuda_time_bracket"] = leg(host_bracket, fs, args)
             result["tile_fed_accumulate"] = leg(tile_fed_accumulate, fs, samples, types)
+            result["accumulate_by_batch"] = leg(accumulate_by_batch, fs, samples, types)
             result["host_copies"] = leg(host_copy_times, fs, dev)
             result["filter_8_feature_channels"] = leg(eight_channel_filter, fs, args)
             result["pcie_inclusive"] = leg(pcie_inclusive, fs, samples, types, args)
@@ -873,6 +1026,361 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+def block_samples(args, layout, dev, types, rank, world, share=1):
+    """The resident sample pool of block `rank` on `dev`, generated in place (seeded: the same stream whichever backend
+    drives the block).  share = blocks that share the device's memory."""
+    from statmc_amd import synthetic
+    W, H = layout.bw, layout.bh
+    fw, fh = layout.film_size
+    ox, oy = layout.origin
+    scene = synthetic.Scene(W, H, n_regions=min(12 * world, 32), seed=1, device=dev, x_offset=ox, y_offset=oy,
+                            full_width=fw, full_height=fh)
+    chunk = 32
+    bytes_per_spp = 4 * args.channels * W * H
+    pool = args.pool_spp
+    if pool <= 0:
+        free_b = torch.cuda.mem_get_info(dev)[0] // max(1, share - rank if share > 1 else 1)
+        fit = int(0.6 * free_b / bytes_per_spp)
+        pool = args.spp if fit >= args.spp else max(chunk, fit // chunk * chunk)
+    pool = min(pool, args.spp)
+    samples = {t: torch.empty((pool, H, W, synthetic.CHANNELS[t]), dtype=torch.float32, device=dev) for t in types}
+    for s0 in range(0, pool, chunk):
+        part = scene.samples(min(chunk, pool - s0), seed=1000 * (rank + 1) + s0, features=types)
+        for t in types:
+            samples[t][s0:s0 + part[t].shape[0]] = part[t]
+        del part
+    return samples, pool
+
+
+def read_clock_slots(slots, idx):
+    clocks = {}
+    try:
+        sl = slots.cpu().numpy().astype("float64")
+        for name, base in (("accumulate", 0), ("filter", 8)):
+            rows = sl[base:base + idx[name]]
+            rows = rows[rows[:, 1] > 0]
+            if len(rows):
+                ghz = rows[:, 0] / rows[:, 1] * 0.1       # cycles per 10 ns tick
+                clocks["during_" + name + "_GHz"] = round(float(sorted(ghz)[len(ghz) // 2]), 3)
+        clocks["how"] = "one wave on a side stream counting s_memtime against s_memrealtime beside the kernel (median of %d)" % idx["filter"]
+    except Exception as e:      # noqa: BLE001
+        clocks = {"error": repr(e)[:200]}
+    return clocks
+
+
+def build_result(c):
+    """The JSON line from what a leg measured (one process per GPU, or one process for all of them)."""
+    args, world, W, H, fw, fh, S, r = c["args"], c["world"], c["W"], c["H"], c["fw"], c["fh"], c["S"], c["r"]
+    types, batches, pool, ms, variant = c["types"], c["batches"], c["pool"], c["ms"], c["variant"]
+    n_iter, n_acc_launches, overlapped = len(batches), c["n_acc_launches"], c["overlapped"]
+    px_block = W * H
+    ms_per_step = c["elapsed"] * 1e3 / args.steps
+    value = fw * fh * args.steps / c["elapsed"] / 1e6       # whole job: every block's pixels per step time
+    n_flt = n_iter
+    flt_gbs = FILTER_BYTES_PER_PX * px_block * n_flt / (ms["filter"] * 1e-3) / 1e9
+    acc_bytes_px = sum(accumulate_bytes_per_px(b, types) for b in batches)     # every launch re-reads and re-writes the state
+    acc_bpp = accumulate_bytes_per_px(S, types)
+    # the launch the roofline line describes: the whole block's accumulation, or -- in the overlapped order -- the
+    # interior's (the rows that need no neighbour; the two border strips run beside its first moments)
+    acc_px = W * (H - c["border_rows"]) if overlapped else px_block
+    acc_ms = ms["interior_accumulate"] if overlapped else ms["accumulate"]
+    acc_gbs = acc_bytes_px * acc_px / (max(acc_ms, 1e-9) * 1e-3) / 1e9
+    pre_ms = ms["interior_prepass"] if overlapped else ms["prepass"]
+    pre_gbs = (160 if world > 1 else PREPASS_BYTES_PER_PX) * acc_px * n_iter / (max(pre_ms, 1e-6) * 1e-3) / 1e9
+    taps = (2 * r + 1) ** 2
+    # fp32 VALU work of the window filter in lane-operations (a packed op = 2, v_exp_f32 = 4: quarter rate).
+    # Pair-symmetric kernel: every unordered pair once, 29 for weight + gate and 4 + 4 for the two accumulations
+    # = 37 per pair; one-sided kernels: 33 per directed tap.
+    sym = variant.startswith("sym")
+    lane_ops = (37.0 * (taps - 1) / 2 + 33.0) if sym else 33.0 * taps
+    valu_rate = lane_ops * px_block * n_flt / (ms["filter"] * 1e-3) / 1e12
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    # the committed PMC figures were collected on the default workload only
+    default_cfg = (W, H, S, args.channels, r, args.schedule) == (1920, 1080, 256, 11, 20, "single")
+    if default_cfg and os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath))
+        except Exception:
+            traffic = {}
+    traffic_source = None
+    if traffic:
+        traffic_source = ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on another "
+                          "box (%s) -- a committed figure, NOT measured in this run" % str(traffic.get("_note", ""))[:160])
+    # counter-based VALU figure (profiles/: SQ_INSTS_VALU per launch of the same command, and the instruction mix of
+    # the compiled loop): SIMD issue cycles the instructions need at the 2.4 GHz peak clock / the measured time
+    valu_counter = None
+    vc = traffic.get("window_filter_valu") if isinstance(traffic, dict) else None
+    if vc and sym:
+        cyc = vc["SQ_INSTS_VALU"] * vc["cycles_per_inst"] / (256 * 4)
+        bound_ms = cyc / 2.4e6
+        valu_counter = {"SQ_INSTS_VALU_per_launch": vc["SQ_INSTS_VALU"], "issue_cycles_per_inst": vc["cycles_per_inst"],
+                        "alu_pass_bound_ms": round(bound_ms, 4), "frac": round(bound_ms / (ms["filter"] / n_flt), 4),
+                        "source": vc.get("source")}
+    pred = None
+    ppath = os.path.join(ROOT, "profiles", "block_step.json")
+    if world > 1 and os.path.exists(ppath) and (fw, fh, S, args.channels, r, args.schedule, args.grid) == (1920, 1080, 256, 11, 20, "single", "rows"):
+        try:
+            bs = json.load(open(ppath))
+            row = bs["per_rank_step_ms"].get(str(world))
+            if row is not None:
+                pred = {"per_rank_step_ms_without_exchange": row, "n1_step_ms": bs["per_rank_step_ms"]["1"],
+                        "fraction_of_ideal": round(bs["per_rank_step_ms"]["1"] / world / row, 3),
+                        "measured_over_predicted": round(ms_per_step / row, 3), "source": bs.get("source")}
+        except Exception:
+            pred = None
+    kernels = {
+        "filter": {"ms_per_step": round(ms["filter"], 4), "mpixels_per_s": round(px_block * n_flt / ms["filter"] / 1e3, 2)},
+    }
+    if overlapped:
+        # the overlapped order (border rows first, the exchange behind the rest of the accumulation) has keys of its own:
+        # nothing here shares a name with the plain order's stages
+        kernels["border_chain"] = {"ms_per_step": round(ms["border_chain"], 4), "rows": c["border_rows"],
+                                   "what": "accumulate + pre-pass/pack of the rows a neighbour needs (one launch each for both strips), "
+                                           "the exchange issued"}
+        kernels["interior"] = {"accumulate_ms_per_step": round(ms["interior_accumulate"], 4), "prepass_ms_per_step": round(ms["interior_prepass"], 4),
+                               "rows": H - c["border_rows"], "achieved_GBs": round(acc_gbs, 1), "frac_hbm": round(acc_gbs / HBM_PEAK_GBS, 4),
+                               "what": "the rest of the block on a side stream, beside the border chain and the exchange"}
+        kernels["interior_exposed"] = {"ms_per_step": round(ms["interior_exposed"], 4),
+                                       "what": "how long the main stream still waits for the interior once its own chain (border rows, exchange issued) is done"}
+        kernels["exchange_exposed"] = {"ms_per_step": round(ms["exchange_exposed"], 4),
+                                       "what": "how long it then still waits for the halo rows to land (0 = the exchange hid behind the interior)"}
+    else:
+        kernels["accumulate"] = {"ms_per_step": round(ms["accumulate"], 4), "bytes_per_px": acc_bytes_px,
+                                 "achieved_GBs": round(acc_gbs, 1), "frac_hbm": round(acc_gbs / HBM_PEAK_GBS, 4)}
+        kernels["prepass"] = {"ms_per_step": round(ms["prepass"], 4), "bytes_per_px": 160 if world > 1 else PREPASS_BYTES_PER_PX,
+                              "achieved_GBs": round(pre_gbs, 1), "frac_hbm": round(pre_gbs / HBM_PEAK_GBS, 4)}
+        if world > 1:
+            kernels["halo_exchange"] = {"ms_per_step": round(ms["halo"], 4), "order": "after the whole block's accumulation and pre-pass"}
+    result = {
+        "metric": "denoised_mpixels_per_s", "value": round(value, 3), "unit": "Mpixels/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "n_ranks_seen": c["n_ranks_seen"], "backend": c["backend"] if world > 1 else "single",
+        "config": {
+            "workload": "StatMC accumulate+prepass+filter, %dx%d film in %d block(s) of %dx%d, %d spp, %d-channel samples, "
+                        "filterradius %d, filtersd %g, G-buffers normal(sd 0.1)+albedo(sd 0.02) "
+                        "[BASELINE.json %s shape, synthetic stream]%s"
+                        % (fw, fh, world, W, H, S, args.channels, r, args.filtersd,
+                           "configs[4]" if (fw, fh, S) == (3840, 2160, 1024) else "configs[2]",
+                           "" if args.schedule == "single" else
+                           "; reference schedule: %d iterations of %s samples, pre-pass + filter after each, statistics reset per step"
+                           % (n_iter, ",".join(str(b) for b in batches))),
+            "film": "%dx%d" % (fw, fh), "block_grid": "%dx%d" % (c["gx"], c["gy"]),
+            "spp": S, "sample_channels": args.channels, "filter_variant": variant,
+            "schedule": args.schedule, "iterations_per_step": n_iter,
+            "resident_pool_spp": pool, "accumulate_launches_per_step": n_acc_launches,
+            "gather_in_step": bool(args.gather and world > 1),
+            "parallelism": c["parallelism"],
+            "step_order": ("border rows first, exchange behind the interior's accumulation" if overlapped else
+                           "accumulate, pre-pass, exchange, filter" if world > 1 else "accumulate, pre-pass, filter"),
+            "rank0_binding": c["binding"],
+        },
+        # the kernel that dominates the step: the sample-stream accumulation (HBM-bound)
+        "roofline": {
+            "kernel": "accumulate_kernel", "bound": "hbm",
+            "achieved": round(acc_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(acc_gbs / HBM_PEAK_GBS, 4),
+            "traffic": traffic.get("accumulate_kernel"), "traffic_source": traffic_source,
+            "algorithmic_bytes_per_launch": acc_bytes_px * acc_px // n_acc_launches, "bytes_per_px": acc_bpp,
+            "avg_launch_ms": round(acc_ms / n_acc_launches, 4), "launches_per_step": n_acc_launches,
+            "launch": ("the interior rows of the block (%d of %d)" % (H - c["border_rows"], H)) if overlapped else "the whole block",
+        },
+        # the kernel BASELINE.json's metric names.  It is a (2r+1)^2-tap fp32 stencil: three orders of magnitude above
+        # the machine balance, bound by the fp32 VALU issue rate -- no MFMA, it is not a contraction -- so the
+        # fraction that means something is the VALU one; the (necessarily tiny) HBM figures the metric asks for
+        # ride along under "hbm".
+        "roofline_filter": {
+            "kernel": ("window_filter_sym + combine_sym_kernel (%s)" if sym else "window_filter_lds<%d> + combine_parts_kernel (%%s)" % r) % variant,
+            "bound": "valu",
+            "achieved": round(valu_rate, 2), "peak": VALU_PEAK_TOPS, "unit": "T fp32 lane-ops/s",
+            "frac": round(valu_rate / VALU_PEAK_TOPS, 4), "lane_ops_per_px": round(lane_ops, 1),
+            "note": "peak = 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz; a packed op counts 2, v_exp_f32 4",
+            "counter": valu_counter,
+            "avg_launch_ms": round(ms["filter"] / n_flt, 4), "launches_per_step": n_flt,
+            "hbm": {"achieved": round(flt_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(flt_gbs / HBM_PEAK_GBS, 5),
+                    "traffic": traffic.get("window_filter_sym" if sym else "window_filter_lds"), "traffic_source": traffic_source,
+                    "algorithmic_bytes_per_launch": FILTER_BYTES_PER_PX * px_block, "bytes_per_px": FILTER_BYTES_PER_PX},
+        },
+        "shader_clock": c["clocks"],
+        "kernels": kernels,
+    }
+    if world > 1:
+        g = c["gather_ms"]
+        result["gather_ms"] = round(g, 4)
+        result["gather"] = {"ms": round(g, 4), "in_step": bool(args.gather), "bytes": 12 * fw * fh,
+                            "what": "film-f blocks assembled on rank 0 / device 0 (median of 5)"}
+        if args.gather:
+            result["kernels"]["gather"] = {"ms_per_step": round(ms["gather"], 4)}
+        result["block_step_prediction"] = pred
+        result["overlap_self_check"] = c["self_check"]
+    for k in ("host_enqueue_ms_per_step", "devices"):
+        if k in c:
+            result[k] = c[k]
+    return result
+
+
+def main_peer(args):
+    """--backend peer: ONE process drives all N devices through the C ABI -- per block statmc_accumulate_row_ranges ->
+    statmc_prepass_pack_rows -> statmc_halo_exchange (device-to-device copies, peer access over xGMI) ->
+    statmc_window_filter, in the border-first order of the one-process-per-GPU leg.  No torch.distributed, no RCCL: the
+    N > 1 measurement that cannot fail on RCCL bring-up, and the leg the nccl one falls back to."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a gfx950 GPU (no CPU fallback exists for the product path)")
+    from statmc_amd import api, peer, sharding, synthetic
+    n = args.gpus
+    n_dev = torch.cuda.device_count()
+    if args.share_device:
+        devices = [0] * n
+    else:
+        if n_dev < n:
+            raise SystemExit("bench.py --gpus %d --backend peer: %d device(s) visible (--share-device rehearses on one)" % (n, n_dev))
+        devices = list(range(n))
+    S, r = args.spp, args.radius
+    types = list(synthetic.FEATURES) if args.channels == 11 else ["radiance", "normal", "albedo"]
+    grid = sharding.row_strips(n) if args.grid == "rows" else sharding.grid_for(n)
+    if args.scaling == "strong":
+        if args.width % grid[0] or args.height % grid[1]:
+            raise SystemExit("film %dx%d does not split into a %dx%d grid of equal blocks" % (args.width, args.height, *grid))
+        W, H = args.width // grid[0], args.height // grid[1]
+    else:
+        W, H = args.width, args.height
+    pf = peer.PeerFilm(n, W, H, r, devices, types, filter_sd=args.filtersd, grid=grid, overlap=args.overlap_halo)
+    fw, fh = pf.film_size
+    batches = synthetic.sample_schedule(S) if args.schedule == "reference" else [S]
+    pools, per_block = [], []
+    for b, blk in enumerate(pf.blocks):
+        with torch.cuda.device(blk.dev):
+            smp, pool = block_samples(args, blk.layout, blk.dev, types, b, n, share=n if args.share_device else 1)
+            torch.cuda.synchronize(blk.dev)
+        pools.append(pool)
+        per_block.append(smp)
+    pool = min(pools)
+    # one prepared plan per iteration of the schedule (its accumulate launches: the slices of the resident pool)
+    def make_plans(overlap=None):
+        out, pos = [], 0
+        for bsz in batches:
+            sl = pool_slices(pos, bsz, pool)
+            out.append(pf.prepare_step([[smp if (a, e) == (0, smp[types[0]].shape[0]) else {t: v[a:e] for t, v in smp.items()} for a, e in sl]
+                                        for smp in per_block], overlap=overlap))
+            pos += bsz
+        return out
+    plans = make_plans()
+    n_acc_launches = sum(len(pool_slices(sum(batches[:i]), bsz, pool)) for i, bsz in enumerate(batches))
+    marks = {}
+
+    def timer(b, name, stream):
+        if b != 0:
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream)
+        marks.setdefault(name, []).append(e)
+
+    host_s = [0.0]
+
+    def step(record):
+        if args.schedule == "reference":
+            pf.reset()
+        h0 = time.perf_counter()
+        for plan in plans:
+            pf.run(plan, timer if record else None)
+        host_s[0] += time.perf_counter() - h0
+
+    for _ in range(args.warmup):
+        step(False)
+    pf.synchronize()
+    host_s[0] = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    pf.synchronize()
+    elapsed = time.perf_counter() - t0
+    host_ms = host_s[0] * 1e3 / args.steps
+    variant = api.last_filter_variant()
+
+    def span(a, b):
+        return sum(x.elapsed_time(y) for x, y in zip(marks[a], marks[b])) / args.steps
+    ms = {k: 0.0 for k in ("accumulate", "prepass", "halo", "filter", "gather", "border_chain", "interior_accumulate", "interior_prepass",
+                           "interior_exposed", "exchange_exposed")}
+    border_rows = sum(y1 - y0 for y0, y1 in pf.blocks[0].border_rows()) if pf.overlap else 0
+    if pf.overlap:
+        ms["border_chain"] = span("start", "border")
+        ms["exchange_exposed"] = span("border", "exchange")     # on the main stream: neighbours' packs awaited + the copies
+        ms["interior_exposed"] = span("exchange", "joined")
+        ms["interior_accumulate"] = span("interior_start", "interior_accumulated")
+        ms["interior_prepass"] = span("interior_accumulated", "interior")
+        ms["filter"] = span("joined", "filter")
+    else:
+        ms["accumulate"] = span("start", "accumulated")
+        ms["prepass"] = span("accumulated", "border")
+        ms["halo"] = span("border", "exchange")
+        ms["filter"] = span("exchange", "filter")
+    # film-f assembled on device 0 (SURVEY 8e "final gather")
+    film_f = torch.empty(fh, fw, 3, dtype=torch.float32, device=pf.blocks[0].dev)
+    times = []
+    for _ in range(5):
+        pf.synchronize()
+        g0 = time.perf_counter()
+        pf.gather(film_f)
+        pf.synchronize()
+        times.append((time.perf_counter() - g0) * 1e3)
+    gather_ms = sorted(times)[len(times) // 2]
+    # overlapped against plain order, from empty statistics (same bits)
+    self_check, outs = None, []
+    for pl in ([plans, make_plans(overlap=False)] if pf.overlap else [plans]):
+        pf.reset()
+        for _ in range(1 if args.schedule == "reference" else 3):
+            if args.schedule == "reference":
+                pf.reset()
+            for plan in pl:
+                pf.run(plan)
+        pf.synchronize()
+        outs.append(pf.gather().clone())
+        pf.synchronize()
+    if len(outs) == 2:
+        self_check = {"overlapped_vs_plain_order": "bit-identical" if torch.equal(outs[0], outs[1]) else "DIFFERENT", "ranks": n,
+                      "backend": "peer", "overlapped_order_used": True, "steps_each": 1 if args.schedule == "reference" else 3}
+    if args.dump_film_f:
+        import numpy as np
+        np.save(args.dump_film_f, outs[0].cpu().numpy())
+    eight = None
+    if n > 1 and args.channels == 11 and not args.no_host_legs:
+        try:
+            names = ("materialid", "depth", "normal", "albedo")
+            pf8 = peer.PeerFilm(n, W, H, r, devices, types, filter_sd=args.filtersd, grid=grid, overlap=False, g_buffers=names)
+            plan8 = pf8.prepare_step([[{t: v[:min(8, pool)] for t, v in smp.items()}] for smp in per_block])
+            pf8.run(plan8)
+            pf8.synchronize()
+            blk0 = pf8.blocks[0]
+            c = plan8["filter"][0]
+            api.check(pf8.lib.statmc_set_device(blk0.device_index))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(blk0.main)
+            for _ in range(10):
+                api.check(c.fn(*c.args))
+            e1.record(blk0.main)
+            pf8.synchronize()
+            eight = {"g_buffers": list(names), "feature_channels": 8, "packed_channels": int(blk0.packed.shape[2]),
+                     "filter_variant": api.last_filter_variant(), "avg_ms": round(e0.elapsed_time(e1) / 10, 4), "block": "%dx%d" % (W, H),
+                     "what": "window filter of block 0's block + halo image with eight feature planes, back to back"}
+            del pf8
+        except Exception as e:      # noqa: BLE001
+            eight = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
+    ctx = dict(args=args, world=n, W=W, H=H, fw=fw, fh=fh, gx=pf.gx, gy=pf.gy, S=S, r=r, types=types, batches=batches, pool=pool,
+               n_acc_launches=n_acc_launches, ms=ms, elapsed=elapsed, variant=variant,
+               binding={"bound": False, "why": "one process drives every device"}, n_ranks_seen=len(pf.blocks), clocks=None,
+               overlapped=pf.overlap, gather_ms=gather_ms, backend="peer", border_rows=border_rows, self_check=self_check,
+               parallelism="film blocks x%d, ONE process, statmc_halo_exchange (device-to-device copies, peer access over xGMI%s)"
+                           % (n, "; all blocks on device 0" if args.share_device else ""),
+               host_enqueue_ms_per_step=round(host_ms, 4), devices=devices)
+    result = build_result(ctx)
+    result["n_gpus"] = n
+    if eight is not None:
+        result["filter_8_feature_channels"] = eight
+    print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -66,8 +66,8 @@ int statmc_get_significance(void);
  * (a repeated statmc_setup of the same device keeps what was loaded). */
 int statmc_set_t_quantiles(int table, const float *quantiles, int n_dof);
 
-/* Copies significance level, filter spec and the quantile tables (built-in or caller-supplied) of `src_device` to
- * `dst_device`; both must have been set up.  All of these are per-device state: a host that spreads one Estimator's
+/* Copies significance level, filter spec, window-sweep split and the quantile tables (built-in or caller-supplied) of
+ * `src_device` to `dst_device`; both must have been set up.  All of these are per-device state: a host that spreads one Estimator's
  * film over several devices (statmc::FilmShards) calls this so that every block is filtered under the same rules. */
 int statmc_copy_device_settings(int src_device, int dst_device);
 
@@ -105,6 +105,22 @@ int statmc_get_filter_spec(statmc_filter_spec *spec);
 int statmc_reset_filter_spec(void);
 const char *statmc_pinned_from(void);
 
+/* ---- window-sweep split (reproducibility across image shapes and devices).  The LDS window filters may sweep the window
+ * rows of a work tile with several workgroups ("parts") whose partial sums are added afterwards; how many is chosen per
+ * call from the number of tiles of the LOCAL image and the device's CU count, so that the launch fills the chip.  The
+ * parts decide how a pixel's 1681 terms are grouped: two calls with a different split agree to <= 1e-6 relative L2, two
+ * calls with the same split (and the same film-anchored tile grid, statmc_filter_args::film_x0 / film_y0) agree BIT FOR BIT
+ * -- whatever the image shape, the region of interest or the device.  Within one image the split never depends on the
+ * region a call filters (bands of the Upload / Denoise / Download pipeline = the whole-image call, bit for bit).
+ * A host that needs the blocks of a sharded film to reproduce the single-device result exactly pins the split:
+ *     statmc_set_filter_split(statmc_filter_split_auto(film_width, film_height, radius))   on every device,
+ * at the price of a launch that is no longer fitted to the block (a 1920 x 135 strip: + 34 % filter time with the whole
+ * film's split of 1).  parts = 0 (default) = automatic.  Per device; acts on the current device. */
+int statmc_set_filter_split(int parts);
+int statmc_get_filter_split(void);
+/* The split the automatic choice makes on the current device for a whole image of this size (pair-symmetric kernel). */
+int statmc_filter_split_auto(int width, int height, int radius);
+
 /* Device memory + copies: the GpuMat role inside Buffer (src/statistics/buffer.h:25,57-63). */
 int statmc_malloc(void **dev_ptr, size_t bytes);
 int statmc_free(void *dev_ptr);
@@ -115,17 +131,6 @@ int statmc_free_host(void *host_ptr);
 int statmc_memset(void *dev_ptr, int value, size_t bytes, void *stream);
 int statmc_upload(void *dev_dst, const void *host_src, size_t bytes, void *stream);   /* Buffer::upload */
 int statmc_download(void *host_dst, const void *dev_src, size_t bytes, void *stream); /* Buffer::download */
-/* statmc_upload by a small kernel that pulls page-locked (statmc_malloc_host) memory over PCIe instead of by the copy
- * engine: same result, same rate (57 GB/s), another queue -- the second transport of the Upload / Denoise / Download band
- * pipeline (include/statmc_bands.hpp).  Host memory the device cannot address goes through statmc_upload. */
-int statmc_upload_by_kernel(void *dev_dst, const void *host_src, size_t bytes, void *stream);
-/* Several images in one launch (all images of one transfer of the band pipeline: no gap between them). */
-typedef struct statmc_copy_segment {
-    void *dev_dst;
-    const void *host_src;
-    size_t bytes;
-} statmc_copy_segment;
-int statmc_upload_segments_by_kernel(const statmc_copy_segment *segs, int n_segs, void *stream);
 int statmc_stream_create(void **stream);
 /* priority_class 0 normal, > 0 high, < 0 low.  Streams of different classes never share a hardware queue (the runtime
  * keeps one pool of GPU_MAX_HW_QUEUES queues per priority level), so the barrier packets of one cannot hold back the
@@ -185,15 +190,21 @@ typedef struct statmc_filter_args {
     int32_t roi_x0, roi_y0, roi_x1, roi_y1;
     /* Packed filter inputs (multi-GPU block path; data == NULL = not used).  A [height][width][15]
      * fp32 image holding, per pixel, mean_corr.rgb, discriminator.rgb, colour.rgb, g_buffers[0].rgb,
-     * g_buffers[1].rgb -- the layout the halo exchange moves as one message.  When set,
-     * statmc_window_filter (T = float3, two 3-channel G-buffers, radius <= 20, n_buffers = 1) reads
-     * its inputs from it and ignores mean_corr / discriminator / film / g_buffers.
-     * statmc_pack_filter_inputs fills the owned block of such an image. */
+     * g_buffers[1].rgb -- the layout the halo exchange moves as one message -- or a [height][width][17]
+     * image that adds two 1-channel G-buffers behind them (depth, material id: src/statistics/statpath.cpp:828-835,
+     * 1096-1130; slots = the call's RGB G-buffers in argument order, then its 1-channel ones; an absent one is 0).
+     * When set, statmc_window_filter (T = float3, radius <= 20, n_buffers = 1) reads its inputs from it and ignores
+     * mean_corr / discriminator / film / g_buffers (g_dr_factors and, for 17 channels, g_channel_counts still describe
+     * the G-buffers: 15 channels = two RGB; 17 = up to two RGB + up to two 1-channel, pair-symmetric kernel only).
+     * statmc_pack_filter_inputs / statmc_prepass_pack fill the owned block of such an image; the channel count is the
+     * image's row pitch / (cols * 4). */
     statmc_image packed_inputs;
     /* Film coordinates of local pixel (0, 0) (multi-GPU block path; 0, 0 = the local image is the film).  The
      * window filter lays its work tiles on a grid fixed in FILM coordinates, so a pixel's sums are formed in the
      * same order whether it is filtered as part of the whole film or of a block + halo image: block-decomposed
-     * results are bit-identical to the single-GPU result. */
+     * results equal the single-GPU result bit for bit WHEN BOTH USE THE SAME WINDOW-SWEEP SPLIT (statmc_set_filter_split;
+     * the automatic split depends on the local image's shape and the device's CU count), and to <= 1e-6 relative L2
+     * under the automatic split. */
     int32_t film_x0, film_y0;
 } statmc_filter_args;
 
@@ -209,7 +220,8 @@ int statmc_window_filter(const statmc_filter_args *args, int channels); /* mean_
 /* Copies the five window-filter inputs of buffer 0 (mean_corr[0], discriminator[0], the colour
  * image -- film_buffer if denoise_film, else film[0] --, g_buffers[0], g_buffers[1]; all
  * width x height x 3) into the 15-channel image `packed` at pixel offset (dst_x0, dst_y0): the
- * owned block inside a block + halo image.  One pass, 60 B read + 60 B written per pixel. */
+ * owned block inside a block + halo image.  One pass, 60 B read + 60 B written per pixel.  A 17-channel `packed`
+ * (row pitch cols * 68) takes up to two RGB and up to two 1-channel G-buffers (g_channel_counts says which). */
 int statmc_pack_filter_inputs(const statmc_filter_args *args, const statmc_image *packed, int dst_x0, int dst_y0);
 
 /* statmc_prepass (T = float3, buffer 0) and statmc_pack_filter_inputs in one pass over the block:
@@ -227,7 +239,7 @@ int statmc_prepass_pack_rows(const statmc_filter_args *args, const statmc_image 
  * (peer access over xGMI, enabled on demand). */
 typedef struct statmc_block {
     int32_t device;      /* HIP device that owns the block (statmc_setup must have run for it) */
-    statmc_image packed; /* [block_h + halo rows][block_w + halo columns][15] fp32 on that device: the block + halo image
+    statmc_image packed; /* [block_h + halo rows][block_w + halo columns][15 | 17] fp32 on that device: the block + halo image
                             statmc_prepass_pack fills and statmc_window_filter reads; a side that lies on the film
                             border has no halo */
     void *stream;        /* the block's stream: its pack was enqueued there, the copies into it go there */
@@ -235,7 +247,10 @@ typedef struct statmc_block {
 /* Fills the halo margins of every block's packed image from its neighbours.  blocks[by * gx + bx] = block (bx, by) of
  * a gx x gy grid of equal block_w x block_h blocks; radius = halo width.  Two phases, as in statmc_amd/sharding.py:
  * columns first, then rows over the widened blocks so that the corners ride along; every copy runs on the stream of
- * its destination block and is ordered behind the source block's pack / first phase by events.  Asynchronous. */
+ * its destination block and is ordered behind the source block's pack / first phase by events.  Asynchronous.
+ * A caller that runs exchange after exchange orders the REWRITE of a block's packed image behind its neighbours' copies
+ * out of it itself (an event recorded on each neighbour's stream after this call, awaited before the next pack:
+ * statmc_amd/peer.py does). */
 int statmc_halo_exchange(const statmc_block *blocks, int gx, int gy, int block_w, int block_h, int radius);
 /* Rectangle copy between device images of any two devices of the process (block cut / block paste of the sharded
  * path).  elem_bytes = bytes per pixel; runs on `stream` (a stream of dst_device). */

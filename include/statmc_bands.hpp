@@ -158,15 +158,7 @@ struct Streams {
         return q;
     }
     void *upStream(int q) const { return q ? up2 : up; }
-    // Transport of the second queue: false = hipMemcpyAsync like the first (two copy-engine streams: fastest when nothing
-    // stalls, but the runtime's enqueue path occasionally blocks the host thread for milliseconds with two of them in
-    // flight -- DESIGN.md 4.5 (b)); true = statmc_upload_by_kernel, a small kernel that pulls the page-locked image over
-    // PCIe (tools/microbench/pcie_read.hip: the link's rate alone, and the link's rate in total beside the copy engine).
-    bool pullSecond = false;
-    void upload(int q, void *dst, const void *src, size_t bytes) const {
-        if (q && pullSecond) ok(statmc_upload_by_kernel(dst, src, bytes, up2), "statmc_upload_by_kernel");
-        else ok(statmc_upload(dst, src, bytes, upStream(q)), "statmc_upload");
-    }
+    void upload(int q, void *dst, const void *src, size_t bytes) const { ok(statmc_upload(dst, src, bytes, upStream(q)), "statmc_upload"); }
     // transfer k starts on both queues only when transfer k - 1 has landed on both: the queues stay in step, a band is
     // complete when it would have been on one queue (minus the gaps)
     void beginTransfer(int k) const {

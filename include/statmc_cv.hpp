@@ -391,9 +391,8 @@ void filter(uchar nBuffers, ushort width, ushort height, float filterDSFactor, u
     //      the Estimator); the copies themselves run at the same rate in slow and fast processes, three bands never
     //      showed it (0 of 32), HSA_ENABLE_INTERRUPT=0 nearly removes it (1 of 96 iterations against 8 of 96): a
     //      wake-up path inside the runtime, not something this side of the API can order differently.
-    static const int nQueues = [] { const char *e = std::getenv("STATMC_CV_UPLOAD_QUEUES"); return e ? std::atoi(e) : 1; }();
+    static const int nQueues = [] { const char *e = std::getenv("STATMC_CV_UPLOAD_QUEUES"); return e && std::atoi(e) >= 2 ? 2 : 1; }();
     const std::vector<int> queue = B::Streams::deal(rowBytes, nQueues);
-    st.pullSecond = nQueues == 3;   // 3: the second queue is a pulling kernel (statmc_upload_by_kernel), not a copy-engine stream
     for (int k = 0; k < nb; k++) {
         const int y0 = plan.arrival(k), y1 = plan.arrival(k + 1);
         st.beginTransfer(k);

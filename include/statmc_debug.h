@@ -1,0 +1,42 @@
+/* statmc_debug.h -- test, A/B and diagnostic switches of libstatmc_hip.so.  NOT part of the drop-in boundary
+ * (include/statmc.h): nothing here has a counterpart in the reference, and a product host never calls it.  tests/,
+ * bench.py's secondary legs and tools/experiments do.
+ *
+ * Like all library state the switches are PER DEVICE: they act on the calling thread's current device (statmc_set_device),
+ * which must have been set up, and return STATMC_ERR_NO_DEVICE otherwise. */
+#ifndef STATMC_DEBUG_H
+#define STATMC_DEBUG_H
+
+#include "statmc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Window-filter kernel of the device: 0 automatic; 1 window_filter_generic (global memory); 2 the one-sided LDS kernel's
+ * runtime-radius build; 3 its compile-time r = 20 build (the kernel the pair-symmetric one replaced). */
+int statmc_debug_force_filter_variant(int variant);
+/* Older name of statmc_set_filter_split (include/statmc.h). */
+int statmc_debug_force_filter_parts(int parts);
+/* Parts per tile of the calling thread's last window-filter call. */
+int statmc_debug_last_filter_parts(void);
+
+/* Film-major accumulation: n > 0 runs it as n resident workgroups (0 = the large interleaved grid, default). */
+int statmc_debug_accumulate_resident_blocks(int n);
+/* 1 (default): RGB sample planes stream through LDS-DMA; 0: loads into registers (same bits). */
+int statmc_debug_accumulate_dma(int on);
+/* 2: the mean-only feature types of the film-major kernel prefetch twice as deep (default 1). */
+int statmc_debug_accumulate_umul(int umul);
+/* Tile-fed accumulation: prefetch depth of the mean-only types (1 | 2, default 2), item order, workgroups per CU. */
+int statmc_debug_accumulate_tiles_variant(int umul, int order, int wg_per_cu);
+
+/* Non-zero: the library was built with a timing-only / diagnostic switch (statmc_sym_experiments.h); its results are
+ * not the product's and statmc_amd.api refuses to load it. */
+int statmc_debug_diagnostic_build(void);
+/* Largest filter workspace of the current device (diagnostic builds read their counters back from it). */
+int statmc_debug_last_workspace(void **ptr, size_t *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STATMC_DEBUG_H */

@@ -752,12 +752,9 @@ class Estimator {
     // bracket, every iteration.  2 (SetUploadQueues / STATMC_UPLOAD_QUEUES=2) gives 3.5 ms when nothing stalls, but about
     // one iteration in twelve then takes 7 - 10 ms because the host thread blocks inside a hipMemcpyAsync enqueue
     // (statmc_cv.hpp, note (b); tools/experiments/iter_times.py): 4.1 ms on average, with a tail.
-    // 3: the second queue is a pulling kernel (statmc_upload_by_kernel) instead of a copy-engine stream; 4: no copy engine, one
-    // pulling kernel per transfer (statmc_upload_segments_by_kernel: the link's rate without a gap between the images,
-    // the copies in done 0.3 ms earlier -- but its eight workgroups hold eight CUs, a band's filter then needs a third
-    // round, and the bracket ends where it did: 3.65 against 3.73 ms).  Both give the same bits; both need page-locked
-    // host images.  DESIGN.md 4.5.
-    void SetUploadQueues(int n) { uploadQueues = n; }
+    // (Two further transports -- a pulling kernel as the second queue, or instead of the copy engine altogether -- were
+    // measured in round 3 and gained nothing, profiles/r03_upload_modes.log; they are no longer part of the library.)
+    void SetUploadQueues(int n) { uploadQueues = n < 2 ? 1 : 2; }
     int PipelineBands() const {
         if (!allocateDevice || acc.dry) return 1;
         return bandPlan().count();
@@ -782,24 +779,6 @@ class Estimator {
             rowBytes.push_back((size_t)b->mat.cols * b->mat.channels() * 4);
         }
         const std::vector<int> queue = bands::Streams::deal(rowBytes, uploadQueues);
-        pipe.pullSecond = uploadQueues == 3;   // 3: two queues, the second one a pulling kernel instead of a copy-engine stream
-        if (uploadQueues == 4) {
-            // 4: no copy engine at all -- ONE pulling kernel per transfer moves the rows of every image (statmc_upload_segments_by_kernel:
-            // no gap between the images of a transfer), the transfers queue up behind each other on one stream and each
-            // marks its band as arrived on both events
-            for (int k = 0; k < nb; k++) {
-                const int y0 = arrivalEdge(k, nb), y1 = arrivalEdge(k + 1, nb);
-                std::vector<statmc_copy_segment> segs;
-                for (size_t i = 0; i < moving.size(); i++)
-                    segs.push_back({static_cast<char *>(moving[i]->gpuMat.data()) + y0 * rowBytes[i], moving[i]->mat.ptr<char>() + y0 * rowBytes[i],
-                                    (size_t)(y1 - y0) * rowBytes[i]});
-                check(statmc_upload_segments_by_kernel(segs.data(), (int)segs.size(), pipe.up2));
-                check(statmc_event_record(pipe.arrived[k], pipe.up2));
-                check(statmc_event_record(pipe.arrived2[k], pipe.up2));
-            }
-            pipe.uploaded = pipe.pendingJoin = nb;
-            return;
-        }
         for (int k = 0; k < nb; k++) {
             const int y0 = arrivalEdge(k, nb), y1 = arrivalEdge(k + 1, nb);
             pipe.beginTransfer(k);
@@ -1084,7 +1063,7 @@ class Estimator {
         bool downloading = false;
     } pipe;
     int bandsRequested = 0;
-    int uploadQueues = [] { const char *e = std::getenv("STATMC_UPLOAD_QUEUES"); return e ? std::atoi(e) : 1; }();
+    int uploadQueues = [] { const char *e = std::getenv("STATMC_UPLOAD_QUEUES"); return e && std::atoi(e) >= 2 ? 2 : 1; }();
     // where the bands lie (statmc_bands.hpp: automatic = fitted to the window filter's rounds); the same plan serves Upload,
     // Denoise and Download of an iteration because it depends on the image, the radius and the request only
     bands::Plan bandPlan() const { return bands::plan(width, height, filterRadius, bandsRequested); }
@@ -1377,9 +1356,12 @@ class FilmShards {
     FilmShards(Estimator &est, int gx, int gy, std::vector<int> devices = {}) : est(est), gx(gx), gy(gy) {
         if (gx < 1 || gy < 1 || est.width % gx || est.height % gy)
             throw Error(STATMC_ERR_INVALID, "FilmShards: the film does not split into equal blocks");
-        if (est.rgbBufferCounts[DenoiseGroup] != 1 || est.gBuffers.size() != 2 || est.gBufferChannelCounts[0] != 3 ||
-            est.gBufferChannelCounts[1] != 3)
-            throw Error(STATMC_ERR_UNSUPPORTED, "FilmShards: one RGB radiance buffer under two RGB G-buffers (the shipped denoise configuration)");
+        int nRgb = 0, nSc = 0;
+        for (size_t g = 0; g < est.gBuffers.size(); g++) (est.gBufferChannelCounts[g] == 3 ? nRgb : nSc)++;
+        if (est.rgbBufferCounts[DenoiseGroup] != 1 || nRgb > 2 || nSc > 2)
+            throw Error(STATMC_ERR_UNSUPPORTED, "FilmShards: one RGB radiance buffer under at most two RGB and two 1-channel G-buffers");
+        // the block + halo image: 15 channels for the shipped two RGB G-buffers, 17 with depth / material id
+        pch = (nRgb == 2 && nSc == 0) ? 15 : 17;
         bw = est.width / gx;
         bh = est.height / gy;
         r = est.filterRadius;
@@ -1393,12 +1375,17 @@ class FilmShards {
             B.x0 = bx * bw; B.y0 = by * bh;
             check(statmc_setup(B.device));               // idempotent; makes the device current for the allocations
             B.n = DeviceImage(bh, bw, I32C1);
-            for (DeviceImage *im : {&B.mean, &B.m2, &B.m3, &B.colour, &B.g0, &B.g1}) *im = DeviceImage(bh, bw, F32C3);
+            for (DeviceImage *im : {&B.mean, &B.m2, &B.m3, &B.colour}) *im = DeviceImage(bh, bw, F32C3);
+            for (size_t g = 0; g < est.gBuffers.size(); g++) {
+                B.g.push_back(DeviceImage(bh, bw, est.gBufferChannelCounts[g] == 3 ? F32C3 : F32C1));
+                B.gch.push_back(est.gBufferChannelCounts[g]);
+            }
+            B.dg.resize(B.g.size());
             const int pw = bw + B.pl + B.pr, ph = bh + B.pt + B.pb;
             void *p = nullptr;
-            check(statmc_malloc(&p, (size_t)pw * ph * 60));
+            check(statmc_malloc(&p, (size_t)pw * ph * pch * 4));
             B.packed = std::shared_ptr<void>(p, [](void *q) { statmc_free(q); });
-            B.packedDesc = statmc_image{p, (size_t)pw * 60, pw, ph};
+            B.packedDesc = statmc_image{p, (size_t)pw * pch * 4, pw, ph};
             B.out = DeviceImage(ph, pw, F32C3);
             void *st = nullptr;
             check(statmc_stream_create(&st));
@@ -1429,7 +1416,8 @@ class FilmShards {
                 check(statmc_copy_rect(&d, B.device, 0, 0, &w, src, B.x0, B.y0, bw, bh, elem, st));
             };
             cut(t.n[0], B.n, 4); cut(t.mean[0], B.mean, 12); cut(t.m2[0], B.m2, 12); cut(t.m3[0], B.m3, 12);
-            cut(colour, B.colour, 12); cut(est.gBufferImages[0], B.g0, 12); cut(est.gBufferImages[1], B.g1, 12);
+            cut(colour, B.colour, 12);
+            for (size_t g = 0; g < B.g.size(); g++) cut(est.gBufferImages[g], B.g[g], 4 * B.gch[g]);
             statmc_filter_args a = args(B);
             check(statmc_prepass_pack(&a, &B.packedDesc, B.pl, B.pt));
             desc[b] = statmc_block{B.device, B.packedDesc, st};
@@ -1461,19 +1449,21 @@ class FilmShards {
   private:
     struct Block {
         int device = 0, pl = 0, pr = 0, pt = 0, pb = 0, x0 = 0, y0 = 0;
-        DeviceImage n, mean, m2, m3, colour, g0, g1, out;
+        DeviceImage n, mean, m2, m3, colour, out;
+        std::vector<DeviceImage> g;          // the Estimator's G-buffers, in its order
         std::shared_ptr<void> packed, stream;
         statmc_image packedDesc{};
         // descriptor storage the argument block points into
-        statmc_image dn{}, dmean{}, dm2{}, dm3{}, dcol{}, dg[2]{};
-        uint8_t gch[2] = {3, 3};
+        statmc_image dn{}, dmean{}, dm2{}, dm3{}, dcol{};
+        std::vector<statmc_image> dg;
+        std::vector<uint8_t> gch;
     };
     // the argument block of filter<float3> for one block (reference order, estimator.cpp:465-487)
     statmc_filter_args args(Block &B) {
         statmc_filter_args a;
         std::memset(&a, 0, sizeof(a));
         B.dn = B.n.desc(); B.dmean = B.mean.desc(); B.dm2 = B.m2.desc(); B.dm3 = B.m3.desc(); B.dcol = B.colour.desc();
-        B.dg[0] = B.g0.desc(); B.dg[1] = B.g1.desc();
+        for (size_t g = 0; g < B.g.size(); g++) B.dg[g] = B.g[g].desc();
         a.n_buffers = 1;
         a.width = (uint16_t)bw;
         a.height = (uint16_t)bh;
@@ -1481,15 +1471,15 @@ class FilmShards {
         a.filter_radius = est.filterRadius;
         a.denoise_film = 0;
         a.n = &B.dn; a.mean = &B.dmean; a.m2 = &B.dm2; a.m3 = &B.dm3; a.film = &B.dcol;
-        a.g_buffers = B.dg;
-        a.g_channel_counts = B.gch;
+        a.g_buffers = B.dg.data();
+        a.g_channel_counts = B.gch.data();
         a.g_dr_factors = est.gBufferDRFactors.data();
-        a.n_g_buffers = 2;
+        a.n_g_buffers = B.g.size();
         a.stream = B.stream.get();
         return a;
     }
     Estimator &est;
-    int gx, gy, bw = 0, bh = 0, r = 0;
+    int gx, gy, bw = 0, bh = 0, r = 0, pch = 15;
     std::vector<Block> blocks;
 };
 

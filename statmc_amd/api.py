@@ -65,7 +65,8 @@ class StatType(C.Structure):
 EXPORTS = [
     "statmc_last_error", "statmc_setup", "statmc_set_device", "statmc_set_significance", "statmc_get_significance", "statmc_set_t_quantiles",
     "statmc_set_filter_spec", "statmc_get_filter_spec", "statmc_reset_filter_spec", "statmc_pinned_from", "statmc_copy_device_settings",
-    "statmc_malloc", "statmc_free", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_upload_by_kernel", "statmc_upload_segments_by_kernel", "statmc_download",
+    "statmc_set_filter_split", "statmc_get_filter_split", "statmc_filter_split_auto",
+    "statmc_malloc", "statmc_free", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_download",
     "statmc_stream_create", "statmc_stream_create_with_priority", "statmc_stream_destroy", "statmc_synchronize",
     "statmc_event_create", "statmc_event_destroy", "statmc_event_record", "statmc_stream_wait_event",
     "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs", "statmc_prepass_pack", "statmc_prepass_pack_rows",
@@ -102,13 +103,14 @@ def load():
     lib.statmc_set_filter_spec.argtypes = [C.POINTER(FilterSpec)]
     lib.statmc_get_filter_spec.argtypes = [C.POINTER(FilterSpec)]
     lib.statmc_copy_device_settings.argtypes = [C.c_int, C.c_int]
+    lib.statmc_set_filter_split.argtypes = [C.c_int]
+    lib.statmc_filter_split_auto.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.statmc_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     lib.statmc_free.argtypes = [C.c_void_p]
     lib.statmc_malloc_host.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     lib.statmc_free_host.argtypes = [C.c_void_p]
     lib.statmc_memset.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
     lib.statmc_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
-    lib.statmc_upload_by_kernel.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.statmc_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.statmc_stream_create.argtypes = [C.POINTER(C.c_void_p)]
     lib.statmc_stream_create_with_priority.argtypes = [C.POINTER(C.c_void_p), C.c_int]
@@ -125,6 +127,10 @@ def load():
     lib.statmc_pack_filter_inputs.argtypes = [C.POINTER(FilterArgs), C.POINTER(Image), C.c_int, C.c_int]
     lib.statmc_prepass_pack.argtypes = [C.POINTER(FilterArgs), C.POINTER(Image), C.c_int, C.c_int]
     lib.statmc_prepass_pack_rows.argtypes = [C.POINTER(FilterArgs), C.POINTER(Image), C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int]
+    lib.statmc_halo_exchange.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.statmc_copy_rect.argtypes = [C.POINTER(Image), C.c_int, C.c_int, C.c_int, C.POINTER(Image), C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.statmc_set_device.argtypes = [C.c_int]
     lib.statmc_calculate_mean_vars.argtypes = [C.c_uint8, C.c_uint16, C.c_uint16, C.c_int,
                                                C.POINTER(Image), C.POINTER(Image), C.POINTER(Image),
                                                C.c_int, C.c_void_p]
@@ -188,23 +194,42 @@ def last_filter_variant():
 
 
 def force_filter_variant(v):
-    """0 auto, 1 generic (global-memory) kernel, 2 runtime-radius one-sided LDS kernel, 3 one-sided r = 20 LDS kernel."""
-    load().statmc_debug_force_filter_variant(int(v))
+    """0 auto, 1 generic (global-memory) kernel, 2 runtime-radius one-sided LDS kernel, 3 one-sided r = 20 LDS kernel.
+    (include/statmc_debug.h; per device, like the two switches below)"""
+    check(load().statmc_debug_force_filter_variant(int(v)))
 
 
 def accumulate_resident_blocks(n):
     """0: default large grid; n > 0: the accumulate kernel runs as n resident workgroups."""
-    load().statmc_debug_accumulate_resident_blocks(int(n))
+    check(load().statmc_debug_accumulate_resident_blocks(int(n)))
 
 
 def accumulate_dma(on):
     """1 (default): the RGB sample planes of the accumulation stream through LDS-DMA; 0: loads into registers (A/B, tests)."""
-    load().statmc_debug_accumulate_dma(int(on))
+    check(load().statmc_debug_accumulate_dma(int(on)))
 
 
 def force_filter_parts(k):
-    """0 automatic; k >= 1: the LDS kernel sweeps the window with k workgroups per tile."""
-    load().statmc_debug_force_filter_parts(int(k))
+    """0 automatic; k >= 1: the LDS kernels sweep the window with k workgroups per tile (= set_filter_split)."""
+    check(load().statmc_set_filter_split(int(k)))
+
+
+def set_filter_split(parts):
+    """Window-sweep split of the current device: 0 = automatic (fitted to the local image and the device), k >= 1 = pinned.
+    Calls with the same split reproduce each other bit for bit whatever the image shape (include/statmc.h)."""
+    check(load().statmc_set_filter_split(int(parts)))
+
+
+def get_filter_split():
+    return int(load().statmc_get_filter_split())
+
+
+def filter_split_auto(width, height, radius):
+    """What the automatic choice picks on the current device for a whole image of this size."""
+    k = int(load().statmc_filter_split_auto(int(width), int(height), int(radius)))
+    if k < 0:
+        check(k)
+    return k
 
 
 # ------------------------------------------------------------------ torch marshalling
@@ -237,10 +262,12 @@ def _img_array(tensors):
 
 def make_filter_args(n, mean, m2, m3, film, mean_corr, disc, film_filtered, g_buffers, g_sds=None,
                      g_dr=None, filter_sd=10.0, radius=20, denoise_film=False, film_buffer=None,
-                     film_filtered_buffer=None, roi=None, stream=None, keep=None, packed=None, film_origin=None):
+                     film_filtered_buffer=None, roi=None, stream=None, keep=None, packed=None, film_origin=None,
+                     packed_g_channels=None):
     """Build a statmc_filter_args from lists of per-buffer device tensors (reference argument
-    order, estimator.cpp:437-459).  Returns (args, keepalive).  packed: optional [H, W, 15]
-    block + halo tensor the window filter reads instead of the separate images."""
+    order, estimator.cpp:437-459).  Returns (args, keepalive).  packed: optional [H, W, 15 | 17]
+    block + halo tensor the window filter reads instead of the separate images (17: packed_g_channels
+    names the channel count of every G-buffer in it, e.g. [3, 3, 1, 1], one g_sds / g_dr entry each)."""
     tables = [mean_corr, mean, film, film_filtered, n]
     nb = max(len(t) for t in tables) if packed is None else 1
     ref = next(t[0] for t in tables if t) if packed is None else packed
@@ -272,12 +299,16 @@ def make_filter_args(n, mean, m2, m3, film, mean_corr, disc, film_filtered, g_bu
         a.g_buffers, a.g_channel_counts, a.g_dr_factors = garr, gch, gdr
     a.n_g_buffers = ng
     if packed is not None:
-        a.packed_inputs = Image(C.c_void_p(packed.data_ptr()), w * 15 * 4, w, h)
+        pch = packed.shape[2]
+        a.packed_inputs = Image(C.c_void_p(packed.data_ptr()), w * pch * 4, w, h)
         if g_dr is None:
             g_dr = [-0.5 / (sd * sd) for sd in g_sds]
-        gdr = (C.c_float * 2)(*g_dr)
-        ka.append(gdr)
-        a.g_dr_factors, a.n_g_buffers = gdr, 2
+        gch_list = list(packed_g_channels) if packed_g_channels is not None else [3] * len(g_dr)
+        assert len(gch_list) == len(g_dr)
+        gdr = (C.c_float * len(g_dr))(*g_dr)
+        gch = (C.c_uint8 * len(g_dr))(*gch_list)
+        ka += [gdr, gch]
+        a.g_dr_factors, a.g_channel_counts, a.n_g_buffers = gdr, gch, len(g_dr)
     a.stream = stream if stream is not None else current_stream_handle()
     if roi is not None:
         a.roi_x0, a.roi_y0, a.roi_x1, a.roi_y1 = roi

@@ -1,6 +1,7 @@
 // statmc_abi.hip -- the extern "C" surface declared in include/statmc.h.
 // Validation + argument marshalling only; kernels live in statmc_pointwise.hip / statmc_filter.hip.
 
+#include <cmath>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -21,10 +22,6 @@ namespace {
 thread_local char g_err[512] = "";
 thread_local const char *g_variant = "none";
 thread_local int g_last_parts = 0;
-std::atomic<int> g_accumulate_resident_blocks{0};
-std::atomic<int> g_tiles_umul{2}, g_tiles_order{0}, g_tiles_wg_per_cu{0};   // tile-fed path: deeper prefetch of the mean-only types by default
-std::atomic<int> g_accumulate_umul{1};
-std::atomic<int> g_accumulate_dma{1};   // RGB sample planes by LDS-DMA (statmc_debug_accumulate_dma(0): loads into registers, A/B)
 std::mutex g_mu;
 
 // Everything the library remembers is kept per device (one Estimator per device in a process that drives
@@ -35,6 +32,12 @@ struct DeviceState {
     int alpha_index = STATMC_PINNED_SIGNIFICANCE;   // include/statmc_pinned_spec.h (tools/pin_from_dumps.sh)
     statmc_filter_spec spec = STATMC_PINNED_SPEC;
     int cus = 0;
+    int split = 0;   // window-sweep parts per tile (statmc_set_filter_split): 0 = automatic
+    // A/B and test switches (include/statmc_debug.h) -- per device like everything else, so that a test that pins one
+    // device's dispatch does not reach a second Estimator on another device
+    int force_variant = 0;                                    // statmc_debug_force_filter_variant
+    int acc_resident_blocks = 0, acc_umul = 1, acc_dma = 1;   // film-major accumulation
+    int tiles_umul = 2, tiles_order = 0, tiles_wg_per_cu = 0; // tile-fed accumulation (deeper prefetch of the mean-only types by default)
 };
 std::unordered_map<int, DeviceState> g_dev;  // guarded by g_mu
 
@@ -152,10 +155,17 @@ void apply_spec(const DeviceState &d, statmc::FilterArgs &k, const statmc_filter
     k.channel_rule = d.spec.channel_rule;
     k.dof = d.spec.dof;
     k.border = d.spec.border;
+    k.force_variant = d.force_variant;
+    k.force_parts = d.split;
     k.n = nullptr;
     k.tq = nullptr;
-    if (d.spec.dof == STATMC_DOF_WELCH)
-        k.tq = statmc::t_table_device_ptr(d.alpha_index + STATMC_TQ_N_ALPHAS * (d.spec.sides ? 1 : 0));
+    k.tq2 = nullptr;
+    if (d.spec.dof == STATMC_DOF_WELCH) {
+        const int table = d.alpha_index + STATMC_TQ_N_ALPHAS * (d.spec.sides ? 1 : 0);
+        k.tq = statmc::t_table_device_ptr(table);
+        const float *sq = statmc::t_table_sq_device_ptr(table);
+        k.tq2 = sq ? sq - 1 : nullptr;   // indexed by dof = 1 .. 4096
+    }
     (void)a;
 }
 // pair-symmetric kernel: tile range, parts and the patch workspace of this launch
@@ -179,7 +189,7 @@ int prepare_sym(const DeviceState &d, statmc::FilterArgs &k, const statmc_filter
     k.sym.fx0 = a->film_x0;
     k.sym.fy0 = a->film_y0;
     k.sym.tab_rt = nullptr;
-    if (k.radius != 20) {
+    if (k.radius != 20 || k.dof == STATMC_DOF_WELCH) {   // (the Welch modes run the runtime-radius build at r = 20 too)
         if (int rc = spatial_table(k.radius, k.ds, &k.sym.tab_rt, true)) return rc;
     }
     k.n_parts = parts_for_whole_image(k, d.cus, true);
@@ -216,6 +226,38 @@ int check_image(const statmc_image &im, int w, int h, int channels, const char *
     return STATMC_OK;
 }
 
+
+// Channels per pixel of a block + halo image: 15 (mean-corr, discriminator, colour, two RGB G-buffers) or 17 (+ two
+// 1-channel G-buffers: depth, material id -- statpath.cpp:828-835); 0 = neither.
+int packed_channels(const statmc_image &im) {
+    if (im.cols <= 0) return 0;
+    if (im.step == (size_t)im.cols * 15 * 4) return 15;
+    if (im.step == (size_t)im.cols * 17 * 4) return 17;
+    return 0;
+}
+// The G-buffers of a call sorted into the slots of the packed image: up to two RGB images (argument order), then up to
+// two 1-channel images (argument order).  15 channels: exactly two RGB images, as the reference's shipped configurations have.
+struct PackedSlots {
+    const float *rgb[2] = {nullptr, nullptr}, *sc[2] = {nullptr, nullptr};
+};
+int packed_slots(const statmc_filter_args *a, int ch, int W, int H, PackedSlots &out) {
+    if (ch == 15) {
+        if (a->n_g_buffers != 2 || !a->g_buffers || (a->g_channel_counts && (a->g_channel_counts[0] != 3 || a->g_channel_counts[1] != 3)))
+            return fail(STATMC_ERR_INVALID, "a 15-channel block + halo image holds exactly two RGB G-buffers");
+    } else if (!a->g_buffers || !a->g_channel_counts || a->n_g_buffers > 4) {
+        return fail(STATMC_ERR_INVALID, "a 17-channel block + halo image holds up to two RGB and two 1-channel G-buffers (g_channel_counts needed)");
+    }
+    int n_rgb = 0, n_sc = 0;
+    for (size_t g = 0; g < a->n_g_buffers; g++) {
+        const int gc = a->g_channel_counts ? a->g_channel_counts[g] : 3;
+        if ((gc != 1 && gc != 3) || (gc == 3 && n_rgb == 2) || (gc == 1 && (n_sc == 2 || ch == 15)))
+            return fail(STATMC_ERR_UNSUPPORTED, "g_buffers[%zu]: %d channels do not fit the %d-channel block + halo image", g, gc, ch);
+        if (int rc = check_image(a->g_buffers[g], W, H, gc, "g_buffers", (int)g)) return rc;
+        (gc == 3 ? out.rgb[n_rgb++] : out.sc[n_sc++]) = static_cast<const float *>(a->g_buffers[g].data);
+    }
+    return STATMC_OK;
+}
+
 #define CHECK_IMG(im, ch, what, idx)                                          \
     do {                                                                      \
         int rc_ = check_image((im), W, H, (ch), (what), (idx));               \
@@ -230,43 +272,6 @@ int check_common(const statmc_filter_args *a, int channels) {
     if (a->n_g_buffers > STATMC_MAX_GBUFFERS)
         return fail(STATMC_ERR_UNSUPPORTED, "n_g_buffers > %d", STATMC_MAX_GBUFFERS);
     return STATMC_OK;
-}
-
-// statmc_upload_by_kernel: 64 workgroups walk the image in 16-byte pieces (host memory mapped into the device's address space)
-// Few, large workgroups: the pulling waves sit on their CUs for the whole transfer, and a CU that holds one of them cannot
-// take a window-filter workgroup (151 KB of LDS, the whole register file).  64 workgroups of 256 threads spread over 64 CUs
-// and cost a concurrent band filter a third round (0.42 -> 0.59 ms: rocprofv3 timeline); kPullGroups workgroups of 1024
-// threads with four 16-byte loads in flight per thread keep the link as busy from kPullGroups CUs.
-constexpr int kPullThreads = 1024, kPullUnroll = 4;
-#ifndef STATMC_PULL_GROUPS
-#define STATMC_PULL_GROUPS 8
-#endif
-constexpr int kPullGroups = STATMC_PULL_GROUPS;
-__device__ __forceinline__ void pull_range(const uint4 *__restrict__ host, uint4 *__restrict__ dev, size_t n16) {
-    const size_t stride = (size_t)gridDim.x * kPullThreads;
-    size_t i = (size_t)blockIdx.x * kPullThreads + threadIdx.x;
-    for (; i + (kPullUnroll - 1) * stride < n16; i += kPullUnroll * stride) {
-        uint4 v[kPullUnroll];
-#pragma unroll
-        for (int u = 0; u < kPullUnroll; u++) v[u] = host[i + u * stride];
-#pragma unroll
-        for (int u = 0; u < kPullUnroll; u++) dev[i + u * stride] = v[u];
-    }
-    for (; i < n16; i += stride) dev[i] = host[i];
-}
-__global__ __launch_bounds__(kPullThreads) void pull_host_kernel(const uint4 *__restrict__ host, uint4 *__restrict__ dev, size_t n16) {
-    pull_range(host, dev, n16);
-}
-
-// statmc_upload_segments_by_kernel: the same for up to 8 images in one launch (a whole transfer of the band pipeline)
-struct PullSegments {
-    const uint4 *src[8];
-    uint4 *dst[8];
-    size_t n16[8];
-    int n;
-};
-__global__ __launch_bounds__(kPullThreads) void pull_segments_kernel(PullSegments p) {
-    for (int s = 0; s < p.n; s++) pull_range(p.src[s], p.dst[s], p.n16[s]);
 }
 
 // one wave: `cycles` shader clocks against the constant-rate clock (statmc_clock_probe)
@@ -375,6 +380,8 @@ int statmc_set_t_quantiles(int table, const float *quantiles, int n_dof) {
         return STATMC_OK;
     }
     if (!quantiles || n_dof < 1 || n_dof > 4096) return fail(STATMC_ERR_INVALID, "need 1..4096 quantiles");
+    for (int i = 0; i < n_dof; i++)
+        if (!(quantiles[i] >= 0.f) || !std::isfinite(quantiles[i])) return fail(STATMC_ERR_INVALID, "quantile %d is not a finite non-negative number", i + 1);
     std::vector<float> t(4096);
     for (int i = 0; i < 4096; i++) t[i] = quantiles[i < n_dof ? i : n_dof - 1];
     HIP_TRY(statmc::upload_t_table(table, t.data()));
@@ -405,6 +412,7 @@ int statmc_copy_device_settings(int src_device, int dst_device) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_dev[dst_device].alpha_index = src.alpha_index;
     g_dev[dst_device].spec = src.spec;
+    g_dev[dst_device].split = src.split;
     return STATMC_OK;
 }
 
@@ -433,59 +441,6 @@ int statmc_memset(void *dev_ptr, int value, size_t bytes, void *stream) {
 int statmc_upload(void *dev_dst, const void *host_src, size_t bytes, void *stream) {
     HIP_TRY(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, S(stream)));
     return STATMC_OK;
-}
-int statmc_upload_by_kernel(void *dev_dst, const void *host_src, size_t bytes, void *stream) {
-    // The second transport of the band pipeline's copies in: a small kernel pulls page-locked host memory over PCIe at the
-    // copy engine's rate (tools/microbench/pcie_read.hip: 57 GB/s from 64 workgroups, and 57 GB/s in total beside a
-    // hipMemcpyAsync), so a transfer dealt over the copy engine AND this kernel keeps the link busy through the ~9.5 us
-    // a queue pays between two copies -- without a second hipMemcpyAsync stream, whose enqueue path occasionally blocks
-    // the host thread for milliseconds.  Memory the device cannot address (pageable, or not 16-byte
-    // aligned) goes through the copy engine.
-    void *mapped = nullptr;
-    const bool aligned = (((uintptr_t)dev_dst | (uintptr_t)host_src) & 15) == 0;
-    if (bytes == 0) return STATMC_OK;
-    if (!aligned || bytes < 4096 || hipHostGetDevicePointer(&mapped, const_cast<void *>(host_src), 0) != hipSuccess || !mapped) {
-        (void)hipGetLastError();
-        HIP_TRY(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, S(stream)));
-        return STATMC_OK;
-    }
-    const size_t n16 = bytes / 16;
-    hipLaunchKernelGGL(pull_host_kernel, dim3(kPullGroups), dim3(kPullThreads), 0, S(stream), static_cast<const uint4 *>(mapped),
-                       static_cast<uint4 *>(dev_dst), n16);
-    HIP_TRY(hipGetLastError());
-    if (bytes & 15)
-        HIP_TRY(hipMemcpyAsync(static_cast<char *>(dev_dst) + n16 * 16, static_cast<const char *>(host_src) + n16 * 16, bytes & 15,
-                               hipMemcpyHostToDevice, S(stream)));
-    return STATMC_OK;
-}
-int statmc_upload_segments_by_kernel(const statmc_copy_segment *segs, int n_segs, void *stream) {
-    if (n_segs < 0 || (n_segs && !segs)) return fail(STATMC_ERR_INVALID, "null segment table");
-    PullSegments p;
-    p.n = 0;
-    auto flush = [&]() -> int {
-        if (p.n == 0) return STATMC_OK;
-        hipLaunchKernelGGL(pull_segments_kernel, dim3(kPullGroups), dim3(kPullThreads), 0, S(stream), p);
-        HIP_TRY(hipGetLastError());
-        p.n = 0;
-        return STATMC_OK;
-    };
-    for (int i = 0; i < n_segs; i++) {
-        const statmc_copy_segment &g = segs[i];
-        if (g.bytes == 0) continue;
-        void *mapped = nullptr;
-        const bool aligned = (((uintptr_t)g.dev_dst | (uintptr_t)g.host_src | g.bytes) & 15) == 0;
-        if (!aligned || hipHostGetDevicePointer(&mapped, const_cast<void *>(g.host_src), 0) != hipSuccess || !mapped) {
-            (void)hipGetLastError();   // memory the device cannot address (or an odd size): the copy engine, in stream order
-            HIP_TRY(hipMemcpyAsync(g.dev_dst, g.host_src, g.bytes, hipMemcpyHostToDevice, S(stream)));
-            continue;
-        }
-        p.src[p.n] = static_cast<const uint4 *>(mapped);
-        p.dst[p.n] = static_cast<uint4 *>(g.dev_dst);
-        p.n16[p.n] = g.bytes / 16;
-        if (++p.n == 8)
-            if (int rc = flush()) return rc;
-    }
-    return flush();
 }
 int statmc_download(void *host_dst, const void *dev_src, size_t bytes, void *stream) {
     HIP_TRY(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, S(stream)));
@@ -621,34 +576,58 @@ static int window_filter_impl(const statmc_filter_args *a, int channels) {
     }
     const bool packed = a->packed_inputs.data != nullptr;
     if (packed) {
-        // block + halo path: everything the window filter reads comes from one 15-channel image
-        if (channels != 3 || a->n_buffers != 1 || a->n_g_buffers != 2 || !a->g_dr_factors)
-            return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs: needs T = float3, n_buffers = 1, two G-buffers");
-        CHECK_IMG(a->packed_inputs, 15, "packed_inputs", 0);
+        // block + halo path: everything the window filter reads comes from one 15- or 17-channel image
+        const int pch = packed_channels(a->packed_inputs);
+        if (channels != 3 || a->n_buffers != 1 || !a->g_dr_factors || pch == 0)
+            return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs: needs T = float3, n_buffers = 1 and a packed 15- or 17-channel image");
+        CHECK_IMG(a->packed_inputs, pch, "packed_inputs", 0);
         if (!a->film_filtered) return fail(STATMC_ERR_INVALID, "null film_filtered table");
         CHECK_IMG(a->film_filtered[0], 3, "film_filtered", 0);
-        for (int g = 0; g < 2; g++) {
-            k.g[g].data = nullptr;
-            k.g[g].channels = 3;
-            k.g[g].dr = a->g_dr_factors[g];
+        if (pch == 15) {
+            if (a->n_g_buffers != 2) return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (15 channels): two RGB G-buffers");
+            for (int g = 0; g < 2; g++) {
+                k.g[g].data = nullptr;
+                k.g[g].channels = 3;
+                k.g[g].dr = a->g_dr_factors[g];
+            }
+        } else {
+            if (a->n_g_buffers > 4 || !a->g_channel_counts)
+                return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (17 channels): up to two RGB and two 1-channel G-buffers, g_channel_counts needed");
+            for (int g = 0; g < k.n_g; g++) {
+                k.g[g].data = nullptr;
+                k.g[g].channels = a->g_channel_counts[g];
+                k.g[g].dr = a->g_dr_factors[g];
+            }
         }
-        if (!statmc::fast_path_eligible(k, 3))
-            return fail(STATMC_ERR_UNSUPPORTED,
-                        "packed_inputs: radius must be 1..20, DR factors finite and <= 0, and the discriminator's degrees "
-                        "of freedom per pixel (STATMC_DOF_PIXEL)");
-        if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
-        k.gscale0 = sqrtf(-k.g[0].dr * 1.44269504088896340736f);
-        k.gscale1 = sqrtf(-k.g[1].dr * 1.44269504088896340736f);
-        // before the kernel is chosen: sym_eligible looks at k.packed (the clamped border's taps beyond the image are read
-        // from the five separate images, which a block + halo call does not have -> one-sided kernel)
         k.packed = static_cast<const float *>(a->packed_inputs.data);
+        k.packed_ch = pch;
         k.out = static_cast<float *>(a->film_filtered[0].data);
-        if (statmc::sym_path_selected(k, 3)) {
+        if (pch == 17) {
+            // eight feature planes: the pair-symmetric kernel only (the one-sided kernel has six feature slots)
+            if (!statmc::sym_eligible(k, 3))
+                return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (17 channels): runs on the pair-symmetric kernel only -- radius 1..20, DR factors "
+                                                    "finite and <= 0, STATMC_DOF_PIXEL, STATMC_BORDER_CLIP, at most two RGB and two 1-channel G-buffers");
+            if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
+            if (!statmc::sym_path_selected(k, 3)) return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (17 channels): the forced kernel variant cannot read them");
+            statmc::sym_feature_slots(k);
             if (int rc = prepare_sym(dstate, k, a)) return rc;
         } else {
-            k.n_parts = parts_for_whole_image(k, dstate.cus, false);
-            if (k.n_parts > 1) {
-                if (int rc = partial_workspace((size_t)k.n_parts * W * H * 4 * sizeof(float), a->stream, &k.partial)) return rc;
+            if (!statmc::fast_path_eligible(k, 3))
+                return fail(STATMC_ERR_UNSUPPORTED,
+                            "packed_inputs: radius must be 1..20, DR factors finite and <= 0, and the discriminator's degrees "
+                            "of freedom per pixel (STATMC_DOF_PIXEL)");
+            if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
+            k.gscale0 = sqrtf(-k.g[0].dr * 1.44269504088896340736f);
+            k.gscale1 = sqrtf(-k.g[1].dr * 1.44269504088896340736f);
+            // (k.packed is set before the kernel is chosen: sym_eligible looks at it -- the clamped border's taps beyond the
+            // image are read from the five separate images, which a block + halo call does not have -> one-sided kernel)
+            if (statmc::sym_path_selected(k, 3)) {
+                if (int rc = prepare_sym(dstate, k, a)) return rc;
+            } else {
+                k.n_parts = parts_for_whole_image(k, dstate.cus, false);
+                if (k.n_parts > 1) {
+                    if (int rc = partial_workspace((size_t)k.n_parts * W * H * 4 * sizeof(float), a->stream, &k.partial)) return rc;
+                }
             }
         }
         const char *variant = "none";
@@ -746,8 +725,9 @@ int statmc_pack_filter_inputs(const statmc_filter_args *a, const statmc_image *p
     NEED_READY();
     if (int rc = check_common(a, 3)) return rc;
     if (!packed || !packed->data) return fail(STATMC_ERR_INVALID, "null packed image");
-    if (a->n_buffers < 1 || a->n_g_buffers != 2 || !a->mean_corr || !a->discriminator || !a->g_buffers)
-        return fail(STATMC_ERR_INVALID, "pack needs buffer 0 and two G-buffers");
+    if (a->n_buffers < 1 || !a->mean_corr || !a->discriminator) return fail(STATMC_ERR_INVALID, "pack needs buffer 0");
+    const int pch = packed_channels(*packed);
+    if (pch == 0) return fail(STATMC_ERR_UNSUPPORTED, "packed image must have packed rows of 15 or 17 channels");
     const int W = a->width, H = a->height;
     const bool film = a->denoise_film != 0;
     if (!film && !a->film) return fail(STATMC_ERR_INVALID, "null film table");
@@ -755,16 +735,14 @@ int statmc_pack_filter_inputs(const statmc_filter_args *a, const statmc_image *p
     CHECK_IMG(a->mean_corr[0], 3, "mean_corr", 0);
     CHECK_IMG(a->discriminator[0], 3, "discriminator", 0);
     CHECK_IMG(colour, 3, "colour", 0);
-    CHECK_IMG(a->g_buffers[0], 3, "g_buffers", 0);
-    CHECK_IMG(a->g_buffers[1], 3, "g_buffers", 1);
+    PackedSlots gs;
+    if (int rc = packed_slots(a, pch, W, H, gs)) return rc;
     if (dst_x0 < 0 || dst_y0 < 0 || dst_x0 + W > packed->cols || dst_y0 + H > packed->rows)
         return fail(STATMC_ERR_INVALID, "block %dx%d at (%d,%d) does not fit the %dx%d packed image", W, H, dst_x0, dst_y0,
                     packed->cols, packed->rows);
-    if (packed->step != (size_t)packed->cols * 15 * 4) return fail(STATMC_ERR_UNSUPPORTED, "packed image must have packed rows");
     statmc::PackArgs k{static_cast<const float *>(a->mean_corr[0].data), static_cast<const float *>(a->discriminator[0].data),
-                       static_cast<const float *>(colour.data), static_cast<const float *>(a->g_buffers[0].data),
-                       static_cast<const float *>(a->g_buffers[1].data), static_cast<float *>(packed->data),
-                       W, H, packed->cols, dst_x0, dst_y0};
+                       static_cast<const float *>(colour.data), gs.rgb[0], gs.rgb[1], static_cast<float *>(packed->data),
+                       W, H, packed->cols, dst_x0, dst_y0, gs.sc[0], gs.sc[1], pch};
     HIP_TRY(statmc::launch_pack_inputs(k, S(a->stream)));
     return STATMC_OK;
 }
@@ -779,8 +757,10 @@ int statmc_prepass_pack_rows(const statmc_filter_args *a, const statmc_image *pa
     NEED_READY();
     if (int rc = check_common(a, 3)) return rc;
     if (!packed || !packed->data) return fail(STATMC_ERR_INVALID, "null packed image");
-    if (a->n_buffers < 1 || a->n_g_buffers != 2 || !a->n || !a->mean || !a->m2 || !a->m3 || !a->g_buffers)
-        return fail(STATMC_ERR_INVALID, "prepass_pack needs buffer 0 (n, mean, m2, m3) and two G-buffers");
+    if (a->n_buffers < 1 || !a->n || !a->mean || !a->m2 || !a->m3)
+        return fail(STATMC_ERR_INVALID, "prepass_pack needs buffer 0 (n, mean, m2, m3)");
+    const int pch = packed_channels(*packed);
+    if (pch == 0) return fail(STATMC_ERR_UNSUPPORTED, "packed image must have packed rows of 15 or 17 channels");
     const int W = a->width, H = a->height;
     const bool film = a->denoise_film != 0;
     if (!film && !a->film) return fail(STATMC_ERR_INVALID, "null film table");
@@ -790,8 +770,8 @@ int statmc_prepass_pack_rows(const statmc_filter_args *a, const statmc_image *pa
     CHECK_IMG(a->m2[0], 3, "m2", 0);
     CHECK_IMG(a->m3[0], 3, "m3", 0);
     CHECK_IMG(colour, 3, "colour", 0);
-    CHECK_IMG(a->g_buffers[0], 3, "g_buffers", 0);
-    CHECK_IMG(a->g_buffers[1], 3, "g_buffers", 1);
+    PackedSlots gs;
+    if (int rc = packed_slots(a, pch, W, H, gs)) return rc;
     float *mc = nullptr, *dc = nullptr;
     if (a->mean_corr && a->discriminator && a->mean_corr[0].data && a->discriminator[0].data) {
         CHECK_IMG(a->mean_corr[0], 3, "mean_corr", 0);
@@ -802,13 +782,12 @@ int statmc_prepass_pack_rows(const statmc_filter_args *a, const statmc_image *pa
     if (dst_x0 < 0 || dst_y0 < 0 || dst_x0 + W > packed->cols || dst_y0 + H > packed->rows)
         return fail(STATMC_ERR_INVALID, "block %dx%d at (%d,%d) does not fit the %dx%d packed image", W, H, dst_x0, dst_y0,
                     packed->cols, packed->rows);
-    if (packed->step != (size_t)packed->cols * 15 * 4) return fail(STATMC_ERR_UNSUPPORTED, "packed image must have packed rows");
     statmc::PrepassPackArgs k{static_cast<const int32_t *>(a->n[0].data), static_cast<const float *>(a->mean[0].data),
                               static_cast<const float *>(a->m2[0].data), static_cast<const float *>(a->m3[0].data),
-                              static_cast<const float *>(colour.data), static_cast<const float *>(a->g_buffers[0].data),
-                              static_cast<const float *>(a->g_buffers[1].data), mc, dc, static_cast<float *>(packed->data),
+                              static_cast<const float *>(colour.data), gs.rgb[0], gs.rgb[1], mc, dc, static_cast<float *>(packed->data),
                               W, H, packed->cols, dst_x0, dst_y0, prepass_table(dstate),
-                              dstate.spec.dof == STATMC_DOF_WELCH, dstate.spec.small_n == STATMC_SMALL_N_EXCLUDE, H, 0};
+                              dstate.spec.dof == STATMC_DOF_WELCH, dstate.spec.small_n == STATMC_SMALL_N_EXCLUDE, H, 0,
+                              gs.sc[0], gs.sc[1], pch};
     if (n_ranges < 0 || n_ranges > 2 || (n_ranges && !ranges)) return fail(STATMC_ERR_INVALID, "0, 1 or 2 row ranges");
     if (n_ranges) {
         const int a0 = ranges[0], a1 = ranges[1], b0 = n_ranges == 2 ? ranges[2] : a1, b1 = n_ranges == 2 ? ranges[3] : a1;
@@ -817,7 +796,11 @@ int statmc_prepass_pack_rows(const statmc_filter_args *a, const statmc_image *pa
         // the launch walks (a1 - a0) + (b1 - b0) rows of images that start at row a0; its rows from a1 - a0 on sit b0 - a1 further down
         const long long px0 = (long long)a0 * W;
         k.n += px0;
-        k.mean += 3 * px0; k.m2 += 3 * px0; k.m3 += 3 * px0; k.colour += 3 * px0; k.g0 += 3 * px0; k.g1 += 3 * px0;
+        k.mean += 3 * px0; k.m2 += 3 * px0; k.m3 += 3 * px0; k.colour += 3 * px0;
+        if (k.g0) k.g0 += 3 * px0;
+        if (k.g1) k.g1 += 3 * px0;
+        if (k.s0) k.s0 += px0;
+        if (k.s1) k.s1 += px0;
         if (k.mean_corr) { k.mean_corr += 3 * px0; k.disc += 3 * px0; }
         k.dst_y0 = dst_y0 + a0;
         k.src_h = (a1 - a0) + (b1 - b0);
@@ -873,12 +856,14 @@ int statmc_halo_exchange(const statmc_block *blocks, int gx, int gy, int block_w
     auto halo = [&](int bx, int by, int &pl, int &pr, int &pt, int &pb) {
         pl = bx > 0 ? r : 0; pr = bx + 1 < gx ? r : 0; pt = by > 0 ? r : 0; pb = by + 1 < gy ? r : 0;
     };
+    const int pch = packed_channels(blocks[0].packed), px_bytes = pch * 4;
     for (int b = 0; b < n; b++) {
         int pl, pr, pt, pb;
         halo(b % gx, b / gx, pl, pr, pt, pb);
         const statmc_image &im = blocks[b].packed;
-        if (!im.data || im.cols != block_w + pl + pr || im.rows != block_h + pt + pb || im.step != (size_t)im.cols * 60)
-            return fail(STATMC_ERR_INVALID, "block %d: packed image is not the %dx%dx15 block + halo image", b, block_w + pl + pr, block_h + pt + pb);
+        if (!im.data || pch == 0 || im.cols != block_w + pl + pr || im.rows != block_h + pt + pb || packed_channels(im) != pch)
+            return fail(STATMC_ERR_INVALID, "block %d: packed image is not the %dx%d block + halo image of 15 or 17 channels (the same for every block)", b,
+                        block_w + pl + pr, block_h + pt + pb);
     }
     int cur = 0;
     HIP_TRY(hipGetDevice(&cur));
@@ -896,7 +881,7 @@ int statmc_halo_exchange(const statmc_block *blocks, int gx, int gy, int block_w
     }
     auto copy = [&](int dst, int dx, int dy, int src, int sx, int sy, int w, int h) {
         if (rc != STATMC_OK) return;
-        rc = statmc_copy_rect(&blocks[dst].packed, blocks[dst].device, dx, dy, &blocks[src].packed, blocks[src].device, sx, sy, w, h, 60,
+        rc = statmc_copy_rect(&blocks[dst].packed, blocks[dst].device, dx, dy, &blocks[src].packed, blocks[src].device, sx, sy, w, h, px_bytes,
                               blocks[dst].stream);
     };
     // phase 1: columns of the owned rows, from the left / right neighbour's interior
@@ -1205,9 +1190,9 @@ int statmc_accumulate_row_ranges(uint16_t width, uint16_t height, const statmc_s
         }
     }
     if (k.n_types == 0) return STATMC_OK;
-    k.resident_blocks = g_accumulate_resident_blocks;
-    k.umul = g_accumulate_umul;
-    k.dma = g_accumulate_dma;
+    k.resident_blocks = dstate.acc_resident_blocks;
+    k.umul = dstate.acc_umul;
+    k.dma = dstate.acc_dma;
     HIP_TRY(statmc::launch_accumulate(k, S(stream)));
     return STATMC_OK;
 }
@@ -1233,10 +1218,10 @@ int statmc_accumulate_tiles(uint16_t width, uint16_t height, const statmc_stat_t
     k.n_tiles = n_tiles;
     k.width = width;
     k.height = height;
-    k.dma = g_accumulate_dma;
-    k.umul = g_tiles_umul;
-    k.order = g_tiles_order;
-    k.wg_per_cu = g_tiles_wg_per_cu;
+    k.dma = dstate.acc_dma;
+    k.umul = dstate.tiles_umul;
+    k.order = dstate.tiles_order;
+    k.wg_per_cu = dstate.tiles_wg_per_cu;
     HIP_TRY(statmc::launch_accumulate_tiles(k, S(stream)));
     return STATMC_OK;
 }
@@ -1289,29 +1274,59 @@ int statmc_clock_probe(int64_t *out, int cycles, void *stream) {
     return STATMC_OK;
 }
 
-// test/bench hooks (not part of the reference surface)
-int statmc_debug_force_filter_variant(int v) {  // 0 auto, 1 generic, 2 runtime-radius LDS
-    statmc::set_filter_variant_override(v);
+// ---- window-sweep split (include/statmc.h): per device, declared
+int statmc_set_filter_split(int parts) {
+    if (parts < 0 || parts > 64) return fail(STATMC_ERR_INVALID, "parts must be 0 (automatic) .. 64");
+    int dev = 0;
+    NEED_READY();
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_dev[dev].split = parts;
     return STATMC_OK;
+}
+int statmc_get_filter_split(void) { return current_state().split; }
+int statmc_filter_split_auto(int width, int height, int radius) {
+    NEED_READY();
+    if (width < 1 || height < 1 || radius < 1 || radius > 20) return fail(STATMC_ERR_INVALID, "need a non-empty image and a radius in 1..20");
+    statmc::FilterArgs k;
+    memset(&k, 0, sizeof(k));
+    k.width = width;
+    k.height = height;
+    k.rx1 = width;
+    k.ry1 = height;
+    k.radius = radius;
+    statmc::sym_geometry(k);
+    return statmc::sym_filter_parts(k, dstate.cus);
+}
+
+// ---- test / A-B switches (include/statmc_debug.h; not part of the reference surface).  Per device: they act on the calling
+// thread's current device, which must have been set up.
+#define STATMC_DEBUG_SET(stmt)                                       \
+    do {                                                             \
+        int dev = 0;                                                 \
+        NEED_READY();                                                \
+        HIP_TRY(hipGetDevice(&dev));                                 \
+        std::lock_guard<std::mutex> lk(g_mu);                        \
+        DeviceState &d = g_dev[dev];                                 \
+        stmt;                                                        \
+        return STATMC_OK;                                            \
+    } while (0)
+int statmc_debug_force_filter_variant(int v) {  // 0 auto, 1 generic, 2 runtime-radius one-sided LDS, 3 one-sided r = 20
+    STATMC_DEBUG_SET(d.force_variant = v);
 }
 int statmc_debug_accumulate_resident_blocks(int n) {  // 0 large grid (default), n > 0: n resident workgroups
-    g_accumulate_resident_blocks = n < 0 ? 0 : n;
-    return STATMC_OK;
+    STATMC_DEBUG_SET(d.acc_resident_blocks = n < 0 ? 0 : n);
 }
 int statmc_debug_accumulate_dma(int on) {   // 1 (default): RGB sample planes stream through LDS-DMA; 0: loads into registers
-    g_accumulate_dma = on ? 1 : 0;
-    return STATMC_OK;
+    STATMC_DEBUG_SET(d.acc_dma = on ? 1 : 0);
 }
 int statmc_debug_accumulate_umul(int umul) {   // film-major kernel: 2 = the mean-only feature types prefetch twice as deep
-    g_accumulate_umul = umul == 2 ? 2 : 1;
-    return STATMC_OK;
+    STATMC_DEBUG_SET(d.acc_umul = umul == 2 ? 2 : 1);
 }
 int statmc_debug_accumulate_tiles_variant(int umul, int order, int wg_per_cu) {  // experiments (time_accumulate_tiles.py)
-    g_tiles_umul = umul == 2 ? 2 : 1;
-    g_tiles_order = order ? 1 : 0;
-    g_tiles_wg_per_cu = wg_per_cu < 0 ? 0 : wg_per_cu;
-    return STATMC_OK;
+    STATMC_DEBUG_SET(d.tiles_umul = umul == 2 ? 2 : 1; d.tiles_order = order ? 1 : 0; d.tiles_wg_per_cu = wg_per_cu < 0 ? 0 : wg_per_cu);
 }
+int statmc_debug_force_filter_parts(int k) { return statmc_set_filter_split(k < 0 ? 0 : k); }   // the older name of the pin
 // non-zero: the library was built with an experiment switch of statmc_sym_experiments.h (never the product build)
 int statmc_debug_diagnostic_build(void) { return statmc::sym_diagnostic_bits() | statmc::acc_diagnostic_bits(); }
 int statmc_debug_last_filter_parts(void) { return g_last_parts; }
@@ -1329,9 +1344,4 @@ int statmc_debug_last_workspace(void **ptr, size_t *bytes) {
         }
     return STATMC_OK;
 }  // parts per tile of this thread's last window filter
-int statmc_debug_force_filter_parts(int k) {  // 0 auto, k >= 1: window-sweep parts per tile
-    statmc::set_filter_parts_override(k);
-    return STATMC_OK;
-}
-
 }  // extern "C"

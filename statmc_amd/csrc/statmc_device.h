@@ -92,8 +92,13 @@ struct FilterArgs {
     float *out;
     // filter spec (statmc_filter_spec): every field but dof = Welch has an LDS kernel (statmc_filter.hip, statmc_filter_sym.hip)
     int gate, channel_rule, dof, border;
+    // dispatch overrides of the device (statmc_abi.hip DeviceState): force_variant 0 auto, 1 generic, 2 lds_rt (one-sided,
+    // runtime radius), 3 lds_r20 (one-sided, compile-time radius 20); force_parts 0 automatic, k >= 1: window-sweep parts
+    // per tile (statmc_set_filter_split)
+    int force_variant, force_parts;
     const int32_t *n;            // Welch mode: sample counts
     const float *tq;             // Welch mode: this device's quantile table (4096 entries)
+    const float *tq2;            // ... and its squares, BIASED BY ONE ENTRY: tq2[dof] = fl(t_dof * t_dof), dof = 1 .. 4096 (pair-symmetric kernel)
     int width, height;           // local image
     int rx0, ry0, rx1, ry1;      // output ROI
     int rx_split, n_main_items;  // LDS kernel: regular tiles cover [rx0, rx_split), DUAL tiles [rx_split, rx1)
@@ -120,7 +125,8 @@ struct FilterArgs {
     const float *f_mean_corr[3], *f_disc[3], *f_colour[3];
     float *f_out[3];
     int f_active;
-    const float *packed;         // optional [height][width][15] inputs: mc, disc, colour, g0, g1 (RGB each)
+    const float *packed;         // optional [height][width][packed_ch] inputs: mc, disc, colour, g0, g1 (RGB each)[, s0, s1]
+    int packed_ch;               // 15, or 17 (+ two 1-channel G-buffers: the eight-plane build of the pair-symmetric kernel)
     // pair-symmetric kernel (statmc_filter_sym.hip): tiles of 128 x 8 pixels on a grid fixed in film coordinates
     struct SymGeom {
         int tx0, ty0, ntx, nty;   // tile range of the launch (film tile indices)
@@ -141,9 +147,11 @@ struct FilterArgs {
 };
 
 struct PackArgs {
-    const float *mean_corr, *disc, *colour, *g0, *g1;  // [src_h][src_w][3]
-    float *packed;                                      // [dst_h][dst_w][15]
+    const float *mean_corr, *disc, *colour, *g0, *g1;  // [src_h][src_w][3]  (an absent G-buffer: nullptr, packed as zeros)
+    float *packed;                                      // [dst_h][dst_w][ch]
     int src_w, src_h, dst_w, dst_x0, dst_y0;
+    const float *s0, *s1;                               // ch = 17: the two 1-channel G-buffers [src_h][src_w] (nullptr: zeros)
+    int ch;                                             // 15 | 17
 };
 hipError_t launch_pack_inputs(const PackArgs &a, hipStream_t s);
 
@@ -153,15 +161,18 @@ struct PrepassPackArgs {
     const int32_t *n;
     const float *mean, *m2, *m3, *colour, *g0, *g1;
     float *mean_corr, *disc;   // optional
-    float *packed;             // [dst_h][dst_w][15]
+    float *packed;             // [dst_h][dst_w][ch]
     int src_w, src_h, dst_w, dst_x0, dst_y0, table, welch, small_n_exclude;
     int split_row, skip_rows;   // rows >= split_row of the launch's src_h rows sit skip_rows further down in every image (two row ranges in one launch)
+    const float *s0, *s1;       // ch = 17: the two 1-channel G-buffers (nullptr: zeros); g0 / g1 may be nullptr as well then
+    int ch;                     // 15 | 17
 };
 hipError_t launch_prepass_pack(const PrepassPackArgs &a, hipStream_t s);
 
 hipError_t upload_t_tables();
 hipError_t upload_t_table(int table, const float *host_4096);
 const float *t_table_device_ptr(int table);  // current device's copy of quantile table `table`
+const float *t_table_sq_device_ptr(int table);  // ... of its squares (fl(t * t), what the Welch pair test multiplies with)
 hipError_t launch_prepass(const PrepassArgs &a, hipStream_t s);
 hipError_t launch_mean_vars(const MeanVarsArgs &a, hipStream_t s);
 hipError_t launch_accumulate(const AccumulateArgs &a, hipStream_t s);
@@ -182,9 +193,6 @@ bool fast_path_eligible(const FilterArgs &a, int channels);
 void set_feature_layout(FilterArgs &a);   // gscale0/1, feat[] of an eligible G-buffer set
 bool lds_path_selected(const FilterArgs &a, int channels);
 
-// force a variant for tests/benchmarks: 0 = auto, 1 = generic, 2 = lds_rt (one-sided, runtime radius),
-// 3 = lds_r20 (one-sided, compile-time radius 20; the kernel the pair-symmetric one replaced)
-void set_filter_variant_override(int v);
 // pair-symmetric kernel
 bool sym_eligible(const FilterArgs &a, int channels);
 void sym_feature_slots(FilterArgs &a);                       // fills a.sym.g8 / rgb / sc from a.g[] (eligible sets only)
@@ -199,9 +207,7 @@ int sym_diagnostic_bits();   // non-zero: built with a STATMC_SYM_* experiment s
 int acc_diagnostic_bits();   // non-zero: the accumulation was built with a timing-only switch (STATMC_ACC_SKIP_STORES: bit 7)
 hipError_t launch_border_virtual(const FilterArgs &a, hipStream_t s);   // the clamped border's taps beyond the image (RGB)
 int choose_parts(int tiles, int n_rows, int n_cus);
-int filter_parts_override();
 // parts per tile the LDS kernel would use for this ROI on a device with n_cus compute units
 int lds_filter_parts(const FilterArgs &a, int n_cus);
-void set_filter_parts_override(int k);  // 0 = automatic
 
 }  // namespace statmc

@@ -59,8 +59,8 @@
 
 namespace statmc {
 
-static std::atomic<int> g_variant_override{0};
-void set_filter_variant_override(int v) { g_variant_override = v; }
+// (dispatch overrides -- forced kernel variant, pinned window-sweep split -- are per-device state of the C-ABI layer
+// and reach this file in FilterArgs::force_variant / force_parts)
 
 
 // ====================================================================== generic kernel
@@ -324,7 +324,7 @@ void fill_spatial_table(float *tab, int radius, float ds) {
 
 // The pair-symmetric kernel's runtime-radius build keeps the r = 20 staging geometry: tab[dy][dx + 23] for dy = 0 .. r,
 // 47 entries per row, -inf for |dx| > r (those taps get weight 0).
-size_t sym_rt_table_floats(int radius) { return radius < 1 || radius >= kMaxR ? 0 : (size_t)(radius + 1) * tab_width(kMaxR); }
+size_t sym_rt_table_floats(int radius) { return radius < 1 || radius > kMaxR ? 0 : (size_t)(radius + 1) * tab_width(kMaxR); }
 void fill_sym_rt_table(float *tab, int radius, float ds) {
     const int tw = tab_width(kMaxR);
     for (int dy = 0; dy <= radius; dy++)
@@ -749,12 +749,17 @@ __global__ __launch_bounds__(256) void pack_inputs_kernel(PackArgs a) {
     const long long n = (long long)a.src_w * a.src_h;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int y = (int)(i / a.src_w), x = (int)(i - (long long)y * a.src_w);
-        f3 *dst = reinterpret_cast<f3 *>(a.packed + ((long long)(y + a.dst_y0) * a.dst_w + (x + a.dst_x0)) * 15);
+        float *px = a.packed + ((long long)(y + a.dst_y0) * a.dst_w + (x + a.dst_x0)) * a.ch;
+        f3 *dst = reinterpret_cast<f3 *>(px);
         dst[0] = reinterpret_cast<const f3 *>(a.mean_corr)[i];
         dst[1] = reinterpret_cast<const f3 *>(a.disc)[i];
         dst[2] = reinterpret_cast<const f3 *>(a.colour)[i];
-        dst[3] = reinterpret_cast<const f3 *>(a.g0)[i];
-        dst[4] = reinterpret_cast<const f3 *>(a.g1)[i];
+        dst[3] = a.g0 ? reinterpret_cast<const f3 *>(a.g0)[i] : f3{0.f, 0.f, 0.f};
+        dst[4] = a.g1 ? reinterpret_cast<const f3 *>(a.g1)[i] : f3{0.f, 0.f, 0.f};
+        if (a.ch == 17) {
+            px[15] = a.s0 ? a.s0[i] : 0.f;
+            px[16] = a.s1 ? a.s1[i] : 0.f;
+        }
     }
 }
 
@@ -826,15 +831,11 @@ int choose_parts(int tiles, int n_rows, int n_cus) {
     return best;
 }
 
-static std::atomic<int> g_parts_override{0};
-void set_filter_parts_override(int k) { g_parts_override = k; }
-int filter_parts_override() { return g_parts_override; }
-
 bool sym_path_selected(const FilterArgs &a, int channels) {
-    return sym_eligible(a, channels) && a.spatial_tab != nullptr && g_variant_override == 0;
+    return sym_eligible(a, channels) && a.spatial_tab != nullptr && a.force_variant == 0;
 }
 int sym_filter_parts(const FilterArgs &a, int n_cus) {
-    const int forced = g_parts_override;
+    const int forced = a.force_parts;
     if (forced > 0) return forced < a.radius + 1 ? forced : a.radius + 1;
     return sym_choose_parts(sym_tiles(a), n_cus, a.radius + 1);
 }
@@ -893,7 +894,7 @@ static hipError_t launch_lds(FilterArgs a, hipStream_t s) {
 }
 
 int lds_filter_parts(const FilterArgs &a, int n_cus) {
-    const int forced = g_parts_override;
+    const int forced = a.force_parts;
     if (forced > 0) return forced < 2 * a.radius + 1 ? forced : 2 * a.radius + 1;
     return choose_parts(lds_tiles(a), 2 * a.radius + 1, n_cus);
 }
@@ -901,15 +902,16 @@ int lds_filter_parts(const FilterArgs &a, int n_cus) {
 // True when launch_window_filter will run the LDS kernel for these arguments (the C-ABI layer
 // groups float buffers three per launch only then).
 bool lds_path_selected(const FilterArgs &a, int channels) {
-    return fast_path_eligible(a, channels) && a.spatial_tab != nullptr && g_variant_override != 1;
+    return fast_path_eligible(a, channels) && a.spatial_tab != nullptr && a.force_variant != 1;
 }
 
 // "sym_r20|sym_rt[_f][_g8][_asym][_joint][_clamp]": compile-time / runtime radius, float buffers, eight feature planes, then the spec's non-default choices
 static const char *sym_variant_name(const FilterArgs &a, int channels) {
     static thread_local char name[64];
     const bool joint = a.channel_rule == STATMC_CHANNELS_JOINT && channels == 3;
-    snprintf(name, sizeof(name), "%s%s%s%s%s%s", a.radius == 20 ? "sym_r20" : "sym_rt", channels == 1 ? "_f" : "", a.sym.g8 ? "_g8" : "",
-             a.gate == STATMC_GATE_ASYMMETRIC ? "_asym" : "", joint ? "_joint" : "", a.border == STATMC_BORDER_CLAMP ? "_clamp" : "");
+    const bool welch = a.dof == STATMC_DOF_WELCH;   // (one build for every radius; the gate field has no meaning under Welch)
+    snprintf(name, sizeof(name), "%s%s%s%s%s%s", welch ? "sym_welch" : a.radius == 20 ? "sym_r20" : "sym_rt", channels == 1 ? "_f" : "", a.sym.g8 ? "_g8" : "",
+             a.gate == STATMC_GATE_ASYMMETRIC && !welch ? "_asym" : "", joint ? "_joint" : "", a.border == STATMC_BORDER_CLAMP ? "_clamp" : "");
     return name;
 }
 
@@ -924,7 +926,7 @@ static hipError_t launch_lds_spec(const FilterArgs &a, hipStream_t s, const char
     constexpr bool rgb = K == 0;
     switch (lds_spec_of(a, rgb)) {
     case 0:
-        if (a.radius == 20 && g_variant_override != 2) {
+        if (a.radius == 20 && a.force_variant != 2) {
             *variant = rgb ? "lds_r20" : "lds_r20_f";
             return launch_lds<20, K>(a, s);
         }

@@ -51,6 +51,7 @@
 #include <cmath>
 #include <mutex>
 #include <set>
+#include <type_traits>
 #include <utility>
 
 #include "statmc_device.h"
@@ -76,6 +77,13 @@ constexpr int kModeRgb = 0, kModePair = 1, kModeJoint = 2, kModeAsym = 3, kModeA
 // sums, fma(d, d, -D_p) <= D_q whether p enters q's -- so the pair carries two weights.
 constexpr int kModes = 5;
 constexpr bool mode_asym(int m) { return m == kModeAsym || m == kModeAsymJoint; }
+// Welch-Satterthwaite degrees of freedom (STATMC_DOF_WELCH), channels one by one / pooled: the discriminator image holds
+// v = s^2 / n, a fourth statistics image E = v^2 / (n - 1) is staged with it, and the pair looks its squared quantile up
+// at floor(nu), nu = (v_p + v_q)^2 / (E_p + E_q) -- symmetric in (p, q) like everything else the pair needs, so the pair
+// is still evaluated once.  These two modes exist in ONE build (register staging, six feature planes, runtime radius):
+// 18 input + 8 accumulator planes leave no room for the LDS-DMA landing area.
+constexpr int kModeWelch = 5, kModeWelchJoint = 6;
+constexpr bool mode_welch(int m) { return m == kModeWelch || m == kModeWelchJoint; }
 constexpr int kR = 20;
 constexpr int kPx = 4;                    // pixels per lane
 constexpr int kW = 32 * kPx;              // 128 tile columns: half a wave per row
@@ -102,16 +110,16 @@ __host__ __device__ inline int wave_cols(int wave) { return wave < 2 ? 44 : wave
 // two 1-channel G-buffers (depth, material id: statpath.cpp:828-835, 1096-1130) -- 17 input + 8 accumulator planes per
 // row: 9 x 25 x 168 floats = 151 200 B of ring, and the LDS-DMA landing area shrinks to exactly the 168 columns a row
 // has (wave w's columns at wave_col0(w) x 17 floats) so that the lot still fits the CU's 160 KiB: 163 392 B.
-template <int NG>
+template <int NG, bool W = false>
 struct Planes {
-    static constexpr int kIn = NG + 9;                       // input planes per row: features, mean, -D, colour
-    static constexpr int cMC = NG, cND = NG + 3, cCOL = NG + 6;
+    static constexpr int kIn = NG + 9 + (W ? 3 : 0);         // input planes per row: features, mean, -D, colour[, E (Welch)]
+    static constexpr int cMC = NG, cND = NG + 3, cCOL = NG + 6, cE = NG + 9;
     static constexpr int kSlotFloats = (kIn + kQ) * kP;
-    static constexpr int kRawTotal = NG == 6 ? 4 * kWaveCols * 15 : kP * kIn;
+    static constexpr int kRawTotal = W ? 0 : NG == 6 ? 4 * kWaveCols * 15 : kP * kIn;
     static constexpr size_t kLdsBytes = (size_t)(kSlots * kSlotFloats + 2 * kTabPad + kRawTotal) * sizeof(float);
-    __host__ __device__ static inline int raw_off(int wave) { return NG == 6 ? (wave & 3) * kWaveCols * 15 : wave_col0(wave & 3) * kIn; }
+    __host__ __device__ static inline int raw_off(int wave) { return W ? 0 : NG == 6 ? (wave & 3) * kWaveCols * 15 : wave_col0(wave & 3) * kIn; }
 };
-static_assert(Planes<6>::kLdsBytes <= 160 * 1024 && Planes<8>::kLdsBytes <= 160 * 1024, "LDS budget");
+static_assert(Planes<6>::kLdsBytes <= 160 * 1024 && Planes<8>::kLdsBytes <= 160 * 1024 && Planes<6, true>::kLdsBytes <= 160 * 1024, "LDS budget");
 
 // steps = window rows dy = 0 .. r a tile sweeps: kSteps in the r = 20 builds, radius + 1 in the runtime-radius ones
 __host__ __device__ inline int step_lo(int part, int n_parts, int steps) { return (steps * part) / n_parts; }
@@ -120,8 +128,10 @@ __host__ __device__ inline int q_rows_max(int n_parts, int steps) { return (step
 // The lane's own 4 pixels.  Their values enter the packed instructions as broadcasts of ONE half of a register
 // pair (op_sel), so two different scalars share every pair: 6 + 6 + 4 pairs per pixel instead of 15 + 15
 // registers holding (x, x) duplicates -- which is what a `v2f{x, x}` splat of a scalar compiles to.
-template <int NG>
-struct Lane {
+struct LaneWelch { v2f pe[kPx][2]; };   // Welch: (E_r, E_g), (E_b, -) of the lane's pixels
+struct LaneNoWelch {};
+template <int NG, bool W = false>
+struct Lane : std::conditional<W, LaneWelch, LaneNoWelch>::type {
     v2f pg[kPx][NG / 2];   // scaled features: (n.x, n.y), (n.z, a.x), (a.y, a.z)[, (depth, material id)]
     v2f ms[kPx][3];    // per channel (corrected mean, discriminator)
     v2f pc[kPx][2];    // colour (r, g), (b, -)
@@ -146,6 +156,12 @@ __device__ __forceinline__ v2f rsub_bc(const v2f &t, const v2f &pair, int half) 
     else asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(t), "v"(pair));
     return d;
 }
+__device__ __forceinline__ v2f add_bc(const v2f &pair, int half, const v2f &t) {   // bc(pair.half) + t
+    v2f d;
+    if (half) asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(d) : "v"(pair), "v"(t));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "v"(pair), "v"(t));
+    return d;
+}
 __device__ __forceinline__ v2f fma_bc(const v2f &w, const v2f &pair, int half, const v2f &acc) {  // w * bc(pair.half) + acc
     v2f d;
     if (half) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(d) : "v"(w), "v"(pair), "v"(acc));
@@ -153,6 +169,11 @@ __device__ __forceinline__ v2f fma_bc(const v2f &w, const v2f &pair, int half, c
     return d;
 }
 
+__device__ __forceinline__ int cvt_i32(float x) {   // truncation; NaN -> 0, out of range saturates (the hardware's rule)
+    int i;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(i) : "v"(x));
+    return i;
+}
 __device__ __forceinline__ v2f fma_sq_nbc(const v2f &d, const v2f &pair) {  // d * d - bc(pair.y)
     v2f r;
     asm("v_pk_fma_f32 %0, %1, %1, %2 op_sel:[0,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(d), "v"(pair));
@@ -189,8 +210,8 @@ __device__ __forceinline__ v2f pair_of(const v4f &v) {
 }
 
 // range weight exponent of tap pair H against the lane's 4 pixels: tab - |k_n dn|^2 - |k_a da|^2 (log2 domain)
-template <int H, unsigned MASK, int NG>
-__device__ __forceinline__ void range_exponent(const Lane<NG> &st, const v4f *g, const float *__restrict__ tab, int j, v2f (&e)[kPx]) {
+template <int H, unsigned MASK, int NG, class LaneT>
+__device__ __forceinline__ void range_exponent(const LaneT &st, const v4f *g, const float *__restrict__ tab, int j, v2f (&e)[kPx]) {
     using M = Taps<H, MASK>;
     v2f tp[kPx];
 #pragma unroll
@@ -211,11 +232,52 @@ __device__ __forceinline__ void range_exponent(const Lane<NG> &st, const v4f *g,
 // membership gate and weight of tap pair H: w = member ? exp2(e) : 0   (mcn: corrected mean planes 0..2, -D planes 3..5)
 // PAIR (two float buffers in the (x, y) channels): one weight per buffer, w for buffer 0 and wb for buffer 1 -- the
 // buffers share the range weight and gate separately (filter<float>: every buffer is its own 1-channel test).
-template <int H, unsigned MASK, int MODE, int NG>
-__device__ __forceinline__ void gate_weight(const Lane<NG> &st, const v4f *mcn, const v2f (&e)[kPx], v2f (&w)[kPx], v2f (&wb)[kPx]) {
+// Welch (en: the three E planes; tq2: the device's table of SQUARED quantiles, indexed by dof): per channel
+//     nu = s^2 / (E_p + E_q),  s = v_p + v_q;   dof = nu >= 1 ? min((int)nu, 4096) : 1;   u = fma(d, d, -(t_dof^2 * s))
+// The quotient is a reciprocal with one residual correction (correctly rounded except in rare last-bit cases, which
+// can move a pair whose nu lies within an ulp of an integer to the neighbouring table entry); when the correction is
+// NaN -- E_p + E_q underflowed to 0 or both variances are infinite -- the plain product stands, which has the oracle's
+// value there (inf, NaN).  A NaN becomes dof 1 in the integer clamp, exactly the oracle's `nu >= 1.f` branch.
+template <int H, unsigned MASK, int MODE, int NG, class LaneT>
+__device__ __forceinline__ void gate_weight(const LaneT &st, const v4f *mcn, const v4f *en, const float *__restrict__ tq2,
+                                            const v2f (&e)[kPx], v2f (&w)[kPx], v2f (&wb)[kPx]) {
     using M = Taps<H, MASK>;
     constexpr bool PAIR = MODE == kModePair;
     constexpr int NC = PAIR ? 2 : 3;
+    if constexpr (mode_welch(MODE)) {
+        // one pixel at a time: three independent chains of ~20 instructions each, and the fewest live registers
+#pragma unroll
+        for (int k = 0; k < kPx; k++) if (M::on(k)) {
+            v2f u[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const v2f d = sub_bc(st.ms[k][ch], 0, pair_of<H>(mcn[ch]));
+                const v2f sn = rsub_bc(pair_of<H>(mcn[3 + ch]), st.ms[k][ch], 1);      // -(v_p + v_q)
+                const v2f den = add_bc(st.pe[k][ch >> 1], ch & 1, pair_of<H>(en[ch]));   // E_p + E_q
+                const v2f s2 = sn * sn;
+                const v2f r = v2f{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                const v2f q0 = s2 * r;
+                const v2f er = __builtin_elementwise_fma(-q0, den, s2);
+                const v2f q1 = __builtin_elementwise_fma(er, r, q0);
+                const float nx = q1.x == q1.x ? q1.x : q0.x, ny = q1.y == q1.y ? q1.y : q0.y;
+                // v_cvt_i32_f32 of a NaN is 0, of +inf INT_MAX (spelled out: the C++ conversion of such a value is undefined);
+                // the integer clamp (v_med3_i32) turns them into dof 1 and 4096
+                const int ix = min(max(cvt_i32(nx), 1), 4096), iy = min(max(cvt_i32(ny), 1), 4096);
+                const v2f t2 = v2f{tq2[ix], tq2[iy]};
+                u[ch] = __builtin_elementwise_fma(d, d, t2 * sn);
+            }
+            w[k] = v2f{__builtin_amdgcn_exp2f(e[k].x), __builtin_amdgcn_exp2f(e[k].y)};
+            if constexpr (MODE == kModeWelchJoint) {
+                const v2f m = (u[0] + u[1]) + u[2];
+                w[k] = v2f{M::in0(k) && m.x <= 0.f ? w[k].x : 0.f, M::in1(k) && m.y <= 0.f ? w[k].y : 0.f};
+            } else {
+                const float m0 = __builtin_fmaxf(__builtin_fmaxf(u[0].x, u[1].x), u[2].x);
+                const float m1 = __builtin_fmaxf(__builtin_fmaxf(u[0].y, u[1].y), u[2].y);
+                w[k] = v2f{M::in0(k) && m0 <= 0.f ? w[k].x : 0.f, M::in1(k) && m1 <= 0.f ? w[k].y : 0.f};
+            }
+        }
+        return;
+    }
     if constexpr (mode_asym(MODE)) {
         // one-sided gate: w decides q's membership in p's window (p side), wb p's membership in q's (q side); plain
         // compares, as the oracle writes them (a NaN statistic fails every one)
@@ -300,8 +362,8 @@ __device__ __forceinline__ void gate_weight(const Lane<NG> &st, const v4f *mcn, 
 // p side: the lane's pixels collect w * colour_q; q side (SYM): the taps' accumulators collect w * colour_p.
 // PAIR: the four sums per pixel are (sum w0 c0, sum w1 c1, sum w0, sum w1) -- acc[0], acc[1], acc[2], sw -- instead of
 // (sum w r, sum w g, sum w b, sum w); the same four packed operations per side.
-template <int H, unsigned MASK, bool SYM, int MODE, int NG>
-__device__ __forceinline__ void accumulate(Lane<NG> &st, const v4f *col, const v2f (&w)[kPx], const v2f (&wb)[kPx], v2f (&qv)[4]) {
+template <int H, unsigned MASK, bool SYM, int MODE, int NG, class LaneT>
+__device__ __forceinline__ void accumulate(LaneT &st, const v4f *col, const v2f (&w)[kPx], const v2f (&wb)[kPx], v2f (&qv)[4]) {
     using M = Taps<H, MASK>;
     constexpr bool PAIR = MODE == kModePair;
     if constexpr (PAIR) {
@@ -373,14 +435,17 @@ __device__ __forceinline__ void lds_wait(v4f &a, v4f &b, v4f &c, v4f &d) {
 // planes of the taps).  PIPE: the statistics planes are requested before the feature planes and the colour /
 // accumulator planes before the gates, by hand-placed reads, so that two of the three phases find their operands
 // in registers; otherwise the compiler's own loads (each phase waits for its operands).
-template <unsigned MASK, bool SYM, bool PIPE, int MODE, int NG>
-__device__ __forceinline__ void chunk(Lane<NG> &st, const float *__restrict__ row, const float *__restrict__ tab, float *__restrict__ qrow, int j) {
+template <unsigned MASK, bool SYM, bool PIPE, int MODE, int NG, class LaneT>
+__device__ __forceinline__ void chunk(LaneT &st, const float *__restrict__ row, const float *__restrict__ tab, float *__restrict__ qrow, int j,
+                                      const float *__restrict__ tq2) {
     using M0 = Taps<0, MASK>;
     using M1 = Taps<1, MASK>;
     constexpr bool PAIR = MODE == kModePair;
-    constexpr int C_MC = Planes<NG>::cMC, C_COL = Planes<NG>::cCOL;
+    constexpr bool W = mode_welch(MODE);
+    static_assert(!(W && PIPE), "the Welch modes use the compiler-placed reads");
+    constexpr int C_MC = Planes<NG, W>::cMC, C_COL = Planes<NG, W>::cCOL;
     const float *r = row + 4 * j;
-    v4f g[NG], mcn[6], col[3], q4[4];
+    v4f g[NG], mcn[6], col[3], q4[4], en[3];
     v2f e0[kPx], e1[kPx], w0[kPx], w1[kPx], wb0[kPx], wb1[kPx];   // wb*: second buffer's weights (PAIR)
     unsigned ra = 0, qa = 0;
     if constexpr ((kAblate & 32) != 0) {   // timing only: operands from nowhere (no LDS reads in the sweep)
@@ -394,8 +459,10 @@ __device__ __forceinline__ void chunk(Lane<NG> &st, const float *__restrict__ ro
         for (int v = 0; v < 4; v++) asm volatile("" : "=v"(q4[v]));
         if constexpr (M0::any()) range_exponent<0, MASK, NG>(st, g, tab, j, e0);
         if constexpr (M1::any()) range_exponent<1, MASK, NG>(st, g, tab, j, e1);
-        if constexpr (M0::any()) gate_weight<0, MASK, MODE, NG>(st, mcn, e0, w0, wb0);
-        if constexpr (M1::any()) gate_weight<1, MASK, MODE, NG>(st, mcn, e1, w1, wb1);
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) asm volatile("" : "=v"(en[ch]));
+        if constexpr (M0::any()) gate_weight<0, MASK, MODE, NG>(st, mcn, en, tq2, e0, w0, wb0);
+        if constexpr (M1::any()) gate_weight<1, MASK, MODE, NG>(st, mcn, en, tq2, e1, w1, wb1);
         v2f qa2[4], qb2[4];
 #pragma unroll
         for (int v = 0; v < 4; v++) { qa2[v] = pair_of<0>(q4[v]); qb2[v] = pair_of<1>(q4[v]); }
@@ -439,9 +506,13 @@ __device__ __forceinline__ void chunk(Lane<NG> &st, const float *__restrict__ ro
 #pragma unroll
         for (int ch = 0; ch < 6; ch++)
             if (!(PAIR && ch % 3 == 2)) mcn[ch] = *reinterpret_cast<const v4f *>(r + (C_MC + ch) * kP);
+        if constexpr (W) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) en[ch] = *reinterpret_cast<const v4f *>(r + (Planes<NG, W>::cE + ch) * kP);
+        }
     }
-    if constexpr (M0::any()) gate_weight<0, MASK, MODE, NG>(st, mcn, e0, w0, wb0);
-    if constexpr (M1::any()) gate_weight<1, MASK, MODE, NG>(st, mcn, e1, w1, wb1);
+    if constexpr (M0::any()) gate_weight<0, MASK, MODE, NG>(st, mcn, en, tq2, e0, w0, wb0);
+    if constexpr (M1::any()) gate_weight<1, MASK, MODE, NG>(st, mcn, en, tq2, e1, w1, wb1);
 #if STATMC_SYM_COUNT
     if constexpr (MASK == 0xFFFFu && SYM && MODE == kModeRgb) {   // full read groups of the default mode
         bool any0 = false, any1 = false;
@@ -512,21 +583,21 @@ struct Range {
     static constexpr int last_full() { for (int j = kChunks - 1; j >= 0; j--) if (m(j) == kFull) return j; return -1; }
 };
 
-template <int LO, int HI, bool SYM, int MODE, int NG>
-__device__ __forceinline__ void sweep_range(Lane<NG> &st, const float *row, const float *tab, float *qrow) {
+template <int LO, int HI, bool SYM, int MODE, int NG, class LaneT>
+__device__ __forceinline__ void sweep_range(LaneT &st, const float *row, const float *tab, float *qrow, const float *tq2) {
     using R = Range<LO, HI>;
     constexpr int j0 = R::first(), j1 = R::last(), f0 = R::first_full(), f1 = R::last_full();
     static_assert(j0 <= j1, "empty range");
     constexpr bool has_full = f0 <= f1;
     constexpr int lo_end = has_full ? f0 : j1 + 1;      // masked groups j0 .. lo_end-1, full f0 .. f1, masked f1+1 .. j1
     static_assert(lo_end - j0 <= 2 && (!has_full || j1 - f1 <= 2), "more than two cut groups at an end");
-    if constexpr (j0 < lo_end) chunk<R::m(j0), SYM, kPipe, MODE, NG>(st, row, tab, qrow, j0);
-    if constexpr (j0 + 1 < lo_end) chunk<R::m(j0 + 1), SYM, kPipe, MODE, NG>(st, row, tab, qrow, j0 + 1);
+    if constexpr (j0 < lo_end) chunk<R::m(j0), SYM, kPipe && !mode_welch(MODE), MODE, NG>(st, row, tab, qrow, j0, tq2);
+    if constexpr (j0 + 1 < lo_end) chunk<R::m(j0 + 1), SYM, kPipe && !mode_welch(MODE), MODE, NG>(st, row, tab, qrow, j0 + 1, tq2);
     if constexpr (has_full) {
 #pragma unroll 1
-        for (int j = f0; j <= f1; j++) chunk<R::kFull, SYM, kPipe, MODE, NG>(st, row, tab, qrow, j);
-        if constexpr (f1 + 1 <= j1) chunk<R::m(f1 + 1 <= j1 ? f1 + 1 : 0), SYM, kPipe, MODE, NG>(st, row, tab, qrow, f1 + 1);
-        if constexpr (f1 + 2 <= j1) chunk<R::m(f1 + 2 <= j1 ? f1 + 2 : 0), SYM, kPipe, MODE, NG>(st, row, tab, qrow, f1 + 2);
+        for (int j = f0; j <= f1; j++) chunk<R::kFull, SYM, kPipe && !mode_welch(MODE), MODE, NG>(st, row, tab, qrow, j, tq2);
+        if constexpr (f1 + 1 <= j1) chunk<R::m(f1 + 1 <= j1 ? f1 + 1 : 0), SYM, kPipe && !mode_welch(MODE), MODE, NG>(st, row, tab, qrow, f1 + 1, tq2);
+        if constexpr (f1 + 2 <= j1) chunk<R::m(f1 + 2 <= j1 ? f1 + 2 : 0), SYM, kPipe && !mode_welch(MODE), MODE, NG>(st, row, tab, qrow, f1 + 2, tq2);
     }
 }
 
@@ -542,38 +613,39 @@ __device__ __forceinline__ void sweep_range(Lane<NG> &st, const float *row, cons
 // read groups a half sweeps are groups [j_lo, 4] + the cut group 5 (half 0) and the cut group 5 + groups [6, j_hi] (half 1),
 // where j_lo / j_hi are the outermost groups that hold a tap with |dx| <= r; taps of those groups beyond r carry a
 // spatial exponent of -inf in the table (weight 0).
-template <int HF, int MODE, int NG, bool RT>
-__device__ __forceinline__ void eval_half_row(Lane<NG> &st, const float *row, const float *tab, float *qrow, bool dy0, int j_lo, int j_hi) {
+template <int HF, int MODE, int NG, bool RT, class LaneT>
+__device__ __forceinline__ void eval_half_row(LaneT &st, const float *row, const float *tab, float *qrow, bool dy0, int j_lo, int j_hi, const float *tq2) {
+    constexpr bool kPipe = sym::kPipe && !mode_welch(MODE);
     if constexpr (RT) {
         static_assert(kSplit == 0, "the runtime-radius build splits the window in the middle");
         if constexpr (HF == 0) {
             if (dy0) {
-                sweep_range<0, 0, false, MODE, NG>(st, row, tab, qrow);
+                sweep_range<0, 0, false, MODE, NG>(st, row, tab, qrow, tq2);
             } else {
 #pragma unroll 1
-                for (int j = j_lo; j < kMid; j++) chunk<0xFFFFu, true, kPipe, MODE, NG>(st, row, tab, qrow, j);
-                chunk<Range<-kR, 0>::m(kMid), true, kPipe, MODE, NG>(st, row, tab, qrow, kMid);
+                for (int j = j_lo; j < kMid; j++) chunk<0xFFFFu, true, kPipe, MODE, NG>(st, row, tab, qrow, j, tq2);
+                chunk<Range<-kR, 0>::m(kMid), true, kPipe, MODE, NG>(st, row, tab, qrow, kMid, tq2);
             }
         } else {
-            chunk<Range<1, kR>::m(kMid), true, kPipe, MODE, NG>(st, row, tab, qrow, kMid);
+            chunk<Range<1, kR>::m(kMid), true, kPipe, MODE, NG>(st, row, tab, qrow, kMid, tq2);
 #pragma unroll 1
-            for (int j = kMid + 1; j <= j_hi; j++) chunk<0xFFFFu, true, kPipe, MODE, NG>(st, row, tab, qrow, j);
+            for (int j = kMid + 1; j <= j_hi; j++) chunk<0xFFFFu, true, kPipe, MODE, NG>(st, row, tab, qrow, j, tq2);
         }
         return;
     }
     if constexpr (HF == 0) {
         if (dy0) {
-            sweep_range<0, 0, false, MODE, NG>(st, row, tab, qrow);
-            if constexpr (kSplit >= 1) sweep_range<1, kSplit, true, MODE, NG>(st, row, tab, qrow);
+            sweep_range<0, 0, false, MODE, NG>(st, row, tab, qrow, tq2);
+            if constexpr (kSplit >= 1) sweep_range<1, kSplit, true, MODE, NG>(st, row, tab, qrow, tq2);
         } else {
-            sweep_range<-kR, kSplit, true, MODE, NG>(st, row, tab, qrow);
+            sweep_range<-kR, kSplit, true, MODE, NG>(st, row, tab, qrow, tq2);
         }
     } else {
         if constexpr (kSplit >= 1) {
-            sweep_range<kSplit + 1, kR, true, MODE, NG>(st, row, tab, qrow);
+            sweep_range<kSplit + 1, kR, true, MODE, NG>(st, row, tab, qrow, tq2);
         } else {
-            if (dy0) sweep_range<1, kR, true, MODE, NG>(st, row, tab, qrow);
-            else sweep_range<kSplit + 1, kR, true, MODE, NG>(st, row, tab, qrow);
+            if (dy0) sweep_range<1, kR, true, MODE, NG>(st, row, tab, qrow, tq2);
+            else sweep_range<kSplit + 1, kR, true, MODE, NG>(st, row, tab, qrow, tq2);
         }
     }
 }
@@ -593,6 +665,7 @@ __device__ __forceinline__ Feat features_of(const FilterArgs &a) {
 struct Staged {   // one staged pixel: the 15 values of the common layout + the two 1-channel features (NG = 8)
     StagedPixel p;
     float s0, s1;
+    float nm1;     // Welch: n - 1 as the oracle forms it, (float)n - 1.f
 };
 
 // pixel (x, yrow) of the input images (an absent G-buffer has factor 0 and is not read)
@@ -601,12 +674,18 @@ __device__ __forceinline__ Staged load_px(const FilterArgs &a, const Feat &F, in
     Staged r;
     StagedPixel &s = r.p;
     r.s0 = r.s1 = 0.f;
+    r.nm1 = 1.f;
     s.valid = x >= 0 && x < a.width && yrow >= 0 && yrow < a.height;
     if (s.valid) {
         const long long q = (long long)yrow * a.width + x;
+        if (a.n) r.nm1 = (float)a.n[q] - 1.f;   // Welch modes only (never with a packed image)
         if (a.packed) {
-            const f3 *px = reinterpret_cast<const f3 *>(a.packed + q * 15);
+            const float *pf = a.packed + q * a.packed_ch;
+            const f3 *px = reinterpret_cast<const f3 *>(pf);
             s.mc = px[0]; s.d = px[1]; s.col = px[2]; s.g0 = px[3]; s.g1 = px[4];
+            if constexpr (NG == 8) {
+                if (a.packed_ch == 17) { r.s0 = pf[15]; r.s1 = pf[16]; }
+            }
             return r;
         }
         s.mc = reinterpret_cast<const f3 *>(a.mean_corr)[q];
@@ -623,7 +702,9 @@ __device__ __forceinline__ Staged load_px(const FilterArgs &a, const Feat &F, in
 }
 
 // stage column i of a row: inputs (NG = 6: exactly as the one-sided kernel stages them), accumulators cleared
-template <int NG>
+// W (Welch): + the three planes E = v * v / (n - 1), the per-pixel addend of the Welch-Satterthwaite denominator, formed
+// as the oracle forms it (pair_member: Dp * Dp / ((float)n[p] - 1.f))
+template <int NG, bool W = false>
 __device__ __forceinline__ void stage_store(float *slot, int i, const Staged &r, const Feat &F, bool rgb) {
     const StagedPixel &s = r.p;
     if constexpr (NG == 6) {
@@ -640,14 +721,21 @@ __device__ __forceinline__ void stage_store(float *slot, int i, const Staged &r,
         p[11 * kP] = ok.x ? -s.d.x : 0.f; p[12 * kP] = ok.y ? -s.d.y : 0.f; p[13 * kP] = ok.z ? -s.d.z : 0.f;
         p[14 * kP] = ok.x ? s.col.x : 0.f; p[15 * kP] = ok.y ? s.col.y : 0.f; p[16 * kP] = ok.z ? s.col.z : 0.f;
     }
+    if constexpr (W) {
+        const Validity ok = pixel_validity(s.mc, s.d, s.col, s.valid, rgb);
+        float *p = slot + Planes<NG, W>::cE * kP + i;
+        p[0 * kP] = ok.x ? s.d.x * s.d.x / r.nm1 : 0.f;
+        p[1 * kP] = ok.y ? s.d.y * s.d.y / r.nm1 : 0.f;
+        p[2 * kP] = ok.z ? s.d.z * s.d.z / r.nm1 : 0.f;
+    }
 #pragma unroll
-    for (int v = 0; v < kQ; v++) slot[(Planes<NG>::kIn + v) * kP + i] = 0.f;
+    for (int v = 0; v < kQ; v++) slot[(Planes<NG, W>::kIn + v) * kP + i] = 0.f;
 }
 
 // the accumulators of row `rel` (tile-relative) leave the ring: copy A + copy B -> patch
-template <int NG>
+template <int NG, bool W = false>
 __device__ __forceinline__ void flush_q(const float *slot, int i, float4 *patch_q_row) {
-    const float *q = slot + Planes<NG>::kIn * kP + i;
+    const float *q = slot + Planes<NG, W>::kIn * kP + i;
     patch_q_row[i] = make_float4(q[0 * kP] + q[4 * kP], q[1 * kP] + q[5 * kP], q[2 * kP] + q[6 * kP], q[3 * kP] + q[7 * kP]);
 }
 
@@ -660,7 +748,8 @@ __device__ __forceinline__ void flush_q(const float *slot, int i, float4 *patch_
 template <int NG>
 __device__ __forceinline__ void dma_row(const FilterArgs &a, const Feat &F, float *raw_w, int lane, int xw0, int yrow, int ncols) {
     if (yrow < 0 || yrow >= a.height) return;
-    const int per_img = ncols * 3 / 4, per_sc = ncols / 4, total = 5 * per_img + (NG == 8 ? 2 * per_sc : 0);
+    const int per_img = ncols * 3 / 4, per_sc = ncols / 4;
+    const int total = a.packed ? ncols * a.packed_ch / 4 : 5 * per_img + (NG == 8 ? 2 * per_sc : 0);
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const int idx = 64 * j + lane;
@@ -668,9 +757,9 @@ __device__ __forceinline__ void dma_row(const FilterArgs &a, const Feat &F, floa
             const float *src;
             bool inside;
             if (a.packed) {
-                const long long f = (long long)xw0 * 15 + 4 * idx;   // float offset inside the AoS row
-                inside = f >= 0 && f + 4 <= (long long)a.width * 15;
-                src = a.packed + (long long)yrow * a.width * 15 + f;
+                const long long f = (long long)xw0 * a.packed_ch + 4 * idx;   // float offset inside the AoS row
+                inside = f >= 0 && f + 4 <= (long long)a.width * a.packed_ch;
+                src = a.packed + (long long)yrow * a.width * a.packed_ch + f;
             } else if (NG == 8 && idx >= 5 * per_img) {
                 const int i2 = idx - 5 * per_img, m = i2 / per_sc, p = i2 - m * per_sc;
                 const float *img = m == 0 ? F.s0 : F.s1;
@@ -696,7 +785,7 @@ __device__ __forceinline__ Staged raw_pixel(const FilterArgs &a, const Feat &F, 
     Staged out;
     StagedPixel &s = out.p;
     s.valid = x >= 0 && x < a.width && yrow >= 0 && yrow < a.height;
-    const int im = a.packed ? 3 : ncols * 3, px = a.packed ? 15 : 3;   // float stride between images / pixels
+    const int im = a.packed ? 3 : ncols * 3, px = a.packed ? a.packed_ch : 3;   // float stride between images / pixels
     const float *r = raw_w + c * px;
     s.mc = f3{r[0], r[1], r[2]};
     s.d = f3{r[im], r[im + 1], r[im + 2]};
@@ -705,8 +794,13 @@ __device__ __forceinline__ Staged raw_pixel(const FilterArgs &a, const Feat &F, 
     s.g1 = F.k1 != 0.f ? f3{r[4 * im], r[4 * im + 1], r[4 * im + 2]} : f3{0.f, 0.f, 0.f};
     out.s0 = out.s1 = 0.f;
     if constexpr (NG == 8) {
-        out.s0 = F.k2 != 0.f ? raw_w[15 * ncols + c] : 0.f;
-        out.s1 = F.k3 != 0.f ? raw_w[16 * ncols + c] : 0.f;
+        if (a.packed) {   // (a 15-channel packed image on this build: no 1-channel features, their factors are 0)
+            out.s0 = F.k2 != 0.f ? r[15] : 0.f;
+            out.s1 = F.k3 != 0.f ? r[16] : 0.f;
+        } else {
+            out.s0 = F.k2 != 0.f ? raw_w[15 * ncols + c] : 0.f;
+            out.s1 = F.k3 != 0.f ? raw_w[16 * ncols + c] : 0.f;
+        }
     }
     return out;
 }
@@ -720,8 +814,11 @@ template <bool DMA, int MODE, int NG, bool RT>
 __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool PAIR = MODE == kModePair;
-    constexpr int kSlotFloats = Planes<NG>::kSlotFloats, kIn = Planes<NG>::kIn;
+    constexpr bool W = mode_welch(MODE);
+    static_assert(!W || (!DMA && NG == 6 && RT), "the Welch modes exist in one build: register staging, six feature planes, runtime radius");
+    constexpr int kSlotFloats = Planes<NG, W>::kSlotFloats, kIn = Planes<NG, W>::kIn;
     const Feat F = features_of<NG>(a);
+    const float *tq2 = W ? a.tq2 : nullptr;
     // XCD-aware work mapping (as in the one-sided kernel): each XCD walks a contiguous range of items
     const int n_items = gridDim.x, b = blockIdx.x;
     const int q8 = n_items >> 3, rem8 = n_items & 7, xcd = b & 7, idx = b >> 3;
@@ -752,7 +849,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     if constexpr (kPrio == 1) { if (half == 1) __builtin_amdgcn_s_setprio(2); }
 
     // ---- the lane's own 4 pixels (loads clamped into the image; outside it the pixel takes no part)
-    Lane<NG> st;
+    Lane<NG, W> st;
     const int py = y0 + trow;
     const int pyc = min(max(py, 0), a.height - 1);
 #pragma unroll
@@ -763,8 +860,12 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
         f3 mc, d, g0, g1, col;
         float sc0 = 0.f, sc1 = 0.f;
         if (a.packed) {
-            const f3 *q = reinterpret_cast<const f3 *>(a.packed + p * 15);
+            const float *pf = a.packed + p * a.packed_ch;
+            const f3 *q = reinterpret_cast<const f3 *>(pf);
             mc = q[0]; d = q[1]; col = q[2]; g0 = q[3]; g1 = q[4];
+            if constexpr (NG == 8) {
+                if (a.packed_ch == 17) { sc0 = pf[15]; sc1 = pf[16]; }
+            }
         } else {
             mc = reinterpret_cast<const f3 *>(a.mean_corr)[p];
             d = reinterpret_cast<const f3 *>(a.disc)[p];
@@ -789,13 +890,18 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
         // a pixel that takes no part adds nothing to its taps: weight 0, colour 0 (0 * NaN would poison them)
         st.pc[k][0] = v2f{ok.x ? col.x : 0.f, ok.y ? col.y : 0.f};
         st.pc[k][1] = v2f{ok.z ? col.z : 0.f, 0.f};
+        if constexpr (W) {
+            const float nm1 = (float)a.n[p] - 1.f;
+            st.pe[k][0] = v2f{d.x * d.x / nm1, d.y * d.y / nm1};
+            st.pe[k][1] = v2f{d.z * d.z / nm1, 0.f};
+        }
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) st.acc[k][ch] = v2f{0.f, 0.f};
         st.sw[k] = v2f{0.f, 0.f};
     }
 
     // wave-local staging geometry (DMA): this wave's columns of every staged row
-    float *raw_w = tab_lds + 2 * kTabPad + Planes<NG>::raw_off(wave);
+    float *raw_w = tab_lds + 2 * kTabPad + Planes<NG, W>::raw_off(wave);
     const int wcol0 = wave_col0(wave);                                 // first staged column (0..167) of the wave
     const int ncols = wave_cols(wave);                                 // 44, 44, 40, 40, then none
     if (s_a < s_b) {
@@ -820,7 +926,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             const int idx2 = (int)threadIdx.x + it * kThreads;
             if (idx2 < kRows * kP) {
                 const int rr = idx2 / kP, i = idx2 - rr * kP;
-                stage_store<NG>(lds + ((s_a + rr) % kSlots) * kSlotFloats, i, pro[it], F, !PAIR);
+                stage_store<NG, W>(lds + ((s_a + rr) % kSlots) * kSlotFloats, i, pro[it], F, !PAIR);
             }
         }
         if ((int)threadIdx.x < tw) {
@@ -849,13 +955,13 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             auto housekeeping = [&]() {
                 const int dead = s - 1;
                 if (mine && dead >= q_first && y0 + dead >= 0 && !(kAblate & 4))
-                    flush_q<NG>(lds + (dead % kSlots) * kSlotFloats, i, patch_q + (long long)(dead - q_first) * kP);
+                    flush_q<NG, W>(lds + (dead % kSlots) * kSlotFloats, i, patch_q + (long long)(dead - q_first) * kP);
                 if constexpr (DMA) {
                     if (s + 1 < s_b && !(kAblate & 2)) {
                         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's own transfers
                         if (stage) {
                             const Staged sp = raw_pixel<NG>(a, F, raw_w, lane, ncols, x0 - kR + i, y0 + s + kRows);
-                            stage_store<NG>(lds + ((s + kRows) % kSlots) * kSlotFloats, i, sp, F, !PAIR);
+                            stage_store<NG, W>(lds + ((s + kRows) % kSlots) * kSlotFloats, i, sp, F, !PAIR);
                         }
                         if (s + 2 < s_b) {
                             __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the raw area has been read
@@ -882,16 +988,16 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             const float *tab = tab_lds + ((s - s_a) & 1) * kTabPad;
             if (kAblate & 8) {
             } else if (half == 0) {
-                eval_half_row<0, MODE, NG, RT>(st, row, tab, qrow, s == 0, j_lo, j_hi);
+                eval_half_row<0, MODE, NG, RT>(st, row, tab, qrow, s == 0, j_lo, j_hi, tq2);
             } else {
-                eval_half_row<1, MODE, NG, RT>(st, row, tab, qrow, s == 0, j_lo, j_hi);
+                eval_half_row<1, MODE, NG, RT>(st, row, tab, qrow, s == 0, j_lo, j_hi, tq2);
             }
 
             if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_ev += t - tk0; tk0 = t; }
             if (DMA && kHkAtEnd && half == 0) housekeeping();
             if (tstage) *reinterpret_cast<v2f *>(tab_lds + ((s - s_a + 1) & 1) * kTabPad + 2 * ti) = tnext;
             if constexpr (!DMA) {
-                if (stage) stage_store<NG>(lds + ((s + kRows) % kSlots) * kSlotFloats, i, nxt, F, !PAIR);
+                if (stage) stage_store<NG, W>(lds + ((s + kRows) % kSlots) * kSlotFloats, i, nxt, F, !PAIR);
             }
             if (!(kAblate & 16)) __syncthreads();
             if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_bar += t - tk0; tk0 = t; }
@@ -905,7 +1011,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             const int rr = idx2 / kP, i = idx2 - rr * kP;
             const int rel = s_b - 1 + rr;
             if (rel >= q_first && y0 + rel >= 0 && y0 + rel < a.height)
-                flush_q<NG>(lds + (rel % kSlots) * kSlotFloats, i, patch_q + (long long)(rel - q_first) * kP);
+                flush_q<NG, W>(lds + (rel % kSlots) * kSlotFloats, i, patch_q + (long long)(rel - q_first) * kP);
         }
         __syncthreads();
     }
@@ -998,7 +1104,7 @@ __global__ __launch_bounds__(256) void combine_sym_kernel(FilterArgs a) {
     if (t.w > 0.f) {
         o.x = t.x / t.w; o.y = t.y / t.w; o.z = t.z / t.w;
     } else {
-        o = a.packed ? reinterpret_cast<const f3 *>(a.packed + p * 15)[2] : reinterpret_cast<const f3 *>(a.colour)[p];
+        o = a.packed ? reinterpret_cast<const f3 *>(a.packed + p * a.packed_ch)[2] : reinterpret_cast<const f3 *>(a.colour)[p];
     }
     reinterpret_cast<f3 *>(a.out)[p] = o;
 }
@@ -1057,12 +1163,14 @@ size_t sym_patch_floats(const FilterArgs &a, int n_parts) {
     return (size_t)sym_tiles(a) * n_parts * (sym::kPatchP + (size_t)sym::q_rows_max(n_parts, a.radius + 1) * sym::kP) * 4;
 }
 
-// filter<float3> and filter<float> (two buffers per launch), radius 20, every spec but Welch degrees of freedom.
+// filter<float3> and filter<float> (two buffers per launch), radius 1..20, every spec but Welch degrees of freedom.
 // G-buffers: up to two RGB images (six feature planes, the shipped normal + albedo), or up to two RGB and up to two
-// 1-channel images in any order (eight feature planes: + depth + material id; not for block + halo calls, whose packed
-// image has 15 channels)
+// 1-channel images in any order (eight feature planes: + depth + material id; block + halo calls carry them in a
+// 17-channel packed image)
 bool sym_eligible(const FilterArgs &a, int channels) {
-    if (a.radius < 1 || a.radius > sym::kR || (channels != 1 && channels != 3) || a.dof != STATMC_DOF_PIXEL) return false;
+    if (a.radius < 1 || a.radius > sym::kR || (channels != 1 && channels != 3)) return false;
+    // Welch degrees of freedom: one RGB buffer from the separate images (the pair needs the sample counts)
+    if (a.dof != STATMC_DOF_PIXEL && (channels != 3 || a.packed)) return false;
     // the pair-symmetric kernel implements both gates and both channel rules; the clamped border's taps beyond the image
     // are added by border_virtual_kernel
     // float buffers with the one-sided gate (four weights per pair for two buffers): one-sided kernel
@@ -1076,8 +1184,8 @@ bool sym_eligible(const FilterArgs &a, int channels) {
         if (!(a.g[g].dr <= 0.f) || !std::isfinite(a.g[g].dr)) return false;
     }
     if (n_rgb > 2 || n_sc > 2) return false;
-    if (n_sc > 0 && a.packed) return false;
-    if (n_sc > 0 && a.radius != sym::kR) return false;   // the eight-plane build exists for the shipped radius only
+    if (a.packed && (n_sc > 0) != (a.packed_ch == 17)) return false;   // 1-channel features travel in the 17-channel block + halo image
+    if (a.dof != STATMC_DOF_PIXEL && n_sc > 0) return false;            // the Welch build has six feature planes
     return true;
 }
 
@@ -1104,8 +1212,10 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     if (a.sym.border_extra && a.packed) return hipErrorInvalidValue;
     a.sym.steps = a.radius + 1;
     a.sym.item_stride4 = kPatchP + (long long)q_rows_max(a.n_parts, a.sym.steps) * kP;
-    const bool rt = a.radius != kR;
+    const bool welch = a.dof == STATMC_DOF_WELCH;
+    const bool rt = a.radius != kR || welch;    // (the Welch modes exist in the runtime-radius build only; it serves r = 20 as well)
     if (rt && a.sym.tab_rt == nullptr) return hipErrorInvalidValue;
+    if (welch && (a.n == nullptr || a.tq2 == nullptr || a.sym.pair || a.sym.g8 || a.packed)) return hipErrorInvalidValue;
     // LDS-DMA staging needs whole 16-byte pieces: images 16-byte aligned, width and film x-origin multiples of 4 pixels
     auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool g8 = a.sym.g8 != 0;
@@ -1135,12 +1245,16 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     const int mode = pair ? kModePair : asym ? (joint ? kModeAsymJoint : kModeAsym) : joint ? kModeJoint : kModeRgb;
 #define STATMC_SYM_K(D, M, G, R) reinterpret_cast<const void *>(&window_filter_sym<D, M, G, R>)
 #define STATMC_SYM_ROW(D, G, R) {STATMC_SYM_K(D, kModeRgb, G, R), STATMC_SYM_K(D, kModePair, G, R), STATMC_SYM_K(D, kModeJoint, G, R), STATMC_SYM_K(D, kModeAsym, G, R), STATMC_SYM_K(D, kModeAsymJoint, G, R)}
-    // [eight feature planes | runtime radius (six planes)][LDS-DMA staging][mode]
-    const void *kernels[3][2][kModes] = {{STATMC_SYM_ROW(false, 6, false), STATMC_SYM_ROW(true, 6, false)}, {STATMC_SYM_ROW(false, 8, false), STATMC_SYM_ROW(true, 8, false)},
-                                         {STATMC_SYM_ROW(false, 6, true), STATMC_SYM_ROW(true, 6, true)}};
+    // [runtime radius][eight feature planes][LDS-DMA staging][mode]
+    const void *kernels[2][2][2][kModes] = {{{STATMC_SYM_ROW(false, 6, false), STATMC_SYM_ROW(true, 6, false)}, {STATMC_SYM_ROW(false, 8, false), STATMC_SYM_ROW(true, 8, false)}},
+                                            {{STATMC_SYM_ROW(false, 6, true), STATMC_SYM_ROW(true, 6, true)}, {STATMC_SYM_ROW(false, 8, true), STATMC_SYM_ROW(true, 8, true)}}};
 #undef STATMC_SYM_ROW
 #undef STATMC_SYM_K
-    const void *kernel = kernels[rt ? 2 : g8 ? 1 : 0][dma ? 1 : 0][mode];
+    const void *kernel = kernels[rt ? 1 : 0][g8 ? 1 : 0][dma ? 1 : 0][mode];
+    if (welch) {   // (the gate field has no meaning under Welch: there is one test, symmetric in the pair)
+        kernel = joint ? reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelchJoint, 6, true>)
+                       : reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelch, 6, true>);
+    }
     static std::mutex mu;
     static std::set<std::pair<int, const void *>> done;
     int dev = 0;
@@ -1154,7 +1268,8 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     }
     const dim3 grid(sym_tiles(a) * a.n_parts);
     void *kargs[] = {&a};
-    if (hipError_t e = hipLaunchKernel(kernel, grid, dim3(kThreads), kargs, g8 ? Planes<8>::kLdsBytes : Planes<6>::kLdsBytes, s); e != hipSuccess) return e;
+    const size_t lds_bytes = welch ? Planes<6, true>::kLdsBytes : g8 ? Planes<8>::kLdsBytes : Planes<6>::kLdsBytes;
+    if (hipError_t e = hipLaunchKernel(kernel, grid, dim3(kThreads), kargs, lds_bytes, s); e != hipSuccess) return e;
     if (a.sym.border_extra) {
         if (hipError_t e = launch_border_virtual(a, s); e != hipSuccess) return e;
     }

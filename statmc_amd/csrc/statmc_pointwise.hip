@@ -73,14 +73,30 @@ template <int N> __device__ __forceinline__ void acc_wait_vmcnt() { asm volatile
 
 // Student-t tables, uploaded once by statmc_setup() (hipMemcpyToSymbol).
 __device__ float g_tq[STATMC_TQ_N_TABLES][STATMC_TQ_N_DOF];
-
-hipError_t upload_t_tables() {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_tq), statmc_tq_tables, sizeof(statmc_tq_tables));
-}
+// fl(t * t) of every entry: what the Welch pair test of the pair-symmetric kernel multiplies with (the oracle forms
+// (t * t) * s; the product t * t rounds the same here as there)
+__device__ float g_tq2[STATMC_TQ_N_TABLES][STATMC_TQ_N_DOF];
 
 hipError_t upload_t_table(int table, const float *host_4096) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_tq), host_4096, sizeof(float) * STATMC_TQ_N_DOF,
-                             sizeof(float) * STATMC_TQ_N_DOF * table);
+    if (hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_tq), host_4096, sizeof(float) * STATMC_TQ_N_DOF, sizeof(float) * STATMC_TQ_N_DOF * table); e != hipSuccess)
+        return e;
+    static thread_local float sq[STATMC_TQ_N_DOF];
+    for (int i = 0; i < STATMC_TQ_N_DOF; i++) {
+        volatile float t = host_4096[i];     // one rounded product, never contracted or widened
+        sq[i] = t * t;
+    }
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tq2), sq, sizeof(float) * STATMC_TQ_N_DOF, sizeof(float) * STATMC_TQ_N_DOF * table);
+}
+
+hipError_t upload_t_tables() {
+    for (int t = 0; t < STATMC_TQ_N_TABLES; t++)
+        if (hipError_t e = upload_t_table(t, statmc_tq_tables[t]); e != hipSuccess) return e;
+    return hipSuccess;
+}
+const float *t_table_sq_device_ptr(int table) {
+    float *base = nullptr;
+    if (hipGetSymbolAddress(reinterpret_cast<void **>(&base), HIP_SYMBOL(g_tq2)) != hipSuccess) return nullptr;
+    return base + (size_t)table * STATMC_TQ_N_DOF;
 }
 const float *t_table_device_ptr(int table) {
     float *base = nullptr;
@@ -193,12 +209,18 @@ __global__ __launch_bounds__(kBlock) void prepass_pack_kernel(PrepassPackArgs a)
         prepass_elem(ni, t, mu.z, s2.z, s3.z, mc.z, dc.z, a.small_n_exclude);
         if (a.mean_corr) reinterpret_cast<f3p *>(a.mean_corr)[i] = mc;
         if (a.disc) reinterpret_cast<f3p *>(a.disc)[i] = dc;
-        f3p *dst = reinterpret_cast<f3p *>(a.packed + ((long long)(y + a.dst_y0) * a.dst_w + (x + a.dst_x0)) * 15);
+        float *px = a.packed + ((long long)(y + a.dst_y0) * a.dst_w + (x + a.dst_x0)) * a.ch;
+        f3p *dst = reinterpret_cast<f3p *>(px);
+        const f3p zero = {0.f, 0.f, 0.f};
         dst[0] = mc;
         dst[1] = dc;
         dst[2] = reinterpret_cast<const f3p *>(a.colour)[i];
-        dst[3] = reinterpret_cast<const f3p *>(a.g0)[i];
-        dst[4] = reinterpret_cast<const f3p *>(a.g1)[i];
+        dst[3] = a.g0 ? reinterpret_cast<const f3p *>(a.g0)[i] : zero;
+        dst[4] = a.g1 ? reinterpret_cast<const f3p *>(a.g1)[i] : zero;
+        if (a.ch == 17) {
+            px[15] = a.s0 ? a.s0[i] : 0.f;
+            px[16] = a.s1 ? a.s1[i] : 0.f;
+        }
     }
 }
 

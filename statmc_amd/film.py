@@ -8,13 +8,14 @@ import torch
 from . import api
 
 # (channels, transform, max_moment, filter sd) of the shipped denoise configuration
-# (statpath.cpp:1027-1160; scenes/render-denoise.pbrt:19-22) plus the two float G-buffers.
+# (statpath.cpp:1027-1160; scenes/render-denoise.pbrt:19-22) plus the two float G-buffers (their sds: this build's
+# choice for the synthetic scene -- the reference takes them from the scene file's `filterbuffersds`, no default).
 STAT_TYPES = {
     "radiance":   dict(channels=3, transform=True,  max_moment=3, sd=None),
     "normal":     dict(channels=3, transform=False, max_moment=1, sd=0.1),
     "albedo":     dict(channels=3, transform=False, max_moment=1, sd=0.02),
-    "depth":      dict(channels=1, transform=False, max_moment=1, sd=None),
-    "materialid": dict(channels=1, transform=False, max_moment=1, sd=None),
+    "depth":      dict(channels=1, transform=False, max_moment=1, sd=1.0),
+    "materialid": dict(channels=1, transform=False, max_moment=1, sd=0.5),
 }
 
 

@@ -9,16 +9,26 @@ from . import api, film, sharding
 
 
 class BlockPipeline:
-    def __init__(self, layout, device, types, filter_sd=10.0, radius=20, via_host=False):
+    def __init__(self, layout, device, types, filter_sd=10.0, radius=20, via_host=False, reproducible=False,
+                 g_buffers=("normal", "albedo"), g_sds=None):
+        """reproducible: pin the window-sweep split of this device to the one a single device would choose for the WHOLE
+        film (statmc_set_filter_split), so that the assembled blocks equal the one-device result bit for bit; default: the
+        split fitted to the block (faster on strips, <= 1e-6 from the one-device result)."""
         self.layout, self.device, self.via_host = layout, device, via_host
-        self.fs = film.FilmStats(layout.bw, layout.bh, device, types=types, filter_sd=filter_sd, radius=radius)
+        self.fs = film.FilmStats(layout.bw, layout.bh, device, types=types, filter_sd=filter_sd, radius=radius,
+                                 g_buffers=g_buffers, g_sds=g_sds)
+        self.g_channels = [film.STAT_TYPES[g]["channels"] for g in self.fs.g_names]
+        if reproducible:
+            fw, fh = layout.film_size
+            api.set_filter_split(api.filter_split_auto(fw, fh, radius))
         self.filter_sd, self.radius = filter_sd, radius
         self.multi = layout.world > 1
         self.side = None   # stream of the interior's accumulation in the overlapped order
         if self.multi:
             # block + halo: one 15-channel image (mean-corr, discriminator, colour, normal, albedo per
-            # pixel) is what the pack kernel writes, the halo exchange moves and the filter reads
-            self.packed = layout.new_padded(15, device)
+            # pixel) is what the pack kernel writes, the halo exchange moves and the filter reads; with 1-channel
+            # G-buffers (depth, material id) it has 17 channels
+            self.packed = layout.new_padded(17 if 1 in self.g_channels else 15, device)
             self.out_pad = layout.new_padded(3, device)
 
     def accumulate(self, samples, rows=None):
@@ -112,9 +122,13 @@ class BlockPipeline:
                 run("accumulate", self.accumulate, samples_or_fn, rows)
             run("prepass", self.prepass, rows)
 
+    def join_side(self):
+        """Orders the current stream behind the interior's chain (side stream)."""
+        torch.cuda.current_stream(self.device).wait_stream(self.side)
+
     def join_interior(self, in_flight):
         """Orders the current stream behind the interior's chain and the receives."""
-        torch.cuda.current_stream(self.device).wait_stream(self.side)
+        self.join_side()
         in_flight.wait()
 
     def exchange_start(self):
@@ -132,7 +146,7 @@ class BlockPipeline:
         a, keep = api.make_filter_args(
             n=[], mean=[], m2=[], m3=[], film=[], mean_corr=[], disc=[], film_filtered=[self.out_pad],
             g_buffers=[], g_sds=self.fs.g_sds, filter_sd=self.filter_sd, radius=self.radius, roi=L.roi,
-            packed=self.packed, film_origin=(ox - L.pl, oy - L.pt))
+            packed=self.packed, film_origin=(ox - L.pl, oy - L.pt), packed_g_channels=self.g_channels)
         api.window_filter(a, 3)
         return L.interior(self.out_pad)
 

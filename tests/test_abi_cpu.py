@@ -16,17 +16,22 @@ def lib():
     return api.load()
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "statmc.h")).read()
+def declared_symbols(header="statmc.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(statmc_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_symbols_are_exported(lib):
+    """Every symbol a C header under include/ declares: the boundary (statmc.h) and the test / A-B switches (statmc_debug.h)."""
     syms = declared_symbols()
     assert len(syms) >= 20
-    missing = [s for s in syms if not hasattr(lib, s)]
+    dbg = declared_symbols("statmc_debug.h")
+    assert len(dbg) >= 8 and all(s.startswith("statmc_debug_") for s in dbg)
+    missing = [s for s in syms + dbg if not hasattr(lib, s)]
     assert not missing, missing
+    # nothing of the debug surface leaks into the boundary header, and no experiment transport is left in it
+    assert not [s for s in syms if s.startswith("statmc_debug_") or "by_kernel" in s]
 
 
 def test_python_export_list_matches_header():

@@ -60,7 +60,17 @@ def test_strong_scaling_two_ranks_share_the_device(gpu, grid, blocks):
     assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["n_ranks_seen"] == 2
     assert r["config"]["film"] == "512x256" and r["config"]["block_grid"] == blocks      # one film, two blocks
     assert abs(r["value"] - 512 * 256 / r["ms_per_step"] / 1e3) < 1e-2 * r["value"]      # film pixels per step time
-    assert r["kernels"]["halo_exchange"]["ms_per_step"] > 0
+    k = r["kernels"]
+    if grid == "rows":      # 512 x 128 strips: the overlapped order, with keys of its own (nothing shares a name with the plain order)
+        assert r["config"]["step_order"].startswith("border rows first")
+        assert k["border_chain"]["ms_per_step"] > 0 and k["border_chain"]["rows"] == 20
+        assert k["interior"]["accumulate_ms_per_step"] > 0 and k["interior"]["rows"] == 108
+        assert k["interior_exposed"]["ms_per_step"] >= 0 and k["exchange_exposed"]["ms_per_step"] >= 0
+        assert "accumulate" not in k and "halo_exchange" not in k
+    else:
+        assert k["halo_exchange"]["ms_per_step"] > 0 and k["accumulate"]["ms_per_step"] > 0 and "border_chain" not in k
+    assert r["backend"] == "gloo"
+    assert r["overlap_self_check"]["overlapped_vs_plain_order"] == "bit-identical" and r["overlap_self_check"]["ranks"] == 2
     assert r["gather_ms"] > 0 and r["gather"]["bytes"] == 12 * 512 * 256 and not r["gather"]["in_step"]
     assert "cpu_baseline" not in r
 
@@ -94,3 +104,60 @@ def test_reference_schedule_with_a_sample_pool(gpu):
     # 4 | 4 | 8 (wraps the pool: 8..12, 0..4) | 16 (4..12, 0..8): 1 + 1 + 2 + 2 launches
     assert c["accumulate_launches_per_step"] == 6 and r["roofline_filter"]["launches_per_step"] == 4
     assert abs(r["value"] - 512 * 256 / r["ms_per_step"] / 1e3) < 1e-2 * r["value"]
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_peer_leg_one_process_all_blocks_and_same_bits_as_the_rank_leg(gpu, tmp_path):
+    """`--backend peer`: ONE process drives both blocks through the C ABI (statmc_halo_exchange's device-to-device copies;
+    here both blocks share the box's one GPU).  Its film-f equals the one-process-per-block leg's (gloo, halos via the
+    host) bit for bit, and -- the blocks being filtered under the default dispatch -- the whole film's within 1e-6."""
+    import numpy as np
+    dumps = {}
+    for backend in ("peer", "gloo"):
+        dumps[backend] = str(tmp_path / ("film_f_%s.npy" % backend))
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", backend, "--share-device",
+               "--dump-film-f", dumps[backend]] + COMMON
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=360, env=_clean_env())
+        assert out.returncode == 0, out.stderr[-3000:]
+        r = _line(out)
+        assert r["backend"] == backend and r["n_gpus"] == 2 and r["n_ranks_seen"] == 2
+        assert r["overlap_self_check"]["overlapped_vs_plain_order"] == "bit-identical"
+        # all four feature types as G-buffers travel in a 17-channel block + halo image and stay on the pair-symmetric kernel
+        e8 = r["filter_8_feature_channels"]
+        assert e8["filter_variant"] == "sym_r20_g8" and e8["packed_channels"] == 17 and e8["avg_ms"] > 0
+        if backend == "peer":
+            assert "fallback_from" not in r and r["devices"] == [0, 0] and r["host_enqueue_ms_per_step"] > 0
+            assert r["config"]["parallelism"].startswith("film blocks x2, ONE process")
+            k = r["kernels"]
+            assert k["border_chain"]["ms_per_step"] > 0 and k["interior"]["accumulate_ms_per_step"] > 0 and k["filter"]["ms_per_step"] > 0
+            assert abs(r["value"] - 512 * 256 / r["ms_per_step"] / 1e3) < 1e-2 * r["value"]
+            assert r["gather"]["bytes"] == 12 * 512 * 256
+    a, b = np.load(dumps["peer"]), np.load(dumps["gloo"])
+    assert a.shape == (256, 512, 3) and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_nccl_failure_falls_back_to_the_peer_leg(gpu, launcher):
+    """The nccl leg cannot come up (forced: STATMC_BENCH_FAIL_NCCL=1; on this one-GPU box RCCL would refuse two ranks on a
+    device anyway) -> a FRESH process runs the peer leg and the line records where it came from.  Both launch forms: the
+    self-launcher's parent owns the fallback, under a foreign launcher (the driver's form) rank 0 does."""
+    if launcher == "self":
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")]
+    else:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py")]
+    cmd += ["--gpus", "2", "--backend", "nccl", "--share-device"] + COMMON
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=_clean_env(STATMC_BENCH_FAIL_NCCL="1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = _line(out)
+    assert r["backend"] == "peer" and r["fallback_from"] == "nccl" and r["n_gpus"] == 2 and r["n_ranks_seen"] == 2
+    assert "why" in r["nccl_error"] and r["value"] > 0

@@ -146,6 +146,61 @@ def blocks_2x2_equal_whole(gpu, fs, colour, variant):
         assert torch.equal(L.interior(out), whole[oy:oy + bh, ox:ox + bw]), rank
 
 
+def test_default_dispatch_blocks_vs_whole_film(gpu, oracle, film1080):
+    """What N GPUs compute under the DEFAULT dispatch -- every block picks the window-sweep split that fits its own shape
+    (1 part for the whole 1080p film, 3 for its 1920 x 135 / 270 / 540 strips on a 256-CU device) -- against the
+    one-device result: the same film to <= 1e-6 relative L2 per channel (the split regroups a pixel's 1681 terms, nothing
+    else), and the same strips of the oracle to <= 1e-5.  With the split PINNED to the whole film's
+    (statmc_set_filter_split(statmc_filter_split_auto(W, H, r)): the declared, per-device setting) the blocks are the
+    one-device result bit for bit.  Row strips for 2 / 4 / 8 devices, 2 x 2 and 4 x 2 blocks."""
+    from statmc_amd import sharding
+    fs, _ = film1080
+    colour = fs.state["radiance"]["film_mean"]
+    assert gpu.get_filter_split() == 0
+    whole = wf(gpu, fs, colour, torch.zeros_like(colour)).clone()
+    assert gpu.last_filter_variant() == "sym_r20"
+    parts_whole = gpu.load().statmc_debug_last_filter_parts()
+    assert parts_whole == gpu.filter_split_auto(W, H, RADIUS)
+    imgs = dict(mean_corr=fs.mean_corr, disc=fs.disc, colour=colour, normal=fs.g_buffer("normal"), albedo=fs.g_buffer("albedo"))
+    seam = (0, 536, W, 544)                         # 8 full-width rows across the y = 540 seam of every grid below
+    ref = oracle_strip(oracle, fs, colour, seam)
+
+    def assemble(gx, gy):
+        out_film, used = torch.empty_like(whole), set()
+        bw, bh = W // gx, H // gy
+        for rank in range(gx * gy):
+            L = sharding.BlockLayout(rank, gx * gy, bw, bh, RADIUS, grid=(gx, gy))
+            ox, oy = L.origin
+            loc = {k: v[oy - L.pt:oy + bh + L.pb, ox - L.pl:ox + bw + L.pr].contiguous() for k, v in imgs.items()}
+            out = torch.zeros_like(loc["colour"])
+            a, keep = gpu.make_filter_args([], [], [], [], [loc["colour"]], [loc["mean_corr"]], [loc["disc"]], [out],
+                                           [loc["normal"], loc["albedo"]], g_sds=[SD_NORMAL, SD_ALBEDO],
+                                           filter_sd=FILTER_SD, radius=RADIUS, roi=L.roi, film_origin=(ox - L.pl, oy - L.pt))
+            gpu.window_filter(a, 3)
+            torch.cuda.synchronize()
+            assert gpu.last_filter_variant() == "sym_r20"
+            used.add(gpu.load().statmc_debug_last_filter_parts())
+            out_film[oy:oy + bh, ox:ox + bw] = L.interior(out)
+        return out_film, used
+
+    differing = 0
+    for gx, gy in ((1, 2), (1, 4), (1, 8), (2, 2), (4, 2)):
+        got, used = assemble(gx, gy)
+        differing += used != {parts_whole}
+        g, w = got.cpu().numpy(), whole.cpu().numpy()
+        for c in range(3):
+            assert rel_l2(g[..., c], w[..., c]) <= 1e-6, (gx, gy, c, used)
+            assert rel_l2(g[536:544, :, c], ref[..., c]) <= 1e-5, (gx, gy, c)
+    assert differing > 0        # the case the bound is stated for: some grid did run under another split than the film
+    gpu.set_filter_split(parts_whole)
+    try:
+        for gx, gy in ((1, 8), (4, 2)):
+            got, used = assemble(gx, gy)
+            assert used == {parts_whole} and torch.equal(got, whole), (gx, gy)
+    finally:
+        gpu.set_filter_split(0)
+
+
 # ====================================================================== every BASELINE.json config
 # configs[0] 256x256 / 16 spp, configs[1] 1280x720 / 64 spp, configs[2] 1920x1080 / 256 spp,
 # configs[3] 1920x1080 / 64 spp cut 2x2, configs[4] 3840x2160 cut 4x2 (spp bounded here: the per-pixel update

@@ -714,7 +714,11 @@ def test_filter_generic_gbuffer_sets(gpu, oracle, channels):
     g_dr = [-0.5 / 0.3 ** 2, -0.5 / 0.2 ** 2, -0.5 / 0.1 ** 2]
     ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / 16.0, r)
     out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, 4.0, r, channels=channels)
-    assert v == ("lds_rt" if channels == 3 else "lds_rt_f")           # 3 + 1 + 1 channels at r = 7: slot layout of the one-sided kernel
+    # 3 + 1 + 1 channels at r = 7: since round 4 the pair-symmetric kernel's eight-plane build has a runtime radius ...
+    assert v == ("sym_rt_g8" if channels == 3 else "sym_rt_f_g8")
+    assert rel_l2(out, ref) <= TOL
+    out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, 4.0, r, channels=channels, force=2)
+    assert v == ("lds_rt" if channels == 3 else "lds_rt_f")           # ... and the one-sided kernel still spreads the set over its six slots
     assert rel_l2(out, ref) <= TOL
     out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, 4.0, r, channels=channels, force=1)
     assert v == "generic" and rel_l2(out, ref) <= TOL
@@ -737,19 +741,25 @@ def test_filter_generic_gbuffer_sets(gpu, oracle, channels):
     assert rel_l2(out0, ref0) <= TOL
 
 
-@pytest.mark.parametrize("channels,order,spec_kw,W", [
-    (3, ("normal", "albedo", "depth", "materialid"), dict(), 300),
-    (3, ("depth", "albedo", "materialid", "normal"), dict(), 300),           # any order of the argument list
-    (3, ("albedo", "normal", "depth"), dict(), 300),                          # one 1-channel image
-    (3, ("normal", "albedo", "depth", "materialid"), dict(), 301),            # width not a multiple of 4: register staging
-    (3, ("normal", "albedo", "depth", "materialid"), dict(border=1), 300),
-    (3, ("normal", "albedo", "depth", "materialid"), dict(gate=1, channel_rule=1), 300),
-    (1, ("normal", "albedo", "depth", "materialid"), dict(), 300),            # filter<float>, two buffers per launch
-], ids=["nadm", "danm-order", "three", "unaligned", "clamp", "asym+joint", "float"])
-def test_filter_eight_feature_channels(gpu, oracle, channels, order, spec_kw, W):
+@pytest.mark.parametrize("channels,order,spec_kw,W,radius", [
+    (3, ("normal", "albedo", "depth", "materialid"), dict(), 300, 20),
+    (3, ("depth", "albedo", "materialid", "normal"), dict(), 300, 20),           # any order of the argument list
+    (3, ("albedo", "normal", "depth"), dict(), 300, 20),                          # one 1-channel image
+    (3, ("normal", "albedo", "depth", "materialid"), dict(), 301, 20),            # width not a multiple of 4: register staging
+    (3, ("normal", "albedo", "depth", "materialid"), dict(border=1), 300, 20),
+    (3, ("normal", "albedo", "depth", "materialid"), dict(gate=1, channel_rule=1), 300, 20),
+    (1, ("normal", "albedo", "depth", "materialid"), dict(), 300, 20),            # filter<float>, two buffers per launch
+    (3, ("materialid", "depth", "normal", "albedo"), dict(), 300, 6),             # the shipped small radius (glass-caustics), runtime-radius build
+    (3, ("normal", "albedo", "depth", "materialid"), dict(), 301, 13),
+    (3, ("normal", "albedo", "depth", "materialid"), dict(channel_rule=1, border=1), 300, 7),
+    (1, ("normal", "albedo", "depth", "materialid"), dict(), 300, 3),
+], ids=["nadm", "danm-order", "three", "unaligned", "clamp", "asym+joint", "float", "r6", "r13-unaligned", "r7-joint+clamp", "r3-float"])
+def test_filter_eight_feature_channels(gpu, oracle, channels, order, spec_kw, W, radius):
     """normal + albedo + depth + material id as G-buffers (statpath.cpp:828-835, 1096-1130: `filterbuffers` may name all
-    four) at the shipped radius: eight feature channels run the pair-symmetric kernel's eight-plane build, not the
-    global-memory kernel; same result as the oracle and as the general kernel."""
+    four): eight feature channels run the pair-symmetric kernel's eight-plane build -- compile-time radius 20 or, since
+    round 4, the runtime-radius build (r = 6 is scenes/render-denoise-glass-caustics.pbrt:19-20) -- not the global-memory
+    kernel; same result as the oracle and as the general kernel."""
+    RADIUS = radius
     H = 44
     feats = ("radiance", "normal", "albedo", "depth", "materialid")
     _, smp, st = make_case(W, H, 6, seed=321, features=feats)
@@ -768,7 +778,7 @@ def test_filter_eight_feature_channels(gpu, oracle, channels, order, spec_kw, W)
         out_g, v_g = run_filter(gpu, mc, disc, colour, gbs, g_dr, FILTER_SD, RADIUS, channels=channels, force=1)
     finally:
         gpu.set_filter_spec()
-    want = "sym_r20" + ("_f" if channels == 1 else "") + "_g8" + ("_asym" if spec_kw.get("gate") else "") + \
+    want = ("sym_r20" if radius == 20 else "sym_rt") + ("_f" if channels == 1 else "") + "_g8" + ("_asym" if spec_kw.get("gate") else "") + \
         ("_joint" if spec_kw.get("channel_rule") and channels == 3 else "") + ("_clamp" if spec_kw.get("border") else "")
     assert v == want, v
     assert v_g == "generic"
@@ -1165,44 +1175,6 @@ def test_device_memory_and_streams_roundtrip(gpu):
     assert lib.statmc_setup(99) == gpu.ERR_INVALID and b"out of range" in lib.statmc_last_error()
 
 
-def test_upload_by_kernel(gpu):
-    """statmc_upload_by_kernel / statmc_upload_segments_by_kernel: a kernel pulls page-locked host memory over PCIe (the second
-    transport of the band pipeline's copies in); pageable, unaligned or odd-sized memory goes through the copy engine.  Same
-    bytes as statmc_upload either way."""
-    lib = gpu.load()
-
-    class Seg(C.Structure):
-        _fields_ = [("dev_dst", C.c_void_p), ("host_src", C.c_void_p), ("bytes", C.c_size_t)]
-    lib.statmc_upload_segments_by_kernel.argtypes = [C.POINTER(Seg), C.c_int, C.c_void_p]
-    n = 3 * 1000 * 1000 + 5                                              # not a multiple of 16 bytes: a tail through the copy engine
-    pinned = C.c_void_p()
-    gpu.check(lib.statmc_malloc_host(C.byref(pinned), 4 * n))
-    try:
-        host = np.ctypeslib.as_array(C.cast(pinned, C.POINTER(C.c_float)), shape=(n,))
-        host[:] = np.random.default_rng(3).random(n, dtype=np.float32)
-        pageable = host.copy()
-        for src, what in ((host, "page-locked"), (pageable, "pageable"), (host[1:], "unaligned")):
-            dev = torch.zeros(src.size, device=DEV)
-            gpu.check(lib.statmc_upload_by_kernel(dev.data_ptr(), src.ctypes.data, src.nbytes, None))
-            torch.cuda.synchronize()
-            assert np.array_equal(dev.cpu().numpy(), src), what
-        # ten segments (two launches of up to eight), one of them pageable, one empty
-        cuts = np.linspace(0, n - 5, 11).astype(np.int64) // 4 * 4
-        dev = torch.zeros(n, device=DEV)
-        segs = (Seg * 11)()
-        for i in range(10):
-            a, b = int(cuts[i]), int(cuts[i + 1])
-            src = pageable if i == 4 else host
-            segs[i] = Seg(dev.data_ptr() + 4 * a, src.ctypes.data + 4 * a, 4 * (b - a))
-        segs[10] = Seg(dev.data_ptr(), host.ctypes.data, 0)
-        gpu.check(lib.statmc_upload_segments_by_kernel(segs, 11, None))
-        torch.cuda.synchronize()
-        assert np.array_equal(dev.cpu().numpy()[:int(cuts[-1])], host[:int(cuts[-1])])
-        assert lib.statmc_upload_segments_by_kernel(None, 2, None) == gpu.ERR_INVALID
-    finally:
-        gpu.check(lib.statmc_free_host(pinned))
-
-
 def test_filter_randomised_configurations(gpu, oracle):
     """40 seeded random configurations: image size, radius, filter sds, ROI, window-sweep parts,
     kernel variant -- every one against the oracle."""
@@ -1288,7 +1260,9 @@ def expected_lds_variant(spec_kw, channels, radius):
     membership tests in its runtime-radius build)."""
     gate, joint, border = spec_kw.get("gate", 0), spec_kw.get("channel_rule", 0) and channels == 3, spec_kw.get("border", 0)
     if spec_kw.get("dof", 0):
-        return "generic"
+        # Welch degrees of freedom: an RGB buffer runs the pair-symmetric kernel's Welch build (one build for every radius;
+        # the gate field has no meaning under Welch), float buffers the general kernel
+        return "sym_welch" + ("_joint" if joint else "") + ("_clamp" if border else "") if channels == 3 else "generic"
     f = "_f" if channels == 1 else ""
     if channels == 3 or not gate:       # the pair-symmetric kernel: compile-time radius 20, runtime radius below
         return ("sym_r20" if radius == 20 else "sym_rt") + f + ("_asym" if gate else "") + ("_joint" if joint else "") + ("_clamp" if border else "")
@@ -1313,10 +1287,10 @@ def test_filter_spec_variants_match_oracle(gpu, oracle, spec_kw):
         assert variant_g == "generic"
         for c in range(3):
             assert rel_l2(out[..., c], out_g[..., c]) <= TOL, c
-        # ... and the one-sided LDS kernel's build for the spec
+        # ... and the one-sided LDS kernel's build for the spec (Welch: it has none -- the general kernel)
         _, _, out_l, variant_l, _ = run_spec(gpu, oracle, st, spec_kw, radius=7, sd=4.0, alpha_index=2, force=2)
         gate, joint = spec_kw.get("gate", 0), spec_kw.get("channel_rule", 0)
-        assert variant_l == "lds_rt" + ("_asym" if gate else "") + ("_joint" if joint else ""), variant_l
+        assert variant_l == ("generic" if spec_kw.get("dof", 0) else "lds_rt" + ("_asym" if gate else "") + ("_joint" if joint else "")), variant_l
         for c in range(3):
             assert rel_l2(out_l[..., c], oout[..., c]) <= TOL, c
 

@@ -23,6 +23,9 @@ def _free_port():
 
 BW, BH, SPP, RADIUS = 272, 40, 6, 20
 TYPES = ("radiance", "normal", "albedo")
+# all four feature types as G-buffers (statpath.cpp:828-835, 1096-1130): eight feature planes, a 17-channel block + halo image
+TYPES8 = ("radiance", "normal", "albedo", "depth", "materialid")
+G8 = ("materialid", "depth", "normal", "albedo")     # the reference's stat-type order (statpath.cpp:1096-1160)
 
 
 def _grid(world, rows):
@@ -30,15 +33,15 @@ def _grid(world, rows):
     return sharding.row_strips(world) if rows else sharding.grid_for(world)
 
 
-def _film_samples(world, rows, BH=BH):
+def _film_samples(world, rows, BH=BH, g8=False):
     """Whole-film sample stream, identical in every process (CPU generator, fixed seed)."""
     from statmc_amd import synthetic
     gx, gy = _grid(world, rows)
     scene = synthetic.Scene(gx * BW, gy * BH, n_regions=9, seed=21)
-    return scene.samples(SPP, seed=22, features=TYPES)
+    return scene.samples(SPP, seed=22, features=TYPES8 if g8 else TYPES)
 
 
-def _worker(rank, world, rows, port, q, BH=BH):
+def _worker(rank, world, rows, port, q, BH=BH, g8=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch.distributed as dist
@@ -47,7 +50,7 @@ def _worker(rank, world, rows, port, q, BH=BH):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        _run(rank, world, rows, q, dist, api, pipeline, sharding, BH)
+        _run(rank, world, rows, q, dist, api, pipeline, sharding, BH, g8)
     except Exception as e:                      # report instead of leaving the parent waiting
         q.put((rank, "error", repr(e), None))
         raise
@@ -55,35 +58,43 @@ def _worker(rank, world, rows, port, q, BH=BH):
         dist.destroy_process_group()
 
 
-def _run(rank, world, rows, q, dist, api, pipeline, sharding, BH=BH):
+def _run(rank, world, rows, q, dist, api, pipeline, sharding, BH=BH, g8=False):
     if True:
         dev = torch.device("cuda:0")
         api.setup(0)
         api.force_filter_parts(2)            # same window-row split as the single-process run
         L = sharding.BlockLayout(rank, world, BW, BH, RADIUS, grid=_grid(world, rows))
         ox, oy = L.origin
-        smp = {k: v[:, oy:oy + BH, ox:ox + BW].contiguous().to(dev) for k, v in _film_samples(world, rows, BH).items()}
-        pipe = pipeline.BlockPipeline(L, dev, TYPES, radius=RADIUS, via_host=True)
+        smp = {k: v[:, oy:oy + BH, ox:ox + BW].contiguous().to(dev) for k, v in _film_samples(world, rows, BH, g8).items()}
+        pipe = pipeline.BlockPipeline(L, dev, TYPES8 if g8 else TYPES, radius=RADIUS, via_host=True,
+                                      **(dict(g_buffers=G8) if g8 else {}))
+        assert pipe.packed.shape[2] == (17 if g8 else 15)
         # row strips tall enough for it take the overlapped order: the rows a neighbour needs first, the exchange started,
         # the rest accumulated behind it (BlockPipeline.accumulate_and_denoise); everything else the plain order
         overlapped = bool(pipe.border_rows())
         out = pipe.accumulate_and_denoise(smp).clone()
         torch.cuda.synchronize()
+        assert api.last_filter_variant() == ("sym_r20_g8" if g8 else "sym_r20")
         assert overlapped == (rows and BH >= 2 * RADIUS + 8)
         q.put((rank, ox, oy, out.cpu().numpy()))
         dist.barrier()
 
 
-@pytest.mark.parametrize("world,rows,BH", [(2, False, 40), (4, False, 40), (3, True, 40), (3, True, 56), (2, True, 64)],
-                         ids=["2x1", "2x2", "1x3-rows", "1x3-rows-overlapped", "1x2-rows-overlapped"])
-def test_blocks_equal_whole_film(gpu, world, rows, BH):
+@pytest.mark.parametrize("world,rows,BH,g8", [(2, False, 40, False), (4, False, 40, False), (3, True, 40, False), (3, True, 56, False),
+                                              (2, True, 64, False), (2, False, 40, True), (3, True, 56, True)],
+                         ids=["2x1", "2x2", "1x3-rows", "1x3-rows-overlapped", "1x2-rows-overlapped", "2x1-eight-planes",
+                              "1x3-rows-overlapped-eight-planes"])
+def test_blocks_equal_whole_film(gpu, world, rows, BH, g8):
+    """(The window-sweep split is pinned to the same value on both sides -- statmc_set_filter_split, the declared
+    per-device setting: that is what makes the comparison bit for bit; tests/test_gpu_fullsize.py has the default dispatch.)"""
     from statmc_amd import pipeline, sharding
     dev = torch.device("cuda:0")
     gx, gy = _grid(world, rows)
-    whole = _film_samples(world, rows, BH)
+    whole = _film_samples(world, rows, BH, g8)
     gpu.force_filter_parts(2)
     try:
-        one = pipeline.BlockPipeline(sharding.BlockLayout(0, 1, gx * BW, gy * BH, RADIUS), dev, TYPES, radius=RADIUS)
+        one = pipeline.BlockPipeline(sharding.BlockLayout(0, 1, gx * BW, gy * BH, RADIUS), dev, TYPES8 if g8 else TYPES, radius=RADIUS,
+                                     **(dict(g_buffers=G8) if g8 else {}))
         one.accumulate({k: v.to(dev) for k, v in whole.items()})
         ref = one.denoise().cpu().numpy()
     finally:
@@ -91,7 +102,7 @@ def test_blocks_equal_whole_film(gpu, world, rows, BH):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(rk, world, rows, port, q, BH)) for rk in range(world)]
+    procs = [ctx.Process(target=_worker, args=(rk, world, rows, port, q, BH, g8)) for rk in range(world)]
     for p in procs:
         p.start()
     got = []

@@ -6,7 +6,7 @@ choice the tree leaves open is a run-time option of this build (statmc_filter_sp
 sides, per-pixel / Welch dof, border policy, n < 2).  Given dumps written by the CUDA build --
 `<stem>-<spp>-{film,t0-b0-n,t0-b0-mean,t0-b0-m2,t0-b0-m3,t1-b0-film-mean,t2-b0-film-mean}.pfm` (inputs,
 scenes/render-for-ours.pbrt:24) and `<ref>-<spp>-{film-f,t0-b0-mean-corr,t0-b0-discriminator}.pfm` (its outputs) --
-this runs every spec x significance level through tools/bin/statmc_denoise --compare and prints the per-channel
+this runs every spec x significance level through tools/bin/statmc_denoise --sweep --compare (one process) and prints the per-channel
 relative L2 table, best first.  BASELINE.json's bound is 1e-5 per channel.  Every candidate runs on the general
 kernel (--kernel general), whose sums are formed in one order for every spec: the differences in the table are the
 specs', not the kernels' (the fast kernels agree with it within 1e-6, which is more than rounding-twin specs differ by).
@@ -46,22 +46,28 @@ def main():
     ap.add_argument("--exe", default=os.path.join(ROOT, "tools", "bin", "statmc_denoise"))
     args = ap.parse_args()
     rows = []
-    for sig in args.significance.split(","):
-        for spec in variants(args.quick):
-            cmd = [args.exe, "--stem", args.stem, "--spp", args.spp, "--filtersd", args.filtersd, "--filterradius",
-                   args.filterradius, "--significance", sig, "--spec", spec, "--compare", args.ref, "--no-write", "--kernel", "general",
-                   "--output", "film-f,t0-b0-mean-corr,t0-b0-discriminator"]
-            if args.tquantiles:
-                cmd += ["--tquantiles", args.tquantiles]
-            out = subprocess.run(cmd, capture_output=True, text=True)
-            if out.returncode != 0:
-                print("FAILED", spec, out.stderr.strip()[-200:], file=sys.stderr)
-                continue
-            errs = {}
-            for m in re.finditer(r"compare (\S+) ch(\d) rel_l2 (\S+)", out.stdout):
-                errs.setdefault(m.group(1), []).append(float(m.group(3)))     # worst over channels and iterations
-            worst = {k: max(v) for k, v in errs.items()}
-            rows.append((worst.get("film-f", float("inf")), sig, spec, worst))
+    # ONE process for the whole grid (statmc_denoise --sweep): a process per candidate spent 0.35 s each on bringing the
+    # device up -- 2 min for 192 candidates of a small dump
+    cmd = [args.exe, "--stem", args.stem, "--spp", args.spp, "--filtersd", args.filtersd, "--filterradius", args.filterradius,
+           "--sweep", "quick" if args.quick else "all", "--sweep-significance", args.significance, "--compare", args.ref, "--no-write",
+           "--kernel", "general", "--output", "film-f,t0-b0-mean-corr,t0-b0-discriminator"]
+    if args.tquantiles:
+        cmd += ["--tquantiles", args.tquantiles]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    if out.returncode != 0:
+        print("FAILED", out.stderr.strip()[-400:], file=sys.stderr)
+        return 1
+    want = set(variants(args.quick))
+    for block in out.stdout.split("==== sweep significance ")[1:]:
+        head, _, body = block.partition("\n")
+        sig, _, spec = head.partition(" spec ")
+        spec = spec.strip()
+        assert spec in want, spec
+        errs = {}
+        for m in re.finditer(r"compare (\S+) ch(\d) rel_l2 (\S+)", body):
+            errs.setdefault(m.group(1), []).append(float(m.group(3)))     # worst over channels and iterations
+        worst = {k: max(v) for k, v in errs.items()}
+        rows.append((worst.get("film-f", float("inf")), sig.strip(), spec, worst))
     rows.sort(key=lambda r: r[0])
     print("%-12s %-3s %-80s %s" % ("film-f", "sig", "spec", "mean-corr / discriminator"))
     for w, sig, spec, worst in rows:

@@ -99,6 +99,13 @@ def main():
               "arithmetic differs (mean-corr / discriminator columns: pre-pass; film-f only: window filter)." % BOUND)
         return 3
     ints = spec_ints(spec)
+    # the description ends up inside a C string literal: backslash and double quote escaped, anything else outside
+    # printable ASCII replaced (a dump stem is a file name of the user's)
+    def c_string(text):
+        return "".join(("\\" + ch) if ch in '\\"' else (ch if 32 <= ord(ch) < 127 else "?") for ch in text)
+    # written next to the target and renamed into place only when everything after it has succeeded (or --no-rebuild):
+    # a rebuild that fails halfway leaves the tracked header as it was
+    final_header, args.header = args.header, args.header + ".new"
     with open(args.header, "w") as h:
         h.write("/* statmc_pinned_spec.h -- the filter spec and significance level a freshly set-up device (and the CPU oracle) start\n"
                 " * with.  WRITTEN by tools/pin_from_dumps.sh: the spec that reproduces the dumps named below is the default of\n"
@@ -107,10 +114,21 @@ def main():
                 "#define STATMC_PINNED_SPEC {%s}\n#define STATMC_PINNED_SIGNIFICANCE %d\n"
                 "#define STATMC_PINNED_FROM \"%s\"\n#endif\n"
                 % (", ".join(str(i) for i in ints), int(sig),
-                   "%s, significance %s: film-f within %.2e of %d stem(s) of dumps (%s)" % (spec, sig, w["film-f"], len(sets), ",".join(sorted(sets)))))
-    print("wrote", args.header)
+                   c_string("%s, significance %s: film-f within %.2e of %d stem(s) of dumps (%s)" % (spec, sig, w["film-f"], len(sets), ",".join(sorted(sets))))))
     if args.no_rebuild:
+        os.replace(args.header, final_header)
+        print("wrote", final_header)
         return 0
+    backup = None
+    if os.path.exists(final_header):
+        backup = open(final_header).read()
+    os.replace(args.header, final_header)
+    print("wrote", final_header)
+
+    def restore():
+        if backup is not None:
+            open(final_header, "w").write(backup)
+            print("rebuild failed: %s restored (rebuild once more to get the library back in step with it)" % final_header)
     env = dict(os.environ, PYTHONPATH=ROOT)
     for cmd in ([sys.executable, os.path.join(ROOT, "__graft_entry__.py")],
                 [sys.executable, os.path.join(ROOT, "tests", "golden", "make_golden.py")],
@@ -118,6 +136,7 @@ def main():
         print("+", " ".join(cmd), flush=True)
         rc = subprocess.call(cmd, cwd=ROOT, env=env)
         if rc != 0:
+            restore()
             return rc
     print("pinned: library, oracle and tests/golden/ now follow %s" % spec)
     return 0

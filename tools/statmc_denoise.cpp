@@ -36,8 +36,7 @@
 
 using namespace statmc;
 
-extern "C" int statmc_debug_force_filter_parts(int k);   // test hook of the library: window-sweep parts per tile
-extern "C" int statmc_debug_force_filter_variant(int v);  // test hook: 1 = the general kernel for every call
+#include "statmc_debug.h"   // --kernel general: the A/B switch of the library (per device; the split is a declared setting of statmc.h)
 
 static std::vector<std::string> split(const std::string &s) {
     std::vector<std::string> out;
@@ -118,7 +117,7 @@ int main(int argc, char **argv) {
         std::string stem, sppList, output = "film-f", config = "denoise", compareStem, tqFile, specText, gridText, devicesText;
         bool noWrite = false;
         int forceParts = 0, bands = 0;
-        std::string kernel;
+        std::string kernel, sweep, sweepSignificance = "0,1,2";
         int significance = 0;
         StatPathParams params = shippedConfig("denoise");
         bool catalogue = false, warmup = false, configGiven = false;
@@ -146,6 +145,8 @@ int main(int argc, char **argv) {
             else if (a == "--significance") significance = std::stoi(next());
             else if (a == "--tquantiles") tqFile = next();
             else if (a == "--spec") specText = next();
+            else if (a == "--sweep") sweep = next();            // "all" | "quick": every filter spec x significance level in ONE process (tools/fit_spec.py)
+            else if (a == "--sweep-significance") sweepSignificance = next();
             else if (a == "--grid") gridText = next();          // GXxGY: the denoise pass sharded over film blocks
             else if (a == "--devices") devicesText = next();    // devices the blocks go to, round robin (default: one)
             else if (a == "--parts") forceParts = std::stoi(next());
@@ -206,20 +207,40 @@ int main(int argc, char **argv) {
         est.AllocateBuffers(reg);
         est.SetPipelineBands(bands);
         std::cout << "pipeline bands: " << est.PipelineBands() << std::endl;
+        std::vector<float> tq;
         if (!tqFile.empty()) {
             std::ifstream in(tqFile);
             if (!in) throw std::runtime_error("cannot open " + tqFile);
-            std::vector<float> q;
-            for (float v; in >> v;) q.push_back(v);
-            if (q.empty()) throw std::runtime_error(tqFile + ": no quantiles");
-            // the table the pre-pass will read: one-sided tables sit behind the two-sided ones
-            const statmc_filter_spec sp = stat_denoiser::parseFilterSpec(specText);
-            stat_denoiser::setTQuantiles(significance + (sp.sides ? 3 : 0), q);
+            for (float v; in >> v;) tq.push_back(v);
+            if (tq.empty()) throw std::runtime_error(tqFile + ": no quantiles");
         }
-        stat_denoiser::setSignificance(significance);
-        stat_denoiser::setFilterSpec(stat_denoiser::parseFilterSpec(specText));
+        // one (significance level, spec) per run; --sweep: the whole grid of tools/fit_spec.py in this process
+        std::vector<std::pair<int, std::string>> runs;
+        if (sweep.empty()) {
+            runs.push_back({significance, specText});
+        } else {
+            if (sweep != "all" && sweep != "quick") throw std::runtime_error("--sweep all | quick");
+            const char *names[6] = {"gate", "channels", "sides", "dof", "border", "small_n"};
+            const char *vals[6][2] = {{"sym", "asym"}, {"and", "joint"}, {"two", "one"}, {"pixel", "welch"}, {"clip", "clamp"}, {"accept", "exclude"}};
+            const int nFree = sweep == "quick" ? 3 : 6;
+            for (const auto &sg : split(sweepSignificance))
+                for (int m = 0; m < (1 << nFree); m++) {
+                    std::string t;
+                    for (int f = 0; f < nFree; f++)   // first field slowest, like itertools.product
+                        t += std::string(f ? "," : "") + names[f] + "=" + vals[f][(m >> (nFree - 1 - f)) & 1];
+                    runs.push_back({std::stoi(sg), t});
+                }
+        }
+        auto applyRun = [&](int sig, const std::string &spec) {
+            const statmc_filter_spec sp = stat_denoiser::parseFilterSpec(spec);
+            // the table the pre-pass will read: one-sided tables sit behind the two-sided ones
+            if (!tq.empty()) stat_denoiser::setTQuantiles(sig + (sp.sides ? 3 : 0), tq);
+            stat_denoiser::setSignificance(sig);
+            stat_denoiser::setFilterSpec(sp);
+        };
+        applyRun(runs[0].first, runs[0].second);
         const std::vector<std::string> outputs = split(output);
-        if (forceParts > 0) statmc_debug_force_filter_parts(forceParts);
+        if (forceParts > 0 && statmc_set_filter_split(forceParts) != STATMC_OK) throw std::runtime_error(statmc_last_error());
         if (kernel == "general") statmc_debug_force_filter_variant(1);
         else if (!kernel.empty()) throw std::runtime_error("--kernel general (or nothing)");
         std::unique_ptr<FilmShards> shards;
@@ -291,14 +312,20 @@ int main(int argc, char **argv) {
                 if (!noWrite && !(comparing && other == mine)) writePfm(mine, width, height, host.channels(), pixels);
             }
         };
-        if (warmup) {  // --warmup (statpath.cpp:543-547)
-            std::cout << "==== Warm-Up Start ====" << std::endl;
-            iteration(spps[0], false);
-            std::cout << "==== Warm-Up End ====" << std::endl;
-        }
-        for (size_t i = 0; i < spps.size(); i++) {
-            std::cout << "Iteration: " << (i + 1) << std::endl;
-            iteration(spps[i], true);
+        for (const auto &run : runs) {
+            if (!sweep.empty()) {
+                std::cout << "==== sweep significance " << run.first << " spec " << run.second << std::endl;
+                applyRun(run.first, run.second);
+            }
+            if (warmup) {  // --warmup (statpath.cpp:543-547)
+                std::cout << "==== Warm-Up Start ====" << std::endl;
+                iteration(spps[0], false);
+                std::cout << "==== Warm-Up End ====" << std::endl;
+            }
+            for (size_t i = 0; i < spps.size(); i++) {
+                std::cout << "Iteration: " << (i + 1) << std::endl;
+                iteration(spps[i], true);
+            }
         }
         return 0;
     } catch (const std::exception &e) {
