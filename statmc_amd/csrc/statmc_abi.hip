@@ -651,6 +651,9 @@ static int window_filter_impl(const statmc_filter_args *a, int channels) {
             statmc::set_feature_layout(k);
             k.n_parts = parts_for_whole_image(k, dstate.cus, false);
         } else {
+            // pair-symmetric kernel only: eight feature planes (their factors come from sym_feature_slots) or the Welch
+            // build, whose six planes take the two-RGB-image factors like every six-plane build
+            if (k.dof == STATMC_DOF_WELCH) statmc::set_feature_layout(k);
             k.n_parts = 1;
         }
     } else {

@@ -245,13 +245,13 @@ __device__ __forceinline__ void gate_weight(const LaneT &st, const v4f *mcn, con
     constexpr bool PAIR = MODE == kModePair;
     constexpr int NC = PAIR ? 2 : 3;
     if constexpr (mode_welch(MODE)) {
-        // one pixel at a time: three independent chains of ~20 instructions each, and the fewest live registers
-#pragma unroll
-        for (int k = 0; k < kPx; k++) if (M::on(k)) {
-            v2f u[3];
+        // Software pipeline over the lane's pixels: the table look-ups of pixel k are in flight (six loads from the L1-resident
+        // band of the table) while pixel k - 1 is tested -- issued one pixel at a time they cost a full memory latency per
+        // channel (the file is compiled without the machine scheduler: source order is issue order).
+        v2f t2[2][3];
+        auto lookup = [&](int k, v2f (&out)[3]) {
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-                const v2f d = sub_bc(st.ms[k][ch], 0, pair_of<H>(mcn[ch]));
                 const v2f sn = rsub_bc(pair_of<H>(mcn[3 + ch]), st.ms[k][ch], 1);      // -(v_p + v_q)
                 const v2f den = add_bc(st.pe[k][ch >> 1], ch & 1, pair_of<H>(en[ch]));   // E_p + E_q
                 const v2f s2 = sn * sn;
@@ -263,8 +263,16 @@ __device__ __forceinline__ void gate_weight(const LaneT &st, const v4f *mcn, con
                 // v_cvt_i32_f32 of a NaN is 0, of +inf INT_MAX (spelled out: the C++ conversion of such a value is undefined);
                 // the integer clamp (v_med3_i32) turns them into dof 1 and 4096
                 const int ix = min(max(cvt_i32(nx), 1), 4096), iy = min(max(cvt_i32(ny), 1), 4096);
-                const v2f t2 = v2f{tq2[ix], tq2[iy]};
-                u[ch] = __builtin_elementwise_fma(d, d, t2 * sn);
+                out[ch] = v2f{tq2[ix], tq2[iy]};
+            }
+        };
+        auto test = [&](int k, const v2f (&tt)[3]) {
+            v2f u[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const v2f d = sub_bc(st.ms[k][ch], 0, pair_of<H>(mcn[ch]));
+                const v2f sn = rsub_bc(pair_of<H>(mcn[3 + ch]), st.ms[k][ch], 1);      // (again: cheaper than keeping it)
+                u[ch] = __builtin_elementwise_fma(d, d, tt[ch] * sn);
             }
             w[k] = v2f{__builtin_amdgcn_exp2f(e[k].x), __builtin_amdgcn_exp2f(e[k].y)};
             if constexpr (MODE == kModeWelchJoint) {
@@ -275,7 +283,15 @@ __device__ __forceinline__ void gate_weight(const LaneT &st, const v4f *mcn, con
                 const float m1 = __builtin_fmaxf(__builtin_fmaxf(u[0].y, u[1].y), u[2].y);
                 w[k] = v2f{M::in0(k) && m0 <= 0.f ? w[k].x : 0.f, M::in1(k) && m1 <= 0.f ? w[k].y : 0.f};
             }
+        };
+        int prev = -1;      // (constant after unrolling)
+#pragma unroll
+        for (int k = 0; k < kPx; k++) if (M::on(k)) {
+            lookup(k, t2[k & 1]);
+            if (prev >= 0) test(prev, t2[prev & 1]);
+            prev = k;
         }
+        if (prev >= 0) test(prev, t2[prev & 1]);
         return;
     }
     if constexpr (mode_asym(MODE)) {

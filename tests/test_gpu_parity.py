@@ -730,11 +730,18 @@ def test_filter_generic_gbuffer_sets(gpu, oracle, channels):
     assert v2 == ("sym_r20_g8" if channels == 3 else "sym_r20_f_g8") and rel_l2(out2, ref2) <= TOL
     out2b, v2b = run_filter(gpu, mc, disc, colour, gbs2, dr2, 10.0, 20, channels=channels, force=3)
     assert v2b == ("lds_r20" if channels == 3 else "lds_r20_f") and rel_l2(out2b, ref2) <= TOL  # slot layout of the one-sided kernel
-    # seven channels do not fit
+    # seven channels: two RGB + one 1-channel image is an eight-plane set of the pair-symmetric kernel (runtime radius since round 4)
     gbs7 = [gbs[0], rng.random((H, W, 3), dtype=np.float32), gbs[1]]
     ref7 = oracle.filter_image(mc, disc, colour, gbs7, g_dr, -0.5 / 16.0, r)
     out7, v7 = run_filter(gpu, mc, disc, colour, gbs7, g_dr, 4.0, r, channels=channels)
-    assert v7 == "generic" and rel_l2(out7, ref7) <= TOL
+    assert v7 == ("sym_rt_g8" if channels == 3 else "sym_rt_f_g8") and rel_l2(out7, ref7) <= TOL
+    out7g, v7g = run_filter(gpu, mc, disc, colour, gbs7, g_dr, 4.0, r, channels=channels, force=2)   # ... which the one-sided kernel has no slots for
+    assert v7g == "generic" and rel_l2(out7g, ref7) <= TOL
+    # three RGB images (nine channels) fit nowhere
+    gbs9 = [gbs[0], gbs7[1], rng.random((H, W, 3), dtype=np.float32)]
+    ref9 = oracle.filter_image(mc, disc, colour, gbs9, g_dr, -0.5 / 16.0, r)
+    out9, v9 = run_filter(gpu, mc, disc, colour, gbs9, g_dr, 4.0, r, channels=channels)
+    assert v9 == "generic" and rel_l2(out9, ref9) <= TOL
     # no G-buffers at all
     ref0 = oracle.filter_image(mc, disc, colour, [], [], -0.5 / 16.0, r)
     out0, _ = run_filter(gpu, mc, disc, colour, [], [], 4.0, r, channels=channels)
