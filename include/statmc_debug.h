@@ -25,6 +25,10 @@ int statmc_debug_last_filter_parts(void);
 int statmc_debug_accumulate_resident_blocks(int n);
 /* 1 (default): RGB sample planes stream through LDS-DMA; 0: loads into registers (same bits). */
 int statmc_debug_accumulate_dma(int on);
+/* Film-major launch shape: grid_mode -1 = chosen by the batch length (default); 1 = one pass per workgroup, stat types
+ * round-robin; 0 = capped grid with slots per type and a grid-stride walk.  dma_first 1 = the first rows of the LDS-DMA
+ * ring are requested before the state loads (A/B; default 0). */
+int statmc_debug_accumulate_launch(int grid_mode, int dma_first);
 /* 2: the mean-only feature types of the film-major kernel prefetch twice as deep (default 1). */
 int statmc_debug_accumulate_umul(int umul);
 /* Tile-fed accumulation: prefetch depth of the mean-only types (1 | 2, default 2), item order, workgroups per CU. */

@@ -37,6 +37,7 @@ struct DeviceState {
     // device's dispatch does not reach a second Estimator on another device
     int force_variant = 0;                                    // statmc_debug_force_filter_variant
     int acc_resident_blocks = 0, acc_umul = 1, acc_dma = 1;   // film-major accumulation
+    int acc_grid_mode = -1, acc_dma_first = 0;                // launch shape: -1 automatic (by batch length), 0 capped grid, 1 one pass per workgroup; A/B: ring rows requested before the state
     int tiles_umul = 2, tiles_order = 0, tiles_wg_per_cu = 0; // tile-fed accumulation (deeper prefetch of the mean-only types by default)
 };
 std::unordered_map<int, DeviceState> g_dev;  // guarded by g_mu
@@ -1196,6 +1197,8 @@ int statmc_accumulate_row_ranges(uint16_t width, uint16_t height, const statmc_s
     k.resident_blocks = dstate.acc_resident_blocks;
     k.umul = dstate.acc_umul;
     k.dma = dstate.acc_dma;
+    k.grid_mode = dstate.acc_grid_mode;
+    k.dma_first = dstate.acc_dma_first;
     HIP_TRY(statmc::launch_accumulate(k, S(stream)));
     return STATMC_OK;
 }
@@ -1322,6 +1325,9 @@ int statmc_debug_accumulate_resident_blocks(int n) {  // 0 large grid (default),
 }
 int statmc_debug_accumulate_dma(int on) {   // 1 (default): RGB sample planes stream through LDS-DMA; 0: loads into registers
     STATMC_DEBUG_SET(d.acc_dma = on ? 1 : 0);
+}
+int statmc_debug_accumulate_launch(int grid_mode, int dma_first) {   // A/B of the film-major launch shape (round 4)
+    STATMC_DEBUG_SET(d.acc_grid_mode = grid_mode < 0 ? -1 : grid_mode == 1 ? 1 : 0; d.acc_dma_first = dma_first ? 1 : 0);
 }
 int statmc_debug_accumulate_umul(int umul) {   // film-major kernel: 2 = the mean-only feature types prefetch twice as deep
     STATMC_DEBUG_SET(d.acc_umul = umul == 2 ? 2 : 1);

@@ -44,6 +44,8 @@ struct AccumulateArgs {
     int resident_blocks;  // 0: large interleaved grid; > 0: that many workgroups walk all types
     int umul;             // 2: the mean-only feature types prefetch twice as deep (statmc_debug_accumulate_umul; A/B)
     int dma;              // RGB sample planes arrive by LDS-DMA (default 1; 0: loads into registers, A/B)
+    int grid_mode;        // -1: by batch length (default); 0: capped grid, slots per type in proportion to cost, grid-stride; 1: one pass per workgroup, types round-robin
+    int dma_first;        // the first rows of the LDS-DMA ring are requested before the state loads
     // large grid: workgroup b serves slot b % n_slots; slots are dealt to types in proportion to cost
     int n_slots;
     int type_slots[kMaxStatTypes];

@@ -376,12 +376,41 @@ __device__ __forceinline__ void add_sample2(PairState *st, const v2f *nf, const 
 // (they are the first n_active lanes).  Without DMA an inactive lane returns at once.
 template <int C, int MAXM, bool TRANSFORM, int UMUL = 1, bool DMA = false>
 __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long long p0_in, const float *sp,
-                                                long long stride, int S, float *ring = nullptr, bool active = true, int n_active = 64) {
+                                                long long stride, int S, float *ring = nullptr, bool active = true, int n_active = 64,
+                                                bool dma_first = false) {
     constexpr bool kDma = DMA && C == 3;
     if constexpr (!kDma) {
         if (!active) return;
     }
     const long long p0 = active ? p0_in : 0;   // an inactive lane of the cooperative walk touches no state: its loads read group 0, it stores nothing
+    // LDS-DMA walk: the geometry of the wave's sample rows.  (dma_first: the first D rows requested BEFORE the state loads, so
+    // that the two latencies a wave pays before its first fold overlap instead of adding up -- measured in round 4 at 4 .. 256
+    // samples per pixel, 720p / 1080p / 4K: within +- 0.5 % of requesting them behind the state, profiles/r04_acc_launch.log;
+    // kept as a switch of the A/B hook, off.)
+    [[maybe_unused]] int dma_piece[3] = {0, 0, 0};
+    [[maybe_unused]] const float *dma_row0 = nullptr;
+    auto dma_issue = [&](int s, int slot) {
+        const float *src = dma_row0 + (long long)s * stride;
+        float *dst = ring + slot * 768;
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            __builtin_amdgcn_global_load_lds(src + dma_piece[k], (__attribute__((address_space(3))) void *)(dst + 256 * k), 16, 0, 2);
+    };
+    if constexpr (kDma) {
+        const int lane = threadIdx.x & 63;
+        dma_row0 = sp - 12 * lane;                          // the wave's row of sample 0 (lane l sits 12 l floats in; the same value in every lane)
+        const int row_floats = 12 * n_active;               // the part of the wave's row that exists
+        // Every lane issues all three transfers of a row, whatever part of the row exists: the waits of the walk COUNT
+        // transfers (vmcnt), so their number per row must not depend on n_active.  A piece beyond the row's end re-reads the
+        // row's first 16 bytes (memory that exists) into a part of the slot nobody reads.
+#pragma unroll
+        for (int k = 0; k < 3; k++) dma_piece[k] = 256 * k + 4 * lane < row_floats ? 256 * k + 4 * lane : 0;
+        if (dma_first) {
+#pragma unroll
+            for (int d = 0; d < kAccDmaD; d++)
+                if (d < S) dma_issue(d, d);
+        }
+    }
     constexpr int NE = 4 * C;  // elements per lane
     const long long e0 = p0 * C;
     PairState st[NE / 2];   // element pairs (2 i, 2 i + 1) of the lane's 4 C consecutive elements
@@ -486,32 +515,21 @@ __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long lo
     auto walk_samples_dma = [&](auto same) {
         constexpr int D = kAccDmaD;
         const int lane = threadIdx.x & 63;
-        const float *row0 = sp - 12 * lane;                 // the wave's row of sample 0 (lane l sits 12 l floats in; the same value in every lane)
-        const int row_floats = 12 * n_active;               // the part of the wave's row that exists
-        // Every lane issues all three transfers of a row, whatever part of the row exists: the waits below COUNT transfers
-        // (vmcnt), so their number per row must not depend on n_active.  A piece beyond the row's end re-reads the row's first
-        // 16 bytes (memory that exists) into a part of the slot nobody reads.
-        int piece[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) piece[k] = 256 * k + 4 * lane < row_floats ? 256 * k + 4 * lane : 0;
-        auto issue = [&](int s, int slot) {
-            const float *src = row0 + (long long)s * stride;
-            float *dst = ring + slot * 768;
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-                __builtin_amdgcn_global_load_lds(src + piece[k], (__attribute__((address_space(3))) void *)(dst + 256 * k), 16, 0, 2);
-        };
+        auto issue = dma_issue;
         auto take = [&](vfloat4 (&q)[C], int slot) {
             const float *mine = ring + slot * 768 + 12 * lane;
 #pragma unroll
             for (int k = 0; k < C; k++) q[k] = *reinterpret_cast<const vfloat4 *>(mine + 4 * k);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read before the slot is refilled
         };
-        // every earlier access of the wave to memory (the state loads above) has completed before the counted waits start
+        // every earlier access of the wave to memory (the state loads above; with dma_first also the first D rows, requested
+        // ahead of them) has completed before the counted waits start
         acc_wait_vmcnt<0>();
+        if (!dma_first) {
 #pragma unroll
-        for (int d = 0; d < D; d++)
-            if (d < S) issue(d, d);
+            for (int d = 0; d < D; d++)
+                if (d < S) issue(d, d);
+        }
         const int S_full = S >= D ? S - D + 1 : 0;          // samples s < S_full have D - 1 later rows in flight behind them
         int s = 0;
         for (; s + D <= S_full; s += D) {
@@ -593,7 +611,7 @@ __device__ __forceinline__ void accumulate_pixel(const AccumulateType &t, long l
 // Film-major batch: one lane owns 4 consecutive PIXELS of one stat type and walks the batch's
 // samples in order (sample s of pixel p, channel c is at samples[s*n_elems + p*C + c]).
 template <int C, int MAXM, bool TRANSFORM, bool VEC, int UMUL, bool DMA>
-__device__ __forceinline__ void accumulate_type(const AccumulateType &t, long long blk, long long nblk, float *ring) {
+__device__ __forceinline__ void accumulate_type(const AccumulateType &t, long long blk, long long nblk, float *ring, bool dma_first) {
     const long long n_px = t.n_elems / C;
     const long long n_groups = (n_px + 3) >> 2;
     const long long n_full = VEC ? (n_px >> 2) : 0;          // complete 4-pixel groups: the vector path's share
@@ -607,7 +625,7 @@ __device__ __forceinline__ void accumulate_type(const AccumulateType &t, long lo
         const int n_active = left >= 64 ? 64 : left > 0 ? (int)left : 0;
         if (n_active > 0)
             accumulate_lane<C, MAXM, TRANSFORM, (!TRANSFORM && MAXM == 1) ? UMUL : 1, DMA>(t, p0, t.samples + p0 * C, t.stride, t.n_samples,
-                                                                                            ring, active, n_active);
+                                                                                            ring, active, n_active, dma_first);
         if (!active && g < n_groups) {   // unaligned images, the ragged last group
             for (long long p = p0; p < n_px && p < p0 + 4; p++)
                 accumulate_pixel<C, MAXM, TRANSFORM>(t, p, t.samples + p * C, t.stride, t.n_samples);
@@ -616,15 +634,15 @@ __device__ __forceinline__ void accumulate_type(const AccumulateType &t, long lo
 }
 
 template <int C, bool VEC, int UMUL, bool DMA>
-__device__ __forceinline__ void accumulate_dispatch(const AccumulateType &t, long long blk, long long nblk, float *ring) {
+__device__ __forceinline__ void accumulate_dispatch(const AccumulateType &t, long long blk, long long nblk, float *ring, bool dma_first) {
     if (t.transform) {
-        if (t.max_moment >= 3) accumulate_type<C, 3, true, VEC, UMUL, DMA>(t, blk, nblk, ring);
-        else if (t.max_moment == 2) accumulate_type<C, 2, true, VEC, UMUL, DMA>(t, blk, nblk, ring);
-        else accumulate_type<C, 1, true, VEC, UMUL, DMA>(t, blk, nblk, ring);
+        if (t.max_moment >= 3) accumulate_type<C, 3, true, VEC, UMUL, DMA>(t, blk, nblk, ring, dma_first);
+        else if (t.max_moment == 2) accumulate_type<C, 2, true, VEC, UMUL, DMA>(t, blk, nblk, ring, dma_first);
+        else accumulate_type<C, 1, true, VEC, UMUL, DMA>(t, blk, nblk, ring, dma_first);
     } else {
-        if (t.max_moment >= 3) accumulate_type<C, 3, false, VEC, UMUL, DMA>(t, blk, nblk, ring);
-        else if (t.max_moment == 2) accumulate_type<C, 2, false, VEC, UMUL, DMA>(t, blk, nblk, ring);
-        else accumulate_type<C, 1, false, VEC, UMUL, DMA>(t, blk, nblk, ring);
+        if (t.max_moment >= 3) accumulate_type<C, 3, false, VEC, UMUL, DMA>(t, blk, nblk, ring, dma_first);
+        else if (t.max_moment == 2) accumulate_type<C, 2, false, VEC, UMUL, DMA>(t, blk, nblk, ring, dma_first);
+        else accumulate_type<C, 1, false, VEC, UMUL, DMA>(t, blk, nblk, ring, dma_first);
     }
 }
 
@@ -644,9 +662,20 @@ __global__ __launch_bounds__(kBlock, STATMC_ACC_WAVES) void accumulate_kernel(Ac
     if (a.resident_blocks > 0) {
         for (int i = 0; i < a.n_types; i++) {
             const AccumulateType &t = a.t[(blockIdx.x + i) % a.n_types];
-            if (t.channels == 3) accumulate_dispatch<3, VEC, UMUL, DMA>(t, blockIdx.x, gridDim.x, ring);
-            else accumulate_dispatch<1, VEC, UMUL, DMA>(t, blockIdx.x, gridDim.x, ring);
+            if (t.channels == 3) accumulate_dispatch<3, VEC, UMUL, DMA>(t, blockIdx.x, gridDim.x, ring, a.dma_first != 0);
+            else accumulate_dispatch<1, VEC, UMUL, DMA>(t, blockIdx.x, gridDim.x, ring, a.dma_first != 0);
         }
+        return;
+    }
+    if (a.grid_mode == 1) {
+        // One pass per workgroup: block b serves stat type b % n_types, groups [256 (b / n_types), + 256) -- every
+        // workgroup of a type does the same amount of work, none walks a second, ragged stride.  The dispatcher hands the
+        // blocks out in order, so the resident mix always holds every type and the launch ends within one workgroup's time.
+        const int ti = blockIdx.x % a.n_types;
+        const AccumulateType &t = a.t[ti];
+        const long long blk = blockIdx.x / a.n_types, nblk = gridDim.x / a.n_types;
+        if (t.channels == 3) accumulate_dispatch<3, VEC, UMUL, DMA>(t, blk, nblk, ring, a.dma_first != 0);
+        else accumulate_dispatch<1, VEC, UMUL, DMA>(t, blk, nblk, ring, a.dma_first != 0);
         return;
     }
     // Workgroups are dealt to the stat types in rounds of n_slots, each type holding a number of
@@ -657,8 +686,8 @@ __global__ __launch_bounds__(kBlock, STATMC_ACC_WAVES) void accumulate_kernel(Ac
     const AccumulateType &t = a.t[ti];
     const long long blk = (long long)round * a.type_slots[ti] + a.slot_rank[slot];
     const long long nblk = (long long)n_rounds * a.type_slots[ti];
-    if (t.channels == 3) accumulate_dispatch<3, VEC, UMUL, DMA>(t, blk, nblk, ring);
-    else accumulate_dispatch<1, VEC, UMUL, DMA>(t, blk, nblk, ring);
+    if (t.channels == 3) accumulate_dispatch<3, VEC, UMUL, DMA>(t, blk, nblk, ring, a.dma_first != 0);
+    else accumulate_dispatch<1, VEC, UMUL, DMA>(t, blk, nblk, ring, a.dma_first != 0);
 }
 
 int acc_diagnostic_bits() { return STATMC_ACC_SKIP_STORES ? 128 : 0; }
@@ -699,7 +728,17 @@ hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
         if (groups > max_groups) max_groups = groups;
     }
     const int rounds = (grid_for(max_groups, 256 * 8) * a.n_types + a.n_slots - 1) / a.n_slots;
-    const dim3 grid(a.resident_blocks > 0 ? a.resident_blocks : rounds * a.n_slots);
+    const long long units = (max_groups + kBlock - 1) / kBlock;     // workgroups that cover the largest type once
+    // Launch shape.  Long batches: a capped grid, every type holding slots in proportion to its cost, grid-stride walk
+    // (the resident mix favours the ALU-heavy radiance type: + 1 - 2 % at 64 and 256 samples per pixel).  Short batches --
+    // the 4-, 4-, 8-, 16-sample iterations the reference's progressive schedule starts with (statpath.cpp:272-279) -- are
+    // bound by the chain of latencies a workgroup pays per pass, and the capped grid gives the cheap 1-channel types up to
+    // three passes per workgroup: there every workgroup makes ONE pass, types round-robin (1080p: 4 spp 5.1 -> 6.6 TB/s,
+    // 8 spp 6.1 -> 7.0, 16 spp 6.2 -> 6.6; 4K: 4 spp 4.9 -> 5.7, 16 spp 5.74 -> 5.63; profiles/r04_acc_launch.log).
+    int max_s = 0;
+    for (int i = 0; i < a.n_types; i++) max_s = a.t[i].n_samples > max_s ? a.t[i].n_samples : max_s;
+    if (a.grid_mode < 0) a.grid_mode = (max_s <= 8 || (max_s <= 16 && max_groups <= (1 << 20))) ? 1 : 0;
+    const dim3 grid(a.resident_blocks > 0 ? a.resident_blocks : a.grid_mode == 1 ? (unsigned)(units * a.n_types) : rounds * a.n_slots);
     if (vec && a.dma)
         hipLaunchKernelGGL((accumulate_kernel<true, 1, true>), grid, dim3(kBlock), kAccLdsBytes, s, a);
     else if (vec && a.umul == 2)

@@ -80,4 +80,18 @@ for nb, label in ((5, "acrr_filter_f32_5_buffers"), (12, "smis_filter_f32_12_buf
                                    [fs.g_buffer("normal"), fs.g_buffer("albedo")], g_sds=[0.1, 0.02])
     t = timeit(lambda: api.filter_f32(a), 3)
     out[label] = {"ms": round(t, 4), "variant": api.last_filter_variant(), "mpix_s_per_buffer": round(nb * W * H / t / 1e3, 1)}
+
+# The accumulation at the batch sizes the reference's progressive schedule launches (statpath.cpp:272-279: 4, 4, 8, 16, ...
+# samples per iteration): film-major and tile-fed, 1080p and 4K (bench.py's `accumulate_by_batch` leg on two films)
+import bench  # noqa: E402
+bench.torch = torch
+for W, H in ((1920, 1080), (3840, 2160)):
+    sc = synthetic.Scene(W, H, seed=1, device=dev)
+    chunks = [sc.samples(32, seed=10 + s0, features=synthetic.FEATURES) for s0 in range(0, 64, 32)]
+    smp = {t: torch.cat([c[t] for c in chunks]) for t in synthetic.FEATURES}
+    del chunks
+    fs = film.FilmStats(W, H, dev, types=synthetic.FEATURES)
+    out["accumulate_by_batch_%dx%d" % (W, H)] = bench.accumulate_by_batch(fs, smp, list(synthetic.FEATURES))
+    del smp, fs, sc
+    torch.cuda.empty_cache()
 print(json.dumps(out, indent=1))
