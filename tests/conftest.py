@@ -55,3 +55,20 @@ def make_case(width, height, spp, seed=1, features=("radiance", "normal", "albed
         st[t] = o.new_state(height, width, STAT_TYPES[t]["channels"])
         o.accumulate(st[t], smp[t], STAT_TYPES[t]["transform"], STAT_TYPES[t]["max_moment"])
     return scene, smp, st
+
+
+def edge_case_stream(W=8, H=8, S=24, seed=7):
+    """SURVEY 8c's edge cases as one small sample file: rows 0-2 log-normal radiance with 20 % zero paths, row 3 all zeros
+    (Box-Cox -> -2), row 4 constants (m2 = m3 = 0), row 5 one firefly among small values, row 6 a single sample (n = 1),
+    row 7 ragged counts 1 .. 8.  Returns (count [H, W] int32, samples [S, H, W, 3] float32)."""
+    rng = np.random.default_rng(seed)
+    smp = np.exp(rng.normal(0.0, 1.0, (S, H, W, 3))).astype(np.float32)
+    smp *= (rng.random((S, H, W, 1)) >= 0.2)
+    smp[:, 3] = 0.0
+    smp[:, 4] = (0.25 * (1 + np.arange(W, dtype=np.float32)))[None, :, None]
+    smp[:, 5] = (0.01 + 0.001 * rng.random((S, W, 3))).astype(np.float32)
+    smp[7, 5] *= 1000.0
+    count = np.full((H, W), S, np.int32)
+    count[6] = 1
+    count[7] = 1 + np.arange(W)
+    return count, np.ascontiguousarray(smp, np.float32)

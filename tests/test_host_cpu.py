@@ -170,11 +170,20 @@ def test_patches_apply_to_the_reference():
     assert r.stdout.count("applied 000") == 3 and "patches apply" in r.stdout
 
 
-def test_patched_reference_compiles_and_links_against_the_adaptor():
+def test_patched_reference_compiles_and_links_against_the_adaptor(oracle, tmp_path):
     """SURVEY 8 (f3), checked for real: the reference's own statistics/{estimator,buffer,statpath}.cpp and
     core/{film,api,integrator}.cpp, patched by patches/0001-0003, pass g++ -fsyntax-only against include/statmc_cv.hpp, and
     estimator.o + buffer.o link with a small main against libstatmc_hip.so alone.  Container only (the reference does not
-    travel); the work happens in a scratch directory."""
+    travel); the work happens in a scratch directory.
+
+    Then the reference's own StatTile<Float> / StatTile<Vec3> (estimator.h:147-239) RUN on the adaptor's cv::Vec
+    (tests/cpp/ref_stattile_main.cpp: no Estimator, no setup(), no GPU) over SURVEY 8c's edge cases -- zeros, constants, one
+    firefly, n = 1, ragged counts -- through all six Add[Transform]SampleM{1,2,3}, built by g++ (no contraction) and by clang
+    -O3 -march=x86-64-v3 -ffp-contract=on (the reference's own recipe): every pixel equals oracle_add_sample BIT FOR BIT
+    in the matching contraction mode.  This tests product code -- the operators of include/statmc_cv.hpp that the patched
+    reference's CPU accumulation runs on -- and, as a by-product, that the oracle's restatement follows the source it
+    cites.  By the rules it does NOT pin the oracle (the build needs a logging stub and this repository's cv:: stand-in):
+    `parity` stays "partial -- unpinned"."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -182,9 +191,40 @@ def test_patched_reference_compiles_and_links_against_the_adaptor():
         pytest.skip("no reference checkout here")
     from statmc_amd import build
     build.build()
-    r = subprocess.run([os.path.join(root, "tools", "check_reference_compiles.sh")], capture_output=True, text=True, timeout=900)
+    from conftest import edge_case_stream
+    count, smp = edge_case_stream()
+    S, H, W, _ = smp.shape
+    fin, fout = str(tmp_path / "stattile_in.bin"), str(tmp_path / "stattile_out")
+    with open(fin, "wb") as f:
+        f.write(np.array([W, H, S], np.int32).tobytes() + count.tobytes() + smp.tobytes())
+    r = subprocess.run([os.path.join(root, "tools", "check_reference_compiles.sh")], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, STATTILE_IN=fin, STATTILE_OUT=fout))
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("syntax ok") == 6 and "linked" in r.stdout and "reference compiles and links against the adaptor" in r.stdout
+    assert "ran         the reference's StatTile" in r.stdout
+    builds = [("gcc", False)] + ([("clang", True)] if os.path.exists(fout + ".clang") else [])
+    assert len(builds) == 2, "AMD clang is part of the image: both contraction modes are expected"
+    try:
+        for tag, contract in builds:
+            oracle.set_fp_contract(contract)
+            raw = open(fout + "." + tag, "rb").read()
+            off = 0
+            for c in (1, 3):
+                dt = oracle.TILE_PIXEL_DTYPE[c]
+                for transform in (0, 1):
+                    for moment in (1, 2, 3):
+                        got = np.frombuffer(raw, dtype=dt, count=W * H, offset=off).reshape(H, W)
+                        off += W * H * dt.itemsize
+                        for y in range(H):
+                            for x in range(W):
+                                seq = smp[:count[y, x], y, x, :c]
+                                want = oracle.add_samples_to_pixel(seq, c, transform, moment)
+                                for field in dt.names:
+                                    a, b = np.asarray(got[y, x][field]), np.asarray(want[field])
+                                    assert a.tobytes() == b.tobytes(), (tag, c, transform, moment, y, x, field, a, b)
+            assert off == len(raw)
+    finally:
+        oracle.set_fp_contract(False)
 
 
 def test_tools_built_from_other_sources_are_rebuilt(denoise_bin, tmp_path, monkeypatch):

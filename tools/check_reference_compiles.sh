@@ -8,6 +8,12 @@
 #      (tests/cpp/stubs; glog's submodule directory is empty in the checkout)
 #   3. compile estimator.cpp + buffer.cpp to objects and LINK them with tests/cpp/ref_link_main.cpp against
 #      libstatmc_hip.so alone (no OpenCV, no CUDA).  Link only: the binary is not run here.
+#   4. (when STATTILE_IN / STATTILE_OUT are set) build tests/cpp/ref_stattile_main.cpp -- the reference's own StatTile<T>
+#      on include/statmc_cv.hpp's cv::Vec, nothing else of the reference -- twice: g++ (no contraction: the survey's
+#      probe build) and AMD clang -O3 -march=x86-64-v3 (-ffp-contract=on, the reference's own recipe, scripts/_build.sh),
+#      and RUN both on the sample file STATTILE_IN -> ${STATTILE_OUT}.gcc / .clang (CPU only, no GPU call).
+#      tests/test_host_cpu.py compares them with the oracle bit for bit.  This tests PRODUCT code (the adaptor's operators);
+#      it is not a pin of the oracle (the build uses a logging stub and this repository's cv:: stand-in).
 # Exit 77 = no reference checkout (skipped).
 set -e
 REF=${1:-/root/reference}
@@ -49,3 +55,17 @@ if [ -n "$undef" ]; then echo "unresolved beyond the tev viewer:"; echo "$undef"
 echo "linked      main.o + estimator.o + buffer.o -> libstatmc_hip.so: $(nm -u ref_estimator_on_statmc | grep -c ' statmc_') statmc_* imports; left to pbrt's link line: $(grep -c "undefined reference to .pbrtv4::DisplayStatic" link.log) reference(s) to pbrtv4::DisplayStatic"
 if nm -u ref_estimator_on_statmc | grep -qiE "opencv|cuda[A-Z]|_ZN2cv"; then echo "an OpenCV / CUDA import is left"; exit 1; fi
 echo "reference compiles and links against the adaptor"
+if [ -n "${STATTILE_IN:-}" ] && [ -n "${STATTILE_OUT:-}" ]; then
+  CLANG=/opt/rocm/lib/llvm/bin/clang++
+  g++ "${FLAGS[@]}" -O2 "$ROOT/tests/cpp/ref_stattile_main.cpp" -o stattile_gcc -L"$ROOT/statmc_amd" -lstatmc_hip -Wl,-rpath,"$ROOT/statmc_amd" -Wl,--unresolved-symbols=ignore-all &
+  if [ -x "$CLANG" ]; then
+    "$CLANG" "${FLAGS[@]}" -O3 -march=x86-64-v3 -ffp-contract=on -Wno-everything "$ROOT/tests/cpp/ref_stattile_main.cpp" -o stattile_clang -L"$ROOT/statmc_amd" -lstatmc_hip -Wl,-rpath,"$ROOT/statmc_amd" -Wl,--unresolved-symbols=ignore-all &
+  fi
+  wait
+  ./stattile_gcc "$STATTILE_IN" "$STATTILE_OUT.gcc"
+  echo "ran         the reference's StatTile<Float> / StatTile<Vec3> on statmc_cv.hpp's cv::Vec (g++, no contraction)"
+  if [ -x stattile_clang ]; then
+    ./stattile_clang "$STATTILE_IN" "$STATTILE_OUT.clang"
+    echo "ran         ... and built by clang -O3 -march=x86-64-v3 -ffp-contract=on (the reference's own recipe)"
+  fi
+fi
