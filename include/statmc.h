@@ -47,6 +47,10 @@ const char *statmc_last_error(void);
  * below acts on the calling thread's current device (statmc_set_device). */
 int statmc_setup(int device);
 
+/* Compute units of the current device (0 before statmc_setup): what the launches are fitted to -- the window-sweep split,
+ * and the row bands of the Upload / Denoise / Download pipeline (include/statmc_bands.hpp). */
+int statmc_device_cus(void);
+
 /* Makes `device` current for the calling thread (HIP's current device is per thread): a thread
  * other than the one that ran statmc_setup -- e.g. a render worker whose Merge*Tiles call triggers a
  * flush -- calls this before using a device other than 0.  The device must have been set up. */
@@ -112,10 +116,13 @@ const char *statmc_pinned_from(void);
  * calls with the same split (and the same film-anchored tile grid, statmc_filter_args::film_x0 / film_y0) agree BIT FOR BIT
  * -- whatever the image shape, the region of interest or the device.  Within one image the split never depends on the
  * region a call filters (bands of the Upload / Denoise / Download pipeline = the whole-image call, bit for bit).
- * A host that needs the blocks of a sharded film to reproduce the single-device result exactly pins the split:
- *     statmc_set_filter_split(statmc_filter_split_auto(film_width, film_height, radius))   on every device,
+ * A host that needs the blocks of a sharded film and the single-device result to be the same bits pins ONE split on every
+ * device involved, the single one included:
+ *     statmc_set_filter_split(statmc_filter_split_auto(film_width, film_height, radius)),
  * at the price of a launch that is no longer fitted to the block (a 1920 x 135 strip: + 34 % filter time with the whole
- * film's split of 1).  parts = 0 (default) = automatic.  Per device; acts on the current device. */
+ * film's split of 1).  parts = 0 (default) = automatic: the fitted count, and for tile counts that leave the last round
+ * of workgroups mostly empty (1280 x 720: 900 tiles on 256 CUs) more parts for the last tile rows.  Per device; acts on
+ * the current device. */
 int statmc_set_filter_split(int parts);
 int statmc_get_filter_split(void);
 /* The split the automatic choice makes on the current device for a whole image of this size (pair-symmetric kernel). */

@@ -64,8 +64,11 @@ struct Plan {
         return std::min(height, edge(k) + halo(radius));
     }
 };
-constexpr int kFilterCUs = 256, kTileW = 128, kTileH = 8, kAutoBandsMax = 6;   // MI355X; the pair-symmetric kernel's tile
-inline Plan plan(int width, int height, int radius, int requested) {
+constexpr int kTileW = 128, kTileH = 8, kAutoBandsMax = 6;   // the pair-symmetric kernel's tile
+// cus: compute units of the device the filter runs on (statmc_device_cus(); 256 on a whole MI355X, fewer on a partitioned one)
+inline Plan plan(int width, int height, int radius, int requested, int cus = 0) {
+    const int devCUs = cus > 0 ? cus : statmc_device_cus();
+    const int kFilterCUs = devCUs > 0 ? devCUs : 256;   // (no device set up: the plan of a whole MI355X)
     Plan p;
     p.height = height;
     p.radius = radius;

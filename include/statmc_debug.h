@@ -20,6 +20,8 @@ int statmc_debug_force_filter_variant(int variant);
 int statmc_debug_force_filter_parts(int parts);
 /* Parts per tile of the calling thread's last window-filter call. */
 int statmc_debug_last_filter_parts(void);
+/* ... and its tail split: the last *tail_rows tile rows of the image swept with *parts_hi parts (0, 0: uniform). */
+int statmc_debug_last_filter_tail(int *parts_hi, int *tail_rows);
 
 /* Film-major accumulation: n > 0 runs it as n resident workgroups (0 = the large interleaved grid, default). */
 int statmc_debug_accumulate_resident_blocks(int n);

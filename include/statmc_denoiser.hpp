@@ -41,6 +41,7 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_set>
+#include <tuple>
 #include <vector>
 
 #include "statmc.h"
@@ -1066,7 +1067,16 @@ class Estimator {
     int uploadQueues = [] { const char *e = std::getenv("STATMC_UPLOAD_QUEUES"); return e && std::atoi(e) >= 2 ? 2 : 1; }();
     // where the bands lie (statmc_bands.hpp: automatic = fitted to the window filter's rounds); the same plan serves Upload,
     // Denoise and Download of an iteration because it depends on the image, the radius and the request only
-    bands::Plan bandPlan() const { return bands::plan(width, height, filterRadius, bandsRequested); }
+    // (cached: the plan is asked for at every band edge, and building it reads the environment and the device's CU count)
+    const bands::Plan &bandPlan() const {
+        if (planCache.height != height || planCacheKey != std::make_tuple(width, height, (int)filterRadius, bandsRequested)) {
+            planCache = bands::plan(width, height, filterRadius, bandsRequested);
+            planCacheKey = std::make_tuple(width, height, (int)filterRadius, bandsRequested);
+        }
+        return planCache;
+    }
+    mutable bands::Plan planCache;
+    mutable std::tuple<int, int, int, int> planCacheKey{-1, -1, -1, -1};
     int bandEdge(int k, int) const { return bandPlan().edge(k); }
     int arrivalEdge(int k, int) const { return bandPlan().arrival(k); }
     void ensurePipeline(int nb) {

@@ -63,7 +63,7 @@ class StatType(C.Structure):
 
 
 EXPORTS = [
-    "statmc_last_error", "statmc_setup", "statmc_set_device", "statmc_set_significance", "statmc_get_significance", "statmc_set_t_quantiles",
+    "statmc_last_error", "statmc_setup", "statmc_device_cus", "statmc_set_device", "statmc_set_significance", "statmc_get_significance", "statmc_set_t_quantiles",
     "statmc_set_filter_spec", "statmc_get_filter_spec", "statmc_reset_filter_spec", "statmc_pinned_from", "statmc_copy_device_settings",
     "statmc_set_filter_split", "statmc_get_filter_split", "statmc_filter_split_auto",
     "statmc_malloc", "statmc_free", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_download",

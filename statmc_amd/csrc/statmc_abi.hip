@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -21,7 +22,7 @@ namespace {
 
 thread_local char g_err[512] = "";
 thread_local const char *g_variant = "none";
-thread_local int g_last_parts = 0;
+thread_local int g_last_parts = 0, g_last_parts_hi = 0, g_last_tail_rows = 0;
 std::mutex g_mu;
 
 // Everything the library remembers is kept per device (one Estimator per device in a process that drives
@@ -193,15 +194,21 @@ int prepare_sym(const DeviceState &d, statmc::FilterArgs &k, const statmc_filter
     if (k.radius != 20 || k.dof == STATMC_DOF_WELCH) {   // (the Welch modes run the runtime-radius build at r = 20 too)
         if (int rc = spatial_table(k.radius, k.ds, &k.sym.tab_rt, true)) return rc;
     }
-    k.n_parts = parts_for_whole_image(k, d.cus, true);
-    statmc::sym_geometry(k);
-    float *ws = nullptr;
-    // sized for the whole local image whatever region this call filters: the bands of the Upload / Denoise / Download
-    // pipeline then share one allocation (growing it mid-pipeline means a stream synchronisation and a hipFree between
-    // two bands)
+    // parts -- and the tail split, if the whole image's tile count leaves its last round mostly empty -- are chosen for
+    // the WHOLE local image whatever region this call filters; so is the workspace: the bands of the Upload / Denoise /
+    // Download pipeline then share one allocation (growing it mid-pipeline means a stream synchronisation and a hipFree
+    // between two bands)
     statmc::FilterArgs whole = k;
     whole.rx0 = 0; whole.ry0 = 0; whole.rx1 = k.width; whole.ry1 = k.height;
     statmc::sym_geometry(whole);
+    statmc::sym_choose_split(whole, d.cus);
+    statmc::sym_apply_split(whole);
+    k.n_parts = whole.n_parts;
+    k.sym.parts_hi = whole.sym.parts_hi;
+    k.sym.split_ty = whole.sym.split_ty;
+    statmc::sym_geometry(k);
+    statmc::sym_apply_split(k);
+    float *ws = nullptr;
     const size_t patch_floats = (statmc::sym_patch_floats(whole, k.n_parts) + 3) & ~(size_t)3;
     const size_t image_floats = pair ? (size_t)9 * k.width * k.height : 0;
     const size_t extra_floats = k.border == STATMC_BORDER_CLAMP ? (size_t)4 * k.width * k.height : 0;
@@ -210,6 +217,8 @@ int prepare_sym(const DeviceState &d, statmc::FilterArgs &k, const statmc_filter
     k.sym.pair = pair ? 1 : 0;
     k.sym.pair_images = pair ? ws + patch_floats : nullptr;
     k.sym.border_extra = extra_floats ? reinterpret_cast<float4 *>(ws + patch_floats + image_floats) : nullptr;
+    g_last_parts_hi = whole.sym.parts_hi;
+    g_last_tail_rows = whole.sym.parts_hi ? whole.sym.ty0 + whole.sym.nty - whole.sym.split_ty : 0;
     return STATMC_OK;
 }
 int prepass_table(const DeviceState &d) { return d.alpha_index + STATMC_TQ_N_ALPHAS * (d.spec.sides ? 1 : 0); }
@@ -322,6 +331,8 @@ int statmc_setup(int device) {
     d.cus = cus;
     return STATMC_OK;
 }
+
+int statmc_device_cus(void) { return current_state().cus; }
 
 int statmc_set_device(int device) {
     {
@@ -956,13 +967,23 @@ struct PackedRowsCall {
     std::vector<statmc_image> n, mean, m2, m3, film, g, mc, disc, ff;
     std::vector<DenseTwin> twins;
 };
-std::unordered_map<WsKey, Workspace, WsHash> g_dense;   // arena of the packed twins, one per (device, stream)
+// arena of the packed twins, one per (device, stream).  `in_use` is held for the WHOLE of a with_packed_rows call: a second
+// host thread on the same stream must not grow (= free) the arena between this call's pointer fetch and its enqueues.
+struct DenseArena : Workspace {
+    std::mutex in_use;
+};
+std::unordered_map<WsKey, std::unique_ptr<DenseArena>, WsHash> g_dense;
 
-int dense_arena(size_t bytes, void *stream, char **out) {
+DenseArena *dense_arena_of(void *stream) {
     int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(g_mu);
-    Workspace &w = g_dense[WsKey{dev, stream}];
+    auto &slot = g_dense[WsKey{dev, stream}];
+    if (!slot) slot.reset(new DenseArena());
+    return slot.get();
+}
+
+int dense_arena(DenseArena &w, size_t bytes, void *stream, char **out) {   // caller holds w.in_use
     if (w.bytes < bytes) {
         if (w.ptr) {
             HIP_TRY(hipStreamSynchronize(S(stream)));
@@ -979,9 +1000,12 @@ int dense_arena(size_t bytes, void *stream, char **out) {
 void free_dense_arenas(void *stream) {
     for (auto it = g_dense.begin(); it != g_dense.end();) {
         if (it->first.stream == stream && stream != nullptr) {
-            if (it->second.ptr) {
-                (void)hipStreamSynchronize(S(stream));
-                (void)hipFree(it->second.ptr);
+            {
+                std::lock_guard<std::mutex> busy(it->second->in_use);   // a call still enqueueing on the stream finishes first
+                if (it->second->ptr) {
+                    (void)hipStreamSynchronize(S(stream));
+                    (void)hipFree(it->second->ptr);
+                }
             }
             it = g_dense.erase(it);
         } else {
@@ -1034,7 +1058,10 @@ int with_packed_rows(const statmc_filter_args *a, int channels, bool writes_stat
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));   // (NEED_READY of the entry point runs inside fn; an arena needs no library state)
     char *arena = nullptr;
-    if (int rc = dense_arena(total, a->stream, &arena)) return rc;
+    DenseArena *da = dense_arena_of(a->stream);
+    if (!da) return fail(STATMC_ERR_HIP, "no current device");
+    std::lock_guard<std::mutex> busy(da->in_use);     // until every copy and kernel of this call has been enqueued
+    if (int rc = dense_arena(*da, total, a->stream, &arena)) return rc;
     size_t off = 0;
     auto twin = [&](statmc_image &im, int ch, bool copy_back) -> int {
         if (!pitched(im, ch)) return STATMC_OK;
@@ -1339,6 +1366,12 @@ int statmc_debug_force_filter_parts(int k) { return statmc_set_filter_split(k < 
 // non-zero: the library was built with an experiment switch of statmc_sym_experiments.h (never the product build)
 int statmc_debug_diagnostic_build(void) { return statmc::sym_diagnostic_bits() | statmc::acc_diagnostic_bits(); }
 int statmc_debug_last_filter_parts(void) { return g_last_parts; }
+// the tail split of the calling thread's last pair-symmetric launch: parts of the last `*tail_rows` tile rows (0: uniform)
+int statmc_debug_last_filter_tail(int *parts_hi, int *tail_rows) {
+    if (parts_hi) *parts_hi = g_last_parts_hi;
+    if (tail_rows) *tail_rows = g_last_tail_rows;
+    return STATMC_OK;
+}
 // the partial-sum / patch workspace of the calling thread's current device and stream 0 (diagnostic builds read it back)
 int statmc_debug_last_workspace(void **ptr, size_t *bytes) {
     int dev = 0;

@@ -140,6 +140,11 @@ struct FilterArgs {
         float4 *border_extra;     // border rule "clamp": per pixel, the sums over the taps beyond the image (border_virtual_kernel)
         // eight feature planes (NG = 8 build): up to two RGB and up to two 1-channel G-buffers of the argument list, sorted
         // into slots by sym_feature_slots(); scale = sqrt(-dr * log2 e), 0 = empty slot (never read)
+        // Tail split (round 4): the tiles of the film's tile rows >= split_ty sweep with parts_hi workgroups each instead of
+        // n_parts, so that the launch's last round of workgroups is full (1280 x 720: 900 tiles = 3.5 rounds of 256).  The
+        // work items of the n_parts-tiles come first (n_lo_items of them: the launch's tile rows below split_ty), then
+        // those of the parts_hi-tiles.  parts_hi = 0: every tile has n_parts.  Chosen for the WHOLE local image, like n_parts.
+        int parts_hi, split_ty, n_lo_tiles, n_lo_items;
         int steps;                // window rows a tile sweeps: radius + 1
         const float *tab_rt;      // runtime-radius build (radius < 20): [radius + 1][47] spatial exponents, row = dy, -inf beyond the radius
         int g8;
@@ -203,6 +208,9 @@ void sym_geometry(FilterArgs &a);                            // fills a.sym.tx0 
 int sym_tiles(const FilterArgs &a);
 int sym_choose_parts(int tiles, int n_cus, int steps);
 int sym_filter_parts(const FilterArgs &a, int n_cus);
+void sym_choose_split(FilterArgs &whole, int n_cus);        // n_parts, sym.parts_hi, sym.split_ty for the whole local image (a.sym geometry filled)
+void sym_apply_split(FilterArgs &a);                        // n_lo_tiles / n_lo_items of this launch's tile range
+long long sym_items(const FilterArgs &a);
 size_t sym_patch_floats(const FilterArgs &a, int n_parts);
 hipError_t launch_sym(FilterArgs a, hipStream_t s);
 int sym_diagnostic_bits();   // non-zero: built with a STATMC_SYM_* experiment switch (statmc_sym_experiments.h)

@@ -48,8 +48,12 @@
 //     border (this kernel sums the taps inside the image, border_virtual_kernel in statmc_filter.hip adds the taps
 //     beyond it for the pixels next to an edge, combine_sym_kernel joins the two).
 #include <algorithm>
+#include <array>
 #include <cmath>
+#include <functional>
+#include <map>
 #include <mutex>
+#include <vector>
 #include <set>
 #include <type_traits>
 #include <utility>
@@ -836,18 +840,44 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     const Feat F = features_of<NG>(a);
     const float *tq2 = W ? a.tq2 : nullptr;
     // XCD-aware work mapping (as in the one-sided kernel): each XCD walks a contiguous range of items
-    const int n_items = gridDim.x, b = blockIdx.x;
-    const int q8 = n_items >> 3, rem8 = n_items & 7, xcd = b & 7, idx = b >> 3;
-    const int u = xcd < rem8 ? xcd * (q8 + 1) + idx : rem8 * (q8 + 1) + (xcd - rem8) * q8 + idx;
+    // With a tail split the items of the n_parts-tiles (the long ones) go first in every XCD's range and the short
+    // items of the parts_hi-tiles fill the end of the launch.
+    const int n_items = gridDim.x, b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int n_long = a.sym.parts_hi ? a.sym.n_lo_items : n_items, n_short = n_items - n_long;
+    int u;
+    {
+        const int ql = n_long >> 3, rl = n_long & 7;
+        const int long_here = ql + (xcd < rl ? 1 : 0), long_start = xcd < rl ? xcd * (ql + 1) : rl * (ql + 1) + (xcd - rl) * ql;
+        if (idx < long_here) {
+            u = long_start + idx;
+        } else {
+            // short items of this XCD: what its share of the grid leaves after its long items; their start is the sum over the XCDs before it
+            const int qt = n_items >> 3, rt = n_items & 7;
+            int short_start = 0;
+            for (int x = 0; x < xcd; x++) short_start += qt + (x < rt ? 1 : 0) - (ql + (x < rl ? 1 : 0));
+            u = n_long + short_start + (idx - long_here);
+            if (u >= n_items) return;   // (cannot happen: the shares add up to n_short; a guard against a grid of another size)
+        }
+        (void)n_short;
+    }
 
     unsigned long long t_start = 0, t_swept = 0, c_pro = 0, s_hk = 0, s_ev = 0, s_bar = 0;
     if constexpr (kStamps) t_start = __builtin_amdgcn_s_memtime();
-    const int part = u % a.n_parts, tile = u / a.n_parts;
+    int part, tile, n_parts;
+    if (!a.sym.parts_hi || u < a.sym.n_lo_items) {
+        n_parts = a.n_parts;
+        part = u % n_parts;
+        tile = u / n_parts;
+    } else {
+        n_parts = a.sym.parts_hi;
+        part = (u - a.sym.n_lo_items) % n_parts;
+        tile = a.sym.n_lo_tiles + (u - a.sym.n_lo_items) / n_parts;
+    }
     const int x0 = kW * (a.sym.tx0 + tile % a.sym.ntx) - a.sym.fx0;     // local coordinates of the tile
     const int y0 = kRows * (a.sym.ty0 + tile / a.sym.ntx) - a.sym.fy0;
     const int steps = RT ? a.sym.steps : kSteps;
-    const int s_a = step_lo(part, a.n_parts, steps);
-    const int s_b = min(step_lo(part + 1, a.n_parts, steps), a.height - y0);  // window rows below the image are not swept
+    const int s_a = step_lo(part, n_parts, steps);
+    const int s_b = min(step_lo(part + 1, n_parts, steps), a.height - y0);  // window rows below the image are not swept
     // spatial exponents: [dy + 20][..] of the (2r+1)-row table (r = 20) / [dy][..] of the runtime-radius table
     const float *stab = RT ? a.sym.tab_rt : a.spatial_tab + kR * kTabW;
     const int j_lo = RT ? (kR - a.radius) / 4 : 0, j_hi = RT ? min(kChunks - 1, (a.radius + kR + 3) / 4) : kChunks - 1;
@@ -1091,10 +1121,13 @@ __global__ __launch_bounds__(256) void combine_sym_kernel(FilterArgs a) {
         const int rel = Y - kRows * Ty;  // 0 .. kSteps + kRows - 2
         for (int Tx = tx_lo; Tx <= tx_hi; Tx++) {
             const int c = X - kW * Tx + kR;  // 0 .. kP - 1
-            const long long item0 = ((long long)(Ty - a.sym.ty0) * a.sym.ntx + (Tx - a.sym.tx0)) * a.n_parts;
-            for (int k = 0; k < a.n_parts; k++) {
+            const bool hi = a.sym.parts_hi != 0 && Ty >= a.sym.split_ty;
+            const int n_parts = hi ? a.sym.parts_hi : a.n_parts;
+            const long long tile_local = (long long)(Ty - a.sym.ty0) * a.sym.ntx + (Tx - a.sym.tx0);   // lo tiles first: rows below split_ty
+            const long long item0 = hi ? a.sym.n_lo_items + (tile_local - a.sym.n_lo_tiles) * n_parts : tile_local * n_parts;
+            for (int k = 0; k < n_parts; k++) {
                 const float4 *patch = a.sym.patch + (item0 + k) * a.sym.item_stride4;
-                const int s_a = step_lo(k, a.n_parts, steps), s_b = step_lo(k + 1, a.n_parts, steps), q_first = s_a;
+                const int s_a = step_lo(k, n_parts, steps), s_b = step_lo(k + 1, n_parts, steps), q_first = s_a;
                 if (Ty == ty_own && Tx == tx_own) {
                     const float4 v = patch[rel * kW + (X - kW * Tx)];
                     t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
@@ -1175,8 +1208,93 @@ int sym_choose_parts(int tiles, int n_cus, int steps) {
     }
     return best;
 }
+// Work items of a launch (sym geometry and split applied)
+long long sym_items(const FilterArgs &a) {
+    if (!a.sym.parts_hi) return (long long)sym_tiles(a) * a.n_parts;
+    return (long long)a.sym.n_lo_items + (long long)(sym_tiles(a) - a.sym.n_lo_tiles) * a.sym.parts_hi;
+}
+void sym_apply_split(FilterArgs &a) {
+    if (!a.sym.parts_hi) {
+        a.sym.n_lo_tiles = sym_tiles(a);
+        a.sym.n_lo_items = a.sym.n_lo_tiles * a.n_parts;
+        return;
+    }
+    const int lo_rows = std::max(0, std::min(a.sym.ty0 + a.sym.nty, a.sym.split_ty) - a.sym.ty0);
+    a.sym.n_lo_tiles = lo_rows * a.sym.ntx;
+    a.sym.n_lo_items = a.sym.n_lo_tiles * a.n_parts;
+}
+// (n_parts: the smaller part count of the launch -- its items have the most accumulator rows and set the item stride)
 size_t sym_patch_floats(const FilterArgs &a, int n_parts) {
-    return (size_t)sym_tiles(a) * n_parts * (sym::kPatchP + (size_t)sym::q_rows_max(n_parts, a.radius + 1) * sym::kP) * 4;
+    return (size_t)sym_items(a) * (sym::kPatchP + (size_t)sym::q_rows_max(n_parts, a.radius + 1) * sym::kP) * 4;
+}
+
+// Makespan of a launch in step units: one workgroup per CU, items handed out in order to whichever CU is free.
+static double sym_makespan(long long n_long, double c_long, long long n_short, double c_short, int n_cus) {
+    std::vector<double> cu((size_t)n_cus, 0.0);   // a binary heap of finish times
+    auto run = [&](long long n, double c) {
+        for (long long i = 0; i < n; i++) {
+            std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
+            cu.back() += c;
+            std::push_heap(cu.begin(), cu.end(), std::greater<double>());
+        }
+    };
+    run(n_long, c_long);
+    run(n_short, c_short);
+    return *std::max_element(cu.begin(), cu.end());
+}
+
+// Parts for the whole local image: the uniform choice of sym_choose_parts, or -- when that leaves the last round of
+// workgroups mostly empty -- the same with the last tile rows swept by more parts (a "tail split"): their short items fill
+// the end of the launch.  1280 x 720 (900 tiles): 4 rounds of 21 steps -> 3 rounds + half-length items.  Cost of an item as in
+// sym_choose_parts: ceil(steps / parts) + 1.35 steps.  Results are cached per (tile grid, CUs, steps): the search simulates
+// the dispatch.  A pinned split (statmc_set_filter_split) is uniform: no tail.
+void sym_choose_split(FilterArgs &w, int n_cus) {
+    w.sym.parts_hi = 0;
+    w.sym.split_ty = 0;
+    if (w.force_parts > 0) {
+        w.n_parts = sym_filter_parts(w, n_cus);
+        return;
+    }
+    struct Choice { int lo, hi, tail_rows; };
+    static std::mutex mu;
+    static std::map<std::array<int, 4>, Choice> cache;
+    const int steps = w.radius + 1, ntx = w.sym.ntx, nty = w.sym.nty;
+    const std::array<int, 4> key = {ntx, nty, n_cus, steps};
+    Choice c{1, 0, 0};
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) {
+            c = it->second;
+        } else {
+            const long long tiles = (long long)ntx * nty;
+            auto cost = [&](int k) { return (double)((steps + k - 1) / k) + 1.35; };
+            c.lo = sym_choose_parts((int)tiles, n_cus, steps);
+            double best = sym_makespan(tiles * c.lo, cost(c.lo), 0, 0.0, n_cus);
+            for (int lo = 1; lo <= 3 && lo <= steps; lo++)
+                for (int hi = 2 * lo; hi <= 4 * lo && hi <= steps && hi <= 8; hi += lo) {
+                    // the long items fill whole rounds; the tail starts at the first tile row after them (whole rows: the
+                    // item order of any rectangular sub-range then stays "long first")
+                    const long long full_rounds = tiles * lo / n_cus;
+                    for (long long r = full_rounds; r >= 0 && r + 1 >= full_rounds; r--) {
+                        const long long long_tiles = std::min(tiles, r * n_cus / lo);
+                        const int lo_rows = (int)(long_tiles / ntx), tail_rows = nty - lo_rows;
+                        if (tail_rows <= 0 || tail_rows >= nty) continue;
+                        const double t = sym_makespan((long long)lo_rows * ntx * lo, cost(lo), (long long)tail_rows * ntx * hi, cost(hi), n_cus);
+                        if (t < best * 0.97) {     // a mixed launch has to be worth its second patch geometry
+                            best = t;
+                            c = Choice{lo, hi, tail_rows};
+                        }
+                    }
+                }
+            cache[key] = c;
+        }
+    }
+    w.n_parts = c.lo;
+    if (c.hi) {
+        w.sym.parts_hi = c.hi;
+        w.sym.split_ty = w.sym.ty0 + nty - c.tail_rows;
+    }
 }
 
 // filter<float3> and filter<float> (two buffers per launch), radius 1..20, every spec but Welch degrees of freedom.
@@ -1282,7 +1400,7 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
             done.insert({dev, kernel});
         }
     }
-    const dim3 grid(sym_tiles(a) * a.n_parts);
+    const dim3 grid((unsigned)sym_items(a));
     void *kargs[] = {&a};
     const size_t lds_bytes = welch ? Planes<6, true>::kLdsBytes : g8 ? Planes<8>::kLdsBytes : Planes<6>::kLdsBytes;
     if (hipError_t e = hipLaunchKernel(kernel, grid, dim3(kThreads), kargs, lds_bytes, s); e != hipSuccess) return e;

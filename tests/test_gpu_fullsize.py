@@ -298,6 +298,24 @@ def test_config1_1280x720_64spp(gpu, oracle):
     check_strips(gpu, oracle, fs, [(0, 352, 1280, 364), (0, 0, 300, 8), (1280 - 300, 720 - 8, 1280, 720), (1000, 0, 1280, 6)])
     parts = gpu.load().statmc_debug_last_filter_parts()
     assert parts >= 1
+    # 10 x 90 = 900 tiles leave the fourth round of a 256-CU device half empty: the automatic split gives the last tile
+    # rows more parts (tail split, round 4) -- and a call for a band of rows across that boundary is the whole-image
+    # call's result bit for bit (the split belongs to the image, not to the region)
+    import ctypes as C
+    hi, rows = C.c_int(0), C.c_int(0)
+    gpu.load().statmc_debug_last_filter_tail(C.byref(hi), C.byref(rows))
+    if gpu.load().statmc_device_cus() == 256:
+        assert parts == 1 and hi.value >= 2 and 0 < rows.value < 90, (parts, hi.value, rows.value)
+    colour = fs.state["radiance"]["film_mean"]
+    whole = wf(gpu, fs, colour, torch.zeros_like(colour)).clone()
+    y_split = 720 - 8 * rows.value if rows.value else 360
+    for roi in ((0, max(0, y_split - 40), 1280, min(720, y_split + 48)), (256, 0, 1024, 720), (0, 704, 1280, 720)):
+        x0, y0, x1, y1 = roi
+        part = wf(gpu, fs, colour, torch.zeros_like(colour), roi=roi)
+        assert torch.equal(part[y0:y1, x0:x1], whole[y0:y1, x0:x1]), roi
+    ref = oracle_strip(oracle, fs, colour, (0, 704, 1280, 720))          # the image's last rows: inside the tail
+    for c in range(3):
+        assert rel_l2(whole[704:720, :, c].cpu().numpy(), ref[..., c]) <= 1e-5, c
     # any other split of the sweep agrees with the default one
     colour = fs.state["radiance"]["film_mean"]
     base = wf(gpu, fs, colour, torch.zeros_like(colour)).clone()

@@ -13,6 +13,9 @@ oracle.build(); gpu.setup(0)
 R20 = "--r20" in sys.argv
 if R20:
     sys.argv.remove("--r20")
+WELCH = "--welch" in sys.argv      # round 4: Welch degrees of freedom half of the time (the pair-symmetric kernel's Welch build)
+if WELCH:
+    sys.argv.remove("--welch")
 
 
 def random_spec(rng):
@@ -21,7 +24,7 @@ def random_spec(rng):
     if rng.random() < (0.25 if R20 else 0.5):
         return {}
     kw = dict(gate=int(rng.integers(0, 2)), channel_rule=int(rng.integers(0, 2)), border=int(rng.integers(0, 2)))
-    if rng.random() < 0.1:
+    if rng.random() < (0.7 if WELCH else 0.1):
         kw["dof"] = 1
     return kw
 
@@ -66,7 +69,12 @@ def filter_case(case, verbose=False):
         colour[y, x, rng.integers(0, 3)] = [np.nan, np.inf, -np.inf][int(rng.integers(0, 3))]
         inj.append((9, x, y))
     spec_kw = random_spec(rng)
-    n = rng.integers(2, 400, size=(H, W)).astype(np.int32) if spec_kw.get("dof") else None
+    n = None
+    if spec_kw.get("dof"):      # Welch: sample counts -- ragged, uniform (the usual film), or with pixels of fewer than two samples
+        kind = int(rng.integers(0, 3))
+        n = rng.integers(2, 400, size=(H, W)).astype(np.int32) if kind == 0 else np.full((H, W), int(rng.choice([2, 3, 4, 16, 64, 256, 1024, 5000])), np.int32)
+        if kind == 2:
+            n[rng.random((H, W)) < 0.05] = int(rng.integers(0, 2))
     ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / sd ** 2, radius, roi=roi, spec=oracle.FilterSpec(**spec_kw), n=n)
     force = int(rng.choice([0, 0, 0, 2, 1, 3]))
     parts = int(rng.choice([0, 0, 1, 2, 3, 5, 41]))
