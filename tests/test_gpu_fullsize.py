@@ -159,8 +159,14 @@ def test_default_dispatch_blocks_vs_whole_film(gpu, oracle, film1080):
     assert gpu.get_filter_split() == 0
     whole = wf(gpu, fs, colour, torch.zeros_like(colour)).clone()
     assert gpu.last_filter_variant() == "sym_r20"
+    import ctypes as C
+
+    def split_used():     # (parts, parts of the tail rows, tail rows): 0, 0 = every tile the same
+        hi, rows = C.c_int(0), C.c_int(0)
+        gpu.load().statmc_debug_last_filter_tail(C.byref(hi), C.byref(rows))
+        return (gpu.load().statmc_debug_last_filter_parts(), hi.value, rows.value)
     parts_whole = gpu.load().statmc_debug_last_filter_parts()
-    assert parts_whole == gpu.filter_split_auto(W, H, RADIUS)
+    assert parts_whole == gpu.filter_split_auto(W, H, RADIUS) and split_used() == (parts_whole, 0, 0)
     imgs = dict(mean_corr=fs.mean_corr, disc=fs.disc, colour=colour, normal=fs.g_buffer("normal"), albedo=fs.g_buffer("albedo"))
     seam = (0, 536, W, 544)                         # 8 full-width rows across the y = 540 seam of every grid below
     ref = oracle_strip(oracle, fs, colour, seam)
@@ -179,14 +185,14 @@ def test_default_dispatch_blocks_vs_whole_film(gpu, oracle, film1080):
             gpu.window_filter(a, 3)
             torch.cuda.synchronize()
             assert gpu.last_filter_variant() == "sym_r20"
-            used.add(gpu.load().statmc_debug_last_filter_parts())
+            used.add(split_used())
             out_film[oy:oy + bh, ox:ox + bw] = L.interior(out)
         return out_film, used
 
     differing = 0
     for gx, gy in ((1, 2), (1, 4), (1, 8), (2, 2), (4, 2)):
         got, used = assemble(gx, gy)
-        differing += used != {parts_whole}
+        differing += used != {(parts_whole, 0, 0)}
         g, w = got.cpu().numpy(), whole.cpu().numpy()
         for c in range(3):
             assert rel_l2(g[..., c], w[..., c]) <= 1e-6, (gx, gy, c, used)
@@ -196,7 +202,7 @@ def test_default_dispatch_blocks_vs_whole_film(gpu, oracle, film1080):
     try:
         for gx, gy in ((1, 8), (4, 2)):
             got, used = assemble(gx, gy)
-            assert used == {parts_whole} and torch.equal(got, whole), (gx, gy)
+            assert used == {(parts_whole, 0, 0)} and torch.equal(got, whole), (gx, gy)
     finally:
         gpu.set_filter_split(0)
 

@@ -31,7 +31,11 @@ for world in (2, 4, 8):
             pipe.window_filter()
         e1.record()
         torch.cuda.synchronize()
+        import ctypes
         used = api.load().statmc_debug_last_filter_parts()
-        line.append("%s%d: %.3f" % ("auto=" if parts == 0 else "", used, e0.elapsed_time(e1) / 30))
+        hi, rows = ctypes.c_int(0), ctypes.c_int(0)
+        api.load().statmc_debug_last_filter_tail(ctypes.byref(hi), ctypes.byref(rows))
+        tail = " (+%d parts on the last %d tile rows)" % (hi.value, rows.value) if hi.value else ""
+        line.append("%s%d%s: %.3f" % ("auto=" if parts == 0 else "", used, tail, e0.elapsed_time(e1) / 30))
     api.force_filter_parts(0)
     print("N=%d block %dx%d: %s ms" % (world, W, H, "  ".join(line)), flush=True)
