@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): kernel-trace stats + PMC passes of the bench workload.
 # Outputs under gpurun_out/prof_<tag>/ ; summaries are copied into profiles/ by tools/summarise_profile.py.
 set -u
-TAG=${1:-r03a}
+TAG=${1:-r04a}
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
