@@ -364,15 +364,20 @@ void oracle_prepass(int width, int height, int channels, int alpha_index,
 }
 
 /* a pixel takes part in windows (as centre and as tap) when its corrected mean is finite in every channel, its
- * discriminator is not NaN and its colour is finite (v2: a NaN / inf colour would otherwise spread to every
- * window that accepts the pixel; the reference never produces one -- statpath.cpp:333-351 blacks such samples) */
-static int pixel_valid(int channels, const float *mc, const float *disc, const float *colour, size_t p) {
+ * discriminator is not NaN, its colour is finite (v2: a NaN / inf colour would otherwise spread to every
+ * window that accepts the pixel; the reference never produces one -- statpath.cpp:333-351 blacks such samples) and
+ * -- v2.1, round 4 -- every G-buffer value of the pixel is finite (a NaN feature makes the range weight of every pair
+ * with the pixel NaN: the same spreading, through the weight instead of the colour) */
+static int pixel_valid(int channels, const float *mc, const float *disc, const float *colour, int n_g,
+                       const float *const *g_buffers, const int *g_channels, size_t p) {
     int v = 1;
     for (int c = 0; c < channels; c++) {
         v &= isfinite(mc[p * channels + c]) != 0;
         v &= !isnan(disc[p * channels + c]);
         v &= isfinite(colour[p * channels + c]) != 0;
     }
+    for (int g = 0; g < n_g; g++)
+        for (int c = 0; c < g_channels[g]; c++) v &= isfinite(g_buffers[g][p * g_channels[g] + c]) != 0;
     return v;
 }
 
@@ -426,7 +431,7 @@ void oracle_filter_spec_run(int width, int height, int channels, float ds, int r
         for (int x = rx0; x < rx1; x++) {
             const size_t p = (size_t)y * width + x;
             float sum_w = 0.f, acc[3] = {0.f, 0.f, 0.f};
-            const int p_valid = pixel_valid(channels, mean_corr, disc, colour, p);
+            const int p_valid = pixel_valid(channels, mean_corr, disc, colour, n_g, g_buffers, g_channels, p);
             for (int dy = -radius; p_valid && dy <= radius; dy++) {
                 int qy = y + dy;
                 if (qy < 0 || qy >= height) {
@@ -440,7 +445,7 @@ void oracle_filter_spec_run(int width, int height, int channels, float ds, int r
                         qx = qx < 0 ? 0 : width - 1;
                     }
                     const size_t q = (size_t)qy * width + qx;
-                    if (!pixel_valid(channels, mean_corr, disc, colour, q)) continue;
+                    if (!pixel_valid(channels, mean_corr, disc, colour, n_g, g_buffers, g_channels, q)) continue;
                     if (!pair_member(spec, channels, table, mean_corr, disc, n, p, q)) continue;
                     float e = ds * (float)(dx * dx + dy * dy);
                     for (int g = 0; g < n_g; g++) {

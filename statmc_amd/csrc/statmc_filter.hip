@@ -79,9 +79,16 @@ __device__ __forceinline__ bool pixel_valid(const float *mc, const float *dc, co
     }
     return v;
 }
+// ... and (spec v2.1) every G-buffer value of the pixel is finite
+__device__ __forceinline__ bool features_valid(const FilterArgs &a, long long p) {
+    bool v = true;
+    for (int g = 0; g < a.n_g; g++)
+        for (int c = 0; c < a.g[g].channels; c++) v = v && __builtin_isfinite(a.g[g].data[p * a.g[g].channels + c]);
+    return v;
+}
 template <int C>
 __device__ __forceinline__ bool pixel_valid(const FilterArgs &a, long long p) {
-    return pixel_valid<C>(a.mean_corr, a.disc, a.colour, p);
+    return pixel_valid<C>(a.mean_corr, a.disc, a.colour, p) && features_valid(a, p);
 }
 
 template <int C>
@@ -221,11 +228,11 @@ __global__ __launch_bounds__(256) void border_virtual_kernel(FilterArgs a) {
             acc[c] = 0.f;
         }
         float sum_w = 0.f;
-        if (pixel_valid<C>(mc, dc, col, p)) {
+        if (pixel_valid<C>(mc, dc, col, p) && features_valid(a, p)) {
             // one (pixel, edge pixel) pair: membership, range weight, times the summed spatial weight of the taps it stands for
             auto pair = [&](int qx, int qy, int d_along, float t_across) {
                 const long long q = (long long)qy * W + qx;
-                if (!pixel_valid<C>(mc, dc, col, q)) return;
+                if (!pixel_valid<C>(mc, dc, col, q) || !features_valid(a, q)) return;
                 if (!pair_member<C>(a, mc, dc, pc, pd, p, q)) return;
                 float e = a.ds * (float)(d_along * d_along);
                 for (int g = 0; g < a.n_g; g++) {
@@ -593,8 +600,10 @@ __device__ __forceinline__ void filter_tile(const FilterArgs &a, float *lds, int
             d = f3{a.f_disc[0][p], a.f_disc[1][p], a.f_disc[2][p]};
             col = f3{a.f_colour[0][p], a.f_colour[1][p], a.f_colour[2][p]};
         }
-        mc = canonical_mean(mc, pixel_validity(mc, d, col, true, RGB));  // the same rule as for the staged taps
         if (!(RGB && a.packed)) load_features(a, p, g0, g1);
+        bool fin = features_finite(g0, g1);   // spec v2.1: a pixel with a non-finite feature takes no part
+        if (!fin) g0 = g1 = f3{0.f, 0.f, 0.f};
+        mc = canonical_mean(mc, pixel_validity(mc, d, col, fin, RGB));  // the same rule as for the staged taps
         st.pg[k][0] = g0.x * k0; st.pg[k][1] = g0.y * k0; st.pg[k][2] = g0.z * k0;
         st.pg[k][3] = g1.x * k1; st.pg[k][4] = g1.y * k1; st.pg[k][5] = g1.z * k1;
         st.pmc[k][0] = mc.x; st.pmc[k][1] = mc.y; st.pmc[k][2] = mc.z;

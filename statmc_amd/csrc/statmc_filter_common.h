@@ -89,6 +89,14 @@ __device__ __forceinline__ Validity pixel_validity(const f3 &mc, const f3 &d, co
     }
     return Validity{vx, vy, vz};
 }
+// Spec v2.1 (round 4): a pixel with a non-finite G-buffer value takes no part either -- its range weights would be NaN for
+// every pair (and, in the runtime-radius builds of the pair-symmetric kernel, for taps just beyond a small radius, whose
+// exponent is -inf only as long as the feature term is a number).  Callers pass `in_image && features_finite(...)` where
+// pixel_validity asks whether the pixel exists, and stage such a pixel's features as 0.
+__device__ __forceinline__ bool features_finite(const f3 &g0, const f3 &g1, float s0 = 0.f, float s1 = 0.f) {
+    return __builtin_isfinite(g0.x) && __builtin_isfinite(g0.y) && __builtin_isfinite(g0.z) && __builtin_isfinite(g1.x) &&
+           __builtin_isfinite(g1.y) && __builtin_isfinite(g1.z) && __builtin_isfinite(s0) && __builtin_isfinite(s1);
+}
 // Staging rule for the corrected mean: it is what switches a tap off in the inner loop -- NaN there
 // fails every comparison (and v_max3 drops a NaN in a single channel, hence all three for RGB).
 __device__ __forceinline__ f3 canonical_mean(const f3 &mc, const Validity &v) {
@@ -98,7 +106,7 @@ __device__ __forceinline__ f3 canonical_mean(const f3 &mc, const Validity &v) {
 
 __device__ __forceinline__ void store_pixel(float *slot, int pitch, int i, const StagedPixel &s, float k0, float k1,
                                             bool rgb) {
-    const bool v = s.valid;
+    const bool v = s.valid && features_finite(s.g0, s.g1);
     const Validity ok = pixel_validity(s.mc, s.d, s.col, v, rgb);
     const f3 mc = canonical_mean(s.mc, ok);
     float *p = slot + i;

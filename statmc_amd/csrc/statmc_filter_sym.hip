@@ -730,7 +730,7 @@ __device__ __forceinline__ void stage_store(float *slot, int i, const Staged &r,
     if constexpr (NG == 6) {
         store_pixel(slot, kP, i, s, F.k0, F.k1, rgb);
     } else {
-        const bool v = s.valid;
+        const bool v = s.valid && features_finite(s.g0, s.g1, r.s0, r.s1);
         const Validity ok = pixel_validity(s.mc, s.d, s.col, v, rgb);
         const f3 mc = canonical_mean(s.mc, ok);
         float *p = slot + i;
@@ -742,7 +742,7 @@ __device__ __forceinline__ void stage_store(float *slot, int i, const Staged &r,
         p[14 * kP] = ok.x ? s.col.x : 0.f; p[15 * kP] = ok.y ? s.col.y : 0.f; p[16 * kP] = ok.z ? s.col.z : 0.f;
     }
     if constexpr (W) {
-        const Validity ok = pixel_validity(s.mc, s.d, s.col, s.valid, rgb);
+        const Validity ok = pixel_validity(s.mc, s.d, s.col, s.valid && features_finite(s.g0, s.g1), rgb);
         float *p = slot + Planes<NG, W>::cE * kP + i;
         p[0 * kP] = ok.x ? s.d.x * s.d.x / r.nm1 : 0.f;
         p[1 * kP] = ok.y ? s.d.y * s.d.y / r.nm1 : 0.f;
@@ -923,7 +923,12 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
                 sc1 = F.k3 != 0.f ? F.s1[p] : 0.f;
             }
         }
-        const bool inside = px >= 0 && px < a.width && py >= 0 && py < a.height;
+        bool inside = px >= 0 && px < a.width && py >= 0 && py < a.height;
+        if (!features_finite(g0, g1, sc0, sc1)) {   // spec v2.1: such a pixel takes no part; its features enter no exponent as NaN
+            inside = false;
+            g0 = g1 = f3{0.f, 0.f, 0.f};
+            sc0 = sc1 = 0.f;
+        }
         const Validity ok = pixel_validity(mc, d, col, inside, !PAIR);   // per pixel (RGB) / per buffer (PAIR)
         mc = canonical_mean(mc, ok);
         st.pg[k][0] = v2f{g0.x * F.k0, g0.y * F.k0};

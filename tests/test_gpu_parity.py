@@ -1338,6 +1338,55 @@ def test_filter_spec_errors_and_per_device_state(gpu):
     assert lib.statmc_set_device(torch.cuda.device_count() + 3) == gpu.ERR_NO_DEVICE
 
 
+def test_filter_non_finite_feature(gpu, oracle):
+    """ADVICE r3 / spec v2.1: a NaN or infinite G-buffer value used to make the range weight of every pair with that pixel NaN
+    -- in the oracle too -- and, in the runtime-radius builds of the pair-symmetric kernel, the weight of taps just BEYOND a
+    small radius (their exponent is -inf only while the feature term is a number).  Now such a pixel takes no part, like one
+    with a non-finite colour: it keeps its own colour, every other pixel is what it would be without it; every kernel
+    agrees with the oracle.  Small radii put the NaN just outside many windows; six and eight feature planes; a clamped border
+    (the edge pixel that a clamped tap repeats is the bad one)."""
+    for radius, sd, planes8, spec_kw in ((20, 10.0, False, {}), (3, 2.0, False, {}), (6, 3.0, True, {}), (7, 4.0, False, dict(border=1)),
+                                         (20, 10.0, True, {}), (5, 3.0, False, dict(dof=1))):
+        mc, disc, colour, gbs = stats_case(oracle, 300, 30, 6, seed=77 + radius)
+        gbs = [g.copy() for g in gbs]
+        g_dr = list(G_DR)
+        if planes8:
+            rng = np.random.default_rng(radius)
+            gbs += [rng.random(mc.shape[:2] + (1,), dtype=np.float32) * 3, rng.integers(0, 4, mc.shape[:2] + (1,)).astype(np.float32)]
+            g_dr += [-0.5 / 0.7 ** 2, -0.5 / 0.5 ** 2]
+            gbs[2][11, 150, 0] = np.inf
+            gbs[3][25, 7, 0] = np.nan
+        gbs[0][4, 60, 1] = np.nan
+        gbs[1][12, 200, 2] = -np.inf
+        gbs[0][0, 0, 0] = np.nan                       # the corner pixel: what a clamped border repeats
+        gbs[1][29, 140, 0] = np.nan                    # last row
+        bad_px = [(4, 60), (12, 200), (0, 0), (29, 140)] + ([(11, 150), (25, 7)] if planes8 else [])
+        n = np.full(mc.shape[:2], 6, np.int32)
+        ospec = oracle.FilterSpec(**spec_kw)
+        if spec_kw.get("dof"):                          # Welch: the discriminator image holds s^2 / n
+            disc = (disc / np.float32(oracle.t_quantile(0, 5)) ** 2).astype(np.float32)
+        ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / sd ** 2, radius, spec=ospec, n=n)
+        assert np.isfinite(ref).all()                  # nothing spreads
+        for y, x in bad_px:
+            assert np.array_equal(ref[y, x], colour[y, x])       # the pixel passes its own colour through
+        clean = [np.nan_to_num(g, nan=0.5, posinf=0.5, neginf=0.5) for g in gbs]
+        ref_clean = oracle.filter_image(mc, disc, colour, clean, g_dr, -0.5 / sd ** 2, radius, spec=ospec, n=n)
+        far = np.ones(mc.shape[:2], bool)
+        for y, x in bad_px:
+            far[max(0, y - radius):y + radius + 1, max(0, x - radius):x + radius + 1] = False
+        if not spec_kw.get("border"):
+            assert np.array_equal(ref[far], ref_clean[far])      # pixels whose window does not hold a bad one are untouched
+        gpu.set_filter_spec(**spec_kw)
+        try:
+            for force in (0, 2, 1):
+                out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, sd, radius, force=force, n=n if spec_kw.get("dof") else None)
+                assert np.isfinite(out).all(), (v, radius)
+                for c in range(3):
+                    assert rel_l2(out[..., c], ref[..., c]) <= TOL, (v, radius, c)
+        finally:
+            gpu.set_filter_spec()
+
+
 def test_filter_non_finite_colour(gpu, oracle):
     """a NaN / inf colour at a pixel that is not a member (or not valid) used to reach the sums of
     the LDS kernel as 0 * NaN.  Spec v2: such a pixel takes no part; all three kernels agree with the oracle."""

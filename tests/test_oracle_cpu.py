@@ -394,3 +394,28 @@ def test_fp_contract_mode(oracle):
     finally:
         oracle.set_fp_contract(False)
     assert abs(float(px["m3"]) - kat["m3"]) <= 1e-5 * abs(kat["m3"])
+
+
+def test_filter_pixel_with_a_non_finite_feature_takes_no_part(oracle):
+    """Spec v2.1 (round 4): a NaN / infinite G-buffer value no longer spreads through the range weight -- the pixel takes no
+    part (it keeps its colour), its neighbours are filtered as if it were not there."""
+    rng = np.random.default_rng(5)
+    H, W, r = 16, 24, 4
+    mc = rng.standard_normal((H, W, 3)).astype(np.float32) * 0.1
+    disc = np.full((H, W, 3), 0.5, np.float32)
+    colour = rng.random((H, W, 3), dtype=np.float32)
+    g = [rng.random((H, W, 3), dtype=np.float32), rng.random((H, W, 1), dtype=np.float32)]
+    g[0][5, 7, 2] = np.nan
+    g[1][10, 20, 0] = np.inf
+    out = oracle.filter_image(mc, disc, colour, g, [-2.0, -3.0], -0.5 / 9.0, r)
+    assert np.isfinite(out).all()
+    assert np.array_equal(out[5, 7], colour[5, 7]) and np.array_equal(out[10, 20], colour[10, 20])
+    # the same film with the two pixels made invalid by their statistics instead: every other pixel gets the same bits
+    mc2 = mc.copy()
+    mc2[5, 7] = np.nan
+    mc2[10, 20] = np.nan
+    g2 = [np.nan_to_num(x, nan=0.25, posinf=0.25) for x in g]
+    out2 = oracle.filter_image(mc2, disc, colour, g2, [-2.0, -3.0], -0.5 / 9.0, r)
+    mask = np.ones((H, W), bool)
+    mask[5, 7] = mask[10, 20] = False
+    assert np.array_equal(out[mask], out2[mask])
