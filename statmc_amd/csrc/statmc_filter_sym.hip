@@ -259,15 +259,22 @@ __device__ __forceinline__ void gate_weight(const LaneT &st, const v4f *mcn, con
                 const v2f sn = rsub_bc(pair_of<H>(mcn[3 + ch]), st.ms[k][ch], 1);      // -(v_p + v_q)
                 const v2f den = add_bc(st.pe[k][ch >> 1], ch & 1, pair_of<H>(en[ch]));   // E_p + E_q
                 const v2f s2 = sn * sn;
-                const v2f r = v2f{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                const v2f q0 = s2 * r;
-                const v2f er = __builtin_elementwise_fma(-q0, den, s2);
-                const v2f q1 = __builtin_elementwise_fma(er, r, q0);
-                const float nx = q1.x == q1.x ? q1.x : q0.x, ny = q1.y == q1.y ? q1.y : q0.y;
+                float nx, ny;
+                if constexpr ((STATMC_SYM_WELCH_ABLATE & 4) != 0) {   // timing only
+                    nx = s2.x + den.x; ny = s2.y + den.y;
+                } else {
+                    const v2f r = v2f{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                    const v2f q0 = s2 * r;
+                    const v2f er = __builtin_elementwise_fma(-q0, den, s2);
+                    const v2f q1 = __builtin_elementwise_fma(er, r, q0);
+                    if constexpr ((STATMC_SYM_WELCH_ABLATE & 2) != 0) { nx = q1.x; ny = q1.y; }   // timing only
+                    else { nx = q1.x == q1.x ? q1.x : q0.x; ny = q1.y == q1.y ? q1.y : q0.y; }
+                }
                 // v_cvt_i32_f32 of a NaN is 0, of +inf INT_MAX (spelled out: the C++ conversion of such a value is undefined);
                 // the integer clamp (v_med3_i32) turns them into dof 1 and 4096
                 const int ix = min(max(cvt_i32(nx), 1), 4096), iy = min(max(cvt_i32(ny), 1), 4096);
-                out[ch] = v2f{tq2[ix], tq2[iy]};
+                if constexpr ((STATMC_SYM_WELCH_ABLATE & 1) != 0) out[ch] = v2f{(float)ix * 1e-3f + 9.f, (float)iy * 1e-3f + 9.f};   // timing only: no gather
+                else out[ch] = v2f{tq2[ix], tq2[iy]};
             }
         };
         auto test = [&](int k, const v2f (&tt)[3]) {

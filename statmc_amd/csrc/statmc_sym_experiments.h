@@ -37,10 +37,16 @@
 #define STATMC_SYM_PRIO 0
 #endif
 
+// timing-only ablations of the Welch gate (round 4): 1 = no table gather (a constant quantile), 2 = no NaN select on the
+// quotient, 4 = no quotient at all (nu = s^2): results are wrong with any bit set
+#ifndef STATMC_SYM_WELCH_ABLATE
+#define STATMC_SYM_WELCH_ABLATE 0
+#endif
+
 #define STATMC_SYM_DIAGNOSTIC_BITS                                                                                        \
     ((STATMC_SYM_ABLATE ? 1 : 0) | (STATMC_SYM_HK_END ? 2 : 0) | (STATMC_SYM_PIPE ? 4 : 0) | (STATMC_SYM_STAMPS ? 8 : 0) | \
-     (STATMC_SYM_SPLIT ? 16 : 0) | (STATMC_SYM_COUNT ? 32 : 0) | (STATMC_SYM_PRIO ? 64 : 0))
+     (STATMC_SYM_SPLIT ? 16 : 0) | (STATMC_SYM_COUNT ? 32 : 0) | (STATMC_SYM_PRIO ? 64 : 0) | (STATMC_SYM_WELCH_ABLATE ? 256 : 0))
 
-#if defined(STATMC_PRODUCT_BUILD) && STATMC_SYM_ABLATE + STATMC_SYM_HK_END + STATMC_SYM_PIPE + STATMC_SYM_STAMPS + STATMC_SYM_SPLIT * STATMC_SYM_SPLIT + STATMC_SYM_COUNT + STATMC_SYM_PRIO != 0
+#if defined(STATMC_PRODUCT_BUILD) && STATMC_SYM_ABLATE + STATMC_SYM_HK_END + STATMC_SYM_PIPE + STATMC_SYM_STAMPS + STATMC_SYM_SPLIT * STATMC_SYM_SPLIT + STATMC_SYM_COUNT + STATMC_SYM_PRIO + STATMC_SYM_WELCH_ABLATE != 0
 #error "a STATMC_SYM_* diagnostic switch is set in the product build (statmc_amd/build.py): it would ship a wrong or slower filter"
 #endif
