@@ -951,12 +951,14 @@ def main():
     # 17-channel block + halo image through the same pack / exchange / filter path), on 8 samples of the pool
     eight = None
     if world > 1 and args.channels == 11 and not args.no_host_legs:
+        # (no collective inside the try: a rank that fails here must not leave the others waiting; the halo of the 17-channel
+        # image stays zero -- the filter's time does not depend on what the halo holds)
+        names = ("materialid", "depth", "normal", "albedo")
+        local_ms, info, err8 = -1.0, {}, None
         try:
-            names = ("materialid", "depth", "normal", "albedo")
             pipe8 = pipeline.BlockPipeline(layout, dev, types, filter_sd=args.filtersd, radius=r, via_host=args.backend == "gloo", g_buffers=names)
             pipe8.accumulate({t: v[:min(8, pool)] for t, v in samples.items()})
             pipe8.prepass()
-            pipe8.exchange()
             for _ in range(2):
                 pipe8.window_filter()
             torch.cuda.synchronize()
@@ -966,14 +968,18 @@ def main():
                 pipe8.window_filter()
             e1.record()
             torch.cuda.synchronize()
-            t8 = torch.tensor([e0.elapsed_time(e1) / 10], dtype=torch.float64, device=cdev)
-            dist.all_reduce(t8, op=dist.ReduceOp.MAX)
-            eight = {"g_buffers": list(names), "feature_channels": 8, "packed_channels": int(pipe8.packed.shape[2]),
-                     "filter_variant": api.last_filter_variant(), "avg_ms": round(float(t8.item()), 4), "block": "%dx%d" % (W, H),
-                     "what": "window filter of one block + halo image with eight feature planes, back to back (max over ranks)"}
+            local_ms = e0.elapsed_time(e1) / 10
+            info = {"packed_channels": int(pipe8.packed.shape[2]), "filter_variant": api.last_filter_variant()}
             del pipe8
         except Exception as e:      # noqa: BLE001
-            eight = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
+            err8 = "%s: %s" % (type(e).__name__, str(e)[-300:])
+        t8 = torch.tensor([local_ms], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t8, op=dist.ReduceOp.MAX)
+        if err8 is not None:
+            eight = {"error": err8}
+        else:
+            eight = dict({"g_buffers": list(names), "feature_channels": 8, "avg_ms": round(float(t8.item()), 4), "block": "%dx%d" % (W, H),
+                          "what": "window filter of one block + halo image with eight feature planes (halo left empty), back to back; max over ranks"}, **info)
     if args.dump_film_f:
         if world == 1:
             fs.reset()

@@ -260,7 +260,8 @@ typedef struct statmc_block {
  * statmc_amd/peer.py does). */
 int statmc_halo_exchange(const statmc_block *blocks, int gx, int gy, int block_w, int block_h, int radius);
 /* Rectangle copy between device images of any two devices of the process (block cut / block paste of the sharded
- * path).  elem_bytes = bytes per pixel; runs on `stream` (a stream of dst_device). */
+ * path).  elem_bytes = bytes per pixel; runs on `stream`, a stream of either device (peer access is enabled in both
+ * directions on first use). */
 int statmc_copy_rect(const statmc_image *dst, int dst_device, int dst_x, int dst_y, const statmc_image *src,
                      int src_device, int src_x, int src_y, int width, int height, int elem_bytes, void *stream);
 

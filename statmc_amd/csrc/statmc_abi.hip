@@ -855,7 +855,10 @@ int statmc_copy_rect(const statmc_image *dst, int dst_device, int dst_x, int dst
     if (elem_bytes <= 0 || dst_x < 0 || dst_y < 0 || src_x < 0 || src_y < 0 || dst_x + width > dst->cols || dst_y + height > dst->rows ||
         src_x + width > src->cols || src_y + height > src->rows)
         return fail(STATMC_ERR_INVALID, "rectangle outside an image");
+    // access in both directions: the copy runs on `stream`, which may belong to either of the two devices (a block's own
+    // stream when its result is pasted into another device's image), and whichever device executes it touches the other's memory
     if (int rc = enable_peer(dst_device, src_device)) return rc;
+    if (int rc = enable_peer(src_device, dst_device)) return rc;
     const char *s = static_cast<const char *>(src->data) + (size_t)src_y * src->step + (size_t)src_x * elem_bytes;
     char *d = static_cast<char *>(dst->data) + (size_t)dst_y * dst->step + (size_t)dst_x * elem_bytes;
     HIP_TRY(hipMemcpy2DAsync(d, dst->step, s, src->step, (size_t)width * elem_bytes, height, hipMemcpyDeviceToDevice, S(stream)));
