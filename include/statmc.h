@@ -86,6 +86,9 @@ int statmc_copy_device_settings(int src_device, int dst_device);
  * the pre-pass. */
 #define STATMC_GATE_SYMMETRIC 0   /* member <=> fma(d, d, -(D_p + D_q)) <= 0, i.e. d^2 <= D_p + D_q        */
 #define STATMC_GATE_ASYMMETRIC 1  /* member <=> fma(d, d, -D_q) <= D_p      (this build's spec v1.x)       */
+#define STATMC_GATE_CENTRE 2      /* member <=> d * d <= D_p: the neighbour's mean inside the CENTRE pixel's confidence interval
+                                     (Moon et al. 2013; what the reference's CUDA source computes under -DMEMFNC=1, README.md:147-150 --
+                                     with significance 0.002 and the Box-Cox transform switched off, as that paragraph says) */
 #define STATMC_CHANNELS_AND 0     /* every channel of an RGB buffer must pass                              */
 #define STATMC_CHANNELS_JOINT 1   /* sum over channels of the left sides <= sum of the right sides        */
 #define STATMC_SIDES_TWO 0        /* tabulated quantile t_{1-alpha/2, dof}                                */

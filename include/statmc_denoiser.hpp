@@ -162,7 +162,7 @@ inline statmc_filter_spec getFilterSpec() {
     return s;
 }
 // "gate=asym,channels=joint,sides=one,dof=welch,border=clamp,small_n=exclude" (any subset, any order;
-// the other value of each field is its default: sym / and / two / pixel / clip / accept)
+// the other value of each field is its default: sym / and / two / pixel / clip / accept; gate has a third value, centre)
 inline statmc_filter_spec parseFilterSpec(const std::string &text) {
     statmc_filter_spec s = {0, 0, 0, 0, 0, 0};
     size_t pos = 0;
@@ -180,7 +180,7 @@ inline statmc_filter_spec parseFilterSpec(const std::string &text) {
             if (v == one || v == "1") return 1;
             throw std::runtime_error("filter spec: " + k + " is '" + zero + "' or '" + one + "', not '" + v + "'");
         };
-        if (k == "gate") s.gate = pick("sym", "asym");
+        if (k == "gate") s.gate = (v == "centre" || v == "2") ? 2 : pick("sym", "asym");   // centre: Moon et al. 2013 (-DMEMFNC=1)
         else if (k == "channels") s.channel_rule = pick("and", "joint");
         else if (k == "sides") s.sides = pick("two", "one");
         else if (k == "dof") s.dof = pick("pixel", "welch");

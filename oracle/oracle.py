@@ -32,7 +32,7 @@ class FilterSpec(C.Structure):
         return (self.gate, self.channel_rule, self.sides, self.dof, self.border, self.small_n)
 
 
-GATE_SYMMETRIC, GATE_ASYMMETRIC = 0, 1
+GATE_SYMMETRIC, GATE_ASYMMETRIC, GATE_CENTRE = 0, 1, 2
 CHANNELS_AND, CHANNELS_JOINT = 0, 1
 SIDES_TWO, SIDES_ONE = 0, 1
 DOF_PIXEL, DOF_WELCH = 0, 1

@@ -402,6 +402,9 @@ static int pair_member(const oracle_filter_spec *spec, int channels, int table, 
             }
             lhs = fmaf(d, d, -Dsum);
             rhs = 0.f;
+        } else if (spec->gate == ORACLE_GATE_CENTRE) {
+            lhs = d * d;           /* Moon et al. 2013 (the reference's -DMEMFNC=1): q's mean inside p's confidence interval */
+            rhs = Dp;
         } else if (spec->gate == ORACLE_GATE_ASYMMETRIC) {
             lhs = fmaf(d, d, -Dq); /* spec v1.x */
             rhs = Dp;

@@ -99,14 +99,17 @@ int oracle_get_fp_contract(void);
 /* ---- filter spec v2 (self-specified; see header comment) --------------------------------
  * Everything SURVEY.md App. B lists as unknown about cv::cuda::stat_denoiser::filter<T> is a field here, mirrored
  * by statmc_filter_spec of the C ABI (include/statmc.h).  All-zero = this build's default. */
-enum { ORACLE_GATE_SYMMETRIC = 0, ORACLE_GATE_ASYMMETRIC = 1 };
+enum { ORACLE_GATE_SYMMETRIC = 0, ORACLE_GATE_ASYMMETRIC = 1, ORACLE_GATE_CENTRE = 2 };
 enum { ORACLE_CHANNELS_AND = 0, ORACLE_CHANNELS_JOINT = 1 };
 enum { ORACLE_SIDES_TWO = 0, ORACLE_SIDES_ONE = 1 };
 enum { ORACLE_DOF_PIXEL = 0, ORACLE_DOF_WELCH = 1 };
 enum { ORACLE_BORDER_CLIP = 0, ORACLE_BORDER_CLAMP = 1 };
 enum { ORACLE_SMALL_N_ACCEPT = 0, ORACLE_SMALL_N_EXCLUDE = 1 };
 typedef struct {
-    int32_t gate;         /* SYMMETRIC: fma(d, d, -(D_p + D_q)) <= 0;  ASYMMETRIC (spec v1): fma(d, d, -D_q) <= D_p */
+    int32_t gate;         /* SYMMETRIC: fma(d, d, -(D_p + D_q)) <= 0;  ASYMMETRIC (spec v1): fma(d, d, -D_q) <= D_p;
+                             CENTRE: d * d <= D_p -- the neighbour's mean inside the CENTRE pixel's confidence interval, its own
+                             interval playing no part: the membership of Moon et al. 2013, which the reference's CUDA source
+                             switches to under -DMEMFNC=1 (README.md:147-150) */
     int32_t channel_rule; /* AND: every channel passes;  JOINT: sum_c lhs_c <= sum_c rhs_c */
     int32_t sides;        /* TWO: t_{1-alpha/2};  ONE: t_{1-alpha} */
     int32_t dof;          /* PIXEL: D = t(n-1)^2 s^2/n per pixel;  WELCH: the discriminator image holds s^2/n and the

@@ -360,7 +360,7 @@ int statmc_set_filter_spec(const statmc_filter_spec *spec) {
     if (!spec) return fail(STATMC_ERR_INVALID, "null spec");
     const int32_t v[6] = {spec->gate, spec->channel_rule, spec->sides, spec->dof, spec->border, spec->small_n};
     for (int i = 0; i < 6; i++)
-        if (v[i] != 0 && v[i] != 1) return fail(STATMC_ERR_INVALID, "filter spec field %d: %d is not 0 or 1", i, v[i]);
+        if (v[i] < 0 || v[i] > (i == 0 ? 2 : 1)) return fail(STATMC_ERR_INVALID, "filter spec field %d: %d is out of range", i, v[i]);
     int dev = 0;
     NEED_READY();
     HIP_TRY(hipGetDevice(&dev));

@@ -112,6 +112,9 @@ __device__ __forceinline__ bool pair_member(const FilterArgs &a, const float *mc
             }
             lhs = __builtin_fmaf(d, d, -Dsum);
             rhs = 0.f;
+        } else if (a.gate == STATMC_GATE_CENTRE) {
+            lhs = d * d;
+            rhs = Dp;
         } else if (a.gate == STATMC_GATE_ASYMMETRIC) {
             lhs = __builtin_fmaf(d, d, -Dq);
             rhs = Dp;
@@ -619,7 +622,7 @@ __device__ __forceinline__ void filter_tile(const FilterArgs &a, float *lds, int
     for (int idx = threadIdx.x; idx < G::ROWS * pitch; idx += kThreads) {
         const int rel = idx / pitch, i = idx - rel * pitch;
         const StagedPixel s = load_pixel<RGB>(a, x0 - rp + i, y0 - r + s0 + rel);
-        store_pixel(lds + rel * slot_floats, pitch, i, s, k0, k1, RGB);
+        store_pixel(lds + rel * slot_floats, pitch, i, s, k0, k1, RGB, a.gate == STATMC_GATE_CENTRE);
     }
     if ((int)threadIdx.x < tw) {
         const float *t = a.spatial_tab + s0 * tw + threadIdx.x;
@@ -650,7 +653,7 @@ __device__ __forceinline__ void filter_tile(const FilterArgs &a, float *lds, int
         eval_row<RT, K, SPEC>(st, row, pitch, tab_lds + ((step - s0) & 1) * tw_pad, n_chunks);
 
         if (tstage) *reinterpret_cast<v2f *>(tab_lds + ((step - s0 + 1) & 1) * tw_pad + 2 * ti) = tnext;
-        if (stage) store_pixel(lds + fill * slot_floats, pitch, threadIdx.x, nxt, k0, k1, RGB);
+        if (stage) store_pixel(lds + fill * slot_floats, pitch, threadIdx.x, nxt, k0, k1, RGB, a.gate == STATMC_GATE_CENTRE);
         __syncthreads();
         slot = slot + 1 == G::SLOTS ? 0 : slot + 1;
         fill = fill + 1 == G::SLOTS ? 0 : fill + 1;
@@ -920,14 +923,16 @@ static const char *sym_variant_name(const FilterArgs &a, int channels) {
     const bool joint = a.channel_rule == STATMC_CHANNELS_JOINT && channels == 3;
     const bool welch = a.dof == STATMC_DOF_WELCH;   // (one build for every radius; the gate field has no meaning under Welch)
     snprintf(name, sizeof(name), "%s%s%s%s%s%s", welch ? "sym_welch" : a.radius == 20 ? "sym_r20" : "sym_rt", channels == 1 ? "_f" : "", a.sym.g8 ? "_g8" : "",
-             a.gate == STATMC_GATE_ASYMMETRIC && !welch ? "_asym" : "", joint ? "_joint" : "", a.border == STATMC_BORDER_CLAMP ? "_clamp" : "");
+             welch ? "" : a.gate == STATMC_GATE_ASYMMETRIC ? "_asym" : a.gate == STATMC_GATE_CENTRE ? "_centre" : "", joint ? "_joint" : "",
+             a.border == STATMC_BORDER_CLAMP ? "_clamp" : "");
     return name;
 }
 
 // Launch of the one-sided LDS kernel for the arguments' spec.  The default membership test has a compile-time-radius
 // build for r = 20; the other tests (one-sided gate, pooled channels) run the runtime-radius build.
 static int lds_spec_of(const FilterArgs &a, bool rgb) {
-    return (a.gate == STATMC_GATE_ASYMMETRIC ? kSpecAsym : 0) | (rgb && a.channel_rule == STATMC_CHANNELS_JOINT ? kSpecJoint : 0);
+    // (STATMC_GATE_CENTRE runs the one-sided-gate build on rows staged with -D_q = 0)
+    return (a.gate != STATMC_GATE_SYMMETRIC ? kSpecAsym : 0) | (rgb && a.channel_rule == STATMC_CHANNELS_JOINT ? kSpecJoint : 0);
 }
 
 template <int K>
@@ -942,13 +947,13 @@ static hipError_t launch_lds_spec(const FilterArgs &a, hipStream_t s, const char
         *variant = rgb ? "lds_rt" : "lds_rt_f";
         return launch_lds<0, K>(a, s);
     case kSpecAsym:
-        *variant = rgb ? "lds_rt_asym" : "lds_rt_f_asym";
+        *variant = a.gate == STATMC_GATE_CENTRE ? (rgb ? "lds_rt_centre" : "lds_rt_f_centre") : (rgb ? "lds_rt_asym" : "lds_rt_f_asym");
         return launch_lds<0, K, kSpecAsym>(a, s);
     case kSpecJoint:
         *variant = "lds_rt_joint";
         return launch_lds<0, K, rgb ? kSpecJoint : 0>(a, s);
     default:
-        *variant = "lds_rt_asym_joint";
+        *variant = a.gate == STATMC_GATE_CENTRE ? "lds_rt_centre_joint" : "lds_rt_asym_joint";
         return launch_lds<0, K, rgb ? (kSpecAsym | kSpecJoint) : kSpecAsym>(a, s);
     }
 }

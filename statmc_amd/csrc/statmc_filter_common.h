@@ -104,8 +104,10 @@ __device__ __forceinline__ f3 canonical_mean(const f3 &mc, const Validity &v) {
     return f3{v.x ? mc.x : nan, v.y ? mc.y : nan, v.z ? mc.z : nan};
 }
 
+// zero_nd (one-sided kernel under STATMC_GATE_CENTRE): the staged -D_q is 0, so that the one-sided test
+// fma(d, d, -D_q) <= D_p of that kernel reads d * d <= D_p -- the tap's own interval plays no part
 __device__ __forceinline__ void store_pixel(float *slot, int pitch, int i, const StagedPixel &s, float k0, float k1,
-                                            bool rgb) {
+                                            bool rgb, bool zero_nd = false) {
     const bool v = s.valid && features_finite(s.g0, s.g1);
     const Validity ok = pixel_validity(s.mc, s.d, s.col, v, rgb);
     const f3 mc = canonical_mean(s.mc, ok);
@@ -119,9 +121,9 @@ __device__ __forceinline__ void store_pixel(float *slot, int pitch, int i, const
     p[(C_MC + 0) * pitch] = mc.x;
     p[(C_MC + 1) * pitch] = mc.y;
     p[(C_MC + 2) * pitch] = mc.z;
-    p[(C_ND + 0) * pitch] = ok.x ? -s.d.x : 0.f;
-    p[(C_ND + 1) * pitch] = ok.y ? -s.d.y : 0.f;
-    p[(C_ND + 2) * pitch] = ok.z ? -s.d.z : 0.f;
+    p[(C_ND + 0) * pitch] = ok.x && !zero_nd ? -s.d.x : 0.f;
+    p[(C_ND + 1) * pitch] = ok.y && !zero_nd ? -s.d.y : 0.f;
+    p[(C_ND + 2) * pitch] = ok.z && !zero_nd ? -s.d.z : 0.f;
     // the colour of a pixel that takes no part is staged as 0: its weight is 0, and 0 * NaN would
     // otherwise poison the sums of every window that covers it
     p[(C_COL + 0) * pitch] = ok.x ? s.col.x : 0.f;

@@ -79,14 +79,18 @@ constexpr int kModeRgb = 0, kModePair = 1, kModeJoint = 2, kModeAsym = 3, kModeA
 // kModeAsym / kModeAsymJoint: the one-sided gate (STATMC_GATE_ASYMMETRIC), channels one by one / pooled.  The pair is
 // still evaluated once, but its two directions are two tests -- fma(d, d, -D_q) <= D_p decides whether q enters p's
 // sums, fma(d, d, -D_p) <= D_q whether p enters q's -- so the pair carries two weights.
-constexpr int kModes = 5;
-constexpr bool mode_asym(int m) { return m == kModeAsym || m == kModeAsymJoint; }
+// kModeCentre / kModeCentreJoint (STATMC_GATE_CENTRE: Moon et al. 2013, the reference's -DMEMFNC=1): d * d <= D_p decides q's
+// membership in p's window, d * d <= D_q p's in q's -- two tests per pair like the one-sided gate, sharing one square.
+constexpr int kModeCentre = 5, kModeCentreJoint = 6;
+constexpr int kModes = 7;     // columns of the kernel table (the two Welch modes below have one build of their own)
+constexpr bool mode_centre(int m) { return m == kModeCentre || m == kModeCentreJoint; }
+constexpr bool mode_asym(int m) { return m == kModeAsym || m == kModeAsymJoint || mode_centre(m); }   // a pair carries two weights
 // Welch-Satterthwaite degrees of freedom (STATMC_DOF_WELCH), channels one by one / pooled: the discriminator image holds
 // v = s^2 / n, a fourth statistics image E = v^2 / (n - 1) is staged with it, and the pair looks its squared quantile up
 // at floor(nu), nu = (v_p + v_q)^2 / (E_p + E_q) -- symmetric in (p, q) like everything else the pair needs, so the pair
 // is still evaluated once.  These two modes exist in ONE build (register staging, six feature planes, runtime radius):
 // 18 input + 8 accumulator planes leave no room for the LDS-DMA landing area.
-constexpr int kModeWelch = 5, kModeWelchJoint = 6;
+constexpr int kModeWelch = 7, kModeWelchJoint = 8;
 constexpr bool mode_welch(int m) { return m == kModeWelch || m == kModeWelchJoint; }
 constexpr int kR = 20;
 constexpr int kPx = 4;                    // pixels per lane
@@ -314,12 +318,16 @@ __device__ __forceinline__ void gate_weight(const LaneT &st, const v4f *mcn, con
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 const v2f d = sub_bc(st.ms[k][ch], 0, pair_of<H>(mcn[ch]));
-                upq[ch] = __builtin_elementwise_fma(d, d, pair_of<H>(mcn[3 + ch]));   // fma(d, d, -D_q)
-                uqp[ch] = fma_sq_nbc(d, st.ms[k][ch]);                                 // fma(d, d, -D_p)
+                if constexpr (mode_centre(MODE)) {
+                    upq[ch] = uqp[ch] = d * d;                                          // against D_p, and against D_q
+                } else {
+                    upq[ch] = __builtin_elementwise_fma(d, d, pair_of<H>(mcn[3 + ch]));   // fma(d, d, -D_q)
+                    uqp[ch] = fma_sq_nbc(d, st.ms[k][ch]);                                 // fma(d, d, -D_p)
+                }
             }
             const v2f x = v2f{__builtin_amdgcn_exp2f(e[k].x), __builtin_amdgcn_exp2f(e[k].y)};
             bool p0, p1, q0, q1;
-            if constexpr (MODE == kModeAsymJoint) {
+            if constexpr (MODE == kModeAsymJoint || MODE == kModeCentreJoint) {
                 const v2f lp = (upq[0] + upq[1]) + upq[2], lq = (uqp[0] + uqp[1]) + uqp[2];
                 const float rp = (st.ms[k][0].y + st.ms[k][1].y) + st.ms[k][2].y;
                 const v2f rq = -((pair_of<H>(mcn[3]) + pair_of<H>(mcn[4])) + pair_of<H>(mcn[5]));   // (D_q0 + D_q1) + D_q2
@@ -1387,10 +1395,10 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
         dma = a.width % 4 == 0 && a.sym.fx0 % 4 == 0 && al16(mc3) && al16(d3) && al16(c3) && f_al;
     }
     // float buffers have one channel: pooled == per channel
-    const bool joint = a.channel_rule == STATMC_CHANNELS_JOINT, asym = a.gate == STATMC_GATE_ASYMMETRIC;
-    const int mode = pair ? kModePair : asym ? (joint ? kModeAsymJoint : kModeAsym) : joint ? kModeJoint : kModeRgb;
+    const bool joint = a.channel_rule == STATMC_CHANNELS_JOINT, asym = a.gate == STATMC_GATE_ASYMMETRIC, centre = a.gate == STATMC_GATE_CENTRE;
+    const int mode = pair ? kModePair : centre ? (joint ? kModeCentreJoint : kModeCentre) : asym ? (joint ? kModeAsymJoint : kModeAsym) : joint ? kModeJoint : kModeRgb;
 #define STATMC_SYM_K(D, M, G, R) reinterpret_cast<const void *>(&window_filter_sym<D, M, G, R>)
-#define STATMC_SYM_ROW(D, G, R) {STATMC_SYM_K(D, kModeRgb, G, R), STATMC_SYM_K(D, kModePair, G, R), STATMC_SYM_K(D, kModeJoint, G, R), STATMC_SYM_K(D, kModeAsym, G, R), STATMC_SYM_K(D, kModeAsymJoint, G, R)}
+#define STATMC_SYM_ROW(D, G, R) {STATMC_SYM_K(D, kModeRgb, G, R), STATMC_SYM_K(D, kModePair, G, R), STATMC_SYM_K(D, kModeJoint, G, R), STATMC_SYM_K(D, kModeAsym, G, R), STATMC_SYM_K(D, kModeAsymJoint, G, R), STATMC_SYM_K(D, kModeCentre, G, R), STATMC_SYM_K(D, kModeCentreJoint, G, R)}
     // [runtime radius][eight feature planes][LDS-DMA staging][mode]
     const void *kernels[2][2][2][kModes] = {{{STATMC_SYM_ROW(false, 6, false), STATMC_SYM_ROW(true, 6, false)}, {STATMC_SYM_ROW(false, 8, false), STATMC_SYM_ROW(true, 8, false)}},
                                             {{STATMC_SYM_ROW(false, 6, true), STATMC_SYM_ROW(true, 6, true)}, {STATMC_SYM_ROW(false, 8, true), STATMC_SYM_ROW(true, 8, true)}}};

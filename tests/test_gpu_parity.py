@@ -1223,8 +1223,9 @@ def test_filter_randomised_configurations(gpu, oracle):
 # ------------------------------------------------------------------ filter spec v2: every open choice, HIP == oracle
 import itertools
 
+# three gate forms (symmetric, one-sided, centre interval only = Moon et al. / -DMEMFNC=1) x 2^5
 SPEC_VARIANTS = [dict(zip(("gate", "channel_rule", "sides", "dof", "border", "small_n"), v))
-                 for v in itertools.product((0, 1), repeat=6)]
+                 for v in itertools.product((0, 1, 2), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1))]
 
 
 def spec_id(v):
@@ -1271,14 +1272,15 @@ def expected_lds_variant(spec_kw, channels, radius):
         # the gate field has no meaning under Welch), float buffers the general kernel
         return "sym_welch" + ("_joint" if joint else "") + ("_clamp" if border else "") if channels == 3 else "generic"
     f = "_f" if channels == 1 else ""
+    g = ("", "_asym", "_centre")[gate]
     if channels == 3 or not gate:       # the pair-symmetric kernel: compile-time radius 20, runtime radius below
-        return ("sym_r20" if radius == 20 else "sym_rt") + f + ("_asym" if gate else "") + ("_joint" if joint else "") + ("_clamp" if border else "")
-    return "lds_rt" + f + ("_asym" if gate else "") + ("_joint" if joint else "")
+        return ("sym_r20" if radius == 20 else "sym_rt") + f + g + ("_joint" if joint else "") + ("_clamp" if border else "")
+    return "lds_rt" + f + g + ("_joint" if joint else "")
 
 
 @pytest.mark.parametrize("spec_kw", SPEC_VARIANTS, ids=[spec_id(v) for v in SPEC_VARIANTS])
 def test_filter_spec_variants_match_oracle(gpu, oracle, spec_kw):
-    """All 64 combinations of the six open choices (gate form, channel rule, quantile sides, dof, border,
+    """All 96 combinations of the six open choices (gate form, channel rule, quantile sides, dof, border,
     n < 2): pre-pass bit-exact, window filter <= 1e-5 per channel, on a 3-spp case (wide intervals, many
     decisions near the threshold) with a one-sample pixel and a non-default significance level."""
     _, smp, st = make_case(90, 30, 3, seed=17)
@@ -1297,7 +1299,7 @@ def test_filter_spec_variants_match_oracle(gpu, oracle, spec_kw):
         # ... and the one-sided LDS kernel's build for the spec (Welch: it has none -- the general kernel)
         _, _, out_l, variant_l, _ = run_spec(gpu, oracle, st, spec_kw, radius=7, sd=4.0, alpha_index=2, force=2)
         gate, joint = spec_kw.get("gate", 0), spec_kw.get("channel_rule", 0)
-        assert variant_l == ("generic" if spec_kw.get("dof", 0) else "lds_rt" + ("_asym" if gate else "") + ("_joint" if joint else "")), variant_l
+        assert variant_l == ("generic" if spec_kw.get("dof", 0) else "lds_rt" + ("", "_asym", "_centre")[gate] + ("_joint" if joint else "")), variant_l
         for c in range(3):
             assert rel_l2(out_l[..., c], oout[..., c]) <= TOL, c
 
@@ -1318,7 +1320,9 @@ def test_filter_spec_r20_and_float(gpu, oracle, spec_kw, channels):
 
 def test_filter_spec_errors_and_per_device_state(gpu):
     lib = gpu.load()
-    bad = gpu.FilterSpec(gate=2)
+    bad = gpu.FilterSpec(gate=3)
+    assert lib.statmc_set_filter_spec(C.byref(bad)) == gpu.ERR_INVALID
+    bad = gpu.FilterSpec(channel_rule=2)
     assert lib.statmc_set_filter_spec(C.byref(bad)) == gpu.ERR_INVALID
     assert lib.statmc_set_filter_spec(None) == gpu.ERR_INVALID
     gpu.set_filter_spec(border=1, sides=1)

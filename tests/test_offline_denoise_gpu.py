@@ -105,14 +105,14 @@ def test_fit_spec_finds_the_spec_that_wrote_the_dumps(gpu, tmp_path):
     assert best.group(1) == "2" and best.group(2) == "gate=sym,channels=joint,sides=one", out.stdout
     assert float(best.group(3)) <= 1e-5
     rows = [l for l in out.stdout.splitlines() if re.match(r"^\d\.\d+e", l)]
-    assert len(rows) == 3 * 8                                                    # 3 levels x 2^3 specs
+    assert len(rows) == 3 * 12                                                   # 3 levels x (3 gate forms x 2^2) specs
     assert float(rows[1].split()[0]) > 1e-5 or "gate=asym,channels=joint,sides=one" in rows[1]   # only the rounding-twin gate form ties
 
 
 def test_pin_from_dumps_end_to_end(gpu, tmp_path):
     """tools/pin_from_dumps.sh on a directory of dumps: the oracle under a non-default spec (pooled channels, clamped
     border, n < 2 excluded, alpha 0.002) stands in for the CUDA build.  Two stems; the tool must print the table, find
-    exactly that spec over the full 64 x 3 grid and write it as the pinned default (to a scratch header: the tree's
+    exactly that spec over the full 96 x 3 grid and write it as the pinned default (to a scratch header: the tree's
     own default is not touched, nothing is rebuilt)."""
     import re
     import sys
@@ -147,7 +147,7 @@ def test_pin_from_dumps_end_to_end(gpu, tmp_path):
     h = header.read_text()
     assert re.search(r"#define STATMC_PINNED_SPEC \{[01], 1, 0, 0, 1, 1\}", h) and "#define STATMC_PINNED_SIGNIFICANCE 1" in h
     table = (tmp_path / "pin_table.txt").read_text()
-    assert table.count("==== scene") == 2 and len([l for l in table.splitlines() if re.match(r"^\d\.\d+e", l)]) == 2 * 3 * 64
+    assert table.count("==== scene") == 2 and len([l for l in table.splitlines() if re.match(r"^\d\.\d+e", l)]) == 2 * 3 * 96
     # a directory whose outputs no spec reproduces is reported, not pinned
     pfm.write_pfm(str(tmp_path / ("sceneA-%d-film-f.pfm" % spp)), film_f * 1.01)
     out = subprocess.run([os.path.join(root, "tools", "pin_from_dumps.sh"), str(tmp_path), "--filtersd", str(float(g["filter_sd"])),

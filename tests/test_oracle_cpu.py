@@ -419,3 +419,26 @@ def test_filter_pixel_with_a_non_finite_feature_takes_no_part(oracle):
     mask = np.ones((H, W), bool)
     mask[5, 7] = mask[10, 20] = False
     assert np.array_equal(out[mask], out2[mask])
+
+
+def test_centre_gate_is_the_confidence_interval_of_the_centre_pixel(oracle):
+    """STATMC_GATE_CENTRE (round 4): q is a member of p's window iff d^2 <= D_p in every channel -- q's own interval plays no
+    part (Moon et al. 2013; what the reference's CUDA source does under -DMEMFNC=1, README.md:147-150).  Hand-built: a tight
+    pixel next to a wide one is averaged INTO the wide one but does not take the wide one in."""
+    H, W = 1, 2
+    mc = np.zeros((H, W, 3), np.float32)
+    mc[0, 1, :] = 1.0                       # d = 1 in every channel
+    dc = np.zeros((H, W, 3), np.float32)
+    dc[0, 0, :] = 4.0                       # pixel 0: wide interval (d^2 = 1 <= 4)
+    dc[0, 1, :] = 0.25                      # pixel 1: tight interval (1 > 0.25)
+    col = np.zeros((H, W, 3), np.float32)
+    col[0, 0, :] = 10.0
+    col[0, 1, :] = 20.0
+    f = lambda **kw: oracle.filter_image(mc, dc, col, [], [], -0.5, 1, spec=oracle.FilterSpec(**kw))
+    c = f(gate=oracle.GATE_CENTRE)
+    assert 10.0 < c[0, 0, 0] < 20.0         # pixel 1 lies inside pixel 0's interval
+    assert np.all(c[0, 1] == 20.0)          # pixel 0 lies outside pixel 1's
+    s = f()                                  # the symmetric gate takes both: 1 <= 4.25
+    assert 10.0 < s[0, 0, 0] < 20.0 and 10.0 < s[0, 1, 0] < 20.0
+    j = f(gate=oracle.GATE_CENTRE, channel_rule=oracle.CHANNELS_JOINT)    # pooled: 3 <= 12 / 3 > 0.75
+    assert 10.0 < j[0, 0, 0] < 20.0 and np.all(j[0, 1] == 20.0)

@@ -22,7 +22,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FIELDS = (("gate", ("sym", "asym")), ("channels", ("and", "joint")), ("sides", ("two", "one")),
+FIELDS = (("gate", ("sym", "asym", "centre")), ("channels", ("and", "joint")), ("sides", ("two", "one")),
           ("dof", ("pixel", "welch")), ("border", ("clip", "clamp")), ("small_n", ("accept", "exclude")))
 
 

@@ -10,7 +10,7 @@ denoising run for the outputs): for every <stem> and sample count
     outputs  <stem>-<spp>-{film-f, t0-b0-mean-corr, t0-b0-discriminator}.pfm         (in <dir> or in --ref <dir>)
 What it does:
   1. finds the (stem, spp) sets that are complete,
-  2. runs tools/fit_spec.py over them: all 64 filter specs x 3 significance levels through the HIP library
+  2. runs tools/fit_spec.py over them: all 96 filter specs (three gate forms x 2^5) x 3 significance levels through the HIP library
      (tools/bin/statmc_denoise --compare), per-channel relative L2 of film-f / mean-corr / discriminator -> <dir>/pin_table.txt,
   3. writes the winner as the NEW DEFAULT of library and oracle: include/statmc_pinned_spec.h,
   4. unless --no-rebuild: rebuilds libstatmc_hip.so, the host tools and the oracle, regenerates tests/golden/ with the
@@ -27,7 +27,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INPUTS = ("film", "t0-b0-n", "t0-b0-mean", "t0-b0-m2", "t0-b0-m3", "t1-b0-film-mean", "t2-b0-film-mean")
 OUTPUTS = ("film-f", "t0-b0-mean-corr", "t0-b0-discriminator")
-FIELDS = (("gate", ("sym", "asym")), ("channels", ("and", "joint")), ("sides", ("two", "one")),
+FIELDS = (("gate", ("sym", "asym", "centre")), ("channels", ("and", "joint")), ("sides", ("two", "one")),
           ("dof", ("pixel", "welch")), ("border", ("clip", "clamp")), ("small_n", ("accept", "exclude")))
 BOUND = 1e-5
 
@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--tquantiles", default=None)
     ap.add_argument("--header", default=os.path.join(ROOT, "include", "statmc_pinned_spec.h"))
     ap.add_argument("--no-rebuild", action="store_true")
-    ap.add_argument("--quick", action="store_true", help="gate / channel rule / sides only (8 specs x 3 levels)")
+    ap.add_argument("--quick", action="store_true", help="gate / channel rule / sides only (12 specs x 3 levels)")
     args = ap.parse_args()
     refdir = args.ref or args.dir
     sets = discover(args.dir, refdir)

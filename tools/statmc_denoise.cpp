@@ -222,14 +222,15 @@ int main(int argc, char **argv) {
             if (sweep != "all" && sweep != "quick") throw std::runtime_error("--sweep all | quick");
             const char *names[6] = {"gate", "channels", "sides", "dof", "border", "small_n"};
             const char *vals[6][2] = {{"sym", "asym"}, {"and", "joint"}, {"two", "one"}, {"pixel", "welch"}, {"clip", "clamp"}, {"accept", "exclude"}};
+            const char *gates[3] = {"sym", "asym", "centre"};
             const int nFree = sweep == "quick" ? 3 : 6;
             for (const auto &sg : split(sweepSignificance))
-                for (int m = 0; m < (1 << nFree); m++) {
-                    std::string t;
-                    for (int f = 0; f < nFree; f++)   // first field slowest, like itertools.product
-                        t += std::string(f ? "," : "") + names[f] + "=" + vals[f][(m >> (nFree - 1 - f)) & 1];
-                    runs.push_back({std::stoi(sg), t});
-                }
+                for (int g = 0; g < 3; g++)          // first field slowest, like itertools.product
+                    for (int m = 0; m < (1 << (nFree - 1)); m++) {
+                        std::string t = std::string("gate=") + gates[g];
+                        for (int f = 1; f < nFree; f++) t += std::string(",") + names[f] + "=" + vals[f][(m >> (nFree - 1 - f)) & 1];
+                        runs.push_back({std::stoi(sg), t});
+                    }
         }
         auto applyRun = [&](int sig, const std::string &spec) {
             const statmc_filter_spec sp = stat_denoiser::parseFilterSpec(spec);
