@@ -13,7 +13,7 @@ scene = synthetic.Scene(W, H, seed=1, device=dev)
 fs = film.FilmStats(W, H, dev)
 fs.accumulate(scene.samples(32, seed=2, features=("radiance", "normal", "albedo")))
 torch.cuda.synchronize()
-for kw in (dict(), dict(border=1), dict(gate=1), dict(channel_rule=1), dict(gate=1, channel_rule=1, border=1), dict(sides=1, small_n=1), dict(dof=1)):
+for kw in (dict(), dict(border=1), dict(gate=1), dict(channel_rule=1), dict(gate=1, channel_rule=1, border=1), dict(sides=1, small_n=1), dict(gate=2), dict(gate=2, channel_rule=1), dict(dof=1)):
     api.set_filter_spec(**kw)
     fs.prepass()
     a, keep = fs.filter_args()
