@@ -57,20 +57,10 @@ class PeerBlock:
             self.ev[name] = e
 
     def border_rows(self):
-        L = self.layout
-        out = []
-        if L.world > 1 and L.gx == 1 and L.bh >= 2 * L.r + 8:
-            if L.up is not None:
-                out.append((0, L.r))
-            if L.down is not None:
-                out.append((L.bh - L.r, L.bh))
-        return out
+        return self.layout.border_rows()
 
     def interior_rows(self):
-        b = self.border_rows()
-        lo = self.layout.r if any(y0 == 0 for y0, _ in b) else 0
-        hi = self.layout.bh - (self.layout.r if any(y1 == self.layout.bh for _, y1 in b) else 0)
-        return (lo, hi)
+        return self.layout.interior_rows()
 
 
 class PeerFilm:

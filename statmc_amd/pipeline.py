@@ -56,20 +56,10 @@ class BlockPipeline:
     # those of the one-piece order.
     def border_rows(self):
         """Row ranges of the owned block that go to a neighbour: [(0, r)] and / or [(bh - r, bh)]."""
-        L = self.layout
-        out = []
-        if self.multi and L.gx == 1 and L.bh >= 2 * L.r + 8:
-            if L.up is not None:
-                out.append((0, L.r))
-            if L.down is not None:
-                out.append((L.bh - L.r, L.bh))
-        return out
+        return self.layout.border_rows()
 
     def interior_rows(self):
-        b = self.border_rows()
-        lo = self.layout.r if any(y0 == 0 for y0, _ in b) else 0
-        hi = self.layout.bh - (self.layout.r if any(y1 == self.layout.bh for _, y1 in b) else 0)
-        return (lo, hi)
+        return self.layout.interior_rows()
 
     def accumulate_and_denoise(self, samples, overlap=True):
         """One iteration on this rank's block: accumulate -> pre-pass -> halo exchange -> window filter.  With `overlap`

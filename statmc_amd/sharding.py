@@ -71,6 +71,24 @@ class BlockLayout:
         """Owned pixels inside the padded local image: (x0, y0, x1, y1)."""
         return (self.pl, self.pt, self.pl + self.bw, self.pt + self.bh)
 
+    # Row-strip grids: the rows a neighbour needs (its halo) are accumulated, pre-passed and sent first, the rest of the
+    # block while they travel (pipeline.py, peer.py).  Blocks too short to have an interior keep the plain order.
+    def border_rows(self):
+        """Row ranges of the owned block that go to a neighbour: [(0, r)] and / or [(bh - r, bh)]; [] = plain order."""
+        out = []
+        if self.world > 1 and self.gx == 1 and self.bh >= 2 * self.r + 8:
+            if self.up is not None:
+                out.append((0, self.r))
+            if self.down is not None:
+                out.append((self.bh - self.r, self.bh))
+        return out
+
+    def interior_rows(self):
+        b = self.border_rows()
+        lo = self.r if any(y0 == 0 for y0, _ in b) else 0
+        hi = self.bh - (self.r if any(y1 == self.bh for _, y1 in b) else 0)
+        return (lo, hi)
+
     def new_padded(self, channels, device, dtype=torch.float32):
         return torch.zeros(self.ph, self.pw, channels, dtype=dtype, device=device)
 

@@ -1,0 +1,62 @@
+"""ONE process, every block (statmc_amd/peer.py): the whole step through the C ABI -- statmc_accumulate_row_ranges ->
+statmc_prepass_pack_rows -> statmc_halo_exchange (device-to-device copies) -> statmc_window_filter -- for row strips in the
+overlapped order and for 2-D grids (two exchange phases), six and eight feature planes, several steps in a row (the packed
+images are rewritten every step).  All blocks live on cuda:0 here (the test box has one GPU): the same code drives one
+block per device on a multi-GPU node.  The assembled film equals the whole film, bit for bit under a pinned split."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+TYPES = ("radiance", "normal", "albedo")
+TYPES8 = ("radiance", "normal", "albedo", "depth", "materialid")
+G8 = ("materialid", "depth", "normal", "albedo")
+
+
+@pytest.mark.parametrize("grid,bw,bh,g8,radius", [((1, 3), 272, 56, False, 20), ((2, 2), 144, 40, False, 20), ((2, 1), 136, 48, True, 20),
+                                                  ((1, 2), 260, 64, True, 6), ((1, 4), 128, 24, False, 20)],
+                         ids=["1x3-overlapped", "2x2", "2x1-eight-planes", "1x2-overlapped-eight-planes-r6", "1x4-short-strips"])
+def test_peer_film_equals_whole_film(gpu, grid, bw, bh, g8, radius):
+    from statmc_amd import peer, pipeline, sharding, synthetic
+    gx, gy = grid
+    world = gx * gy
+    types = TYPES8 if g8 else TYPES
+    kw = dict(g_buffers=G8) if g8 else {}
+    scene = synthetic.Scene(gx * bw, gy * bh, n_regions=7, seed=5)
+    batches = [scene.samples(4, seed=6, features=types), scene.samples(3, seed=7, features=types)]     # two steps: 4 + 3 samples
+    gpu.set_filter_split(2)
+    try:
+        one = pipeline.BlockPipeline(sharding.BlockLayout(0, 1, gx * bw, gy * bh, radius), DEV, types, radius=radius, filter_sd=radius / 2.0, **kw)
+        refs = []
+        for smp in batches:
+            one.accumulate({k: v.to(DEV) for k, v in smp.items()})
+            refs.append(one.denoise().clone())
+        pf = peer.PeerFilm(world, bw, bh, radius, [0] * world, types, filter_sd=radius / 2.0, grid=grid, **kw)
+        assert pf.overlap == (gx == 1 and bh >= 2 * radius + 8)
+        assert pf.blocks[0].packed.shape[2] == (17 if g8 else 15)
+        for smp, ref in zip(batches, refs):
+            per_block = []
+            for blk in pf.blocks:
+                ox, oy = blk.layout.origin
+                per_block.append([{k: v[:, oy:oy + bh, ox:ox + bw].contiguous().to(DEV) for k, v in smp.items()}])
+            pf.run(pf.prepare_step(per_block))
+            pf.synchronize()
+            got = pf.gather()
+            pf.synchronize()
+            assert torch.equal(got, ref)
+        # the plain order on a grid that overlaps by default: same bits
+        if pf.overlap:
+            pf.reset()
+            pf.synchronize()
+            for smp in batches:
+                per_block = []
+                for blk in pf.blocks:
+                    ox, oy = blk.layout.origin
+                    per_block.append([{k: v[:, oy:oy + bh, ox:ox + bw].contiguous().to(DEV) for k, v in smp.items()}])
+                pf.run(pf.prepare_step(per_block, overlap=False))
+            pf.synchronize()
+            assert torch.equal(pf.gather(), refs[-1])
+            pf.synchronize()
+    finally:
+        gpu.set_filter_split(0)
