@@ -898,6 +898,33 @@ class Estimator {
         return host;
     }
 
+    // The noise level of the estimate per render tile, for a sampler that spends its next samples where they are needed:
+    // per tileSize x tileSize tile the mean over its pixels of the variance of the mean, film-m2 / ((n - 1) n)
+    // (statmc_calculate_mean_vars, per pixel: no row quirk), summed over the channels in channel order -- one launch of the
+    // per-pixel kernel and one of the wave-level tile reduction (statmc_tile_moments), tiles_x * tiles_y floats back.
+    // Row-major over the tiles; blocks until it is there.  tools/statmc_render_sim.cpp --adaptive is the consumer.
+    std::vector<float> TileNoise(unsigned char type = 0, unsigned char bounce = 0, int tileSize = 16) {
+        joinUploads();
+        const Buffer &m2 = filmM2Buffers.at(type).at(bounce), &n = nBuffers.at(type).at(bounce);
+        const int C = m2.gpuMat.channels();
+        const int tx = (width + tileSize - 1) / tileSize, ty = (height + tileSize - 1) / tileSize;
+        DeviceImage var(height, width, C == 3 ? F32C3 : F32C1), dev(ty, tx * C, F32C3);
+        HostImage host(ty, tx * C, F32C3);
+        const statmc_image dn = n.gpuMat.desc(), dm2 = m2.gpuMat.desc(), dvar = var.desc();
+        check(statmc_calculate_mean_vars(1, (uint16_t)width, (uint16_t)height, C, &dn, &dm2, &dvar, /*row_n_quirk=*/0, stream.handle()));
+        check(statmc_tile_moments((uint16_t)width, (uint16_t)height, C, static_cast<const float *>(var.data()), tileSize,
+                                  static_cast<float *>(dev.data()), stream.handle()));
+        dev.download(host, stream);
+        Synchronize();
+        std::vector<float> noise((size_t)tx * ty);
+        for (size_t t = 0; t < noise.size(); t++) {
+            float s = 0.f;
+            for (int c = 0; c < C; c++) s += host.ptr<float>()[(t * C + c) * 3 + 1];   // {count, mean, M2}: the tile mean
+            noise[t] = s;
+        }
+        return noise;
+    }
+
     // ---- the accumulation side: tiles in, statistics images on the device ------------------
     // The reference's constructor also takes the film's cropped pixel bounds and its pixel reconstruction filter
     // (estimator.h:253,264-265); only GetTilesF reads them, so here they are optional settings.  Defaults: the whole

@@ -39,10 +39,10 @@ def unit(key):
     return (key >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
 
 
-def make_samples(seed, W, H, s0, S):
-    """[S, H, W, 3] radiance, normal, albedo samples number s0 .. s0+S-1 of every pixel (fp32, same
-    operation order as makeSample in tools/statmc_render_sim.cpp)."""
-    y, x = np.mgrid[0:H, 0:W]
+def make_samples(seed, W, H, s0, S, x0=0, y0=0):
+    """[S, H, W, 3] radiance, normal, albedo samples number s0 .. s0+S-1 of every pixel of the W x H window at (x0, y0)
+    (fp32, same operation order as makeSample in tools/statmc_render_sim.cpp)."""
+    y, x = np.mgrid[y0:y0 + H, x0:x0 + W]
     region = ((x // 24) + (y // 20)) % 3
     e = np.float32(0.5) + np.float32(0.5) * (((x * 7 + y * 3) % 32).astype(np.float32) / np.float32(32.0))
     rad = np.zeros((S, H, W, 3), np.float32)
@@ -108,6 +108,71 @@ def test_render_loop_matches_oracle(gpu, oracle, tmp_path, W, H, stage_mb):
         tm = oracle.tile_moments(r["film_mean"], 16)
         assert np.array_equal(rd("t0-b0-tile-mean"), tm[..., 1])
         assert np.array_equal(rd("t0-b0-tile-var"), np.where(tm[..., 0] > 1, tm[..., 2] / np.maximum(tm[..., 0] - 1, 1), 0).astype(np.float32))
+
+
+def test_render_loop_adaptive_budgets(gpu, oracle, tmp_path):
+    """--adaptive: the tile-local moments steer the sampler.  After every iteration the tiles are ranked by
+    Estimator::TileNoise (tile mean of film-m2 / ((n - 1) n), summed over the channels: statmc_calculate_mean_vars +
+    statmc_tile_moments); the noisiest quarter gets twice the schedule's samples in the next iteration, the quietest quarter
+    half.  The budgets are recomputed here from the oracle's statistics alone: the ranking is only the same if the device's
+    per-tile noise equals the oracle's in order, and the ragged statistics that follow are checked per pixel."""
+    from statmc_amd import build, pfm
+    build.build_tools()
+    W, H, spp, iterations, seed, T = 88, 44, 4, 3, 11, 16
+    stem = str(tmp_path / "adaptive")
+    out = subprocess.run([build.RENDER_SIM_BIN, "--width", str(W), "--height", str(H), "--spp", str(spp), "--iterations",
+                          str(iterations), "--threads", "4", "--seed", str(seed), "--stem", stem, "--adaptive"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    tx, ty = (W + T - 1) // T, (H + T - 1) // T
+    n_tiles = tx * ty
+    keys = ("n", "mean", "m2", "m3", "film_mean", "film_m2")
+    st = {k: oracle.new_state(H, W, 3) for k in ("rad", "nrm", "alb")}
+    tile_done = np.zeros(n_tiles, np.int64)
+    noise, done = None, 0
+    for i in range(1, iterations + 1):
+        target = spp if i == 1 else spp << (i - 2)
+        budget = np.full(n_tiles, target, np.int64)
+        if noise is not None:
+            order = np.argsort(noise, kind="stable")
+            q = n_tiles // 4
+            budget[order[:q]] = max(1, target // 2)
+            budget[order[n_tiles - q:]] = 2 * target
+        for t in range(n_tiles):
+            x0, y0 = (t % tx) * T, (t // tx) * T
+            x1, y1 = min(x0 + T, W), min(y0 + T, H)
+            smp = make_samples(seed, x1 - x0, y1 - y0, int(tile_done[t]), int(budget[t]), x0, y0)
+            for name, s_t, (transform, mm) in zip(("rad", "nrm", "alb"), smp, ((True, 3), (False, 1), (False, 1))):
+                sub = oracle.new_state(y1 - y0, x1 - x0, 3)
+                for k in keys:
+                    sub[k][...] = st[name][k][y0:y1, x0:x1]
+                oracle.accumulate(sub, s_t, transform, mm)
+                for k in keys:
+                    st[name][k][y0:y1, x0:x1] = sub[k]
+        tile_done += budget
+        done += target
+        r = st["rad"]
+        tm = oracle.tile_moments(oracle.mean_vars(r["n"], r["film_m2"], row_n_quirk=False), T)     # [ty, tx, 3, {count, mean, M2}]
+        noise = ((tm[..., 0, 1] + tm[..., 1, 1]) + tm[..., 2, 1]).reshape(-1)
+        rd = lambda name: pfm.read_pfm("%s-%d-%s.pfm" % (stem, done, name))
+        assert np.array_equal(rd("t0-b0-n"), r["n"].astype(np.float32)), i
+        assert np.array_equal(rd("t1-b0-n"), st["nrm"]["n"].astype(np.float32)), i
+        assert np.array_equal(rd("t0-b0-film-mean"), r["film_mean"]), i
+        assert np.array_equal(rd("t0-b0-film-m2"), r["film_m2"]), i
+        assert np.array_equal(rd("t1-b0-mean"), st["nrm"]["mean"]), i
+        assert np.array_equal(rd("t2-b0-mean"), st["alb"]["mean"]), i
+        for k in ("mean", "m2", "m3"):
+            assert rel_l2(rd("t0-b0-" + k), r[k]) <= 1e-5, (i, k)
+        assert "Adaptive: samples per pixel so far %d .. %d over %d tiles" % (tile_done.min(), tile_done.max(), n_tiles) in out.stdout
+    assert tile_done.min() < done < tile_done.max()          # the budgets did move
+    # the filter runs on ragged counts: the denoised image against the oracle's on its own statistics
+    r = st["rad"]
+    mc, dc = oracle.prepass(r["n"], r["mean"], r["m2"], r["m3"])
+    ref = oracle.filter_image(mc, dc, r["film_mean"], [st["nrm"]["mean"], st["alb"]["mean"]],
+                              [-0.5 / 0.1 ** 2, -0.5 / 0.02 ** 2], -0.5 / 10.0 ** 2, 20)
+    got = pfm.read_pfm("%s-%d-t0-b0-film-mean-f.pfm" % (stem, done))
+    for c in range(3):
+        assert rel_l2(got[..., c], ref[..., c]) <= 1e-5, c
 
 
 def test_render_loop_statistics_only(gpu, tmp_path):

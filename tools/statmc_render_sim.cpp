@@ -20,6 +20,8 @@
 //   statmc_render_sim --width 96 --height 56 --spp 4 --iterations 3 --stem out/sim [--threads 4]
 //                     [--seed 1] [--filtersd 10] [--filterradius 20] [--stage-mb 2048] [--no-denoise]
 //                     [--config denoise|acrr|smis] [--trackedbounces 5] [--outputregex '.*'] [--warmup] [--tilestats]
+//                     [--adaptive]
+// --adaptive: per-tile sample budgets from the tile-local noise level (Estimator::TileNoise); see RenderLoop.
 // --config denoise: Render<Vec3>, RGB radiance + normal + albedo, filter<float3> (scenes/render-denoise.pbrt).
 // --config acrr:    Render<Float>, "multichannelstats" false: the luminance of the path prefix up to each
 //                   of the tracked bounces is one float stat buffer, filtered together by filter<float>
@@ -104,7 +106,7 @@ struct Options {
     unsigned seed = 1;
     float filterSD = 10.f;
     int filterRadius = 20;
-    bool denoise = true, acrr = false, smis = false, warmUp = false, tileStats = false;
+    bool denoise = true, acrr = false, smis = false, warmUp = false, tileStats = false, adaptive = false;
     std::string stem, outputRegex = ".*";
 };
 
@@ -162,10 +164,27 @@ static void Render(const Options &o) {
 
     const OutputBufferSelection outBufSel(reg, std::regex(o.outputRegex), (o.stem.empty() ? std::string("out") : o.stem) + ".pfm");
 
-    unsigned done = 0;  // samples per pixel so far
+    unsigned done = 0;  // samples per pixel so far (the nominal count: the dumps' names)
+    // --adaptive (no counterpart in the reference: the consumer of the tile-local moments): after every iteration the tiles
+    // are ranked by the noise of their radiance estimate (Estimator::TileNoise: tile mean of the variance of the mean, from
+    // the wave-level reduction statmc_tile_moments), and in the next iteration the noisiest quarter gets twice the
+    // schedule's samples per pixel, the quietest quarter half of them (at least one).  Counts then differ from tile to tile.
+    std::vector<unsigned> tileDone(nTilesTotal, 0u);      // samples per pixel so far, tile by tile
+    std::vector<float> tileNoise;                          // of the last iteration (empty: no ranking yet)
     auto RenderLoop = [&](const int nIterations, const bool writeOutput) {
     for (int i = 1; i <= nIterations; i++) {
         const unsigned target = i == 1 ? (unsigned)o.spp : (unsigned)o.spp << std::max(i - 2, 0);  // statpath.cpp:272-279
+        std::vector<unsigned> tileTarget(nTilesTotal, target);
+        if (o.adaptive && !tileNoise.empty()) {
+            std::vector<int> order(nTilesTotal);
+            for (int t = 0; t < nTilesTotal; t++) order[t] = t;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return tileNoise[a] < tileNoise[b]; });   // ties: tile order
+            const int q = nTilesTotal / 4;
+            for (int k = 0; k < q; k++) {
+                tileTarget[order[k]] = std::max(1u, target / 2);
+                tileTarget[order[nTilesTotal - 1 - k]] = 2 * target;
+            }
+        }
         auto begin = std::chrono::steady_clock::now();
         std::atomic<int> nextTile{0};
         std::atomic<bool> failed{false};
@@ -176,6 +195,7 @@ static void Render(const Options &o) {
                 std::vector<Vec3> Ls(nLs);
                 for (int t = nextTile.fetch_add(1); t < nTilesTotal; t = nextTile.fetch_add(1)) {
                     const Bounds2i tb = tileBoundsOf(t);
+                    const unsigned target = tileTarget[t], done = tileDone[t];   // (shadow the schedule's: this tile's)
                     std::vector<StatTile<T>> &tileLs = lTiles[t];
                     std::vector<std::vector<StatTile<Vec3>>> &tileRGBFeatures = rgbFeatureTiles[t];
                     std::vector<std::vector<StatTile<float>>> &tileMISTallies = misTallyTiles[t];
@@ -218,6 +238,7 @@ static void Render(const Options &o) {
         for (auto &t : pool) t.join();
         if (failed) throw std::runtime_error(failure);
         done += target;
+        for (int t = 0; t < nTilesTotal; t++) tileDone[t] += tileTarget[t];
         auto end = std::chrono::steady_clock::now();
         std::cout << "Iteration: " << i << std::endl;
         std::cout << "SPP: " << target << std::endl;
@@ -232,6 +253,12 @@ static void Render(const Options &o) {
         estimator.Synchronize();
         end = std::chrono::steady_clock::now();
         std::cout << "CUDA time [ns]: " << std::chrono::duration_cast<std::chrono::nanoseconds>(end - begin).count() << std::endl;
+        if (o.adaptive && sCfgs[Radiance].enable) {
+            tileNoise = estimator.TileNoise(sCfgs[Radiance].index, 0, tileSize);
+            unsigned lo = ~0u, hi = 0;
+            for (unsigned v : tileDone) { lo = std::min(lo, v); hi = std::max(hi, v); }
+            std::cout << "Adaptive: samples per pixel so far " << lo << " .. " << hi << " over " << nTilesTotal << " tiles" << std::endl;
+        }
 
         begin = std::chrono::steady_clock::now();
         if (!o.stem.empty() && writeOutput) {  // statpath.cpp:419-427: outBufSel.PrepareOutput(); outBufSel.Write(total spp)
@@ -283,6 +310,8 @@ static void Render(const Options &o) {
         // the reference re-creates its tiles, i.e. all statistics, for the real run
         for (unsigned char t = 0; t < estimator.statTypeConfigs.nEnabled; t++) estimator.ResetStatistics(t);
         done = 0;
+        std::fill(tileDone.begin(), tileDone.end(), 0u);
+        tileNoise.clear();
     }
     RenderLoop(o.iterations, true);
 }
@@ -313,6 +342,7 @@ int main(int argc, char **argv) {
         else if (a == "--no-denoise") o.denoise = false;
         else if (a == "--warmup") o.warmUp = true;
         else if (a == "--tilestats") o.tileStats = true;
+        else if (a == "--adaptive") o.adaptive = true;
         else if (a == "--config") {
             const std::string c = next();
             if (c != "denoise" && c != "acrr" && c != "smis") {
