@@ -39,6 +39,10 @@ int statmc_debug_accumulate_tiles_variant(int umul, int order, int wg_per_cu);
 /* Non-zero: the library was built with a timing-only / diagnostic switch (statmc_sym_experiments.h); its results are
  * not the product's and statmc_amd.api refuses to load it. */
 int statmc_debug_diagnostic_build(void);
+/* Welch degrees of freedom on the pair-symmetric kernel: the number of work items of the calling thread's last launch
+ * that left their band of the quantile table and were computed again from the table in global memory (0 for a film of
+ * uniform sample count; -1: the last pair-symmetric launch was not a Welch one).  Waits for the device. */
+int statmc_debug_welch_far_items(void);
 /* Largest filter workspace of the current device (diagnostic builds read their counters back from it). */
 int statmc_debug_last_workspace(void **ptr, size_t *bytes);
 

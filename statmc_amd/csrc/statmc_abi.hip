@@ -23,6 +23,8 @@ namespace {
 thread_local char g_err[512] = "";
 thread_local const char *g_variant = "none";
 thread_local int g_last_parts = 0, g_last_parts_hi = 0, g_last_tail_rows = 0;
+thread_local const int *g_last_redo = nullptr;   // the item flags of the calling thread's last Welch launch (device memory)
+thread_local int g_last_redo_n = 0;
 std::mutex g_mu;
 
 // Everything the library remembers is kept per device (one Estimator per device in a process that drives
@@ -165,8 +167,7 @@ void apply_spec(const DeviceState &d, statmc::FilterArgs &k, const statmc_filter
     if (d.spec.dof == STATMC_DOF_WELCH) {
         const int table = d.alpha_index + STATMC_TQ_N_ALPHAS * (d.spec.sides ? 1 : 0);
         k.tq = statmc::t_table_device_ptr(table);
-        const float *sq = statmc::t_table_sq_device_ptr(table);
-        k.tq2 = sq ? sq - 1 : nullptr;   // indexed by dof = 1 .. 4096
+        k.tq2 = statmc::t_table_sq_device_ptr(table);   // indexed by dof = 0 .. 4096 (entry 0 = entry 1)
     }
     (void)a;
 }
@@ -212,11 +213,15 @@ int prepare_sym(const DeviceState &d, statmc::FilterArgs &k, const statmc_filter
     const size_t patch_floats = (statmc::sym_patch_floats(whole, k.n_parts) + 3) & ~(size_t)3;
     const size_t image_floats = pair ? (size_t)9 * k.width * k.height : 0;
     const size_t extra_floats = k.border == STATMC_BORDER_CLAMP ? (size_t)4 * k.width * k.height : 0;
-    if (int rc = partial_workspace((patch_floats + image_floats + extra_floats) * sizeof(float), a->stream, &ws)) return rc;
+    const size_t redo_floats = k.dof == STATMC_DOF_WELCH ? ((size_t)statmc::sym_items(whole) + 3) & ~(size_t)3 : 0;
+    if (int rc = partial_workspace((patch_floats + image_floats + extra_floats + redo_floats) * sizeof(float), a->stream, &ws)) return rc;
     k.sym.patch = reinterpret_cast<float4 *>(ws);
     k.sym.pair = pair ? 1 : 0;
     k.sym.pair_images = pair ? ws + patch_floats : nullptr;
     k.sym.border_extra = extra_floats ? reinterpret_cast<float4 *>(ws + patch_floats + image_floats) : nullptr;
+    k.sym.redo = redo_floats ? reinterpret_cast<int *>(ws + patch_floats + image_floats + extra_floats) : nullptr;
+    g_last_redo = k.sym.redo;
+    g_last_redo_n = k.sym.redo ? (int)statmc::sym_items(k) : 0;
     g_last_parts_hi = whole.sym.parts_hi;
     g_last_tail_rows = whole.sym.parts_hi ? whole.sym.ty0 + whole.sym.nty - whole.sym.split_ty : 0;
     return STATMC_OK;
@@ -1374,6 +1379,18 @@ int statmc_debug_last_filter_tail(int *parts_hi, int *tail_rows) {
     if (parts_hi) *parts_hi = g_last_parts_hi;
     if (tail_rows) *tail_rows = g_last_tail_rows;
     return STATMC_OK;
+}
+// Welch degrees of freedom on the pair-symmetric kernel: how many work items of the calling thread's last launch asked
+// for a quantile outside their band of the table and were computed again by the build that reads it in global memory
+// (-1: the last launch was not a Welch one).  Waits for the device.
+int statmc_debug_welch_far_items(void) {
+    if (g_last_redo == nullptr || g_last_redo_n <= 0) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    std::vector<int> f((size_t)g_last_redo_n);
+    if (hipMemcpy(f.data(), g_last_redo, f.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    int n = 0;
+    for (int v : f) n += v != 0;
+    return n;
 }
 // the partial-sum / patch workspace of the calling thread's current device and stream 0 (diagnostic builds read it back)
 int statmc_debug_last_workspace(void **ptr, size_t *bytes) {

@@ -100,7 +100,7 @@ struct FilterArgs {
     int force_variant, force_parts;
     const int32_t *n;            // Welch mode: sample counts
     const float *tq;             // Welch mode: this device's quantile table (4096 entries)
-    const float *tq2;            // ... and its squares, BIASED BY ONE ENTRY: tq2[dof] = fl(t_dof * t_dof), dof = 1 .. 4096 (pair-symmetric kernel)
+    const float *tq2;            // ... and its squares: tq2[dof] = fl(t_dof * t_dof), dof = 0 .. 4096, entry 0 = entry 1 (pair-symmetric kernel)
     int width, height;           // local image
     int rx0, ry0, rx1, ry1;      // output ROI
     int rx_split, n_main_items;  // LDS kernel: regular tiles cover [rx0, rx_split), DUAL tiles [rx_split, rx1)
@@ -138,6 +138,7 @@ struct FilterArgs {
         int pair;                 // filter<float>: f_active (1 or 2) 1-channel buffers (f_mean_corr / f_disc / f_colour / f_out) per launch
         float *pair_images;       // ... staged from three [height][width][3] images this launch packs them into
         float4 *border_extra;     // border rule "clamp": per pixel, the sums over the taps beyond the image (border_virtual_kernel)
+        int *redo;                // Welch: one flag per work item, set by the band build for the items the far build computes again
         // eight feature planes (NG = 8 build): up to two RGB and up to two 1-channel G-buffers of the argument list, sorted
         // into slots by sym_feature_slots(); scale = sqrt(-dr * log2 e), 0 = empty slot (never read)
         // Tail split (round 4): the tiles of the film's tile rows >= split_ty sweep with parts_hi workgroups each instead of

@@ -90,8 +90,13 @@ constexpr bool mode_asym(int m) { return m == kModeAsym || m == kModeAsymJoint |
 // at floor(nu), nu = (v_p + v_q)^2 / (E_p + E_q) -- symmetric in (p, q) like everything else the pair needs, so the pair
 // is still evaluated once.  These two modes exist in ONE build (register staging, six feature planes, runtime radius):
 // 18 input + 8 accumulator planes leave no room for the LDS-DMA landing area.
-constexpr int kModeWelch = 7, kModeWelchJoint = 8;
-constexpr bool mode_welch(int m) { return m == kModeWelch || m == kModeWelchJoint; }
+// Each in two builds: the first reads the quantiles from a band of the table in LDS and flags the items in which a pair
+// asked for an entry outside it; the second ("far") reads the table in global memory and runs behind the first over the
+// flagged items only (none in a film of uniform sample count).
+constexpr int kModeWelch = 7, kModeWelchJoint = 8, kModeWelchFar = 9, kModeWelchJointFar = 10;
+constexpr bool mode_welch(int m) { return m >= kModeWelch && m <= kModeWelchJointFar; }
+constexpr bool mode_welch_joint(int m) { return m == kModeWelchJoint || m == kModeWelchJointFar; }
+constexpr bool mode_welch_far(int m) { return m == kModeWelchFar || m == kModeWelchJointFar; }
 constexpr int kR = 20;
 constexpr int kPx = 4;                    // pixels per lane
 constexpr int kW = 32 * kPx;              // 128 tile columns: half a wave per row
@@ -118,13 +123,26 @@ __host__ __device__ inline int wave_cols(int wave) { return wave < 2 ? 44 : wave
 // two 1-channel G-buffers (depth, material id: statpath.cpp:828-835, 1096-1130) -- 17 input + 8 accumulator planes per
 // row: 9 x 25 x 168 floats = 151 200 B of ring, and the LDS-DMA landing area shrinks to exactly the 168 columns a row
 // has (wave w's columns at wave_col0(w) x 17 floats) so that the lot still fits the CU's 160 KiB: 163 392 B.
+// Welch: the part of the squared-quantile table the pairs of one item can ask for lives in LDS (what is left of the 160 KiB
+// beside the ring): entries lo .. lo + kWelchBand - 1, lo = (least n of the item's pixels) - 2.  nu lies between
+// min(n_p, n_q) - 1 and n_p + n_q - 2, so a film of uniform n <= 720 never leaves the band; a pair that does takes the
+// table in global memory (a wave-uniform branch).
+constexpr int kWelchBand = 1440;
+struct WelchTab {
+    const float *table;     // global: entries 0 .. 4096 (entry 0 = entry 1)
+    const float *band;      // LDS, at address 0: band[j] = table[min(lo + j, 4096)]
+    unsigned neg4lo;        // -4 lo: (dof << 2) + neg4lo is the byte offset of a quantile in the band
+    unsigned oob;           // a dof >= oob lies beyond the band (~0u when the band reaches the table's end)
+};
+
 template <int NG, bool W = false>
 struct Planes {
     static constexpr int kIn = NG + 9 + (W ? 3 : 0);         // input planes per row: features, mean, -D, colour[, E (Welch)]
     static constexpr int cMC = NG, cND = NG + 3, cCOL = NG + 6, cE = NG + 9;
     static constexpr int kSlotFloats = (kIn + kQ) * kP;
     static constexpr int kRawTotal = W ? 0 : NG == 6 ? 4 * kWaveCols * 15 : kP * kIn;
-    static constexpr size_t kLdsBytes = (size_t)(kSlots * kSlotFloats + 2 * kTabPad + kRawTotal) * sizeof(float);
+    static constexpr int kBandTotal = W ? kWelchBand + 16 : 0;   // Welch: a band of the squared-quantile table + the item's {min n, max n}
+    static constexpr size_t kLdsBytes = (size_t)(kSlots * kSlotFloats + 2 * kTabPad + kRawTotal + kBandTotal) * sizeof(float);
     __host__ __device__ static inline int raw_off(int wave) { return W ? 0 : NG == 6 ? (wave & 3) * kWaveCols * 15 : wave_col0(wave & 3) * kIn; }
 };
 static_assert(Planes<6>::kLdsBytes <= 160 * 1024 && Planes<8>::kLdsBytes <= 160 * 1024 && Planes<6, true>::kLdsBytes <= 160 * 1024, "LDS budget");
@@ -136,7 +154,7 @@ __host__ __device__ inline int q_rows_max(int n_parts, int steps) { return (step
 // The lane's own 4 pixels.  Their values enter the packed instructions as broadcasts of ONE half of a register
 // pair (op_sel), so two different scalars share every pair: 6 + 6 + 4 pairs per pixel instead of 15 + 15
 // registers holding (x, x) duplicates -- which is what a `v2f{x, x}` splat of a scalar compiles to.
-struct LaneWelch { v2f pe[kPx][2]; };   // Welch: (E_r, E_g), (E_b, -) of the lane's pixels
+struct LaneWelch { v2f pe[kPx][2]; unsigned far; };   // Welch: (E_r, E_g), (E_b, -) of the lane's pixels; the greatest dof asked for
 struct LaneNoWelch {};
 template <int NG, bool W = false>
 struct Lane : std::conditional<W, LaneWelch, LaneNoWelch>::type {
@@ -177,10 +195,28 @@ __device__ __forceinline__ v2f fma_bc(const v2f &w, const v2f &pair, int half, c
     return d;
 }
 
-__device__ __forceinline__ int cvt_i32(float x) {   // truncation; NaN -> 0, out of range saturates (the hardware's rule)
-    int i;
-    asm("v_cvt_i32_f32 %0, %1" : "=v"(i) : "v"(x));
+__device__ __forceinline__ unsigned cvt_u32(float x) {   // truncation; NaN and negative -> 0, above 2^32 - 1 saturates (the hardware's rule)
+    unsigned i;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(i) : "v"(x));
     return i;
+}
+__device__ __forceinline__ unsigned lshl2_add_u32(unsigned a, unsigned b) {   // (a << 2) + b, b wave-uniform
+    unsigned d;
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(d) : "v"(a), "s"(b));
+    return d;
+}
+__device__ __forceinline__ float lds_at0(unsigned byte_offset) {   // the float at an LDS address (the Welch band starts at 0)
+    return *reinterpret_cast<const __attribute__((address_space(3))) float *>((unsigned long)byte_offset);
+}
+__device__ __forceinline__ unsigned max3_u32(unsigned a, unsigned b, unsigned c) {
+    unsigned d;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float min_finite(float x) {   // min(x, FLT_MAX); a NaN becomes FLT_MAX (v_min_f32 returns the other operand)
+    float r;
+    asm("v_min_f32 %0, 0x7f7fffff, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 __device__ __forceinline__ v2f fma_sq_nbc(const v2f &d, const v2f &pair) {  // d * d - bc(pair.y)
     v2f r;
@@ -242,55 +278,78 @@ __device__ __forceinline__ void range_exponent(const LaneT &st, const v4f *g, co
 // buffers share the range weight and gate separately (filter<float>: every buffer is its own 1-channel test).
 // Welch (en: the three E planes; tq2: the device's table of SQUARED quantiles, indexed by dof): per channel
 //     nu = s^2 / (E_p + E_q),  s = v_p + v_q;   dof = nu >= 1 ? min((int)nu, 4096) : 1;   u = fma(d, d, -(t_dof^2 * s))
-// The quotient is a reciprocal with one residual correction (correctly rounded except in rare last-bit cases, which
-// can move a pair whose nu lies within an ulp of an integer to the neighbouring table entry); when the correction is
-// NaN -- E_p + E_q underflowed to 0 or both variances are infinite -- the plain product stands, which has the oracle's
-// value there (inf, NaN).  A NaN becomes dof 1 in the integer clamp, exactly the oracle's `nu >= 1.f` branch.
+// The quotient is a reciprocal with one residual correction: correctly rounded except in rare last-bit cases, which can
+// move a pair whose nu lies within an ulp of an integer to the neighbouring table entry.  The correction is not optional:
+// nu is an exact integer whenever one side's variance is 0 (nu = n_p - 1 then: black next to lit pixels), and the bare
+// s^2 * rcp(.) lands below it half of the time (tried; tests/test_gpu_parity.py caught it at 3 spp).  The first product
+// goes through min(., FLT_MAX), which also turns a NaN into FLT_MAX: with that the correction reproduces the oracle's
+// quotient in the special cases too -- E_p + E_q = 0 gives inf (s^2 > 0) or NaN (0 / 0), an infinite E_p + E_q gives
+// NaN where the oracle has 0 -- both dof 1 --, infinite s^2 gives inf or NaN as there; no select on the result.
+// A NaN becomes dof 1 in the conversion, exactly the oracle's `nu >= 1.f` branch.
 template <int H, unsigned MASK, int MODE, int NG, class LaneT>
-__device__ __forceinline__ void gate_weight(const LaneT &st, const v4f *mcn, const v4f *en, const float *__restrict__ tq2,
+__device__ __forceinline__ void gate_weight(LaneT &st, const v4f *mcn, const v4f *en, const WelchTab &tq2,
                                             const v2f (&e)[kPx], v2f (&w)[kPx], v2f (&wb)[kPx]) {
     using M = Taps<H, MASK>;
     constexpr bool PAIR = MODE == kModePair;
     constexpr int NC = PAIR ? 2 : 3;
     if constexpr (mode_welch(MODE)) {
-        // Software pipeline over the lane's pixels: the table look-ups of pixel k are in flight (six loads from the L1-resident
-        // band of the table) while pixel k - 1 is tested -- issued one pixel at a time they cost a full memory latency per
-        // channel (the file is compiled without the machine scheduler: source order is issue order).
+        // Software pipeline over the lane's pixels: the table look-ups of pixel k are in flight (six ds_read_b32 from the band
+        // in LDS; the far build: six loads from the table in global memory, 1 ms more at 256 spp, where a wave's 64 lanes
+        // spread over eight cache lines) while pixel k - 1 is tested -- issued one pixel at a time they cost a full latency
+        // per channel (the file is compiled without the machine scheduler: source order is issue order).
         v2f t2[2][3];
         auto lookup = [&](int k, v2f (&out)[3]) {
+            unsigned dx[3], dy[3];
+            // (all six reciprocals ahead of the corrections -- no s_nop behind them -- needs twelve more registers and times
+            // the same: 3.385 against 3.361 ms)
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 const v2f sn = rsub_bc(pair_of<H>(mcn[3 + ch]), st.ms[k][ch], 1);      // -(v_p + v_q)
                 const v2f den = add_bc(st.pe[k][ch >> 1], ch & 1, pair_of<H>(en[ch]));   // E_p + E_q
                 const v2f s2 = sn * sn;
-                float nx, ny;
+                v2f nu;
                 if constexpr ((STATMC_SYM_WELCH_ABLATE & 4) != 0) {   // timing only
-                    nx = s2.x + den.x; ny = s2.y + den.y;
+                    nu = s2 + den;
                 } else {
                     const v2f r = v2f{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                    const v2f q0 = s2 * r;
+                    const v2f p = s2 * r;
+                    const v2f q0 = v2f{min_finite(p.x), min_finite(p.y)};
                     const v2f er = __builtin_elementwise_fma(-q0, den, s2);
-                    const v2f q1 = __builtin_elementwise_fma(er, r, q0);
-                    if constexpr ((STATMC_SYM_WELCH_ABLATE & 2) != 0) { nx = q1.x; ny = q1.y; }   // timing only
-                    else { nx = q1.x == q1.x ? q1.x : q0.x; ny = q1.y == q1.y ? q1.y : q0.y; }
+                    nu = __builtin_elementwise_fma(er, r, q0);
                 }
-                // v_cvt_i32_f32 of a NaN is 0, of +inf INT_MAX (spelled out: the C++ conversion of such a value is undefined);
-                // the integer clamp (v_med3_i32) turns them into dof 1 and 4096
-                const int ix = min(max(cvt_i32(nx), 1), 4096), iy = min(max(cvt_i32(ny), 1), 4096);
-                if constexpr ((STATMC_SYM_WELCH_ABLATE & 1) != 0) out[ch] = v2f{(float)ix * 1e-3f + 9.f, (float)iy * 1e-3f + 9.f};   // timing only: no gather
-                else out[ch] = v2f{tq2[ix], tq2[iy]};
+                // v_cvt_u32_f32 truncates, sends a NaN and everything below 1 to 0 and saturates above (spelled out: the C++
+                // conversion of such values is undefined); entry 0 of the table is entry 1, which finishes the oracle's
+                // `nu >= 1 ? min((int)nu, 4096) : 1` but for the upper clamp -- that is in the band's fill
+                dx[ch] = cvt_u32(nu.x);
+                dy[ch] = cvt_u32(nu.y);
+                if constexpr (mode_welch_far(MODE)) {
+                    out[ch] = v2f{tq2.table[min(dx[ch], 4096u)], tq2.table[min(dy[ch], 4096u)]};
+                } else if constexpr ((STATMC_SYM_WELCH_ABLATE & 1) != 0) {   // timing only: no gather
+                    out[ch] = v2f{(float)dx[ch] * 1e-3f + 9.f, (float)dy[ch] * 1e-3f + 9.f};
+                } else {
+                    // byte offset in the band: one shift-and-add, one minimum.  A dof beyond the band's end reads its last
+                    // entry (and flags the item, below); a dof below its start wraps around to the same place -- that is dof
+                    // 0 next to sample counts > 2, i.e. a NaN nu from 0 / 0, where s = 0 makes the quantile immaterial
+                    // (or, with E_p + E_q denormal, a quotient without a correct digit).
+                    const unsigned bx = min(lshl2_add_u32(dx[ch], tq2.neg4lo), 4u * (unsigned)kWelchBand - 4u);
+                    const unsigned by = min(lshl2_add_u32(dy[ch], tq2.neg4lo), 4u * (unsigned)kWelchBand - 4u);
+                    out[ch] = v2f{lds_at0(bx), lds_at0(by)};
+                }
             }
+            // the greatest dof of the item: beyond the band's end (films whose sample counts differ by more than the band
+            // holds) the item is flagged and computed again by the build that reads the table in global memory
+            if constexpr (!mode_welch_far(MODE)) st.far = max3_u32(st.far, max3_u32(dx[0], dy[0], dx[1]), max3_u32(dy[1], dx[2], dy[2]));
         };
         auto test = [&](int k, const v2f (&tt)[3]) {
             v2f u[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 const v2f d = sub_bc(st.ms[k][ch], 0, pair_of<H>(mcn[ch]));
-                const v2f sn = rsub_bc(pair_of<H>(mcn[3 + ch]), st.ms[k][ch], 1);      // (again: cheaper than keeping it)
+                const v2f sn = rsub_bc(pair_of<H>(mcn[3 + ch]), st.ms[k][ch], 1);      // (the compiler keeps the look-up's)
                 u[ch] = __builtin_elementwise_fma(d, d, tt[ch] * sn);
             }
             w[k] = v2f{__builtin_amdgcn_exp2f(e[k].x), __builtin_amdgcn_exp2f(e[k].y)};
-            if constexpr (MODE == kModeWelchJoint) {
+            if constexpr (mode_welch_joint(MODE)) {
                 const v2f m = (u[0] + u[1]) + u[2];
                 w[k] = v2f{M::in0(k) && m.x <= 0.f ? w[k].x : 0.f, M::in1(k) && m.y <= 0.f ? w[k].y : 0.f};
             } else {
@@ -472,7 +531,7 @@ __device__ __forceinline__ void lds_wait(v4f &a, v4f &b, v4f &c, v4f &d) {
 // in registers; otherwise the compiler's own loads (each phase waits for its operands).
 template <unsigned MASK, bool SYM, bool PIPE, int MODE, int NG, class LaneT>
 __device__ __forceinline__ void chunk(LaneT &st, const float *__restrict__ row, const float *__restrict__ tab, float *__restrict__ qrow, int j,
-                                      const float *__restrict__ tq2) {
+                                      const WelchTab &tq2) {
     using M0 = Taps<0, MASK>;
     using M1 = Taps<1, MASK>;
     constexpr bool PAIR = MODE == kModePair;
@@ -619,7 +678,7 @@ struct Range {
 };
 
 template <int LO, int HI, bool SYM, int MODE, int NG, class LaneT>
-__device__ __forceinline__ void sweep_range(LaneT &st, const float *row, const float *tab, float *qrow, const float *tq2) {
+__device__ __forceinline__ void sweep_range(LaneT &st, const float *row, const float *tab, float *qrow, const WelchTab &tq2) {
     using R = Range<LO, HI>;
     constexpr int j0 = R::first(), j1 = R::last(), f0 = R::first_full(), f1 = R::last_full();
     static_assert(j0 <= j1, "empty range");
@@ -649,7 +708,7 @@ __device__ __forceinline__ void sweep_range(LaneT &st, const float *row, const f
 // where j_lo / j_hi are the outermost groups that hold a tap with |dx| <= r; taps of those groups beyond r carry a
 // spatial exponent of -inf in the table (weight 0).
 template <int HF, int MODE, int NG, bool RT, class LaneT>
-__device__ __forceinline__ void eval_half_row(LaneT &st, const float *row, const float *tab, float *qrow, bool dy0, int j_lo, int j_hi, const float *tq2) {
+__device__ __forceinline__ void eval_half_row(LaneT &st, const float *row, const float *tab, float *qrow, bool dy0, int j_lo, int j_hi, const WelchTab &tq2) {
     constexpr bool kPipe = sym::kPipe && !mode_welch(MODE);
     if constexpr (RT) {
         static_assert(kSplit == 0, "the runtime-radius build splits the window in the middle");
@@ -847,13 +906,16 @@ __device__ __forceinline__ Staged raw_pixel(const FilterArgs &a, const Feat &F, 
 // and normalise separately.
 template <bool DMA, int MODE, int NG, bool RT>
 __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // Welch (band build): the quantile band sits at LDS address 0 -- a look-up's byte offset is its address -- and the
+    // ring behind it
+    float *const lds = smem + Planes<NG, mode_welch(MODE)>::kBandTotal;
     constexpr bool PAIR = MODE == kModePair;
     constexpr bool W = mode_welch(MODE);
     static_assert(!W || (!DMA && NG == 6 && RT), "the Welch modes exist in one build: register staging, six feature planes, runtime radius");
     constexpr int kSlotFloats = Planes<NG, W>::kSlotFloats, kIn = Planes<NG, W>::kIn;
     const Feat F = features_of<NG>(a);
-    const float *tq2 = W ? a.tq2 : nullptr;
+    WelchTab tq2{nullptr, nullptr, 0u, ~0u};
     // XCD-aware work mapping (as in the one-sided kernel): each XCD walks a contiguous range of items
     // With a tail split the items of the n_parts-tiles (the long ones) go first in every XCD's range and the short
     // items of the parts_hi-tiles fill the end of the launch.
@@ -887,6 +949,9 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
         n_parts = a.sym.parts_hi;
         part = (u - a.sym.n_lo_items) % n_parts;
         tile = a.sym.n_lo_tiles + (u - a.sym.n_lo_items) / n_parts;
+    }
+    if constexpr (mode_welch_far(MODE)) {
+        if (a.sym.redo[u] == 0) return;   // (block-uniform) the band build served every pair of this item
     }
     const int x0 = kW * (a.sym.tx0 + tile % a.sym.ntx) - a.sym.fx0;     // local coordinates of the tile
     const int y0 = kRows * (a.sym.ty0 + tile / a.sym.ntx) - a.sym.fy0;
@@ -965,12 +1030,44 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
         for (int ch = 0; ch < 3; ch++) st.acc[k][ch] = v2f{0.f, 0.f};
         st.sw[k] = v2f{0.f, 0.f};
     }
+    if constexpr (W) st.far = 0u;
 
     // wave-local staging geometry (DMA): this wave's columns of every staged row
     float *raw_w = tab_lds + 2 * kTabPad + Planes<NG, W>::raw_off(wave);
     const int wcol0 = wave_col0(wave);                                 // first staged column (0..167) of the wave
     const int ncols = wave_cols(wave);                                 // 44, 44, 40, 40, then none
     if (s_a < s_b) {
+        if constexpr (W && mode_welch_far(MODE)) tq2 = WelchTab{a.tq2, nullptr, 0u, ~0u};
+        if constexpr (W && !mode_welch_far(MODE)) {
+            // ---- the band of the squared-quantile table this item's pairs can ask for: least sample count over the rows the
+            // item touches (its own rows and the staged ones, rel 0 .. s_b+6) x the staged columns, then kWelchBand entries
+            // from (least n) - 2 into LDS.  (The two below the mathematical minimum min(n_p, n_q) - 1 take the computed
+            // quotient's last-bit errors; a computed nu below even that -- possible only where E_p + E_q is denormal --
+            // reads the band's first entry.)
+            float *band = smem;
+            int *nrange = reinterpret_cast<int *>(band + kWelchBand);   // {least n, item flag}
+            if (threadIdx.x == 0) { nrange[0] = 0x7fffffff; nrange[1] = 0; }
+            __syncthreads();
+            {
+                const int ya = max(y0, 0), yb = min(y0 + s_b + kRows - 2, a.height - 1);
+                const int xa = max(x0 - kR, 0), xb = min(x0 + kW + kR - 1, a.width - 1);
+                const int wc = xb - xa + 1, cnt = wc * (yb - ya + 1);
+                int mn = 0x7fffffff;
+                for (int idx2 = threadIdx.x; idx2 < cnt; idx2 += kThreads) {
+                    const int yy = idx2 / wc, xx = idx2 - yy * wc;
+                    mn = min(mn, a.n[(long long)(ya + yy) * a.width + xa + xx]);
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
+                if (lane == 0) atomicMin(&nrange[0], mn);
+            }
+            __syncthreads();
+            const int n_lo = __builtin_amdgcn_readfirstlane(nrange[0]);
+            const unsigned lo = (unsigned)min(max(n_lo - 2, 0), 4096);
+            for (int j = threadIdx.x; j < kWelchBand; j += kThreads) band[j] = a.tq2[min(lo + (unsigned)j, 4096u)];
+            tq2 = WelchTab{a.tq2, band, 0u - 4u * lo, lo + (unsigned)kWelchBand - 1u >= 4096u ? ~0u : lo + (unsigned)kWelchBand - 1u};
+            // (the barrier after the prologue's staging comes before the first look-up)
+        }
         if constexpr (DMA) {   // the first row the sweep will need beyond the prologue: on its way during the prologue
             if (s_a + 1 < s_b && !(kAblate & 2)) dma_row<NG>(a, F, raw_w, lane, x0 - kR + wcol0, y0 + s_a + kRows, ncols);
         }
@@ -1079,7 +1176,13 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             if (rel >= q_first && y0 + rel >= 0 && y0 + rel < a.height)
                 flush_q<NG, W>(lds + (rel % kSlots) * kSlotFloats, i, patch_q + (long long)(rel - q_first) * kP);
         }
+        if constexpr (W && !mode_welch_far(MODE)) {
+            if (st.far >= tq2.oob) reinterpret_cast<int *>(smem + kWelchBand)[1] = 1;
+        }
         __syncthreads();
+    }
+    if constexpr (W && !mode_welch_far(MODE)) {   // (an item without a sweep: nothing to do again)
+        if (threadIdx.x == 0) a.sym.redo[u] = s_a < s_b ? reinterpret_cast<const int *>(smem + kWelchBand)[1] : 0;
     }
 
     // ---- p side: half 1 hands its sums to half 0 through LDS, half 0 writes the patch
@@ -1405,9 +1508,13 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
 #undef STATMC_SYM_ROW
 #undef STATMC_SYM_K
     const void *kernel = kernels[rt ? 1 : 0][g8 ? 1 : 0][dma ? 1 : 0][mode];
+    const void *kernel_far = nullptr;
     if (welch) {   // (the gate field has no meaning under Welch: there is one test, symmetric in the pair)
+        if (a.sym.redo == nullptr) return hipErrorInvalidValue;
         kernel = joint ? reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelchJoint, 6, true>)
                        : reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelch, 6, true>);
+        kernel_far = joint ? reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelchJointFar, 6, true>)
+                           : reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelchFar, 6, true>);
     }
     static std::mutex mu;
     static std::set<std::pair<int, const void *>> done;
@@ -1415,15 +1522,19 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (!done.count({dev, kernel})) {
-            if (hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e != hipSuccess) return e;
-            done.insert({dev, kernel});
+        for (const void *kf : {kernel, kernel_far}) {
+            if (kf == nullptr || done.count({dev, kf})) continue;
+            if (hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e != hipSuccess) return e;
+            done.insert({dev, kf});
         }
     }
     const dim3 grid((unsigned)sym_items(a));
     void *kargs[] = {&a};
     const size_t lds_bytes = welch ? Planes<6, true>::kLdsBytes : g8 ? Planes<8>::kLdsBytes : Planes<6>::kLdsBytes;
     if (hipError_t e = hipLaunchKernel(kernel, grid, dim3(kThreads), kargs, lds_bytes, s); e != hipSuccess) return e;
+    if (kernel_far != nullptr) {   // Welch: the items the band build flagged, again with the table in global memory
+        if (hipError_t e = hipLaunchKernel(kernel_far, grid, dim3(kThreads), kargs, lds_bytes, s); e != hipSuccess) return e;
+    }
     if (a.sym.border_extra) {
         if (hipError_t e = launch_border_virtual(a, s); e != hipSuccess) return e;
     }

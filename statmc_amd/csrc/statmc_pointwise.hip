@@ -74,18 +74,21 @@ template <int N> __device__ __forceinline__ void acc_wait_vmcnt() { asm volatile
 // Student-t tables, uploaded once by statmc_setup() (hipMemcpyToSymbol).
 __device__ float g_tq[STATMC_TQ_N_TABLES][STATMC_TQ_N_DOF];
 // fl(t * t) of every entry: what the Welch pair test of the pair-symmetric kernel multiplies with (the oracle forms
-// (t * t) * s; the product t * t rounds the same here as there)
-__device__ float g_tq2[STATMC_TQ_N_TABLES][STATMC_TQ_N_DOF];
+// (t * t) * s; the product t * t rounds the same here as there).  Indexed by the degrees of freedom themselves, 0 .. 4096:
+// entry 0 repeats entry 1, which is where nu < 1 and a NaN nu land (the oracle's `nu >= 1 ? ... : 1`) after the
+// hardware's unsigned conversion.
+__device__ float g_tq2[STATMC_TQ_N_TABLES][STATMC_TQ_N_DOF + 1];
 
 hipError_t upload_t_table(int table, const float *host_4096) {
     if (hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_tq), host_4096, sizeof(float) * STATMC_TQ_N_DOF, sizeof(float) * STATMC_TQ_N_DOF * table); e != hipSuccess)
         return e;
-    static thread_local float sq[STATMC_TQ_N_DOF];
+    static thread_local float sq[STATMC_TQ_N_DOF + 1];
     for (int i = 0; i < STATMC_TQ_N_DOF; i++) {
         volatile float t = host_4096[i];     // one rounded product, never contracted or widened
-        sq[i] = t * t;
+        sq[i + 1] = t * t;
     }
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_tq2), sq, sizeof(float) * STATMC_TQ_N_DOF, sizeof(float) * STATMC_TQ_N_DOF * table);
+    sq[0] = sq[1];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tq2), sq, sizeof(sq), sizeof(sq) * table);
 }
 
 hipError_t upload_t_tables() {
@@ -96,7 +99,7 @@ hipError_t upload_t_tables() {
 const float *t_table_sq_device_ptr(int table) {
     float *base = nullptr;
     if (hipGetSymbolAddress(reinterpret_cast<void **>(&base), HIP_SYMBOL(g_tq2)) != hipSuccess) return nullptr;
-    return base + (size_t)table * STATMC_TQ_N_DOF;
+    return base + (size_t)table * (STATMC_TQ_N_DOF + 1);
 }
 const float *t_table_device_ptr(int table) {
     float *base = nullptr;

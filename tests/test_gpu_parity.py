@@ -1318,6 +1318,30 @@ def test_filter_spec_r20_and_float(gpu, oracle, spec_kw, channels):
         assert rel_l2(out[..., c], oout[..., c]) <= TOL, c
 
 
+@pytest.mark.parametrize("joint", [0, 1], ids=["per-channel", "joint"])
+def test_filter_welch_quantile_band(gpu, oracle, joint):
+    """Welch degrees of freedom on the pair-symmetric kernel read their quantiles from a band of the table in LDS, chosen per
+    work item from the least sample count it touches; an item whose pairs ask for more than the band holds is flagged and
+    computed again from the table in global memory.  Uniform counts (whatever their size) never leave the band; a film
+    whose counts jump from 3 to thousands inside a tile does -- both against the oracle, with the number of items that
+    took the second path read back (statmc_debug_welch_far_items)."""
+    lib = gpu.load()
+    lib.statmc_debug_welch_far_items.restype = C.c_int
+    spec_kw = dict(dof=1, channel_rule=joint)
+    for n_of, far_expected in ((lambda n: n, False),                                      # 4 everywhere
+                               (lambda n: np.full_like(n, 900), False),                   # nu in 899 .. 1798: band from 898
+                               (lambda n: np.full_like(n, 5000), False),                  # beyond the table: its last entry
+                               (lambda n: np.where(np.arange(n.shape[1])[None, :] < 150, n, 2600).astype(n.dtype), True)):
+        _, smp, st = make_case(280, 26, 4, seed=29)
+        st["radiance"]["n"][...] = n_of(st["radiance"]["n"])
+        mc, dc, out, variant, (omc, odc, oout) = run_spec(gpu, oracle, st, spec_kw, radius=RADIUS, sd=FILTER_SD)
+        far = lib.statmc_debug_welch_far_items()
+        assert variant == "sym_welch" + ("_joint" if joint else ""), variant
+        assert (far > 0) == far_expected, far
+        for c in range(3):
+            assert rel_l2(out[..., c], oout[..., c]) <= TOL, (c, far)
+
+
 def test_filter_spec_errors_and_per_device_state(gpu):
     lib = gpu.load()
     bad = gpu.FilterSpec(gate=3)

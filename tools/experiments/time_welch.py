@@ -9,12 +9,13 @@ from statmc_amd import api, film, synthetic
 
 dev = torch.device("cuda:0")
 api.setup(0)
-for W in (1920, 1922):
+for W, spp in ((1920, 32), (1922, 32), (1922, 256), (1922, 8)):
     H = 1080
     scene = synthetic.Scene(W, H, seed=1, device=dev)
     for r, sd in ((20, 10.0), (6, 3.0)):
         fs = film.FilmStats(W, H, dev, filter_sd=sd, radius=r)
-        fs.accumulate(scene.samples(32, seed=2, features=("radiance", "normal", "albedo")))
+        for b in range(max(spp // 32, 1)):
+            fs.accumulate(scene.samples(min(spp, 32), seed=2 + b, features=("radiance", "normal", "albedo")))
         for kw in (dict(), dict(dof=1), dict(dof=1, channel_rule=1)):
             api.set_filter_spec(**kw)
             fs.prepass()
@@ -27,6 +28,6 @@ for W in (1920, 1922):
                 api.window_filter(a, 3)
             e1.record()
             torch.cuda.synchronize()
-            print("%dx%d r = %2d %-32s %-18s %.3f ms" % (W, H, r, kw or "default", api.last_filter_variant(), e0.elapsed_time(e1) / 10), flush=True)
+            print("%dx%d %3d spp r = %2d %-32s %-18s %.3f ms" % (W, H, spp, r, kw or "default", api.last_filter_variant(), e0.elapsed_time(e1) / 10), flush=True)
         api.set_filter_spec()
         del fs
