@@ -202,7 +202,10 @@ typedef struct statmc_filter_args {
      * fp32 image holding, per pixel, mean_corr.rgb, discriminator.rgb, colour.rgb, g_buffers[0].rgb,
      * g_buffers[1].rgb -- the layout the halo exchange moves as one message -- or a [height][width][17]
      * image that adds two 1-channel G-buffers behind them (depth, material id: src/statistics/statpath.cpp:828-835,
-     * 1096-1130; slots = the call's RGB G-buffers in argument order, then its 1-channel ones; an absent one is 0).
+     * 1096-1130; slots = the call's RGB G-buffers in argument order, then its 1-channel ones; an absent one is 0),
+     * or a [height][width][16] image whose channel 15 holds the BITS of the pixel's int32 sample count: the layout for
+     * STATMC_DOF_WELCH, whose pair test reads n_p and n_q (two RGB G-buffers; pair-symmetric kernel only; refused under
+     * STATMC_DOF_PIXEL, as a 15- or 17-channel image is under STATMC_DOF_WELCH).
      * When set, statmc_window_filter (T = float3, radius <= 20, n_buffers = 1) reads its inputs from it and ignores
      * mean_corr / discriminator / film / g_buffers (g_dr_factors and, for 17 channels, g_channel_counts still describe
      * the G-buffers: 15 channels = two RGB; 17 = up to two RGB + up to two 1-channel, pair-symmetric kernel only).
@@ -231,7 +234,8 @@ int statmc_window_filter(const statmc_filter_args *args, int channels); /* mean_
  * image -- film_buffer if denoise_film, else film[0] --, g_buffers[0], g_buffers[1]; all
  * width x height x 3) into the 15-channel image `packed` at pixel offset (dst_x0, dst_y0): the
  * owned block inside a block + halo image.  One pass, 60 B read + 60 B written per pixel.  A 17-channel `packed`
- * (row pitch cols * 68) takes up to two RGB and up to two 1-channel G-buffers (g_channel_counts says which). */
+ * (row pitch cols * 68) takes up to two RGB and up to two 1-channel G-buffers (g_channel_counts says which); a
+ * 16-channel one (row pitch cols * 64) also takes n[0] (channel 15: the count's bits). */
 int statmc_pack_filter_inputs(const statmc_filter_args *args, const statmc_image *packed, int dst_x0, int dst_y0);
 
 /* statmc_prepass (T = float3, buffer 0) and statmc_pack_filter_inputs in one pass over the block:

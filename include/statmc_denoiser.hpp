@@ -1397,8 +1397,7 @@ class FilmShards {
         for (size_t g = 0; g < est.gBuffers.size(); g++) (est.gBufferChannelCounts[g] == 3 ? nRgb : nSc)++;
         if (est.rgbBufferCounts[DenoiseGroup] != 1 || nRgb > 2 || nSc > 2)
             throw Error(STATMC_ERR_UNSUPPORTED, "FilmShards: one RGB radiance buffer under at most two RGB and two 1-channel G-buffers");
-        // the block + halo image: 15 channels for the shipped two RGB G-buffers, 17 with depth / material id
-        pch = (nRgb == 2 && nSc == 0) ? 15 : 17;
+        plainTwoRgb = nRgb == 2 && nSc == 0;
         bw = est.width / gx;
         bh = est.height / gy;
         r = est.filterRadius;
@@ -1419,22 +1418,20 @@ class FilmShards {
             }
             B.dg.resize(B.g.size());
             const int pw = bw + B.pl + B.pr, ph = bh + B.pt + B.pb;
-            void *p = nullptr;
-            check(statmc_malloc(&p, (size_t)pw * ph * pch * 4));
-            B.packed = std::shared_ptr<void>(p, [](void *q) { statmc_free(q); });
-            B.packedDesc = statmc_image{p, (size_t)pw * pch * 4, pw, ph};
             B.out = DeviceImage(ph, pw, F32C3);
             void *st = nullptr;
             check(statmc_stream_create(&st));
             B.stream = std::shared_ptr<void>(st, [](void *q) { statmc_stream_destroy(q); });
         }
         check(statmc_set_device(est.deviceIndex()));
+        layOutPacked();
     }
 
     // Estimator::Denoise() for the RGB buffer, sharded.  The inputs must be on the Estimator's device (after Upload()
     // or a flush of the device accumulation); returns with the work enqueued and the Estimator's stream waiting for it.
     void Denoise() {
         est.Synchronize();   // the cuts below read what the Estimator's stream wrote
+        layOutPacked();      // (the filter spec may have changed since the last call)
         // filter spec, significance level and quantile tables are per-device state: every block device filters under the
         // Estimator's device's rules (a seam between blocks under different specs would not be the unsharded result)
         for (const Block &B : blocks)
@@ -1482,8 +1479,32 @@ class FilmShards {
     }
 
     int nBlocks() const { return (int)blocks.size(); }
+    int packedChannels() const { return pch; }
 
   private:
+    // The block + halo images for the filter spec of the Estimator's device: 15 channels for the shipped two RGB G-buffers,
+    // 17 with depth / material id, 16 under Welch degrees of freedom (+ the sample count, which the pair test reads).
+    void layOutPacked() {
+        statmc_filter_spec spec;
+        check(statmc_set_device(est.deviceIndex()));
+        check(statmc_get_filter_spec(&spec));
+        const bool welch = spec.dof == STATMC_DOF_WELCH;
+        if (welch && !plainTwoRgb)
+            throw Error(STATMC_ERR_UNSUPPORTED, "FilmShards: Welch degrees of freedom need exactly two RGB G-buffers (the sample count takes the image's 16th channel)");
+        const int want = welch ? 16 : plainTwoRgb ? 15 : 17;
+        if (want == pch) return;
+        pch = want;
+        for (Block &B : blocks) {
+            check(statmc_set_device(B.device));
+            check(statmc_synchronize(B.stream.get()));
+            const int pw = bw + B.pl + B.pr, ph = bh + B.pt + B.pb;
+            void *p = nullptr;
+            check(statmc_malloc(&p, (size_t)pw * ph * pch * 4));
+            B.packed = std::shared_ptr<void>(p, [](void *q) { statmc_free(q); });
+            B.packedDesc = statmc_image{p, (size_t)pw * pch * 4, pw, ph};
+        }
+        check(statmc_set_device(est.deviceIndex()));
+    }
     struct Block {
         int device = 0, pl = 0, pr = 0, pt = 0, pb = 0, x0 = 0, y0 = 0;
         DeviceImage n, mean, m2, m3, colour, out;
@@ -1516,7 +1537,8 @@ class FilmShards {
         return a;
     }
     Estimator &est;
-    int gx, gy, bw = 0, bh = 0, r = 0, pch = 15;
+    int gx, gy, bw = 0, bh = 0, r = 0, pch = 0;
+    bool plainTwoRgb = true;
     std::vector<Block> blocks;
 };
 

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 STATMC_OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = -1, -2, -3, -4
+DOF_PIXEL, DOF_WELCH = 0, 1      # statmc_filter_spec.dof (include/statmc.h)
 MAX_BUFFERS, MAX_GBUFFERS = 16, 8
 
 
@@ -265,8 +266,9 @@ def make_filter_args(n, mean, m2, m3, film, mean_corr, disc, film_filtered, g_bu
                      film_filtered_buffer=None, roi=None, stream=None, keep=None, packed=None, film_origin=None,
                      packed_g_channels=None):
     """Build a statmc_filter_args from lists of per-buffer device tensors (reference argument
-    order, estimator.cpp:437-459).  Returns (args, keepalive).  packed: optional [H, W, 15 | 17]
-    block + halo tensor the window filter reads instead of the separate images (17: packed_g_channels
+    order, estimator.cpp:437-459).  Returns (args, keepalive).  packed: optional [H, W, 15 | 16 | 17]
+    block + halo tensor the window filter reads instead of the separate images (16: + the sample count, for Welch degrees
+    of freedom; 17: packed_g_channels
     names the channel count of every G-buffer in it, e.g. [3, 3, 1, 1], one g_sds / g_dr entry each)."""
     tables = [mean_corr, mean, film, film_filtered, n]
     nb = max(len(t) for t in tables) if packed is None else 1
@@ -328,7 +330,7 @@ def window_filter(args, channels):
 
 
 def pack_filter_inputs(args, packed, dst_x0, dst_y0):
-    """Owned block of the five filter inputs -> [Hp, Wp, 15] block + halo tensor at (dst_x0, dst_y0)."""
+    """Owned block of the five filter inputs -> [Hp, Wp, 15 | 16 | 17] block + halo tensor at (dst_x0, dst_y0)."""
     img = image_of(packed)
     check(load().statmc_pack_filter_inputs(C.byref(args), C.byref(img), dst_x0, dst_y0))
 

@@ -242,11 +242,13 @@ int check_image(const statmc_image &im, int w, int h, int channels, const char *
 }
 
 
-// Channels per pixel of a block + halo image: 15 (mean-corr, discriminator, colour, two RGB G-buffers) or 17 (+ two
-// 1-channel G-buffers: depth, material id -- statpath.cpp:828-835); 0 = neither.
+// Channels per pixel of a block + halo image: 15 (mean-corr, discriminator, colour, two RGB G-buffers), 16 (+ the sample
+// count, as its bits: Welch degrees of freedom read it per pair) or 17 (+ two 1-channel G-buffers: depth, material id --
+// statpath.cpp:828-835); 0 = none of them.
 int packed_channels(const statmc_image &im) {
     if (im.cols <= 0) return 0;
     if (im.step == (size_t)im.cols * 15 * 4) return 15;
+    if (im.step == (size_t)im.cols * 16 * 4) return 16;
     if (im.step == (size_t)im.cols * 17 * 4) return 17;
     return 0;
 }
@@ -256,16 +258,16 @@ struct PackedSlots {
     const float *rgb[2] = {nullptr, nullptr}, *sc[2] = {nullptr, nullptr};
 };
 int packed_slots(const statmc_filter_args *a, int ch, int W, int H, PackedSlots &out) {
-    if (ch == 15) {
+    if (ch == 15 || ch == 16) {
         if (a->n_g_buffers != 2 || !a->g_buffers || (a->g_channel_counts && (a->g_channel_counts[0] != 3 || a->g_channel_counts[1] != 3)))
-            return fail(STATMC_ERR_INVALID, "a 15-channel block + halo image holds exactly two RGB G-buffers");
+            return fail(STATMC_ERR_INVALID, "a 15- or 16-channel block + halo image holds exactly two RGB G-buffers");
     } else if (!a->g_buffers || !a->g_channel_counts || a->n_g_buffers > 4) {
         return fail(STATMC_ERR_INVALID, "a 17-channel block + halo image holds up to two RGB and two 1-channel G-buffers (g_channel_counts needed)");
     }
     int n_rgb = 0, n_sc = 0;
     for (size_t g = 0; g < a->n_g_buffers; g++) {
         const int gc = a->g_channel_counts ? a->g_channel_counts[g] : 3;
-        if ((gc != 1 && gc != 3) || (gc == 3 && n_rgb == 2) || (gc == 1 && (n_sc == 2 || ch == 15)))
+        if ((gc != 1 && gc != 3) || (gc == 3 && n_rgb == 2) || (gc == 1 && (n_sc == 2 || ch != 17)))
             return fail(STATMC_ERR_UNSUPPORTED, "g_buffers[%zu]: %d channels do not fit the %d-channel block + halo image", g, gc, ch);
         if (int rc = check_image(a->g_buffers[g], W, H, gc, "g_buffers", (int)g)) return rc;
         (gc == 3 ? out.rgb[n_rgb++] : out.sc[n_sc++]) = static_cast<const float *>(a->g_buffers[g].data);
@@ -589,19 +591,20 @@ static int window_filter_impl(const statmc_filter_args *a, int channels) {
     apply_spec(dstate, k, a);
     if (k.dof == STATMC_DOF_WELCH) {
         if (!k.tq) return fail(STATMC_ERR_HIP, "quantile table of the device not found");
-        if (packed_in || !a->n) return fail(STATMC_ERR_INVALID, "Welch dof: the window filter reads the sample counts (args->n)");
+        if (packed_in ? packed_channels(a->packed_inputs) != 16 : !a->n)
+            return fail(STATMC_ERR_INVALID, "Welch dof: the window filter reads the sample counts (args->n, or channel 15 of a 16-channel block + halo image)");
     }
     const bool packed = a->packed_inputs.data != nullptr;
     if (packed) {
         // block + halo path: everything the window filter reads comes from one 15- or 17-channel image
         const int pch = packed_channels(a->packed_inputs);
         if (channels != 3 || a->n_buffers != 1 || !a->g_dr_factors || pch == 0)
-            return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs: needs T = float3, n_buffers = 1 and a packed 15- or 17-channel image");
+            return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs: needs T = float3, n_buffers = 1 and a packed 15-, 16- or 17-channel image");
         CHECK_IMG(a->packed_inputs, pch, "packed_inputs", 0);
         if (!a->film_filtered) return fail(STATMC_ERR_INVALID, "null film_filtered table");
         CHECK_IMG(a->film_filtered[0], 3, "film_filtered", 0);
-        if (pch == 15) {
-            if (a->n_g_buffers != 2) return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (15 channels): two RGB G-buffers");
+        if (pch == 15 || pch == 16) {
+            if (a->n_g_buffers != 2) return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (15 / 16 channels): two RGB G-buffers");
             for (int g = 0; g < 2; g++) {
                 k.g[g].data = nullptr;
                 k.g[g].channels = 3;
@@ -627,6 +630,16 @@ static int window_filter_impl(const statmc_filter_args *a, int channels) {
             if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
             if (!statmc::sym_path_selected(k, 3)) return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (17 channels): the forced kernel variant cannot read them");
             statmc::sym_feature_slots(k);
+            if (int rc = prepare_sym(dstate, k, a)) return rc;
+        } else if (pch == 16) {
+            // + the sample counts: the Welch builds of the pair-symmetric kernel, and only they
+            if (k.dof != STATMC_DOF_WELCH || !statmc::sym_eligible(k, 3))
+                return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (16 channels): for STATMC_DOF_WELCH on the pair-symmetric kernel -- radius 1..20, DR "
+                                                    "factors finite and <= 0, STATMC_BORDER_CLIP, two RGB G-buffers");
+            if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
+            k.gscale0 = sqrtf(-k.g[0].dr * 1.44269504088896340736f);
+            k.gscale1 = sqrtf(-k.g[1].dr * 1.44269504088896340736f);
+            if (!statmc::sym_path_selected(k, 3)) return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (16 channels): the forced kernel variant cannot read them");
             if (int rc = prepare_sym(dstate, k, a)) return rc;
         } else {
             if (!statmc::fast_path_eligible(k, 3))
@@ -747,11 +760,15 @@ int statmc_pack_filter_inputs(const statmc_filter_args *a, const statmc_image *p
     if (!packed || !packed->data) return fail(STATMC_ERR_INVALID, "null packed image");
     if (a->n_buffers < 1 || !a->mean_corr || !a->discriminator) return fail(STATMC_ERR_INVALID, "pack needs buffer 0");
     const int pch = packed_channels(*packed);
-    if (pch == 0) return fail(STATMC_ERR_UNSUPPORTED, "packed image must have packed rows of 15 or 17 channels");
+    if (pch == 0) return fail(STATMC_ERR_UNSUPPORTED, "packed image must have packed rows of 15, 16 or 17 channels");
     const int W = a->width, H = a->height;
     const bool film = a->denoise_film != 0;
     if (!film && !a->film) return fail(STATMC_ERR_INVALID, "null film table");
     const statmc_image &colour = film ? a->film_buffer : a->film[0];
+    if (pch == 16) {
+        if (!a->n) return fail(STATMC_ERR_INVALID, "a 16-channel block + halo image carries the sample counts: null n table");
+        CHECK_IMG(a->n[0], 1, "n", 0);
+    }
     CHECK_IMG(a->mean_corr[0], 3, "mean_corr", 0);
     CHECK_IMG(a->discriminator[0], 3, "discriminator", 0);
     CHECK_IMG(colour, 3, "colour", 0);
@@ -762,7 +779,8 @@ int statmc_pack_filter_inputs(const statmc_filter_args *a, const statmc_image *p
                     packed->cols, packed->rows);
     statmc::PackArgs k{static_cast<const float *>(a->mean_corr[0].data), static_cast<const float *>(a->discriminator[0].data),
                        static_cast<const float *>(colour.data), gs.rgb[0], gs.rgb[1], static_cast<float *>(packed->data),
-                       W, H, packed->cols, dst_x0, dst_y0, gs.sc[0], gs.sc[1], pch};
+                       W, H, packed->cols, dst_x0, dst_y0, gs.sc[0], gs.sc[1], pch,
+                       pch == 16 ? static_cast<const int32_t *>(a->n[0].data) : nullptr};
     HIP_TRY(statmc::launch_pack_inputs(k, S(a->stream)));
     return STATMC_OK;
 }
@@ -780,7 +798,7 @@ int statmc_prepass_pack_rows(const statmc_filter_args *a, const statmc_image *pa
     if (a->n_buffers < 1 || !a->n || !a->mean || !a->m2 || !a->m3)
         return fail(STATMC_ERR_INVALID, "prepass_pack needs buffer 0 (n, mean, m2, m3)");
     const int pch = packed_channels(*packed);
-    if (pch == 0) return fail(STATMC_ERR_UNSUPPORTED, "packed image must have packed rows of 15 or 17 channels");
+    if (pch == 0) return fail(STATMC_ERR_UNSUPPORTED, "packed image must have packed rows of 15, 16 or 17 channels");
     const int W = a->width, H = a->height;
     const bool film = a->denoise_film != 0;
     if (!film && !a->film) return fail(STATMC_ERR_INVALID, "null film table");

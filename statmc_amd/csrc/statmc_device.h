@@ -128,7 +128,8 @@ struct FilterArgs {
     float *f_out[3];
     int f_active;
     const float *packed;         // optional [height][width][packed_ch] inputs: mc, disc, colour, g0, g1 (RGB each)[, s0, s1]
-    int packed_ch;               // 15, or 17 (+ two 1-channel G-buffers: the eight-plane build of the pair-symmetric kernel)
+    int packed_ch;               // 15, 16 (+ the sample count's bits: the Welch builds of the pair-symmetric kernel) or 17 (+ two
+                                 // 1-channel G-buffers: its eight-plane build)
     // pair-symmetric kernel (statmc_filter_sym.hip): tiles of 128 x 8 pixels on a grid fixed in film coordinates
     struct SymGeom {
         int tx0, ty0, ntx, nty;   // tile range of the launch (film tile indices)
@@ -159,7 +160,8 @@ struct PackArgs {
     float *packed;                                      // [dst_h][dst_w][ch]
     int src_w, src_h, dst_w, dst_x0, dst_y0;
     const float *s0, *s1;                               // ch = 17: the two 1-channel G-buffers [src_h][src_w] (nullptr: zeros)
-    int ch;                                             // 15 | 17
+    int ch;                                             // 15 | 16 | 17
+    const int32_t *n;                                   // ch = 16: the sample counts (channel 15 holds their bits: Welch dof)
 };
 hipError_t launch_pack_inputs(const PackArgs &a, hipStream_t s);
 
@@ -173,7 +175,7 @@ struct PrepassPackArgs {
     int src_w, src_h, dst_w, dst_x0, dst_y0, table, welch, small_n_exclude;
     int split_row, skip_rows;   // rows >= split_row of the launch's src_h rows sit skip_rows further down in every image (two row ranges in one launch)
     const float *s0, *s1;       // ch = 17: the two 1-channel G-buffers (nullptr: zeros); g0 / g1 may be nullptr as well then
-    int ch;                     // 15 | 17
+    int ch;                     // 15 | 16 (channel 15 = the bits of n: Welch degrees of freedom) | 17
 };
 hipError_t launch_prepass_pack(const PrepassPackArgs &a, hipStream_t s);
 

@@ -756,7 +756,7 @@ __global__ __launch_bounds__(256) void combine_parts_kernel(FilterArgs a) {
     }
 }
 
-// Owned block of the five filter inputs -> 15-channel block + halo image (one pass).
+// Owned block of the five filter inputs (+ sample counts / + two 1-channel G-buffers) -> 15 / 16 / 17-channel block + halo image (one pass).
 __global__ __launch_bounds__(256) void pack_inputs_kernel(PackArgs a) {
     const long long n = (long long)a.src_w * a.src_h;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -771,6 +771,8 @@ __global__ __launch_bounds__(256) void pack_inputs_kernel(PackArgs a) {
         if (a.ch == 17) {
             px[15] = a.s0 ? a.s0[i] : 0.f;
             px[16] = a.s1 ? a.s1[i] : 0.f;
+        } else if (a.ch == 16) {
+            px[15] = __int_as_float(a.n[i]);
         }
     }
 }

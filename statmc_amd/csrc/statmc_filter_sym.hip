@@ -762,6 +762,10 @@ struct Staged {   // one staged pixel: the 15 values of the common layout + the 
     float nm1;     // Welch: n - 1 as the oracle forms it, (float)n - 1.f
 };
 
+// Welch builds: the sample count of pixel p -- its own image, or channel 15 of a 16-channel block + halo image
+__device__ __forceinline__ int sample_count(const FilterArgs &a, long long p) {
+    return a.packed ? __float_as_int(a.packed[p * a.packed_ch + 15]) : a.n[p];
+}
 // pixel (x, yrow) of the input images (an absent G-buffer has factor 0 and is not read)
 template <int NG>
 __device__ __forceinline__ Staged load_px(const FilterArgs &a, const Feat &F, int x, int yrow) {
@@ -772,11 +776,12 @@ __device__ __forceinline__ Staged load_px(const FilterArgs &a, const Feat &F, in
     s.valid = x >= 0 && x < a.width && yrow >= 0 && yrow < a.height;
     if (s.valid) {
         const long long q = (long long)yrow * a.width + x;
-        if (a.n) r.nm1 = (float)a.n[q] - 1.f;   // Welch modes only (never with a packed image)
+        if (a.n) r.nm1 = (float)a.n[q] - 1.f;   // Welch builds only
         if (a.packed) {
             const float *pf = a.packed + q * a.packed_ch;
             const f3 *px = reinterpret_cast<const f3 *>(pf);
             s.mc = px[0]; s.d = px[1]; s.col = px[2]; s.g0 = px[3]; s.g1 = px[4];
+            if (a.packed_ch == 16) r.nm1 = (float)__float_as_int(pf[15]) - 1.f;   // Welch builds: the sample count's bits
             if constexpr (NG == 8) {
                 if (a.packed_ch == 17) { r.s0 = pf[15]; r.s1 = pf[16]; }
             }
@@ -1022,7 +1027,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
         st.pc[k][0] = v2f{ok.x ? col.x : 0.f, ok.y ? col.y : 0.f};
         st.pc[k][1] = v2f{ok.z ? col.z : 0.f, 0.f};
         if constexpr (W) {
-            const float nm1 = (float)a.n[p] - 1.f;
+            const float nm1 = (float)sample_count(a, p) - 1.f;
             st.pe[k][0] = v2f{d.x * d.x / nm1, d.y * d.y / nm1};
             st.pe[k][1] = v2f{d.z * d.z / nm1, 0.f};
         }
@@ -1055,7 +1060,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
                 int mn = 0x7fffffff;
                 for (int idx2 = threadIdx.x; idx2 < cnt; idx2 += kThreads) {
                     const int yy = idx2 / wc, xx = idx2 - yy * wc;
-                    mn = min(mn, a.n[(long long)(ya + yy) * a.width + xa + xx]);
+                    mn = min(mn, sample_count(a, (long long)(ya + yy) * a.width + xa + xx));
                 }
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
@@ -1426,8 +1431,10 @@ void sym_choose_split(FilterArgs &w, int n_cus) {
 // 17-channel packed image)
 bool sym_eligible(const FilterArgs &a, int channels) {
     if (a.radius < 1 || a.radius > sym::kR || (channels != 1 && channels != 3)) return false;
-    // Welch degrees of freedom: one RGB buffer from the separate images (the pair needs the sample counts)
-    if (a.dof != STATMC_DOF_PIXEL && (channels != 3 || a.packed)) return false;
+    // Welch degrees of freedom: one RGB buffer; the pair needs the sample counts -- from their own image, or from channel
+    // 15 of a 16-channel block + halo image (and that image is for the Welch builds only)
+    if (a.dof != STATMC_DOF_PIXEL && (channels != 3 || (a.packed && a.packed_ch != 16))) return false;
+    if (a.packed && a.packed_ch == 16 && a.dof != STATMC_DOF_WELCH) return false;
     // the pair-symmetric kernel implements both gates and both channel rules; the clamped border's taps beyond the image
     // are added by border_virtual_kernel
     // float buffers with the one-sided gate (four weights per pair for two buffers): one-sided kernel
@@ -1472,7 +1479,7 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     const bool welch = a.dof == STATMC_DOF_WELCH;
     const bool rt = a.radius != kR || welch;    // (the Welch modes exist in the runtime-radius build only; it serves r = 20 as well)
     if (rt && a.sym.tab_rt == nullptr) return hipErrorInvalidValue;
-    if (welch && (a.n == nullptr || a.tq2 == nullptr || a.sym.pair || a.sym.g8 || a.packed)) return hipErrorInvalidValue;
+    if (welch && (a.tq2 == nullptr || a.sym.pair || a.sym.g8 || (a.packed ? a.packed_ch != 16 : a.n == nullptr))) return hipErrorInvalidValue;
     // LDS-DMA staging needs whole 16-byte pieces: images 16-byte aligned, width and film x-origin multiples of 4 pixels
     auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool g8 = a.sym.g8 != 0;

@@ -223,6 +223,8 @@ __global__ __launch_bounds__(kBlock) void prepass_pack_kernel(PrepassPackArgs a)
         if (a.ch == 17) {
             px[15] = a.s0 ? a.s0[i] : 0.f;
             px[16] = a.s1 ? a.s1[i] : 0.f;
+        } else if (a.ch == 16) {
+            px[15] = __int_as_float(ni);
         }
     }
 }

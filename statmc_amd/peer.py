@@ -42,7 +42,9 @@ class PeerBlock:
         self.fs = film.FilmStats(layout.bw, layout.bh, self.dev, types=types, filter_sd=filter_sd, radius=radius,
                                  g_buffers=g_buffers, g_sds=g_sds)
         self.g_channels = [film.STAT_TYPES[g]["channels"] for g in self.fs.g_names]
-        self.channels = 17 if 1 in self.g_channels else 15
+        api.check(api.load().statmc_set_device(self.device_index))
+        # (laid out for the device's filter spec at this moment: 16 channels under Welch degrees of freedom)
+        self.channels = sharding.block_image_channels(self.g_channels, api.get_filter_spec().dof == api.DOF_WELCH)
         self.packed = layout.new_padded(self.channels, self.dev)
         self.out_pad = layout.new_padded(3, self.dev)
         self.main = torch.cuda.Stream(device=self.dev)

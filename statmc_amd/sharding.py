@@ -96,6 +96,17 @@ class BlockLayout:
         return padded[self.pt:self.pt + self.bh, self.pl:self.pl + self.bw]
 
 
+def block_image_channels(g_channels, welch=False):
+    """Channels per pixel of a block + halo image: 15 (mean-corr, discriminator, colour, two RGB G-buffers), 17 with
+    1-channel G-buffers (depth, material id), 16 under Welch degrees of freedom (STATMC_DOF_WELCH: + the sample count,
+    which the pair test reads; two RGB G-buffers only -- the Welch builds have six feature planes)."""
+    if welch:
+        if 1 in g_channels:
+            raise ValueError("Welch degrees of freedom: the block + halo image holds two RGB G-buffers, no 1-channel ones")
+        return 16
+    return 17 if 1 in g_channels else 15
+
+
 def exchange_halo(layout, padded, group=None, via_host=False):
     """Fill the halo margins of `padded` ([ph, pw, C], interior already written) from the
     neighbouring ranks.  Works on any backend (nccl == RCCL on ROCm, gloo on CPU).  via_host

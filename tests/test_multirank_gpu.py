@@ -36,6 +36,7 @@ def _grid(world, rows):
 def _film_samples(world, rows, BH=BH, g8=False):
     """Whole-film sample stream, identical in every process (CPU generator, fixed seed)."""
     from statmc_amd import synthetic
+    g8 = g8 is True
     gx, gy = _grid(world, rows)
     scene = synthetic.Scene(gx * BW, gy * BH, n_regions=9, seed=21)
     return scene.samples(SPP, seed=22, features=TYPES8 if g8 else TYPES)
@@ -63,27 +64,31 @@ def _run(rank, world, rows, q, dist, api, pipeline, sharding, BH=BH, g8=False):
         dev = torch.device("cuda:0")
         api.setup(0)
         api.force_filter_parts(2)            # same window-row split as the single-process run
+        welch = g8 == "welch"                # Welch degrees of freedom: the sample count travels in a 16-channel image
+        g8 = g8 is True
+        if welch:
+            api.set_filter_spec(dof=1)
         L = sharding.BlockLayout(rank, world, BW, BH, RADIUS, grid=_grid(world, rows))
         ox, oy = L.origin
         smp = {k: v[:, oy:oy + BH, ox:ox + BW].contiguous().to(dev) for k, v in _film_samples(world, rows, BH, g8).items()}
         pipe = pipeline.BlockPipeline(L, dev, TYPES8 if g8 else TYPES, radius=RADIUS, via_host=True,
                                       **(dict(g_buffers=G8) if g8 else {}))
-        assert pipe.packed.shape[2] == (17 if g8 else 15)
+        assert pipe.packed.shape[2] == (17 if g8 else 16 if welch else 15)
         # row strips tall enough for it take the overlapped order: the rows a neighbour needs first, the exchange started,
         # the rest accumulated behind it (BlockPipeline.accumulate_and_denoise); everything else the plain order
         overlapped = bool(pipe.border_rows())
         out = pipe.accumulate_and_denoise(smp).clone()
         torch.cuda.synchronize()
-        assert api.last_filter_variant() == ("sym_r20_g8" if g8 else "sym_r20")
+        assert api.last_filter_variant() == ("sym_r20_g8" if g8 else "sym_welch" if welch else "sym_r20")
         assert overlapped == (rows and BH >= 2 * RADIUS + 8)
         q.put((rank, ox, oy, out.cpu().numpy()))
         dist.barrier()
 
 
 @pytest.mark.parametrize("world,rows,BH,g8", [(2, False, 40, False), (4, False, 40, False), (3, True, 40, False), (3, True, 56, False),
-                                              (2, True, 64, False), (2, False, 40, True), (3, True, 56, True)],
+                                              (2, True, 64, False), (2, False, 40, True), (3, True, 56, True), (2, True, 64, "welch")],
                          ids=["2x1", "2x2", "1x3-rows", "1x3-rows-overlapped", "1x2-rows-overlapped", "2x1-eight-planes",
-                              "1x3-rows-overlapped-eight-planes"])
+                              "1x3-rows-overlapped-eight-planes", "1x2-rows-overlapped-welch"])
 def test_blocks_equal_whole_film(gpu, world, rows, BH, g8):
     """(The window-sweep split is pinned to the same value on both sides -- statmc_set_filter_split, the declared
     per-device setting: that is what makes the comparison bit for bit; tests/test_gpu_fullsize.py has the default dispatch.)"""
@@ -91,7 +96,11 @@ def test_blocks_equal_whole_film(gpu, world, rows, BH, g8):
     dev = torch.device("cuda:0")
     gx, gy = _grid(world, rows)
     whole = _film_samples(world, rows, BH, g8)
+    welch = g8 == "welch"
+    g8 = g8 is True
     gpu.force_filter_parts(2)
+    if welch:
+        gpu.set_filter_spec(dof=1)
     try:
         one = pipeline.BlockPipeline(sharding.BlockLayout(0, 1, gx * BW, gy * BH, RADIUS), dev, TYPES8 if g8 else TYPES, radius=RADIUS,
                                      **(dict(g_buffers=G8) if g8 else {}))
@@ -99,10 +108,11 @@ def test_blocks_equal_whole_film(gpu, world, rows, BH, g8):
         ref = one.denoise().cpu().numpy()
     finally:
         gpu.force_filter_parts(0)
+        gpu.set_filter_spec()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(rk, world, rows, port, q, BH, g8)) for rk in range(world)]
+    procs = [ctx.Process(target=_worker, args=(rk, world, rows, port, q, BH, "welch" if welch else g8)) for rk in range(world)]
     for p in procs:
         p.start()
     got = []

@@ -179,6 +179,14 @@ def test_sharded_denoise_through_the_cpp_host(gpu, tmp_path, grid):
         outs[g] = pfm.read_pfm("%s-%d-film-f.pfm" % (stem, spp))
     assert np.isfinite(outs[None]).all() and np.abs(outs[None] - rad["film_mean"]).max() > 0
     assert np.array_equal(outs[grid], outs[None])
+    if grid == "2x2":     # Welch degrees of freedom: the sample count rides in the block + halo image's 16th channel
+        for g in (None, grid):
+            cmd = [exe, "--stem", stem, "--spp", str(spp), "--output", "film-f", "--parts", "2", "--spec", "dof=welch"] + (["--grid", g] if g else [])
+            out = subprocess.run(cmd, capture_output=True, text=True)
+            assert out.returncode == 0, out.stderr
+            outs["welch", g] = pfm.read_pfm("%s-%d-film-f.pfm" % (stem, spp))
+        assert np.array_equal(outs["welch", grid], outs["welch", None])
+        assert not np.array_equal(outs["welch", None], outs[None])
 
 
 def test_cv_adaptor_matches_the_library(gpu, tmp_path):
