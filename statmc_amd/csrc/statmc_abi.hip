@@ -720,6 +720,11 @@ static int window_filter_impl(const statmc_filter_args *a, int channels) {
                 k.f_disc[j] = static_cast<const float *>(a->discriminator[b].data);
                 k.f_colour[j] = static_cast<const float *>(a->film[b].data);
                 k.f_out[j] = static_cast<float *>(a->film_filtered[b].data);
+                k.f_n[j] = nullptr;
+                if (k.dof == STATMC_DOF_WELCH) {   // every buffer has its own sample counts
+                    CHECK_IMG(a->n[b], 1, "n", b);
+                    k.f_n[j] = static_cast<const int32_t *>(a->n[b].data);
+                }
                 if (k.f_out[j] == k.f_colour[j]) return fail(STATMC_ERR_INVALID, "filter cannot run in place (buffer %d)", b);
             }
             HIP_TRY(statmc::launch_window_filter(k, channels, S(a->stream), &variant));

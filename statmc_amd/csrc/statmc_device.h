@@ -125,6 +125,7 @@ struct FilterArgs {
     // fast path, filter<float>: up to three 1-channel buffers per launch (f_active of them real;
     // the rest repeat the last one and are not stored)
     const float *f_mean_corr[3], *f_disc[3], *f_colour[3];
+    const int32_t *f_n[3];       // Welch degrees of freedom: the buffers' sample counts (pair-symmetric kernel: two buffers per launch)
     float *f_out[3];
     int f_active;
     const float *packed;         // optional [height][width][packed_ch] inputs: mc, disc, colour, g0, g1 (RGB each)[, s0, s1]

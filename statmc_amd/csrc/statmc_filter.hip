@@ -93,7 +93,8 @@ __device__ __forceinline__ bool pixel_valid(const FilterArgs &a, long long p) {
 
 template <int C>
 __device__ __forceinline__ bool pair_member(const FilterArgs &a, const float *mc, const float *dc, const float *pc, const float *pd,
-                                            long long p, long long q) {
+                                            long long p, long long q, const int32_t *n = nullptr) {
+    if (n == nullptr) n = a.n;   // (the buffer's own counts: filter<float> with several buffers per launch)
     bool all = true;
     float lhs_sum = 0.f, rhs_sum = 0.f;
 #pragma unroll
@@ -105,7 +106,7 @@ __device__ __forceinline__ bool pair_member(const FilterArgs &a, const float *mc
             const float s = Dp + Dq;
             float Dsum = s;
             if (s > 0.f && __builtin_isfinite(s)) {
-                const float nu = (s * s) / (Dp * Dp / ((float)a.n[p] - 1.f) + Dq * Dq / ((float)a.n[q] - 1.f));
+                const float nu = (s * s) / (Dp * Dp / ((float)n[p] - 1.f) + Dq * Dq / ((float)n[q] - 1.f));
                 const int dof = nu >= 1.f ? (nu < 4096.f ? (int)nu : 4096) : 1;
                 const float t = a.tq[dof - 1];
                 Dsum = (t * t) * s;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void border_virtual_kernel(FilterArgs a) {
             auto pair = [&](int qx, int qy, int d_along, float t_across) {
                 const long long q = (long long)qy * W + qx;
                 if (!pixel_valid<C>(mc, dc, col, q) || !features_valid(a, q)) return;
-                if (!pair_member<C>(a, mc, dc, pc, pd, p, q)) return;
+                if (!pair_member<C>(a, mc, dc, pc, pd, p, q, NB == 0 ? a.n : a.f_n[b])) return;
                 float e = a.ds * (float)(d_along * d_along);
                 for (int g = 0; g < a.n_g; g++) {
                     const int gc = a.g[g].channels;

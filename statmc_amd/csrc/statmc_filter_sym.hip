@@ -93,10 +93,12 @@ constexpr bool mode_asym(int m) { return m == kModeAsym || m == kModeAsymJoint |
 // Each in two builds: the first reads the quantiles from a band of the table in LDS and flags the items in which a pair
 // asked for an entry outside it; the second ("far") reads the table in global memory and runs behind the first over the
 // flagged items only (none in a film of uniform sample count).
-constexpr int kModeWelch = 7, kModeWelchJoint = 8, kModeWelchFar = 9, kModeWelchJointFar = 10;
-constexpr bool mode_welch(int m) { return m >= kModeWelch && m <= kModeWelchJointFar; }
+// kModeWelchPair: filter<float>, two buffers per launch as in kModePair, each with its own sample counts and its own test.
+constexpr int kModeWelch = 7, kModeWelchJoint = 8, kModeWelchFar = 9, kModeWelchJointFar = 10, kModeWelchPair = 11, kModeWelchPairFar = 12;
+constexpr bool mode_welch(int m) { return m >= kModeWelch && m <= kModeWelchPairFar; }
 constexpr bool mode_welch_joint(int m) { return m == kModeWelchJoint || m == kModeWelchJointFar; }
-constexpr bool mode_welch_far(int m) { return m == kModeWelchFar || m == kModeWelchJointFar; }
+constexpr bool mode_welch_far(int m) { return m == kModeWelchFar || m == kModeWelchJointFar || m == kModeWelchPairFar; }
+constexpr bool mode_pair(int m) { return m == 1 /* kModePair */ || m == kModeWelchPair || m == kModeWelchPairFar; }
 constexpr int kR = 20;
 constexpr int kPx = 4;                    // pixels per lane
 constexpr int kW = 32 * kPx;              // 128 tile columns: half a wave per row
@@ -290,7 +292,7 @@ template <int H, unsigned MASK, int MODE, int NG, class LaneT>
 __device__ __forceinline__ void gate_weight(LaneT &st, const v4f *mcn, const v4f *en, const WelchTab &tq2,
                                             const v2f (&e)[kPx], v2f (&w)[kPx], v2f (&wb)[kPx]) {
     using M = Taps<H, MASK>;
-    constexpr bool PAIR = MODE == kModePair;
+    constexpr bool PAIR = mode_pair(MODE);
     constexpr int NC = PAIR ? 2 : 3;
     if constexpr (mode_welch(MODE)) {
         // Software pipeline over the lane's pixels: the table look-ups of pixel k are in flight (six ds_read_b32 from the band
@@ -299,11 +301,11 @@ __device__ __forceinline__ void gate_weight(LaneT &st, const v4f *mcn, const v4f
         // per channel (the file is compiled without the machine scheduler: source order is issue order).
         v2f t2[2][3];
         auto lookup = [&](int k, v2f (&out)[3]) {
-            unsigned dx[3], dy[3];
+            unsigned dx[3] = {0u, 0u, 0u}, dy[3] = {0u, 0u, 0u};   // (PAIR: two channels = the two buffers)
             // (all six reciprocals ahead of the corrections -- no s_nop behind them -- needs twelve more registers and times
             // the same: 3.385 against 3.361 ms)
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
+            for (int ch = 0; ch < NC; ch++) {
                 const v2f sn = rsub_bc(pair_of<H>(mcn[3 + ch]), st.ms[k][ch], 1);      // -(v_p + v_q)
                 const v2f den = add_bc(st.pe[k][ch >> 1], ch & 1, pair_of<H>(en[ch]));   // E_p + E_q
                 const v2f s2 = sn * sn;
@@ -343,13 +345,17 @@ __device__ __forceinline__ void gate_weight(LaneT &st, const v4f *mcn, const v4f
         auto test = [&](int k, const v2f (&tt)[3]) {
             v2f u[3];
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
+            for (int ch = 0; ch < NC; ch++) {
                 const v2f d = sub_bc(st.ms[k][ch], 0, pair_of<H>(mcn[ch]));
                 const v2f sn = rsub_bc(pair_of<H>(mcn[3 + ch]), st.ms[k][ch], 1);      // (the compiler keeps the look-up's)
                 u[ch] = __builtin_elementwise_fma(d, d, tt[ch] * sn);
             }
             w[k] = v2f{__builtin_amdgcn_exp2f(e[k].x), __builtin_amdgcn_exp2f(e[k].y)};
-            if constexpr (mode_welch_joint(MODE)) {
+            if constexpr (PAIR) {   // every buffer its own test (a pixel that takes no part in a buffer has a NaN mean there)
+                const v2f x = w[k];
+                w[k] = v2f{M::in0(k) && u[0].x <= 0.f ? x.x : 0.f, M::in1(k) && u[0].y <= 0.f ? x.y : 0.f};
+                wb[k] = v2f{M::in0(k) && u[1].x <= 0.f ? x.x : 0.f, M::in1(k) && u[1].y <= 0.f ? x.y : 0.f};
+            } else if constexpr (mode_welch_joint(MODE)) {
                 const v2f m = (u[0] + u[1]) + u[2];
                 w[k] = v2f{M::in0(k) && m.x <= 0.f ? w[k].x : 0.f, M::in1(k) && m.y <= 0.f ? w[k].y : 0.f};
             } else {
@@ -459,7 +465,7 @@ __device__ __forceinline__ void gate_weight(LaneT &st, const v4f *mcn, const v4f
 template <int H, unsigned MASK, bool SYM, int MODE, int NG, class LaneT>
 __device__ __forceinline__ void accumulate(LaneT &st, const v4f *col, const v2f (&w)[kPx], const v2f (&wb)[kPx], v2f (&qv)[4]) {
     using M = Taps<H, MASK>;
-    constexpr bool PAIR = MODE == kModePair;
+    constexpr bool PAIR = mode_pair(MODE);
     if constexpr (PAIR) {
 #pragma unroll
         for (int k = 0; k < kPx; k++) if (M::on(k)) { st.acc[k][2] += w[k]; st.sw[k] += wb[k]; }
@@ -534,7 +540,7 @@ __device__ __forceinline__ void chunk(LaneT &st, const float *__restrict__ row, 
                                       const WelchTab &tq2) {
     using M0 = Taps<0, MASK>;
     using M1 = Taps<1, MASK>;
-    constexpr bool PAIR = MODE == kModePair;
+    constexpr bool PAIR = mode_pair(MODE);
     constexpr bool W = mode_welch(MODE);
     static_assert(!(W && PIPE), "the Welch modes use the compiler-placed reads");
     constexpr int C_MC = Planes<NG, W>::cMC, C_COL = Planes<NG, W>::cCOL;
@@ -759,12 +765,18 @@ __device__ __forceinline__ Feat features_of(const FilterArgs &a) {
 struct Staged {   // one staged pixel: the 15 values of the common layout + the two 1-channel features (NG = 8)
     StagedPixel p;
     float s0, s1;
-    float nm1;     // Welch: n - 1 as the oracle forms it, (float)n - 1.f
+    float nm1, nm1b;   // Welch: n - 1 as the oracle forms it, (float)n - 1.f; nm1b: the second buffer's (filter<float>)
 };
 
-// Welch builds: the sample count of pixel p -- its own image, or channel 15 of a 16-channel block + halo image
-__device__ __forceinline__ int sample_count(const FilterArgs &a, long long p) {
-    return a.packed ? __float_as_int(a.packed[p * a.packed_ch + 15]) : a.n[p];
+// Welch builds: the sample count of pixel p -- its own image, or channel 15 of a 16-channel block + halo image;
+// filter<float> (two buffers per launch): n0 / n1 = the two buffers' counts, else both the pixel's
+__device__ __forceinline__ void sample_counts(const FilterArgs &a, long long p, int &n0, int &n1) {
+    if (a.sym.pair) {
+        n0 = a.f_n[0][p];
+        n1 = a.f_active > 1 ? a.f_n[1][p] : n0;
+    } else {
+        n0 = n1 = a.packed ? __float_as_int(a.packed[p * a.packed_ch + 15]) : a.n[p];
+    }
 }
 // pixel (x, yrow) of the input images (an absent G-buffer has factor 0 and is not read)
 template <int NG>
@@ -772,16 +784,21 @@ __device__ __forceinline__ Staged load_px(const FilterArgs &a, const Feat &F, in
     Staged r;
     StagedPixel &s = r.p;
     r.s0 = r.s1 = 0.f;
-    r.nm1 = 1.f;
+    r.nm1 = r.nm1b = 1.f;
     s.valid = x >= 0 && x < a.width && yrow >= 0 && yrow < a.height;
     if (s.valid) {
         const long long q = (long long)yrow * a.width + x;
-        if (a.n) r.nm1 = (float)a.n[q] - 1.f;   // Welch builds only
+        if (a.dof == STATMC_DOF_WELCH && !a.packed) {
+            int n0, n1;
+            sample_counts(a, q, n0, n1);
+            r.nm1 = (float)n0 - 1.f;
+            r.nm1b = (float)n1 - 1.f;
+        }
         if (a.packed) {
             const float *pf = a.packed + q * a.packed_ch;
             const f3 *px = reinterpret_cast<const f3 *>(pf);
             s.mc = px[0]; s.d = px[1]; s.col = px[2]; s.g0 = px[3]; s.g1 = px[4];
-            if (a.packed_ch == 16) r.nm1 = (float)__float_as_int(pf[15]) - 1.f;   // Welch builds: the sample count's bits
+            if (a.packed_ch == 16) r.nm1 = r.nm1b = (float)__float_as_int(pf[15]) - 1.f;   // Welch builds: the sample count's bits
             if constexpr (NG == 8) {
                 if (a.packed_ch == 17) { r.s0 = pf[15]; r.s1 = pf[16]; }
             }
@@ -824,7 +841,7 @@ __device__ __forceinline__ void stage_store(float *slot, int i, const Staged &r,
         const Validity ok = pixel_validity(s.mc, s.d, s.col, s.valid && features_finite(s.g0, s.g1), rgb);
         float *p = slot + Planes<NG, W>::cE * kP + i;
         p[0 * kP] = ok.x ? s.d.x * s.d.x / r.nm1 : 0.f;
-        p[1 * kP] = ok.y ? s.d.y * s.d.y / r.nm1 : 0.f;
+        p[1 * kP] = ok.y ? s.d.y * s.d.y / (rgb ? r.nm1 : r.nm1b) : 0.f;
         p[2 * kP] = ok.z ? s.d.z * s.d.z / r.nm1 : 0.f;
     }
 #pragma unroll
@@ -915,7 +932,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     // Welch (band build): the quantile band sits at LDS address 0 -- a look-up's byte offset is its address -- and the
     // ring behind it
     float *const lds = smem + Planes<NG, mode_welch(MODE)>::kBandTotal;
-    constexpr bool PAIR = MODE == kModePair;
+    constexpr bool PAIR = mode_pair(MODE);
     constexpr bool W = mode_welch(MODE);
     static_assert(!W || (!DMA && NG == 6 && RT), "the Welch modes exist in one build: register staging, six feature planes, runtime radius");
     constexpr int kSlotFloats = Planes<NG, W>::kSlotFloats, kIn = Planes<NG, W>::kIn;
@@ -1027,8 +1044,10 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
         st.pc[k][0] = v2f{ok.x ? col.x : 0.f, ok.y ? col.y : 0.f};
         st.pc[k][1] = v2f{ok.z ? col.z : 0.f, 0.f};
         if constexpr (W) {
-            const float nm1 = (float)sample_count(a, p) - 1.f;
-            st.pe[k][0] = v2f{d.x * d.x / nm1, d.y * d.y / nm1};
+            int n0, n1;
+            sample_counts(a, p, n0, n1);
+            const float nm1 = (float)n0 - 1.f, nm1b = (float)n1 - 1.f;
+            st.pe[k][0] = v2f{d.x * d.x / nm1, d.y * d.y / nm1b};
             st.pe[k][1] = v2f{d.z * d.z / nm1, 0.f};
         }
 #pragma unroll
@@ -1060,7 +1079,9 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
                 int mn = 0x7fffffff;
                 for (int idx2 = threadIdx.x; idx2 < cnt; idx2 += kThreads) {
                     const int yy = idx2 / wc, xx = idx2 - yy * wc;
-                    mn = min(mn, sample_count(a, (long long)(ya + yy) * a.width + xa + xx));
+                    int n0, n1;
+                    sample_counts(a, (long long)(ya + yy) * a.width + xa + xx, n0, n1);
+                    mn = min(mn, min(n0, n1));
                 }
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
@@ -1431,14 +1452,14 @@ void sym_choose_split(FilterArgs &w, int n_cus) {
 // 17-channel packed image)
 bool sym_eligible(const FilterArgs &a, int channels) {
     if (a.radius < 1 || a.radius > sym::kR || (channels != 1 && channels != 3)) return false;
-    // Welch degrees of freedom: one RGB buffer; the pair needs the sample counts -- from their own image, or from channel
-    // 15 of a 16-channel block + halo image (and that image is for the Welch builds only)
-    if (a.dof != STATMC_DOF_PIXEL && (channels != 3 || (a.packed && a.packed_ch != 16))) return false;
+    // Welch degrees of freedom: the pair needs the sample counts -- from their own images (one RGB buffer, or two float
+    // buffers per launch), or from channel 15 of a 16-channel block + halo image (and that image is for the Welch builds only)
+    if (a.dof != STATMC_DOF_PIXEL && a.packed && a.packed_ch != 16) return false;
     if (a.packed && a.packed_ch == 16 && a.dof != STATMC_DOF_WELCH) return false;
     // the pair-symmetric kernel implements both gates and both channel rules; the clamped border's taps beyond the image
     // are added by border_virtual_kernel
     // float buffers with the one-sided gate (four weights per pair for two buffers): one-sided kernel
-    if (a.gate != STATMC_GATE_SYMMETRIC && channels != 3) return false;
+    if (a.gate != STATMC_GATE_SYMMETRIC && channels != 3 && a.dof == STATMC_DOF_PIXEL) return false;   // (Welch: one test, no gate form)
     if (a.border == STATMC_BORDER_CLAMP && a.packed) return false;   // the border kernel reads the five images, not the packed one
     int n_rgb = 0, n_sc = 0;
     for (int g = 0; g < a.n_g; g++) {
@@ -1479,7 +1500,9 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     const bool welch = a.dof == STATMC_DOF_WELCH;
     const bool rt = a.radius != kR || welch;    // (the Welch modes exist in the runtime-radius build only; it serves r = 20 as well)
     if (rt && a.sym.tab_rt == nullptr) return hipErrorInvalidValue;
-    if (welch && (a.tq2 == nullptr || a.sym.pair || a.sym.g8 || (a.packed ? a.packed_ch != 16 : a.n == nullptr))) return hipErrorInvalidValue;
+    if (welch && (a.tq2 == nullptr || a.sym.g8 || (a.sym.pair ? (a.packed != nullptr || a.f_n[0] == nullptr || (a.f_active > 1 && a.f_n[1] == nullptr))
+                                                                 : a.packed ? a.packed_ch != 16 : a.n == nullptr)))
+        return hipErrorInvalidValue;
     // LDS-DMA staging needs whole 16-byte pieces: images 16-byte aligned, width and film x-origin multiples of 4 pixels
     auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool g8 = a.sym.g8 != 0;
@@ -1518,10 +1541,12 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     const void *kernel_far = nullptr;
     if (welch) {   // (the gate field has no meaning under Welch: there is one test, symmetric in the pair)
         if (a.sym.redo == nullptr) return hipErrorInvalidValue;
-        kernel = joint ? reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelchJoint, 6, true>)
-                       : reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelch, 6, true>);
-        kernel_far = joint ? reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelchJointFar, 6, true>)
-                           : reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelchFar, 6, true>);
+        kernel = pair    ? reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelchPair, 6, true>)
+                 : joint ? reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelchJoint, 6, true>)
+                         : reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelch, 6, true>);
+        kernel_far = pair    ? reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelchPairFar, 6, true>)
+                     : joint ? reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelchJointFar, 6, true>)
+                             : reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelchFar, 6, true>);
     }
     static std::mutex mu;
     static std::set<std::pair<int, const void *>> done;

@@ -866,6 +866,58 @@ def test_filter_float_multibuffer_fast_path(gpu, oracle, n_buffers, radius, vari
             assert rel_l2(args["film_filtered"][b].cpu().numpy(), refs[b]) <= TOL, (name, b)
 
 
+@pytest.mark.parametrize("radius,border", [(20, 0), (6, 1)], ids=["r20", "r6-clamp"])
+def test_filter_float_multibuffer_welch(gpu, oracle, radius, border):
+    """filter<float> under Welch degrees of freedom: three buffers with DIFFERENT sample counts (5, 9 and 2 400 samples; two
+    buffers share a launch of the pair-symmetric kernel's Welch build, each with its own counts, its own test and its own
+    band entries -- 5 next to 2 400 leaves the band: those work items take the far build), against the oracle per buffer
+    and against the general kernel."""
+    W, H = 276, 27
+    _, smp, st = make_case(W, H, 9, seed=61)
+    gbs = [st["normal"]["mean"], st["albedo"]["mean"]]
+    lum = smp["radiance"].mean(axis=3, keepdims=True)
+    spec = oracle.FilterSpec(dof=1, border=border)
+    refs, args = [], dict(n=[], mean=[], m2=[], m3=[], film=[], mean_corr=[], disc=[], film_filtered=[])
+    for b, spp in enumerate((5, 9, 9)):
+        s = oracle.new_state(H, W, 1)
+        oracle.accumulate(s, np.ascontiguousarray(lum[:spp] * np.float32(1.0 / (1 + b))), True, 3)
+        if b == 2:
+            s["n"][...] = 2400          # (statistics of 9 samples under a count of 2 400: the filter only sees numbers)
+        mc, dc = oracle.prepass(s["n"], s["mean"], s["m2"], s["m3"], spec=spec)
+        refs.append(oracle.filter_image(mc, dc, s["film_mean"], gbs, G_DR, -0.5 / (radius / 2.0) ** 2, radius, spec=spec, n=s["n"]))
+        for k, v in (("n", s["n"]), ("mean", s["mean"]), ("m2", s["m2"]), ("m3", s["m3"]), ("film", s["film_mean"])):
+            args[k].append(to_dev(v))
+        for k in ("mean_corr", "disc", "film_filtered"):
+            args[k].append(torch.zeros(H, W, 1, device=DEV))
+    # order: (5, 2 400) share the first launch, 9 the second
+    for k in args:
+        args[k] = [args[k][0], args[k][2], args[k][1]]
+    refs = [refs[0], refs[2], refs[1]]
+    a, keep = gpu.make_filter_args(g_buffers=[to_dev(g) for g in gbs], g_sds=[SD_NORMAL, SD_ALBEDO],
+                                   filter_sd=radius / 2.0, radius=radius, **args)
+    lib = gpu.load()
+    lib.statmc_debug_welch_far_items.restype = C.c_int
+    gpu.set_filter_spec(dof=1, border=border)
+    try:
+        gpu.filter_f32(a)
+        torch.cuda.synchronize()
+        assert gpu.last_filter_variant() == "sym_welch_f" + ("_clamp" if border else "")
+        assert lib.statmc_debug_welch_far_items() == 0          # (the last launch: the 9-sample buffer alone)
+        got = [t.cpu().numpy() for t in args["film_filtered"]]
+        gpu.force_filter_variant(1)
+        for t in args["film_filtered"]:
+            t.zero_()
+        gpu.filter_f32(a)
+        torch.cuda.synchronize()
+        assert gpu.last_filter_variant() == "generic"
+    finally:
+        gpu.force_filter_variant(0)
+        gpu.set_filter_spec()
+    for b in range(3):
+        assert rel_l2(got[b], refs[b]) <= TOL, b
+        assert rel_l2(args["film_filtered"][b].cpu().numpy(), refs[b]) <= TOL, ("generic", b)
+
+
 def test_filter_entry_point_reference_argument_order(gpu, oracle):
     """statmc_filter_f32x3 with the reference's argument block: nBuffers = 2, denoiseFilm set:
     buffer 0 filters `film` into `film-f`, buffer 1 filters its own film-mean (estimator.cpp:465-487)."""
@@ -1268,9 +1320,9 @@ def expected_lds_variant(spec_kw, channels, radius):
     membership tests in its runtime-radius build)."""
     gate, joint, border = spec_kw.get("gate", 0), spec_kw.get("channel_rule", 0) and channels == 3, spec_kw.get("border", 0)
     if spec_kw.get("dof", 0):
-        # Welch degrees of freedom: an RGB buffer runs the pair-symmetric kernel's Welch build (one build for every radius;
-        # the gate field has no meaning under Welch), float buffers the general kernel
-        return "sym_welch" + ("_joint" if joint else "") + ("_clamp" if border else "") if channels == 3 else "generic"
+        # Welch degrees of freedom: the pair-symmetric kernel's Welch builds (one per buffer type for every radius; the gate
+        # field has no meaning under Welch) -- an RGB buffer, or two float buffers per launch
+        return "sym_welch" + ("_f" if channels == 1 else "") + ("_joint" if joint else "") + ("_clamp" if border else "")
     f = "_f" if channels == 1 else ""
     g = ("", "_asym", "_centre")[gate]
     if channels == 3 or not gate:       # the pair-symmetric kernel: compile-time radius 20, runtime radius below
