@@ -9,10 +9,27 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_${TAG}_variants
 mkdir -p $OUT
 cd $ROOT
-for s in time_welch time_g8_radii time_specs; do
+for s in time_welch time_float_welch time_g8_radii time_specs; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$s -- python3 $ROOT/tools/experiments/$s.py > $OUT/$s.log 2>&1
   tail -3 $OUT/$s.log
 done
+# instruction counters of the default and the Welch build (one short run each counter set: tools/experiments/time_welch_variant.py)
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_welch -- python3 $ROOT/tools/experiments/time_welch_variant.py > $OUT/pmc_welch.log 2>&1
+python3 - <<PY
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$OUT/pmc_welch/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "window_filter_sym" in r["Kernel_Name"]:
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open("$ROOT/gpurun_out/${TAG}_welch_pmc_per_launch.csv", "w") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "counter", "launches", "mean_per_launch"])
+    for k, d in sorted(agg.items()):
+        for c, v in sorted(d.items()):
+            w.writerow([k, c, len(v), "%.6g" % (sum(v) / len(v))])
+print(len(agg), "kernels with counters")
+PY
 python3 - <<PY
 import csv, glob, os
 rows = []
