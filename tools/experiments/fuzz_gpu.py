@@ -187,11 +187,22 @@ def float_filter_case(case):
             y, x = int(rng.integers(0, H)), int(rng.integers(0, W))
             cols[b][y, x] = [np.nan, np.inf][int(rng.integers(0, 2))]
     outs = [torch.zeros(H, W, 1, device=T.DEV) for _ in range(nb)]
-    a, keep = gpu.make_filter_args([], [], [], [], [T.to_dev(c) for c in cols], [T.to_dev(m) for m in mcs], [T.to_dev(d) for d in dcs],
-                                   outs, [T.to_dev(g) for g in gbs], g_dr=g_dr, filter_sd=sd, radius=radius)
     force = int(rng.choice([0, 0, 0, 2, 1, 3]))
     parts = int(rng.choice([0, 0, 1, 2, 3, 7]))
-    spec_kw = {k: v for k, v in random_spec(rng).items() if k != "dof"}
+    spec_kw = random_spec(rng)
+    if not WELCH:
+        spec_kw.pop("dof", None)
+    ns = None
+    if spec_kw.get("dof"):      # Welch: every buffer its own sample counts -- uniform, ragged, or with pixels of fewer than two samples
+        ns = []
+        for b in range(nb):
+            kind = int(rng.integers(0, 3))
+            n = rng.integers(2, 400, size=(H, W)).astype(np.int32) if kind == 0 else np.full((H, W), int(rng.choice([2, 3, 4, 16, 64, 256, 1024, 3000, 5000])), np.int32)
+            if kind == 2:
+                n[rng.random((H, W)) < 0.05] = int(rng.integers(0, 2))
+            ns.append(n)
+    a, keep = gpu.make_filter_args([T.to_dev(n) for n in ns] if ns else [], [], [], [], [T.to_dev(c) for c in cols], [T.to_dev(m) for m in mcs],
+                                   [T.to_dev(d) for d in dcs], outs, [T.to_dev(g) for g in gbs], g_dr=g_dr, filter_sd=sd, radius=radius)
     gpu.force_filter_variant(force)
     gpu.force_filter_parts(parts)
     gpu.set_filter_spec(**spec_kw)
@@ -204,7 +215,8 @@ def float_filter_case(case):
         gpu.set_filter_spec()
     worst, finite_ok = 0.0, True
     for b in range(nb):
-        ref = oracle.filter_image(mcs[b], dcs[b], cols[b], gbs, g_dr, -0.5 / sd ** 2, radius, spec=oracle.FilterSpec(**spec_kw))
+        ref = oracle.filter_image(mcs[b], dcs[b], cols[b], gbs, g_dr, -0.5 / sd ** 2, radius, spec=oracle.FilterSpec(**spec_kw),
+                                  n=ns[b] if ns else None)
         out = outs[b].cpu().numpy()
         mask = np.isfinite(ref)
         finite_ok = finite_ok and np.array_equal(np.isfinite(out), mask)
