@@ -266,6 +266,19 @@ def test_band_pipeline_gives_the_same_bits(gpu, tmp_path, config, W, H):
     for bands, (used, imgs) in results.items():
         for n, v in imgs.items():
             assert np.array_equal(v, base[n]), (bands, used, n)
+    if (W, H) in ((640, 600), (328, 520)):
+        # Welch degrees of freedom (the pair-symmetric kernel's Welch builds: a quantile band per work item, flagged items
+        # computed again): the bands of the pipeline give the bits of the one-stream sequence there too, RGB and float
+        welch = {}
+        for n_bands in (1, 3):
+            out = subprocess.run([exe, "--stem", stem, "--spp", str(spp), "--config", config, "--bands", str(n_bands), "--output", outputs,
+                                  "--spec", "dof=welch"], capture_output=True, text=True)
+            assert out.returncode == 0, out.stderr
+            welch[n_bands] = {n: pfm.read_pfm("%s-%d-%s.pfm" % (stem, spp, n)) for n in outputs.split(",")}
+        first = outputs.split(",")[0]
+        assert not np.array_equal(welch[1][first], base[first])
+        for n, v in welch[3].items():
+            assert np.array_equal(v, welch[1][n]), n
 
 
 def test_cv_adaptor_band_pipeline_same_bits(gpu, tmp_path):
