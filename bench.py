@@ -81,6 +81,8 @@ def parse():
                          "through the C ABI, statmc_halo_exchange's device-to-device copies -- no torch.distributed, no RCCL; "
                          "gloo (+ --share-device) exercises the per-rank code path on a 1-GPU box, halos via the host")
     ap.add_argument("--no-fallback", action="store_true", help="nccl: do not fall back to the peer leg")
+    ap.add_argument("--run-timeout", type=int, default=600, help="nccl ranks under a foreign launcher: seconds after the bring-up before a "
+                    "run that has not printed its line is given up (the ranks leave, rank 0 runs the peer leg in a fresh process)")
     ap.add_argument("--rank-timeout", type=int, default=900, help="self-launched ranks: seconds before the leg is ended (and the peer leg tried)")
     ap.add_argument("--bringup-timeout", type=int, default=150, help="seconds the process-group bring-up (init, first all-reduce, first "
                                                                       "neighbour exchange) may take before it counts as hung")
@@ -623,7 +625,7 @@ def run_peer_child(args, why, error_lines, timeout_s=900):
     if line is not None:
         try:
             d = json.loads(line)
-            d["fallback_from"] = "nccl"
+            d["fallback_from"] = args.backend
             d["nccl_error"] = {"why": why, "last_stderr_lines": error_lines[-8:]}
             line = json.dumps(d)
         except Exception:                                # noqa: BLE001
@@ -684,6 +686,8 @@ def bring_up(args, rank, world, dev):
         if args.backend == "nccl":
             if os.environ.get("STATMC_BENCH_FAIL_NCCL") == "1":          # tests: the forced-failure path
                 raise RuntimeError("STATMC_BENCH_FAIL_NCCL=1 (forced failure of the nccl bring-up)")
+            if os.environ.get("STATMC_BENCH_FAIL_NCCL") == "hang":       # tests: a bring-up that never returns (the watchdog's case)
+                time.sleep(10 ** 6)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=to)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world, timeout=to)
@@ -757,6 +761,30 @@ def main():
                 print(line, flush=True)
             sys.exit(rc if rc else (0 if line is not None else 1))
     n_ranks_seen = dist.get_world_size() if world > 1 else 1
+    run_done = None
+    stall_test = os.environ.get("STATMC_BENCH_FAIL_NCCL") == "stall"      # tests: a run that stalls behind a good bring-up (any backend)
+    if world > 1 and (args.backend == "nccl" or stall_test) and not os.environ.get("STATMC_BENCH_NO_FALLBACK") and not args.no_fallback:
+        # Under a foreign launcher nobody else ends a run that stalls after the bring-up (an exchange that never completes):
+        # past --run-timeout every rank leaves, and rank 0 -- once the others have let go of their devices -- runs the peer leg
+        # in a fresh process.  (Self-launched ranks: the parent's --rank-timeout does this.)
+        import threading as _threading
+        run_done = _threading.Event()
+
+        def run_watchdog():
+            if run_done.wait(args.run_timeout):
+                return
+            sys.stderr.write("bench.py rank %d: the nccl run has not finished %d s after the bring-up\n" % (rank, args.run_timeout))
+            sys.stderr.flush()
+            if rank != 0:
+                os._exit(0)
+            time.sleep(3.0)
+            rc, line = run_peer_child(args, "the nccl run did not finish within %d s of the bring-up" % args.run_timeout, [])
+            if line is not None:
+                print(line, flush=True)
+            os._exit(0 if line is not None else 1)
+        _threading.Thread(target=run_watchdog, daemon=True).start()
+        if stall_test:
+            time.sleep(10 ** 6)
 
     from statmc_amd import api, film, pipeline, sharding, synthetic
     api.setup(local_rank)
@@ -1027,6 +1055,8 @@ def main():
                 result["cpu_baseline"] = cpu_baseline(args, fs, samples, types)
             except Exception as e:          # noqa: BLE001
                 result["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
+    if run_done is not None:
+        run_done.set()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

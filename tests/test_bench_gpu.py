@@ -141,11 +141,13 @@ def test_peer_leg_one_process_all_blocks_and_same_bits_as_the_rank_leg(gpu, tmp_
     assert a.shape == (256, 512, 3) and np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("launcher", ["self", "torchrun"])
-def test_nccl_failure_falls_back_to_the_peer_leg(gpu, launcher):
-    """The nccl leg cannot come up (forced: STATMC_BENCH_FAIL_NCCL=1; on this one-GPU box RCCL would refuse two ranks on a
-    device anyway) -> a FRESH process runs the peer leg and the line records where it came from.  Both launch forms: the
-    self-launcher's parent owns the fallback, under a foreign launcher (the driver's form) rank 0 does."""
+@pytest.mark.parametrize("launcher,mode", [("self", "1"), ("torchrun", "1"), ("self", "hang"), ("torchrun", "hang")],
+                         ids=["self", "torchrun", "self-hang", "torchrun-hang"])
+def test_nccl_failure_falls_back_to_the_peer_leg(gpu, launcher, mode):
+    """The nccl leg cannot come up (forced: STATMC_BENCH_FAIL_NCCL=1 raises in the bring-up, =hang never returns from it and
+    leaves it to the watchdog; on this one-GPU box RCCL would refuse two ranks on a device anyway) -> a FRESH process runs
+    the peer leg and the line records where it came from.  Both launch forms: the self-launcher's parent owns the fallback,
+    under a foreign launcher (the driver's form) rank 0 does."""
     if launcher == "self":
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")]
     else:
@@ -155,9 +157,30 @@ def test_nccl_failure_falls_back_to_the_peer_leg(gpu, launcher):
         s.close()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(ROOT, "bench.py")]
-    cmd += ["--gpus", "2", "--backend", "nccl", "--share-device"] + COMMON
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=_clean_env(STATMC_BENCH_FAIL_NCCL="1"))
+    cmd += ["--gpus", "2", "--backend", "nccl", "--share-device"] + COMMON + (["--bringup-timeout", "6"] if mode == "hang" else [])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=_clean_env(STATMC_BENCH_FAIL_NCCL=mode))
     assert out.returncode == 0, out.stderr[-3000:]
     r = _line(out)
     assert r["backend"] == "peer" and r["fallback_from"] == "nccl" and r["n_gpus"] == 2 and r["n_ranks_seen"] == 2
     assert "why" in r["nccl_error"] and r["value"] > 0
+    if mode == "hang" and launcher == "torchrun":
+        assert "stuck" in r["nccl_error"]["why"]
+
+
+def test_stalled_run_under_a_foreign_launcher_falls_back(gpu):
+    """A run that stalls AFTER a good bring-up (forced: STATMC_BENCH_FAIL_NCCL=stall; gloo ranks here, the box has one GPU)
+    under the driver's launch form, where no parent owns a time limit: past --run-timeout the ranks leave and rank 0 runs
+    the peer leg in a fresh process."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device",
+           "--run-timeout", "5"] + COMMON
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=_clean_env(STATMC_BENCH_FAIL_NCCL="stall"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = _line(out)
+    assert r["backend"] == "peer" and r["fallback_from"] == "gloo" and r["n_ranks_seen"] == 2 and r["value"] > 0
+    assert "did not finish" in r["nccl_error"]["why"]
+
