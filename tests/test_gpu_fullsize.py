@@ -146,6 +146,58 @@ def blocks_2x2_equal_whole(gpu, fs, colour, variant):
         assert torch.equal(L.interior(out), whole[oy:oy + bh, ox:ox + bw]), rank
 
 
+def test_welch_fullsize_strips_band_and_blocks(gpu, oracle, film1080):
+    """Welch degrees of freedom at the full 1080p size (the pin's other candidate for the dof): the pair-symmetric kernel's
+    Welch build against oracle strips <= 1e-5 (middle rows, clipped corners); the film's uniform sample count keeps every
+    work item inside its quantile band (no far items); and what 4 GPUs compute -- 2 x 2 blocks, the sample counts riding in
+    the 16th channel of the block + halo image -- is the single-GPU result bit for bit under a pinned split."""
+    import ctypes as C
+    from statmc_amd import sharding
+    fs, _ = film1080
+    lib = gpu.load()
+    lib.statmc_debug_welch_far_items.restype = C.c_int
+    colour = fs.state["radiance"]["film_mean"]
+    n = fs.state["radiance"]["n"]
+    spec = oracle.FilterSpec(dof=1)
+    gpu.set_filter_spec(dof=1)
+    gpu.force_filter_parts(2)
+    try:
+        fs.prepass()                                  # (Welch: the discriminator image holds s^2 / n)
+        whole = wf(gpu, fs, colour, torch.zeros_like(colour)).clone()
+        assert gpu.last_filter_variant() == "sym_welch" and lib.statmc_debug_welch_far_items() == 0
+        mc, dc, col, nn = fs.mean_corr.cpu().numpy(), fs.disc.cpu().numpy(), colour.cpu().numpy(), n.cpu().numpy()
+        gbs = [fs.g_buffer("normal").cpu().numpy(), fs.g_buffer("albedo").cpu().numpy()]
+        for roi in ((0, 534, W, 542), (0, 0, 300, 6), (W - 300, H - 6, W, H)):
+            x0, y0, x1, y1 = roi
+            ref = oracle.filter_image(mc, dc, col, gbs, G_DR, -0.5 / FILTER_SD ** 2, RADIUS, roi=roi, spec=spec, n=nn)[y0:y1, x0:x1]
+            got = whole[y0:y1, x0:x1].cpu().numpy()
+            for c in range(3):
+                assert rel_l2(got[..., c], ref[..., c]) <= 1e-5, (roi, c)
+        # 2 x 2 blocks through 16-channel block + halo images
+        bw, bh = W // 2, H // 2
+        for rank in range(4):
+            L = sharding.BlockLayout(rank, 4, bw, bh, RADIUS)
+            ox, oy = L.origin
+            cut = lambda t: t[oy - L.pt:oy + bh + L.pb, ox - L.pl:ox + bw + L.pr].contiguous()
+            packed = torch.zeros(L.ph, L.pw, 16, device=DEV)
+            a, keep = gpu.make_filter_args([cut(n)], [], [], [], [cut(colour)], [cut(fs.mean_corr)], [cut(fs.disc)], [torch.zeros_like(cut(colour))],
+                                           [cut(fs.g_buffer("normal")), cut(fs.g_buffer("albedo"))], g_sds=[SD_NORMAL, SD_ALBEDO],
+                                           filter_sd=FILTER_SD, radius=RADIUS)
+            gpu.pack_filter_inputs(a, packed, 0, 0)          # (block + halo cut out of the whole film: one pack, no exchange)
+            out = torch.zeros(L.ph, L.pw, 3, device=DEV)
+            a2, keep2 = gpu.make_filter_args(n=[], mean=[], m2=[], m3=[], film=[], mean_corr=[], disc=[], film_filtered=[out], g_buffers=[],
+                                             g_sds=[SD_NORMAL, SD_ALBEDO], filter_sd=FILTER_SD, radius=RADIUS, roi=L.roi, packed=packed,
+                                             film_origin=(ox - L.pl, oy - L.pt))
+            gpu.window_filter(a2, 3)
+            torch.cuda.synchronize()
+            assert gpu.last_filter_variant() == "sym_welch"
+            assert torch.equal(L.interior(out), whole[oy:oy + bh, ox:ox + bw]), rank
+    finally:
+        gpu.force_filter_parts(0)
+        gpu.set_filter_spec()
+        fs.prepass()                                  # the module's film goes back to the default spec's discriminator
+
+
 def test_default_dispatch_blocks_vs_whole_film(gpu, oracle, film1080):
     """What N GPUs compute under the DEFAULT dispatch -- every block picks the window-sweep split that fits its own shape
     (1 part for the whole 1080p film, 3 for its 1920 x 135 / 270 / 540 strips on a 256-CU device) -- against the
