@@ -18,7 +18,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, bw, bh, r, rows, q):
+def _worker(rank, world, port, bw, bh, r, rows, q, welch=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle import oracle
@@ -38,11 +38,17 @@ def _worker(rank, world, port, bw, bh, r, rows, q):
             "g1": rng.random((fh, fw, 3), dtype=np.float32),
         }
         ox, oy = L.origin
-        packed = L.new_padded(15, "cpu")
+        # Welch degrees of freedom: the block + halo image has a 16th channel, the bits of the pixel's int32 sample count
+        n_film = rng.integers(2, 40, size=(fh, fw)).astype(np.int32)
+        ch = sharding.block_image_channels([3, 3], welch)
+        assert ch == (16 if welch else 15)
+        packed = L.new_padded(ch, "cpu")
         packed.fill_(float("nan"))
         inner = L.interior(packed)
         for i, k in enumerate(("mc", "disc", "colour", "g0", "g1")):
             inner[..., 3 * i:3 * i + 3] = torch.from_numpy(film[k][oy:oy + bh, ox:ox + bw])
+        if welch:
+            inner[..., 15] = torch.from_numpy(n_film[oy:oy + bh, ox:ox + bw].copy()).view(torch.float32)
         if rows:   # row strips: the exchange in two halves (started, something else done, waited for) as the multi-GPU step runs it
             in_flight = sharding.exchange_halo_start(L, packed)
             busy = float(torch.ones(1000).sum())          # (what the rank does meanwhile: the rest of its accumulation)
@@ -53,20 +59,26 @@ def _worker(rank, world, port, bw, bh, r, rows, q):
         # the padded block must now equal the film window around the block
         want = np.concatenate([film[k] for k in ("mc", "disc", "colour", "g0", "g1")], axis=2)[
             oy - L.pt:oy + bh + L.pb, ox - L.pl:ox + bw + L.pr]
-        ok_halo = np.array_equal(packed.numpy(), want)
+        ok_halo = np.array_equal(packed.numpy()[..., :15], want)
+        n_loc = None
+        if welch:
+            n_loc = np.ascontiguousarray(packed.numpy()[..., 15]).view(np.int32)
+            ok_halo = ok_halo and np.array_equal(n_loc, n_film[oy - L.pt:oy + bh + L.pb, ox - L.pl:ox + bw + L.pr])
         # filter the block with ROI = owned pixels, compare with the whole-film filter
         p = packed.numpy()
         loc = [np.ascontiguousarray(p[..., 3 * i:3 * i + 3]) for i in range(5)]
         drs, ds = [-0.5 / 0.3 ** 2, -0.5 / 0.5 ** 2], -0.5 / 4.0 ** 2
-        out = oracle.filter_image(loc[0], loc[1], loc[2], [loc[3], loc[4]], drs, ds, r, roi=L.roi, threads=1)
+        spec = oracle.FilterSpec(dof=oracle.DOF_WELCH) if welch else None
+        out = oracle.filter_image(loc[0], loc[1], loc[2], [loc[3], loc[4]], drs, ds, r, roi=L.roi, threads=1, spec=spec, n=n_loc)
         ref = oracle.filter_image(film["mc"], film["disc"], film["colour"], [film["g0"], film["g1"]], drs, ds, r,
-                                  roi=(ox, oy, ox + bw, oy + bh), threads=1)
+                                  roi=(ox, oy, ox + bw, oy + bh), threads=1, spec=spec, n=n_film if welch else None)
         x0, y0, x1, y1 = L.roi
         ok_filter = np.array_equal(out[y0:y1, x0:x1], ref[oy:oy + bh, ox:ox + bw])
         # final gather: the blocks assembled on rank 0 are the whole-film filter output
         whole = sharding.gather_blocks(L, torch.from_numpy(np.ascontiguousarray(out[y0:y1, x0:x1])))
         if rank == 0:
-            full = oracle.filter_image(film["mc"], film["disc"], film["colour"], [film["g0"], film["g1"]], drs, ds, r, threads=1)
+            full = oracle.filter_image(film["mc"], film["disc"], film["colour"], [film["g0"], film["g1"]], drs, ds, r, threads=1,
+                                       spec=spec, n=n_film if welch else None)
             ok_filter = ok_filter and whole.shape == full.shape and np.array_equal(whole.numpy(), full)
         else:
             ok_filter = ok_filter and whole is None
@@ -75,12 +87,13 @@ def _worker(rank, world, port, bw, bh, r, rows, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,bw,bh,r,rows", [(2, 24, 18, 5, False), (4, 16, 14, 6, False), (3, 20, 9, 4, True), (4, 12, 10, 5, True)])
-def test_halo_exchange_and_block_filter(world, bw, bh, r, rows):
+@pytest.mark.parametrize("world,bw,bh,r,rows,welch", [(2, 24, 18, 5, False, False), (4, 16, 14, 6, False, False), (3, 20, 9, 4, True, False),
+                                                      (4, 12, 10, 5, True, False), (2, 20, 12, 5, True, True), (4, 14, 12, 4, False, True)])
+def test_halo_exchange_and_block_filter(world, bw, bh, r, rows, welch):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(rk, world, port, bw, bh, r, rows, q)) for rk in range(world)]
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, bw, bh, r, rows, q, welch)) for rk in range(world)]
     for p in procs:
         p.start()
     for p in procs:
