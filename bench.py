@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 torch = None   # imported by main() AFTER the launch decision: the parent of a self-launched N > 1 run never touches the GPU
 dist = None
 
+PLACED = {"on": False, "error": None}   # set by main(): buffers of the timed step come from statmc_malloc_placed
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TOPS = 78.6          # 10^12 fp32 lane-ops/s: 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz
 FILTER_BYTES_PER_PX = 72       # 60 B in (5 float3 images) + 12 B out
@@ -53,6 +54,20 @@ def accumulate_bytes_per_px(spp, types):
         planes = {1: 1, 2: 2, 3: 3}[cfg["max_moment"]] + (2 if cfg["transform"] else 0)
         total += 4 * c * spp + 2 * (4 + 4 * c * planes)   # samples + RMW of n and the moment planes
     return total
+
+
+def new_film_stats(W, H, dev, types, **kw):
+    """FilmStats for a secondary leg, its moments placed like the timed step's."""
+    from statmc_amd import film
+    return film.FilmStats(W, H, dev, types=types, placed=PLACED["on"], **kw)
+
+
+def new_arena(shape, dev):
+    """A sample arena (float32), placed like the timed step's."""
+    from statmc_amd import api
+    if PLACED["on"]:
+        return api.empty_placed(shape, torch.float32, dev, api.MEM_STREAM)
+    return torch.empty(shape, dtype=torch.float32, device=dev)
 
 
 def parse():
@@ -100,43 +115,84 @@ def parse():
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: assemble film-f on rank 0 inside every step (default: measured after the timed region as gather_ms)")
     ap.add_argument("--no-bind", action="store_true", help="do not bind the rank to the CPUs of its GPU's NUMA node")
+    ap.add_argument("--no-placement", dest="placement", action="store_false",
+                    help="running moments and sample arenas from torch's allocator (default: statmc_malloc_placed -- the moments in one "
+                         "interference class of the card's memory, the arenas in another: include/statmc.h)")
     args = ap.parse_args()
     if args.film:
         args.width, args.height = (int(v) for v in args.film.lower().split("x"))
     return args
 
 
-def cpu_baseline(args, fs, samples, types, budget_s=7.0):
-    """Times the CPU oracle (the restated reference algorithm, OpenMP over tiles / rows, all host
-    cores) on a bounded sample of the same workload: each leg is sized from a short probe so that
-    it does about `budget_s` seconds of work.  Reported, never used by the GPU path."""
+def cpu_share():
+    """The CPUs this process may use: the affinity mask, and the cgroup's CPU quota where one is set (a GPU box of the pool
+    shows 256 logical CPUs in the mask and a quota of 16: threads beyond the quota are throttled, which is what made 128
+    OpenMP threads deliver 3.3 x one thread in rounds 3 and 4)."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:      # noqa: BLE001
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())       # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:  # noqa: BLE001
+            quota = None
+    usable = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return {"affinity_cpus": aff, "cgroup_quota_cpus": quota, "usable_cpus": usable}
+
+
+def cpu_baseline(args, fs, samples, types, budget_s=6.0):
+    """Times the CPU oracle (the restated reference algorithm, OpenMP over tiles / rows) on a bounded sample of the same
+    workload, on as many threads as the box gives this process (cpu_share): each leg is sized from a short probe so that it
+    does about `budget_s` seconds of work.  The accumulation reads its samples the way the reference's render loop produces
+    them -- tile after tile, pixel after pixel, a pixel's samples one after the other (oracle_accumulate_tile_stream) -- and
+    not as film-major planes, which cost a CPU a cache miss per sample.  Reported, never used by the GPU path."""
     import numpy as np
     from oracle import oracle
     from statmc_amd.film import STAT_TYPES
     W, H = args.width, args.height
     S = next(iter(samples.values())).shape[0]          # the resident samples (all of --spp unless a pool was needed)
-    cores = oracle.num_threads()
+    # the binding to the GPU's NUMA node (bind_to_gpu_numa) is for the GPU path: the CPU legs get every CPU the box allows
+    affinity_before = len(os.sched_getaffinity(0))
+    try:
+        os.sched_setaffinity(0, range(os.cpu_count() or 1))
+    except Exception:      # noqa: BLE001
+        pass
+    share = cpu_share()
+    cores = min(share["usable_cpus"], oracle.num_threads())
 
-    # ---- accumulate: a strip of rows, all spp, all channels, repeated on fresh state
-    ar = min(args.cpu_acc_rows, H)
+    # ---- accumulate: a strip of >= 128 rows (>= 960 tiles at 1080p), all channels, a bounded number of samples per pixel
+    # (the per-sample cost does not depend on the count), repeated on fresh state
+    ar = min(max(args.cpu_acc_rows, 128), H)
+    ar -= ar % 16 if ar >= 16 else 0
     y0 = (H - ar) // 2
-    host = {t: samples[t][:, y0:y0 + ar].contiguous().cpu().numpy() for t in types}
+    S_cpu = min(S, 64)
+    host = {t: samples[t][:S_cpu, y0:y0 + ar].contiguous().cpu().numpy() for t in types}
+    stream = {t: oracle.to_tile_major(host[t]) for t in types}
 
-    def acc_once():
+    def acc_once(threads):
         t0 = time.perf_counter()
         for t in types:
             st = oracle.new_state(ar, W, STAT_TYPES[t]["channels"])
-            oracle.accumulate(st, host[t], STAT_TYPES[t]["transform"], STAT_TYPES[t]["max_moment"])
+            oracle.accumulate_tile_stream(st, stream[t], S_cpu, STAT_TYPES[t]["transform"], STAT_TYPES[t]["max_moment"], threads=threads)
         return time.perf_counter() - t0
 
-    acc_once()  # page in / warm the thread pool
-    t_acc, acc_reps = 0.0, 0
-    while t_acc < budget_s and acc_reps < 200:
-        t_acc += acc_once()
-        acc_reps += 1
-    acc_s_per_px = t_acc / (acc_reps * ar * W)
+    def acc_leg(threads, budget):
+        acc_once(threads)  # page in / warm the thread pool
+        t, reps = 0.0, 0
+        while t < budget and reps < 200:
+            t += acc_once(threads)
+            reps += 1
+        return t / (reps * ar * W) * (S / S_cpu), reps, t       # seconds per pixel at the step's sample count
 
-    # ---- pre-pass (full frame) + filter (rows sized from a 8-row probe, full window)
+    acc_s_per_px, acc_reps, t_acc = acc_leg(cores, budget_s)
+
+    # ---- pre-pass (full frame) + filter (rows sized from a probe, full window)
     rad = {k: v.cpu().numpy() for k, v in fs.state["radiance"].items() if v is not None}
     gb = [fs.g_buffer(g).cpu().numpy() for g in fs.g_names]
     g_dr = [-0.5 / (sd * sd) for sd in fs.g_sds]
@@ -147,21 +203,26 @@ def cpu_baseline(args, fs, samples, types, budget_s=7.0):
 
     last = {}
 
-    def flt(rows):
+    def flt(rows, threads, keep=False):
         fy0 = (H - rows) // 2
         t0 = time.perf_counter()
-        last["out"] = oracle.filter_image(mc, dc, rad["film_mean"], gb, g_dr, ds, args.radius, roi=(0, fy0, W, fy0 + rows))
-        last["rows"] = (fy0, fy0 + rows)
-        return time.perf_counter() - t0
+        out = oracle.filter_image(mc, dc, rad["film_mean"], gb, g_dr, ds, args.radius, roi=(0, fy0, W, fy0 + rows), threads=threads)
+        dt = time.perf_counter() - t0
+        if keep:
+            last["out"], last["rows"] = out, (fy0, fy0 + rows)
+        return dt
 
-    probe_rows = min(max(cores // 4, 8), H)
-    t_probe = flt(probe_rows)
-    fr = int(min(H, max(probe_rows, budget_s / max(t_probe / probe_rows, 1e-9))))
-    t_flt, flt_reps = 0.0, 0
-    while t_flt < budget_s and flt_reps < 50:
-        t_flt += flt(fr)
-        flt_reps += 1
-    flt_s_per_px = t_flt / (flt_reps * fr * W)
+    def flt_leg(threads, budget, keep=False):
+        probe_rows = min(max(2 * threads, 8), H)          # every thread has rows to work on (one row = one work item)
+        t_probe = flt(probe_rows, threads)
+        fr = int(min(H, max(4 * threads, probe_rows, budget / max(t_probe / probe_rows, 1e-9))))
+        t, reps = 0.0, 0
+        while t < budget and reps < 50:
+            t += flt(fr, threads, keep=keep)
+            reps += 1
+        return t / (reps * fr * W), reps, t, fr
+
+    flt_s_per_px, flt_reps, t_flt, fr = flt_leg(cores, budget_s, keep=True)
     s_per_px = acc_s_per_px + t_pre / (W * H) + flt_s_per_px
     # The rows the oracle has just filtered, against what the HIP path left in film-f for the same statistics (the
     # checker at work, not the product: BASELINE's bound is 1e-5 relative L2 per channel; "oracle" = this build's own
@@ -179,37 +240,50 @@ def cpu_baseline(args, fs, samples, types, budget_s=7.0):
     except Exception as e:      # noqa: BLE001
         parity = {"error": repr(e)[:200]}
 
-    # ---- the same two legs on ONE thread (small strips), for the single-core figure
-    ar1 = min(2, ar)
-    t0 = time.perf_counter()
-    for t in types:
-        st = oracle.new_state(ar1, W, STAT_TYPES[t]["channels"])
-        oracle.accumulate(st, np.ascontiguousarray(host[t][:, :ar1]), STAT_TYPES[t]["transform"], STAT_TYPES[t]["max_moment"],
-                          threads=1)
-    acc1 = (time.perf_counter() - t0) / (ar1 * W)
-    fy1 = H // 2
-    t0 = time.perf_counter()
-    oracle.filter_image(mc, dc, rad["film_mean"], gb, g_dr, ds, args.radius, roi=(0, fy1, W, fy1 + 2), threads=1)
-    flt1 = (time.perf_counter() - t0) / (2 * W)
+    # ---- how the two legs scale with threads on this box (about 1.2 s per point and leg): the evidence behind `cores`
+    scaling = []
+    for th in [t for t in (1, 4, 16, 32, 64, 128) if t <= share["affinity_cpus"]]:
+        if th == cores:
+            a_s, f_s = acc_s_per_px, flt_s_per_px
+        else:
+            a_s = acc_leg(th, 1.2)[0]
+            f_s = flt_leg(th, 1.2)[0]
+        scaling.append({"threads": th, "accumulate_s_per_mpx": round(a_s * 1e6, 4), "filter_s_per_mpx": round(f_s * 1e6, 4),
+                        "mpixels_per_s": round(1e-6 / (a_s + t_pre / (W * H) + f_s), 5)})
+    if not any(r["threads"] == cores for r in scaling):
+        scaling.append({"threads": cores, "accumulate_s_per_mpx": round(acc_s_per_px * 1e6, 4), "filter_s_per_mpx": round(flt_s_per_px * 1e6, 4),
+                        "mpixels_per_s": round(1e-6 / s_per_px, 5)})
+        scaling.sort(key=lambda r: r["threads"])
+    one = next(r for r in scaling if r["threads"] == 1)
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
             cpu_model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
     except Exception:
         pass
+    throttled = None
+    try:
+        throttled = int(open("/sys/fs/cgroup/cpu.stat").read().split("nr_throttled")[1].split()[0])
+    except Exception:      # noqa: BLE001
+        pass
     return {
         "value": round(1e-6 / s_per_px, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-        "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count(),
-        "sample": "oracle (C restatement of the reference algorithm, OpenMP, %d threads): accumulate %d rows x %d px "
-                  "x %d spp x %d ch, %d repetitions (%.1f s); pre-pass full frame (%.2f s); filter %d rows x %d px, "
-                  "full %dx%d window, %d repetitions (%.1f s); per-pixel times summed and inverted"
-                  % (cores, ar, W, S, args.channels, acc_reps, t_acc, t_pre, fr, W, 2 * args.radius + 1,
+        "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count(), "cpu_share": share,
+        "affinity": {"cpus_during_gpu_legs": affinity_before, "cpus_during_cpu_legs": len(os.sched_getaffinity(0))},
+        "cgroup_throttled_periods_so_far": throttled,
+        "sample": "oracle (C restatement of the reference algorithm, OpenMP, %d threads = the CPUs this box gives the process: %d in the "
+                  "affinity mask, cgroup quota %s): accumulate %d rows x %d px (%d tiles) x %d of the %d spp x %d ch, samples in tile-major "
+                  "pixel-major order, %d repetitions (%.1f s), scaled to %d spp; pre-pass full frame (%.2f s); filter %d rows x %d px, full "
+                  "%dx%d window, %d repetitions (%.1f s); per-pixel times summed and inverted"
+                  % (cores, share["affinity_cpus"], ("%.1f CPUs" % share["cgroup_quota_cpus"]) if share["cgroup_quota_cpus"] else "none",
+                     ar, W, (ar // 16) * (W // 16), S_cpu, S, args.channels, acc_reps, t_acc, S, t_pre, fr, W, 2 * args.radius + 1,
                      2 * args.radius + 1, flt_reps, t_flt),
         "parity_of_the_same_run": parity,
         "accumulate_s_per_mpx": round(acc_s_per_px * 1e6, 4),
         "filter_s_per_mpx": round(flt_s_per_px * 1e6, 4),
-        "single_thread": {"value": round(1e-6 / (acc1 + t_pre / (W * H) + flt1), 5), "unit": "Mpixels/s", "cores": 1,
-                          "sample": "accumulate %d rows, filter 2 rows, one thread" % ar1},
+        "threads_scaling": scaling,
+        "speedup_over_one_thread": round(one["mpixels_per_s"] and (1e-6 / s_per_px) / one["mpixels_per_s"], 2),
+        "single_thread": {"value": one["mpixels_per_s"], "unit": "Mpixels/s", "cores": 1},
     }
 
 
@@ -341,13 +415,13 @@ def _tile_fed_measure(W, H, dev, samples, types, S, reps=5):
     bounds = torch.tensor(tiles, dtype=torch.int32, device=dev)
     npx = torch.tensor([(x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in tiles], dtype=torch.int64)
     offs = torch.cumsum(npx * S, 0) - npx * S
-    st2 = film.FilmStats(W, H, dev, types=types)
+    st2 = new_film_stats(W, H, dev, types)
     sts, keep = [], []
     for t in types:
         c = film.STAT_TYPES[t]["channels"]
         src = samples[t][:S]
         # [S, H, W, C] -> per tile [S, th, tw, C]: full 16-row bands by reshape, the ragged last band by hand
-        arena = torch.empty(int((npx * S).sum()) * c, device=dev)
+        arena = new_arena((int((npx * S).sum()) * c,), dev)
         pos = 0
         for y in range(0, H, 16):
             th = min(16, H - y)
@@ -401,7 +475,7 @@ def accumulate_by_batch(fs, samples, types, batch_sizes=(4, 8, 16, 32, 64), reps
     for S in batch_sizes:
         if S > S_all:
             continue
-        st2 = film.FilmStats(W, H, dev, types=types)
+        st2 = new_film_stats(W, H, dev, types)
         part = {t: v[:S] for t, v in samples.items()}
         st2.accumulate(part)
         torch.cuda.synchronize()
@@ -802,8 +876,16 @@ def main():
     fw, fh = layout.film_size
 
     # ---- synthetic inputs, generated in place in HBM (seeded; same generator as the tests)
-    pipe = pipeline.BlockPipeline(layout, dev, types, filter_sd=args.filtersd, radius=r,
-                                  via_host=args.backend == "gloo")
+    # The running moments and the sample arenas come from statmc_malloc_placed (moments in one interference class of the
+    # card's memory, arenas in another: + 6 - 17 % on the accumulation, the same bits); anything that goes wrong there is
+    # reported in the line and the buffers come from torch's allocator instead.
+    PLACED["on"] = bool(args.placement) and not args.share_device
+    try:
+        pipe = pipeline.BlockPipeline(layout, dev, types, filter_sd=args.filtersd, radius=r,
+                                      via_host=args.backend == "gloo", placed=PLACED["on"])
+    except api.StatmcError as e:
+        PLACED.update(on=False, error=str(e)[-300:])
+        pipe = pipeline.BlockPipeline(layout, dev, types, filter_sd=args.filtersd, radius=r, via_host=args.backend == "gloo")
     fs = pipe.fs
     samples, pool = block_samples(args, layout, dev, types, rank, world, share=world if args.share_device else 1)
     batches = synthetic.sample_schedule(S) if args.schedule == "reference" else [S]
@@ -1035,6 +1117,12 @@ def main():
         result = build_result(ctx)
         if eight is not None:
             result["filter_8_feature_channels"] = eight
+        # (before the host-side legs: their page-locked staging buffers and band pipelines keep threads and memory busy)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(args, fs, samples, types)
+            except Exception as e:          # noqa: BLE001
+                result["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
         if world == 1 and not args.no_host_legs:
             # secondary measurements, outside `value`: the reference's own `CUDA time` bracket through the C++ host
             # side, the tile-fed accumulation, and the raw host <-> device copy rates
@@ -1050,11 +1138,6 @@ def main():
             result["host_copies"] = leg(host_copy_times, fs, dev)
             result["filter_8_feature_channels"] = leg(eight_channel_filter, fs, args)
             result["pcie_inclusive"] = leg(pcie_inclusive, fs, samples, types, args)
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                result["cpu_baseline"] = cpu_baseline(args, fs, samples, types)
-            except Exception as e:          # noqa: BLE001
-                result["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
     if run_done is not None:
         run_done.set()
     if world > 1:
@@ -1081,7 +1164,15 @@ def block_samples(args, layout, dev, types, rank, world, share=1):
         fit = int(0.6 * free_b / bytes_per_spp)
         pool = args.spp if fit >= args.spp else max(chunk, fit // chunk * chunk)
     pool = min(pool, args.spp)
-    samples = {t: torch.empty((pool, H, W, synthetic.CHANNELS[t]), dtype=torch.float32, device=dev) for t in types}
+    samples = None
+    if PLACED["on"]:
+        try:
+            samples = {t: new_arena((pool, H, W, synthetic.CHANNELS[t]), dev) for t in types}
+        except Exception as e:      # noqa: BLE001  (placement is an optimisation: report and go on without)
+            PLACED.update(on=False, error="%s: %s" % (type(e).__name__, str(e)[-300:]))
+            samples = None
+    if samples is None:
+        samples = {t: torch.empty((pool, H, W, synthetic.CHANNELS[t]), dtype=torch.float32, device=dev) for t in types}
     for s0 in range(0, pool, chunk):
         part = scene.samples(min(chunk, pool - s0), seed=1000 * (rank + 1) + s0, features=types)
         for t in types:
@@ -1104,6 +1195,24 @@ def read_clock_slots(slots, idx):
     except Exception as e:      # noqa: BLE001
         clocks = {"error": repr(e)[:200]}
     return clocks
+
+
+def placement_report():
+    """Where the timed step's buffers came from (include/statmc.h: statmc_malloc_placed)."""
+    out = {"requested": PLACED["on"] or PLACED["error"] is not None, "error": PLACED["error"]}
+    if PLACED["on"]:
+        try:
+            from statmc_amd import api
+            info = api.placement_info()
+            out.update(active=bool(info["active"]), slots=info["slots"], probes=info["probes"], slots_a=info["slots_a"], slots_b=info["slots_b"],
+                       slots_c=info["slots_c"], slots_unclear=info["slots_unclear"], slots_idle=info["slots_idle"],
+                       slots_as_they_came=info["slots_as_they_came"], probe_ms=[round(info["fast_probe_ms"], 4), round(info["slow_probe_ms"], 4)],
+                       state_GiB=round(info["slab_bytes"][0] / 2 ** 30, 1), stream_GiB=round(info["slab_bytes"][1] / 2 ** 30, 1), map=info["map"],
+                       what="running moments in GiB slots of class A, sample arenas in class B (a stream read beside writes into its own "
+                            "class runs ~ 9 % slower on MI355X; the class belongs to the mapping and is measured per slot, 0.2 ms each)")
+        except Exception as e:      # noqa: BLE001
+            out["info_error"] = repr(e)[:200]
+    return out
 
 
 def build_result(c):
@@ -1243,6 +1352,7 @@ def build_result(c):
         },
         "shader_clock": c["clocks"],
         "kernels": kernels,
+        "placement": placement_report(),
     }
     if world > 1:
         g = c["gather_ms"]

@@ -54,6 +54,7 @@ def lib():
         _lib.oracle_t_quantile.argtypes = [C.c_int, C.c_int]
         _lib.oracle_add_sample.argtypes = [C.c_void_p, C.c_int, f32p, C.c_int, C.c_int]
         _lib.oracle_accumulate_image.argtypes = [C.c_int] * 6 + [f32p, i32p] + [f32p] * 5 + [C.c_int] * 2
+        _lib.oracle_accumulate_tile_stream.argtypes = [C.c_int] * 6 + [f32p, i32p] + [f32p] * 5 + [C.c_int] * 2
         _lib.oracle_merge_tile.argtypes = [C.c_void_p] + [C.c_int] * 6 + [i32p] + [f32p] * 5
         _lib.oracle_mean_vars.argtypes = [C.c_int] * 3 + [i32p, f32p, f32p, C.c_int]
         _lib.oracle_prepass.argtypes = [C.c_int] * 4 + [i32p] + [f32p] * 5
@@ -141,6 +142,30 @@ def accumulate(state, samples, transform, max_moment, tile_size=16, threads=0):
     lib().oracle_accumulate_image(w, h, c, int(transform), int(max_moment), S, _f(samples),
                                   _i(state["n"]), _f(state["mean"]), _f(state["m2"]), _f(state["m3"]),
                                   _f(state["film_mean"]), _f(state["film_m2"]), tile_size, threads)
+    return state
+
+
+def to_tile_major(samples, tile_size=16):
+    """[S, H, W, C] -> flat [tile][pixel][S][C] (tiles and the pixels inside a tile in row-major order): the order
+    StatPathIntegrator::Render produces samples in (statpath.cpp:132,255,294-375)."""
+    S, h, w, c = samples.shape
+    parts = []
+    for y0 in range(0, h, tile_size):
+        for x0 in range(0, w, tile_size):
+            blk = samples[:, y0:y0 + tile_size, x0:x0 + tile_size]          # [S, th, tw, C]
+            parts.append(np.ascontiguousarray(blk.transpose(1, 2, 0, 3)).reshape(-1))
+    return np.concatenate(parts) if parts else np.zeros(0, np.float32)
+
+
+def accumulate_tile_stream(state, samples_tile_major, n_samples, transform, max_moment, tile_size=16, threads=0):
+    """The accumulation fed tile-major, pixel-major samples (to_tile_major): the same bits as accumulate()."""
+    h, w = state["n"].shape
+    c = state["mean"].shape[2] if state["mean"].ndim == 3 else 1
+    smp = np.ascontiguousarray(samples_tile_major, dtype=np.float32)
+    assert smp.size == n_samples * h * w * c
+    lib().oracle_accumulate_tile_stream(w, h, c, int(transform), int(max_moment), int(n_samples), _f(smp),
+                                        _i(state["n"]), _f(state["mean"]), _f(state["m2"]), _f(state["m3"]),
+                                        _f(state["film_mean"]), _f(state["film_m2"]), tile_size, threads)
     return state
 
 

@@ -201,6 +201,73 @@ void oracle_accumulate_image(int width, int height, int channels, int transform,
     }
 }
 
+/* The same accumulation with the samples laid out the way StatPathIntegrator::Render produces them: tile after tile
+ * (statpath.cpp:132, 16 x 16), inside a tile pixel after pixel (statpath.cpp:255), every pixel's samples one after the other
+ * (statpath.cpp:294-375) -- `samples` is [tile][pixel][n_samples][channels], tiles in row-major order over the film, pixels in
+ * row-major order inside the tile (ragged edge tiles hold their own pixel count).  The reference never stores a sample: it
+ * hands each one to AddSample as it is traced, so its per-sample memory traffic is nil; a CPU timing of this path should read
+ * the samples as a stream, which this layout gives, and not with a cache miss per sample, which the film-major planes of
+ * oracle_accumulate_image cost a CPU (one plane of the film between a pixel's consecutive samples).  Same arithmetic, same
+ * order per pixel: the two entry points leave the same bits (tests/test_oracle_cpu.py). */
+void oracle_accumulate_tile_stream(int width, int height, int channels, int transform, int max_moment,
+                                   int n_samples, const float *samples,
+                                   int32_t *n, float *mean, float *m2, float *m3,
+                                   float *film_mean, float *film_m2,
+                                   int tile_size, int threads) {
+    if (tile_size <= 0) tile_size = 16;
+    const int ntx = (width + tile_size - 1) / tile_size;
+    const int nty = (height + tile_size - 1) / tile_size;
+    /* offset of every tile's block, in pixels (x n_samples x channels floats) */
+    size_t *first = (size_t *)malloc(sizeof(size_t) * ((size_t)ntx * nty + 1));
+    first[0] = 0;
+    for (int t = 0; t < ntx * nty; t++) {
+        const int x0 = (t % ntx) * tile_size, y0 = (t / ntx) * tile_size;
+        const int tw = (x0 + tile_size < width ? x0 + tile_size : width) - x0;
+        const int th = (y0 + tile_size < height ? y0 + tile_size : height) - y0;
+        first[t + 1] = first[t] + (size_t)tw * th;
+    }
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+#endif
+    for (int t = 0; t < ntx * nty; t++) {
+        const int x0 = (t % ntx) * tile_size, y0 = (t / ntx) * tile_size;
+        const int x1 = x0 + tile_size < width ? x0 + tile_size : width;
+        const int y1 = y0 + tile_size < height ? y0 + tile_size : height;
+        const int tw = x1 - x0, th = y1 - y0;
+        const size_t psz = channels == 1 ? sizeof(oracle_tile_pixel_f1) : sizeof(oracle_tile_pixel_f3);
+        unsigned char *tile = (unsigned char *)aligned_alloc(64, psz * tw * th);
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                const size_t off = (size_t)y * width + x;
+                void *px = tile + psz * ((size_t)(y - y0) * tw + (x - x0));
+                if (channels == 1) {
+                    oracle_tile_pixel_f1 *p = (oracle_tile_pixel_f1 *)px;
+                    p->n = (uint64_t)n[off];
+                    p->mean = mean[off]; p->m2 = m2[off]; p->m3 = m3[off];
+                    p->film_mean = film_mean[off]; p->film_m2 = film_m2[off];
+                } else {
+                    oracle_tile_pixel_f3 *p = (oracle_tile_pixel_f3 *)px;
+                    p->n = (uint64_t)n[off];
+                    for (int c = 0; c < 3; c++) {
+                        p->mean[c] = mean[3 * off + c]; p->m2[c] = m2[3 * off + c];
+                        p->m3[c] = m3[3 * off + c];
+                        p->film_mean[c] = film_mean[3 * off + c]; p->film_m2[c] = film_m2[3 * off + c];
+                    }
+                }
+            }
+        const float *sp = samples + first[t] * (size_t)n_samples * channels;
+        for (int i = 0; i < tw * th; i++) {
+            void *px = tile + psz * (size_t)i;
+            for (int s = 0; s < n_samples; s++, sp += channels)
+                oracle_add_sample(px, channels, sp, transform, max_moment);
+        }
+        oracle_merge_tile(tile, channels, x0, y0, x1, y1, width, n, mean, m2, m3, film_mean, film_m2);
+        free(tile);
+    }
+    free(first);
+}
+
 /* estimator.cpp:524-568 */
 void oracle_mean_vars(int width, int height, int channels, const int32_t *n,
                       const float *film_m2, float *film_mean_var, int row_n_quirk) {

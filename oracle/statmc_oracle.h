@@ -64,6 +64,12 @@ void oracle_accumulate_image(int width, int height, int channels, int transform,
                              int32_t *n, float *mean, float *m2, float *m3,
                              float *film_mean, float *film_m2,
                              int tile_size, int threads);
+/* the same with samples laid out [tile][pixel][n_samples][channels] (the order Render<T> produces them in) */
+void oracle_accumulate_tile_stream(int width, int height, int channels, int transform, int max_moment,
+                             int n_samples, const float *samples,
+                             int32_t *n, float *mean, float *m2, float *m3,
+                             float *film_mean, float *film_m2,
+                             int tile_size, int threads);
 
 /* a7 alone: scatter one AoS tile (tile pixel bounds [x0,x1) x [y0,y1)) into the images
  * (estimator.cpp:341-352 MergeTile, 376-388 MergeTransformTile).  film_* may be NULL

@@ -54,6 +54,16 @@ class FilterSpec(C.Structure):
         return (self.gate, self.channel_rule, self.sides, self.dof, self.border, self.small_n)
 
 
+class PlacementInfo(C.Structure):
+    _fields_ = [("active", C.c_int32), ("virtual_memory", C.c_int32), ("slots", C.c_int32), ("probes", C.c_int32),
+                ("slots_a", C.c_int32), ("slots_b", C.c_int32), ("slots_c", C.c_int32), ("slots_unclear", C.c_int32), ("slots_idle", C.c_int32),
+                ("slots_as_they_came", C.c_int32 * 2), ("fast_probe_ms", C.c_float), ("slow_probe_ms", C.c_float),
+                ("slab_bytes", C.c_uint64 * 2), ("live_bytes", C.c_uint64 * 2)]
+
+
+MEM_STATE, MEM_STREAM = 0, 1
+
+
 class StatType(C.Structure):
     _fields_ = [
         ("channels", C.c_int32), ("transform", C.c_int32), ("max_moment", C.c_int32),
@@ -67,7 +77,7 @@ EXPORTS = [
     "statmc_last_error", "statmc_setup", "statmc_device_cus", "statmc_set_device", "statmc_set_significance", "statmc_get_significance", "statmc_set_t_quantiles",
     "statmc_set_filter_spec", "statmc_get_filter_spec", "statmc_reset_filter_spec", "statmc_pinned_from", "statmc_copy_device_settings",
     "statmc_set_filter_split", "statmc_get_filter_split", "statmc_filter_split_auto",
-    "statmc_malloc", "statmc_free", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_download",
+    "statmc_malloc", "statmc_free", "statmc_malloc_placed", "statmc_placement_info", "statmc_placement_map", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_download",
     "statmc_stream_create", "statmc_stream_create_with_priority", "statmc_stream_destroy", "statmc_synchronize",
     "statmc_event_create", "statmc_event_destroy", "statmc_event_record", "statmc_stream_wait_event",
     "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs", "statmc_prepass_pack", "statmc_prepass_pack_rows",
@@ -108,6 +118,8 @@ def load():
     lib.statmc_filter_split_auto.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.statmc_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     lib.statmc_free.argtypes = [C.c_void_p]
+    lib.statmc_malloc_placed.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_int]
+    lib.statmc_placement_info.argtypes = [C.POINTER(PlacementInfo)]
     lib.statmc_malloc_host.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     lib.statmc_free_host.argtypes = [C.c_void_p]
     lib.statmc_memset.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
@@ -353,6 +365,55 @@ def filter_f32x3(args):
 
 def filter_f32(args):
     check(load().statmc_filter_f32(C.byref(args)))
+
+
+class _PlacedBlock:
+    """A statmc_malloc_placed block seen by torch through __cuda_array_interface__; freed (statmc_free) when the last
+    tensor that aliases it goes away."""
+
+    def __init__(self, nbytes, role, shape, typestr):
+        p = C.c_void_p()
+        check(load().statmc_malloc_placed(C.byref(p), max(int(nbytes), 1), int(role)))
+        self.ptr = p.value
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (self.ptr, False), "version": 2, "strides": None}
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                load().statmc_free(C.c_void_p(self.ptr))
+        except Exception:      # noqa: BLE001  (interpreter shutdown)
+            pass
+        self.ptr = None
+
+
+def empty_placed(shape, dtype, device, role):
+    """torch tensor on `device` in memory placed by HBM rank (include/statmc.h: statmc_malloc_placed): role MEM_STATE for
+    the images a launch reads and writes (the running moments), MEM_STREAM for read-once sample arenas.  Uninitialised."""
+    import torch
+    typestr = {torch.float32: "<f4", torch.int32: "<i4", torch.uint8: "|u1", torch.int64: "<i8"}[dtype]
+    n = 1
+    for d in shape:
+        n *= int(d)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(idx):
+        blk = _PlacedBlock(n * torch.empty((), dtype=dtype).element_size(), role, shape if n else (0,), typestr)
+        if n == 0:
+            return torch.empty(shape, dtype=dtype, device=device)
+        return torch.as_tensor(blk, device=device)
+
+
+def zeros_placed(shape, dtype, device, role):
+    return empty_placed(shape, dtype, device, role).zero_()
+
+
+def placement_info():
+    info = PlacementInfo()
+    check(load().statmc_placement_info(C.byref(info)))
+    out = {k: (list(getattr(info, k)) if k in ("slots_as_they_came", "slab_bytes", "live_bytes") else getattr(info, k)) for k, _ in PlacementInfo._fields_}
+    buf = C.create_string_buffer(1024)
+    check(load().statmc_placement_map(buf, 1024))
+    out["map"] = buf.value.decode()
+    return out
 
 
 def make_stat_type(samples, state, transform, max_moment):

@@ -63,6 +63,18 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+}  // namespace
+namespace statmc {
+int abi_fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace statmc
+namespace {
+
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \
@@ -142,11 +154,11 @@ int partial_workspace(size_t bytes, void *stream, float **out) {
     if (w.bytes < bytes) {
         if (w.ptr) {
             HIP_TRY(hipStreamSynchronize(S(stream)));  // earlier launches on this stream may still read the old block
-            HIP_TRY(hipFree(w.ptr));
+            HIP_TRY(statmc::workspace_free(w.ptr));
         }
         w.ptr = nullptr;
         w.bytes = 0;
-        HIP_TRY(hipMalloc(&w.ptr, bytes));
+        HIP_TRY(statmc::workspace_alloc(reinterpret_cast<void **>(&w.ptr), bytes));
         w.bytes = bytes;
     }
     *out = w.ptr;
@@ -441,6 +453,7 @@ int statmc_malloc(void **dev_ptr, size_t bytes) {
     return STATMC_OK;
 }
 int statmc_free(void *dev_ptr) {
+    if (dev_ptr && statmc::placement_free(dev_ptr)) return STATMC_OK;   // a statmc_malloc_placed block goes back to its slab
     HIP_TRY(hipFree(dev_ptr));
     return STATMC_OK;
 }
@@ -495,7 +508,7 @@ int statmc_stream_destroy(void *stream) {
             if (it->first.stream == stream && stream != nullptr) {
                 if (it->second.ptr) {
                     (void)hipStreamSynchronize(S(stream));
-                    (void)hipFree(it->second.ptr);
+                    (void)statmc::workspace_free(it->second.ptr);
                 }
                 it = g_ws.erase(it);
             } else {
@@ -1018,11 +1031,11 @@ int dense_arena(DenseArena &w, size_t bytes, void *stream, char **out) {   // ca
     if (w.bytes < bytes) {
         if (w.ptr) {
             HIP_TRY(hipStreamSynchronize(S(stream)));
-            HIP_TRY(hipFree(w.ptr));
+            HIP_TRY(statmc::workspace_free(w.ptr));
         }
         w.ptr = nullptr;
         w.bytes = 0;
-        HIP_TRY(hipMalloc(&w.ptr, bytes));
+        HIP_TRY(statmc::workspace_alloc(reinterpret_cast<void **>(&w.ptr), bytes));
         w.bytes = bytes;
     }
     *out = reinterpret_cast<char *>(w.ptr);
@@ -1035,7 +1048,7 @@ void free_dense_arenas(void *stream) {
                 std::lock_guard<std::mutex> busy(it->second->in_use);   // a call still enqueueing on the stream finishes first
                 if (it->second->ptr) {
                     (void)hipStreamSynchronize(S(stream));
-                    (void)hipFree(it->second->ptr);
+                    (void)statmc::workspace_free(it->second->ptr);
                 }
             }
             it = g_dense.erase(it);
@@ -1381,8 +1394,8 @@ int statmc_debug_force_filter_variant(int v) {  // 0 auto, 1 generic, 2 runtime-
 int statmc_debug_accumulate_resident_blocks(int n) {  // 0 large grid (default), n > 0: n resident workgroups
     STATMC_DEBUG_SET(d.acc_resident_blocks = n < 0 ? 0 : n);
 }
-int statmc_debug_accumulate_dma(int on) {   // 1 (default): RGB sample planes stream through LDS-DMA; 0: loads into registers
-    STATMC_DEBUG_SET(d.acc_dma = on ? 1 : 0);
+int statmc_debug_accumulate_dma(int on) {   // 1 (default): RGB sample planes stream through LDS-DMA; 0: loads into registers; 3 .. 6: that ring depth (experiment builds)
+    STATMC_DEBUG_SET(d.acc_dma = on < 0 ? 1 : on > 6 ? 6 : on == 2 ? 1 : on);
 }
 int statmc_debug_accumulate_launch(int grid_mode, int dma_first) {   // A/B of the film-major launch shape (round 4)
     STATMC_DEBUG_SET(d.acc_grid_mode = grid_mode < 0 ? -1 : grid_mode == 1 ? 1 : 0; d.acc_dma_first = dma_first ? 1 : 0);

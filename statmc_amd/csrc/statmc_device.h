@@ -221,6 +221,11 @@ int sym_diagnostic_bits();   // non-zero: built with a STATMC_SYM_* experiment s
 int acc_diagnostic_bits();   // non-zero: the accumulation was built with a timing-only switch (STATMC_ACC_SKIP_STORES: bit 7)
 hipError_t launch_border_virtual(const FilterArgs &a, hipStream_t s);   // the clamped border's taps beyond the image (RGB)
 int choose_parts(int tiles, int n_rows, int n_cus);
+// statmc_placement.hip (device memory placed by HBM rank)
+int abi_fail(int code, const char *fmt, ...);   // records the calling thread's statmc_last_error() text, returns `code` (statmc_abi.hip)
+bool placement_free(void *ptr);                 // true: `ptr` was a statmc_malloc_placed block and is free now
+hipError_t workspace_alloc(void **p, size_t bytes);   // the library's own read-and-written workspaces: STATE role where the device's caller uses placed memory, hipMalloc otherwise
+hipError_t workspace_free(void *p);
 // parts per tile the LDS kernel would use for this ROI on a device with n_cus compute units
 int lds_filter_parts(const FilterArgs &a, int n_cus);
 

@@ -1,0 +1,473 @@
+// statmc_placement.hip -- device memory dealt by interference class (statmc_malloc_placed, include/statmc.h).
+//
+// What this is for.  accumulate_kernel streams a read-once sample arena (44 B per pixel and sample) and read-modify-writes
+// the running moments (224 B per pixel and launch).  On MI355X the price of those few writes depends on where the two are
+// MAPPED.  Measured with everything carved out of one allocation (tools/experiments/acc_fastslow.py, all stat types):
+//                                                        1080p / 256 spp      4K / 64 spp        1080p / 64 spp
+//     arenas and state in GiB slots of the same class    3.92 ms  0.760       4.67 ms  0.675     1.095 ms  0.720   (of the 8 TB/s HBM peak)
+//     arenas in one class, state in another              3.52 ms  0.846       3.99 ms  0.789     0.947 ms  0.832
+// whichever of the two is where; same kernel, same bits.  What a "class" is (round 5's ledger):
+//   * every GiB of a mapping falls into one of three classes; about a third of the slots each, in runs of 4 .. 64 slots;
+//     a read-only stream runs at the same rate from any of them -- only a stream READ beside WRITES into the same class pays
+//     (9 % for a 25 % share of read-modify-writes: tools/microbench/rank_probe.hip, bimodal with an empty gap);
+//   * the class belongs to the MAPPING, not to the physical memory: the same physical GiB mapped at another address changes
+//     class, four different physical pieces mapped one after the other at one address show the same class (rank_probe mode 2),
+//     and it stays what it is for as long as the mapping lives.  The plausible carrier is the slot's page-directory page
+//     (one 4-KiB page of the driver's per GiB of address space, placed when the slot is first mapped): translation reads
+//     that compete with the write stream inside the DRAM.  Nothing in the HIP API exposes it, so this allocator MEASURES it.
+//
+// How.  One reserved address range per device, cut into GiB slots.  A slot is backed once, by its own 1-GiB physical
+// allocation (hipMemCreate + hipMemMap), and probed IN PLACE against slot 0, which the allocator keeps for itself: the probe
+// kernel streams the slot with non-temporal loads while every fourth step read-modify-writes 16 bytes of slot 0 (0.175 ms
+// against 0.192 ms; a GiB is beyond the 256 MiB Infinity Cache, so the probe reaches the DRAM).  The first slot found apart
+// from slot 0 becomes the second probe target, which tells the other two classes apart.  Slots of slot 0's class (A) hold
+// STATE blocks; STREAM blocks go to ONE of the other classes (B) as long as the card has room: arenas inside one class and
+// state in another measured 0.842 of the HBM peak at 1080p / 256 spp, arenas spread over both other classes 0.818, everything
+// in one class 0.760 (tools/experiments/acc_classes.py, acc_fastslow.py).  A block never spans slots of an unsuitable class, so a
+// 6-GiB arena waits for a run of six suitable slots in a row (the range is extended until there is one, up to 60 % of the
+// card; after that the third class, then both, then anything).  Slots are never unmapped: what no role uses stays mapped and
+// idle (about twice what the arenas take, on a 288 GB card).  No contrast between the probes, no
+// virtual-memory support, too little memory: the call degrades to slots as they come -- placement is an optimisation, never
+// a requirement -- and statmc_placement_info says so.  STATMC_PLACEMENT=0 turns the call into hipMalloc.
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "statmc_device.h"
+
+namespace {
+
+constexpr size_t kSlot = 1ull << 30;          // mapping, physical allocation and probe unit
+constexpr size_t kBlock = 2ull << 20;         // granularity of the blocks handed out
+constexpr size_t kReserveSlots = 640;         // address range per device (more than the card holds)
+constexpr size_t kProbeWindow = 64ull << 20;  // bytes of slot 0 the probe writes
+constexpr int kProbeEvery = 4;                // one 16-byte read-modify-write per this many 16-byte loads
+constexpr float kSameAbove = 1.055f, kApartBelow = 1.035f;   // x the fastest probe (the two levels sit at 1.00 and 1.09)
+constexpr int kCalibrationCap = 96;           // slots probed without seeing both levels: no classes to tell apart here
+
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+typedef unsigned vuint4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void slot_probe_kernel(const vfloat4 *x, vuint4 *ref, size_t n4, size_t window4, float *sink) {
+    vfloat4 acc = {0.f, 0.f, 0.f, 0.f};
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t k = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride, k++) {
+        acc += __builtin_nontemporal_load(x + i);
+        if ((k & (kProbeEvery - 1)) == 0) {
+            const size_t j = (i / kProbeEvery) % window4;
+            vuint4 v = ref[j];
+            v.x += 1u;
+            ref[j] = v;
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x;
+}
+
+enum SlotClass { kUnknown = -1, kClassA = 0, kClassB = 1, kClassC = 2, kMixed = 3, kNotA = 4 };   // A: slot 0's; B: the second target's; kNotA: B or C, not probed against the second target yet
+constexpr int kPrivate = -2;  // Slot::role of the allocator's own slots (probe targets)
+
+struct Slot {
+    hipMemGenericAllocationHandle_t handle;
+    float probe_ms[2] = {0.f, 0.f};   // against slot 0 / against the second target
+    int role = -1;            // -1: not dealt to a role yet; STATMC_MEM_STATE / STATMC_MEM_STREAM: its space belongs to that role's free list
+    bool as_it_came = false;  // dealt to a role without the wanted class
+};
+
+struct Placement {
+    bool init_tried = false, vmm = false, calibrated = false, no_contrast = false;
+    hipMemAllocationProp prop;
+    hipMemAccessDesc access;
+    char *base = nullptr;                    // GiB-aligned start of the slots (inside the reservation)
+    float *sink = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<Slot> slots;                 // slot 0 is the allocator's own (probe target)
+    int target2 = -1;                        // the second probe target: the first slot found apart from slot 0 (private too)
+    size_t total_bytes = 0;                  // of the card
+    float fastest_ms = 0.f, slowest_ms = 0.f;
+    int n_probes = 0;
+    const char *last_note = "-";             // why the last attempt to back a slot ended (diagnostics)
+    std::map<size_t, size_t> free_blocks[2]; // per role: offset from base -> bytes (coalesced; never across slots of another role)
+    std::map<size_t, std::pair<size_t, int>> live;   // offset -> (bytes, role)
+};
+
+std::mutex g_place_mu;
+std::unordered_map<int, Placement> g_place;   // per device
+
+bool placement_disabled() {
+    const char *e = getenv("STATMC_PLACEMENT");
+    return e && e[0] == '0';
+}
+
+int classify(const Placement &P, const Slot &s) {
+    if (P.no_contrast || !P.calibrated || s.probe_ms[0] <= 0.f) return kUnknown;
+    if (s.probe_ms[0] > kSameAbove * P.fastest_ms) return kClassA;
+    if (s.probe_ms[0] >= kApartBelow * P.fastest_ms) return kMixed;
+    if (s.probe_ms[1] <= 0.f) return kNotA;
+    if (s.probe_ms[1] > kSameAbove * P.fastest_ms) return kClassB;
+    if (s.probe_ms[1] < kApartBelow * P.fastest_ms) return kClassC;
+    return kMixed;
+}
+
+hipError_t probe_slot(Placement &P, size_t index, int which = 0) {
+    const char *cand = P.base + index * kSlot;
+    char *target = which == 0 ? P.base : P.base + (size_t)P.target2 * kSlot;
+    float best = 1e30f;
+    hipError_t err = hipSuccess;
+    for (int rep = 0; rep < 6 && err == hipSuccess; rep++) {      // the first one is the warm-up (first touch of the slot)
+        hipEventRecord(P.e0, P.stream);
+        hipLaunchKernelGGL(slot_probe_kernel, dim3(2048), dim3(256), 0, P.stream, reinterpret_cast<const vfloat4 *>(cand),
+                           reinterpret_cast<vuint4 *>(target), kSlot / 16, kProbeWindow / 16, P.sink);
+        hipEventRecord(P.e1, P.stream);
+        err = hipEventSynchronize(P.e1);
+        float ms = 0.f;
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, P.e0, P.e1);
+        if (rep > 0 && ms < best) best = ms;
+    }
+    if (err != hipSuccess) return err;
+    P.slots[index].probe_ms[which] = best;
+    P.n_probes++;
+    if (getenv("STATMC_PLACEMENT_DEBUG")) fprintf(stderr, "statmc placement: slot %zu against target %d: %.4f ms\n", index, which, best);
+    if (P.fastest_ms == 0.f || best < P.fastest_ms) P.fastest_ms = best;
+    if (best > P.slowest_ms) P.slowest_ms = best;
+    return hipSuccess;
+}
+
+// once both levels are known: the first slot apart from slot 0 becomes the second target (the allocator's own, like slot 0),
+// and every other slot apart from slot 0 is probed against it -- B (its class) or C
+hipError_t split_not_a(Placement &P) {
+    if (P.no_contrast || !P.calibrated) return hipSuccess;
+    if (P.target2 < 0) {
+        for (size_t i = 1; i < P.slots.size() && P.target2 < 0; i++)
+            if (P.slots[i].role == -1 && classify(P, P.slots[i]) == kNotA) P.target2 = (int)i;
+        if (P.target2 < 0) return hipSuccess;
+        P.slots[P.target2].role = kPrivate;
+        if (hipError_t e = hipMemsetAsync(P.base + (size_t)P.target2 * kSlot, 0, kProbeWindow, P.stream); e != hipSuccess) return e;
+    }
+    for (size_t i = 1; i < P.slots.size(); i++)
+        if ((int)i != P.target2 && classify(P, P.slots[i]) == kNotA)
+            if (hipError_t e = probe_slot(P, i, 1); e != hipSuccess) return e;
+    return hipSuccess;
+}
+
+// backs the next slot of the range with memory (and probes it, index > 0); false when the card or the range has no room left
+bool back_next_slot(Placement &P, hipError_t *err) {
+    *err = hipSuccess;
+    if (P.slots.size() >= kReserveSlots) {
+        P.last_note = "address range used up";
+        return false;
+    }
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < kSlot + (512ull << 20)) {
+        P.last_note = "less than 1.5 GiB free";
+        return false;
+    }
+    Slot s;
+    if (hipError_t e = hipMemCreate(&s.handle, kSlot, &P.prop, 0); e != hipSuccess) {
+        (void)hipGetLastError();
+        P.last_note = hipGetErrorString(e);
+        return false;
+    }
+    char *at = P.base + P.slots.size() * kSlot;
+    hipError_t e = hipMemMap(at, kSlot, 0, s.handle, 0);
+    if (e == hipSuccess) {
+        e = hipMemSetAccess(at, kSlot, &P.access, 1);
+        if (e != hipSuccess) hipMemUnmap(at, kSlot);
+    }
+    if (e != hipSuccess) {
+        hipMemRelease(s.handle);
+        *err = e;
+        return false;
+    }
+    P.slots.push_back(s);
+    if (P.slots.size() > 1) {
+        hipError_t pe = probe_slot(P, P.slots.size() - 1);
+        if (pe == hipSuccess) pe = split_not_a(P);
+        if (pe != hipSuccess) {
+            *err = pe;          // the slot stays mapped (unprobed = class unknown); the caller reports the error
+            return false;
+        }
+    }
+    return true;
+}
+
+bool init(Placement &P, int dev) {
+    if (P.init_tried) return P.vmm;
+    P.init_tried = true;
+    if (placement_disabled()) return false;
+    int vmm = 0;
+    if (hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, dev) != hipSuccess || !vmm) {
+        (void)hipGetLastError();
+        return false;
+    }
+    memset(&P.prop, 0, sizeof(P.prop));
+    P.prop.type = hipMemAllocationTypePinned;
+    P.prop.location.type = hipMemLocationTypeDevice;
+    P.prop.location.id = dev;
+    memset(&P.access, 0, sizeof(P.access));
+    P.access.location = P.prop.location;
+    P.access.flags = hipMemAccessFlagsProtReadWrite;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 4 * kSlot) return false;
+    P.total_bytes = total_b;
+    char *raw = nullptr;
+    bool ok = hipMemAddressReserve(reinterpret_cast<void **>(&raw), (kReserveSlots + 1) * kSlot, kSlot, nullptr, 0) == hipSuccess;
+    // (the runtime does not honour the alignment asked for: the slots start at the first GiB boundary inside the range)
+    if (ok) P.base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(raw) + kSlot - 1) / kSlot * kSlot);
+    ok = ok && hipMalloc(&P.sink, 64) == hipSuccess && hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreate(&P.e0) == hipSuccess && hipEventCreate(&P.e1) == hipSuccess;
+    hipError_t err = hipSuccess;
+    ok = ok && back_next_slot(P, &err);                  // slot 0: the probe's write target, never handed out
+    if (ok) P.slots[0].role = kPrivate;
+    ok = ok && hipMemsetAsync(P.base, 0, kProbeWindow, P.stream) == hipSuccess && hipStreamSynchronize(P.stream) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        return false;                                    // what was reserved stays reserved: address space, at most one GiB
+    }
+    P.vmm = true;
+    return true;
+}
+
+// Nothing is classified before BOTH levels of the probe have been seen: the classes come in runs of 4 .. 64 slots, so the
+// first dozen slots may well all be of one class -- slot 0's or not -- and one level alone does not say which.  Slots are
+// backed until a probe differs from the fastest by the distance of the two levels; none after kCalibrationCap: no classes to
+// tell apart on this device.
+hipError_t calibrate(Placement &P) {
+    hipError_t err = hipSuccess;
+    while (!P.calibrated) {
+        if (P.n_probes >= 2 && P.slowest_ms > kSameAbove * P.fastest_ms) {
+            P.calibrated = true;
+        } else if (P.n_probes >= kCalibrationCap || !back_next_slot(P, &err)) {
+            P.calibrated = true;
+            P.no_contrast = true;
+        }
+    }
+    if (err == hipSuccess) err = split_not_a(P);
+    return err;
+}
+
+// class masks of the searches a role makes, strongest first
+constexpr unsigned bit(int c) { return 1u << c; }
+constexpr unsigned kAnyClass = ~0u;
+bool suits(const Placement &P, const Slot &s, unsigned mask) {
+    if (s.role != -1) return false;
+    if (P.no_contrast || mask == kAnyClass) return true;
+    const int c = classify(P, s);
+    return c >= 0 && (mask & bit(c));
+}
+
+void add_free(std::map<size_t, size_t> &fl, size_t off, size_t len) {
+    auto next = fl.lower_bound(off);
+    if (next != fl.end() && off + len == next->first) {
+        len += next->second;
+        next = fl.erase(next);
+    }
+    if (next != fl.begin()) {
+        auto prev = std::prev(next);
+        if (prev->first + prev->second == off) {
+            off = prev->first;
+            len += prev->second;
+            fl.erase(prev);
+        }
+    }
+    fl[off] = len;
+}
+
+// deals `count` consecutive undealt slots, starting at slot `first`, to the role's free list
+void deal(Placement &P, int role, size_t first, size_t count, bool wanted_class) {
+    for (size_t i = first; i < first + count; i++) {
+        P.slots[i].role = role;
+        P.slots[i].as_it_came = !wanted_class && !P.no_contrast;
+    }
+    add_free(P.free_blocks[role], first * kSlot, count * kSlot);
+}
+
+// Finds `want_slots` undealt slots of the classes in `mask` in a row and deals them to the role; backs new slots at the end of
+// the range, up to `cap_slots` in all, until there is such a run.  STATMC_ERR_UNSUPPORTED: none (the caller searches weaker).
+int find_run(Placement &P, int role, size_t want_slots, unsigned mask, size_t cap_slots, bool wanted_class) {
+    for (;;) {
+        size_t run = 0;
+        for (size_t i = 1; i < P.slots.size(); i++) {
+            run = suits(P, P.slots[i], mask) ? run + 1 : 0;
+            if (run == want_slots) {
+                deal(P, role, i + 1 - want_slots, want_slots, wanted_class);
+                return STATMC_OK;
+            }
+        }
+        if (P.slots.size() >= cap_slots) return STATMC_ERR_UNSUPPORTED;
+        hipError_t err = hipSuccess;
+        if (!back_next_slot(P, &err)) {
+            if (err != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "placement: %s", hipGetErrorString(err));
+            return STATMC_ERR_UNSUPPORTED;
+        }
+    }
+}
+
+int take_block(Placement &P, int role, size_t need, void **out) {
+    auto &fl = P.free_blocks[role];
+    for (auto it = fl.begin(); it != fl.end(); ++it) {
+        if (it->second < need) continue;
+        const size_t off = it->first, len = it->second;
+        fl.erase(it);
+        if (len > need) fl[off + need] = len - need;
+        P.live[off] = std::make_pair(need, role);
+        *out = P.base + off;
+        return STATMC_OK;
+    }
+    return STATMC_ERR_UNSUPPORTED;
+}
+
+int placed_alloc(Placement &P, int role, size_t bytes, void **out) {
+    const size_t need = (bytes + kBlock - 1) / kBlock * kBlock;
+    if (take_block(P, role, need, out) == STATMC_OK) return STATMC_OK;
+    if (hipError_t e = calibrate(P); e != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "placement probe: %s", hipGetErrorString(e));
+    // whole slots are dealt; the free list joins them with what the role already holds next to them
+    const size_t want_slots = (need + kSlot - 1) / kSlot;
+    const size_t soft_cap = std::min<size_t>(kReserveSlots, (size_t)(0.6 * (double)P.total_bytes / (double)kSlot));
+    struct Search { unsigned mask; size_t cap; bool wanted; };
+    const Search state_order[] = {{bit(kClassA), soft_cap, true}, {bit(kClassA) | bit(kMixed), 0, false}, {kAnyClass, kReserveSlots, false}};
+    const Search stream_order[] = {{bit(kClassB), soft_cap, true},                       // one class for all arenas
+                                   {bit(kClassC), 0, true},                              // ... or the other one
+                                   {bit(kClassB) | bit(kClassC) | bit(kNotA), kReserveSlots, true},   // both (still apart from the state)
+                                   {kAnyClass, kReserveSlots, false}};
+    int rc = STATMC_ERR_UNSUPPORTED;
+    const Search *order = role == STATMC_MEM_STATE ? state_order : stream_order;
+    const int n_order = role == STATMC_MEM_STATE ? 3 : 4;
+    for (int k = 0; k < n_order && rc == STATMC_ERR_UNSUPPORTED; k++) rc = find_run(P, role, want_slots, order[k].mask, order[k].cap, order[k].wanted);
+    if (rc == STATMC_ERR_HIP) return rc;
+    if (rc != STATMC_OK) {
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        return statmc::abi_fail(STATMC_ERR_HIP, "statmc_malloc_placed: out of device memory (%zu slots backed, %d probes %.3f .. %.3f ms, %.1f GiB free, last: %s)",
+                                P.slots.size(), P.n_probes, P.fastest_ms, P.slowest_ms, free_b / 1073741824.0, P.last_note);
+    }
+    if (take_block(P, role, need, out) == STATMC_OK) return STATMC_OK;
+    return statmc::abi_fail(STATMC_ERR_HIP, "statmc_malloc_placed: internal error (no block after dealing %zu slots)", want_slots);
+}
+
+}  // namespace
+
+namespace statmc {
+
+// The library's own workspaces (patch sums of the window filter, packed twins of pitched images) are written and read by
+// every launch: on a device whose caller uses placed memory they live with the STATE role, so that what the filter leaves
+// dirty in the caches is not written back into the class the next accumulation streams its samples from.  Plain hipMalloc
+// where the placed allocator is not in use on the current device.
+hipError_t workspace_alloc(void **p, size_t bytes) {
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lk(g_place_mu);
+        auto it = g_place.find(dev);
+        if (it != g_place.end() && it->second.vmm && it->second.calibrated && !it->second.no_contrast &&
+            placed_alloc(it->second, STATMC_MEM_STATE, bytes ? bytes : 1, p) == STATMC_OK)
+            return hipSuccess;
+    }
+    return hipMalloc(p, bytes);
+}
+hipError_t workspace_free(void *p) {
+    if (p && placement_free(p)) return hipSuccess;
+    return hipFree(p);
+}
+
+// statmc_free's question: is this pointer one of the placed allocator's?  Frees it if so.
+bool placement_free(void *ptr) {
+    std::lock_guard<std::mutex> lk(g_place_mu);
+    for (auto &kv : g_place) {
+        Placement &P = kv.second;
+        if (!P.base || (char *)ptr < P.base || (char *)ptr >= P.base + P.slots.size() * kSlot) continue;
+        auto it = P.live.find((size_t)((char *)ptr - P.base));
+        if (it == P.live.end()) return true;            // inside the range, not a live block: nothing to do (and not hipFree's either)
+        add_free(P.free_blocks[it->second.second], it->first, it->second.first);
+        P.live.erase(it);
+        return true;
+    }
+    return false;
+}
+
+}  // namespace statmc
+
+extern "C" {
+
+int statmc_malloc_placed(void **dev_ptr, size_t bytes, int role) {
+    if (!dev_ptr) return statmc::abi_fail(STATMC_ERR_INVALID, "null dev_ptr");
+    if (role != STATMC_MEM_STATE && role != STATMC_MEM_STREAM) return statmc::abi_fail(STATMC_ERR_INVALID, "role must be STATMC_MEM_STATE or STATMC_MEM_STREAM");
+    if (bytes == 0) bytes = 1;
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lk(g_place_mu);
+    Placement &P = g_place[dev];
+    if (!init(P, dev)) {                                   // no virtual-memory management, too little memory, or switched off
+        void *p = nullptr;
+        if (hipError_t e = hipMalloc(&p, bytes); e != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
+        *dev_ptr = p;
+        return STATMC_OK;
+    }
+    return placed_alloc(P, role, bytes, dev_ptr);
+}
+
+int statmc_placement_info(statmc_placement_info_t *out) {
+    if (!out) return statmc::abi_fail(STATMC_ERR_INVALID, "null out");
+    memset(out, 0, sizeof(*out));
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lk(g_place_mu);
+    auto it = g_place.find(dev);
+    if (it == g_place.end()) return STATMC_OK;
+    const Placement &P = it->second;
+    out->active = P.vmm && P.calibrated && !P.no_contrast ? 1 : 0;
+    out->virtual_memory = P.vmm ? 1 : 0;
+    out->slots = (int)P.slots.size();
+    out->probes = P.n_probes;
+    out->fast_probe_ms = P.fastest_ms;
+    out->slow_probe_ms = P.slowest_ms;
+    for (size_t i = 1; i < P.slots.size(); i++) {
+        const Slot &s = P.slots[i];
+        const int c = classify(P, s);
+        (c == kClassA ? out->slots_a : c == kClassB ? out->slots_b : c == kClassC ? out->slots_c : out->slots_unclear)++;
+        if (s.role == kPrivate) continue;
+        if (s.role == -1) out->slots_idle++;
+        else {
+            out->slab_bytes[s.role] += kSlot;
+            if (s.as_it_came) out->slots_as_they_came[s.role]++;
+        }
+    }
+    for (const auto &kv : P.live) out->live_bytes[kv.second.second] += kv.second.first;
+    return STATMC_OK;
+}
+
+// One character per backed slot: '#' the allocator's own, a / b / c an idle slot of that class, A / B / C one dealt to a role
+// (upper case S / T when it was dealt without the wanted class: S state, T stream), '?' unclear or unprobed.
+int statmc_placement_map(char *out, int capacity) {
+    if (!out || capacity < 1) return statmc::abi_fail(STATMC_ERR_INVALID, "null out");
+    out[0] = 0;
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lk(g_place_mu);
+    auto it = g_place.find(dev);
+    if (it == g_place.end()) return STATMC_OK;
+    const Placement &P = it->second;
+    int n = 0;
+    for (size_t i = 0; i < P.slots.size() && n + 1 < capacity; i++) {
+        const Slot &s = P.slots[i];
+        const int c = classify(P, s);
+        char ch = c == kClassA ? 'a' : c == kClassB ? 'b' : c == kClassC ? 'c' : '?';
+        if (s.role == kPrivate) ch = '#';
+        else if (s.role >= 0 && s.as_it_came) ch = s.role == STATMC_MEM_STATE ? 'S' : 'T';
+        else if (s.role >= 0 && ch != '?') ch = (char)(ch - 'a' + 'A');
+        out[n++] = ch;
+    }
+    out[n] = 0;
+    return STATMC_OK;
+}
+
+}  // extern "C"

@@ -62,13 +62,21 @@
 #ifndef STATMC_ACC_DMA_D
 #define STATMC_ACC_DMA_D 3
 #endif
+#ifndef STATMC_ACC_TILES_DMA_D
+#define STATMC_ACC_TILES_DMA_D 3     // ring depth of the tile-fed kernel
+#endif
+#ifndef STATMC_ACC_DMA_DEPTHS
+#define STATMC_ACC_DMA_DEPTHS 0      // 1 (experiment builds): the film-major kernel at ring depths 3 .. 6, chosen by statmc_debug_accumulate_dma
+#endif
 #include "t_quantiles.h"
 
 namespace statmc {
 
-constexpr int kAccDmaD = STATMC_ACC_DMA_D;                 // sample rows in flight per wave (RGB types)
-constexpr int kAccRingFloats = kAccDmaD * 3 * 256;          // per wave: D rows of 64 lanes x 12 floats
-constexpr size_t kAccLdsBytes = (size_t)4 * kAccRingFloats * sizeof(float);   // four waves per workgroup
+constexpr int kAccDmaD = STATMC_ACC_DMA_D;                 // sample rows in flight per wave (RGB types): the default ring depth
+constexpr int kAccTilesDmaD = STATMC_ACC_TILES_DMA_D;
+constexpr int kAccDmaMaxD = 6;                              // 2 workgroups x 4 waves x D rows x 3 KiB <= 160 KiB of LDS
+constexpr int acc_ring_floats(int d) { return d * 3 * 256; }                                  // per wave: D rows of 64 lanes x 12 floats
+constexpr size_t acc_lds_bytes(int d) { return (size_t)4 * acc_ring_floats(d) * sizeof(float); }   // four waves per workgroup
 template <int N> __device__ __forceinline__ void acc_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Student-t tables, uploaded once by statmc_setup() (hipMemcpyToSymbol).
@@ -379,11 +387,12 @@ __device__ __forceinline__ void add_sample2(PairState *st, const v2f *nf, const 
 // lane fetches belongs to another lane's pixels -- so the whole wave calls in: lane l owns the 4-pixel group at
 // sp_wave + 12 l floats, `active` says whether that group exists, `n_active` (wave-uniform) how many lanes' groups do
 // (they are the first n_active lanes).  Without DMA an inactive lane returns at once.
-template <int C, int MAXM, bool TRANSFORM, int UMUL = 1, bool DMA = false>
+template <int C, int MAXM, bool TRANSFORM, int UMUL = 1, int DMA = 0>
 __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long long p0_in, const float *sp,
                                                 long long stride, int S, float *ring = nullptr, bool active = true, int n_active = 64,
                                                 bool dma_first = false) {
-    constexpr bool kDma = DMA && C == 3;
+    constexpr bool kDma = DMA > 0 && C == 3;
+    constexpr int kD = DMA > 0 ? DMA : 1;               // ring depth: sample rows in flight
     if constexpr (!kDma) {
         if (!active) return;
     }
@@ -412,7 +421,7 @@ __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long lo
         for (int k = 0; k < 3; k++) dma_piece[k] = 256 * k + 4 * lane < row_floats ? 256 * k + 4 * lane : 0;
         if (dma_first) {
 #pragma unroll
-            for (int d = 0; d < kAccDmaD; d++)
+            for (int d = 0; d < kD; d++)
                 if (d < S) dma_issue(d, d);
         }
     }
@@ -518,7 +527,7 @@ __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long lo
     // landed when at most 3 (D - 1) transfers issued after it are outstanding (VMEM operations of a wave complete in
     // order; nothing else touches memory inside the walk).  A slot is refilled once every lane has read its 48 B.
     auto walk_samples_dma = [&](auto same) {
-        constexpr int D = kAccDmaD;
+        constexpr int D = kD;
         const int lane = threadIdx.x & 63;
         auto issue = dma_issue;
         auto take = [&](vfloat4 (&q)[C], int slot) {
@@ -536,24 +545,18 @@ __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long lo
                 if (d < S) issue(d, d);
         }
         const int S_full = S >= D ? S - D + 1 : 0;          // samples s < S_full have D - 1 later rows in flight behind them
-        int s = 0;
-        for (; s + D <= S_full; s += D) {
-#pragma unroll
-            for (int d = 0; d < D; d++) {
-                vfloat4 q[C];
-                acc_wait_vmcnt<3 * (D - 1)>();
-                take(q, d);
-                if (s + d + D < S) issue(s + d + D, d);
-                fold_sample(q, s + d, same);
-            }
-        }
-        for (; s < S; s++) {                                 // the last rows (and batches shorter than the ring)
+        // One row per trip, the slot a run-time index (round 5): unrolled by D with compile-time slots the compiler hoisted the
+        // LDS reads of all D rows to the top of the body -- D x 12 registers, which is what capped the ring at three rows
+        // (240 VGPRs; 5 rows: 256 + AGPR copies, one wave per SIMD).  The body is ~200 instructions; the loop costs nothing.
+        int slot = 0;
+#pragma unroll 1
+        for (int s = 0; s < S; s++) {
             vfloat4 q[C];
-            const int slot = s % D;
-            if (s < S_full) acc_wait_vmcnt<3 * (D - 1)>(); else acc_wait_vmcnt<0>();
+            if (s < S_full) acc_wait_vmcnt<3 * (D - 1)>(); else acc_wait_vmcnt<0>();   // the last D - 1 rows: nothing is issued behind them
             take(q, slot);
             if (s + D < S) issue(s + D, slot);
             fold_sample(q, s, same);
+            slot = slot + 1 == D ? 0 : slot + 1;
         }
     };
     // wave-uniform choice: the fast walk only when every active lane qualifies
@@ -615,7 +618,7 @@ __device__ __forceinline__ void accumulate_pixel(const AccumulateType &t, long l
 
 // Film-major batch: one lane owns 4 consecutive PIXELS of one stat type and walks the batch's
 // samples in order (sample s of pixel p, channel c is at samples[s*n_elems + p*C + c]).
-template <int C, int MAXM, bool TRANSFORM, bool VEC, int UMUL, bool DMA>
+template <int C, int MAXM, bool TRANSFORM, bool VEC, int UMUL, int DMA>
 __device__ __forceinline__ void accumulate_type(const AccumulateType &t, long long blk, long long nblk, float *ring, bool dma_first) {
     const long long n_px = t.n_elems / C;
     const long long n_groups = (n_px + 3) >> 2;
@@ -638,7 +641,7 @@ __device__ __forceinline__ void accumulate_type(const AccumulateType &t, long lo
     }
 }
 
-template <int C, bool VEC, int UMUL, bool DMA>
+template <int C, bool VEC, int UMUL, int DMA>
 __device__ __forceinline__ void accumulate_dispatch(const AccumulateType &t, long long blk, long long nblk, float *ring, bool dma_first) {
     if (t.transform) {
         if (t.max_moment >= 3) accumulate_type<C, 3, true, VEC, UMUL, DMA>(t, blk, nblk, ring, dma_first);
@@ -659,11 +662,11 @@ __device__ __forceinline__ void accumulate_dispatch(const AccumulateType &t, lon
 // running this bandwidth-bound kernel beside the VALU-bound window filter of the previous
 // iteration on a second stream gains <= 15 % (the two contend for VALU issue), so bench.py
 // keeps the kernels back to back.
-template <bool VEC, int UMUL, bool DMA>
+template <bool VEC, int UMUL, int DMA>
 __global__ __launch_bounds__(kBlock, STATMC_ACC_WAVES) void accumulate_kernel(AccumulateArgs a) {
     extern __shared__ __attribute__((aligned(16))) float acc_lds[];
     // the wave's LDS-DMA ring (RGB types, vector path); DMA = false (debug hook, A/B) keeps every type on register loads
-    float *ring = DMA ? acc_lds + (threadIdx.x >> 6) * kAccRingFloats : nullptr;
+    float *ring = DMA ? acc_lds + (threadIdx.x >> 6) * acc_ring_floats(DMA) : nullptr;
     if (a.resident_blocks > 0) {
         for (int i = 0; i < a.n_types; i++) {
             const AccumulateType &t = a.t[(blockIdx.x + i) % a.n_types];
@@ -744,14 +747,23 @@ hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
     for (int i = 0; i < a.n_types; i++) max_s = a.t[i].n_samples > max_s ? a.t[i].n_samples : max_s;
     if (a.grid_mode < 0) a.grid_mode = (max_s <= 8 || (max_s <= 16 && max_groups <= (1 << 20))) ? 1 : 0;
     const dim3 grid(a.resident_blocks > 0 ? a.resident_blocks : a.grid_mode == 1 ? (unsigned)(units * a.n_types) : rounds * a.n_slots);
-    if (vec && a.dma)
-        hipLaunchKernelGGL((accumulate_kernel<true, 1, true>), grid, dim3(kBlock), kAccLdsBytes, s, a);
-    else if (vec && a.umul == 2)
-        hipLaunchKernelGGL((accumulate_kernel<true, 2, false>), grid, dim3(kBlock), 0, s, a);
+    // a.dma: 0 = loads into registers (A/B), 1 = the default ring depth, 3 .. 6 = that depth where the build holds it
+    // (STATMC_ACC_DMA_DEPTHS: experiment builds instantiate every depth, the product build the default one)
+    const int depth = a.dma == 1 ? kAccDmaD : a.dma;
+#define STATMC_LAUNCH_DEPTH(D) \
+    if (vec && depth == D) { hipLaunchKernelGGL((accumulate_kernel<true, 1, D>), grid, dim3(kBlock), acc_lds_bytes(D), s, a); return hipGetLastError(); }
+    STATMC_LAUNCH_DEPTH(kAccDmaD)
+#if STATMC_ACC_DMA_DEPTHS
+    STATMC_LAUNCH_DEPTH(3) STATMC_LAUNCH_DEPTH(4) STATMC_LAUNCH_DEPTH(5) STATMC_LAUNCH_DEPTH(6)
+#endif
+#undef STATMC_LAUNCH_DEPTH
+    if (vec && depth != 0) return hipErrorInvalidValue;      // a ring depth this build does not hold
+    if (vec && a.umul == 2)
+        hipLaunchKernelGGL((accumulate_kernel<true, 2, 0>), grid, dim3(kBlock), 0, s, a);
     else if (vec)
-        hipLaunchKernelGGL((accumulate_kernel<true, 1, false>), grid, dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL((accumulate_kernel<true, 1, 0>), grid, dim3(kBlock), 0, s, a);
     else
-        hipLaunchKernelGGL((accumulate_kernel<false, 1, false>), grid, dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL((accumulate_kernel<false, 1, 0>), grid, dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 
@@ -761,7 +773,7 @@ hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
 // block [S_tile][tile_h][tile_w][C] of a per-type arena, S_tile the same for every pixel of the
 // tile but free to differ between tiles.  One wave per (tile, type): a 16 x 16 tile is exactly
 // 64 lanes x 4 pixels, a sample plane of the block is one contiguous 1 / 3 KiB read of the wave.
-template <int C, int MAXM, bool TRANSFORM, int UMUL, bool DMA>
+template <int C, int MAXM, bool TRANSFORM, int UMUL, int DMA>
 __device__ __forceinline__ void accumulate_tile(const AccumulateType &t, const AccumulateTilesArgs &a, int x0, int y0,
                                                 int tw, int th, long long off, int S, float *ring) {
     const int lane = threadIdx.x & 63;
@@ -791,7 +803,7 @@ __device__ __forceinline__ void accumulate_tile(const AccumulateType &t, const A
     }
 }
 
-template <int C, int UMUL, bool DMA>
+template <int C, int UMUL, int DMA>
 __device__ __forceinline__ void accumulate_tile_dispatch(const AccumulateType &t, const AccumulateTilesArgs &a, int x0,
                                                          int y0, int tw, int th, long long off, int S, float *ring) {
     if (t.transform) {
@@ -805,10 +817,10 @@ __device__ __forceinline__ void accumulate_tile_dispatch(const AccumulateType &t
     }
 }
 
-template <int UMUL, bool DMA>
+template <int UMUL, int DMA>
 __global__ __launch_bounds__(kBlock) void accumulate_tiles_kernel(AccumulateTilesArgs a) {
     extern __shared__ __attribute__((aligned(16))) float acc_lds[];
-    float *ring = DMA ? acc_lds + (threadIdx.x >> 6) * kAccRingFloats : nullptr;
+    float *ring = DMA ? acc_lds + (threadIdx.x >> 6) * acc_ring_floats(DMA) : nullptr;
     const long long n_items = (long long)a.n_tiles * a.n_types;
     const long long n_waves = (long long)gridDim.x * (kBlock / 64);
     // item = (tile, type), types innermost: the waves of a workgroup work on the types of one
@@ -840,10 +852,10 @@ hipError_t launch_accumulate_tiles(const AccumulateTilesArgs &a_in, hipStream_t 
     const long long items = (long long)a.n_tiles * a.n_types;
     const int grid = grid_for(items * 64, 256 * (a.wg_per_cu > 0 ? a.wg_per_cu : 8));  // one wave per item, at most 8 workgroups per CU
     // (the DMA walk needs the vector path: a.vec; the scalar path of unaligned images never touches the ring)
-    if (a.vec && a.dma && a.umul == 2) hipLaunchKernelGGL((accumulate_tiles_kernel<2, true>), dim3(grid), dim3(kBlock), kAccLdsBytes, s, a);
-    else if (a.vec && a.dma) hipLaunchKernelGGL((accumulate_tiles_kernel<1, true>), dim3(grid), dim3(kBlock), kAccLdsBytes, s, a);
-    else if (a.umul == 2) hipLaunchKernelGGL((accumulate_tiles_kernel<2, false>), dim3(grid), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((accumulate_tiles_kernel<1, false>), dim3(grid), dim3(kBlock), 0, s, a);
+    if (a.vec && a.dma && a.umul == 2) hipLaunchKernelGGL((accumulate_tiles_kernel<2, kAccTilesDmaD>), dim3(grid), dim3(kBlock), acc_lds_bytes(kAccTilesDmaD), s, a);
+    else if (a.vec && a.dma) hipLaunchKernelGGL((accumulate_tiles_kernel<1, kAccTilesDmaD>), dim3(grid), dim3(kBlock), acc_lds_bytes(kAccTilesDmaD), s, a);
+    else if (a.umul == 2) hipLaunchKernelGGL((accumulate_tiles_kernel<2, 0>), dim3(grid), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((accumulate_tiles_kernel<1, 0>), dim3(grid), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 

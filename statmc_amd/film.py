@@ -19,9 +19,16 @@ STAT_TYPES = {
 }
 
 
-def new_state(height, width, channels, device, transform=True):
-    z = lambda: torch.zeros(height, width, channels, dtype=torch.float32, device=device)
-    st = dict(n=torch.zeros(height, width, dtype=torch.int32, device=device), mean=z(), m2=z(), m3=z())
+def new_state(height, width, channels, device, transform=True, placed=False):
+    """placed: the images come from statmc_malloc_placed(STATMC_MEM_STATE) -- one HBM rank, apart from the sample arenas
+    (api.empty_placed(..., api.MEM_STREAM)): include/statmc.h, "Device memory placed by HBM rank"."""
+    if placed:
+        z = lambda: api.zeros_placed((height, width, channels), torch.float32, device, api.MEM_STATE)
+        n = api.zeros_placed((height, width), torch.int32, device, api.MEM_STATE)
+    else:
+        z = lambda: torch.zeros(height, width, channels, dtype=torch.float32, device=device)
+        n = torch.zeros(height, width, dtype=torch.int32, device=device)
+    st = dict(n=n, mean=z(), m2=z(), m3=z())
     if transform:
         st["film_mean"], st["film_m2"] = z(), z()
     else:  # non-transform types alias mean/m2 (estimator.cpp:127-137)
@@ -33,16 +40,19 @@ class FilmStats:
     """One GPU's block of the film: per-type running moments and the filter's work images."""
 
     def __init__(self, width, height, device, types=("radiance", "normal", "albedo"),
-                 filter_sd=10.0, radius=20, g_buffers=("normal", "albedo"), g_sds=None):
+                 filter_sd=10.0, radius=20, g_buffers=("normal", "albedo"), g_sds=None, placed=False):
         api.setup(device.index if device.index is not None else 0)
         self.width, self.height, self.device = width, height, device
         self.types = list(types)
+        self.placed = placed
         self.state = {t: new_state(height, width, STAT_TYPES[t]["channels"], device,
-                                   STAT_TYPES[t]["transform"]) for t in self.types}
+                                   STAT_TYPES[t]["transform"], placed=placed) for t in self.types}
         self.filter_sd, self.radius = filter_sd, radius
         self.g_names = list(g_buffers)
         self.g_sds = list(g_sds) if g_sds is not None else [STAT_TYPES[g]["sd"] for g in self.g_names]
-        z3 = lambda: torch.zeros(height, width, 3, dtype=torch.float32, device=device)
+        # the filter's work images are written by one kernel and read by the next: with the moments (placed: state role)
+        z3 = (lambda: api.zeros_placed((height, width, 3), torch.float32, device, api.MEM_STATE)) if placed else \
+             (lambda: torch.zeros(height, width, 3, dtype=torch.float32, device=device))
         self.mean_corr, self.disc, self.film, self.film_f = z3(), z3(), z3(), z3()
 
     def reset(self):

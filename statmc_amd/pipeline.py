@@ -10,13 +10,15 @@ from . import api, film, sharding
 
 class BlockPipeline:
     def __init__(self, layout, device, types, filter_sd=10.0, radius=20, via_host=False, reproducible=False,
-                 g_buffers=("normal", "albedo"), g_sds=None):
-        """reproducible: pin the window-sweep split of this device to the one a single device would choose for the WHOLE
+                 g_buffers=("normal", "albedo"), g_sds=None, placed=False):
+        """placed: the running moments come from statmc_malloc_placed(STATMC_MEM_STATE) (include/statmc.h; the caller
+        allocates its sample arenas with api.empty_placed(..., api.MEM_STREAM)).
+        reproducible: pin the window-sweep split of this device to the one a single device would choose for the WHOLE
         film (statmc_set_filter_split), so that the assembled blocks equal the one-device result bit for bit; default: the
         split fitted to the block (faster on strips, <= 1e-6 from the one-device result)."""
         self.layout, self.device, self.via_host = layout, device, via_host
         self.fs = film.FilmStats(layout.bw, layout.bh, device, types=types, filter_sd=filter_sd, radius=radius,
-                                 g_buffers=g_buffers, g_sds=g_sds)
+                                 g_buffers=g_buffers, g_sds=g_sds, placed=placed)
         self.g_channels = [film.STAT_TYPES[g]["channels"] for g in self.fs.g_names]
         if reproducible:
             fw, fh = layout.film_size

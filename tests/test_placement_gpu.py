@@ -1,0 +1,81 @@
+"""statmc_malloc_placed (include/statmc.h, "Device memory dealt by interference class"): the blocks are ordinary device memory
+-- same bits as torch's allocator through the accumulation and the filter --, free / reuse works, the report is consistent,
+and the switch-off path is plain hipMalloc."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_placed_blocks_are_ordinary_memory(gpu):
+    dev = torch.device("cuda:0")
+    a = gpu.empty_placed((3, 5, 7), torch.float32, dev, gpu.MEM_STATE)
+    b = gpu.empty_placed((1 << 20,), torch.int32, dev, gpu.MEM_STREAM)
+    assert a.data_ptr() % (2 << 20) == 0 and b.data_ptr() % (2 << 20) == 0
+    a.copy_(torch.arange(105, dtype=torch.float32, device=dev).view(3, 5, 7))
+    b.fill_(7)
+    assert float(a.sum().item()) == 105 * 104 / 2 and int(b.sum().item()) == 7 << 20
+    info = gpu.placement_info()
+    assert info["virtual_memory"] == 1 and info["slots"] >= 3
+    assert info["live_bytes"][gpu.MEM_STATE] >= a.numel() * 4 and info["live_bytes"][gpu.MEM_STREAM] >= b.numel() * 4
+    assert len(info["map"]) == info["slots"] and info["map"][0] == "#"
+    if info["active"]:
+        # the state block sits in a slot of class A, the stream block in one of class B (or C)
+        base_state = next(i for i, ch in enumerate(info["map"]) if ch == "A")
+        assert any(ch in "BC" for ch in info["map"]) and base_state >= 1
+        assert info["slow_probe_ms"] > 1.05 * info["fast_probe_ms"]
+    # free -> the space is reused by the next block of the same role
+    p = a.data_ptr()
+    del a
+    a2 = gpu.empty_placed((3, 5, 7), torch.float32, dev, gpu.MEM_STATE)
+    assert a2.data_ptr() == p
+    lib = gpu.load()
+    assert lib.statmc_malloc_placed(None, 16, 0) == gpu.ERR_INVALID
+    q = C.c_void_p()
+    assert lib.statmc_malloc_placed(C.byref(q), 16, 5) == gpu.ERR_INVALID
+
+
+def test_accumulate_and_filter_on_placed_memory_give_the_same_bits(gpu):
+    from statmc_amd import film, synthetic
+    dev = torch.device("cuda:0")
+    W, H, S = 256, 96, 12
+    types = list(synthetic.FEATURES)
+    scene = synthetic.Scene(W, H, seed=3, device=dev)
+    smp = scene.samples(S, seed=11)
+    placed_smp = {t: gpu.empty_placed(tuple(v.shape), torch.float32, dev, gpu.MEM_STREAM) for t, v in smp.items()}
+    for t in types:
+        placed_smp[t].copy_(smp[t])
+    fs_t = film.FilmStats(W, H, dev, types=types, radius=6)
+    fs_p = film.FilmStats(W, H, dev, types=types, radius=6, placed=True)
+    for _ in range(2):
+        fs_t.accumulate(smp)
+        fs_p.accumulate(placed_smp)
+    out_t, out_p = fs_t.denoise().clone(), fs_p.denoise().clone()
+    torch.cuda.synchronize()
+    for t in types:
+        for k, v in fs_t.state[t].items():
+            if v is not None:
+                assert torch.equal(v.view(torch.int32), fs_p.state[t][k].view(torch.int32)), (t, k)
+    assert torch.equal(out_t.view(torch.int32), out_p.view(torch.int32))
+    assert np.isfinite(out_p.cpu().numpy()).all()
+
+
+def test_switch_off_is_plain_hipmalloc():
+    code = ("import torch, sys; sys.path.insert(0, %r)\n"
+            "from statmc_amd import api\n"
+            "api.setup(0)\n"
+            "t = api.zeros_placed((1000,), torch.float32, torch.device('cuda:0'), api.MEM_STATE)\n"
+            "i = api.placement_info()\n"
+            "assert i['virtual_memory'] == 0 and i['slots'] == 0 and i['active'] == 0, i\n"
+            "assert float(t.sum().item()) == 0.0\n"
+            "print('ok')\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, STATMC_PLACEMENT="0"))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-800:]

@@ -6,7 +6,7 @@ NAME=$1; shift
 OUT=$ROOT/tools/experiments/variants
 mkdir -p $OUT/obj_$NAME
 FLAGS="-O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-function ${STATMC_VARIANT_BASE_FLAGS--mllvm -enable-misched=0}"
-for f in statmc_pointwise statmc_filter statmc_filter_sym statmc_abi; do
+for f in statmc_pointwise statmc_filter statmc_filter_sym statmc_placement statmc_abi; do
   hipcc $FLAGS "$@" -c $ROOT/statmc_amd/csrc/$f.hip -o $OUT/obj_$NAME/$f.o &
 done
 wait
