@@ -80,10 +80,17 @@ int statmc_copy_device_settings(int src_device, int dst_device);
  * only the call sites src/statistics/estimator.cpp:437-487 and the buffer meanings README.md:317-325
  * are in the tree).  Every open choice is a field, so that pinning this build to dumps of the CUDA
  * denoiser is a search over specs (tools/fit_spec.py), not a kernel rewrite.  All-zero = this build's
- * default ("spec v2").  Every combination runs on an LDS kernel (an RGB buffer at the
- * shipped radius 20 on the pair-symmetric one: 1.4 - 1.9 ms per 1080p buffer) except Welch degrees of freedom,
- * which take the general kernel (65 ms; same results as the CPU oracle).  `sides` and `small_n` only change
- * the pre-pass. */
+ * default ("spec v2").  `sides` and `small_n` only change the pre-pass.
+ * What serves which spec (statmc_last_filter_variant() names the kernel of the calling thread's last filter call;
+ * times: one 1080p RGB buffer, r = 20):
+ *   every gate x channel rule x border, per-pixel dof, <= 2 RGB + <= 2 one-channel G-buffers   pair-symmetric LDS kernel   1.4 - 1.9 ms
+ *   ... float buffers under the asymmetric / centre gate                                       one-sided LDS kernel        2.1 ms per 3 buffers
+ *   Welch dof (dof = 1), <= 2 RGB G-buffers, any channel rule / border, RGB or float buffers   pair-symmetric Welch build  3.5 ms (1.5 per float buffer)
+ *   Welch dof x a one-channel G-buffer (depth, material id)                                    general kernel ("generic")  ~ 60 ms; on a block +
+ *                                                                                              halo image: STATMC_ERR_UNSUPPORTED
+ *   Welch dof x clamped border on a block + halo image (multi-GPU)                             STATMC_ERR_UNSUPPORTED (one device: Welch build + border kernel)
+ *   radius > 20, more than eight feature channels, G-buffers of other channel counts          general kernel ("generic")
+ * All of them return the CPU oracle's results to <= 1e-5 (tests/test_gpu_parity.py::test_filter_spec_variants_match_oracle). */
 #define STATMC_GATE_SYMMETRIC 0   /* member <=> fma(d, d, -(D_p + D_q)) <= 0, i.e. d^2 <= D_p + D_q        */
 #define STATMC_GATE_ASYMMETRIC 1  /* member <=> fma(d, d, -D_q) <= D_p      (this build's spec v1.x)       */
 #define STATMC_GATE_CENTRE 2      /* member <=> d * d <= D_p: the neighbour's mean inside the CENTRE pixel's confidence interval

@@ -144,7 +144,9 @@ struct WsHash {
     size_t operator()(const WsKey &k) const { return std::hash<void *>()(k.stream) ^ ((size_t)k.dev * 0x9e3779b97f4a7c15ull); }
 };
 std::unordered_map<WsKey, Workspace, WsHash> g_ws;
-void free_dense_arenas(void *stream);   // packed twins of pitched images (below); caller holds g_mu
+struct DenseArena;
+std::vector<std::shared_ptr<DenseArena>> detach_dense_arenas(void *stream);   // packed twins of pitched images (below); caller holds g_mu
+void free_detached_arenas(std::vector<std::shared_ptr<DenseArena>> &arenas, void *stream);   // caller does not
 
 int partial_workspace(size_t bytes, void *stream, float **out) {
     int dev = 0;
@@ -502,6 +504,7 @@ int statmc_stream_create_with_priority(void **stream, int priority_class) {
 }
 int statmc_stream_destroy(void *stream) {
     // the stream's filter workspace goes with it (a later stream may get the same handle)
+    std::vector<std::shared_ptr<DenseArena>> arenas;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         for (auto it = g_ws.begin(); it != g_ws.end();) {
@@ -515,8 +518,9 @@ int statmc_stream_destroy(void *stream) {
                 ++it;
             }
         }
-        free_dense_arenas(stream);
+        arenas = detach_dense_arenas(stream);
     }
+    free_detached_arenas(arenas, stream);
     HIP_TRY(hipStreamDestroy(S(stream)));
     return STATMC_OK;
 }
@@ -1016,15 +1020,19 @@ struct PackedRowsCall {
 struct DenseArena : Workspace {
     std::mutex in_use;
 };
-std::unordered_map<WsKey, std::unique_ptr<DenseArena>, WsHash> g_dense;
+// Held by shared_ptr: a call that has fetched its arena keeps it alive while statmc_stream_destroy drops the table's
+// reference, so a waiter never locks a destroyed mutex.  Lock order: g_mu is never held while in_use is taken
+// -- dense_arena_of releases it before the caller locks in_use, statmc_stream_destroy detaches the stream's arenas under
+// g_mu and frees them after releasing it (the entry points wrapped by with_packed_rows take g_mu under in_use).
+std::unordered_map<WsKey, std::shared_ptr<DenseArena>, WsHash> g_dense;
 
-DenseArena *dense_arena_of(void *stream) {
+std::shared_ptr<DenseArena> dense_arena_of(void *stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(g_mu);
     auto &slot = g_dense[WsKey{dev, stream}];
-    if (!slot) slot.reset(new DenseArena());
-    return slot.get();
+    if (!slot) slot = std::make_shared<DenseArena>();
+    return slot;
 }
 
 int dense_arena(DenseArena &w, size_t bytes, void *stream, char **out) {   // caller holds w.in_use
@@ -1041,21 +1049,31 @@ int dense_arena(DenseArena &w, size_t bytes, void *stream, char **out) {   // ca
     *out = reinterpret_cast<char *>(w.ptr);
     return STATMC_OK;
 }
-void free_dense_arenas(void *stream) {
+// caller holds g_mu: takes the stream's arenas out of the table (nothing is locked or freed here)
+std::vector<std::shared_ptr<DenseArena>> detach_dense_arenas(void *stream) {
+    std::vector<std::shared_ptr<DenseArena>> out;
     for (auto it = g_dense.begin(); it != g_dense.end();) {
         if (it->first.stream == stream && stream != nullptr) {
-            {
-                std::lock_guard<std::mutex> busy(it->second->in_use);   // a call still enqueueing on the stream finishes first
-                if (it->second->ptr) {
-                    (void)hipStreamSynchronize(S(stream));
-                    (void)statmc::workspace_free(it->second->ptr);
-                }
-            }
+            out.push_back(it->second);
             it = g_dense.erase(it);
         } else {
             ++it;
         }
     }
+    return out;
+}
+// caller does NOT hold g_mu
+void free_detached_arenas(std::vector<std::shared_ptr<DenseArena>> &arenas, void *stream) {
+    for (auto &da : arenas) {
+        std::lock_guard<std::mutex> busy(da->in_use);   // a call still enqueueing on the stream finishes first
+        if (da->ptr) {
+            (void)hipStreamSynchronize(S(stream));
+            (void)statmc::workspace_free(da->ptr);
+            da->ptr = nullptr;
+            da->bytes = 0;
+        }
+    }
+    arenas.clear();
 }
 inline bool pitched(const statmc_image &im, int channels) {
     return im.data && im.cols > 0 && im.rows > 0 && im.step > (size_t)im.cols * channels * 4;
@@ -1102,7 +1120,7 @@ int with_packed_rows(const statmc_filter_args *a, int channels, bool writes_stat
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));   // (NEED_READY of the entry point runs inside fn; an arena needs no library state)
     char *arena = nullptr;
-    DenseArena *da = dense_arena_of(a->stream);
+    std::shared_ptr<DenseArena> da = dense_arena_of(a->stream);
     if (!da) return fail(STATMC_ERR_HIP, "no current device");
     std::lock_guard<std::mutex> busy(da->in_use);     // until every copy and kernel of this call has been enqueued
     if (int rc = dense_arena(*da, total, a->stream, &arena)) return rc;

@@ -1,5 +1,6 @@
-// statmc_filter_sym.hip -- the pair-symmetric window filter (gfx950): filter<float3> under every filter spec but Welch
-// degrees of freedom, filter<float> under the default gate and border; radius 20.
+// statmc_filter_sym.hip -- the pair-symmetric window filter (gfx950): filter<float3> under every filter spec (Welch degrees
+// of freedom included, since round 4: the Welch builds), filter<float> two buffers per launch under the symmetric gate (any
+// gate under Welch); compile-time radius 20, runtime radius 1 .. 19; six or eight feature planes (Welch: six).
 //
 // Replaces the window part of cv::cuda::stat_denoiser::filter<float3> / filter<float> (call sites
 // src/statistics/estimator.cpp:465-487 and 437-459 of the reference; CUDA source not in the tree, arithmetic = this
@@ -1446,7 +1447,8 @@ void sym_choose_split(FilterArgs &w, int n_cus) {
     }
 }
 
-// filter<float3> and filter<float> (two buffers per launch), radius 1..20, every spec but Welch degrees of freedom.
+// filter<float3> and filter<float> (two buffers per launch), radius 1..20, every spec: Welch degrees of freedom run the Welch builds
+// (six feature planes: a Welch call with a 1-channel G-buffer is not eligible and takes the general kernel).
 // G-buffers: up to two RGB images (six feature planes, the shipped normal + albedo), or up to two RGB and up to two
 // 1-channel images in any order (eight feature planes: + depth + material id; block + halo calls carry them in a
 // 17-channel packed image)
@@ -1469,7 +1471,9 @@ bool sym_eligible(const FilterArgs &a, int channels) {
         if (!(a.g[g].dr <= 0.f) || !std::isfinite(a.g[g].dr)) return false;
     }
     if (n_rgb > 2 || n_sc > 2) return false;
-    if (a.packed && (n_sc > 0) != (a.packed_ch == 17)) return false;   // 1-channel features travel in the 17-channel block + halo image
+    if (a.packed && n_sc > 0 && a.packed_ch != 17) return false;   // 1-channel features travel in the 17-channel block + halo image
+    // (a 17-channel image with no 1-channel feature -- FilmShards packs every set other than exactly two RGB G-buffers that way --
+    // runs the eight-plane build with its 1-channel slots at scale 0; the pack kernel writes zeros there)
     if (a.dof != STATMC_DOF_PIXEL && n_sc > 0) return false;            // the Welch build has six feature planes
     return true;
 }
@@ -1486,7 +1490,7 @@ void sym_feature_slots(FilterArgs &a) {
         if (a.g[g].channels == 3 && n_rgb < 2) { a.sym.rgb[n_rgb] = a.g[g].data; a.sym.rgb_scale[n_rgb++] = scale; }
         else if (a.g[g].channels == 1 && n_sc < 2) { a.sym.sc[n_sc] = a.g[g].data; a.sym.sc_scale[n_sc++] = scale; }
     }
-    a.sym.g8 = n_sc > 0;
+    a.sym.g8 = n_sc > 0 || (a.packed && a.packed_ch == 17);
 }
 
 hipError_t launch_sym(FilterArgs a, hipStream_t s) {

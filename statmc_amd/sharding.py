@@ -101,10 +101,12 @@ def block_image_channels(g_channels, welch=False):
     1-channel G-buffers (depth, material id), 16 under Welch degrees of freedom (STATMC_DOF_WELCH: + the sample count,
     which the pair test reads; two RGB G-buffers only -- the Welch builds have six feature planes)."""
     if welch:
-        if 1 in g_channels:
+        if list(g_channels) != [3, 3]:
             raise ValueError("Welch degrees of freedom: the block + halo image holds two RGB G-buffers, no 1-channel ones")
         return 16
-    return 17 if 1 in g_channels else 15
+    # exactly two RGB G-buffers: the 15-channel image; every other set of up to two RGB and two 1-channel images: 17 channels,
+    # absent slots zero (what statmc::FilmShards does on the C++ side)
+    return 15 if list(g_channels) == [3, 3] else 17
 
 
 def exchange_halo(layout, padded, group=None, via_host=False):

@@ -794,6 +794,40 @@ def test_filter_eight_feature_channels(gpu, oracle, channels, order, spec_kw, W,
         assert rel_l2(out_g[..., c], ref[..., c]) <= TOL, c
 
 
+@pytest.mark.parametrize("channels", [3, 1])
+def test_filter_welch_with_one_channel_gbuffers_is_served_by_the_general_kernel(gpu, oracle, channels):
+    """Welch degrees of freedom x a 1-channel G-buffer (depth / material id, statpath.cpp:828-835): the pair-symmetric kernel's
+    Welch builds hold six feature planes, so this product runs the general (global-memory) kernel -- correct, ~ 35 x slower --
+    and says so in statmc_last_filter_variant (include/statmc.h lists the product in its table "what serves which spec");
+    on a block + halo image it is refused (sharding.block_image_channels raises; statmc_window_filter: STATMC_ERR_UNSUPPORTED)."""
+    from statmc_amd import sharding
+    feats = ("radiance", "normal", "albedo", "depth", "materialid")
+    _, smp, st = make_case(120, 36, 5, seed=77, features=feats)
+    rad = st["radiance"]
+    pick = (lambda a: a) if channels == 3 else (lambda a: np.ascontiguousarray(a[..., :1]))
+    ospec = oracle.FilterSpec(dof=1)
+    mc, disc = oracle.prepass(rad["n"], pick(rad["mean"]), pick(rad["m2"]), pick(rad["m3"]), spec=ospec)
+    colour = pick(rad["film_mean"])
+    sds = dict(normal=SD_NORMAL, albedo=SD_ALBEDO, depth=2.0, materialid=0.5)
+    order = ("normal", "albedo", "depth")
+    gbs = [st[g]["mean"] for g in order]
+    g_dr = [-0.5 / sds[g] ** 2 for g in order]
+    ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / FILTER_SD ** 2, RADIUS, spec=ospec, n=rad["n"])
+    gpu.set_filter_spec(dof=1)
+    try:
+        out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, FILTER_SD, RADIUS, channels=channels, n=rad["n"])
+        # the same spec with the two RGB G-buffers alone stays on the pair-symmetric kernel
+        _, v6 = run_filter(gpu, mc, disc, colour, gbs[:2], g_dr[:2], FILTER_SD, RADIUS, channels=channels, n=rad["n"])
+    finally:
+        gpu.set_filter_spec()
+    assert v == "generic", v
+    assert v6 == ("sym_welch" if channels == 3 else "sym_welch_f"), v6
+    for c in range(channels):
+        assert rel_l2(out[..., c], ref[..., c]) <= TOL, c
+    with pytest.raises(ValueError):
+        sharding.block_image_channels([3, 3, 1], welch=True)
+
+
 @pytest.mark.parametrize("channels", [1, 3])
 @pytest.mark.parametrize("n_g", [0, 1])
 def test_filter_fewer_gbuffers_on_the_lds_kernel(gpu, oracle, channels, n_g):
