@@ -600,7 +600,10 @@ class Estimator {
             uploadBuffers.push_back(&this->filmBuffer);
             downloadBuffers.push_back(&this->filmFilteredBuffer);
         }
-        if (allocateDevice) stat_denoiser::setup(device);
+        if (allocateDevice) {
+            stat_denoiser::setup(device);
+            deviceCUs = statmc_device_cus();      // of THIS Estimator's device (setup made it current): what the band plan is fitted to
+        }
     }
     Estimator(const Estimator &) = delete;
     Estimator &operator=(const Estimator &) = delete;
@@ -1095,15 +1098,22 @@ class Estimator {
     // where the bands lie (statmc_bands.hpp: automatic = fitted to the window filter's rounds); the same plan serves Upload,
     // Denoise and Download of an iteration because it depends on the image, the radius and the request only
     // (cached: the plan is asked for at every band edge, and building it reads the environment and the device's CU count)
+    // The CU count is the Estimator's own device's, read once in the constructor -- not the calling thread's current device
+    // (a render worker that never called statmc_set_device would plan for the 256-CU default) -- and part of the key; the
+    // cache is guarded: Upload / Denoise / Download may be driven from different host threads.
     const bands::Plan &bandPlan() const {
-        if (planCache.height != height || planCacheKey != std::make_tuple(width, height, (int)filterRadius, bandsRequested)) {
-            planCache = bands::plan(width, height, filterRadius, bandsRequested);
-            planCacheKey = std::make_tuple(width, height, (int)filterRadius, bandsRequested);
+        std::lock_guard<std::mutex> lk(planMutex);
+        const auto key = std::make_tuple(width, height, (int)filterRadius, bandsRequested, deviceCUs);
+        if (planCache.height != height || planCacheKey != key) {
+            planCache = bands::plan(width, height, filterRadius, bandsRequested, deviceCUs);
+            planCacheKey = key;
         }
         return planCache;
     }
     mutable bands::Plan planCache;
-    mutable std::tuple<int, int, int, int> planCacheKey{-1, -1, -1, -1};
+    mutable std::tuple<int, int, int, int, int> planCacheKey{-1, -1, -1, -1, -1};
+    mutable std::mutex planMutex;
+    int deviceCUs = 0;
     int bandEdge(int k, int) const { return bandPlan().edge(k); }
     int arrivalEdge(int k, int) const { return bandPlan().arrival(k); }
     void ensurePipeline(int nb) {

@@ -330,12 +330,14 @@ __device__ __forceinline__ void gate_weight(LaneT &st, const v4f *mcn, const v4f
                 } else if constexpr ((STATMC_SYM_WELCH_ABLATE & 1) != 0) {   // timing only: no gather
                     out[ch] = v2f{(float)dx[ch] * 1e-3f + 9.f, (float)dy[ch] * 1e-3f + 9.f};
                 } else {
-                    // byte offset in the band: one shift-and-add, one minimum.  A dof beyond the band's end reads its last
-                    // entry (and flags the item, below); a dof below its start wraps around to the same place -- that is dof
-                    // 0 next to sample counts > 2, i.e. a NaN nu from 0 / 0, where s = 0 makes the quantile immaterial
-                    // (or, with E_p + E_q denormal, a quotient without a correct digit).
-                    const unsigned bx = min(lshl2_add_u32(dx[ch], tq2.neg4lo), 4u * (unsigned)kWelchBand - 4u);
-                    const unsigned by = min(lshl2_add_u32(dy[ch], tq2.neg4lo), 4u * (unsigned)kWelchBand - 4u);
+                    // byte offset in the band: the table's upper clamp, one shift-and-add, one minimum.  A dof beyond the band's
+                    // end reads its LAST entry (and flags the item, below: the far build computes it again from the whole
+                    // table); a dof below the band's start wraps around (unsigned) and lands on the last entry too -- that is
+                    // dof 0 next to sample counts > 2, i.e. a NaN nu from 0 / 0, where s = 0 makes the quantile immaterial
+                    // (or, with E_p + E_q denormal, a quotient without a correct digit).  The clamp to 4096 comes first
+                    // (ADVICE r4): without it a garbage dof >= 2^30 wrapped in the shift and could land INSIDE the band.
+                    const unsigned bx = min(lshl2_add_u32(min(dx[ch], 4096u), tq2.neg4lo), 4u * (unsigned)kWelchBand - 4u);
+                    const unsigned by = min(lshl2_add_u32(min(dy[ch], 4096u), tq2.neg4lo), 4u * (unsigned)kWelchBand - 4u);
                     out[ch] = v2f{lds_at0(bx), lds_at0(by)};
                 }
             }
@@ -1068,7 +1070,9 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             // item touches (its own rows and the staged ones, rel 0 .. s_b+6) x the staged columns, then kWelchBand entries
             // from (least n) - 2 into LDS.  (The two below the mathematical minimum min(n_p, n_q) - 1 take the computed
             // quotient's last-bit errors; a computed nu below even that -- possible only where E_p + E_q is denormal --
-            // reads the band's first entry.)
+            // wraps around in the unsigned offset and reads the band's last entry, like a dof beyond the band: gate_weight.)
+            // The band is addressed from LDS address 0 (lds_at0): `smem` is the kernel's only LDS allocation, which the
+            // compiler places at 0; the diagnostic builds (STATMC_SYM_STAMPS) check it.
             float *band = smem;
             int *nrange = reinterpret_cast<int *>(band + kWelchBand);   // {least n, item flag}
             if (threadIdx.x == 0) { nrange[0] = 0x7fffffff; nrange[1] = 0; }

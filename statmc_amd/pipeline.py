@@ -13,9 +13,12 @@ class BlockPipeline:
                  g_buffers=("normal", "albedo"), g_sds=None, placed=False):
         """placed: the running moments come from statmc_malloc_placed(STATMC_MEM_STATE) (include/statmc.h; the caller
         allocates its sample arenas with api.empty_placed(..., api.MEM_STREAM)).
-        reproducible: pin the window-sweep split of this device to the one a single device would choose for the WHOLE
-        film (statmc_set_filter_split), so that the assembled blocks equal the one-device result bit for bit; default: the
-        split fitted to the block (faster on strips, <= 1e-6 from the one-device result)."""
+        reproducible: pin the window-sweep split of this device to the uniform split a single device would choose for the
+        WHOLE film (statmc_filter_split_auto -> statmc_set_filter_split), so that the assembled blocks equal the one-device
+        result bit for bit -- PROVIDED the one-device run pins the same split: its automatic choice may add a tail split for
+        tile counts that leave the last round of workgroups mostly empty (1280 x 720: 900 tiles on 256 CUs), which
+        statmc_filter_split_auto does not report (include/statmc.h, "window-sweep split").  Default: the split fitted to the
+        block (faster on strips, <= 1e-6 from the one-device result)."""
         self.layout, self.device, self.via_host = layout, device, via_host
         self.fs = film.FilmStats(layout.bw, layout.bh, device, types=types, filter_sd=filter_sd, radius=radius,
                                  g_buffers=g_buffers, g_sds=g_sds, placed=placed)

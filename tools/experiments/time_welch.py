@@ -1,15 +1,20 @@
 """Welch degrees of freedom on the pair-symmetric kernel at 1080p (round 4): against the default spec on the same film, with
 LDS-DMA staging (width 1920) and with register staging (width 1922: what the Welch build always uses).
-python tools/experiments/time_welch.py"""
+python tools/experiments/time_welch.py [variant.so]     (a variant library: the timing-only ablations STATMC_SYM_WELCH_ABLATE;
+                                                          QUICK=1: the first shape only -- what tools/profile_variants.sh counts)"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from statmc_amd import build
+if len(sys.argv) > 1:
+    os.environ.setdefault("STATMC_ALLOW_DIAGNOSTIC_BUILD", "1")
+    build.SO = os.path.abspath(sys.argv[1])
 import torch
 from statmc_amd import api, film, synthetic
 
 dev = torch.device("cuda:0")
 api.setup(0)
-for W, spp in ((1920, 32), (1922, 32), (1922, 256), (1922, 8)):
+for W, spp in (((1920, 32),) if os.environ.get("QUICK") else ((1920, 32), (1922, 32), (1922, 256), (1922, 8))):
     H = 1080
     scene = synthetic.Scene(W, H, seed=1, device=dev)
     for r, sd in ((20, 10.0), (6, 3.0)):

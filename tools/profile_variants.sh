@@ -13,8 +13,9 @@ for s in time_welch time_float_welch time_g8_radii time_specs; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$s -- python3 $ROOT/tools/experiments/$s.py > $OUT/$s.log 2>&1
   tail -3 $OUT/$s.log
 done
-# instruction counters of the default and the Welch build (one short run each counter set: tools/experiments/time_welch_variant.py)
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_welch -- python3 $ROOT/tools/experiments/time_welch_variant.py > $OUT/pmc_welch.log 2>&1
+# instruction counters of the default and the Welch build (one short run each counter set: QUICK=1 tools/experiments/time_welch.py)
+export QUICK=1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_welch -- python3 $ROOT/tools/experiments/time_welch.py > $OUT/pmc_welch.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
