@@ -940,7 +940,11 @@ def main():
                 timed("prepass", record, pipe.prepass)
                 if world > 1:
                     timed("halo", record, pipe.exchange)
-            block = timed("filter", record, pipe.window_filter)
+            if os.environ.get("STATMC_BENCH_SKIP_FILTER") == "1":      # experiment (tools/experiments: what follows the filter costs the accumulation)
+                block = fs.film_f
+                timed("filter", record, lambda: None)
+            else:
+                block = timed("filter", record, pipe.window_filter)
             if probe is not None:
                 probe("filter")
             if world > 1 and args.gather:

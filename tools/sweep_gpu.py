@@ -13,6 +13,20 @@ from statmc_amd import api, film, synthetic  # noqa: E402
 
 dev = torch.device("cuda:0")
 api.setup(0)
+PLACED = os.environ.get("STATMC_SWEEP_PLACED", "1") != "0"      # moments and arenas from statmc_malloc_placed; 0: torch's allocator
+
+
+def arena_of(chunks, t):
+    """the type's samples of all chunks as one arena (placed: a statmc_malloc_placed stream block)"""
+    if not PLACED:
+        return torch.cat([c[t] for c in chunks])
+    S = sum(c[t].shape[0] for c in chunks)
+    a = api.empty_placed((S,) + tuple(chunks[0][t].shape[1:]), torch.float32, dev, api.MEM_STREAM)
+    pos = 0
+    for c in chunks:
+        a[pos:pos + c[t].shape[0]] = c[t]
+        pos += c[t].shape[0]
+    return a
 
 
 def timeit(fn, n=5):
@@ -36,7 +50,7 @@ def acc_bpp(spp, types):
     return t
 
 
-out = {}
+out = {"placed_buffers": PLACED}
 for name, W, H, spp, types, radius, sd in (
         ("C2_1280x720_64spp_11ch_r20", 1280, 720, 64, synthetic.FEATURES, 20, 10.0),
         ("C3_1920x1080_256spp_9ch_r20", 1920, 1080, 256, ("radiance", "normal", "albedo"), 20, 10.0),
@@ -44,9 +58,9 @@ for name, W, H, spp, types, radius, sd in (
         ("C5_3840x2160_64spp_11ch_r20", 3840, 2160, 64, synthetic.FEATURES, 20, 10.0)):
     sc = synthetic.Scene(W, H, seed=1, device=dev)
     chunks = [sc.samples(min(32, spp - s0), seed=10 + s0, features=types) for s0 in range(0, spp, 32)]
-    smp = {t: torch.cat([c[t] for c in chunks]) for t in types}
+    smp = {t: arena_of(chunks, t) for t in types}
     del chunks
-    fs = film.FilmStats(W, H, dev, types=types, filter_sd=sd, radius=radius)
+    fs = film.FilmStats(W, H, dev, types=types, filter_sd=sd, radius=radius, placed=PLACED)
     t_acc = timeit(lambda: fs.accumulate(smp), 3)
     t_pre = timeit(fs.prepass)
     t_flt = timeit(fs.window_filter, 3)
@@ -85,13 +99,16 @@ for nb, label in ((5, "acrr_filter_f32_5_buffers"), (12, "smis_filter_f32_12_buf
 # samples per iteration): film-major and tile-fed, 1080p and 4K (bench.py's `accumulate_by_batch` leg on two films)
 import bench  # noqa: E402
 bench.torch = torch
+bench.PLACED["on"] = PLACED
 for W, H in ((1920, 1080), (3840, 2160)):
     sc = synthetic.Scene(W, H, seed=1, device=dev)
     chunks = [sc.samples(32, seed=10 + s0, features=synthetic.FEATURES) for s0 in range(0, 64, 32)]
-    smp = {t: torch.cat([c[t] for c in chunks]) for t in synthetic.FEATURES}
+    smp = {t: arena_of(chunks, t) for t in synthetic.FEATURES}
     del chunks
-    fs = film.FilmStats(W, H, dev, types=synthetic.FEATURES)
+    fs = film.FilmStats(W, H, dev, types=synthetic.FEATURES, placed=PLACED)
     out["accumulate_by_batch_%dx%d" % (W, H)] = bench.accumulate_by_batch(fs, smp, list(synthetic.FEATURES))
     del smp, fs, sc
     torch.cuda.empty_cache()
+if PLACED:
+    out["placement"] = api.placement_info()
 print(json.dumps(out, indent=1))
