@@ -7,7 +7,12 @@
 // of the bytes); time per probe, best of 3.  Row k of the output: reference piece r_k (r_0 = piece 0, r_1 = the first piece
 // that ran fast against r_0, r_2 = the first piece fast against both, ...), one character per piece: '=' slow against r_k
 // (same class), '.' fast.
-// hipcc -O3 --offload-arch=gfx950 rank_probe.hip -o rank_probe && ./rank_probe [pieces]
+// Modes (second argument): 0 the class rows above; 1 the same with a copy as the probe (no clean levels); 2 pieces probed through ONE
+// re-used address window, then side by side (+ a third argument: one piece at many addresses); 4 two pieces, addresses only;
+// 5 (unused: 2-MiB tail mappings are refused by hipMemSetAccess); 6 ONE physical GiB mapped at every slot; 7 the decider: one
+// physical GiB mapped at 140 addresses, each mapping made after a fresh physical allocation, against those 140 allocations mapped
+// in one burst -- the class follows the physical memory.
+// hipcc -O3 --offload-arch=gfx950 rank_probe.hip -o rank_probe && ./rank_probe [pieces] [mode]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -63,6 +68,152 @@ int main(int argc, char **argv) {
     if ((size_t)n * GiB > free_b - 4 * GiB) n = (int)((free_b - 4 * GiB) / GiB);
     printf("granularity %zu B, free %.1f GiB, pieces %d\n", gran, free_b / (double)GiB, n);
     const int mode = argc > 2 ? atoi(argv[2]) : 0;
+    if (mode == 7) {
+        // Page tables or data?  Slot i gets a mapping of the ONE physical GiB D, made right after a fresh physical GiB F_i was
+        // created (so that the mappings' page-table pages are placed at different moments of the allocator's life, the data being
+        // the same everywhere); afterwards F_i is mapped at slot N + i (own data, page tables placed in one burst).
+        const int slots = n / 2;
+        char *raw = nullptr;
+        CHK(hipMemAddressReserve((void **)&raw, (size_t)(2 * slots + 3) * GiB, GiB, nullptr, 0));
+        char *va = (char *)(((uintptr_t)raw + GiB - 1) / GiB * GiB);
+        hipMemAccessDesc ad = {};
+        ad.location = prop.location;
+        ad.flags = hipMemAccessFlagsProtReadWrite;
+        hipMemGenericAllocationHandle_t hd, ht;
+        CHK(hipMemCreate(&ht, GiB, &prop, 0));
+        char *target = va + (size_t)(2 * slots + 1) * GiB;
+        CHK(hipMemMap(target, GiB, 0, ht, 0));
+        CHK(hipMemSetAccess(target, GiB, &ad, 1));
+        CHK(hipMemset(target, 0, 64ull << 20));
+        CHK(hipMemCreate(&hd, GiB, &prop, 0));
+        float *out2;
+        CHK(hipMalloc(&out2, 64));
+        hipEvent_t a0, a1;
+        CHK(hipEventCreate(&a0));
+        CHK(hipEventCreate(&a1));
+        auto probe2 = [&](const char *x) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 5; rep++) {
+                CHK(hipEventRecord(a0));
+                hipLaunchKernelGGL(probe, dim3(2048), dim3(256), 0, 0, (const vfloat4 *)x, (vfloat4 *)target, GiB / 16, (64ull << 20) / 16, out2);
+                CHK(hipEventRecord(a1));
+                CHK(hipEventSynchronize(a1));
+                float ms;
+                CHK(hipEventElapsedTime(&ms, a0, a1));
+                if (rep > 0 && ms < best) best = ms;
+            }
+            return best;
+        };
+        std::vector<hipMemGenericAllocationHandle_t> f(slots);
+        for (int i = 0; i < slots; i++) {
+            CHK(hipMemCreate(&f[i], GiB, &prop, 0));
+            CHK(hipMemMap(va + (size_t)i * GiB, GiB, 0, hd, 0));
+            CHK(hipMemSetAccess(va + (size_t)i * GiB, GiB, &ad, 1));
+        }
+        std::vector<float> pd(slots), pf(slots);
+        for (int i = 0; i < slots; i++) pd[i] = probe2(va + (size_t)i * GiB);
+        for (int i = 0; i < slots; i++) {
+            CHK(hipMemMap(va + (size_t)(slots + i) * GiB, GiB, 0, f[i], 0));
+            CHK(hipMemSetAccess(va + (size_t)(slots + i) * GiB, GiB, &ad, 1));
+        }
+        for (int i = 0; i < slots; i++) pf[i] = probe2(va + (size_t)(slots + i) * GiB);
+        printf("slot i = the same physical GiB D, mapped right after physical GiB F_i was created:\n  ");
+        for (int i = 0; i < slots; i++) putchar(pd[i] > 0.185f ? '=' : '.');
+        printf("\nslot N + i = F_i itself, all mapped afterwards in one go:\n  ");
+        for (int i = 0; i < slots; i++) putchar(pf[i] > 0.185f ? '=' : '.');
+        printf("\n");
+        return 0;
+    }
+    if (mode == 6) {
+        // ONE physical GiB (D) mapped at many slots at once: does every mapping have a class of its own?  Does the class of a slot
+        // survive exchanging D for a fresh physical GiB?  Does it change when another mapping is made between unmap and map?
+        const int slots = n, spare = 16;
+        char *raw = nullptr;
+        CHK(hipMemAddressReserve((void **)&raw, (size_t)(slots + spare + 3) * GiB, GiB, nullptr, 0));
+        char *va = (char *)(((uintptr_t)raw + GiB - 1) / GiB * GiB);
+        hipMemAccessDesc ad = {};
+        ad.location = prop.location;
+        ad.flags = hipMemAccessFlagsProtReadWrite;
+        hipMemGenericAllocationHandle_t hd, ht;
+        CHK(hipMemCreate(&hd, GiB, &prop, 0));
+        CHK(hipMemCreate(&ht, GiB, &prop, 0));
+        char *target = va + (size_t)(slots + spare + 1) * GiB;
+        CHK(hipMemMap(target, GiB, 0, ht, 0));
+        CHK(hipMemSetAccess(target, GiB, &ad, 1));
+        CHK(hipMemset(target, 0, 64ull << 20));
+        float *out2;
+        CHK(hipMalloc(&out2, 64));
+        hipEvent_t a0, a1;
+        CHK(hipEventCreate(&a0));
+        CHK(hipEventCreate(&a1));
+        auto probe2 = [&](const char *x) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 5; rep++) {
+                CHK(hipEventRecord(a0));
+                hipLaunchKernelGGL(probe, dim3(2048), dim3(256), 0, 0, (const vfloat4 *)x, (vfloat4 *)target, GiB / 16, (64ull << 20) / 16, out2);
+                CHK(hipEventRecord(a1));
+                CHK(hipEventSynchronize(a1));
+                float ms;
+                CHK(hipEventElapsedTime(&ms, a0, a1));
+                if (rep > 0 && ms < best) best = ms;
+            }
+            return best;
+        };
+        std::vector<float> p1(slots), p1b(slots), p2(slots, 0.f), p3(slots, 0.f);
+        for (int j = 0; j < slots; j++) {
+            hipError_t e = hipMemMap(va + (size_t)j * GiB, GiB, 0, hd, 0);
+            if (e != hipSuccess) { printf("mapping the same allocation a second time: %s (slot %d)\n", hipGetErrorString(e), j); return 0; }
+            CHK(hipMemSetAccess(va + (size_t)j * GiB, GiB, &ad, 1));
+        }
+        for (int j = 0; j < slots; j++) p1[j] = probe2(va + (size_t)j * GiB);
+        for (int j = 0; j < slots; j++) p1b[j] = probe2(va + (size_t)j * GiB);
+        auto show = [&](const char *what, const std::vector<float> &t) {
+            printf("%s\n  ", what);
+            for (int j = 0; j < slots; j++) putchar(t[j] == 0.f ? ' ' : t[j] > 0.185f ? '=' : '.');
+            putchar('\n');
+            fflush(stdout);
+        };
+        show("one physical GiB mapped at every slot:", p1);
+        show("the same again:", p1b);
+        // pick 8 slots of each class for the plain exchange (A) and 8 of each for the exchange with a mapping in between (B)
+        std::vector<int> same, apart;
+        for (int j = 0; j < slots; j++) (p1[j] > 0.185f ? same : apart).push_back(j);
+        printf("%zu slots of the target's class, %zu apart\n", same.size(), apart.size());
+        std::vector<int> setA, setB;
+        for (int k = 0; k < 8; k++) {
+            if (k < (int)same.size()) setA.push_back(same[k]);
+            if (k < (int)apart.size()) setA.push_back(apart[k]);
+            if (k + 8 < (int)same.size()) setB.push_back(same[k + 8]);
+            if (k + 8 < (int)apart.size()) setB.push_back(apart[k + 8]);
+        }
+        for (int j : setA) {
+            hipMemGenericAllocationHandle_t f;
+            CHK(hipMemCreate(&f, GiB, &prop, 0));
+            CHK(hipMemUnmap(va + (size_t)j * GiB, GiB));
+            CHK(hipMemMap(va + (size_t)j * GiB, GiB, 0, f, 0));
+            CHK(hipMemSetAccess(va + (size_t)j * GiB, GiB, &ad, 1));
+            p2[j] = probe2(va + (size_t)j * GiB);
+        }
+        show("A: D exchanged for a fresh physical GiB (unmap, map):", p2);
+        std::vector<float> p4(slots, 0.f);
+        int k = 0;
+        for (int j : setB) {
+            if (k >= spare) break;
+            hipMemGenericAllocationHandle_t f;
+            CHK(hipMemCreate(&f, GiB, &prop, 0));
+            CHK(hipMemUnmap(va + (size_t)j * GiB, GiB));
+            CHK(hipMemMap(va + (size_t)(slots + k) * GiB, GiB, 0, hd, 0));
+            CHK(hipMemSetAccess(va + (size_t)(slots + k) * GiB, GiB, &ad, 1));
+            CHK(hipMemMap(va + (size_t)j * GiB, GiB, 0, f, 0));
+            CHK(hipMemSetAccess(va + (size_t)j * GiB, GiB, &ad, 1));
+            p3[j] = probe2(va + (size_t)j * GiB);
+            p4[j] = probe2(va + (size_t)(slots + k) * GiB);
+            k++;
+        }
+        show("B: the same with ANOTHER mapping made between unmap and map:", p3);
+        show("   ... and the class of that other mapping (shown under the slot):", p4);
+        return 0;
+    }
     if (mode == 5) {
         // Is a slot's class a property of its PAGE-TABLE page?  GiB-aligned slots; every slot keeps a 2-MiB handle mapped at its
         // tail (which keeps the slot's page-directory page alive); ONE probe piece of 1022 MiB visits the slots in turn.
