@@ -31,6 +31,9 @@ int statmc_debug_accumulate_dma(int on);
  * round-robin; 0 = capped grid with slots per type and a grid-stride walk.  dma_first 1 = the first rows of the LDS-DMA
  * ring are requested before the state loads (A/B; default 0). */
 int statmc_debug_accumulate_launch(int grid_mode, int dma_first);
+/* Experiment builds (-DSTATMC_ACC_OCC_AB=1): 3 = the film-major kernel compiled for three waves per SIMD (168 VGPRs; default 2
+ * waves, 202 VGPRs).  Other builds ignore it. */
+int statmc_debug_accumulate_occupancy(int waves_per_simd);
 /* 2: the mean-only feature types of the film-major kernel prefetch twice as deep (default 1). */
 int statmc_debug_accumulate_umul(int umul);
 /* Tile-fed accumulation: prefetch depth of the mean-only types (1 | 2, default 2), item order, workgroups per CU. */

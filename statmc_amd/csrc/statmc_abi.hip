@@ -40,6 +40,7 @@ struct DeviceState {
     // device's dispatch does not reach a second Estimator on another device
     int force_variant = 0;                                    // statmc_debug_force_filter_variant
     int acc_resident_blocks = 0, acc_umul = 1, acc_dma = 1;   // film-major accumulation
+    int acc_occ = 0;                                          // experiment builds: 3 = the accumulate kernel compiled for three waves per SIMD
     int acc_grid_mode = -1, acc_dma_first = 0;                // launch shape: -1 automatic (by batch length), 0 capped grid, 1 one pass per workgroup; A/B: ring rows requested before the state
     int tiles_umul = 2, tiles_order = 0, tiles_wg_per_cu = 0; // tile-fed accumulation (deeper prefetch of the mean-only types by default)
 };
@@ -1288,6 +1289,7 @@ int statmc_accumulate_row_ranges(uint16_t width, uint16_t height, const statmc_s
     k.dma = dstate.acc_dma;
     k.grid_mode = dstate.acc_grid_mode;
     k.dma_first = dstate.acc_dma_first;
+    k.occ = dstate.acc_occ;
     HIP_TRY(statmc::launch_accumulate(k, S(stream)));
     return STATMC_OK;
 }
@@ -1414,6 +1416,9 @@ int statmc_debug_accumulate_resident_blocks(int n) {  // 0 large grid (default),
 }
 int statmc_debug_accumulate_dma(int on) {   // 1 (default): RGB sample planes stream through LDS-DMA; 0: loads into registers; 3 .. 6: that ring depth (experiment builds)
     STATMC_DEBUG_SET(d.acc_dma = on < 0 ? 1 : on > 6 ? 6 : on == 2 ? 1 : on);
+}
+int statmc_debug_accumulate_occupancy(int waves_per_simd) {   // experiment builds (-DSTATMC_ACC_OCC_AB=1): 3 = the 168-VGPR build
+    STATMC_DEBUG_SET(d.acc_occ = waves_per_simd == 3 ? 3 : 0);
 }
 int statmc_debug_accumulate_launch(int grid_mode, int dma_first) {   // A/B of the film-major launch shape (round 4)
     STATMC_DEBUG_SET(d.acc_grid_mode = grid_mode < 0 ? -1 : grid_mode == 1 ? 1 : 0; d.acc_dma_first = dma_first ? 1 : 0);

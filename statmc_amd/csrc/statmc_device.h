@@ -46,6 +46,7 @@ struct AccumulateArgs {
     int dma;              // RGB sample planes arrive by LDS-DMA (default 1; 0: loads into registers, A/B)
     int grid_mode;        // -1: by batch length (default); 0: capped grid, slots per type in proportion to cost, grid-stride; 1: one pass per workgroup, types round-robin
     int dma_first;        // the first rows of the LDS-DMA ring are requested before the state loads
+    int occ;              // experiment builds (STATMC_ACC_OCC_AB): 3 = the build for three waves per SIMD
     // large grid: workgroup b serves slot b % n_slots; slots are dealt to types in proportion to cost
     int n_slots;
     int type_slots[kMaxStatTypes];

@@ -65,6 +65,9 @@
 #ifndef STATMC_ACC_TILES_DMA_D
 #define STATMC_ACC_TILES_DMA_D 3     // ring depth of the tile-fed kernel
 #endif
+#ifndef STATMC_ACC_OCC_AB
+#define STATMC_ACC_OCC_AB 0
+#endif
 #ifndef STATMC_ACC_DMA_DEPTHS
 #define STATMC_ACC_DMA_DEPTHS 0      // 1 (experiment builds): the film-major kernel at ring depths 3 .. 6, chosen by statmc_debug_accumulate_dma
 #endif
@@ -662,8 +665,8 @@ __device__ __forceinline__ void accumulate_dispatch(const AccumulateType &t, lon
 // running this bandwidth-bound kernel beside the VALU-bound window filter of the previous
 // iteration on a second stream gains <= 15 % (the two contend for VALU issue), so bench.py
 // keeps the kernels back to back.
-template <bool VEC, int UMUL, int DMA>
-__global__ __launch_bounds__(kBlock, STATMC_ACC_WAVES) void accumulate_kernel(AccumulateArgs a) {
+template <bool VEC, int UMUL, int DMA, int OCC = STATMC_ACC_WAVES>
+__global__ __launch_bounds__(kBlock, OCC) void accumulate_kernel(AccumulateArgs a) {
     extern __shared__ __attribute__((aligned(16))) float acc_lds[];
     // the wave's LDS-DMA ring (RGB types, vector path); DMA = false (debug hook, A/B) keeps every type on register loads
     float *ring = DMA ? acc_lds + (threadIdx.x >> 6) * acc_ring_floats(DMA) : nullptr;
@@ -752,6 +755,12 @@ hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
     const int depth = a.dma == 1 ? kAccDmaD : a.dma;
 #define STATMC_LAUNCH_DEPTH(D) \
     if (vec && depth == D) { hipLaunchKernelGGL((accumulate_kernel<true, 1, D>), grid, dim3(kBlock), acc_lds_bytes(D), s, a); return hipGetLastError(); }
+#if STATMC_ACC_OCC_AB       // experiment builds: the default depth compiled for three waves per SIMD as well (statmc_debug_accumulate_occupancy)
+    if (vec && depth == kAccDmaD && a.occ == 3) {
+        hipLaunchKernelGGL((accumulate_kernel<true, 1, kAccDmaD, 3>), grid, dim3(kBlock), acc_lds_bytes(kAccDmaD), s, a);
+        return hipGetLastError();
+    }
+#endif
     STATMC_LAUNCH_DEPTH(kAccDmaD)
 #if STATMC_ACC_DMA_DEPTHS
     STATMC_LAUNCH_DEPTH(3) STATMC_LAUNCH_DEPTH(4) STATMC_LAUNCH_DEPTH(5) STATMC_LAUNCH_DEPTH(6)
