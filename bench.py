@@ -1165,7 +1165,8 @@ def block_samples(args, layout, dev, types, rank, world, share=1):
     pool = args.pool_spp
     if pool <= 0:
         free_b = torch.cuda.mem_get_info(dev)[0] // max(1, share - rank if share > 1 else 1)
-        fit = int(0.6 * free_b / bytes_per_spp)
+        # (placed arenas keep slots of the classes they cannot use backed and idle: up to half as much again)
+        fit = int((0.4 if PLACED["on"] else 0.6) * free_b / bytes_per_spp)
         pool = args.spp if fit >= args.spp else max(chunk, fit // chunk * chunk)
     pool = min(pool, args.spp)
     samples = None

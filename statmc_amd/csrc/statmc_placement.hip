@@ -29,7 +29,7 @@
 // state in another measured 0.842 of the HBM peak at 1080p / 256 spp, arenas spread over both other classes 0.818, everything
 // in one class 0.760 (tools/experiments/acc_classes.py, acc_fastslow.py).  A block never spans slots of an unsuitable class, so a
 // 6-GiB arena waits for a run of six suitable slots in a row (the range is extended until there is one, up to 60 % of the
-// card; after that the third class, then both, then anything).  Slots are never unmapped: what no role uses stays mapped and
+// card; after that the third class, then both up to 75 % of the card, then anything).  Slots are never unmapped: what no role uses stays mapped and
 // idle (about twice what the arenas take, on a 288 GB card).  No contrast between the probes, no
 // virtual-memory support, too little memory: the call degrades to slots as they come -- placement is an optimisation, never
 // a requirement -- and statmc_placement_info says so.  STATMC_PLACEMENT=0 turns the call into hipMalloc.
@@ -336,16 +336,20 @@ int placed_alloc(Placement &P, int role, size_t bytes, void **out) {
     if (hipError_t e = calibrate(P); e != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "placement probe: %s", hipGetErrorString(e));
     // whole slots are dealt; the free list joins them with what the role already holds next to them
     const size_t want_slots = (need + kSlot - 1) / kSlot;
-    const size_t soft_cap = std::min<size_t>(kReserveSlots, (size_t)(0.6 * (double)P.total_bytes / (double)kSlot));
+    // how much of the card the search for the right class may back: 60 % for the first choice, 75 % at all (the rest of the
+    // process -- the caller's other allocations, the runtime's -- needs room too; beyond that: what is backed already, any class)
+    const size_t soft_cap = std::min<size_t>(kReserveSlots, (size_t)(0.60 * (double)P.total_bytes / (double)kSlot));
+    const size_t hard_cap = std::min<size_t>(kReserveSlots, (size_t)(0.75 * (double)P.total_bytes / (double)kSlot));
     struct Search { unsigned mask; size_t cap; bool wanted; };
-    const Search state_order[] = {{bit(kClassA), soft_cap, true}, {bit(kClassA) | bit(kMixed), 0, false}, {kAnyClass, kReserveSlots, false}};
+    const Search state_order[] = {{bit(kClassA), soft_cap, true}, {bit(kClassA) | bit(kMixed), 0, false}, {kAnyClass, hard_cap, false},
+                                  {kAnyClass, kReserveSlots, false}};                    // (last resort: until the card is full)
     const Search stream_order[] = {{bit(kClassB), soft_cap, true},                       // one class for all arenas
                                    {bit(kClassC), 0, true},                              // ... or the other one
-                                   {bit(kClassB) | bit(kClassC) | bit(kNotA), kReserveSlots, true},   // both (still apart from the state)
-                                   {kAnyClass, kReserveSlots, false}};
+                                   {bit(kClassB) | bit(kClassC) | bit(kNotA), hard_cap, true},   // both (still apart from the state)
+                                   {kAnyClass, hard_cap, false}, {kAnyClass, kReserveSlots, false}};
     int rc = STATMC_ERR_UNSUPPORTED;
     const Search *order = role == STATMC_MEM_STATE ? state_order : stream_order;
-    const int n_order = role == STATMC_MEM_STATE ? 3 : 4;
+    const int n_order = role == STATMC_MEM_STATE ? 4 : 5;
     for (int k = 0; k < n_order && rc == STATMC_ERR_UNSUPPORTED; k++) rc = find_run(P, role, want_slots, order[k].mask, order[k].cap, order[k].wanted);
     if (rc == STATMC_ERR_HIP) return rc;
     if (rc != STATMC_OK) {
