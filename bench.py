@@ -1399,7 +1399,12 @@ def main_peer(args):
         W, H = args.width // grid[0], args.height // grid[1]
     else:
         W, H = args.width, args.height
-    pf = peer.PeerFilm(n, W, H, r, devices, types, filter_sd=args.filtersd, grid=grid, overlap=args.overlap_halo)
+    PLACED["on"] = bool(args.placement) and not args.share_device      # (blocks that share a device would split its slots between them)
+    try:
+        pf = peer.PeerFilm(n, W, H, r, devices, types, filter_sd=args.filtersd, grid=grid, overlap=args.overlap_halo, placed=PLACED["on"])
+    except api.StatmcError as e:
+        PLACED.update(on=False, error=str(e)[-300:])
+        pf = peer.PeerFilm(n, W, H, r, devices, types, filter_sd=args.filtersd, grid=grid, overlap=args.overlap_halo)
     fw, fh = pf.film_size
     batches = synthetic.sample_schedule(S) if args.schedule == "reference" else [S]
     pools, per_block = [], []

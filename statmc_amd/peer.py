@@ -36,11 +36,12 @@ class _Call:
 class PeerBlock:
     """Block b of the grid, resident on its device: statistics, block + halo image, two streams."""
 
-    def __init__(self, layout, device_index, types, filter_sd, radius, g_buffers=("normal", "albedo"), g_sds=None):
+    def __init__(self, layout, device_index, types, filter_sd, radius, g_buffers=("normal", "albedo"), g_sds=None, placed=False):
         self.layout, self.device_index = layout, int(device_index)
         self.dev = torch.device("cuda", self.device_index)
-        self.fs = film.FilmStats(layout.bw, layout.bh, self.dev, types=types, filter_sd=filter_sd, radius=radius,
-                                 g_buffers=g_buffers, g_sds=g_sds)
+        with torch.cuda.device(self.dev):      # (placed: statmc_malloc_placed acts on the current device)
+            self.fs = film.FilmStats(layout.bw, layout.bh, self.dev, types=types, filter_sd=filter_sd, radius=radius,
+                                     g_buffers=g_buffers, g_sds=g_sds, placed=placed)
         self.g_channels = [film.STAT_TYPES[g]["channels"] for g in self.fs.g_names]
         api.check(api.load().statmc_set_device(self.device_index))
         # (laid out for the device's filter spec at this moment: 16 channels under Welch degrees of freedom)
@@ -73,7 +74,8 @@ class PeerFilm:
     per step: pooled sample slices, the reference's progressive schedule is the caller's loop)."""
 
     def __init__(self, world, block_w, block_h, radius, devices, types, filter_sd=10.0, grid=None, overlap=True,
-                 g_buffers=("normal", "albedo"), g_sds=None):
+                 g_buffers=("normal", "albedo"), g_sds=None, placed=False):
+        """placed: every block's running moments come from statmc_malloc_placed(STATMC_MEM_STATE) on its device."""
         self.lib = api.load()
         self.world, self.radius, self.filter_sd, self.types = world, radius, filter_sd, list(types)
         assert len(devices) == world
@@ -84,7 +86,7 @@ class PeerFilm:
                 if d != devices[0]:
                     api.check(self.lib.statmc_copy_device_settings(devices[0], d))
         self.blocks = [PeerBlock(sharding.BlockLayout(b, world, block_w, block_h, radius, grid=grid), devices[b], types,
-                                 filter_sd, radius, g_buffers=g_buffers, g_sds=g_sds) for b in range(world)]
+                                 filter_sd, radius, g_buffers=g_buffers, g_sds=g_sds, placed=placed) for b in range(world)]
         L0 = self.blocks[0].layout
         self.gx, self.gy, self.bw, self.bh = L0.gx, L0.gy, block_w, block_h
         self.overlap = bool(overlap) and all(len(b.border_rows()) > 0 for b in self.blocks) and world > 1

@@ -84,6 +84,32 @@ def test_tile_order_is_irrelevant(oracle):
     assert all(np.array_equal(a[k], b[k]) for k in a)
 
 
+@pytest.mark.parametrize("channels,transform,max_moment", [(3, True, 3), (1, False, 1), (3, False, 2), (1, True, 3)])
+def test_tile_stream_gives_the_bits_of_the_film_major_entry(oracle, channels, transform, max_moment):
+    """oracle_accumulate_tile_stream (samples laid out [tile][pixel][S][C], the order Render<T> produces them in: what bench.py's
+    cpu_baseline times) == oracle_accumulate_image (film-major planes), bit for bit, ragged edge tiles and a second batch included."""
+    rng = np.random.default_rng(11 + channels + max_moment)
+    for h, w in ((40, 52), (32, 64), (5, 7)):
+        S = 7
+        a, b = oracle.new_state(h, w, channels), oracle.new_state(h, w, channels)
+        for batch in range(2):
+            smp = rng.random((S, h, w, channels), dtype=np.float32) * (1 + batch)
+            oracle.accumulate(a, smp, transform, max_moment)
+            oracle.accumulate_tile_stream(b, oracle.to_tile_major(smp), S, transform, max_moment, threads=1 + batch)
+        for k in a:
+            assert np.array_equal(a[k].view(np.int32), b[k].view(np.int32)), (k, h, w)
+
+
+def test_bench_cpu_share_reads_the_quota():
+    """bench.py's cpu_share(): the affinity mask and, where the cgroup sets one, the CPU quota -- what the CPU baseline sizes its
+    thread count by (a GPU box of the pool: 256 CPUs in the mask, a quota of 16)."""
+    import bench
+    sh = bench.cpu_share()
+    assert sh["affinity_cpus"] == len(os.sched_getaffinity(0)) >= 1
+    assert 1 <= sh["usable_cpus"] <= sh["affinity_cpus"]
+    assert sh["cgroup_quota_cpus"] is None or sh["cgroup_quota_cpus"] > 0
+
+
 def test_merge_tile_layout(oracle):
     """StatTilePixel<Vec3> is 128 B, <float> 64 B (estimator.h:104-124); MergeTile does not
     touch the film images, MergeTransformTile does (estimator.cpp:341-388)."""
