@@ -880,6 +880,9 @@ def main():
     # card's memory, arenas in another: + 6 - 17 % on the accumulation, the same bits); anything that goes wrong there is
     # reported in the line and the buffers come from torch's allocator instead.
     PLACED["on"] = bool(args.placement) and not args.share_device
+    _ballast = None
+    if os.environ.get("STATMC_BENCH_BALLAST_GB"):      # experiment: occupy the first GiB of the card before anything is placed
+        _ballast = torch.empty(int(float(os.environ["STATMC_BENCH_BALLAST_GB"]) * 2 ** 28), dtype=torch.float32, device=dev)
     try:
         pipe = pipeline.BlockPipeline(layout, dev, types, filter_sd=args.filtersd, radius=r,
                                       via_host=args.backend == "gloo", placed=PLACED["on"])

@@ -395,6 +395,13 @@ bool placement_free(void *ptr) {
         if (!P.base || (char *)ptr < P.base || (char *)ptr >= P.base + P.slots.size() * kSlot) continue;
         auto it = P.live.find((size_t)((char *)ptr - P.base));
         if (it == P.live.end()) return true;            // inside the range, not a live block: nothing to do (and not hipFree's either)
+        // like hipFree: work that may still use the block has finished before its memory can be handed out again
+        int cur = 0;
+        if (hipGetDevice(&cur) == hipSuccess) {
+            if (cur != kv.first) (void)hipSetDevice(kv.first);
+            (void)hipDeviceSynchronize();
+            if (cur != kv.first) (void)hipSetDevice(cur);
+        }
         add_free(P.free_blocks[it->second.second], it->first, it->second.first);
         P.live.erase(it);
         return true;
