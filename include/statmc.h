@@ -148,7 +148,7 @@ int statmc_free(void *dev_ptr);   /* blocks of statmc_malloc and of statmc_mallo
  * and a stream that is READ beside WRITES into memory of its own class runs ~ 9 % slower than beside writes into another
  * class (a read-only stream does not care).  With the moments in one class and the
  * sample arenas in the others the 1080p / 256-spp launch of all stat types runs at 0.85 of the HBM peak instead of 0.76
- * (4K / 64 spp: 0.79 instead of 0.68; DESIGN.md section 4.1a, tools/experiments/acc_fastslow.py) -- the same kernel, the
+ * (4K / 64 spp: 0.79 instead of 0.68; DESIGN.md section 4.1a, tools/experiments/acc_pool.py fastslow) -- the same kernel, the
  * same bits.  The class travels with the physical memory and HIP does not expose it, so the allocator MEASURES it: one reserved address range per device, backed GiB by GiB, every GiB probed
  * against two GiB of the allocator's own (0.2 ms each; statmc_amd/csrc/statmc_placement.hip).
  *   role STATMC_MEM_STATE   images a kernel reads AND writes per launch: n, mean, m2, m3, film-mean, film-m2 (class A)

@@ -2,7 +2,7 @@
 //
 // What this is for.  accumulate_kernel streams a read-once sample arena (44 B per pixel and sample) and read-modify-writes
 // the running moments (224 B per pixel and launch).  On MI355X the price of those few writes depends on which memory
-// holds the two.  Measured with everything carved out of one allocation (tools/experiments/acc_fastslow.py, all stat types):
+// holds the two.  Measured with everything carved out of one allocation (tools/experiments/acc_pool.py fastslow, all stat types):
 //                                                        1080p / 256 spp      4K / 64 spp        1080p / 64 spp
 //     arenas and state in GiB slots of the same class    3.92 ms  0.760       4.67 ms  0.675     1.095 ms  0.720   (of the 8 TB/s HBM peak)
 //     arenas in one class, state in another              3.52 ms  0.846       3.99 ms  0.789     0.947 ms  0.832
@@ -27,7 +27,7 @@
 // from slot 0 becomes the second probe target, which tells the other two classes apart.  Slots of slot 0's class (A) hold
 // STATE blocks; STREAM blocks go to ONE of the other classes (B) as long as the card has room: arenas inside one class and
 // state in another measured 0.842 of the HBM peak at 1080p / 256 spp, arenas spread over both other classes 0.818, everything
-// in one class 0.760 (tools/experiments/acc_classes.py, acc_fastslow.py).  A block never spans slots of an unsuitable class, so a
+// in one class 0.760 (tools/experiments/acc_pool.py classes / fastslow).  A block never spans slots of an unsuitable class, so a
 // 6-GiB arena waits for a run of six suitable slots in a row (the range is extended until there is one, up to 60 % of the
 // card; after that the third class, then both up to 75 % of the card, then anything).  Slots are never unmapped: what no role uses stays mapped and
 // idle (about twice what the arenas take, on a 288 GB card).  No contrast between the probes, no

@@ -1,0 +1,128 @@
+"""Round 5: three follow-ups on statmc_malloc_placed (all stat types unless said, 1080p / 256 spp).
+python tools/experiments/acc_placed_more.py MODE
+  block   the five arenas carved out of ONE placed block against five placed blocks against torch's allocator: contiguity of
+          the arenas is not a factor                                                    (profiles/r05_acc_placed2.log)
+  pairs   one stat type, eight placed arenas x three placed states, every pair: 6.75 .. 6.79 TB/s -- "apart" is uniform
+                                                                                        (profiles/r05_acc_placed3.log)
+  where   a state allocated before the arenas, one after, one in another slot, one in torch's memory (ORDER=arenas-first for
+          the other order): where in the state role the moments sit does not matter     (profiles/r05_acc_placed4.log)"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from statmc_amd import api, film, synthetic
+
+dev = torch.device("cuda:0")
+api.setup(0)
+types = list(synthetic.FEATURES)
+MODE = sys.argv[1] if len(sys.argv) > 1 else "block"
+W, H, S = 1920, 1080, 256
+
+
+def bpp(S):
+    t = 0
+    for x in types:
+        c = film.STAT_TYPES[x]
+        planes = c["max_moment"] + (2 if c["transform"] else 0)
+        t += 4 * c["channels"] * S + 2 * (4 + 4 * c["channels"] * planes)
+    return t
+
+
+def timed(fs, a, reps=8):
+    fs.accumulate(a)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fs.accumulate(a)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / reps)
+    return best
+
+
+if MODE == "block":
+    fs = film.FilmStats(W, H, dev, types=types, placed=True)
+    n_el = {t: S * H * W * synthetic.CHANNELS[t] for t in types}
+    big = api.empty_placed((sum(n_el.values()),), torch.float32, dev, api.MEM_STREAM)
+    one, pos = {}, 0
+    for t in types:
+        one[t] = big[pos:pos + n_el[t]].view(S, H, W, synthetic.CHANNELS[t])
+        pos += n_el[t]
+        for s0 in range(0, S, 16):
+            one[t][s0:s0 + 16].uniform_()
+    print("map after the one block:   ", api.placement_info()["map"], flush=True)
+    five = {t: api.empty_placed((S, H, W, synthetic.CHANNELS[t]), torch.float32, dev, api.MEM_STREAM) for t in types}
+    for t in types:
+        five[t].copy_(one[t])
+    print("map after five more blocks:", api.placement_info()["map"], flush=True)
+    plain = {t: one[t].clone() for t in types}
+    fs_t = film.FilmStats(W, H, dev, types=types)
+    for rnd in range(2):
+        for name, f, a in (("arenas in one placed block", fs, one), ("five placed blocks", fs, five), ("torch arenas, placed state", fs, plain), ("torch arenas, torch state", fs_t, plain),
+                           ("placed block, torch state", fs_t, one)):
+            ms = timed(f, a)
+            print("%-28s %.3f ms  %.3f of 8 TB/s" % (name, ms, bpp(S) * W * H / ms / 8e9), flush=True)
+
+if MODE == "pairs":
+    W, H, S = 1920, 1080, 256
+    states, spacers = [], []
+    for k in range(3):
+        states.append(film.FilmStats(W, H, dev, types=["normal"], placed=True))
+        spacers.append(api.empty_placed((900 << 18,), torch.float32, dev, api.MEM_STATE))      # 900 MiB: the next state starts in another slot
+    arenas = []
+    for k in range(8):
+        a = api.empty_placed((S, H, W, 3), torch.float32, dev, api.MEM_STREAM)
+        for s0 in range(0, S, 32):
+            a[s0:s0 + 32].uniform_()
+        arenas.append(a)
+    info = api.placement_info()
+    base = None
+    print("map:", info["map"], flush=True)
+    print("state blocks at (GiB from the first):", [round((st.state["normal"]["mean"].data_ptr() - states[0].state["normal"]["mean"].data_ptr()) / 2 ** 30, 2) for st in states])
+    print("arena blocks at (GiB from the first state):", [round((a.data_ptr() - states[0].state["normal"]["mean"].data_ptr()) / 2 ** 30, 2) for a in arenas], flush=True)
+    for rnd in range(2):
+        for si, st in enumerate(states):
+            row = []
+            for a in arenas:
+                smp = {"normal": a}
+                st.accumulate(smp)
+                torch.cuda.synchronize()
+                best = 1e9
+                for _ in range(3):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(6):
+                        st.accumulate(smp)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    best = min(best, e0.elapsed_time(e1) / 6)
+                row.append("%.2f" % (12 * S * W * H / best / 1e9))
+            print("state %d: TB/s per arena: %s" % (si, " ".join(row)), flush=True)
+
+if MODE == "where":
+    order = os.environ.get("ORDER", "state-first")
+    states = {}
+    if order == "state-first":
+        states["state before the arenas"] = film.FilmStats(W, H, dev, types=types, placed=True)
+    arenas = {t: api.empty_placed((S, H, W, synthetic.CHANNELS[t]), torch.float32, dev, api.MEM_STREAM) for t in types}
+    for t in types:
+        for s0 in range(0, S, 16):
+            arenas[t][s0:s0 + 16].uniform_()
+    states["state after the arenas"] = film.FilmStats(W, H, dev, types=types, placed=True)
+    spacer = api.empty_placed((1 << 28,), torch.float32, dev, api.MEM_STATE)          # 1 GiB: the next state lies in another slot
+    states["state in another slot"] = film.FilmStats(W, H, dev, types=types, placed=True)
+    states["state in torch's memory"] = film.FilmStats(W, H, dev, types=types)
+    info = api.placement_info()
+    print("order:", order, " map:", info["map"], flush=True)
+    base = min(a.data_ptr() for a in arenas.values())
+    p0 = None
+    for name, fs in states.items():
+        ptr = fs.state["radiance"]["n"].data_ptr()
+        print("%-28s radiance n at %+8.3f GiB from the first arena" % (name, (ptr - base) / 2 ** 30), flush=True)
+    for rnd in range(2):
+        for name, fs in states.items():
+            ms = timed(fs, arenas)
+            print("%-28s %.3f ms  %.3f of 8 TB/s" % (name, ms, bpp(S) * W * H / ms / 8e9), flush=True)

@@ -1,5 +1,5 @@
 // Round 5: which physical 1-GiB pieces of the card interfere with each other when one is READ as a stream and the other is
-// WRITTEN beside it?  (tools/experiments/acc_fastslow.py: the accumulation runs 12 - 17 % faster when the sample arenas and
+// WRITTEN beside it?  (tools/experiments/acc_pool.py fastslow: the accumulation runs 12 - 17 % faster when the sample arenas and
 // the read-modify-write state lie in regions of different "class" -- whatever a class is physically; same class or not is
 // what this program maps.)
 // N physical allocations of 1 GiB (hipMemCreate) are mapped side by side into one reserved range.  probe(x, r) streams piece x
