@@ -9,6 +9,7 @@
 
 #include "statmc.h"
 
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -38,6 +39,11 @@ int statmc_debug_accumulate_occupancy(int waves_per_simd);
 int statmc_debug_accumulate_umul(int umul);
 /* Tile-fed accumulation: prefetch depth of the mean-only types (1 | 2, default 2), item order, workgroups per CU. */
 int statmc_debug_accumulate_tiles_variant(int umul, int order, int wg_per_cu);
+
+/* The placed allocator's probe (statmc_amd/csrc/statmc_placement.hip) on memory of the caller's: streams [stream_ptr, + stream_bytes)
+ * while every fourth step read-modify-writes 16 bytes inside [rmw_ptr, + rmw_bytes) -- the words there change.  Best of five, ms.
+ * Two buffers in the same interference class: ~ 9 % slower than two in different ones (1-GiB stream, 64-MiB window). */
+int statmc_debug_interference_probe(const void *stream_ptr, size_t stream_bytes, void *rmw_ptr, size_t rmw_bytes, float *ms);
 
 /* Non-zero: the library was built with a timing-only / diagnostic switch (statmc_sym_experiments.h); its results are
  * not the product's and statmc_amd.api refuses to load it. */

@@ -460,6 +460,36 @@ int statmc_placement_info(statmc_placement_info_t *out) {
     return STATMC_OK;
 }
 
+// Test / experiment hook (include/statmc_debug.h): the allocator's probe on memory of the caller's -- streams `stream_bytes` at
+// `stream_ptr` while every fourth step read-modify-writes 16 bytes inside [rmw_ptr, rmw_ptr + rmw_bytes) (their values change: + 1 in
+// every fourth word).  Best of five in *ms.
+int statmc_debug_interference_probe(const void *stream_ptr, size_t stream_bytes, void *rmw_ptr, size_t rmw_bytes, float *ms) {
+    if (!stream_ptr || !rmw_ptr || !ms || stream_bytes < (1u << 20) || rmw_bytes < (1u << 20) || (stream_bytes | rmw_bytes) % 16)
+        return statmc::abi_fail(STATMC_ERR_INVALID, "statmc_debug_interference_probe: two buffers of at least 1 MiB, sizes multiples of 16");
+    float *sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t err = hipMalloc(&sink, 64);
+    if (err == hipSuccess) err = hipEventCreate(&e0);
+    if (err == hipSuccess) err = hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 6 && err == hipSuccess; rep++) {
+        hipEventRecord(e0, nullptr);
+        hipLaunchKernelGGL(slot_probe_kernel, dim3(2048), dim3(256), 0, nullptr, static_cast<const vfloat4 *>(stream_ptr), static_cast<vuint4 *>(rmw_ptr),
+                           stream_bytes / 16, rmw_bytes / 16, sink);
+        hipEventRecord(e1, nullptr);
+        err = hipEventSynchronize(e1);
+        float t = 0.f;
+        if (err == hipSuccess) err = hipEventElapsedTime(&t, e0, e1);
+        if (rep > 0 && t < best) best = t;
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (sink) hipFree(sink);
+    if (err != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "interference probe: %s", hipGetErrorString(err));
+    *ms = best;
+    return STATMC_OK;
+}
+
 // One character per backed slot: '#' the allocator's own, a / b / c an idle slot of that class, A / B / C one dealt to a role
 // (upper case S / T when it was dealt without the wanted class: S state, T stream), '?' unclear or unprobed.
 int statmc_placement_map(char *out, int capacity) {

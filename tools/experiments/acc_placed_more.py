@@ -5,7 +5,9 @@ python tools/experiments/acc_placed_more.py MODE
   pairs   one stat type, eight placed arenas x three placed states, every pair: 6.75 .. 6.79 TB/s -- "apart" is uniform
                                                                                         (profiles/r05_acc_placed3.log)
   where   a state allocated before the arenas, one after, one in another slot, one in torch's memory (ORDER=arenas-first for
-          the other order): where in the state role the moments sit does not matter     (profiles/r05_acc_placed4.log)"""
+          the other order): where in the state role the moments sit does not matter     (profiles/r05_acc_placed4.log)
+  ranks   the allocator's probe (statmc_debug_interference_probe) on every GiB of every arena against the state and against every
+          arena: all apart from the state, all in one class among themselves            (profiles/r05_acc_ranks.log)"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -126,3 +128,35 @@ if MODE == "where":
         for name, fs in states.items():
             ms = timed(fs, arenas)
             print("%-28s %.3f ms  %.3f of 8 TB/s" % (name, ms, bpp(S) * W * H / ms / 8e9), flush=True)
+
+if MODE == "ranks":
+    # Are the arenas of a placed launch in ONE class among themselves?  The allocator's probe on every GiB of every arena against the
+    # first 64 MiB of every arena (and of the state): '=' same class, '.' apart.  (The probed words change: run this last.)
+    import ctypes as C
+    lib = api.load()
+    lib.statmc_debug_interference_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_float)]
+    fs = film.FilmStats(W, H, dev, types=types, placed=os.environ.get("ORDER") != "arenas-first")
+    arenas = {t: api.empty_placed((S, H, W, synthetic.CHANNELS[t]), torch.float32, dev, api.MEM_STREAM) for t in types}
+    for t in types:
+        for s0 in range(0, S, 16):
+            arenas[t][s0:s0 + 16].uniform_()
+    if os.environ.get("ORDER") == "arenas-first":
+        fs = film.FilmStats(W, H, dev, types=types, placed=True)
+    ms = timed(fs, arenas)
+    print("map:", api.placement_info()["map"])
+    print("the launch: %.3f ms  %.3f of 8 TB/s" % (ms, bpp(S) * W * H / ms / 8e9), flush=True)
+    GiB = 1 << 30
+    targets = [("state", fs.state["radiance"]["mean"].data_ptr())] + [(t, arenas[t].data_ptr()) for t in types]
+    for t in types:
+        n_gib = arenas[t].numel() * 4 // GiB
+        for g in range(max(n_gib, 1)):
+            row = []
+            for name, ptr in targets:
+                out = C.c_float()
+                nbytes = min(GiB, arenas[t].numel() * 4 - g * GiB) // 16 * 16
+                if name == t and g == 0:
+                    row.append("  #  ")
+                    continue
+                api.check(lib.statmc_debug_interference_probe(C.c_void_p(arenas[t].data_ptr() + g * GiB), nbytes, C.c_void_p(ptr), 64 << 20, C.byref(out)))
+                row.append("%.3f" % (out.value * GiB / nbytes))
+            print("%-10s GiB %d against the first 64 MiB of [%s]: %s" % (t, g, " ".join(n for n, _ in targets), " ".join(row)), flush=True)
