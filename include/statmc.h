@@ -174,8 +174,13 @@ typedef struct statmc_placement_info_t {
     uint64_t slab_bytes[2], live_bytes[2];   /* per role: bytes of the slots dealt to it / bytes in live blocks */
 } statmc_placement_info_t;
 int statmc_placement_info(statmc_placement_info_t *out);   /* current device */
-/* One character per backed GiB slot of the current device, NUL-terminated: '#' the allocator's own, a / b / c an idle slot of
- * that class, A / B / C one dealt to a role, S / T one dealt to the state / stream role without the wanted class, '?' unclear. */
+/* Gives the memory of the idle slots of the current device (backed and probed, dealt to no role: the classes nobody asked for)
+ * back to the driver; returns how many, or a negative error.  Synchronises the device.  Later statmc_malloc_placed calls back
+ * and probe new slots as they need them. */
+int statmc_placement_trim(void);
+/* One character per GiB slot of the current device, NUL-terminated: '#' the allocator's own, a / b / c an idle slot of
+ * that class, A / B / C one dealt to a role, S / T one dealt to the state / stream role without the wanted class, '?' unclear,
+ * '_' released by statmc_placement_trim. */
 int statmc_placement_map(char *out, int capacity);
 /* Page-locked host memory for the staging side of statmc_upload / statmc_download (sample arenas
  * of the tile path, dump buffers): copies from it run at the full PCIe rate and stay asynchronous. */

@@ -77,7 +77,7 @@ EXPORTS = [
     "statmc_last_error", "statmc_setup", "statmc_device_cus", "statmc_set_device", "statmc_set_significance", "statmc_get_significance", "statmc_set_t_quantiles",
     "statmc_set_filter_spec", "statmc_get_filter_spec", "statmc_reset_filter_spec", "statmc_pinned_from", "statmc_copy_device_settings",
     "statmc_set_filter_split", "statmc_get_filter_split", "statmc_filter_split_auto",
-    "statmc_malloc", "statmc_free", "statmc_malloc_placed", "statmc_placement_info", "statmc_placement_map", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_download",
+    "statmc_malloc", "statmc_free", "statmc_malloc_placed", "statmc_placement_info", "statmc_placement_map", "statmc_placement_trim", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_download",
     "statmc_stream_create", "statmc_stream_create_with_priority", "statmc_stream_destroy", "statmc_synchronize",
     "statmc_event_create", "statmc_event_destroy", "statmc_event_record", "statmc_stream_wait_event",
     "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs", "statmc_prepass_pack", "statmc_prepass_pack_rows",
@@ -414,6 +414,14 @@ def placement_info():
     check(load().statmc_placement_map(buf, 1024))
     out["map"] = buf.value.decode()
     return out
+
+
+def placement_trim():
+    """Releases the idle slots of the current device's placed allocator (statmc_placement_trim); returns how many."""
+    n = load().statmc_placement_trim()
+    if n < 0:
+        check(n)
+    return n
 
 
 def make_stat_type(samples, state, transform, max_moment):

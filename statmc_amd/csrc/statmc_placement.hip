@@ -29,8 +29,8 @@
 // state in another measured 0.842 of the HBM peak at 1080p / 256 spp, arenas spread over both other classes 0.818, everything
 // in one class 0.760 (tools/experiments/acc_pool.py classes / fastslow).  A block never spans slots of an unsuitable class, so a
 // 6-GiB arena waits for a run of six suitable slots in a row (the range is extended until there is one, up to 60 % of the
-// card; after that the third class, then both up to 75 % of the card, then anything).  Slots are never unmapped: what no role uses stays mapped and
-// idle (about twice what the arenas take, on a 288 GB card).  No contrast between the probes, no
+// card; after that the third class, then both up to 75 % of the card, then anything).  What no role uses stays mapped and idle (about twice what the
+// arenas take, on a 288 GB card) until statmc_placement_trim gives it back to the driver.  No contrast between the probes, no
 // virtual-memory support, too little memory: the call degrades to slots as they come -- placement is an optimisation, never
 // a requirement -- and statmc_placement_info says so.  STATMC_PLACEMENT=0 turns the call into hipMalloc.
 
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void slot_probe_kernel(const vfloat4 *x, vuint
 
 enum SlotClass { kUnknown = -1, kClassA = 0, kClassB = 1, kClassC = 2, kMixed = 3, kNotA = 4 };   // A: slot 0's; B: the second target's; kNotA: B or C, not probed against the second target yet
 constexpr int kPrivate = -2;  // Slot::role of the allocator's own slots (probe targets)
+constexpr int kReleased = -3; // Slot::role of a slot whose memory went back to the driver (statmc_placement_trim): an address hole
 
 struct Slot {
     hipMemGenericAllocationHandle_t handle;
@@ -158,7 +159,7 @@ hipError_t split_not_a(Placement &P) {
         if (hipError_t e = hipMemsetAsync(P.base + (size_t)P.target2 * kSlot, 0, kProbeWindow, P.stream); e != hipSuccess) return e;
     }
     for (size_t i = 1; i < P.slots.size(); i++)
-        if ((int)i != P.target2 && classify(P, P.slots[i]) == kNotA)
+        if ((int)i != P.target2 && P.slots[i].role != kReleased && classify(P, P.slots[i]) == kNotA)
             if (hipError_t e = probe_slot(P, i, 1); e != hipSuccess) return e;
     return hipSuccess;
 }
@@ -263,7 +264,7 @@ hipError_t calibrate(Placement &P) {
 constexpr unsigned bit(int c) { return 1u << c; }
 constexpr unsigned kAnyClass = ~0u;
 bool suits(const Placement &P, const Slot &s, unsigned mask) {
-    if (s.role != -1) return false;
+    if (s.role != -1) return false;      // dealt, private or released
     if (P.no_contrast || mask == kAnyClass) return true;
     const int c = classify(P, s);
     return c >= 0 && (mask & bit(c));
@@ -449,7 +450,7 @@ int statmc_placement_info(statmc_placement_info_t *out) {
         const Slot &s = P.slots[i];
         const int c = classify(P, s);
         (c == kClassA ? out->slots_a : c == kClassB ? out->slots_b : c == kClassC ? out->slots_c : out->slots_unclear)++;
-        if (s.role == kPrivate) continue;
+        if (s.role == kPrivate || s.role == kReleased) continue;
         if (s.role == -1) out->slots_idle++;
         else {
             out->slab_bytes[s.role] += kSlot;
@@ -490,6 +491,30 @@ int statmc_debug_interference_probe(const void *stream_ptr, size_t stream_bytes,
     return STATMC_OK;
 }
 
+// Gives the memory of every idle slot (backed, probed, dealt to no role) back to the driver; the slots stay as holes in the
+// address range.  For a host that has made its allocations and wants the rest of the card for something else: the next
+// statmc_malloc_placed that needs room backs and probes new slots at the end of the range (the driver may well hand the same
+// memory out again).  Returns the number of slots released, or a negative error.
+int statmc_placement_trim(void) {
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lk(g_place_mu);
+    auto it = g_place.find(dev);
+    if (it == g_place.end() || !it->second.vmm) return 0;
+    Placement &P = it->second;
+    (void)hipDeviceSynchronize();
+    int n = 0;
+    for (size_t i = 1; i < P.slots.size(); i++) {
+        Slot &s = P.slots[i];
+        if (s.role != -1) continue;
+        if (hipError_t e = hipMemUnmap(P.base + i * kSlot, kSlot); e != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "hipMemUnmap: %s", hipGetErrorString(e));
+        (void)hipMemRelease(s.handle);
+        s.role = kReleased;
+        n++;
+    }
+    return n;
+}
+
 // One character per backed slot: '#' the allocator's own, a / b / c an idle slot of that class, A / B / C one dealt to a role
 // (upper case S / T when it was dealt without the wanted class: S state, T stream), '?' unclear or unprobed.
 int statmc_placement_map(char *out, int capacity) {
@@ -507,6 +532,7 @@ int statmc_placement_map(char *out, int capacity) {
         const int c = classify(P, s);
         char ch = c == kClassA ? 'a' : c == kClassB ? 'b' : c == kClassC ? 'c' : '?';
         if (s.role == kPrivate) ch = '#';
+        else if (s.role == kReleased) ch = '_';
         else if (s.role >= 0 && s.as_it_came) ch = s.role == STATMC_MEM_STATE ? 'S' : 'T';
         else if (s.role >= 0 && ch != '?') ch = (char)(ch - 'a' + 'A');
         out[n++] = ch;

@@ -68,6 +68,22 @@ def test_accumulate_and_filter_on_placed_memory_give_the_same_bits(gpu):
     assert np.isfinite(out_p.cpu().numpy()).all()
 
 
+def test_trim_releases_the_idle_slots_and_the_allocator_goes_on(gpu):
+    dev = torch.device("cuda:0")
+    keep = gpu.empty_placed((1 << 20,), torch.float32, dev, gpu.MEM_STREAM)
+    keep.fill_(3.0)
+    before = gpu.placement_info()
+    n = gpu.placement_trim()
+    after = gpu.placement_info()
+    assert n == before["slots_idle"] and after["slots_idle"] == 0 and after["map"].count("_") >= n
+    assert after["live_bytes"] == before["live_bytes"] and float(keep.sum().item()) == 3.0 * (1 << 20)
+    # a block that needs fresh slots: backed and probed at the end of the range
+    big = gpu.empty_placed((3 << 28,), torch.float32, dev, gpu.MEM_STREAM)          # 3 GiB
+    big[: 1 << 20].fill_(1.0)
+    assert float(big[: 1 << 20].sum().item()) == float(1 << 20)
+    assert gpu.placement_info()["slots"] >= after["slots"]
+
+
 def test_switch_off_is_plain_hipmalloc():
     code = ("import torch, sys; sys.path.insert(0, %r)\n"
             "from statmc_amd import api\n"
