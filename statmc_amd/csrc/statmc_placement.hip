@@ -54,7 +54,13 @@ constexpr size_t kBlock = 2ull << 20;         // granularity of the blocks hande
 constexpr size_t kReserveSlots = 640;         // address range per device (more than the card holds)
 constexpr size_t kProbeWindow = 64ull << 20;  // bytes of slot 0 the probe writes
 constexpr int kProbeEvery = 4;                // one 16-byte read-modify-write per this many 16-byte loads
-constexpr float kSameAbove = 1.055f, kApartBelow = 1.035f;   // x the fastest probe (the two levels sit at 1.00 and 1.09)
+constexpr float kSameAbove = 1.055f;          // x the fastest probe: the two levels sit at 1.00 .. 1.03 and 1.075 .. 1.10
+constexpr float kApartBelowDefault = 1.035f;
+inline float apart_below() {                 // STATMC_PLACEMENT_APART=1.02 (experiment): only the purest pieces count as apart
+    static const float v = [] { const char *e = getenv("STATMC_PLACEMENT_APART"); const float x = e ? (float)atof(e) : 0.f; return x > 1.f && x < kSameAbove ? x : kApartBelowDefault; }();
+    return v;
+}
+#define kApartBelow apart_below()
 constexpr int kCalibrationCap = 96;           // slots probed without seeing both levels: no classes to tell apart here
 
 typedef float vfloat4 __attribute__((ext_vector_type(4)));

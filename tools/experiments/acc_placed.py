@@ -38,7 +38,22 @@ def timed(fs, a, reps):
     return best
 
 
+ONLY = os.environ.get("ONLY")      # "torch" | "placed": one allocator only (shapes whose arenas do not fit twice: 4K / 256 spp)
 for W, H, S in shapes:
+    if ONLY:
+        if ONLY == "placed":
+            a = {t: api.empty_placed((S, H, W, synthetic.CHANNELS[t]), torch.float32, dev, api.MEM_STREAM) for t in types}
+        else:
+            a = {t: torch.empty((S, H, W, synthetic.CHANNELS[t]), device=dev) for t in types}
+        for t in types:
+            for s0 in range(0, S, 16):
+                a[t][s0:s0 + 16].uniform_()
+        fs = film.FilmStats(W, H, dev, types=types, placed=ONLY == "placed")
+        ms = timed(fs, a, 3)
+        print("%dx%d %3d spp: %s %.3f ms %.3f" % (W, H, S, ONLY, ms, bpp(S) * W * H / ms / 8e9), flush=True)
+        del a, fs
+        torch.cuda.empty_cache()
+        continue
     plain = {t: torch.empty((S, H, W, synthetic.CHANNELS[t]), device=dev) for t in types}
     if os.environ.get("SCENE"):       # bench.py's stream (log-normal radiance, 20 % zero paths, fireflies) instead of uniform numbers
         scene = synthetic.Scene(W, H, n_regions=12, seed=1, device=dev)
