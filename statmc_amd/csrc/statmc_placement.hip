@@ -54,12 +54,17 @@ constexpr size_t kBlock = 2ull << 20;         // granularity of the blocks hande
 constexpr size_t kReserveSlots = 640;         // address range per device (more than the card holds)
 constexpr size_t kProbeWindow = 64ull << 20;  // bytes of slot 0 the probe writes
 constexpr int kProbeEvery = 4;                // one 16-byte read-modify-write per this many 16-byte loads
-constexpr float kSameAbove = 1.055f;          // x the fastest probe: the two levels sit at 1.00 .. 1.03 and 1.075 .. 1.10
-constexpr float kApartBelowDefault = 1.035f;
-inline float apart_below() {                 // STATMC_PLACEMENT_APART=1.02 (experiment): only the purest pieces count as apart
-    static const float v = [] { const char *e = getenv("STATMC_PLACEMENT_APART"); const float x = e ? (float)atof(e) : 0.f; return x > 1.f && x < kSameAbove ? x : kApartBelowDefault; }();
-    return v;
+// x the fastest probe: the two levels sit at 1.00 .. 1.03 and 1.075 .. 1.10; what lies between is a piece that straddles classes.
+// STATMC_PLACEMENT_SAME / STATMC_PLACEMENT_APART (experiments) move the two thresholds.
+constexpr float kContrast = 1.055f;          // calibration: both levels have been seen once two probes differ by this much
+inline float env_threshold(const char *name, float dflt, float lo, float hi) {
+    const char *e = getenv(name);
+    const float x = e ? (float)atof(e) : 0.f;
+    return x > lo && x < hi ? x : dflt;
 }
+inline float same_above() { static const float v = env_threshold("STATMC_PLACEMENT_SAME", 1.055f, 1.03f, 1.10f); return v; }
+inline float apart_below() { static const float v = env_threshold("STATMC_PLACEMENT_APART", 1.035f, 1.0f, 1.055f); return v; }
+#define kSameAbove same_above()
 #define kApartBelow apart_below()
 constexpr int kCalibrationCap = 96;           // slots probed without seeing both levels: no classes to tell apart here
 
@@ -255,7 +260,7 @@ bool init(Placement &P, int dev) {
 hipError_t calibrate(Placement &P) {
     hipError_t err = hipSuccess;
     while (!P.calibrated) {
-        if (P.n_probes >= 2 && P.slowest_ms > kSameAbove * P.fastest_ms) {
+        if (P.n_probes >= 2 && P.slowest_ms > kContrast * P.fastest_ms) {
             P.calibrated = true;
         } else if (P.n_probes >= kCalibrationCap || !back_next_slot(P, &err)) {
             P.calibrated = true;
