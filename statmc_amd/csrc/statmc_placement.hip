@@ -140,10 +140,10 @@ hipError_t probe_slot(Placement &P, size_t index, int which = 0) {
     float best = 1e30f;
     hipError_t err = hipSuccess;
     for (int rep = 0; rep < 6 && err == hipSuccess; rep++) {      // the first one is the warm-up (first touch of the slot)
-        hipEventRecord(P.e0, P.stream);
+        (void)hipEventRecord(P.e0, P.stream);
         hipLaunchKernelGGL(slot_probe_kernel, dim3(2048), dim3(256), 0, P.stream, reinterpret_cast<const vfloat4 *>(cand),
                            reinterpret_cast<vuint4 *>(target), kSlot / 16, kProbeWindow / 16, P.sink);
-        hipEventRecord(P.e1, P.stream);
+        (void)hipEventRecord(P.e1, P.stream);
         err = hipEventSynchronize(P.e1);
         float ms = 0.f;
         if (err == hipSuccess) err = hipEventElapsedTime(&ms, P.e0, P.e1);
@@ -197,10 +197,10 @@ bool back_next_slot(Placement &P, hipError_t *err) {
     hipError_t e = hipMemMap(at, kSlot, 0, s.handle, 0);
     if (e == hipSuccess) {
         e = hipMemSetAccess(at, kSlot, &P.access, 1);
-        if (e != hipSuccess) hipMemUnmap(at, kSlot);
+        if (e != hipSuccess) (void)hipMemUnmap(at, kSlot);
     }
     if (e != hipSuccess) {
-        hipMemRelease(s.handle);
+        (void)hipMemRelease(s.handle);
         *err = e;
         return false;
     }
@@ -485,18 +485,18 @@ int statmc_debug_interference_probe(const void *stream_ptr, size_t stream_bytes,
     if (err == hipSuccess) err = hipEventCreate(&e1);
     float best = 1e30f;
     for (int rep = 0; rep < 6 && err == hipSuccess; rep++) {
-        hipEventRecord(e0, nullptr);
+        (void)hipEventRecord(e0, nullptr);
         hipLaunchKernelGGL(slot_probe_kernel, dim3(2048), dim3(256), 0, nullptr, static_cast<const vfloat4 *>(stream_ptr), static_cast<vuint4 *>(rmw_ptr),
                            stream_bytes / 16, rmw_bytes / 16, sink);
-        hipEventRecord(e1, nullptr);
+        (void)hipEventRecord(e1, nullptr);
         err = hipEventSynchronize(e1);
         float t = 0.f;
         if (err == hipSuccess) err = hipEventElapsedTime(&t, e0, e1);
         if (rep > 0 && t < best) best = t;
     }
-    if (e0) hipEventDestroy(e0);
-    if (e1) hipEventDestroy(e1);
-    if (sink) hipFree(sink);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (sink) (void)hipFree(sink);
     if (err != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "interference probe: %s", hipGetErrorString(err));
     *ms = best;
     return STATMC_OK;
