@@ -176,15 +176,15 @@ hipError_t split_not_a(Placement &P) {
 }
 
 // backs the next slot of the range with memory (and probes it, index > 0); false when the card or the range has no room left
-bool back_next_slot(Placement &P, hipError_t *err) {
+bool back_next_slot(Placement &P, hipError_t *err, size_t leave_free = 512ull << 20) {
     *err = hipSuccess;
     if (P.slots.size() >= kReserveSlots) {
         P.last_note = "address range used up";
         return false;
     }
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < kSlot + (512ull << 20)) {
-        P.last_note = "less than 1.5 GiB free";
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < kSlot + leave_free) {
+        P.last_note = "the card is (nearly) full";
         return false;
     }
     Slot s;
@@ -262,7 +262,7 @@ hipError_t calibrate(Placement &P) {
     while (!P.calibrated) {
         if (P.n_probes >= 2 && P.slowest_ms > kContrast * P.fastest_ms) {
             P.calibrated = true;
-        } else if (P.n_probes >= kCalibrationCap || !back_next_slot(P, &err)) {
+        } else if (P.n_probes >= kCalibrationCap || !back_next_slot(P, &err, 8ull << 30)) {
             P.calibrated = true;
             P.no_contrast = true;
         }
@@ -309,7 +309,7 @@ void deal(Placement &P, int role, size_t first, size_t count, bool wanted_class)
 
 // Finds `want_slots` undealt slots of the classes in `mask` in a row and deals them to the role; backs new slots at the end of
 // the range, up to `cap_slots` in all, until there is such a run.  STATMC_ERR_UNSUPPORTED: none (the caller searches weaker).
-int find_run(Placement &P, int role, size_t want_slots, unsigned mask, size_t cap_slots, bool wanted_class) {
+int find_run(Placement &P, int role, size_t want_slots, unsigned mask, size_t cap_slots, bool wanted_class, size_t leave_free) {
     for (;;) {
         size_t run = 0;
         for (size_t i = 1; i < P.slots.size(); i++) {
@@ -321,7 +321,7 @@ int find_run(Placement &P, int role, size_t want_slots, unsigned mask, size_t ca
         }
         if (P.slots.size() >= cap_slots) return STATMC_ERR_UNSUPPORTED;
         hipError_t err = hipSuccess;
-        if (!back_next_slot(P, &err)) {
+        if (!back_next_slot(P, &err, leave_free)) {
             if (err != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "placement: %s", hipGetErrorString(err));
             return STATMC_ERR_UNSUPPORTED;
         }
@@ -362,7 +362,10 @@ int placed_alloc(Placement &P, int role, size_t bytes, void **out) {
     int rc = STATMC_ERR_UNSUPPORTED;
     const Search *order = role == STATMC_MEM_STATE ? state_order : stream_order;
     const int n_order = role == STATMC_MEM_STATE ? 4 : 5;
-    for (int k = 0; k < n_order && rc == STATMC_ERR_UNSUPPORTED; k++) rc = find_run(P, role, want_slots, order[k].mask, order[k].cap, order[k].wanted);
+    // searching for a CLASS never takes the card's last 8 GiB (other allocators of the process need room); only the last resort --
+    // any class, the request would fail otherwise -- goes down to half a GiB
+    for (int k = 0; k < n_order && rc == STATMC_ERR_UNSUPPORTED; k++)
+        rc = find_run(P, role, want_slots, order[k].mask, order[k].cap, order[k].wanted, k + 1 < n_order ? (8ull << 30) : (512ull << 20));
     if (rc == STATMC_ERR_HIP) return rc;
     if (rc != STATMC_OK) {
         size_t free_b = 0, total_b = 0;
