@@ -1290,6 +1290,10 @@ int statmc_accumulate_row_ranges(uint16_t width, uint16_t height, const statmc_s
     k.grid_mode = dstate.acc_grid_mode;
     k.dma_first = dstate.acc_dma_first;
     k.occ = dstate.acc_occ;
+    // every type's samples in a STREAM block and its moments in a STATE block of the placed allocator: apart by construction
+    k.apart = 1;
+    for (int i = 0; i < k.n_types && k.apart; i++)
+        k.apart = statmc::placement_role_of(k.t[i].samples) == STATMC_MEM_STREAM && statmc::placement_role_of(k.t[i].mean) == STATMC_MEM_STATE;
     HIP_TRY(statmc::launch_accumulate(k, S(stream)));
     return STATMC_OK;
 }

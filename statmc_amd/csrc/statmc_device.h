@@ -47,6 +47,7 @@ struct AccumulateArgs {
     int grid_mode;        // -1: by batch length (default); 0: capped grid, slots per type in proportion to cost, grid-stride; 1: one pass per workgroup, types round-robin
     int dma_first;        // the first rows of the LDS-DMA ring are requested before the state loads
     int occ;              // experiment builds (STATMC_ACC_OCC_AB): 3 = the build for three waves per SIMD
+    int apart;            // 1: samples and moments are known to lie in different interference classes (statmc_malloc_placed blocks)
     // large grid: workgroup b serves slot b % n_slots; slots are dealt to types in proportion to cost
     int n_slots;
     int type_slots[kMaxStatTypes];
@@ -224,6 +225,7 @@ hipError_t launch_border_virtual(const FilterArgs &a, hipStream_t s);   // the c
 int choose_parts(int tiles, int n_rows, int n_cus);
 // statmc_placement.hip (device memory placed by HBM rank)
 int abi_fail(int code, const char *fmt, ...);   // records the calling thread's statmc_last_error() text, returns `code` (statmc_abi.hip)
+int placement_role_of(const void *ptr);         // STATMC_MEM_STATE / _STREAM when `ptr` lies in a block dealt with the wanted class, else -1
 bool placement_free(void *ptr);                 // true: `ptr` was a statmc_malloc_placed block and is free now
 hipError_t workspace_alloc(void **p, size_t bytes);   // the library's own read-and-written workspaces: STATE role where the device's caller uses placed memory, hipMalloc otherwise
 hipError_t workspace_free(void *p);

@@ -402,6 +402,21 @@ hipError_t workspace_free(void *p) {
     return hipFree(p);
 }
 
+// -1: not a block of the placed allocator's (or the allocator is not telling classes apart on that device); else the role it was
+// dealt for.  What statmc_accumulate asks about its buffers: samples in STREAM blocks and moments in STATE blocks are known to
+// lie in different interference classes, and the film-major launch shape is chosen with that in mind (launch_accumulate).
+int placement_role_of(const void *ptr) {
+    std::lock_guard<std::mutex> lk(g_place_mu);
+    for (auto &kv : g_place) {
+        const Placement &P = kv.second;
+        if (!P.base || !P.vmm || !P.calibrated || P.no_contrast) continue;
+        if ((const char *)ptr < P.base || (const char *)ptr >= P.base + P.slots.size() * kSlot) continue;
+        const Slot &s = P.slots[(size_t)((const char *)ptr - P.base) / kSlot];
+        return s.role >= 0 && !s.as_it_came ? s.role : -1;
+    }
+    return -1;
+}
+
 // statmc_free's question: is this pointer one of the placed allocator's?  Frees it if so.
 bool placement_free(void *ptr) {
     std::lock_guard<std::mutex> lk(g_place_mu);

@@ -748,7 +748,14 @@ hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
     // 8 spp 6.1 -> 7.0, 16 spp 6.2 -> 6.6; 4K: 4 spp 4.9 -> 5.7, 16 spp 5.74 -> 5.63; profiles/r04_acc_launch.log).
     int max_s = 0;
     for (int i = 0; i < a.n_types; i++) max_s = a.t[i].n_samples > max_s ? a.t[i].n_samples : max_s;
-    if (a.grid_mode < 0) a.grid_mode = (max_s <= 8 || (max_s <= 16 && max_groups <= (1 << 20))) ? 1 : 0;
+    // Round 5: with the samples and the moments in different interference classes (a.apart: statmc_malloc_placed blocks) the one-pass
+    // shape also wins on 4K films at every batch length (+ 1 - 5 %) and on long batches at 1080p (256 spp: 3.61 against 3.67 - 3.70
+    // ms); 32 - 64 samples on films up to 1080p keep the capped grid (+ 1.5 - 2.5 %).  Three processes, profiles/r05_acc_launch_placed.log.
+    if (a.grid_mode < 0) {
+        const bool big = max_groups >= (1 << 20);
+        if (a.apart) a.grid_mode = (max_s <= 16 || big || max_s >= 128) ? 1 : 0;
+        else a.grid_mode = (max_s <= 8 || (max_s <= 16 && !big)) ? 1 : 0;
+    }
     const dim3 grid(a.resident_blocks > 0 ? a.resident_blocks : a.grid_mode == 1 ? (unsigned)(units * a.n_types) : rounds * a.n_slots);
     // a.dma: 0 = loads into registers (A/B), 1 = the default ring depth, 3 .. 6 = that depth where the build holds it
     // (STATMC_ACC_DMA_DEPTHS: experiment builds instantiate every depth, the product build the default one)

@@ -2,7 +2,8 @@
 grid-stride walk (0) against one pass per workgroup with the types round-robin (1); the LDS-DMA ring's first rows requested
 behind (0) or before (1) the state loads.  Films 720p / 1080p / 4K, launches of 4 .. 256 samples per pixel; the four
 shapes must leave the same bits.
-python tools/experiments/time_accumulate_launch.py"""
+python tools/experiments/time_accumulate_launch.py        (PLACED=1, round 5: moments and arenas from statmc_malloc_placed, one state per
+                                                          shape so that every launch shape runs on the same buffers)"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -13,6 +14,7 @@ dev = torch.device("cuda:0")
 api.setup(0)
 lib = api.load()
 types = list(synthetic.FEATURES)
+PLACED = os.environ.get("PLACED") == "1"
 
 
 def bpp(S):
@@ -24,10 +26,12 @@ def bpp(S):
     return t
 
 
-for W, H, spps in ((1280, 720, (64,)), (1920, 1080, (4, 8, 16, 32, 64, 256)), (3840, 2160, (4, 16, 64))):
+for W, H, spps in ((1280, 720, (64,)), (1920, 1080, (4, 8, 16, 32, 64, 256)), (3840, 2160, (4, 8, 16, 32, 64))):
     scene = synthetic.Scene(W, H, seed=1, device=dev)
     Smax = max(spps)
-    smp = {t: torch.empty((Smax, H, W, synthetic.CHANNELS[t]), device=dev) for t in types}
+    smp = {t: (api.empty_placed((Smax, H, W, synthetic.CHANNELS[t]), torch.float32, dev, api.MEM_STREAM) if PLACED else
+               torch.empty((Smax, H, W, synthetic.CHANNELS[t]), device=dev)) for t in types}
+    fs_shared = film.FilmStats(W, H, dev, types=types, placed=True) if PLACED else None
     for s0 in range(0, Smax, 32):
         part = scene.samples(min(32, Smax - s0), seed=7 + s0, features=types)
         for t in types:
@@ -39,7 +43,8 @@ for W, H, spps in ((1280, 720, (64,)), (1920, 1080, (4, 8, 16, 32, 64, 256)), (3
         line = "%dx%d %3d spp (%5d B/px):" % (W, H, S, bpp(S))
         for grid_mode, dma_first in ((0, 0), (1, 0), (0, 1), (1, 1)):
             api.check(lib.statmc_debug_accumulate_launch(grid_mode, dma_first))
-            fs = film.FilmStats(W, H, dev, types=types)
+            fs = fs_shared if PLACED else film.FilmStats(W, H, dev, types=types)
+            fs.reset()
             fs.accumulate(part)
             torch.cuda.synchronize()
             state = torch.cat([v.reshape(-1).view(torch.int32) for st in fs.state.values() for v in st.values() if v is not None])
@@ -57,7 +62,8 @@ for W, H, spps in ((1280, 720, (64,)), (1920, 1080, (4, 8, 16, 32, 64, 256)), (3
                 torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1) / reps)
             line += "  grid %d dma_first %d: %.4f ms %.2f TB/s" % (grid_mode, dma_first, best, bpp(S) * W * H / best / 1e9)
-            del fs
+            if not PLACED:
+                del fs
         print(line, flush=True)
     del smp
 api.check(lib.statmc_debug_accumulate_launch(-1, 0))
