@@ -9,7 +9,7 @@
 // (same class), '.' fast.
 // Modes (second argument): 0 the class rows above; 1 the same with a copy as the probe (no clean levels); 2 pieces probed through ONE
 // re-used address window, then side by side (+ a third argument: one piece at many addresses); 4 two pieces, addresses only;
-// 5 (unused: 2-MiB tail mappings are refused by hipMemSetAccess); 6 ONE physical GiB mapped at every slot; 7 the decider: one
+// 5 (DO NOT RUN: hipMemSetAccess refuses 2-MiB mappings next to a larger one on ROCm 7.2, and touching such a range faults the GPU); 6 ONE physical GiB mapped at every slot; 7 the decider: one
 // physical GiB mapped at 140 addresses, each mapping made after a fresh physical allocation, against those 140 allocations mapped
 // in one burst -- the class follows the physical memory.
 // hipcc -O3 --offload-arch=gfx950 rank_probe.hip -o rank_probe && ./rank_probe [pieces] [mode]
