@@ -214,6 +214,11 @@ int main(int argc, char **argv) {
         show("   ... and the class of that other mapping (shown under the slot):", p4);
         return 0;
     }
+    if (mode == 5 && !(argc > 4 && atoi(argv[4]) == 1)) {
+        printf("mode 5 is kept for the record only: hipMemSetAccess refuses the 2-MiB tail mappings it needs (ROCm 7.2), and touching a range\n"
+               "whose access was not set faults the GPU.  (A fifth argument of 1 runs it anyway.)\n");
+        return 0;
+    }
     if (mode == 5) {
         // Is a slot's class a property of its PAGE-TABLE page?  GiB-aligned slots; every slot keeps a 2-MiB handle mapped at its
         // tail (which keeps the slot's page-directory page alive); ONE probe piece of 1022 MiB visits the slots in turn.
