@@ -117,13 +117,24 @@ class Stream {
 
 // Device image with shared ownership (the GpuMat role).  `allocate == false` builds a
 // descriptor without device memory: used to inspect the buffer catalogue without a GPU.
+// Opt-in for a host whose samples live on the device (a GPU renderer feeding statmc_accumulate from HBM): device images come
+// from statmc_malloc_placed(STATMC_MEM_STATE) and the sample arenas of the device-side accumulation from
+// statmc_malloc_placed(STATMC_MEM_STREAM), so that the moments and the samples lie in different interference classes of the card's
+// memory (include/statmc.h).  Off by default: the reference's flow uploads 76 B/px per iteration over PCIe and gains
+// nothing from it.  Process-wide; set it before the first Estimator is built.
+inline bool &usePlacedMemory() {
+    static bool on = false;
+    return on;
+}
+
 class DeviceImage {
   public:
     DeviceImage() = default;
     DeviceImage(int rows, int cols, ImageType type, bool allocate = true) : rows(rows), cols(cols), type(type) {
         if (allocate) {
             void *p = nullptr;
-            check(statmc_malloc(&p, bytes()));
+            if (usePlacedMemory()) check(statmc_malloc_placed(&p, bytes(), STATMC_MEM_STATE));
+            else check(statmc_malloc(&p, bytes()));
             mem = std::shared_ptr<void>(p, [](void *q) { statmc_free(q); });
         }
     }
@@ -1166,7 +1177,8 @@ class Estimator {
             if (ptr) statmc_free(ptr);
             ptr = nullptr;
             cap = 0;
-            check(statmc_malloc(&ptr, bytes));
+            if (usePlacedMemory()) check(statmc_malloc_placed(&ptr, bytes, STATMC_MEM_STREAM));   // a sample arena: read once per flush
+            else check(statmc_malloc(&ptr, bytes));
             cap = bytes;
         }
         void *ptr = nullptr;

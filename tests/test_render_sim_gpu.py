@@ -59,8 +59,11 @@ def make_samples(seed, W, H, s0, S, x0=0, y0=0):
     return rad, nrm, alb
 
 
-@pytest.mark.parametrize("W,H,stage_mb", [(88, 44, 1), (50, 37, 2048)], ids=["vector-tiles-small-staging", "scalar-tiles"])
-def test_render_loop_matches_oracle(gpu, oracle, tmp_path, W, H, stage_mb):
+@pytest.mark.parametrize("W,H,stage_mb,placed", [(88, 44, 1, False), (50, 37, 2048, False), (88, 44, 1, True)],
+                         ids=["vector-tiles-small-staging", "scalar-tiles", "placed-memory"])
+def test_render_loop_matches_oracle(gpu, oracle, tmp_path, W, H, stage_mb, placed):
+    """placed: the C++ host side with statmc::usePlacedMemory() -- device images from statmc_malloc_placed(STATE), the sample
+    arenas of the device-side accumulation from statmc_malloc_placed(STREAM): the same files."""
     from statmc_amd import build, pfm
     build.build_tools()
     spp, iterations, seed, radius, sd = 4, 3, 5, 20, 10.0
@@ -68,7 +71,7 @@ def test_render_loop_matches_oracle(gpu, oracle, tmp_path, W, H, stage_mb):
     out = subprocess.run([build.RENDER_SIM_BIN, "--width", str(W), "--height", str(H), "--spp", str(spp),
                           "--iterations", str(iterations), "--threads", "4", "--seed", str(seed), "--stem", stem,
                           "--filtersd", str(sd), "--filterradius", str(radius), "--stage-mb", str(stage_mb), "--warmup",
-                          "--tilestats"],
+                          "--tilestats"] + (["--placed"] if placed else []),
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert out.stdout.count("Noisiest tile:") == iterations

@@ -20,7 +20,7 @@
 //   statmc_render_sim --width 96 --height 56 --spp 4 --iterations 3 --stem out/sim [--threads 4]
 //                     [--seed 1] [--filtersd 10] [--filterradius 20] [--stage-mb 2048] [--no-denoise]
 //                     [--config denoise|acrr|smis] [--trackedbounces 5] [--outputregex '.*'] [--warmup] [--tilestats]
-//                     [--adaptive]
+//                     [--adaptive] [--placed]
 // --adaptive: per-tile sample budgets from the tile-local noise level (Estimator::TileNoise); see RenderLoop.
 // --config denoise: Render<Vec3>, RGB radiance + normal + albedo, filter<float3> (scenes/render-denoise.pbrt).
 // --config acrr:    Render<Float>, "multichannelstats" false: the luminance of the path prefix up to each
@@ -343,6 +343,7 @@ int main(int argc, char **argv) {
         else if (a == "--warmup") o.warmUp = true;
         else if (a == "--tilestats") o.tileStats = true;
         else if (a == "--adaptive") o.adaptive = true;
+        else if (a == "--placed") statmc::usePlacedMemory() = true;   // device images and sample arenas from statmc_malloc_placed
         else if (a == "--config") {
             const std::string c = next();
             if (c != "denoise" && c != "acrr" && c != "smis") {
