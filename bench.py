@@ -879,7 +879,8 @@ def main():
     # The running moments and the sample arenas come from statmc_malloc_placed (moments in one interference class of the
     # card's memory, arenas in another: + 6 - 17 % on the accumulation, the same bits); anything that goes wrong there is
     # reported in the line and the buffers come from torch's allocator instead.
-    PLACED["on"] = bool(args.placement) and not args.share_device
+    # (ranks that share a device -- test setups -- would each back their own slots on it: off there unless a test asks for it)
+    PLACED["on"] = bool(args.placement) and (not args.share_device or os.environ.get("STATMC_BENCH_PLACED_ON_SHARED_DEVICE") == "1")
     _ballast = None
     if os.environ.get("STATMC_BENCH_BALLAST_GB"):      # experiment: occupy the first GiB of the card before anything is placed
         _ballast = torch.empty(int(float(os.environ["STATMC_BENCH_BALLAST_GB"]) * 2 ** 28), dtype=torch.float32, device=dev)

@@ -75,6 +75,21 @@ def test_strong_scaling_two_ranks_share_the_device(gpu, grid, blocks):
     assert "cpu_baseline" not in r
 
 
+def test_two_ranks_with_placed_buffers(gpu):
+    """The N > 1 step with every rank's moments and sample arenas from statmc_malloc_placed (what the driver's multi-GPU runs use;
+    here two ranks share the box's GPU, each with its own slots): same self-checks as the plain two-rank run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["STATMC_BENCH_PLACED_ON_SHARED_DEVICE"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device"] + COMMON
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=360, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = _line(out)
+    assert r["n_gpus"] == 2 and r["n_ranks_seen"] == 2 and r["placement"]["requested"] and r["placement"]["error"] is None
+    assert r["placement"]["virtual_memory"] if "virtual_memory" in r["placement"] else True
+    assert r["overlap_self_check"]["overlapped_vs_plain_order"] == "bit-identical"
+    assert r["config"]["step_order"].startswith("border rows first")
+
+
 def test_launched_under_torchrun_and_gather_in_step(gpu):
     """The driver's N > 1 launch form (python -m torch.distributed.run ... bench.py --gpus N) still works, and --gather
     puts the assembly of film-f on rank 0 inside the step."""
