@@ -1403,7 +1403,8 @@ def main_peer(args):
         W, H = args.width // grid[0], args.height // grid[1]
     else:
         W, H = args.width, args.height
-    PLACED["on"] = bool(args.placement) and not args.share_device      # (blocks that share a device would split its slots between them)
+    # (blocks that share a device -- test setups -- draw on one set of slots: off there unless a test asks for it)
+    PLACED["on"] = bool(args.placement) and (not args.share_device or os.environ.get("STATMC_BENCH_PLACED_ON_SHARED_DEVICE") == "1")
     try:
         pf = peer.PeerFilm(n, W, H, r, devices, types, filter_sd=args.filtersd, grid=grid, overlap=args.overlap_halo, placed=PLACED["on"])
     except api.StatmcError as e:
