@@ -353,11 +353,19 @@ int placed_alloc(Placement &P, int role, size_t bytes, void **out) {
     const size_t soft_cap = std::min<size_t>(kReserveSlots, (size_t)(0.60 * (double)P.total_bytes / (double)kSlot));
     const size_t hard_cap = std::min<size_t>(kReserveSlots, (size_t)(0.75 * (double)P.total_bytes / (double)kSlot));
     struct Search { unsigned mask; size_t cap; bool wanted; };
-    const Search state_order[] = {{bit(kClassA), soft_cap, true}, {bit(kClassA) | bit(kMixed), 0, false}, {kAnyClass, hard_cap, false},
+    // which class serves which role: the state takes slot 0's class (A), the arenas the second target's (B), then the third (C).
+    // STATMC_PLACEMENT_ROLES=BCA etc. (experiment: are the classes interchangeable?) permutes that.
+    static const int cls[3] = {[] { const char *e = getenv("STATMC_PLACEMENT_ROLES"); return e && strlen(e) == 3 ? e[0] - 'A' : 0; }(),
+                               [] { const char *e = getenv("STATMC_PLACEMENT_ROLES"); return e && strlen(e) == 3 ? e[1] - 'A' : 1; }(),
+                               [] { const char *e = getenv("STATMC_PLACEMENT_ROLES"); return e && strlen(e) == 3 ? e[2] - 'A' : 2; }()};
+    const bool perm_ok = cls[0] >= 0 && cls[0] < 3 && cls[1] >= 0 && cls[1] < 3 && cls[2] >= 0 && cls[2] < 3 && cls[0] != cls[1] && cls[1] != cls[2] && cls[0] != cls[2];
+    const int cS = perm_ok ? cls[0] : kClassA, cT = perm_ok ? cls[1] : kClassB, cU = perm_ok ? cls[2] : kClassC;
+    const unsigned not_state = bit(cT) | bit(cU) | (cS == kClassA ? bit(kNotA) : 0u);
+    const Search state_order[] = {{bit(cS), soft_cap, true}, {bit(cS) | bit(kMixed), 0, false}, {kAnyClass, hard_cap, false},
                                   {kAnyClass, kReserveSlots, false}};                    // (last resort: until the card is full)
-    const Search stream_order[] = {{bit(kClassB), soft_cap, true},                       // one class for all arenas
-                                   {bit(kClassC), 0, true},                              // ... or the other one
-                                   {bit(kClassB) | bit(kClassC) | bit(kNotA), hard_cap, true},   // both (still apart from the state)
+    const Search stream_order[] = {{bit(cT), soft_cap, true},                            // one class for all arenas
+                                   {bit(cU), 0, true},                                   // ... or the other one
+                                   {not_state, hard_cap, true},                          // both (still apart from the state)
                                    {kAnyClass, hard_cap, false}, {kAnyClass, kReserveSlots, false}};
     int rc = STATMC_ERR_UNSUPPORTED;
     const Search *order = role == STATMC_MEM_STATE ? state_order : stream_order;

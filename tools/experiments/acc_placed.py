@@ -67,18 +67,31 @@ for W, H, S in shapes:
             for s0 in range(0, S, 16):
                 plain[t][s0:s0 + 16].uniform_()
     t0 = time.perf_counter()
+    if os.environ.get("STATE_FIRST"):
+        fs_p = film.FilmStats(W, H, dev, types=types, placed=True)
     placed = {t: api.empty_placed((S, H, W, synthetic.CHANNELS[t]), torch.float32, dev, api.MEM_STREAM) for t in types}
-    fs_p = film.FilmStats(W, H, dev, types=types, placed=True)
+    if not os.environ.get("STATE_FIRST"):
+        fs_p = film.FilmStats(W, H, dev, types=types, placed=True)
     torch.cuda.synchronize()
     t_alloc = time.perf_counter() - t0
     for t in types:
         placed[t].copy_(plain[t])
+    if os.environ.get("NO_PLAIN"):      # the torch arenas go away before anything is timed (is it their presence?)
+        plain = {t: placed[t] for t in types}
+        torch.cuda.empty_cache()
     fs_t = film.FilmStats(W, H, dev, types=types)
     reps = max(3, min(20, int(30 / (bpp(S) * W * H / 6e9))))
     row = []
     for rnd in range(2):
         row.append("torch %.3f ms %.3f" % ((lambda ms: (ms, bpp(S) * W * H / ms / 8e9))(timed(fs_t, plain, reps))))
         row.append("placed %.3f ms %.3f" % ((lambda ms: (ms, bpp(S) * W * H / ms / 8e9))(timed(fs_p, placed, reps))))
+    if os.environ.get("GRIDS"):      # the placed launch under both launch shapes (statmc_debug_accumulate_launch), same buffers
+        lib = api.load()
+        for g in (0, 1, 0, 1):
+            api.check(lib.statmc_debug_accumulate_launch(g, 0))
+            ms = timed(fs_p, placed, reps)
+            row.append("placed grid %d %.3f ms %.3f" % (g, ms, bpp(S) * W * H / ms / 8e9))
+        api.check(lib.statmc_debug_accumulate_launch(-1, 0))
     # the same launch inside the step of bench.py: accumulate, pre-pass + window filter (VALU-bound, 1.7 ms at 1080p), repeat;
     # only the accumulations are timed
     if W * H <= 1920 * 1080:

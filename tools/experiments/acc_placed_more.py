@@ -160,3 +160,42 @@ if MODE == "ranks":
                 api.check(lib.statmc_debug_interference_probe(C.c_void_p(arenas[t].data_ptr() + g * GiB), nbytes, C.c_void_p(ptr), 64 << 20, C.byref(out)))
                 row.append("%.3f" % (out.value * GiB / nbytes))
             print("%-10s GiB %d against the first 64 MiB of [%s]: %s" % (t, g, " ".join(n for n, _ in targets), " ".join(row)), flush=True)
+
+if MODE == "depth":
+    # Does it matter WHERE on the card a placed launch's buffers lie?  Set after set of (state, five arenas) is allocated and kept,
+    # each one further into the card's memory than the one before; every set is timed (both launch shapes) when it is made and all
+    # of them again at the end.  BALLAST_GB: torch memory allocated (and written) before the first set.
+    lib = api.load()
+    ballast = None
+    if os.environ.get("BALLAST_GB"):
+        ballast = torch.empty(int(float(os.environ["BALLAST_GB"]) * 2 ** 28), dtype=torch.float32, device=dev)
+        ballast.zero_()
+    sets = []
+
+    def measure(k):
+        fs, a = sets[k]
+        out = []
+        for g in (0, 1):
+            api.check(lib.statmc_debug_accumulate_launch(g, 0))
+            ms = timed(fs, a, 7)
+            out.append("grid %d %.3f ms %.3f" % (g, ms, bpp(S) * W * H / ms / 8e9))
+        api.check(lib.statmc_debug_accumulate_launch(-1, 0))
+        return "  ".join(out)
+
+    for k in range(int(os.environ.get("SETS", 5))):
+        a = {t: api.empty_placed((S, H, W, synthetic.CHANNELS[t]), torch.float32, dev, api.MEM_STREAM) for t in types}
+        for t in types:
+            if os.environ.get("FILL") == "copy":      # written by one device-to-device copy of a torch tensor (what acc_placed.py does)
+                src = torch.empty((S, H, W, synthetic.CHANNELS[t]), device=dev)
+                for s0 in range(0, S, 16):
+                    src[s0:s0 + 16].uniform_()
+                a[t].copy_(src)
+                del src
+            else:
+                for s0 in range(0, S, 16):
+                    a[t][s0:s0 + 16].uniform_()
+        sets.append((film.FilmStats(W, H, dev, types=types, placed=True), a))
+        print("set %d (slots so far %d): %s" % (k, api.placement_info()["slots"], measure(k)), flush=True)
+    print("map:", api.placement_info()["map"])
+    for k in range(len(sets)):
+        print("set %d again: %s" % (k, measure(k)), flush=True)
