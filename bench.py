@@ -860,8 +860,18 @@ def main():
         if stall_test:
             time.sleep(10 ** 6)
 
+    if os.environ.get("STATMC_VARIANT"):      # experiments: a variant library (tools/experiments/build_variant.sh); the line says so
+        from statmc_amd import build as _build
+        os.environ.setdefault("STATMC_ALLOW_DIAGNOSTIC_BUILD", "1")
+        _build.SO = os.path.abspath(os.environ["STATMC_VARIANT"])
     from statmc_amd import api, film, pipeline, sharding, synthetic
     api.setup(local_rank)
+    if os.environ.get("STATMC_BENCH_ACC_RESIDENT") or os.environ.get("STATMC_BENCH_ACC_DMA"):      # experiments: launch knobs of the accumulation
+        _lib = api.load()
+        if os.environ.get("STATMC_BENCH_ACC_RESIDENT"):
+            api.check(_lib.statmc_debug_accumulate_resident_blocks(int(os.environ["STATMC_BENCH_ACC_RESIDENT"])))
+        if os.environ.get("STATMC_BENCH_ACC_DMA"):
+            api.check(_lib.statmc_debug_accumulate_dma(int(os.environ["STATMC_BENCH_ACC_DMA"])))
 
     S, r = args.spp, args.radius
     types = list(synthetic.FEATURES) if args.channels == 11 else ["radiance", "normal", "albedo"]
@@ -1363,6 +1373,8 @@ def build_result(c):
         "kernels": kernels,
         "placement": placement_report(),
     }
+    if os.environ.get("STATMC_VARIANT") or os.environ.get("STATMC_BENCH_ACC_RESIDENT") or os.environ.get("STATMC_BENCH_ACC_DMA"):
+        result["experiment"] = {k: os.environ[k] for k in ("STATMC_VARIANT", "STATMC_BENCH_ACC_RESIDENT", "STATMC_BENCH_ACC_DMA") if k in os.environ}
     if world > 1:
         g = c["gather_ms"]
         result["gather_ms"] = round(g, 4)

@@ -26,7 +26,10 @@ def bpp(S):
     return t
 
 
-for W, H, spps in ((1280, 720, (64,)), (1920, 1080, (4, 8, 16, 32, 64, 256)), (3840, 2160, (4, 8, 16, 32, 64))):
+SHAPES = ((1280, 720, (64,)), (1920, 1080, (4, 8, 16, 32, 64, 256)), (3840, 2160, (4, 8, 16, 32, 64)))
+if os.environ.get("LONG"):      # long batches only (round 5: where does the resident grid win?)
+    SHAPES = ((1280, 720, (128, 256, 512)), (1920, 1080, (96, 128, 256, 512)), (3840, 2160, (96, 128)))
+for W, H, spps in SHAPES:
     scene = synthetic.Scene(W, H, seed=1, device=dev)
     Smax = max(spps)
     smp = {t: (api.empty_placed((Smax, H, W, synthetic.CHANNELS[t]), torch.float32, dev, api.MEM_STREAM) if PLACED else
@@ -41,8 +44,10 @@ for W, H, spps in ((1280, 720, (64,)), (1920, 1080, (4, 8, 16, 32, 64, 256)), (3
         part = {t: v[:S] for t, v in smp.items()}
         ref = None
         line = "%dx%d %3d spp (%5d B/px):" % (W, H, S, bpp(S))
-        for grid_mode, dma_first in ((0, 0), (1, 0), (0, 1), (1, 1)):
-            api.check(lib.statmc_debug_accumulate_launch(grid_mode, dma_first))
+        # (grid 2, round 5: the resident grid -- one workgroup per CU, each walking every stat type -- through statmc_debug_accumulate_resident_blocks)
+        for grid_mode, dma_first in ((0, 0), (1, 0), (2, 0), (0, 1), (1, 1)) if os.environ.get("RESIDENT") else ((0, 0), (1, 0), (0, 1), (1, 1)):
+            api.check(lib.statmc_debug_accumulate_resident_blocks(int(os.environ.get("RESIDENT", 256)) if grid_mode == 2 else 0))
+            api.check(lib.statmc_debug_accumulate_launch(0 if grid_mode == 2 else grid_mode, dma_first))
             fs = fs_shared if PLACED else film.FilmStats(W, H, dev, types=types)
             fs.reset()
             fs.accumulate(part)
@@ -67,3 +72,4 @@ for W, H, spps in ((1280, 720, (64,)), (1920, 1080, (4, 8, 16, 32, 64, 256)), (3
         print(line, flush=True)
     del smp
 api.check(lib.statmc_debug_accumulate_launch(-1, 0))
+api.check(lib.statmc_debug_accumulate_resident_blocks(0))
