@@ -68,6 +68,38 @@ def test_accumulate_and_filter_on_placed_memory_give_the_same_bits(gpu):
     assert np.isfinite(out_p.cpu().numpy()).all()
 
 
+def test_random_alloc_free_sequences_keep_blocks_disjoint_and_intact(gpu):
+    """300 random allocations and frees in both roles (2 MiB .. 1.4 GiB: blocks that span slots included): live blocks never
+    overlap, every block keeps the pattern it was given, freed space is reused (the address range does not grow without bound)."""
+    rng = np.random.default_rng(2024)
+    dev = torch.device("cuda:0")
+    live = {}          # id -> (tensor, role, fill value)
+    next_id = 0
+    slots_seen = []
+    for step in range(300):
+        if live and (len(live) > 24 or rng.random() < 0.45):
+            k = list(live)[int(rng.integers(len(live)))]
+            t, role, val = live.pop(k)
+            assert int(t[0].item()) == val and int(t[-1].item()) == val and int(t[t.numel() // 2].item()) == val, (step, k)
+            del t
+        else:
+            role = int(rng.integers(2))
+            mib = int(rng.choice([2, 3, 10, 64, 200, 700, 1400], p=[0.25, 0.2, 0.2, 0.15, 0.1, 0.07, 0.03]))
+            t = gpu.empty_placed((mib << 18,), torch.int32, dev, role)
+            t.fill_(next_id)
+            live[next_id] = (t, role, next_id)
+            next_id += 1
+        if step % 50 == 49:
+            spans = sorted((t.data_ptr(), t.data_ptr() + t.numel() * 4) for t, _, _ in live.values())
+            assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), "live blocks overlap"
+            info = gpu.placement_info()
+            assert sum(info["live_bytes"]) >= sum(t.numel() * 4 for t, _, _ in live.values())
+            slots_seen.append(info["slots"])
+    for k, (t, role, val) in live.items():
+        assert int(t[0].item()) == val and int(t[-1].item()) == val
+    assert slots_seen[-1] <= slots_seen[1] + 8, slots_seen       # steady state: frees are reused
+
+
 def test_trim_releases_the_idle_slots_and_the_allocator_goes_on(gpu):
     dev = torch.device("cuda:0")
     keep = gpu.empty_placed((1 << 20,), torch.float32, dev, gpu.MEM_STREAM)
