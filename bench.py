@@ -501,6 +501,30 @@ def accumulate_by_batch(fs, samples, types, batch_sizes=(4, 8, 16, 32, 64), reps
             "what": "one launch of S samples per pixel, all stat types (bytes = samples + read-modify-write of the state), %d launches back to back" % reps}
 
 
+def accumulate_by_batch_4k(args, dev, types):
+    """The same table on a 3840 x 2160 film (BASELINE configs[4]'s), whose 1.86 GB of state no cache holds between launches: 64
+    samples per pixel generated for the leg, moments and arenas placed like the timed step's.  Secondary."""
+    from statmc_amd import synthetic
+    if (args.width, args.height) == (3840, 2160):
+        return {"skipped": "the bench film is 3840x2160 already: see accumulate_by_batch"}
+    W, H, S = 3840, 2160, 64
+    free_b = torch.cuda.mem_get_info(dev)[0]
+    if free_b < 3 * 4 * args.channels * W * H * S:
+        return {"skipped": "not enough free memory for a 4K / 64-spp pool (%.0f GiB free)" % (free_b / 2 ** 30)}
+    scene = synthetic.Scene(W, H, n_regions=12, seed=1, device=dev)
+    smp = {t: new_arena((S, H, W, synthetic.CHANNELS[t]), dev) for t in types}
+    for s0 in range(0, S, 16):
+        part = scene.samples(16, seed=77 + s0, features=types)
+        for t in types:
+            smp[t][s0:s0 + 16] = part[t]
+        del part
+    fs4 = new_film_stats(W, H, dev, types)
+    out = accumulate_by_batch(fs4, smp, types, reps=6)
+    del smp, fs4
+    torch.cuda.empty_cache()
+    return out
+
+
 def bind_to_gpu_numa(dev_index):
     """Keep the rank on the CPUs of the NUMA node its GPU hangs off (host-side issue latency, pinned staging buffers)."""
     try:
@@ -1153,6 +1177,7 @@ def main():
             result["cuda_time_bracket"] = leg(host_bracket, fs, args)
             result["tile_fed_accumulate"] = leg(tile_fed_accumulate, fs, samples, types)
             result["accumulate_by_batch"] = leg(accumulate_by_batch, fs, samples, types)
+            result["accumulate_by_batch_3840x2160"] = leg(accumulate_by_batch_4k, args, dev, types)
             result["host_copies"] = leg(host_copy_times, fs, dev)
             result["filter_8_feature_channels"] = leg(eight_channel_filter, fs, args)
             result["pcie_inclusive"] = leg(pcie_inclusive, fs, samples, types, args)
