@@ -86,8 +86,9 @@ int statmc_copy_device_settings(int src_device, int dst_device);
  *   every gate x channel rule x border, per-pixel dof, <= 2 RGB + <= 2 one-channel G-buffers   pair-symmetric LDS kernel   1.4 - 1.9 ms
  *   ... float buffers under the asymmetric / centre gate                                       one-sided LDS kernel        2.1 ms per 3 buffers
  *   Welch dof (dof = 1), <= 2 RGB G-buffers, any channel rule / border, RGB or float buffers   pair-symmetric Welch build  3.5 ms (1.5 per float buffer)
- *   Welch dof x a one-channel G-buffer (depth, material id)                                    general kernel ("generic")  ~ 60 ms; on a block +
- *                                                                                              halo image: STATMC_ERR_UNSUPPORTED
+ *   Welch dof x one-channel G-buffers (depth, material id), RGB or float buffers               eight-plane Welch build     4.2 ms (1.85 per float buffer); on a
+ *                                                                                              block + halo image: STATMC_ERR_UNSUPPORTED (such an image
+ *                                                                                              carries the sample counts OR the one-channel features)
  *   Welch dof x clamped border on a block + halo image (multi-GPU)                             STATMC_ERR_UNSUPPORTED (one device: Welch build + border kernel)
  *   radius > 20, more than eight feature channels, G-buffers of other channel counts          general kernel ("generic")
  * All of them return the CPU oracle's results to <= 1e-5 (tests/test_gpu_parity.py::test_filter_spec_variants_match_oracle). */

@@ -140,7 +140,9 @@ struct WelchTab {
 
 template <int NG, bool W = false>
 struct Planes {
-    static constexpr int kIn = NG + 9 + (W ? 3 : 0);         // input planes per row: features, mean, -D, colour[, E (Welch)]
+    // input planes per row: features, mean, -D, colour[, Welch: the three planes E -- or, beside eight feature planes, where
+    // the CU's LDS has room for ONE more plane, n - 1: the taps form E = v * v / (n - 1) themselves (chunk)]
+    static constexpr int kIn = NG + 9 + (W ? (NG == 8 ? 1 : 3) : 0);
     static constexpr int cMC = NG, cND = NG + 3, cCOL = NG + 6, cE = NG + 9;
     static constexpr int kSlotFloats = (kIn + kQ) * kP;
     static constexpr int kRawTotal = W ? 0 : NG == 6 ? 4 * kWaveCols * 15 : kP * kIn;
@@ -148,7 +150,8 @@ struct Planes {
     static constexpr size_t kLdsBytes = (size_t)(kSlots * kSlotFloats + 2 * kTabPad + kRawTotal + kBandTotal) * sizeof(float);
     __host__ __device__ static inline int raw_off(int wave) { return W ? 0 : NG == 6 ? (wave & 3) * kWaveCols * 15 : wave_col0(wave & 3) * kIn; }
 };
-static_assert(Planes<6>::kLdsBytes <= 160 * 1024 && Planes<8>::kLdsBytes <= 160 * 1024 && Planes<6, true>::kLdsBytes <= 160 * 1024, "LDS budget");
+static_assert(Planes<6>::kLdsBytes <= 160 * 1024 && Planes<8>::kLdsBytes <= 160 * 1024 && Planes<6, true>::kLdsBytes <= 160 * 1024 &&
+                  Planes<8, true>::kLdsBytes <= 160 * 1024, "LDS budget");
 
 // steps = window rows dy = 0 .. r a tile sweeps: kSteps in the r = 20 builds, radius + 1 in the runtime-radius ones
 __host__ __device__ inline int step_lo(int part, int n_parts, int steps) { return (steps * part) / n_parts; }
@@ -609,7 +612,18 @@ __device__ __forceinline__ void chunk(LaneT &st, const float *__restrict__ row, 
 #pragma unroll
         for (int ch = 0; ch < 6; ch++)
             if (!(PAIR && ch % 3 == 2)) mcn[ch] = *reinterpret_cast<const v4f *>(r + (C_MC + ch) * kP);
-        if constexpr (W) {
+        if constexpr (W && NG == 8) {
+            // eight feature planes: the ring holds n - 1 and the taps divide -- the oracle's own expression, Dp * Dp / ((float)n - 1.f),
+            // an IEEE division each (12 per read group; a reciprocal with a correction is a last bit off now and then, which
+            // moves nu across an integer exactly where one side's variance is 0).  A pixel that takes no part has -D = 0 and a
+            // NaN mean: whatever E comes out, its weight is 0.  PAIR: the second buffer's n - 1 sits in the (otherwise unread)
+            // third channel's mean plane.
+            const v4f nm1 = *reinterpret_cast<const v4f *>(r + Planes<NG, W>::cE * kP);
+            const v4f nm1b = PAIR ? *reinterpret_cast<const v4f *>(r + (C_MC + 2) * kP) : nm1;
+            en[0] = (mcn[3] * mcn[3]) / nm1;
+            en[1] = (mcn[4] * mcn[4]) / nm1b;
+            if constexpr (!PAIR) en[2] = (mcn[5] * mcn[5]) / nm1;
+        } else if constexpr (W) {
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) en[ch] = *reinterpret_cast<const v4f *>(r + (Planes<NG, W>::cE + ch) * kP);
         }
@@ -840,7 +854,10 @@ __device__ __forceinline__ void stage_store(float *slot, int i, const Staged &r,
         p[11 * kP] = ok.x ? -s.d.x : 0.f; p[12 * kP] = ok.y ? -s.d.y : 0.f; p[13 * kP] = ok.z ? -s.d.z : 0.f;
         p[14 * kP] = ok.x ? s.col.x : 0.f; p[15 * kP] = ok.y ? s.col.y : 0.f; p[16 * kP] = ok.z ? s.col.z : 0.f;
     }
-    if constexpr (W) {
+    if constexpr (W && NG == 8) {
+        slot[Planes<NG, W>::cE * kP + i] = r.nm1;
+        if (!rgb) slot[(Planes<NG, W>::cMC + 2) * kP + i] = r.nm1b;   // (filter<float>: the third channel's planes are not read)
+    } else if constexpr (W) {
         const Validity ok = pixel_validity(s.mc, s.d, s.col, s.valid && features_finite(s.g0, s.g1), rgb);
         float *p = slot + Planes<NG, W>::cE * kP + i;
         p[0 * kP] = ok.x ? s.d.x * s.d.x / r.nm1 : 0.f;
@@ -937,7 +954,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     float *const lds = smem + Planes<NG, mode_welch(MODE)>::kBandTotal;
     constexpr bool PAIR = mode_pair(MODE);
     constexpr bool W = mode_welch(MODE);
-    static_assert(!W || (!DMA && NG == 6 && RT), "the Welch modes exist in one build: register staging, six feature planes, runtime radius");
+    static_assert(!W || (!DMA && RT), "the Welch modes exist in one build per feature-plane count: register staging, runtime radius");
     constexpr int kSlotFloats = Planes<NG, W>::kSlotFloats, kIn = Planes<NG, W>::kIn;
     const Feat F = features_of<NG>(a);
     WelchTab tq2{nullptr, nullptr, 0u, ~0u};
@@ -1452,7 +1469,7 @@ void sym_choose_split(FilterArgs &w, int n_cus) {
 }
 
 // filter<float3> and filter<float> (two buffers per launch), radius 1..20, every spec: Welch degrees of freedom run the Welch builds
-// (six feature planes: a Welch call with a 1-channel G-buffer is not eligible and takes the general kernel).
+// (six or eight feature planes, like the others).
 // G-buffers: up to two RGB images (six feature planes, the shipped normal + albedo), or up to two RGB and up to two
 // 1-channel images in any order (eight feature planes: + depth + material id; block + halo calls carry them in a
 // 17-channel packed image)
@@ -1478,7 +1495,8 @@ bool sym_eligible(const FilterArgs &a, int channels) {
     if (a.packed && n_sc > 0 && a.packed_ch != 17) return false;   // 1-channel features travel in the 17-channel block + halo image
     // (a 17-channel image with no 1-channel feature -- FilmShards packs every set other than exactly two RGB G-buffers that way --
     // runs the eight-plane build with its 1-channel slots at scale 0; the pack kernel writes zeros there)
-    if (a.dof != STATMC_DOF_PIXEL && n_sc > 0) return false;            // the Welch build has six feature planes
+    // (Welch with 1-channel features: the eight-plane Welch builds, on whole images -- a block + halo image has either the
+    // sample counts, 16 channels, or the 1-channel features, 17; the two rules above turn that combination away)
     return true;
 }
 
@@ -1508,7 +1526,7 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     const bool welch = a.dof == STATMC_DOF_WELCH;
     const bool rt = a.radius != kR || welch;    // (the Welch modes exist in the runtime-radius build only; it serves r = 20 as well)
     if (rt && a.sym.tab_rt == nullptr) return hipErrorInvalidValue;
-    if (welch && (a.tq2 == nullptr || a.sym.g8 || (a.sym.pair ? (a.packed != nullptr || a.f_n[0] == nullptr || (a.f_active > 1 && a.f_n[1] == nullptr))
+    if (welch && (a.tq2 == nullptr || (a.sym.g8 && a.packed) || (a.sym.pair ? (a.packed != nullptr || a.f_n[0] == nullptr || (a.f_active > 1 && a.f_n[1] == nullptr))
                                                                  : a.packed ? a.packed_ch != 16 : a.n == nullptr)))
         return hipErrorInvalidValue;
     // LDS-DMA staging needs whole 16-byte pieces: images 16-byte aligned, width and film x-origin multiples of 4 pixels
@@ -1549,12 +1567,10 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     const void *kernel_far = nullptr;
     if (welch) {   // (the gate field has no meaning under Welch: there is one test, symmetric in the pair)
         if (a.sym.redo == nullptr) return hipErrorInvalidValue;
-        kernel = pair    ? reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelchPair, 6, true>)
-                 : joint ? reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelchJoint, 6, true>)
-                         : reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelch, 6, true>);
-        kernel_far = pair    ? reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelchPairFar, 6, true>)
-                     : joint ? reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelchJointFar, 6, true>)
-                             : reinterpret_cast<const void *>(&window_filter_sym<false, kModeWelchFar, 6, true>);
+#define STATMC_SYM_W(M) (g8 ? reinterpret_cast<const void *>(&window_filter_sym<false, M, 8, true>) : reinterpret_cast<const void *>(&window_filter_sym<false, M, 6, true>))
+        kernel = pair ? STATMC_SYM_W(kModeWelchPair) : joint ? STATMC_SYM_W(kModeWelchJoint) : STATMC_SYM_W(kModeWelch);
+        kernel_far = pair ? STATMC_SYM_W(kModeWelchPairFar) : joint ? STATMC_SYM_W(kModeWelchJointFar) : STATMC_SYM_W(kModeWelchFar);
+#undef STATMC_SYM_W
     }
     static std::mutex mu;
     static std::set<std::pair<int, const void *>> done;
@@ -1570,7 +1586,7 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     }
     const dim3 grid((unsigned)sym_items(a));
     void *kargs[] = {&a};
-    const size_t lds_bytes = welch ? Planes<6, true>::kLdsBytes : g8 ? Planes<8>::kLdsBytes : Planes<6>::kLdsBytes;
+    const size_t lds_bytes = welch ? (g8 ? Planes<8, true>::kLdsBytes : Planes<6, true>::kLdsBytes) : g8 ? Planes<8>::kLdsBytes : Planes<6>::kLdsBytes;
     if (hipError_t e = hipLaunchKernel(kernel, grid, dim3(kThreads), kargs, lds_bytes, s); e != hipSuccess) return e;
     if (kernel_far != nullptr) {   // Welch: the items the band build flagged, again with the table in global memory
         if (hipError_t e = hipLaunchKernel(kernel_far, grid, dim3(kThreads), kargs, lds_bytes, s); e != hipSuccess) return e;

@@ -99,7 +99,8 @@ class BlockLayout:
 def block_image_channels(g_channels, welch=False):
     """Channels per pixel of a block + halo image: 15 (mean-corr, discriminator, colour, two RGB G-buffers), 17 with
     1-channel G-buffers (depth, material id), 16 under Welch degrees of freedom (STATMC_DOF_WELCH: + the sample count,
-    which the pair test reads; two RGB G-buffers only -- the Welch builds have six feature planes)."""
+    which the pair test reads; two RGB G-buffers only -- an image carries the counts or the 1-channel features, not both: on one
+    device Welch x 1-channel G-buffers runs the eight-plane Welch builds from the separate images)."""
     if welch:
         if list(g_channels) != [3, 3]:
             raise ValueError("Welch degrees of freedom: the block + halo image holds two RGB G-buffers, no 1-channel ones")

@@ -794,36 +794,56 @@ def test_filter_eight_feature_channels(gpu, oracle, channels, order, spec_kw, W,
         assert rel_l2(out_g[..., c], ref[..., c]) <= TOL, c
 
 
-@pytest.mark.parametrize("channels", [3, 1])
-def test_filter_welch_with_one_channel_gbuffers_is_served_by_the_general_kernel(gpu, oracle, channels):
-    """Welch degrees of freedom x a 1-channel G-buffer (depth / material id, statpath.cpp:828-835): the pair-symmetric kernel's
-    Welch builds hold six feature planes, so this product runs the general (global-memory) kernel -- correct, ~ 35 x slower --
-    and says so in statmc_last_filter_variant (include/statmc.h lists the product in its table "what serves which spec");
-    on a block + halo image it is refused (sharding.block_image_channels raises; statmc_window_filter: STATMC_ERR_UNSUPPORTED)."""
+@pytest.mark.parametrize("channels,joint,radius,border,order,jump", [
+    (3, 0, 20, 0, ("normal", "albedo", "depth"), False), (3, 1, 20, 0, ("depth", "normal", "materialid", "albedo"), True),
+    (3, 0, 6, 1, ("materialid",), False), (1, 0, 20, 0, ("normal", "albedo", "depth", "materialid"), True), (1, 0, 7, 0, ("depth", "albedo"), False),
+    (3, 0, 20, 0, ("albedo", "materialid", "depth"), "ones")],
+    ids=["rgb", "rgb-joint-far-items", "rgb-r6-clamp-one-plane", "float-far-items", "float-r7", "rgb-counts-of-one-and-two"])
+def test_filter_welch_with_one_channel_gbuffers(gpu, oracle, channels, joint, radius, border, order, jump):
+    """Welch degrees of freedom x 1-channel G-buffers (depth / material id, statpath.cpp:828-835): the eight-plane Welch builds of
+    the pair-symmetric kernel.  Beside eight feature planes the CU's LDS has room for one more plane per staged row, so the
+    ring holds n - 1 and every tap forms E = v * v / (n - 1) itself, with the oracle's own rounding (an IEEE division) --
+    against the oracle and the general kernel, with sample counts that jump inside a tile (work items that leave the quantile
+    band and are computed again from the whole table) and with counts of 1 and 2 (E = x / 0: inf or NaN, as in the oracle).
+    On a block + halo image the product is refused (sharding.block_image_channels raises): such an image carries either the
+    sample counts or the 1-channel features."""
     from statmc_amd import sharding
     feats = ("radiance", "normal", "albedo", "depth", "materialid")
-    _, smp, st = make_case(120, 36, 5, seed=77, features=feats)
+    W, H = 280, 30
+    _, smp, st = make_case(W, H, 5, seed=77 + radius + channels, features=feats)
     rad = st["radiance"]
+    if jump == "ones":
+        rad["n"][:, 100:180] = 1
+        rad["n"][:, 180:230] = 2
+    elif jump:
+        rad["n"][:, 150:] = 2600
     pick = (lambda a: a) if channels == 3 else (lambda a: np.ascontiguousarray(a[..., :1]))
-    ospec = oracle.FilterSpec(dof=1)
+    spec_kw = dict(dof=1, channel_rule=joint, border=border)
+    ospec = oracle.FilterSpec(**spec_kw)
     mc, disc = oracle.prepass(rad["n"], pick(rad["mean"]), pick(rad["m2"]), pick(rad["m3"]), spec=ospec)
     colour = pick(rad["film_mean"])
     sds = dict(normal=SD_NORMAL, albedo=SD_ALBEDO, depth=2.0, materialid=0.5)
-    order = ("normal", "albedo", "depth")
     gbs = [st[g]["mean"] for g in order]
     g_dr = [-0.5 / sds[g] ** 2 for g in order]
-    ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / FILTER_SD ** 2, RADIUS, spec=ospec, n=rad["n"])
-    gpu.set_filter_spec(dof=1)
+    sd = radius / 2.0
+    ref = oracle.filter_image(mc, disc, colour, gbs, g_dr, -0.5 / sd ** 2, radius, spec=ospec, n=rad["n"])
+    lib = gpu.load()
+    lib.statmc_debug_welch_far_items.restype = C.c_int
+    gpu.set_filter_spec(**spec_kw)
     try:
-        out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, FILTER_SD, RADIUS, channels=channels, n=rad["n"])
-        # the same spec with the two RGB G-buffers alone stays on the pair-symmetric kernel
-        _, v6 = run_filter(gpu, mc, disc, colour, gbs[:2], g_dr[:2], FILTER_SD, RADIUS, channels=channels, n=rad["n"])
+        out, v = run_filter(gpu, mc, disc, colour, gbs, g_dr, sd, radius, channels=channels, n=rad["n"])
+        far = lib.statmc_debug_welch_far_items()
+        out_g, v_g = run_filter(gpu, mc, disc, colour, gbs, g_dr, sd, radius, channels=channels, n=rad["n"], force=1)
     finally:
         gpu.set_filter_spec()
-    assert v == "generic", v
-    assert v6 == ("sym_welch" if channels == 3 else "sym_welch_f"), v6
+    assert v == "sym_welch" + ("_f" if channels == 1 else "") + "_g8" + ("_joint" if joint and channels == 3 else "") + ("_clamp" if border else ""), v
+    assert v_g == "generic"
+    assert (far > 0) == (jump is True), far
+    finite = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(out), finite)
     for c in range(channels):
-        assert rel_l2(out[..., c], ref[..., c]) <= TOL, c
+        assert rel_l2(np.where(finite, out, 0)[..., c], np.where(finite, ref, 0)[..., c]) <= TOL, c
+        assert rel_l2(np.where(finite, out_g, 0)[..., c], np.where(finite, ref, 0)[..., c]) <= TOL, c
     with pytest.raises(ValueError):
         sharding.block_image_channels([3, 3, 1], welch=True)
 
@@ -900,15 +920,20 @@ def test_filter_float_multibuffer_fast_path(gpu, oracle, n_buffers, radius, vari
             assert rel_l2(args["film_filtered"][b].cpu().numpy(), refs[b]) <= TOL, (name, b)
 
 
-@pytest.mark.parametrize("radius,border", [(20, 0), (6, 1)], ids=["r20", "r6-clamp"])
-def test_filter_float_multibuffer_welch(gpu, oracle, radius, border):
+@pytest.mark.parametrize("radius,border,g8", [(20, 0, False), (6, 1, False), (20, 0, True), (9, 1, True)], ids=["r20", "r6-clamp", "r20-eight-planes", "r9-clamp-eight-planes"])
+def test_filter_float_multibuffer_welch(gpu, oracle, radius, border, g8):
     """filter<float> under Welch degrees of freedom: three buffers with DIFFERENT sample counts (5, 9 and 2 400 samples; two
     buffers share a launch of the pair-symmetric kernel's Welch build, each with its own counts, its own test and its own
     band entries -- 5 next to 2 400 leaves the band: those work items take the far build), against the oracle per buffer
     and against the general kernel."""
     W, H = 276, 27
-    _, smp, st = make_case(W, H, 9, seed=61)
+    _, smp, st = make_case(W, H, 9, seed=61, features=("radiance", "normal", "albedo", "depth", "materialid") if g8 else ("radiance", "normal", "albedo"))
     gbs = [st["normal"]["mean"], st["albedo"]["mean"]]
+    g_drs, g_sds = list(G_DR), [SD_NORMAL, SD_ALBEDO]
+    if g8:      # + depth and material id: the eight-plane Welch build, the second buffer's n - 1 in a plane of its own
+        gbs += [st["depth"]["mean"], st["materialid"]["mean"]]
+        g_sds += [2.0, 0.5]
+        g_drs += [-0.5 / 2.0 ** 2, -0.5 / 0.5 ** 2]
     lum = smp["radiance"].mean(axis=3, keepdims=True)
     spec = oracle.FilterSpec(dof=1, border=border)
     refs, args = [], dict(n=[], mean=[], m2=[], m3=[], film=[], mean_corr=[], disc=[], film_filtered=[])
@@ -918,7 +943,7 @@ def test_filter_float_multibuffer_welch(gpu, oracle, radius, border):
         if b == 2:
             s["n"][...] = 2400          # (statistics of 9 samples under a count of 2 400: the filter only sees numbers)
         mc, dc = oracle.prepass(s["n"], s["mean"], s["m2"], s["m3"], spec=spec)
-        refs.append(oracle.filter_image(mc, dc, s["film_mean"], gbs, G_DR, -0.5 / (radius / 2.0) ** 2, radius, spec=spec, n=s["n"]))
+        refs.append(oracle.filter_image(mc, dc, s["film_mean"], gbs, g_drs, -0.5 / (radius / 2.0) ** 2, radius, spec=spec, n=s["n"]))
         for k, v in (("n", s["n"]), ("mean", s["mean"]), ("m2", s["m2"]), ("m3", s["m3"]), ("film", s["film_mean"])):
             args[k].append(to_dev(v))
         for k in ("mean_corr", "disc", "film_filtered"):
@@ -927,7 +952,7 @@ def test_filter_float_multibuffer_welch(gpu, oracle, radius, border):
     for k in args:
         args[k] = [args[k][0], args[k][2], args[k][1]]
     refs = [refs[0], refs[2], refs[1]]
-    a, keep = gpu.make_filter_args(g_buffers=[to_dev(g) for g in gbs], g_sds=[SD_NORMAL, SD_ALBEDO],
+    a, keep = gpu.make_filter_args(g_buffers=[to_dev(g) for g in gbs], g_sds=g_sds,
                                    filter_sd=radius / 2.0, radius=radius, **args)
     lib = gpu.load()
     lib.statmc_debug_welch_far_items.restype = C.c_int
@@ -935,7 +960,7 @@ def test_filter_float_multibuffer_welch(gpu, oracle, radius, border):
     try:
         gpu.filter_f32(a)
         torch.cuda.synchronize()
-        assert gpu.last_filter_variant() == "sym_welch_f" + ("_clamp" if border else "")
+        assert gpu.last_filter_variant() == "sym_welch_f" + ("_g8" if g8 else "") + ("_clamp" if border else "")
         assert lib.statmc_debug_welch_far_items() == 0          # (the last launch: the 9-sample buffer alone)
         got = [t.cpu().numpy() for t in args["film_filtered"]]
         gpu.force_filter_variant(1)

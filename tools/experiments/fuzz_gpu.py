@@ -16,6 +16,9 @@ if R20:
 WELCH = "--welch" in sys.argv      # round 4: Welch degrees of freedom half of the time (the pair-symmetric kernel's Welch build)
 if WELCH:
     sys.argv.remove("--welch")
+G8 = "--g8" in sys.argv            # round 5: filter<float> with 1-channel G-buffers six times out of ten (the eight-plane builds; with --welch
+if G8:                             # the eight-plane Welch builds, two buffers per launch with their own n - 1 planes)
+    sys.argv.remove("--g8")
 
 
 def random_spec(rng):
@@ -172,6 +175,14 @@ def float_filter_case(case):
     sd = float(rng.uniform(1, 12)); g_sds = [float(rng.uniform(0.05, 0.6)), float(rng.uniform(0.02, 0.5))]
     g_dr = [-0.5 / x ** 2 for x in g_sds]
     gbs = [rng.random((H, W, 3), dtype=np.float32) * 2 - 1, rng.random((H, W, 3), dtype=np.float32)]
+    if G8:      # (a generator of its own: the cases without --g8 stay what they were)
+        rng8 = np.random.default_rng(1000003 * 61 + case)
+        if rng8.random() < 0.6:
+            layout = [[3, 3, 1], [3, 3, 1, 1], [1, 3], [1], [3, 1, 1], [1, 3, 1, 3]][int(rng8.integers(0, 6))]
+            gbs = [(rng8.random((H, W, c), dtype=np.float32) * 2 - (i % 2)).astype(np.float32) for i, c in enumerate(layout)]
+            if rng8.random() < 0.3:
+                gbs = [(np.round(g * 2) / 2).astype(np.float32) for g in gbs]
+            g_dr = [-0.5 / float(10 ** rng8.uniform(-1.5, 0)) ** 2 for _ in layout]
     mcs = [rng.standard_normal((H, W, 1)).astype(np.float32) for _ in range(nb)]
     dcs = [((rng.random((H, W, 1)) ** 3) * 2).astype(np.float32) for _ in range(nb)]
     cols = [rng.random((H, W, 1), dtype=np.float32) * 5 for _ in range(nb)]
