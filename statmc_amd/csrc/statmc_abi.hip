@@ -42,7 +42,7 @@ struct DeviceState {
     int acc_resident_blocks = 0, acc_umul = 1, acc_dma = 1;   // film-major accumulation
     int acc_occ = 0;                                          // experiment builds: 3 = the accumulate kernel compiled for three waves per SIMD
     int acc_grid_mode = -1, acc_dma_first = 0;                // launch shape: -1 automatic (by batch length), 0 capped grid, 1 one pass per workgroup; A/B: ring rows requested before the state
-    int tiles_umul = 2, tiles_order = 0, tiles_wg_per_cu = 0; // tile-fed accumulation (deeper prefetch of the mean-only types by default)
+    int tiles_umul = 2, tiles_order = 2, tiles_wg_per_cu = 0; // tile-fed accumulation (deeper prefetch of the mean-only types; a workgroup = four consecutive tiles of one type)
 };
 std::unordered_map<int, DeviceState> g_dev;  // guarded by g_mu
 
@@ -1431,7 +1431,7 @@ int statmc_debug_accumulate_umul(int umul) {   // film-major kernel: 2 = the mea
     STATMC_DEBUG_SET(d.acc_umul = umul == 2 ? 2 : 1);
 }
 int statmc_debug_accumulate_tiles_variant(int umul, int order, int wg_per_cu) {  // experiments (time_accumulate_tiles.py)
-    STATMC_DEBUG_SET(d.tiles_umul = umul == 2 ? 2 : 1; d.tiles_order = order ? 1 : 0; d.tiles_wg_per_cu = wg_per_cu < 0 ? 0 : wg_per_cu);
+    STATMC_DEBUG_SET(d.tiles_umul = umul == 2 ? 2 : 1; d.tiles_order = order < 0 || order > 2 ? 0 : order; d.tiles_wg_per_cu = wg_per_cu < 0 ? 0 : wg_per_cu);
 }
 int statmc_debug_force_filter_parts(int k) { return statmc_set_filter_split(k < 0 ? 0 : k); }   // the older name of the pin
 // non-zero: the library was built with an experiment switch of statmc_sym_experiments.h (never the product build)

@@ -837,14 +837,24 @@ template <int UMUL, int DMA>
 __global__ __launch_bounds__(kBlock) void accumulate_tiles_kernel(AccumulateTilesArgs a) {
     extern __shared__ __attribute__((aligned(16))) float acc_lds[];
     float *ring = DMA ? acc_lds + (threadIdx.x >> 6) * acc_ring_floats(DMA) : nullptr;
-    const long long n_items = (long long)a.n_tiles * a.n_types;
+    // a.order = 2 (the default since round 5): a workgroup = four consecutive tiles of ONE type, workgroups round-robin over the
+    // types -- the four waves' state rows are 768 contiguous bytes (192 with the types of ONE tile per workgroup, order 0, where
+    // the neighbouring tile's rows are another workgroup's, usually on another XCD: every line of the moments fetched into two L2s):
+    // + 2 - 6 % at 4 .. 64 samples per tile, 1080p and 4K (profiles/r05_tiles_order.log); CUs still hold every type at any time
+    const long long n_items = a.order == 2 ? (((long long)a.n_tiles + 3) >> 2) * 4 * a.n_types : (long long)a.n_tiles * a.n_types;
     const long long n_waves = (long long)gridDim.x * (kBlock / 64);
-    // item = (tile, type), types innermost: the waves of a workgroup work on the types of one
+    // a.order = 0 (rounds 2 - 4; A/B): item = (tile, type), types innermost: the waves of a workgroup work on the types of one
     // tile, so ALU-heavy radiance items and bandwidth-only feature items share every CU
     // (a.order = 1, experiment: tiles innermost -- neighbouring waves read neighbouring blocks of one type's arena)
     for (long long item = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); item < n_items; item += n_waves) {
-        const int tile = __builtin_amdgcn_readfirstlane(a.order ? (int)(item % a.n_tiles) : (int)(item / a.n_types));
-        const int ti = __builtin_amdgcn_readfirstlane(a.order ? (int)(item / a.n_tiles) : (int)(item % a.n_types));
+        int tile = __builtin_amdgcn_readfirstlane(a.order ? (int)(item % a.n_tiles) : (int)(item / a.n_types));
+        int ti = __builtin_amdgcn_readfirstlane(a.order ? (int)(item / a.n_tiles) : (int)(item % a.n_types));
+        if (a.order == 2) {
+            const long long q = item >> 2;
+            ti = __builtin_amdgcn_readfirstlane((int)(q % a.n_types));
+            tile = __builtin_amdgcn_readfirstlane((int)(q / a.n_types) * 4 + (int)(item & 3));
+            if (tile >= a.n_tiles) continue;
+        }
         const int x0 = a.tile_bounds[4 * tile], y0 = a.tile_bounds[4 * tile + 1];
         const int x1 = a.tile_bounds[4 * tile + 2], y1 = a.tile_bounds[4 * tile + 3];
         const int S = a.tile_samples[tile];
@@ -865,7 +875,7 @@ hipError_t launch_accumulate_tiles(const AccumulateTilesArgs &a_in, hipStream_t 
               (!t.transform || (aligned16(t.film_mean) && aligned16(t.film_m2)));
     }
     a.vec = vec ? 1 : 0;
-    const long long items = (long long)a.n_tiles * a.n_types;
+    const long long items = a.order == 2 ? (((long long)a.n_tiles + 3) >> 2) * 4 * a.n_types : (long long)a.n_tiles * a.n_types;
     const int grid = grid_for(items * 64, 256 * (a.wg_per_cu > 0 ? a.wg_per_cu : 8));  // one wave per item, at most 8 workgroups per CU
     // (the DMA walk needs the vector path: a.vec; the scalar path of unaligned images never touches the ring)
     if (a.vec && a.dma && a.umul == 2) hipLaunchKernelGGL((accumulate_tiles_kernel<2, kAccTilesDmaD>), dim3(grid), dim3(kBlock), acc_lds_bytes(kAccTilesDmaD), s, a);

@@ -45,13 +45,13 @@ offs_d = offs.to(dev); cnt = torch.full((len(tiles),), S, dtype=torch.int32, dev
 import ctypes
 lib = api.load()
 lib.statmc_debug_accumulate_tiles_variant.argtypes = [ctypes.c_int] * 3
-for umul, order, wg, dma in ((2, 0, 0, 1), (2, 0, 0, 0), (1, 0, 0, 1), (2, 0, 4, 1)):
+for umul, order, wg, dma in ((2, 2, 0, 1), (2, 0, 0, 1), (2, 2, 0, 0), (1, 2, 0, 1), (2, 2, 4, 1)):
     lib.statmc_debug_accumulate_dma(dma)
     lib.statmc_debug_accumulate_tiles_variant(umul, order, wg)
     tt = min(timeit(lambda: api.accumulate_tiles(W, H, sts, bounds, offs_d, cnt)) for _ in range(2))
     print("S=%d tiles dma %d umul %d order %d wg/cu %2d: %.3f ms (%.0f GB/s, %.3f of 8 TB/s)" % (S, dma, umul, order, wg, tt, bpp * W * H / tt / 1e6, bpp * W * H / tt / 8e9), flush=True)
 lib.statmc_debug_accumulate_dma(1)
-lib.statmc_debug_accumulate_tiles_variant(2, 0, 0)
+lib.statmc_debug_accumulate_tiles_variant(2, 2, 0)
 t_tiles = min(timeit(lambda: api.accumulate_tiles(W, H, sts, bounds, offs_d, cnt)) for _ in range(2))
 fs3 = film.FilmStats(W, H, dev, types=types); fs3.accumulate(smp)
 fs4 = film.FilmStats(W, H, dev, types=types)
