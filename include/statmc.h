@@ -177,7 +177,7 @@ typedef struct statmc_placement_info_t {
 int statmc_placement_info(statmc_placement_info_t *out);   /* current device */
 /* Gives the memory of the idle slots of the current device (backed and probed, dealt to no role: the classes nobody asked for)
  * back to the driver; returns how many, or a negative error.  Synchronises the device.  Later statmc_malloc_placed calls back
- * and probe new slots as they need them. */
+ * and probe new slots as they need them (the released addresses first). */
 int statmc_placement_trim(void);
 /* One character per GiB slot of the current device, NUL-terminated: '#' the allocator's own, a / b / c an idle slot of
  * that class, A / B / C one dealt to a role, S / T one dealt to the state / stream role without the wanted class, '?' unclear,

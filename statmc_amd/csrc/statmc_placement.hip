@@ -175,10 +175,14 @@ hipError_t split_not_a(Placement &P) {
     return hipSuccess;
 }
 
-// backs the next slot of the range with memory (and probes it, index > 0); false when the card or the range has no room left
+// backs the next slot of the range with memory -- the first hole statmc_placement_trim left, else the slot behind the last one --
+// and probes it (index > 0); false when the card or the range has no room left
 bool back_next_slot(Placement &P, hipError_t *err, size_t leave_free = 512ull << 20) {
     *err = hipSuccess;
-    if (P.slots.size() >= kReserveSlots) {
+    size_t index = P.slots.size();
+    for (size_t i = 1; i < P.slots.size(); i++)
+        if (P.slots[i].role == kReleased) { index = i; break; }
+    if (index >= kReserveSlots) {
         P.last_note = "address range used up";
         return false;
     }
@@ -193,7 +197,7 @@ bool back_next_slot(Placement &P, hipError_t *err, size_t leave_free = 512ull <<
         P.last_note = hipGetErrorString(e);
         return false;
     }
-    char *at = P.base + P.slots.size() * kSlot;
+    char *at = P.base + index * kSlot;
     hipError_t e = hipMemMap(at, kSlot, 0, s.handle, 0);
     if (e == hipSuccess) {
         e = hipMemSetAccess(at, kSlot, &P.access, 1);
@@ -204,9 +208,10 @@ bool back_next_slot(Placement &P, hipError_t *err, size_t leave_free = 512ull <<
         *err = e;
         return false;
     }
-    P.slots.push_back(s);
-    if (P.slots.size() > 1) {
-        hipError_t pe = probe_slot(P, P.slots.size() - 1);
+    if (index == P.slots.size()) P.slots.push_back(s);
+    else P.slots[index] = s;            // (a hole filled: undealt, unprobed, like a new slot)
+    if (index > 0) {
+        hipError_t pe = probe_slot(P, index);
         if (pe == hipSuccess) pe = split_not_a(P);
         if (pe != hipSuccess) {
             *err = pe;          // the slot stays mapped (unprobed = class unknown); the caller reports the error
@@ -485,9 +490,10 @@ int statmc_placement_info(statmc_placement_info_t *out) {
     out->slow_probe_ms = P.slowest_ms;
     for (size_t i = 1; i < P.slots.size(); i++) {
         const Slot &s = P.slots[i];
+        if (s.role == kReleased) continue;          // a hole in the range: no memory, no class
         const int c = classify(P, s);
         (c == kClassA ? out->slots_a : c == kClassB ? out->slots_b : c == kClassC ? out->slots_c : out->slots_unclear)++;
-        if (s.role == kPrivate || s.role == kReleased) continue;
+        if (s.role == kPrivate) continue;
         if (s.role == -1) out->slots_idle++;
         else {
             out->slab_bytes[s.role] += kSlot;
@@ -530,8 +536,8 @@ int statmc_debug_interference_probe(const void *stream_ptr, size_t stream_bytes,
 
 // Gives the memory of every idle slot (backed, probed, dealt to no role) back to the driver; the slots stay as holes in the
 // address range.  For a host that has made its allocations and wants the rest of the card for something else: the next
-// statmc_malloc_placed that needs room backs and probes new slots at the end of the range (the driver may well hand the same
-// memory out again).  Returns the number of slots released, or a negative error.
+// statmc_malloc_placed that needs room fills the holes first (new memory, probed anew; the driver may well hand the same
+// memory out again), then goes on at the end of the range.  Returns the number of slots released, or a negative error.
 int statmc_placement_trim(void) {
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
