@@ -5,6 +5,7 @@
 //   free      every workgroup stores when its pass is done (what the kernel does)
 //   barrier1  a soft grid barrier BEFORE the stores (every workgroup has finished reading when the first one writes)
 //   barrier2  ... and another one behind them (nobody reads again before everybody has written)
+// and, free-running, with the state of a wave (and its sample rows) in contiguous blocks instead of one plane per channel.
 // The barrier is bounded (a workgroup goes on after 40 us whatever the counter says): it cannot hang.
 // hipcc -O3 --offload-arch=gfx950 phase_probe.hip -o phase_probe && ./phase_probe [width height]
 #include <hip/hip_runtime.h>
@@ -33,7 +34,9 @@ __device__ __forceinline__ void soft_barrier(unsigned *counter, unsigned target)
 
 // thread t of the grid owns thread-items t, t + T, t + 2 T, ... (item = 4 pixels); float4 k of sample s of item i is at
 // samples[(s * kRowV + k) * n_items + i] (every load of a wave is 1 KiB in a row)
-template <int MODE>
+// LAYOUT 0: every float4 index k a plane of its own (the product's images).  1: the state of a wave's 64 items in one 28-KiB block
+// ([wave block][k][lane]).  2: ... and a wave's sample rows in one block per sample ([s][wave block][k][lane]).
+template <int MODE, int LAYOUT = 0>
 __global__ __launch_bounds__(256, 2) void phases(const vfloat4 *samples, vfloat4 *state, size_t n_items, int S, unsigned *counter) {
     const size_t T = (size_t)gridDim.x * blockDim.x;
     const size_t n_pass = (n_items + T - 1) / T;
@@ -44,17 +47,18 @@ __global__ __launch_bounds__(256, 2) void phases(const vfloat4 *samples, vfloat4
         vfloat4 st[kStateV];
         if (on) {
 #pragma unroll
-            for (int k = 0; k < kStateV; k++) st[k] = state[(size_t)k * n_items + i];
+            for (int k = 0; k < kStateV; k++) st[k] = LAYOUT >= 1 ? state[(i >> 6) * (kStateV * 64) + k * 64 + (i & 63)] : state[(size_t)k * n_items + i];
             for (int s = 0; s < S; s++) {
-                const vfloat4 *row = samples + (size_t)s * kRowV * n_items + i;
+                const vfloat4 *row = LAYOUT >= 2 ? samples + (size_t)s * kRowV * n_items + (i >> 6) * (kRowV * 64) + (i & 63) : samples + (size_t)s * kRowV * n_items + i;
+                const size_t kstride = LAYOUT >= 2 ? 64 : n_items;
 #pragma unroll
-                for (int k = 0; k < kRowV; k++) st[k] += __builtin_nontemporal_load(row + (size_t)k * n_items);
+                for (int k = 0; k < kRowV; k++) st[k] += __builtin_nontemporal_load(row + (size_t)k * kstride);
             }
         }
         if (MODE >= 1) soft_barrier(counter, ++phase * gridDim.x);
         if (on) {
 #pragma unroll
-            for (int k = 0; k < kStateV; k++) state[(size_t)k * n_items + i] = st[k];
+            for (int k = 0; k < kStateV; k++) (LAYOUT >= 1 ? state[(i >> 6) * (kStateV * 64) + k * 64 + (i & 63)] : state[(size_t)k * n_items + i]) = st[k];
         }
         if (MODE >= 2) soft_barrier(counter, ++phase * gridDim.x);
     }
@@ -82,14 +86,16 @@ int main(int argc, char **argv) {
     for (int S : {4, 16, 64}) {
         const double bytes = (double)n_items * (2.0 * kStateV * 16 + (double)S * kRowV * 16);
         printf("S = %2d (%.2f GB):", S, bytes / 1e9);
-        for (int mode = 0; mode < 3; mode++) {
+        for (int mode = 0; mode < 5; mode++) {
             std::vector<float> ms;
             for (int rep = 0; rep < 6; rep++) {
                 CHK(hipMemset(counter, 0, 4));
                 CHK(hipEventRecord(e0, nullptr));
                 if (mode == 0) hipLaunchKernelGGL(phases<0>, dim3(grid), dim3(256), 0, nullptr, samples, state, n_items, S, counter);
                 else if (mode == 1) hipLaunchKernelGGL(phases<1>, dim3(grid), dim3(256), 0, nullptr, samples, state, n_items, S, counter);
-                else hipLaunchKernelGGL(phases<2>, dim3(grid), dim3(256), 0, nullptr, samples, state, n_items, S, counter);
+                else if (mode == 2) hipLaunchKernelGGL(phases<2>, dim3(grid), dim3(256), 0, nullptr, samples, state, n_items, S, counter);
+                else if (mode == 3) hipLaunchKernelGGL((phases<0, 1>), dim3(grid), dim3(256), 0, nullptr, samples, state, n_items, S, counter);
+                else hipLaunchKernelGGL((phases<0, 2>), dim3(grid), dim3(256), 0, nullptr, samples, state, n_items, S, counter);
                 CHK(hipEventRecord(e1, nullptr));
                 CHK(hipEventSynchronize(e1));
                 float t = 0.f;
@@ -97,7 +103,7 @@ int main(int argc, char **argv) {
                 if (rep) ms.push_back(t);
             }
             std::sort(ms.begin(), ms.end());
-            printf("   %s %.3f ms %.2f TB/s", mode == 0 ? "free" : mode == 1 ? "barrier1" : "barrier2", ms[ms.size() / 2], bytes / ms[ms.size() / 2] / 1e9);
+            printf("   %s %.3f ms %.2f TB/s", mode == 0 ? "free" : mode == 1 ? "barrier1" : mode == 2 ? "barrier2" : mode == 3 ? "state-blocked" : "all-blocked", ms[ms.size() / 2], bytes / ms[ms.size() / 2] / 1e9);
         }
         printf("\n");
         fflush(stdout);
