@@ -981,7 +981,8 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     }
 
     unsigned long long t_start = 0, t_swept = 0, c_pro = 0, s_hk = 0, s_ev = 0, s_bar = 0;
-    if constexpr (kStamps) t_start = __builtin_amdgcn_s_memtime();
+    unsigned long long rt_start = 0;     // (the 100 MHz counter every XCD shares: when, within the launch, the item started)
+    if constexpr (kStamps) { t_start = __builtin_amdgcn_s_memtime(); rt_start = __builtin_amdgcn_s_memrealtime(); }
     int part, tile, n_parts;
     if (!a.sym.parts_hi || u < a.sym.n_lo_items) {
         n_parts = a.n_parts;
@@ -1268,7 +1269,11 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
         __syncthreads();
         if (lane == 0 && s_a < s_b) {
             patch[a.sym.item_stride4 - 8 + wave] = make_float4((float)s_hk, (float)s_ev, (float)s_bar, (float)(s_b - s_a));
-            patch[a.sym.item_stride4 - 16 + wave] = make_float4((float)c_pro, (float)(t_end - t_swept), (float)(t_end - t_start), 0.f);
+            patch[a.sym.item_stride4 - 16 + wave] = make_float4((float)c_pro, (float)(t_end - t_swept), (float)(t_end - t_start), (float)(rt_start & 0xFFFFFFull));
+            unsigned xcc = 0, hw = 0;      // where the wave ran (tools/experiments/stamps_roi.py)
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            patch[a.sym.item_stride4 - 24 + wave] = make_float4(__uint_as_float(xcc), __uint_as_float(hw), __uint_as_float(blockIdx.x), 0.f);
         }
     }
 }
