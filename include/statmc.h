@@ -86,9 +86,8 @@ int statmc_copy_device_settings(int src_device, int dst_device);
  *   every gate x channel rule x border, per-pixel dof, <= 2 RGB + <= 2 one-channel G-buffers   pair-symmetric LDS kernel   1.4 - 1.9 ms
  *   ... float buffers under the asymmetric / centre gate                                       one-sided LDS kernel        2.1 ms per 3 buffers
  *   Welch dof (dof = 1), <= 2 RGB G-buffers, any channel rule / border, RGB or float buffers   pair-symmetric Welch build  3.5 ms (1.5 per float buffer)
- *   Welch dof x one-channel G-buffers (depth, material id), RGB or float buffers               eight-plane Welch build     4.2 ms (1.85 per float buffer); on a
- *                                                                                              block + halo image: STATMC_ERR_UNSUPPORTED (such an image
- *                                                                                              carries the sample counts OR the one-channel features)
+ *   Welch dof x one-channel G-buffers (depth, material id), RGB or float buffers               eight-plane Welch build     4.2 ms (1.85 per float buffer); block +
+ *                                                                                              halo images: the 18-channel layout
  *   Welch dof x clamped border on a block + halo image (multi-GPU)                             STATMC_ERR_UNSUPPORTED (one device: Welch build + border kernel)
  *   radius > 20, more than eight feature channels, G-buffers of other channel counts          general kernel ("generic")
  * All of them return the CPU oracle's results to <= 1e-5 (tests/test_gpu_parity.py::test_filter_spec_variants_match_oracle). */
@@ -254,10 +253,12 @@ typedef struct statmc_filter_args {
      * 1096-1130; slots = the call's RGB G-buffers in argument order, then its 1-channel ones; an absent one is 0),
      * or a [height][width][16] image whose channel 15 holds the BITS of the pixel's int32 sample count: the layout for
      * STATMC_DOF_WELCH, whose pair test reads n_p and n_q (two RGB G-buffers; pair-symmetric kernel only; refused under
-     * STATMC_DOF_PIXEL, as a 15- or 17-channel image is under STATMC_DOF_WELCH).
+     * STATMC_DOF_PIXEL, as a 15- or 17-channel image is under STATMC_DOF_WELCH), or a [height][width][18] image with both:
+     * channels 15, 16 the two 1-channel G-buffers, channel 17 the count's bits (STATMC_DOF_WELCH with depth / material id
+     * among the G-buffers: the eight-plane Welch builds).
      * When set, statmc_window_filter (T = float3, radius <= 20, n_buffers = 1) reads its inputs from it and ignores
-     * mean_corr / discriminator / film / g_buffers (g_dr_factors and, for 17 channels, g_channel_counts still describe
-     * the G-buffers: 15 channels = two RGB; 17 = up to two RGB + up to two 1-channel, pair-symmetric kernel only).
+     * mean_corr / discriminator / film / g_buffers (g_dr_factors and, for 17 / 18 channels, g_channel_counts still describe
+     * the G-buffers: 15 / 16 channels = two RGB; 17 / 18 = up to two RGB + up to two 1-channel, pair-symmetric kernel only).
      * statmc_pack_filter_inputs / statmc_prepass_pack fill the owned block of such an image; the channel count is the
      * image's row pitch / (cols * 4). */
     statmc_image packed_inputs;
@@ -284,7 +285,8 @@ int statmc_window_filter(const statmc_filter_args *args, int channels); /* mean_
  * width x height x 3) into the 15-channel image `packed` at pixel offset (dst_x0, dst_y0): the
  * owned block inside a block + halo image.  One pass, 60 B read + 60 B written per pixel.  A 17-channel `packed`
  * (row pitch cols * 68) takes up to two RGB and up to two 1-channel G-buffers (g_channel_counts says which); a
- * 16-channel one (row pitch cols * 64) also takes n[0] (channel 15: the count's bits). */
+ * 16-channel one (row pitch cols * 64) also takes n[0] (channel 15: the count's bits); an 18-channel one (row pitch cols * 72)
+ * takes both (the count in channel 17). */
 int statmc_pack_filter_inputs(const statmc_filter_args *args, const statmc_image *packed, int dst_x0, int dst_y0);
 
 /* statmc_prepass (T = float3, buffer 0) and statmc_pack_filter_inputs in one pass over the block:

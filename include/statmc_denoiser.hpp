@@ -1505,15 +1505,13 @@ class FilmShards {
 
   private:
     // The block + halo images for the filter spec of the Estimator's device: 15 channels for the shipped two RGB G-buffers,
-    // 17 with depth / material id, 16 under Welch degrees of freedom (+ the sample count, which the pair test reads).
+    // 17 with depth / material id, 16 / 18 under Welch degrees of freedom (+ the sample count, which the pair test reads).
     void layOutPacked() {
         statmc_filter_spec spec;
         check(statmc_set_device(est.deviceIndex()));
         check(statmc_get_filter_spec(&spec));
         const bool welch = spec.dof == STATMC_DOF_WELCH;
-        if (welch && !plainTwoRgb)
-            throw Error(STATMC_ERR_UNSUPPORTED, "FilmShards: Welch degrees of freedom need exactly two RGB G-buffers (the sample count takes the image's 16th channel)");
-        const int want = welch ? 16 : plainTwoRgb ? 15 : 17;
+        const int want = welch ? (plainTwoRgb ? 16 : 18) : plainTwoRgb ? 15 : 17;
         if (want == pch) return;
         pch = want;
         for (Block &B : blocks) {

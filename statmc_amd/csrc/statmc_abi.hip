@@ -258,15 +258,16 @@ int check_image(const statmc_image &im, int w, int h, int channels, const char *
 
 
 // Channels per pixel of a block + halo image: 15 (mean-corr, discriminator, colour, two RGB G-buffers), 16 (+ the sample
-// count, as its bits: Welch degrees of freedom read it per pair) or 17 (+ two 1-channel G-buffers: depth, material id --
-// statpath.cpp:828-835); 0 = none of them.
+// count, as its bits: Welch degrees of freedom read it per pair), 17 (+ two 1-channel G-buffers: depth, material id --
+// statpath.cpp:828-835) or 18 (both: channels 15, 16 the 1-channel G-buffers, channel 17 the count); 0 = none of them.
 int packed_channels(const statmc_image &im) {
     if (im.cols <= 0) return 0;
-    if (im.step == (size_t)im.cols * 15 * 4) return 15;
-    if (im.step == (size_t)im.cols * 16 * 4) return 16;
-    if (im.step == (size_t)im.cols * 17 * 4) return 17;
+    for (int ch = 15; ch <= 18; ch++)
+        if (im.step == (size_t)im.cols * ch * 4) return ch;
     return 0;
 }
+inline bool packed_has_counts(int ch) { return ch == 16 || ch == 18; }
+inline bool packed_has_scalars(int ch) { return ch == 17 || ch == 18; }
 // The G-buffers of a call sorted into the slots of the packed image: up to two RGB images (argument order), then up to
 // two 1-channel images (argument order).  15 channels: exactly two RGB images, as the reference's shipped configurations have.
 struct PackedSlots {
@@ -277,12 +278,12 @@ int packed_slots(const statmc_filter_args *a, int ch, int W, int H, PackedSlots 
         if (a->n_g_buffers != 2 || !a->g_buffers || (a->g_channel_counts && (a->g_channel_counts[0] != 3 || a->g_channel_counts[1] != 3)))
             return fail(STATMC_ERR_INVALID, "a 15- or 16-channel block + halo image holds exactly two RGB G-buffers");
     } else if (!a->g_buffers || !a->g_channel_counts || a->n_g_buffers > 4) {
-        return fail(STATMC_ERR_INVALID, "a 17-channel block + halo image holds up to two RGB and two 1-channel G-buffers (g_channel_counts needed)");
+        return fail(STATMC_ERR_INVALID, "a 17- or 18-channel block + halo image holds up to two RGB and two 1-channel G-buffers (g_channel_counts needed)");
     }
     int n_rgb = 0, n_sc = 0;
     for (size_t g = 0; g < a->n_g_buffers; g++) {
         const int gc = a->g_channel_counts ? a->g_channel_counts[g] : 3;
-        if ((gc != 1 && gc != 3) || (gc == 3 && n_rgb == 2) || (gc == 1 && (n_sc == 2 || ch != 17)))
+        if ((gc != 1 && gc != 3) || (gc == 3 && n_rgb == 2) || (gc == 1 && (n_sc == 2 || !packed_has_scalars(ch))))
             return fail(STATMC_ERR_UNSUPPORTED, "g_buffers[%zu]: %d channels do not fit the %d-channel block + halo image", g, gc, ch);
         if (int rc = check_image(a->g_buffers[g], W, H, gc, "g_buffers", (int)g)) return rc;
         (gc == 3 ? out.rgb[n_rgb++] : out.sc[n_sc++]) = static_cast<const float *>(a->g_buffers[g].data);
@@ -609,15 +610,15 @@ static int window_filter_impl(const statmc_filter_args *a, int channels) {
     apply_spec(dstate, k, a);
     if (k.dof == STATMC_DOF_WELCH) {
         if (!k.tq) return fail(STATMC_ERR_HIP, "quantile table of the device not found");
-        if (packed_in ? packed_channels(a->packed_inputs) != 16 : !a->n)
-            return fail(STATMC_ERR_INVALID, "Welch dof: the window filter reads the sample counts (args->n, or channel 15 of a 16-channel block + halo image)");
+        if (packed_in ? !packed_has_counts(packed_channels(a->packed_inputs)) : !a->n)
+            return fail(STATMC_ERR_INVALID, "Welch dof: the window filter reads the sample counts (args->n, or the last channel of a 16- or 18-channel block + halo image)");
     }
     const bool packed = a->packed_inputs.data != nullptr;
     if (packed) {
         // block + halo path: everything the window filter reads comes from one 15- or 17-channel image
         const int pch = packed_channels(a->packed_inputs);
         if (channels != 3 || a->n_buffers != 1 || !a->g_dr_factors || pch == 0)
-            return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs: needs T = float3, n_buffers = 1 and a packed 15-, 16- or 17-channel image");
+            return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs: needs T = float3, n_buffers = 1 and a packed 15-, 16-, 17- or 18-channel image");
         CHECK_IMG(a->packed_inputs, pch, "packed_inputs", 0);
         if (!a->film_filtered) return fail(STATMC_ERR_INVALID, "null film_filtered table");
         CHECK_IMG(a->film_filtered[0], 3, "film_filtered", 0);
@@ -630,7 +631,7 @@ static int window_filter_impl(const statmc_filter_args *a, int channels) {
             }
         } else {
             if (a->n_g_buffers > 4 || !a->g_channel_counts)
-                return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (17 channels): up to two RGB and two 1-channel G-buffers, g_channel_counts needed");
+                return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (17 / 18 channels): up to two RGB and two 1-channel G-buffers, g_channel_counts needed");
             for (int g = 0; g < k.n_g; g++) {
                 k.g[g].data = nullptr;
                 k.g[g].channels = a->g_channel_counts[g];
@@ -640,13 +641,15 @@ static int window_filter_impl(const statmc_filter_args *a, int channels) {
         k.packed = static_cast<const float *>(a->packed_inputs.data);
         k.packed_ch = pch;
         k.out = static_cast<float *>(a->film_filtered[0].data);
-        if (pch == 17) {
-            // eight feature planes: the pair-symmetric kernel only (the one-sided kernel has six feature slots)
-            if (!statmc::sym_eligible(k, 3))
-                return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (17 channels): runs on the pair-symmetric kernel only -- radius 1..20, DR factors "
-                                                    "finite and <= 0, STATMC_DOF_PIXEL, STATMC_BORDER_CLIP, at most two RGB and two 1-channel G-buffers");
+        if (pch == 17 || pch == 18) {
+            // eight feature planes: the pair-symmetric kernel only (the one-sided kernel has six feature slots); 18 channels: its
+            // eight-plane Welch builds, and only they
+            if ((pch == 18 && k.dof != STATMC_DOF_WELCH) || !statmc::sym_eligible(k, 3))
+                return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (17 / 18 channels): runs on the pair-symmetric kernel only -- radius 1..20, DR factors "
+                                                    "finite and <= 0, STATMC_BORDER_CLIP, at most two RGB and two 1-channel G-buffers; 17 channels under "
+                                                    "STATMC_DOF_PIXEL, 18 under STATMC_DOF_WELCH");
             if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
-            if (!statmc::sym_path_selected(k, 3)) return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (17 channels): the forced kernel variant cannot read them");
+            if (!statmc::sym_path_selected(k, 3)) return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (17 / 18 channels): the forced kernel variant cannot read them");
             statmc::sym_feature_slots(k);
             if (int rc = prepare_sym(dstate, k, a)) return rc;
         } else if (pch == 16) {
@@ -783,13 +786,13 @@ int statmc_pack_filter_inputs(const statmc_filter_args *a, const statmc_image *p
     if (!packed || !packed->data) return fail(STATMC_ERR_INVALID, "null packed image");
     if (a->n_buffers < 1 || !a->mean_corr || !a->discriminator) return fail(STATMC_ERR_INVALID, "pack needs buffer 0");
     const int pch = packed_channels(*packed);
-    if (pch == 0) return fail(STATMC_ERR_UNSUPPORTED, "packed image must have packed rows of 15, 16 or 17 channels");
+    if (pch == 0) return fail(STATMC_ERR_UNSUPPORTED, "packed image must have packed rows of 15, 16, 17 or 18 channels");
     const int W = a->width, H = a->height;
     const bool film = a->denoise_film != 0;
     if (!film && !a->film) return fail(STATMC_ERR_INVALID, "null film table");
     const statmc_image &colour = film ? a->film_buffer : a->film[0];
-    if (pch == 16) {
-        if (!a->n) return fail(STATMC_ERR_INVALID, "a 16-channel block + halo image carries the sample counts: null n table");
+    if (packed_has_counts(pch)) {
+        if (!a->n) return fail(STATMC_ERR_INVALID, "a 16- or 18-channel block + halo image carries the sample counts: null n table");
         CHECK_IMG(a->n[0], 1, "n", 0);
     }
     CHECK_IMG(a->mean_corr[0], 3, "mean_corr", 0);
@@ -803,7 +806,7 @@ int statmc_pack_filter_inputs(const statmc_filter_args *a, const statmc_image *p
     statmc::PackArgs k{static_cast<const float *>(a->mean_corr[0].data), static_cast<const float *>(a->discriminator[0].data),
                        static_cast<const float *>(colour.data), gs.rgb[0], gs.rgb[1], static_cast<float *>(packed->data),
                        W, H, packed->cols, dst_x0, dst_y0, gs.sc[0], gs.sc[1], pch,
-                       pch == 16 ? static_cast<const int32_t *>(a->n[0].data) : nullptr};
+                       packed_has_counts(pch) ? static_cast<const int32_t *>(a->n[0].data) : nullptr};
     HIP_TRY(statmc::launch_pack_inputs(k, S(a->stream)));
     return STATMC_OK;
 }
@@ -821,7 +824,7 @@ int statmc_prepass_pack_rows(const statmc_filter_args *a, const statmc_image *pa
     if (a->n_buffers < 1 || !a->n || !a->mean || !a->m2 || !a->m3)
         return fail(STATMC_ERR_INVALID, "prepass_pack needs buffer 0 (n, mean, m2, m3)");
     const int pch = packed_channels(*packed);
-    if (pch == 0) return fail(STATMC_ERR_UNSUPPORTED, "packed image must have packed rows of 15, 16 or 17 channels");
+    if (pch == 0) return fail(STATMC_ERR_UNSUPPORTED, "packed image must have packed rows of 15, 16, 17 or 18 channels");
     const int W = a->width, H = a->height;
     const bool film = a->denoise_film != 0;
     if (!film && !a->film) return fail(STATMC_ERR_INVALID, "null film table");

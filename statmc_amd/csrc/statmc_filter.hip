@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256) void combine_parts_kernel(FilterArgs a) {
     }
 }
 
-// Owned block of the five filter inputs (+ sample counts / + two 1-channel G-buffers) -> 15 / 16 / 17-channel block + halo image (one pass).
+// Owned block of the five filter inputs (+ sample counts / + two 1-channel G-buffers / + both) -> 15 / 16 / 17 / 18-channel block + halo image (one pass).
 __global__ __launch_bounds__(256) void pack_inputs_kernel(PackArgs a) {
     const long long n = (long long)a.src_w * a.src_h;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -769,9 +769,10 @@ __global__ __launch_bounds__(256) void pack_inputs_kernel(PackArgs a) {
         dst[2] = reinterpret_cast<const f3 *>(a.colour)[i];
         dst[3] = a.g0 ? reinterpret_cast<const f3 *>(a.g0)[i] : f3{0.f, 0.f, 0.f};
         dst[4] = a.g1 ? reinterpret_cast<const f3 *>(a.g1)[i] : f3{0.f, 0.f, 0.f};
-        if (a.ch == 17) {
+        if (a.ch >= 17) {
             px[15] = a.s0 ? a.s0[i] : 0.f;
             px[16] = a.s1 ? a.s1[i] : 0.f;
+            if (a.ch == 18) px[17] = __int_as_float(a.n[i]);
         } else if (a.ch == 16) {
             px[15] = __int_as_float(a.n[i]);
         }

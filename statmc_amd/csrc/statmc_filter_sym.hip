@@ -792,7 +792,7 @@ __device__ __forceinline__ void sample_counts(const FilterArgs &a, long long p, 
         n0 = a.f_n[0][p];
         n1 = a.f_active > 1 ? a.f_n[1][p] : n0;
     } else {
-        n0 = n1 = a.packed ? __float_as_int(a.packed[p * a.packed_ch + 15]) : a.n[p];
+        n0 = n1 = a.packed ? __float_as_int(a.packed[p * a.packed_ch + (a.packed_ch == 18 ? 17 : 15)]) : a.n[p];
     }
 }
 // pixel (x, yrow) of the input images (an absent G-buffer has factor 0 and is not read)
@@ -817,7 +817,8 @@ __device__ __forceinline__ Staged load_px(const FilterArgs &a, const Feat &F, in
             s.mc = px[0]; s.d = px[1]; s.col = px[2]; s.g0 = px[3]; s.g1 = px[4];
             if (a.packed_ch == 16) r.nm1 = r.nm1b = (float)__float_as_int(pf[15]) - 1.f;   // Welch builds: the sample count's bits
             if constexpr (NG == 8) {
-                if (a.packed_ch == 17) { r.s0 = pf[15]; r.s1 = pf[16]; }
+                if (a.packed_ch >= 17) { r.s0 = pf[15]; r.s1 = pf[16]; }
+                if (a.packed_ch == 18) r.nm1 = r.nm1b = (float)__float_as_int(pf[17]) - 1.f;
             }
             return r;
         }
@@ -1033,7 +1034,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             const f3 *q = reinterpret_cast<const f3 *>(pf);
             mc = q[0]; d = q[1]; col = q[2]; g0 = q[3]; g1 = q[4];
             if constexpr (NG == 8) {
-                if (a.packed_ch == 17) { sc0 = pf[15]; sc1 = pf[16]; }
+                if (a.packed_ch >= 17) { sc0 = pf[15]; sc1 = pf[16]; }
             }
         } else {
             mc = reinterpret_cast<const f3 *>(a.mean_corr)[p];
@@ -1481,9 +1482,9 @@ void sym_choose_split(FilterArgs &w, int n_cus) {
 bool sym_eligible(const FilterArgs &a, int channels) {
     if (a.radius < 1 || a.radius > sym::kR || (channels != 1 && channels != 3)) return false;
     // Welch degrees of freedom: the pair needs the sample counts -- from their own images (one RGB buffer, or two float
-    // buffers per launch), or from channel 15 of a 16-channel block + halo image (and that image is for the Welch builds only)
-    if (a.dof != STATMC_DOF_PIXEL && a.packed && a.packed_ch != 16) return false;
-    if (a.packed && a.packed_ch == 16 && a.dof != STATMC_DOF_WELCH) return false;
+    // buffers per launch), or from the last channel of a 16- / 18-channel block + halo image (and those images are for the Welch builds only)
+    if (a.dof != STATMC_DOF_PIXEL && a.packed && a.packed_ch != 16 && a.packed_ch != 18) return false;
+    if (a.packed && (a.packed_ch == 16 || a.packed_ch == 18) && a.dof != STATMC_DOF_WELCH) return false;
     // the pair-symmetric kernel implements both gates and both channel rules; the clamped border's taps beyond the image
     // are added by border_virtual_kernel
     // float buffers with the one-sided gate (four weights per pair for two buffers): one-sided kernel
@@ -1497,11 +1498,11 @@ bool sym_eligible(const FilterArgs &a, int channels) {
         if (!(a.g[g].dr <= 0.f) || !std::isfinite(a.g[g].dr)) return false;
     }
     if (n_rgb > 2 || n_sc > 2) return false;
-    if (a.packed && n_sc > 0 && a.packed_ch != 17) return false;   // 1-channel features travel in the 17-channel block + halo image
+    if (a.packed && n_sc > 0 && a.packed_ch != 17 && a.packed_ch != 18) return false;   // 1-channel features travel in the 17- / 18-channel block + halo image
     // (a 17-channel image with no 1-channel feature -- FilmShards packs every set other than exactly two RGB G-buffers that way --
     // runs the eight-plane build with its 1-channel slots at scale 0; the pack kernel writes zeros there)
-    // (Welch with 1-channel features: the eight-plane Welch builds, on whole images -- a block + halo image has either the
-    // sample counts, 16 channels, or the 1-channel features, 17; the two rules above turn that combination away)
+    // (Welch with 1-channel features: the eight-plane Welch builds -- from the separate images, or from an 18-channel block + halo
+    // image, which carries the 1-channel features AND the sample counts)
     return true;
 }
 
@@ -1517,7 +1518,7 @@ void sym_feature_slots(FilterArgs &a) {
         if (a.g[g].channels == 3 && n_rgb < 2) { a.sym.rgb[n_rgb] = a.g[g].data; a.sym.rgb_scale[n_rgb++] = scale; }
         else if (a.g[g].channels == 1 && n_sc < 2) { a.sym.sc[n_sc] = a.g[g].data; a.sym.sc_scale[n_sc++] = scale; }
     }
-    a.sym.g8 = n_sc > 0 || (a.packed && a.packed_ch == 17);
+    a.sym.g8 = n_sc > 0 || (a.packed && (a.packed_ch == 17 || a.packed_ch == 18));
 }
 
 hipError_t launch_sym(FilterArgs a, hipStream_t s) {
@@ -1531,8 +1532,8 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     const bool welch = a.dof == STATMC_DOF_WELCH;
     const bool rt = a.radius != kR || welch;    // (the Welch modes exist in the runtime-radius build only; it serves r = 20 as well)
     if (rt && a.sym.tab_rt == nullptr) return hipErrorInvalidValue;
-    if (welch && (a.tq2 == nullptr || (a.sym.g8 && a.packed) || (a.sym.pair ? (a.packed != nullptr || a.f_n[0] == nullptr || (a.f_active > 1 && a.f_n[1] == nullptr))
-                                                                 : a.packed ? a.packed_ch != 16 : a.n == nullptr)))
+    if (welch && (a.tq2 == nullptr || (a.sym.g8 && a.packed && a.packed_ch != 18) || (a.sym.pair ? (a.packed != nullptr || a.f_n[0] == nullptr || (a.f_active > 1 && a.f_n[1] == nullptr))
+                                                                 : a.packed ? (a.packed_ch != 16 && a.packed_ch != 18) : a.n == nullptr)))
         return hipErrorInvalidValue;
     // LDS-DMA staging needs whole 16-byte pieces: images 16-byte aligned, width and film x-origin multiples of 4 pixels
     auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };

@@ -231,9 +231,10 @@ __global__ __launch_bounds__(kBlock) void prepass_pack_kernel(PrepassPackArgs a)
         dst[2] = reinterpret_cast<const f3p *>(a.colour)[i];
         dst[3] = a.g0 ? reinterpret_cast<const f3p *>(a.g0)[i] : zero;
         dst[4] = a.g1 ? reinterpret_cast<const f3p *>(a.g1)[i] : zero;
-        if (a.ch == 17) {
+        if (a.ch >= 17) {
             px[15] = a.s0 ? a.s0[i] : 0.f;
             px[16] = a.s1 ? a.s1[i] : 0.f;
+            if (a.ch == 18) px[17] = __int_as_float(ni);
         } else if (a.ch == 16) {
             px[15] = __int_as_float(ni);
         }

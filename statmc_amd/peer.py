@@ -44,7 +44,7 @@ class PeerBlock:
                                      g_buffers=g_buffers, g_sds=g_sds, placed=placed)
         self.g_channels = [film.STAT_TYPES[g]["channels"] for g in self.fs.g_names]
         api.check(api.load().statmc_set_device(self.device_index))
-        # (laid out for the device's filter spec at this moment: 16 channels under Welch degrees of freedom)
+        # (laid out for the device's filter spec at this moment: 16 / 18 channels under Welch degrees of freedom)
         self.channels = sharding.block_image_channels(self.g_channels, api.get_filter_spec().dof == api.DOF_WELCH)
         self.packed = layout.new_padded(self.channels, self.dev)
         self.out_pad = layout.new_padded(3, self.dev)

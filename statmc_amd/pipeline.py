@@ -33,7 +33,7 @@ class BlockPipeline:
             # block + halo: one 15-channel image (mean-corr, discriminator, colour, normal, albedo per
             # pixel) is what the pack kernel writes, the halo exchange moves and the filter reads; with 1-channel
             # G-buffers (depth, material id) it has 17 channels, under Welch degrees of freedom (the device's filter spec
-            # at this moment) 16: + the sample count
+            # at this moment) 16 / 18: + the sample count
             welch = api.get_filter_spec().dof == api.DOF_WELCH
             self.packed = layout.new_padded(sharding.block_image_channels(self.g_channels, welch), device)
             self.out_pad = layout.new_padded(3, device)

@@ -98,13 +98,10 @@ class BlockLayout:
 
 def block_image_channels(g_channels, welch=False):
     """Channels per pixel of a block + halo image: 15 (mean-corr, discriminator, colour, two RGB G-buffers), 17 with
-    1-channel G-buffers (depth, material id), 16 under Welch degrees of freedom (STATMC_DOF_WELCH: + the sample count,
-    which the pair test reads; two RGB G-buffers only -- an image carries the counts or the 1-channel features, not both: on one
-    device Welch x 1-channel G-buffers runs the eight-plane Welch builds from the separate images)."""
+    1-channel G-buffers (depth, material id); under Welch degrees of freedom (STATMC_DOF_WELCH) + the sample count, which the
+    pair test reads: 16 and 18 (channels 15, 16 the 1-channel G-buffers, channel 17 the count: the eight-plane Welch builds)."""
     if welch:
-        if list(g_channels) != [3, 3]:
-            raise ValueError("Welch degrees of freedom: the block + halo image holds two RGB G-buffers, no 1-channel ones")
-        return 16
+        return 16 if list(g_channels) == [3, 3] else 18
     # exactly two RGB G-buffers: the 15-channel image; every other set of up to two RGB and two 1-channel images: 17 channels,
     # absent slots zero (what statmc::FilmShards does on the C++ side)
     return 15 if list(g_channels) == [3, 3] else 17

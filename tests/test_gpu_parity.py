@@ -805,8 +805,7 @@ def test_filter_welch_with_one_channel_gbuffers(gpu, oracle, channels, joint, ra
     ring holds n - 1 and every tap forms E = v * v / (n - 1) itself, with the oracle's own rounding (an IEEE division) --
     against the oracle and the general kernel, with sample counts that jump inside a tile (work items that leave the quantile
     band and are computed again from the whole table) and with counts of 1 and 2 (E = x / 0: inf or NaN, as in the oracle).
-    On a block + halo image the product is refused (sharding.block_image_channels raises): such an image carries either the
-    sample counts or the 1-channel features."""
+    On block + halo images the product travels in the 18-channel layout (tests/test_peer_gpu.py, test_multirank_gpu.py)."""
     from statmc_amd import sharding
     feats = ("radiance", "normal", "albedo", "depth", "materialid")
     W, H = 280, 30
@@ -844,8 +843,7 @@ def test_filter_welch_with_one_channel_gbuffers(gpu, oracle, channels, joint, ra
     for c in range(channels):
         assert rel_l2(np.where(finite, out, 0)[..., c], np.where(finite, ref, 0)[..., c]) <= TOL, c
         assert rel_l2(np.where(finite, out_g, 0)[..., c], np.where(finite, ref, 0)[..., c]) <= TOL, c
-    with pytest.raises(ValueError):
-        sharding.block_image_channels([3, 3, 1], welch=True)
+    assert sharding.block_image_channels([3, 3, 1], welch=True) == 18
 
 
 @pytest.mark.parametrize("channels", [1, 3])

@@ -64,8 +64,8 @@ def _run(rank, world, rows, q, dist, api, pipeline, sharding, BH=BH, g8=False):
         dev = torch.device("cuda:0")
         api.setup(0)
         api.force_filter_parts(2)            # same window-row split as the single-process run
-        welch = g8 == "welch"                # Welch degrees of freedom: the sample count travels in a 16-channel image
-        g8 = g8 is True
+        welch = g8 in ("welch", "welch8")    # Welch degrees of freedom: the sample count travels in a 16-channel image (18 with depth / material id)
+        g8 = g8 is True or g8 == "welch8"
         if welch:
             api.set_filter_spec(dof=1)
         L = sharding.BlockLayout(rank, world, BW, BH, RADIUS, grid=_grid(world, rows))
@@ -73,31 +73,32 @@ def _run(rank, world, rows, q, dist, api, pipeline, sharding, BH=BH, g8=False):
         smp = {k: v[:, oy:oy + BH, ox:ox + BW].contiguous().to(dev) for k, v in _film_samples(world, rows, BH, g8).items()}
         pipe = pipeline.BlockPipeline(L, dev, TYPES8 if g8 else TYPES, radius=RADIUS, via_host=True,
                                       **(dict(g_buffers=G8) if g8 else {}))
-        assert pipe.packed.shape[2] == (17 if g8 else 16 if welch else 15)
+        assert pipe.packed.shape[2] == ((18 if welch else 17) if g8 else 16 if welch else 15)
         # row strips tall enough for it take the overlapped order: the rows a neighbour needs first, the exchange started,
         # the rest accumulated behind it (BlockPipeline.accumulate_and_denoise); everything else the plain order
         overlapped = bool(pipe.border_rows())
         out = pipe.accumulate_and_denoise(smp).clone()
         torch.cuda.synchronize()
-        assert api.last_filter_variant() == ("sym_r20_g8" if g8 else "sym_welch" if welch else "sym_r20")
+        assert api.last_filter_variant() == (("sym_welch_g8" if welch else "sym_r20_g8") if g8 else "sym_welch" if welch else "sym_r20")
         assert overlapped == (rows and BH >= 2 * RADIUS + 8)
         q.put((rank, ox, oy, out.cpu().numpy()))
         dist.barrier()
 
 
 @pytest.mark.parametrize("world,rows,BH,g8", [(2, False, 40, False), (4, False, 40, False), (3, True, 40, False), (3, True, 56, False),
-                                              (2, True, 64, False), (2, False, 40, True), (3, True, 56, True), (2, True, 64, "welch")],
+                                              (2, True, 64, False), (2, False, 40, True), (3, True, 56, True), (2, True, 64, "welch"), (2, True, 64, "welch8")],
                          ids=["2x1", "2x2", "1x3-rows", "1x3-rows-overlapped", "1x2-rows-overlapped", "2x1-eight-planes",
-                              "1x3-rows-overlapped-eight-planes", "1x2-rows-overlapped-welch"])
+                              "1x3-rows-overlapped-eight-planes", "1x2-rows-overlapped-welch", "1x2-rows-overlapped-welch-eight-planes"])
 def test_blocks_equal_whole_film(gpu, world, rows, BH, g8):
     """(The window-sweep split is pinned to the same value on both sides -- statmc_set_filter_split, the declared
     per-device setting: that is what makes the comparison bit for bit; tests/test_gpu_fullsize.py has the default dispatch.)"""
     from statmc_amd import pipeline, sharding
     dev = torch.device("cuda:0")
     gx, gy = _grid(world, rows)
+    mode = g8
+    welch = g8 in ("welch", "welch8")
+    g8 = g8 is True or g8 == "welch8"
     whole = _film_samples(world, rows, BH, g8)
-    welch = g8 == "welch"
-    g8 = g8 is True
     gpu.force_filter_parts(2)
     if welch:
         gpu.set_filter_spec(dof=1)
@@ -112,7 +113,7 @@ def test_blocks_equal_whole_film(gpu, world, rows, BH, g8):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(rk, world, rows, port, q, BH, "welch" if welch else g8)) for rk in range(world)]
+    procs = [ctx.Process(target=_worker, args=(rk, world, rows, port, q, BH, mode)) for rk in range(world)]
     for p in procs:
         p.start()
     got = []

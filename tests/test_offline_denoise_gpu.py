@@ -187,6 +187,23 @@ def test_sharded_denoise_through_the_cpp_host(gpu, tmp_path, grid):
             outs["welch", g] = pfm.read_pfm("%s-%d-film-f.pfm" % (stem, spp))
         assert np.array_equal(outs["welch", grid], outs["welch", None])
         assert not np.array_equal(outs["welch", None], outs[None])
+        # ... and with depth among the G-buffers (`filterbuffers ["depth" "normal" "albedo"]`): the 18-channel image, the eight-plane
+        # Welch builds; stat types in the Estimator's order: t1 depth, t2 normal, t3 albedo
+        _, smp8, st8 = make_case(W, H, spp, seed=9, features=("radiance", "normal", "albedo", "depth"))
+        stem8 = str(tmp_path / "scene8")
+        rad8 = st8["radiance"]
+        for name, img in {"film": rad8["film_mean"], "t0-b0-n": rad8["n"], "t0-b0-mean": rad8["mean"], "t0-b0-m2": rad8["m2"],
+                          "t0-b0-m3": rad8["m3"], "t1-b0-film-mean": st8["depth"]["mean"], "t2-b0-film-mean": st8["normal"]["mean"],
+                          "t3-b0-film-mean": st8["albedo"]["mean"]}.items():
+            pfm.write_pfm("%s-%d-%s.pfm" % (stem8, spp, name), img)
+        for g in (None, grid):
+            cmd = [exe, "--stem", stem8, "--spp", str(spp), "--output", "film-f", "--parts", "2", "--spec", "dof=welch",
+                   "--filterbuffers", "depth,normal,albedo", "--filterbuffersds", "2.0,0.1,0.02"] + (["--grid", g] if g else [])
+            out = subprocess.run(cmd, capture_output=True, text=True)
+            assert out.returncode == 0, out.stderr
+            outs["welch8", g] = pfm.read_pfm("%s-%d-film-f.pfm" % (stem8, spp))
+        assert np.isfinite(outs["welch8", None]).all() and np.abs(outs["welch8", None] - rad8["film_mean"]).max() > 0
+        assert np.array_equal(outs["welch8", grid], outs["welch8", None])
 
 
 def test_cv_adaptor_matches_the_library(gpu, tmp_path):

@@ -16,17 +16,19 @@ G8 = ("materialid", "depth", "normal", "albedo")
 
 @pytest.mark.parametrize("grid,bw,bh,g8,radius", [((1, 3), 272, 56, False, 20), ((2, 2), 144, 40, False, 20), ((2, 1), 136, 48, True, 20),
                                                   ((1, 2), 260, 64, True, 6), ((1, 4), 128, 24, False, 20), ((1, 2), 272, 64, "welch", 20),
-                                                  ((2, 2), 144, 40, "welch", 7), ((1, 2), 272, 64, "one-rgb", 20)],
+                                                  ((2, 2), 144, 40, "welch", 7), ((1, 2), 272, 64, "one-rgb", 20), ((1, 2), 272, 64, "welch8", 20),
+                                                  ((2, 2), 144, 40, "welch8", 9)],
                          ids=["1x3-overlapped", "2x2", "2x1-eight-planes", "1x2-overlapped-eight-planes-r6", "1x4-short-strips",
-                              "1x2-overlapped-welch", "2x2-welch-r7", "1x2-one-rgb-gbuffer-in-the-17-channel-image"])
+                              "1x2-overlapped-welch", "2x2-welch-r7", "1x2-one-rgb-gbuffer-in-the-17-channel-image",
+                              "1x2-overlapped-welch-eight-planes", "2x2-welch-eight-planes-r9"])
 def test_peer_film_equals_whole_film(gpu, grid, bw, bh, g8, radius):
     from statmc_amd import peer, pipeline, sharding, synthetic
     gx, gy = grid
     world = gx * gy
     # "welch": Welch degrees of freedom (the device's filter spec): the block + halo image has a 16th channel, the sample count
-    welch = g8 == "welch"
+    welch = g8 in ("welch", "welch8")    # "welch8": + depth and material id among the G-buffers -- the 18-channel image, eight-plane Welch builds
     one_rgb = g8 == "one-rgb"      # any set other than exactly two RGB G-buffers travels in the 17-channel image, 1-channel slots empty
-    g8 = g8 is True
+    g8 = g8 is True or g8 == "welch8"
     types = TYPES8 if g8 else TYPES
     kw = dict(g_buffers=G8) if g8 else dict(g_buffers=("albedo",)) if one_rgb else {}
     scene = synthetic.Scene(gx * bw, gy * bh, n_regions=7, seed=5)
@@ -42,7 +44,7 @@ def test_peer_film_equals_whole_film(gpu, grid, bw, bh, g8, radius):
             refs.append(one.denoise().clone())
         pf = peer.PeerFilm(world, bw, bh, radius, [0] * world, types, filter_sd=radius / 2.0, grid=grid, **kw)
         assert pf.overlap == (gx == 1 and bh >= 2 * radius + 8)
-        assert pf.blocks[0].packed.shape[2] == (17 if (g8 or one_rgb) else 16 if welch else 15)
+        assert pf.blocks[0].packed.shape[2] == ((18 if welch else 17) if (g8 or one_rgb) else 16 if welch else 15)
         for smp, ref in zip(batches, refs):
             per_block = []
             for blk in pf.blocks:
@@ -54,7 +56,7 @@ def test_peer_film_equals_whole_film(gpu, grid, bw, bh, g8, radius):
             pf.synchronize()
             assert torch.equal(got, ref)
             if welch:
-                assert gpu.last_filter_variant() == "sym_welch"
+                assert gpu.last_filter_variant() == ("sym_welch_g8" if g8 else "sym_welch")
         # the plain order on a grid that overlaps by default: same bits
         if pf.overlap:
             pf.reset()

@@ -131,12 +131,11 @@ def test_blocks_smaller_than_the_radius_are_refused():
 
 def test_block_image_channel_rules():
     """15 channels: exactly two RGB G-buffers (the shipped configurations); 17: every other set of up to two RGB and two
-    1-channel images, absent slots zero (what statmc::FilmShards packs); 16: Welch degrees of freedom, two RGB G-buffers only."""
+    1-channel images, absent slots zero (what statmc::FilmShards packs); Welch degrees of freedom: + the sample count, 16 and 18."""
     from statmc_amd import sharding
     assert sharding.block_image_channels([3, 3]) == 15
     for g in ([3], [], [3, 1], [3, 3, 1, 1], [1, 3, 1], [1]):
         assert sharding.block_image_channels(g) == 17, g
     assert sharding.block_image_channels([3, 3], welch=True) == 16
-    for g in ([3], [3, 3, 1], [1, 1]):
-        with pytest.raises(ValueError):
-            sharding.block_image_channels(g, welch=True)
+    for g in ([3], [3, 3, 1], [1, 1], [3, 3, 1, 1]):
+        assert sharding.block_image_channels(g, welch=True) == 18, g
