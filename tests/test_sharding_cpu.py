@@ -38,17 +38,25 @@ def _worker(rank, world, port, bw, bh, r, rows, q, welch=False):
             "g1": rng.random((fh, fw, 3), dtype=np.float32),
         }
         ox, oy = L.origin
-        # Welch degrees of freedom: the block + halo image has a 16th channel, the bits of the pixel's int32 sample count
+        # Welch degrees of freedom: the block + halo image has a 16th channel, the bits of the pixel's int32 sample count;
+        # welch == "g8": + a depth G-buffer -- 18 channels: 15, 16 the 1-channel features (the second slot empty), 17 the count
         n_film = rng.integers(2, 40, size=(fh, fw)).astype(np.int32)
-        ch = sharding.block_image_channels([3, 3], welch)
-        assert ch == (16 if welch else 15)
+        depth = (3 * rng.random((fh, fw, 1))).astype(np.float32)
+        g8 = welch == "g8"
+        welch = bool(welch)
+        ch = sharding.block_image_channels([3, 3, 1] if g8 else [3, 3], welch)
+        assert ch == (18 if g8 else 16 if welch else 15)
+        n_at = 17 if g8 else 15
         packed = L.new_padded(ch, "cpu")
         packed.fill_(float("nan"))
         inner = L.interior(packed)
         for i, k in enumerate(("mc", "disc", "colour", "g0", "g1")):
             inner[..., 3 * i:3 * i + 3] = torch.from_numpy(film[k][oy:oy + bh, ox:ox + bw])
+        if g8:
+            inner[..., 15] = torch.from_numpy(depth[oy:oy + bh, ox:ox + bw, 0].copy())
+            inner[..., 16] = 0.0
         if welch:
-            inner[..., 15] = torch.from_numpy(n_film[oy:oy + bh, ox:ox + bw].copy()).view(torch.float32)
+            inner[..., n_at] = torch.from_numpy(n_film[oy:oy + bh, ox:ox + bw].copy()).view(torch.float32)
         if rows:   # row strips: the exchange in two halves (started, something else done, waited for) as the multi-GPU step runs it
             in_flight = sharding.exchange_halo_start(L, packed)
             busy = float(torch.ones(1000).sum())          # (what the rank does meanwhile: the rest of its accumulation)
@@ -62,22 +70,29 @@ def _worker(rank, world, port, bw, bh, r, rows, q, welch=False):
         ok_halo = np.array_equal(packed.numpy()[..., :15], want)
         n_loc = None
         if welch:
-            n_loc = np.ascontiguousarray(packed.numpy()[..., 15]).view(np.int32)
+            n_loc = np.ascontiguousarray(packed.numpy()[..., n_at]).view(np.int32)
             ok_halo = ok_halo and np.array_equal(n_loc, n_film[oy - L.pt:oy + bh + L.pb, ox - L.pl:ox + bw + L.pr])
+        if g8:
+            ok_halo = ok_halo and np.array_equal(packed.numpy()[..., 15], depth[oy - L.pt:oy + bh + L.pb, ox - L.pl:ox + bw + L.pr, 0])
         # filter the block with ROI = owned pixels, compare with the whole-film filter
         p = packed.numpy()
         loc = [np.ascontiguousarray(p[..., 3 * i:3 * i + 3]) for i in range(5)]
         drs, ds = [-0.5 / 0.3 ** 2, -0.5 / 0.5 ** 2], -0.5 / 4.0 ** 2
+        g_loc, g_film = [loc[3], loc[4]], [film["g0"], film["g1"]]
+        if g8:
+            drs = drs + [-0.5 / 1.5 ** 2]
+            g_loc.append(np.ascontiguousarray(p[..., 15:16]))
+            g_film.append(depth)
         spec = oracle.FilterSpec(dof=oracle.DOF_WELCH) if welch else None
-        out = oracle.filter_image(loc[0], loc[1], loc[2], [loc[3], loc[4]], drs, ds, r, roi=L.roi, threads=1, spec=spec, n=n_loc)
-        ref = oracle.filter_image(film["mc"], film["disc"], film["colour"], [film["g0"], film["g1"]], drs, ds, r,
+        out = oracle.filter_image(loc[0], loc[1], loc[2], g_loc, drs, ds, r, roi=L.roi, threads=1, spec=spec, n=n_loc)
+        ref = oracle.filter_image(film["mc"], film["disc"], film["colour"], g_film, drs, ds, r,
                                   roi=(ox, oy, ox + bw, oy + bh), threads=1, spec=spec, n=n_film if welch else None)
         x0, y0, x1, y1 = L.roi
         ok_filter = np.array_equal(out[y0:y1, x0:x1], ref[oy:oy + bh, ox:ox + bw])
         # final gather: the blocks assembled on rank 0 are the whole-film filter output
         whole = sharding.gather_blocks(L, torch.from_numpy(np.ascontiguousarray(out[y0:y1, x0:x1])))
         if rank == 0:
-            full = oracle.filter_image(film["mc"], film["disc"], film["colour"], [film["g0"], film["g1"]], drs, ds, r, threads=1,
+            full = oracle.filter_image(film["mc"], film["disc"], film["colour"], g_film, drs, ds, r, threads=1,
                                        spec=spec, n=n_film if welch else None)
             ok_filter = ok_filter and whole.shape == full.shape and np.array_equal(whole.numpy(), full)
         else:
@@ -88,7 +103,8 @@ def _worker(rank, world, port, bw, bh, r, rows, q, welch=False):
 
 
 @pytest.mark.parametrize("world,bw,bh,r,rows,welch", [(2, 24, 18, 5, False, False), (4, 16, 14, 6, False, False), (3, 20, 9, 4, True, False),
-                                                      (4, 12, 10, 5, True, False), (2, 20, 12, 5, True, True), (4, 14, 12, 4, False, True)])
+                                                      (4, 12, 10, 5, True, False), (2, 20, 12, 5, True, True), (4, 14, 12, 4, False, True),
+                                                      (2, 20, 12, 5, True, "g8")])
 def test_halo_exchange_and_block_filter(world, bw, bh, r, rows, welch):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
