@@ -646,8 +646,8 @@ static int window_filter_impl(const statmc_filter_args *a, int channels) {
             // eight-plane Welch builds, and only they
             if ((pch == 18 && k.dof != STATMC_DOF_WELCH) || !statmc::sym_eligible(k, 3))
                 return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (17 / 18 channels): runs on the pair-symmetric kernel only -- radius 1..20, DR factors "
-                                                    "finite and <= 0, STATMC_BORDER_CLIP, at most two RGB and two 1-channel G-buffers; 17 channels under "
-                                                    "STATMC_DOF_PIXEL, 18 under STATMC_DOF_WELCH");
+                                                    "finite and <= 0, at most two RGB and two 1-channel G-buffers; 17 channels under STATMC_DOF_PIXEL "
+                                                    "and STATMC_BORDER_CLIP, 18 under STATMC_DOF_WELCH");
             if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
             if (!statmc::sym_path_selected(k, 3)) return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (17 / 18 channels): the forced kernel variant cannot read them");
             statmc::sym_feature_slots(k);
@@ -656,7 +656,7 @@ static int window_filter_impl(const statmc_filter_args *a, int channels) {
             // + the sample counts: the Welch builds of the pair-symmetric kernel, and only they
             if (k.dof != STATMC_DOF_WELCH || !statmc::sym_eligible(k, 3))
                 return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (16 channels): for STATMC_DOF_WELCH on the pair-symmetric kernel -- radius 1..20, DR "
-                                                    "factors finite and <= 0, STATMC_BORDER_CLIP, two RGB G-buffers");
+                                                    "factors finite and <= 0, two RGB G-buffers");
             if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
             k.gscale0 = sqrtf(-k.g[0].dr * 1.44269504088896340736f);
             k.gscale1 = sqrtf(-k.g[1].dr * 1.44269504088896340736f);

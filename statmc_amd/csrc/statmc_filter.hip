@@ -68,14 +68,15 @@ namespace statmc {
 // follow oracle/statmc_oracle.c:oracle_filter_spec_run line by line (same operation order, no contraction).
 // (mc / dc / col: the buffer's corrected mean, discriminator and colour images -- a.mean_corr / a.disc / a.colour, or
 // one of the float buffers of a multi-buffer launch)
+// (S: floats between two pixels of an image -- C, or the channel count of a block + halo image the three are views of)
 template <int C>
-__device__ __forceinline__ bool pixel_valid(const float *mc, const float *dc, const float *col, long long p) {
+__device__ __forceinline__ bool pixel_valid(const float *mc, const float *dc, const float *col, long long p, int S = C) {
     bool v = true;
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        v = v && __builtin_isfinite(mc[p * C + c]);
-        v = v && !__builtin_isnan(dc[p * C + c]);
-        v = v && __builtin_isfinite(col[p * C + c]);
+        v = v && __builtin_isfinite(mc[p * S + c]);
+        v = v && !__builtin_isnan(dc[p * S + c]);
+        v = v && __builtin_isfinite(col[p * S + c]);
     }
     return v;
 }
@@ -91,22 +92,23 @@ __device__ __forceinline__ bool pixel_valid(const FilterArgs &a, long long p) {
     return pixel_valid<C>(a.mean_corr, a.disc, a.colour, p) && features_valid(a, p);
 }
 
+// (S, NS: floats / int32 between two pixels of the images and of the counts: C and 1, or a block + halo image's channel count)
 template <int C>
 __device__ __forceinline__ bool pair_member(const FilterArgs &a, const float *mc, const float *dc, const float *pc, const float *pd,
-                                            long long p, long long q, const int32_t *n = nullptr) {
+                                            long long p, long long q, const int32_t *n = nullptr, int S = C, int NS = 1) {
     if (n == nullptr) n = a.n;   // (the buffer's own counts: filter<float> with several buffers per launch)
     bool all = true;
     float lhs_sum = 0.f, rhs_sum = 0.f;
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        const float d = pc[c] - mc[q * C + c];
-        const float Dp = pd[c], Dq = dc[q * C + c];
+        const float d = pc[c] - mc[q * S + c];
+        const float Dp = pd[c], Dq = dc[q * S + c];
         float lhs, rhs;
         if (a.dof == STATMC_DOF_WELCH) {
             const float s = Dp + Dq;
             float Dsum = s;
             if (s > 0.f && __builtin_isfinite(s)) {
-                const float nu = (s * s) / (Dp * Dp / ((float)n[p] - 1.f) + Dq * Dq / ((float)n[q] - 1.f));
+                const float nu = (s * s) / (Dp * Dp / ((float)n[p * NS] - 1.f) + Dq * Dq / ((float)n[q * NS] - 1.f));
                 const int dof = nu >= 1.f ? (nu < 4096.f ? (int)nu : 4096) : 1;
                 const float t = a.tq[dof - 1];
                 Dsum = (t * t) * s;
@@ -198,9 +200,36 @@ __global__ __launch_bounds__(256) void window_filter_generic(FilterArgs a) {
 // So a pixel evaluates at most 4 x 41 (pixel, edge pixel) pairs instead of up to 1200 taps.
 // NB = 0: one RGB buffer (a.mean_corr / a.disc / a.colour).  NB = 2: the two float buffers of a filter<float> launch
 // (a.f_mean_corr[b] ...; the sums go to (x, z) and (y, w) of the float4, as combine_sym_kernel expects them).
-template <int NB>
+// PACKED (NB = 0): the inputs are the channels of a block + halo image (a.packed: mean 0..2, discriminator 3..5, colour 6..8,
+// the RGB G-buffers of the argument list from 9, its 1-channel ones from 15, the count's bits in the last channel of a 16- /
+// 18-channel image).  The local image's edges that are film edges have no halo, its other edges one of >= r pixels: a pixel of
+// the ROI has taps beyond the local image exactly where it has taps beyond the film.
+template <int NB, bool PACKED = false>
 __global__ __launch_bounds__(256) void border_virtual_kernel(FilterArgs a) {
     constexpr int C = NB == 0 ? 3 : 1;
+    static_assert(!PACKED || NB == 0, "a block + halo image holds one RGB buffer");
+    const int S = PACKED ? a.packed_ch : C;
+    // the G-buffers as (first float, channels, factor) views: the argument list's images, or their slots in the packed image
+    const float *g_data[STATMC_MAX_GBUFFERS];
+    int g_stride[STATMC_MAX_GBUFFERS];
+    {
+        int n_rgb = 0, n_sc = 0;
+        for (int g = 0; g < a.n_g; g++) {
+            if constexpr (PACKED) {
+                g_data[g] = a.g[g].channels == 3 ? a.packed + 9 + 3 * n_rgb++ : a.packed + 15 + n_sc++;
+                g_stride[g] = S;
+            } else {
+                g_data[g] = a.g[g].data;
+                g_stride[g] = a.g[g].channels;
+            }
+        }
+    }
+    auto feats_valid = [&](long long p) {
+        bool v = true;
+        for (int g = 0; g < a.n_g; g++)
+            for (int c = 0; c < a.g[g].channels; c++) v = v && __builtin_isfinite(g_data[g][p * g_stride[g] + c]);
+        return v;
+    };
     const int x = a.rx0 + blockIdx.x * 32 + (threadIdx.x & 31);
     const int y = a.ry0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= a.rx1 || y >= a.ry1) return;
@@ -221,31 +250,32 @@ __global__ __launch_bounds__(256) void border_virtual_kernel(FilterArgs a) {
 #pragma unroll
     for (int b = 0; b < kBuffers; b++) {
         if (NB != 0 && b >= a.f_active) break;
-        const float *mc = NB == 0 ? a.mean_corr : a.f_mean_corr[b];
-        const float *dc = NB == 0 ? a.disc : a.f_disc[b];
-        const float *col = NB == 0 ? a.colour : a.f_colour[b];
+        const float *mc = PACKED ? a.packed : NB == 0 ? a.mean_corr : a.f_mean_corr[b];
+        const float *dc = PACKED ? a.packed + 3 : NB == 0 ? a.disc : a.f_disc[b];
+        const float *col = PACKED ? a.packed + 6 : NB == 0 ? a.colour : a.f_colour[b];
+        const int32_t *cnt = PACKED ? reinterpret_cast<const int32_t *>(a.packed) + (a.packed_ch == 18 ? 17 : 15) : NB == 0 ? a.n : a.f_n[b];
         float pc[C], pd[C], acc[C];
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            pc[c] = mc[p * C + c];
-            pd[c] = dc[p * C + c];
+            pc[c] = mc[p * S + c];
+            pd[c] = dc[p * S + c];
             acc[c] = 0.f;
         }
         float sum_w = 0.f;
-        if (pixel_valid<C>(mc, dc, col, p) && features_valid(a, p)) {
+        if (pixel_valid<C>(mc, dc, col, p, S) && feats_valid(p)) {
             // one (pixel, edge pixel) pair: membership, range weight, times the summed spatial weight of the taps it stands for
             auto pair = [&](int qx, int qy, int d_along, float t_across) {
                 const long long q = (long long)qy * W + qx;
-                if (!pixel_valid<C>(mc, dc, col, q) || !features_valid(a, q)) return;
-                if (!pair_member<C>(a, mc, dc, pc, pd, p, q, NB == 0 ? a.n : a.f_n[b])) return;
+                if (!pixel_valid<C>(mc, dc, col, q, S) || !feats_valid(q)) return;
+                if (!pair_member<C>(a, mc, dc, pc, pd, p, q, cnt, S, PACKED ? S : 1)) return;
                 float e = a.ds * (float)(d_along * d_along);
                 for (int g = 0; g < a.n_g; g++) {
-                    const int gc = a.g[g].channels;
-                    const float *G = a.g[g].data;
-                    const float d0 = G[p * gc] - G[q * gc];
+                    const int gc = a.g[g].channels, gs = g_stride[g];
+                    const float *G = g_data[g];
+                    const float d0 = G[p * gs] - G[q * gs];
                     float dist2 = d0 * d0;
                     for (int c = 1; c < gc; c++) {
-                        const float dcc = G[p * gc + c] - G[q * gc + c];
+                        const float dcc = G[p * gs + c] - G[q * gs + c];
                         dist2 = __builtin_fmaf(dcc, dcc, dist2);
                     }
                     e = __builtin_fmaf(a.g[g].dr, dist2, e);
@@ -253,7 +283,7 @@ __global__ __launch_bounds__(256) void border_virtual_kernel(FilterArgs a) {
                 const float w = __builtin_amdgcn_exp2f(e * kLog2e) * t_across;
                 sum_w += w;
 #pragma unroll
-                for (int c = 0; c < C; c++) acc[c] = __builtin_fmaf(w, col[q * C + c], acc[c]);
+                for (int c = 0; c < C; c++) acc[c] = __builtin_fmaf(w, col[q * S + c], acc[c]);
             };
             for (int dx = -r; dx <= r; dx++) {   // rows beyond the image (corners included): edge rows, clamped column
                 const int tx = x + dx, qx = tx < 0 ? 0 : tx >= W ? W - 1 : tx;
@@ -279,7 +309,9 @@ __global__ __launch_bounds__(256) void border_virtual_kernel(FilterArgs a) {
 
 hipError_t launch_border_virtual(const FilterArgs &a, hipStream_t s) {
     const dim3 grid((a.rx1 - a.rx0 + 31) / 32, (a.ry1 - a.ry0 + 7) / 8);
-    if (a.sym.pair) hipLaunchKernelGGL(border_virtual_kernel<2>, grid, dim3(256), 0, s, a);
+    if (a.packed && a.sym.pair) return hipErrorInvalidValue;
+    if (a.packed) hipLaunchKernelGGL((border_virtual_kernel<0, true>), grid, dim3(256), 0, s, a);
+    else if (a.sym.pair) hipLaunchKernelGGL(border_virtual_kernel<2>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(border_virtual_kernel<0>, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
