@@ -646,8 +646,8 @@ static int window_filter_impl(const statmc_filter_args *a, int channels) {
             // eight-plane Welch builds, and only they
             if ((pch == 18 && k.dof != STATMC_DOF_WELCH) || !statmc::sym_eligible(k, 3))
                 return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (17 / 18 channels): runs on the pair-symmetric kernel only -- radius 1..20, DR factors "
-                                                    "finite and <= 0, at most two RGB and two 1-channel G-buffers; 17 channels under STATMC_DOF_PIXEL "
-                                                    "and STATMC_BORDER_CLIP, 18 under STATMC_DOF_WELCH");
+                                                    "finite and <= 0, at most two RGB and two 1-channel G-buffers; 17 channels under STATMC_DOF_PIXEL, "
+                                                    "18 under STATMC_DOF_WELCH");
             if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
             if (!statmc::sym_path_selected(k, 3)) return fail(STATMC_ERR_UNSUPPORTED, "packed_inputs (17 / 18 channels): the forced kernel variant cannot read them");
             statmc::sym_feature_slots(k);

@@ -17,11 +17,12 @@ G8 = ("materialid", "depth", "normal", "albedo")
 @pytest.mark.parametrize("grid,bw,bh,g8,radius", [((1, 3), 272, 56, False, 20), ((2, 2), 144, 40, False, 20), ((2, 1), 136, 48, True, 20),
                                                   ((1, 2), 260, 64, True, 6), ((1, 4), 128, 24, False, 20), ((1, 2), 272, 64, "welch", 20),
                                                   ((2, 2), 144, 40, "welch", 7), ((1, 2), 272, 64, "one-rgb", 20), ((1, 2), 272, 64, "welch8", 20),
-                                                  ((2, 2), 144, 40, "welch8", 9), ((2, 2), 144, 40, "welch-clamp", 9), ((1, 2), 272, 64, "welch8-clamp", 20)],
+                                                  ((2, 2), 144, 40, "welch8", 9), ((2, 2), 144, 40, "welch-clamp", 9), ((1, 2), 272, 64, "welch8-clamp", 20),
+                                                  ((2, 1), 136, 48, "g8-clamp", 20)],
                          ids=["1x3-overlapped", "2x2", "2x1-eight-planes", "1x2-overlapped-eight-planes-r6", "1x4-short-strips",
                               "1x2-overlapped-welch", "2x2-welch-r7", "1x2-one-rgb-gbuffer-in-the-17-channel-image",
                               "1x2-overlapped-welch-eight-planes", "2x2-welch-eight-planes-r9", "2x2-welch-clamped-border-r9",
-                              "1x2-overlapped-welch-eight-planes-clamped-border"])
+                              "1x2-overlapped-welch-eight-planes-clamped-border", "2x1-eight-planes-clamped-border"])
 def test_peer_film_equals_whole_film(gpu, grid, bw, bh, g8, radius):
     from statmc_amd import peer, pipeline, sharding, synthetic
     gx, gy = grid
@@ -31,14 +32,14 @@ def test_peer_film_equals_whole_film(gpu, grid, bw, bh, g8, radius):
     welch = "welch" in mode              # "welch8": + depth and material id among the G-buffers -- the 18-channel image, eight-plane Welch builds
     clamp = "clamp" in mode              # a clamped border on film blocks under Welch: the border kernel reads the block + halo image
     one_rgb = g8 == "one-rgb"      # any set other than exactly two RGB G-buffers travels in the 17-channel image, 1-channel slots empty
-    g8 = g8 is True or "welch8" in mode
+    g8 = g8 is True or "welch8" in mode or "g8" in mode
     types = TYPES8 if g8 else TYPES
     kw = dict(g_buffers=G8) if g8 else dict(g_buffers=("albedo",)) if one_rgb else {}
     scene = synthetic.Scene(gx * bw, gy * bh, n_regions=7, seed=5)
     batches = [scene.samples(4, seed=6, features=types), scene.samples(3, seed=7, features=types)]     # two steps: 4 + 3 samples
     gpu.set_filter_split(2)
-    if welch:
-        gpu.set_filter_spec(dof=1, border=1 if clamp else 0)
+    if welch or clamp:
+        gpu.set_filter_spec(dof=1 if welch else 0, border=1 if clamp else 0)
     try:
         one = pipeline.BlockPipeline(sharding.BlockLayout(0, 1, gx * bw, gy * bh, radius), DEV, types, radius=radius, filter_sd=radius / 2.0, **kw)
         refs = []
@@ -60,6 +61,8 @@ def test_peer_film_equals_whole_film(gpu, grid, bw, bh, g8, radius):
             assert torch.equal(got, ref)
             if welch:
                 assert gpu.last_filter_variant() == ("sym_welch_g8" if g8 else "sym_welch") + ("_clamp" if clamp else "")
+            elif clamp:
+                assert gpu.last_filter_variant() == "sym_r20_g8_clamp"
         # the plain order on a grid that overlaps by default: same bits
         if pf.overlap:
             pf.reset()
