@@ -88,8 +88,7 @@ int statmc_copy_device_settings(int src_device, int dst_device);
  *   Welch dof (dof = 1), <= 2 RGB G-buffers, any channel rule / border, RGB or float buffers   pair-symmetric Welch build  3.5 ms (1.5 per float buffer)
  *   Welch dof x one-channel G-buffers (depth, material id), RGB or float buffers               eight-plane Welch build     4.2 ms (1.85 per float buffer); block +
  *                                                                                              halo images: the 18-channel layout
- *   a clamped border on a block + halo image (multi-GPU)                                       one-sided LDS kernel (2.1 ms; 15 channels); 16 / 17 / 18 channels: the
- *                                                                                              pair-symmetric builds + the border kernel on the packed image
+ *   a clamped border on a block + halo image (multi-GPU)                                       the pair-symmetric builds + the border kernel, both on the packed image
  *   radius > 20, more than eight feature channels, G-buffers of other channel counts          general kernel ("generic")
  * All of them return the CPU oracle's results to <= 1e-5 (tests/test_gpu_parity.py::test_filter_spec_variants_match_oracle). */
 #define STATMC_GATE_SYMMETRIC 0   /* member <=> fma(d, d, -(D_p + D_q)) <= 0, i.e. d^2 <= D_p + D_q        */

@@ -670,8 +670,8 @@ static int window_filter_impl(const statmc_filter_args *a, int channels) {
             if (int rc = spatial_table(k.radius, k.ds, &k.spatial_tab)) return rc;
             k.gscale0 = sqrtf(-k.g[0].dr * 1.44269504088896340736f);
             k.gscale1 = sqrtf(-k.g[1].dr * 1.44269504088896340736f);
-            // (k.packed is set before the kernel is chosen: sym_eligible looks at it -- the clamped border's taps beyond the
-            // image are read from the five separate images, which a block + halo call does not have -> one-sided kernel)
+            // (k.packed is set before the kernel is chosen: sym_eligible looks at it; the one-sided kernel takes what the
+            // pair-symmetric one does not -- a forced variant)
             if (statmc::sym_path_selected(k, 3)) {
                 if (int rc = prepare_sym(dstate, k, a)) return rc;
             } else {

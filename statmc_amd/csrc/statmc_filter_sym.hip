@@ -1489,9 +1489,8 @@ bool sym_eligible(const FilterArgs &a, int channels) {
     // are added by border_virtual_kernel
     // float buffers with the one-sided gate (four weights per pair for two buffers): one-sided kernel
     if (a.gate != STATMC_GATE_SYMMETRIC && channels != 3 && a.dof == STATMC_DOF_PIXEL) return false;   // (Welch: one test, no gate form)
-    // a clamped border on a block + halo image: the one-sided kernel's builds know it (and hold the bits the multi-GPU tests pin);
-    // where that kernel has no build -- Welch, eight feature planes (17 / 18 channels) -- the border kernel reads the packed image
-    if (a.border == STATMC_BORDER_CLAMP && a.packed && a.packed_ch == 15) return false;
+    // (a clamped border on a block + halo image: the border kernel reads the packed image -- round 5; before, such calls ran the
+    // one-sided kernel and a block decomposition was not bit-identical to the whole film, which runs this kernel)
     int n_rgb = 0, n_sc = 0;
     for (int g = 0; g < a.n_g; g++) {
         if (a.g[g].channels == 3) n_rgb++;
@@ -1526,8 +1525,6 @@ void sym_feature_slots(FilterArgs &a) {
 hipError_t launch_sym(FilterArgs a, hipStream_t s) {
     using namespace sym;
     if (a.rx1 <= a.rx0 || a.ry1 <= a.ry0) return hipSuccess;
-    // a clamped border on a 15-channel block + halo call is the one-sided kernel's (sym_eligible; this is the guard behind it)
-    if (a.sym.border_extra && a.packed && a.packed_ch == 15) return hipErrorInvalidValue;
     a.sym.steps = a.radius + 1;
     a.sym.item_stride4 = kPatchP + (long long)q_rows_max(a.n_parts, a.sym.steps) * kP;
     const bool welch = a.dof == STATMC_DOF_WELCH;

@@ -1070,11 +1070,12 @@ def test_packed_inputs_path(gpu, oracle):
     assert e.value.code == gpu.ERR_INVALID
 
 
-@pytest.mark.parametrize("spec_kw,variant", [(dict(border=1), "lds_r20"), (dict(border=1, gate=1), "lds_rt_asym"), (dict(gate=1), "sym_r20_asym")])
+@pytest.mark.parametrize("spec_kw,variant", [(dict(border=1), "sym_r20_clamp"), (dict(border=1, gate=1), "sym_r20_asym_clamp"), (dict(gate=1), "sym_r20_asym")])
 def test_packed_inputs_under_non_default_specs(gpu, oracle, spec_kw, variant):
     """Block + halo image at r = 20 under a clamped border (this combination once selected the pair-symmetric
-    kernel, whose border pass reads the five separate images a packed call does not have): the one-sided LDS kernel must
-    take it; the result equals the oracle's on the same local image under the same spec."""
+    kernel while its border pass could only read the five separate images a packed call does not have; rounds 2 - 4 sent it to
+    the one-sided LDS kernel; since round 5 the border pass reads the packed image, and a block is filtered by the kernel
+    that filters the whole film): the result equals the oracle's on the same local image under the same spec."""
     W, H, m = 300, 56, 20
     mc, disc, colour, gbs = stats_case(oracle, W, H, 8, seed=405)
     ospec = oracle.FilterSpec(**spec_kw)
