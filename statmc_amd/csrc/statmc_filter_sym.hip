@@ -105,7 +105,7 @@ constexpr int kPx = 4;                    // pixels per lane
 constexpr int kW = 32 * kPx;              // 128 tile columns: half a wave per row
 constexpr int kRows = 8;                  // tile rows: wave (t, h) owns rows t (lanes 0-31) and t + 4 (lanes 32-63)
 constexpr int kSlots = kRows + 1;         // LDS row ring
-constexpr int kP = kW + 2 * kR;           // 296 staged columns per row
+constexpr int kP = kW + 2 * kR;           // 168 staged columns per row
 constexpr int kQ = 8;                     // accumulator planes per row: 2 copies x (r, g, b, w)
 constexpr int kThreads = 512;
 constexpr int kSteps = kR + 1;            // dy = 0 .. 20
