@@ -154,7 +154,8 @@ int statmc_free(void *dev_ptr);   /* blocks of statmc_malloc and of statmc_mallo
  *   role STATMC_MEM_STATE   images a kernel reads AND writes per launch: n, mean, m2, m3, film-mean, film-m2 (class A)
  *   role STATMC_MEM_STREAM  read-once inputs: the sample arenas of statmc_accumulate / statmc_accumulate_tiles (all in class
  *                           B while the card has room: arenas spread over B and C cost 2 - 3 % of the gain)
- * Blocks are 2-MiB aligned, contiguous, freed with statmc_free, and otherwise ordinary device memory.  The first call on
+ * Blocks are 2-MiB aligned, contiguous in the address space (a block above 2 GiB is GiB slots of one class from anywhere on the
+ * card, mapped side by side a second time), freed with statmc_free, and otherwise ordinary device memory.  The first call on
  * a device reserves address space and probes GiB slots until both probe levels have been seen (tens of ms); memory a role
  * has been dealt stays with that role, slots of the classes a request cannot use stay backed and idle (about twice what
  * the arenas take; the search settles for other classes once 60 % of the card is backed).  Where the probes show no contrast, the device has no virtual-memory management or memory runs short

@@ -44,6 +44,9 @@ int statmc_debug_accumulate_tiles_variant(int umul, int order, int wg_per_cu);
  * while every fourth step read-modify-writes 16 bytes inside [rmw_ptr, + rmw_bytes) -- the words there change.  Best of five, ms.
  * Two buffers in the same interference class: ~ 9 % slower than two in different ones (1-GiB stream, 64-MiB window). */
 int statmc_debug_interference_probe(const void *stream_ptr, size_t stream_bytes, void *rmw_ptr, size_t rmw_bytes, float *ms);
+/* The role of the statmc_malloc_placed block that holds `ptr` (any address inside it; window blocks included), -1 when `ptr` is
+ * in none, the block was dealt without the wanted class, or the device tells no classes apart: what statmc_accumulate asks. */
+int statmc_debug_placement_role(const void *ptr);
 
 /* Non-zero: the library was built with a timing-only / diagnostic switch (statmc_sym_experiments.h); its results are
  * not the product's and statmc_amd.api refuses to load it. */

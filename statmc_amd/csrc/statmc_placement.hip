@@ -27,9 +27,13 @@
 // from slot 0 becomes the second probe target, which tells the other two classes apart.  Slots of slot 0's class (A) hold
 // STATE blocks; STREAM blocks go to ONE of the other classes (B) as long as the card has room: arenas inside one class and
 // state in another measured 0.842 of the HBM peak at 1080p / 256 spp, arenas spread over both other classes 0.818, everything
-// in one class 0.760 (tools/experiments/acc_pool.py classes / fastslow).  A block never spans slots of an unsuitable class, so a
-// 6-GiB arena waits for a run of six suitable slots in a row (the range is extended until there is one, up to 60 % of the
-// card; after that the third class, then both up to 75 % of the card, then anything).  What no role uses stays mapped and idle (about twice what the
+// in one class 0.760 (tools/experiments/acc_pool.py classes / fastslow).  A block never spans slots of an unsuitable class.  A
+// large block is a WINDOW: as many suitable slots as it needs, wherever they lie in the range, mapped a second
+// time side by side in a second reserved range (one physical allocation may be mapped at several addresses, and the class is
+// the memory's, not the address's; blocks above 2 GiB) -- so a 6-GiB arena needs six class-B slots, not six in a row: on a card whose classes come
+// in short runs the first version backed 170 GiB to find three runs of six and still put an arena into class C.  Slots are
+// backed until there are enough (up to 60 % of the card; after that the third class, then both up to 75 % of the card, then
+// anything); smaller blocks are carved out of whole slots dealt to their role.  What no role uses stays mapped and idle (about twice what the
 // arenas take, on a 288 GB card) until statmc_placement_trim gives it back to the driver.  No contrast between the probes, no
 // virtual-memory support, too little memory: the call degrades to slots as they come -- placement is an optimisation, never
 // a requirement -- and statmc_placement_info says so.  STATMC_PLACEMENT=0 turns the call into hipMalloc.
@@ -96,6 +100,12 @@ struct Slot {
     float probe_ms[2] = {0.f, 0.f};   // against slot 0 / against the second target
     int role = -1;            // -1: not dealt to a role yet; STATMC_MEM_STATE / STATMC_MEM_STREAM: its space belongs to that role's free list
     bool as_it_came = false;  // dealt to a role without the wanted class
+    int window = -1;          // >= 0: part of a window block -- mapped a second time at that slot of the window range
+};
+struct Window {               // a block of whole slots mapped side by side in the window range
+    size_t first, n, bytes;   // window slots [first, first + n), bytes asked for
+    int role;
+    bool wanted;              // every slot of it has the class the role asks for
 };
 
 struct Placement {
@@ -114,6 +124,9 @@ struct Placement {
     const char *last_note = "-";             // why the last attempt to back a slot ended (diagnostics)
     std::map<size_t, size_t> free_blocks[2]; // per role: offset from base -> bytes (coalesced; never across slots of another role)
     std::map<size_t, std::pair<size_t, int>> live;   // offset -> (bytes, role)
+    char *win_base = nullptr;                // the window range (GiB-aligned; nullptr: no second range, blocks need runs of slots)
+    std::vector<int> win_slot;               // per window slot: the slot mapped there, -1 = free
+    std::map<size_t, Window> windows;        // offset from win_base -> block
 };
 
 std::mutex g_place_mu;
@@ -244,6 +257,13 @@ bool init(Placement &P, int dev) {
     bool ok = hipMemAddressReserve(reinterpret_cast<void **>(&raw), (kReserveSlots + 1) * kSlot, kSlot, nullptr, 0) == hipSuccess;
     // (the runtime does not honour the alignment asked for: the slots start at the first GiB boundary inside the range)
     if (ok) P.base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(raw) + kSlot - 1) / kSlot * kSlot);
+    if (ok && !getenv("STATMC_PLACEMENT_NO_WINDOWS")) {   // (the switch: experiments -- the first version's runs of slots)
+        char *raw2 = nullptr;
+        if (hipMemAddressReserve(reinterpret_cast<void **>(&raw2), (kReserveSlots + 1) * kSlot, kSlot, nullptr, 0) == hipSuccess)
+            P.win_base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(raw2) + kSlot - 1) / kSlot * kSlot);
+        else
+            (void)hipGetLastError();
+    }
     ok = ok && hipMalloc(&P.sink, 64) == hipSuccess && hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking) == hipSuccess &&
          hipEventCreate(&P.e0) == hipSuccess && hipEventCreate(&P.e1) == hipSuccess;
     hipError_t err = hipSuccess;
@@ -333,6 +353,71 @@ int find_run(Placement &P, int role, size_t want_slots, unsigned mask, size_t ca
     }
 }
 
+// Gathers `want` undealt slots of the classes in `mask` (anywhere in the range; new slots are backed at its end, up to `cap_slots`
+// in all, until there are enough) and maps them side by side in the window range.  STATMC_ERR_UNSUPPORTED: not enough of them.
+int window_alloc(Placement &P, int role, size_t bytes, size_t want, unsigned mask, size_t cap_slots, bool wanted_class, size_t leave_free, void **out) {
+    std::vector<size_t> chosen;
+    for (;;) {
+        chosen.clear();
+        for (size_t i = 1; i < P.slots.size() && chosen.size() < want; i++)
+            if (suits(P, P.slots[i], mask)) chosen.push_back(i);
+        if (chosen.size() == want) break;
+        if (P.slots.size() >= cap_slots) return STATMC_ERR_UNSUPPORTED;
+        hipError_t err = hipSuccess;
+        if (!back_next_slot(P, &err, leave_free)) {
+            if (err != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "placement: %s", hipGetErrorString(err));
+            return STATMC_ERR_UNSUPPORTED;
+        }
+    }
+    // `want` free window slots in a row (first fit; the window range is as long as the slot range)
+    size_t first = 0, run = 0;
+    bool found = false;
+    for (size_t w = 0; w < P.win_slot.size() && !found; w++) {
+        run = P.win_slot[w] < 0 ? run + 1 : 0;
+        if (run == want) { first = w + 1 - want; found = true; }
+    }
+    if (!found) {
+        size_t tail = 0;                                   // free window slots at the end of what is in use
+        while (tail < P.win_slot.size() && P.win_slot[P.win_slot.size() - 1 - tail] < 0) tail++;
+        first = P.win_slot.size() - tail;
+        if (first + want > kReserveSlots) return STATMC_ERR_UNSUPPORTED;
+        P.win_slot.resize(first + want, -1);
+    }
+    for (size_t k = 0; k < want; k++) {
+        char *at = P.win_base + (first + k) * kSlot;
+        hipError_t e = hipMemMap(at, kSlot, 0, P.slots[chosen[k]].handle, 0);
+        if (e == hipSuccess) {
+            e = hipMemSetAccess(at, kSlot, &P.access, 1);
+            if (e != hipSuccess) (void)hipMemUnmap(at, kSlot);
+        }
+        if (e != hipSuccess) {
+            for (size_t j = 0; j < k; j++) (void)hipMemUnmap(P.win_base + (first + j) * kSlot, kSlot);
+            (void)hipGetLastError();
+            return statmc::abi_fail(STATMC_ERR_HIP, "placement: mapping a slot into a window: %s", hipGetErrorString(e));
+        }
+    }
+    for (size_t k = 0; k < want; k++) {
+        Slot &s = P.slots[chosen[k]];
+        s.role = role;
+        s.as_it_came = !wanted_class && !P.no_contrast;
+        s.window = (int)(first + k);
+        P.win_slot[first + k] = (int)chosen[k];
+    }
+    P.windows[first * kSlot] = Window{first, want, bytes, role, wanted_class || P.no_contrast};
+    *out = P.win_base + first * kSlot;
+    return STATMC_OK;
+}
+
+// the window block that holds `ptr`, or end()
+std::map<size_t, Window>::iterator window_of(Placement &P, const void *ptr) {
+    if (!P.win_base || (const char *)ptr < P.win_base || (const char *)ptr >= P.win_base + P.win_slot.size() * kSlot) return P.windows.end();
+    const size_t off = (size_t)((const char *)ptr - P.win_base);
+    auto it = P.windows.upper_bound(off);
+    if (it == P.windows.begin()) return P.windows.end();
+    --it;
+    return off < (it->second.first + it->second.n) * kSlot ? it : P.windows.end();
+}
+
 int take_block(Placement &P, int role, size_t need, void **out) {
     auto &fl = P.free_blocks[role];
     for (auto it = fl.begin(); it != fl.end(); ++it) {
@@ -377,6 +462,18 @@ int placed_alloc(Placement &P, int role, size_t bytes, void **out) {
     const int n_order = role == STATMC_MEM_STATE ? 4 : 5;
     // searching for a CLASS never takes the card's last 8 GiB (other allocators of the process need room); only the last resort --
     // any class, the request would fail otherwise -- goes down to half a GiB
+    if (want_slots >= 3 && P.win_base) {                   // (a window takes whole slots: below 2 GiB a run of two is the better deal)
+        // a run of first-choice slots among those already backed serves the block as it is (and its tail stays in the role's free list) ...
+        if (find_run(P, role, want_slots, order[0].mask, 0, true, 8ull << 30) == STATMC_OK && take_block(P, role, need, out) == STATMC_OK) return STATMC_OK;
+        // ... otherwise a window: the slots need not lie side by side
+        for (int k = 0; k < n_order && rc == STATMC_ERR_UNSUPPORTED; k++)
+            rc = window_alloc(P, role, bytes, want_slots, order[k].mask, order[k].cap, order[k].wanted, k + 1 < n_order ? (8ull << 30) : (512ull << 20), out);
+        if (rc == STATMC_OK || rc == STATMC_ERR_HIP) return rc;
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        return statmc::abi_fail(STATMC_ERR_HIP, "statmc_malloc_placed: out of device memory (%zu slots backed, %d probes %.3f .. %.3f ms, %.1f GiB free, last: %s)",
+                                P.slots.size(), P.n_probes, P.fastest_ms, P.slowest_ms, free_b / 1073741824.0, P.last_note);
+    }
     for (int k = 0; k < n_order && rc == STATMC_ERR_UNSUPPORTED; k++)
         rc = find_run(P, role, want_slots, order[k].mask, order[k].cap, order[k].wanted, k + 1 < n_order ? (8ull << 30) : (512ull << 20));
     if (rc == STATMC_ERR_HIP) return rc;
@@ -421,8 +518,9 @@ hipError_t workspace_free(void *p) {
 int placement_role_of(const void *ptr) {
     std::lock_guard<std::mutex> lk(g_place_mu);
     for (auto &kv : g_place) {
-        const Placement &P = kv.second;
+        Placement &P = kv.second;
         if (!P.base || !P.vmm || !P.calibrated || P.no_contrast) continue;
+        if (auto w = window_of(P, ptr); w != P.windows.end()) return w->second.wanted ? w->second.role : -1;
         if ((const char *)ptr < P.base || (const char *)ptr >= P.base + P.slots.size() * kSlot) continue;
         const Slot &s = P.slots[(size_t)((const char *)ptr - P.base) / kSlot];
         return s.role >= 0 && !s.as_it_came ? s.role : -1;
@@ -435,6 +533,26 @@ bool placement_free(void *ptr) {
     std::lock_guard<std::mutex> lk(g_place_mu);
     for (auto &kv : g_place) {
         Placement &P = kv.second;
+        if (auto w = window_of(P, ptr); w != P.windows.end()) {
+            if (P.win_base + w->first != (char *)ptr) return true;   // inside a window, not its start: nothing to do (and not hipFree's either)
+            int cur = 0;
+            if (hipGetDevice(&cur) == hipSuccess) {
+                if (cur != kv.first) (void)hipSetDevice(kv.first);
+                (void)hipDeviceSynchronize();
+                if (cur != kv.first) (void)hipSetDevice(cur);
+            }
+            for (size_t k = 0; k < w->second.n; k++) {                // the slots keep their memory and their class: undealt again
+                const size_t ws = w->second.first + k;
+                (void)hipMemUnmap(P.win_base + ws * kSlot, kSlot);
+                Slot &s = P.slots[(size_t)P.win_slot[ws]];
+                s.role = -1;
+                s.as_it_came = false;
+                s.window = -1;
+                P.win_slot[ws] = -1;
+            }
+            P.windows.erase(w);
+            return true;
+        }
         if (!P.base || (char *)ptr < P.base || (char *)ptr >= P.base + P.slots.size() * kSlot) continue;
         auto it = P.live.find((size_t)((char *)ptr - P.base));
         if (it == P.live.end()) return true;            // inside the range, not a live block: nothing to do (and not hipFree's either)
@@ -501,8 +619,13 @@ int statmc_placement_info(statmc_placement_info_t *out) {
         }
     }
     for (const auto &kv : P.live) out->live_bytes[kv.second.second] += kv.second.first;
+    for (const auto &kv : P.windows) out->live_bytes[kv.second.role] += kv.second.bytes;
     return STATMC_OK;
 }
+
+// Test hook: what statmc_accumulate learns about a buffer -- the role of the placed block `ptr` lies in (any address inside it),
+// -1 when it is not one, was dealt without the wanted class, or the device tells no classes apart
+int statmc_debug_placement_role(const void *ptr) { return statmc::placement_role_of(ptr); }
 
 // Test / experiment hook (include/statmc_debug.h): the allocator's probe on memory of the caller's -- streams `stream_bytes` at
 // `stream_ptr` while every fourth step read-modify-writes 16 bytes inside [rmw_ptr, rmw_ptr + rmw_bytes) (their values change: + 1 in
