@@ -507,6 +507,8 @@ def accumulate_by_batch_4k(args, dev, types):
     from statmc_amd import synthetic
     if (args.width, args.height) == (3840, 2160):
         return {"skipped": "the bench film is 3840x2160 already: see accumulate_by_batch"}
+    if args.width * args.height < 1920 * 1080:
+        return {"skipped": "a leg of the full-size lines (test-sized film)"}
     W, H, S = 3840, 2160, 64
     free_b = torch.cuda.mem_get_info(dev)[0]
     if free_b < 3 * 4 * args.channels * W * H * S:
