@@ -89,8 +89,9 @@ constexpr bool mode_asym(int m) { return m == kModeAsym || m == kModeAsymJoint |
 // Welch-Satterthwaite degrees of freedom (STATMC_DOF_WELCH), channels one by one / pooled: the discriminator image holds
 // v = s^2 / n, a fourth statistics image E = v^2 / (n - 1) is staged with it, and the pair looks its squared quantile up
 // at floor(nu), nu = (v_p + v_q)^2 / (E_p + E_q) -- symmetric in (p, q) like everything else the pair needs, so the pair
-// is still evaluated once.  These two modes exist in ONE build (register staging, six feature planes, runtime radius):
-// 18 input + 8 accumulator planes leave no room for the LDS-DMA landing area.
+// is still evaluated once.  These modes exist in ONE build per feature-plane count (register staging, runtime radius): 18 input
+// + 8 accumulator planes leave no room for the LDS-DMA landing area; with eight feature planes the three E planes shrink to one
+// plane n - 1 and the taps form E themselves (Planes<8, true>, chunk).
 // Each in two builds: the first reads the quantiles from a band of the table in LDS and flags the items in which a pair
 // asked for an entry outside it; the second ("far") reads the table in global memory and runs behind the first over the
 // flagged items only (none in a film of uniform sample count).
