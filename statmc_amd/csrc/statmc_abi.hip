@@ -1326,6 +1326,7 @@ int statmc_accumulate_tiles(uint16_t width, uint16_t height, const statmc_stat_t
     k.umul = dstate.tiles_umul;
     k.order = dstate.tiles_order;
     k.wg_per_cu = dstate.tiles_wg_per_cu;
+    k.dma_first = dstate.acc_dma_first;
     HIP_TRY(statmc::launch_accumulate_tiles(k, S(stream)));
     return STATMC_OK;
 }

@@ -66,6 +66,7 @@ struct AccumulateTilesArgs {
     int n_tiles, width, height, vec;
     int dma;                         // RGB sample planes arrive by LDS-DMA (default 1)
     int umul, order, wg_per_cu;      // experiment knobs (statmc_debug_accumulate_tiles_variant): prefetch depth x2, item order, grid size
+    int dma_first;                   // A/B (statmc_debug_accumulate_launch): the first rows of the LDS-DMA ring requested before the state loads
 };
 
 struct MergeTilesArgs {

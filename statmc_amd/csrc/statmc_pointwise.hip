@@ -809,7 +809,7 @@ __device__ __forceinline__ void accumulate_tile(const AccumulateType &t, const A
             const long long p0 = (long long)(y0 + row) * a.width + x0 + col;
             // deeper prefetch only where the state is one plane (mean-only feature types): the registers are there
             accumulate_lane<C, MAXM, TRANSFORM, (!TRANSFORM && MAXM == 1) ? UMUL : 1, DMA>(t, p0, base + (long long)i * C, stride, S, ring, active,
-                                                                                            n_g - gw >= 64 ? 64 : n_g - gw);
+                                                                                            n_g - gw >= 64 ? 64 : n_g - gw, a.dma_first != 0);
         }
     } else {
         for (int i = lane; i < npx; i += 64) {
@@ -877,7 +877,11 @@ hipError_t launch_accumulate_tiles(const AccumulateTilesArgs &a_in, hipStream_t 
     }
     a.vec = vec ? 1 : 0;
     const long long items = a.order == 2 ? (((long long)a.n_tiles + 3) >> 2) * 4 * a.n_types : (long long)a.n_tiles * a.n_types;
-    const int grid = grid_for(items * 64, 256 * (a.wg_per_cu > 0 ? a.wg_per_cu : 8));  // one wave per item, at most 8 workgroups per CU
+    // one wave per item; films up to ~ 4 Mpixels: at most 8 workgroups per CU, walking the items with a grid stride; larger ones
+    // (4K: 32 400 tiles): every wave ONE item, the dispatcher hands the workgroups out -- + 1 - 4 % at 4 .. 64 samples per tile there,
+    // - 1 - 2 % at 1080p (profiles/r05_tiles_first.log; the film-major launch has the same rule, launch_accumulate)
+    const bool big = a.n_tiles >= 16384;
+    const int grid = grid_for(items * 64, a.wg_per_cu > 0 ? 256 * a.wg_per_cu : big ? (1 << 30) : 256 * 8);
     // (the DMA walk needs the vector path: a.vec; the scalar path of unaligned images never touches the ring)
     if (a.vec && a.dma && a.umul == 2) hipLaunchKernelGGL((accumulate_tiles_kernel<2, kAccTilesDmaD>), dim3(grid), dim3(kBlock), acc_lds_bytes(kAccTilesDmaD), s, a);
     else if (a.vec && a.dma) hipLaunchKernelGGL((accumulate_tiles_kernel<1, kAccTilesDmaD>), dim3(grid), dim3(kBlock), acc_lds_bytes(kAccTilesDmaD), s, a);

@@ -1,7 +1,8 @@
 """Tile-fed accumulation at the reference's batch lengths (4 .. 64 samples per 16 x 16 tile), 1080p and 4K, placed buffers: which
 (tile, type) item a wave takes (order 0: the waves of a workgroup = the types of one tile; 1: tiles innermost; 2: a workgroup = four
 consecutive tiles of ONE type, so a state row of the workgroup is 768 contiguous bytes instead of 192) and how many workgroups
-the grid holds per CU (0 = the default cap of 8; 4096 = one item per wave, no grid-stride walk).
+the grid holds per CU (0 = the default: a cap of 8 up to ~ 4 Mpixels, one item per wave beyond; 4096 = one item per wave, no grid-stride walk),
+and whether the first rows of the LDS-DMA ring are requested before the state loads (f1: no gain).
 python tools/experiments/time_tiles_order.py [4k]"""
 import ctypes
 import os
@@ -30,10 +31,12 @@ for W, H in ((3840, 2160),) if "4k" in sys.argv else ((1920, 1080), (3840, 2160)
         del part
     for S in (4, 8, 16, 64):
         line = "%dx%d %2d spp:" % (W, H, S)
-        for order, wg in ((0, 0), (1, 0), (2, 0), (0, 4096), (2, 4096), (2, 4), (2, 16)):
+        for order, wg, first in ((0, 0, 0), (2, 0, 0), (2, 0, 1), (2, 4096, 0), (2, 4096, 1), (2, 0, 0), (2, 0, 1)):
             lib.statmc_debug_accumulate_tiles_variant(2, order, wg)
+            lib.statmc_debug_accumulate_launch(-1, first)      # (first: the ring's first rows requested before the state loads)
             r = bench._tile_fed_measure(W, H, dev, smp, types, S, reps=6)
-            line += "  o%d/wg%-4d %.4f ms %.3f" % (order, wg, r["avg_ms"], r["frac_hbm"])
+            line += "  o%d/wg%-4d/f%d %.4f ms %.3f" % (order, wg, first, r["avg_ms"], r["frac_hbm"])
+        lib.statmc_debug_accumulate_launch(-1, 0)
         print(line, flush=True)
     lib.statmc_debug_accumulate_tiles_variant(2, 2, 0)
     del smp
