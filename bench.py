@@ -105,6 +105,9 @@ def parse():
     ap.add_argument("--share-device", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--cpu-acc-rows", type=int, default=32, help="rows of the film the CPU baseline accumulates")
     ap.add_argument("--no-host-legs", action="store_true", help="skip the secondary host-side measurements (N = 1)")
+    ap.add_argument("--feed", choices=("film", "tiles"), default="film",
+                    help="how the timed step's samples reach the accumulation: film-major planes through statmc_accumulate (default), or "
+                         "16 x 16 tile blocks through statmc_accumulate_tiles, the way Render<T> hands them over (N = 1, --schedule single)")
     ap.add_argument("--schedule", default="single", choices=("single", "reference"),
                     help="single = one accumulate of --spp samples + one pre-pass + filter per step (default); reference = the "
                          "reference's progressive schedule (statpath.cpp:272-279): iterations of 4, 4, 8, 16, ... samples up to "
@@ -949,6 +952,33 @@ def main():
         for a, b in pool_slices(start, count, pool):
             pipe.accumulate(samples if (a, b) == (0, pool) else {t: v[a:b] for t, v in samples.items()}, rows=rows)
 
+    fed_by_tiles = args.feed == "tiles" and world == 1 and batches == [S] and pool == S and W % 16 == 0
+    if fed_by_tiles:
+        # --feed tiles: the timed step fed the way Render<T> hands samples over -- 16 x 16 tile blocks through statmc_accumulate_tiles
+        # (the same samples, permuted once; `tile_fed_accumulate` measures this launch back to back): 3.61 against 3.68 - 3.74 ms in
+        # the step at 1080p / 256 spp (a wave's consecutive sample rows are 3 KB apart instead of 25 MB)
+        from statmc_amd import film as _film
+        tiles = [(x, y, min(x + 16, W), min(y + 16, H)) for y in range(0, H, 16) for x in range(0, W, 16)]
+        t_bounds = torch.tensor(tiles, dtype=torch.int32, device=dev)
+        t_npx = torch.tensor([(x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in tiles], dtype=torch.int64)
+        t_offs = (torch.cumsum(t_npx * S, 0) - t_npx * S).to(dev)
+        t_cnt = torch.full((len(tiles),), S, dtype=torch.int32, device=dev)
+        t_sts, t_keep = [], []
+        for t in types:
+            c = _film.STAT_TYPES[t]["channels"]
+            arena = new_arena((int((t_npx * S).sum()) * c,), dev)
+            at = 0
+            for y in range(0, H, 16):
+                th = min(16, H - y)
+                band = samples[t][:, y:y + th].reshape(S, th, W // 16, 16, c).permute(2, 0, 1, 3, 4).contiguous().reshape(-1)
+                arena[at:at + band.numel()] = band
+                at += band.numel()
+            t_keep.append(arena)
+            t_sts.append(api.make_stat_type_arena(arena, c, fs.state[t], _film.STAT_TYPES[t]["transform"], _film.STAT_TYPES[t]["max_moment"]))
+
+        def accumulate_range(start, count, rows=None):      # noqa: F811
+            api.accumulate_tiles(W, H, t_sts, t_bounds, t_offs, t_cnt)
+
     # Row-strip grids: the rows a neighbour needs are accumulated, pre-passed and sent first, the rest of the block is
     # accumulated while they travel (BlockPipeline.border_rows; same bits).  On one GPU the split costs 0.04 - 0.06 ms per
     # step (tools/experiments/halo_overlap_cost.py) and leaves the exchange 0.4 - 1.9 ms to hide in.
@@ -1155,7 +1185,7 @@ def main():
         ctx = dict(args=args, world=world, W=W, H=H, fw=fw, fh=fh, gx=layout.gx, gy=layout.gy, S=S, r=r, types=types,
                    batches=batches, pool=pool, n_acc_launches=n_acc_launches, ms=ms, elapsed=elapsed, variant=variant,
                    binding=binding, n_ranks_seen=n_ranks_seen, clocks=clocks, overlapped=bool(border), gather_ms=gather_ms,
-                   backend=args.backend, border_rows=sum(y1 - y0 for y0, y1 in border), self_check=self_check,
+                   backend=args.backend, border_rows=sum(y1 - y0 for y0, y1 in border), self_check=self_check, fed_by_tiles=fed_by_tiles,
                    parallelism="film blocks x%d, one process per GPU, halo exchange over torch.distributed (%s%s)"
                                % (world, args.backend, " = RCCL" if args.backend == "nccl" else ", halos via the host") if world > 1 else "single GPU")
         result = build_result(ctx)
@@ -1369,13 +1399,14 @@ def build_result(c):
             "step_order": ("border rows first, exchange behind the interior's accumulation" if overlapped else
                            "accumulate, pre-pass, exchange, filter" if world > 1 else "accumulate, pre-pass, filter"),
             "rank0_binding": c["binding"],
+            "feed": "16 x 16 tile blocks (statmc_accumulate_tiles)" if c.get("fed_by_tiles") else "film-major planes (statmc_accumulate)",
         },
         # the kernel that dominates the step: the sample-stream accumulation (HBM-bound)
         "roofline": {
-            "kernel": "accumulate_kernel", "bound": "hbm",
+            "kernel": "accumulate_tiles_kernel" if c.get("fed_by_tiles") else "accumulate_kernel", "bound": "hbm",
             "achieved": round(acc_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(acc_gbs / HBM_PEAK_GBS, 4),
-            "traffic": traffic.get("accumulate_kernel"), "traffic_source": traffic_source,
+            "traffic": None if c.get("fed_by_tiles") else traffic.get("accumulate_kernel"), "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": acc_bytes_px * acc_px // n_acc_launches, "bytes_per_px": acc_bpp,
             "avg_launch_ms": round(acc_ms / n_acc_launches, 4), "launches_per_step": n_acc_launches,
             "launch": ("the interior rows of the block (%d of %d)" % (H - c["border_rows"], H)) if overlapped else "the whole block",

@@ -47,6 +47,23 @@ def test_single_gpu_line(gpu):
     assert r["pcie_inclusive"]["GBs"] > 0 and r["pcie_inclusive"]["mpixels_per_s_if_samples_cross_pcie"] < r["value"]
 
 
+def test_step_fed_by_tile_blocks(gpu, tmp_path):
+    """`--feed tiles`: the timed step's samples reach the accumulation as 16 x 16 tile blocks (statmc_accumulate_tiles), the way
+    Render<T> hands them over; the line says so and the step leaves the same film-f as the film-major feed, bit for bit."""
+    films = {}
+    for feed in ("film", "tiles"):
+        dump = str(tmp_path / (feed + ".npy"))
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--feed", feed, "--no-host-legs", "--no-cpu-baseline",
+                              "--dump-film-f", dump] + COMMON, capture_output=True, text=True, timeout=360)
+        assert out.returncode == 0, out.stderr[-2000:]
+        r = _line(out)
+        assert r["config"]["feed"].startswith("16 x 16 tile blocks" if feed == "tiles" else "film-major")
+        assert r["roofline"]["kernel"] == ("accumulate_tiles_kernel" if feed == "tiles" else "accumulate_kernel") and r["value"] > 0
+        import numpy as np
+        films[feed] = np.load(dump)
+    assert films["film"].shape == (256, 512, 3) and (films["film"] == films["tiles"]).all()
+
+
 @pytest.mark.parametrize("grid,blocks", [("rows", "1x2"), ("blocks", "2x1")])
 def test_strong_scaling_two_ranks_share_the_device(gpu, grid, blocks):
     """`python bench.py --gpus 2` with NO launcher around it: bench.py starts its own ranks (fresh processes, before
