@@ -156,8 +156,8 @@ int statmc_free(void *dev_ptr);   /* blocks of statmc_malloc and of statmc_mallo
  *                           B while the card has room: arenas spread over B and C cost 2 - 3 % of the gain)
  * Blocks are 2-MiB aligned, contiguous in the address space (a block above 2 GiB is GiB slots of one class from anywhere on the
  * card, mapped side by side a second time), freed with statmc_free, and otherwise ordinary device memory.  The first call on
- * a device reserves address space and probes GiB slots until both probe levels have been seen (tens of ms); memory a role
- * has been dealt stays with that role, slots of the classes a request cannot use stay backed and idle (about twice what
+ * a device reserves address space and probes GiB slots until both probe levels have been seen (tens of ms); a GiB slot that
+ * holds no live block is idle again (either role may take it), slots of the classes a request cannot use stay backed and idle (about twice what
  * the arenas take; the search settles for other classes once 60 % of the card is backed).  Where the probes show no contrast, the device has no virtual-memory management or memory runs short
  * the call still succeeds with memory as it comes (statmc_placement_info says so); STATMC_PLACEMENT=0 in the environment
  * makes it hipMalloc.  Not to be called while a kernel of the caller's runs (the probe competes for the memory system). */

@@ -323,6 +323,28 @@ void add_free(std::map<size_t, size_t> &fl, size_t off, size_t len) {
     fl[off] = len;
 }
 
+// Whole slots that lie inside free space of a role go back to the pool of undealt slots (same memory, same class): what a large
+// block leaves behind can serve the other role's blocks or a window, not only its own role's next small block.
+void undeal_free_slots(Placement &P, int role) {
+    auto &fl = P.free_blocks[role];
+    for (auto it = fl.begin(); it != fl.end();) {
+        const size_t off = it->first, len = it->second;
+        const size_t s0 = (off + kSlot - 1) / kSlot, s1 = (off + len) / kSlot;   // whole slots [s0, s1) of this free block
+        if (s1 <= s0) {
+            ++it;
+            continue;
+        }
+        fl.erase(it);
+        if (off < s0 * kSlot) fl[off] = s0 * kSlot - off;
+        if (s1 * kSlot < off + len) fl[s1 * kSlot] = off + len - s1 * kSlot;
+        for (size_t i = s0; i < s1; i++) {
+            P.slots[i].role = -1;
+            P.slots[i].as_it_came = false;
+        }
+        it = fl.lower_bound(s1 * kSlot);
+    }
+}
+
 // deals `count` consecutive undealt slots, starting at slot `first`, to the role's free list
 void deal(Placement &P, int role, size_t first, size_t count, bool wanted_class) {
     for (size_t i = first; i < first + count; i++) {
@@ -563,8 +585,10 @@ bool placement_free(void *ptr) {
             (void)hipDeviceSynchronize();
             if (cur != kv.first) (void)hipSetDevice(cur);
         }
-        add_free(P.free_blocks[it->second.second], it->first, it->second.first);
+        const int role = it->second.second;
+        add_free(P.free_blocks[role], it->first, it->second.first);
         P.live.erase(it);
+        undeal_free_slots(P, role);
         return true;
     }
     return false;

@@ -132,6 +132,7 @@ def test_large_blocks_are_windows_over_scattered_slots(gpu):
     assert after["slots"] == before and after["live_bytes"][1] <= info["live_bytes"][1] - 3 * 5 * gib * 4
     again = gpu.empty_placed((12 * gib,), torch.int32, dev, gpu.MEM_STREAM)          # 12 GiB: the idle slots first, new ones for the rest
     again[-1:].fill_(7)
+    # (whole free slots are idle again and reused; how many MORE the card must back for twelve of one class is its business)
     assert int(again[-1].item()) == 7 and gpu.placement_info()["slots"] <= before + 12
 
 
