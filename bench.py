@@ -1284,7 +1284,7 @@ def placement_report():
                        slots_c=info["slots_c"], slots_unclear=info["slots_unclear"], slots_idle=info["slots_idle"],
                        slots_as_they_came=info["slots_as_they_came"], probe_ms=[round(info["fast_probe_ms"], 4), round(info["slow_probe_ms"], 4)],
                        state_GiB=round(info["slab_bytes"][0] / 2 ** 30, 1), stream_GiB=round(info["slab_bytes"][1] / 2 ** 30, 1), map=info["map"],
-                       what="running moments in GiB slots of class A, sample arenas in class B (a stream read beside writes into its own "
+                       what="running moments in GiB slots of class A, sample arenas in ONE of the other two classes -- the one the card has at hand -- (a stream read beside writes into its own "
                             "class runs ~ 9 % slower on MI355X; the class travels with the physical memory -- most likely its HBM rank -- and is measured per GiB, 0.2 ms each)")
         except Exception as e:      # noqa: BLE001
             out["info_error"] = repr(e)[:200]

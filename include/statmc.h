@@ -152,8 +152,8 @@ int statmc_free(void *dev_ptr);   /* blocks of statmc_malloc and of statmc_mallo
  * same bits.  The class travels with the physical memory and HIP does not expose it, so the allocator MEASURES it: one reserved address range per device, backed GiB by GiB, every GiB probed
  * against two GiB of the allocator's own (0.2 ms each; statmc_amd/csrc/statmc_placement.hip).
  *   role STATMC_MEM_STATE   images a kernel reads AND writes per launch: n, mean, m2, m3, film-mean, film-m2 (class A)
- *   role STATMC_MEM_STREAM  read-once inputs: the sample arenas of statmc_accumulate / statmc_accumulate_tiles (all in class
- *                           B while the card has room: arenas spread over B and C cost 2 - 3 % of the gain)
+ *   role STATMC_MEM_STREAM  read-once inputs: the sample arenas of statmc_accumulate / statmc_accumulate_tiles (all in ONE of the
+ *                           other two classes while the card has room: arenas spread over both cost 2 - 3 % of the gain)
  * Blocks are 2-MiB aligned, contiguous in the address space (a block above 2 GiB is GiB slots of one class from anywhere on the
  * card, mapped side by side a second time), freed with statmc_free, and otherwise ordinary device memory.  The first call on
  * a device reserves address space and probes GiB slots until both probe levels have been seen (tens of ms); a GiB slot that

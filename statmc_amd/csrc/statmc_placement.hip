@@ -124,6 +124,7 @@ struct Placement {
     const char *last_note = "-";             // why the last attempt to back a slot ended (diagnostics)
     std::map<size_t, size_t> free_blocks[2]; // per role: offset from base -> bytes (coalesced; never across slots of another role)
     std::map<size_t, std::pair<size_t, int>> live;   // offset -> (bytes, role)
+    int stream_class = -1;                   // kClassB or kClassC once the first STREAM block has chosen: the arenas' class on this device
     char *win_base = nullptr;                // the window range (GiB-aligned; nullptr: no second range, blocks need runs of slots)
     std::vector<int> win_slot;               // per window slot: the slot mapped there, -1 = free
     std::map<size_t, Window> windows;        // offset from win_base -> block
@@ -440,6 +441,25 @@ std::map<size_t, Window>::iterator window_of(Placement &P, const void *ptr) {
     return off < (it->second.first + it->second.n) * kSlot ? it : P.windows.end();
 }
 
+// The arenas' class: whichever of the two classes apart from the state's first has `want` undealt slots among those backed (slots
+// are backed until one has, or `cap_slots` are); the arenas of a device then all go there (one class for all of them measured 0.842
+// of the HBM peak, spread over both 0.818).  Which of the two the card has more of near the start of the range differs from box to
+// box: always taking the second probe target's class (the first version) backed 176 GiB on a card whose first hundred slots were of
+// the other one.
+int pick_stream_class(Placement &P, size_t want, size_t cap_slots, size_t leave_free) {
+    for (;;) {
+        size_t n[2] = {0, 0};
+        for (size_t i = 1; i < P.slots.size(); i++) {
+            if (P.slots[i].role != -1) continue;
+            const int c = classify(P, P.slots[i]);
+            if (c == kClassB || c == kClassC) n[c - kClassB]++;
+        }
+        if (n[0] >= want || n[1] >= want) return n[0] >= want && n[0] >= n[1] ? kClassB : n[1] >= want ? kClassC : kClassB;
+        hipError_t err = hipSuccess;
+        if (P.slots.size() >= cap_slots || !back_next_slot(P, &err, leave_free)) return n[1] > n[0] ? kClassC : kClassB;
+    }
+}
+
 int take_block(Placement &P, int role, size_t need, void **out) {
     auto &fl = P.free_blocks[role];
     for (auto it = fl.begin(); it != fl.end(); ++it) {
@@ -465,13 +485,17 @@ int placed_alloc(Placement &P, int role, size_t bytes, void **out) {
     const size_t soft_cap = std::min<size_t>(kReserveSlots, (size_t)(0.60 * (double)P.total_bytes / (double)kSlot));
     const size_t hard_cap = std::min<size_t>(kReserveSlots, (size_t)(0.75 * (double)P.total_bytes / (double)kSlot));
     struct Search { unsigned mask; size_t cap; bool wanted; };
-    // which class serves which role: the state takes slot 0's class (A), the arenas the second target's (B), then the third (C).
+    // which class serves which role: the state takes slot 0's class (A), the arenas ONE of the other two (pick_stream_class), then the third.
     // STATMC_PLACEMENT_ROLES=BCA etc. (experiment: are the classes interchangeable?) permutes that.
     static const int cls[3] = {[] { const char *e = getenv("STATMC_PLACEMENT_ROLES"); return e && strlen(e) == 3 ? e[0] - 'A' : 0; }(),
                                [] { const char *e = getenv("STATMC_PLACEMENT_ROLES"); return e && strlen(e) == 3 ? e[1] - 'A' : 1; }(),
                                [] { const char *e = getenv("STATMC_PLACEMENT_ROLES"); return e && strlen(e) == 3 ? e[2] - 'A' : 2; }()};
     const bool perm_ok = cls[0] >= 0 && cls[0] < 3 && cls[1] >= 0 && cls[1] < 3 && cls[2] >= 0 && cls[2] < 3 && cls[0] != cls[1] && cls[1] != cls[2] && cls[0] != cls[2];
-    const int cS = perm_ok ? cls[0] : kClassA, cT = perm_ok ? cls[1] : kClassB, cU = perm_ok ? cls[2] : kClassC;
+    int cS = perm_ok ? cls[0] : kClassA, cT = perm_ok ? cls[1] : kClassB, cU = perm_ok ? cls[2] : kClassC;
+    if (role == STATMC_MEM_STREAM && !P.no_contrast && !getenv("STATMC_PLACEMENT_ROLES")) {
+        if (P.stream_class < 0) P.stream_class = pick_stream_class(P, want_slots, soft_cap, 8ull << 30);
+        if (P.stream_class == kClassC) std::swap(cT, cU);
+    }
     const unsigned not_state = bit(cT) | bit(cU) | (cS == kClassA ? bit(kNotA) : 0u);
     const Search state_order[] = {{bit(cS), soft_cap, true}, {bit(cS) | bit(kMixed), 0, false}, {kAnyClass, hard_cap, false},
                                   {kAnyClass, kReserveSlots, false}};                    // (last resort: until the card is full)
