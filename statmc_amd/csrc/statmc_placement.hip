@@ -493,8 +493,12 @@ int placed_alloc(Placement &P, int role, size_t bytes, void **out) {
     const bool perm_ok = cls[0] >= 0 && cls[0] < 3 && cls[1] >= 0 && cls[1] < 3 && cls[2] >= 0 && cls[2] < 3 && cls[0] != cls[1] && cls[1] != cls[2] && cls[0] != cls[2];
     int cS = perm_ok ? cls[0] : kClassA, cT = perm_ok ? cls[1] : kClassB, cU = perm_ok ? cls[2] : kClassC;
     if (role == STATMC_MEM_STREAM && !P.no_contrast && !getenv("STATMC_PLACEMENT_ROLES")) {
-        if (P.stream_class < 0) P.stream_class = pick_stream_class(P, want_slots, soft_cap, 8ull << 30);
-        if (P.stream_class == kClassC) std::swap(cT, cU);
+        int c = P.stream_class;
+        if (c < 0) {
+            c = pick_stream_class(P, want_slots, soft_cap, 8ull << 30);
+            if (want_slots >= 3) P.stream_class = c;       // an arena decides for the device; a small block takes what is at hand
+        }
+        if (c == kClassC) std::swap(cT, cU);
     }
     const unsigned not_state = bit(cT) | bit(cU) | (cS == kClassA ? bit(kNotA) : 0u);
     const Search state_order[] = {{bit(cS), soft_cap, true}, {bit(cS) | bit(kMixed), 0, false}, {kAnyClass, hard_cap, false},
