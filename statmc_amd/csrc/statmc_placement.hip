@@ -68,6 +68,10 @@ inline float env_threshold(const char *name, float dflt, float lo, float hi) {
 }
 inline float same_above() { static const float v = env_threshold("STATMC_PLACEMENT_SAME", 1.055f, 1.03f, 1.10f); return v; }
 inline float apart_below() { static const float v = env_threshold("STATMC_PLACEMENT_APART", 1.035f, 1.0f, 1.055f); return v; }
+// The moments of a film are a few hundred MB in ONE slot: a slot that straddles a class boundary (the runs of a class do not end
+// on the allocator's GiB marks; such a slot probes between the levels, 1.058 in a sample of 114 whose slow cluster starts at
+// 1.073) may hold them in its minority part -- in the arenas' class.  The state's first choice are slots well inside the slow cluster.
+inline float state_above() { static const float v = env_threshold("STATMC_PLACEMENT_STATE", 1.07f, 1.055f, 1.10f); return v; }
 #define kSameAbove same_above()
 #define kApartBelow apart_below()
 constexpr int kCalibrationCap = 96;           // slots probed without seeing both levels: no classes to tell apart here
@@ -300,10 +304,12 @@ hipError_t calibrate(Placement &P) {
 // class masks of the searches a role makes, strongest first
 constexpr unsigned bit(int c) { return 1u << c; }
 constexpr unsigned kAnyClass = ~0u;
+constexpr unsigned kWellInsideA = 1u << 16;   // with bit(kClassA): only slots whose probe lies well inside the slow cluster (state_above)
 bool suits(const Placement &P, const Slot &s, unsigned mask) {
     if (s.role != -1) return false;      // dealt, private or released
     if (P.no_contrast || mask == kAnyClass) return true;
     const int c = classify(P, s);
+    if (c == kClassA && (mask & kWellInsideA) && !(s.probe_ms[0] > state_above() * P.fastest_ms)) return false;
     return c >= 0 && (mask & bit(c));
 }
 
@@ -501,15 +507,15 @@ int placed_alloc(Placement &P, int role, size_t bytes, void **out) {
         if (c == kClassC) std::swap(cT, cU);
     }
     const unsigned not_state = bit(cT) | bit(cU) | (cS == kClassA ? bit(kNotA) : 0u);
-    const Search state_order[] = {{bit(cS), soft_cap, true}, {bit(cS) | bit(kMixed), 0, false}, {kAnyClass, hard_cap, false},
-                                  {kAnyClass, kReserveSlots, false}};                    // (last resort: until the card is full)
+    const Search state_order[] = {{bit(cS) | (cS == kClassA ? kWellInsideA : 0u), soft_cap, true}, {bit(cS), 0, true}, {bit(cS) | bit(kMixed), 0, false},
+                                  {kAnyClass, hard_cap, false}, {kAnyClass, kReserveSlots, false}};   // (last resort: until the card is full)
     const Search stream_order[] = {{bit(cT), soft_cap, true},                            // one class for all arenas
                                    {bit(cU), 0, true},                                   // ... or the other one
                                    {not_state, hard_cap, true},                          // both (still apart from the state)
                                    {kAnyClass, hard_cap, false}, {kAnyClass, kReserveSlots, false}};
     int rc = STATMC_ERR_UNSUPPORTED;
     const Search *order = role == STATMC_MEM_STATE ? state_order : stream_order;
-    const int n_order = role == STATMC_MEM_STATE ? 4 : 5;
+    const int n_order = 5;
     // searching for a CLASS never takes the card's last 8 GiB (other allocators of the process need room); only the last resort --
     // any class, the request would fail otherwise -- goes down to half a GiB
     if (want_slots >= 3 && P.win_base) {                   // (a window takes whole slots: below 2 GiB a run of two is the better deal)
