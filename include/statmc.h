@@ -151,7 +151,8 @@ int statmc_free(void *dev_ptr);   /* blocks of statmc_malloc and of statmc_mallo
  * (4K / 64 spp: 0.79 instead of 0.68; DESIGN.md section 4.1a, tools/experiments/acc_pool.py fastslow) -- the same kernel, the
  * same bits.  The class travels with the physical memory and HIP does not expose it, so the allocator MEASURES it: one reserved address range per device, backed GiB by GiB, every GiB probed
  * against two GiB of the allocator's own (0.2 ms each; statmc_amd/csrc/statmc_placement.hip).
- *   role STATMC_MEM_STATE   images a kernel reads AND writes per launch: n, mean, m2, m3, film-mean, film-m2 (class A)
+ *   role STATMC_MEM_STATE   images a kernel reads AND writes per launch: n, mean, m2, m3, film-mean, film-m2 (the first 960 MiB in
+ *                           the very GiB every other one is probed against, the rest in slots of its class, A)
  *   role STATMC_MEM_STREAM  read-once inputs: the sample arenas of statmc_accumulate / statmc_accumulate_tiles (all in ONE of the
  *                           other two classes while the card has room: arenas spread over both cost 2 - 3 % of the gain)
  * Blocks are 2-MiB aligned, contiguous in the address space (a block above 2 GiB is GiB slots of one class from anywhere on the

@@ -128,6 +128,7 @@ struct Placement {
     const char *last_note = "-";             // why the last attempt to back a slot ended (diagnostics)
     std::map<size_t, size_t> free_blocks[2]; // per role: offset from base -> bytes (coalesced; never across slots of another role)
     std::map<size_t, std::pair<size_t, int>> live;   // offset -> (bytes, role)
+    bool slot0_dealt = false;                // slot 0 behind its probe window belongs to the STATE role's free list
     int stream_class = -1;                   // kClassB or kClassC once the first STREAM block has chosen: the arenas' class on this device
     char *win_base = nullptr;                // the window range (GiB-aligned; nullptr: no second range, blocks need runs of slots)
     std::vector<int> win_slot;               // per window slot: the slot mapped there, -1 = free
@@ -287,6 +288,8 @@ bool init(Placement &P, int dev) {
 // first dozen slots may well all be of one class -- slot 0's or not -- and one level alone does not say which.  Slots are
 // backed until a probe differs from the fastest by the distance of the two levels; none after kCalibrationCap: no classes to
 // tell apart on this device.
+void add_free(std::map<size_t, size_t> &fl, size_t off, size_t len);
+
 hipError_t calibrate(Placement &P) {
     hipError_t err = hipSuccess;
     while (!P.calibrated) {
@@ -298,6 +301,14 @@ hipError_t calibrate(Placement &P) {
         }
     }
     if (err == hipSuccess) err = split_not_a(P);
+    // The state's first home is slot 0 itself, behind the probe's 64-MiB window: every other slot is classified by what a stream of
+    // it suffers beside writes into THAT memory, so "apart from slot 0" is "apart from the moments" without going through a second
+    // slot's own classification (which is fuzzy where the card interleaves its classes finer than a GiB: runs of probe ratios
+    // between the two levels, profiles/r05_acc_bisect5.log).  960 MiB: the moments and work images of a 1080p film twice over.
+    if (err == hipSuccess && !P.no_contrast && !P.slot0_dealt) {
+        add_free(P.free_blocks[STATMC_MEM_STATE], kProbeWindow, kSlot - kProbeWindow);
+        P.slot0_dealt = true;
+    }
     return err;
 }
 
@@ -484,6 +495,7 @@ int placed_alloc(Placement &P, int role, size_t bytes, void **out) {
     const size_t need = (bytes + kBlock - 1) / kBlock * kBlock;
     if (take_block(P, role, need, out) == STATMC_OK) return STATMC_OK;
     if (hipError_t e = calibrate(P); e != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "placement probe: %s", hipGetErrorString(e));
+    if (take_block(P, role, need, out) == STATMC_OK) return STATMC_OK;   // (the calibration deals slot 0's tail to the state role)
     // whole slots are dealt; the free list joins them with what the role already holds next to them
     const size_t want_slots = (need + kSlot - 1) / kSlot;
     // how much of the card the search for the right class may back: 60 % for the first choice, 75 % at all (the rest of the
@@ -578,7 +590,9 @@ int placement_role_of(const void *ptr) {
         if (!P.base || !P.vmm || !P.calibrated || P.no_contrast) continue;
         if (auto w = window_of(P, ptr); w != P.windows.end()) return w->second.wanted ? w->second.role : -1;
         if ((const char *)ptr < P.base || (const char *)ptr >= P.base + P.slots.size() * kSlot) continue;
-        const Slot &s = P.slots[(size_t)((const char *)ptr - P.base) / kSlot];
+        const size_t off = (size_t)((const char *)ptr - P.base);
+        if (off < kSlot) return P.slot0_dealt && off >= kProbeWindow ? STATMC_MEM_STATE : -1;   // slot 0: the allocator's own, and the state's first home
+        const Slot &s = P.slots[off / kSlot];
         return s.role >= 0 && !s.as_it_came ? s.role : -1;
     }
     return -1;
@@ -676,6 +690,7 @@ int statmc_placement_info(statmc_placement_info_t *out) {
             if (s.as_it_came) out->slots_as_they_came[s.role]++;
         }
     }
+    if (P.slot0_dealt) out->slab_bytes[STATMC_MEM_STATE] += kSlot - kProbeWindow;
     for (const auto &kv : P.live) out->live_bytes[kv.second.second] += kv.second.first;
     for (const auto &kv : P.windows) out->live_bytes[kv.second.role] += kv.second.bytes;
     return STATMC_OK;

@@ -28,9 +28,14 @@ def test_placed_blocks_are_ordinary_memory(gpu):
     assert info["live_bytes"][gpu.MEM_STATE] >= a.numel() * 4 and info["live_bytes"][gpu.MEM_STREAM] >= b.numel() * 4
     assert len(info["map"]) == info["slots"] and info["map"][0] == "#"
     if info["active"]:
-        # the state block sits in a slot of class A, the stream block in one of class B (or C)
-        base_state = next(i for i, ch in enumerate(info["map"]) if ch == "A")
-        assert any(ch in "BC" for ch in info["map"]) and base_state >= 1
+        # the state block sits in slot 0 itself, behind the probe's window (what every other slot is measured against), the stream
+        # block in a slot of one of the other two classes
+        lib = gpu.load()
+        lib.statmc_debug_placement_role.restype = C.c_int
+        lib.statmc_debug_placement_role.argtypes = [C.c_void_p]
+        assert lib.statmc_debug_placement_role(C.c_void_p(a.data_ptr())) == gpu.MEM_STATE
+        assert lib.statmc_debug_placement_role(C.c_void_p(b.data_ptr())) == gpu.MEM_STREAM
+        assert any(ch in "BC" for ch in info["map"]) and "A" not in info["map"]
         assert info["slow_probe_ms"] > 1.05 * info["fast_probe_ms"]
     # free -> the space is reused by the next block of the same role
     p = a.data_ptr()
