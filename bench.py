@@ -161,11 +161,27 @@ def cpu_baseline(args, fs, samples, types, budget_s=6.0):
     W, H = args.width, args.height
     S = next(iter(samples.values())).shape[0]          # the resident samples (all of --spp unless a pool was needed)
     # the binding to the GPU's NUMA node (bind_to_gpu_numa) is for the GPU path: the CPU legs get every CPU the box allows
-    affinity_before = len(os.sched_getaffinity(0))
+    mask_before = os.sched_getaffinity(0)
+    affinity_before = len(mask_before)
     try:
         os.sched_setaffinity(0, range(os.cpu_count() or 1))
     except Exception:      # noqa: BLE001
         pass
+    try:
+        return _cpu_baseline_legs(args, fs, samples, types, budget_s, affinity_before)
+    finally:
+        try:                # the host-side legs that follow run under the GPU's NUMA binding again
+            os.sched_setaffinity(0, mask_before)
+        except Exception:      # noqa: BLE001
+            pass
+
+
+def _cpu_baseline_legs(args, fs, samples, types, budget_s, affinity_before):
+    import numpy as np
+    from oracle import oracle
+    from statmc_amd.film import STAT_TYPES
+    W, H = args.width, args.height
+    S = next(iter(samples.values())).shape[0]
     share = cpu_share()
     cores = min(share["usable_cpus"], oracle.num_threads())
 
@@ -525,9 +541,149 @@ def accumulate_by_batch_4k(args, dev, types):
         del part
     fs4 = new_film_stats(W, H, dev, types)
     out = accumulate_by_batch(fs4, smp, types, reps=6)
-    del smp, fs4
+    del fs4
+    try:        # BASELINE configs[4]'s film on ONE GPU, 64 resident spp: the step
+        out["config4_step"] = config_step_leg(W, H, S, dev, types, args, "configs[4] film 3840x2160 on one GPU, 64 spp", reps=4, smp=smp)
+    except Exception as e:      # noqa: BLE001
+        out["config4_step"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
+    del smp
     torch.cuda.empty_cache()
     return out
+
+
+def _ev_ms(pairs):
+    return sum(a.elapsed_time(b) for a, b in pairs)
+
+
+def _step_legs(fs, samples, types, batches, reps, reset_per_step):
+    """`reps` steps of accumulate(batch) -> pre-pass -> window filter per batch on `fs`; per-stage HIP-event sums and the wall
+    time of the whole loop (device-synchronised on both sides)."""
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    stages = {"accumulate": [], "prepass": [], "filter": []}
+
+    def timed(name, fn, *a):
+        e0, e1 = ev(), ev()
+        e0.record()
+        fn(*a)
+        e1.record()
+        stages[name].append((e0, e1))
+
+    def one(record):
+        if reset_per_step:
+            fs.reset()
+        pos = 0
+        for b in batches:
+            part = samples if (pos == 0 and b == next(iter(samples.values())).shape[0]) else {t: v[pos:pos + b] for t, v in samples.items()}
+            if record:
+                timed("accumulate", fs.accumulate, part)
+                timed("prepass", fs.prepass)
+                timed("filter", fs.window_filter)
+            else:
+                fs.accumulate(part)
+                fs.prepass()
+                fs.window_filter()
+            pos += b
+    one(False)
+    one(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one(True)
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3 / reps
+    return wall_ms, {k: _ev_ms(v) / reps for k, v in stages.items()}
+
+
+def reference_schedule_leg(fs, samples, types, args, reps=4):
+    """The step a StatMC user sees: the reference's progressive schedule -- iterations of 4, 4, 8, 16, ...
+    samples up to --spp (statpath.cpp:272-279), the denoiser after EVERY iteration (statpath.cpp:406-418), statistics reset at the
+    start of a render -- on the timed step's own film and sample pool.  Secondary; runs after the CPU baseline (it resets `fs`)."""
+    from statmc_amd import api, synthetic
+    S = next(iter(samples.values())).shape[0]
+    batches = synthetic.sample_schedule(min(args.spp, S))
+    wall_ms, st = _step_legs(fs, samples, types, batches, reps, reset_per_step=True)
+    W, H = fs.width, fs.height
+    acc_bytes = sum(accumulate_bytes_per_px(b, types) for b in batches) * W * H
+    return {"film": "%dx%d" % (W, H), "spp": sum(batches), "iterations": len(batches), "batches": batches,
+            "ms_per_step": round(wall_ms, 4), "mpixels_per_s": round(W * H / wall_ms / 1e3, 2),
+            "accumulate_ms": round(st["accumulate"], 4), "prepass_ms": round(st["prepass"], 4), "filter_ms": round(st["filter"], 4),
+            "filter_share": round(st["filter"] / max(wall_ms, 1e-9), 4),
+            "accumulate_frac_hbm": round(acc_bytes / (st["accumulate"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "filter_ms_per_iteration": round(st["filter"] / len(batches), 4), "filter_variant": api.last_filter_variant(),
+            "what": "one 256-spp render in the reference's own schedule: %d iterations, pre-pass + window filter after each, statistics "
+                    "reset per step (the reset's memsets are inside ms_per_step); %d steps" % (len(batches), reps)}
+
+
+def config_step_leg(W, H, S, dev, types, args, name, reps, smp=None):
+    """One BASELINE config that the timed step does not run, on this GPU: a WxH film, S resident samples per pixel, the same step
+    (accumulate of all S, pre-pass, window filter).  Buffers placed like the timed step's.  Secondary."""
+    from statmc_amd import api, synthetic
+    free_b = torch.cuda.mem_get_info(dev)[0]
+    need = 4 * args.channels * W * H * S
+    if smp is None and free_b < 2 * need + (8 << 30):
+        return {"skipped": "not enough free memory for a %dx%d / %d-spp pool (%.0f GiB free)" % (W, H, S, free_b / 2 ** 30)}
+    own = smp is None
+    if own:
+        scene = synthetic.Scene(W, H, n_regions=12, seed=1, device=dev)
+        smp = {t: new_arena((S, H, W, synthetic.CHANNELS[t]), dev) for t in types}
+        for s0 in range(0, S, 16):
+            part = scene.samples(min(16, S - s0), seed=77 + s0, features=types)
+            for t in types:
+                smp[t][s0:s0 + part[t].shape[0]] = part[t]
+            del part
+    fsx = new_film_stats(W, H, dev, types, filter_sd=args.filtersd, radius=args.radius)
+    wall_ms, st = _step_legs(fsx, smp, types, [S], reps, reset_per_step=False)
+    bpp = accumulate_bytes_per_px(S, types)
+    out = {"config": name, "film": "%dx%d" % (W, H), "spp": S, "ms_per_step": round(wall_ms, 4), "mpixels_per_s": round(W * H / wall_ms / 1e3, 2),
+           "accumulate_ms": round(st["accumulate"], 4), "accumulate_frac_hbm": round(bpp * W * H / (st["accumulate"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "prepass_ms": round(st["prepass"], 4), "filter_ms": round(st["filter"], 4), "filter_variant": api.last_filter_variant(),
+           "filter_parts": api.load().statmc_debug_last_filter_parts(), "steps": reps}
+    del fsx
+    if own:
+        del smp
+        torch.cuda.empty_cache()
+    return out
+
+
+def accumulate_unplaced_ab(fs, samples, types, reps=6):
+    """In-process A/B of the placed allocator: the timed step's accumulation launch, back to back, on the
+    step's own (placed) buffers and on copies of them that come from torch's allocator (hipMalloc).  Outside the timed region."""
+    from statmc_amd import film
+    if not PLACED["on"]:
+        return {"skipped": "the step's buffers are not placed"}
+    W, H, dev = fs.width, fs.height, fs.device
+    need = sum(v.numel() * 4 for v in samples.values())
+    free_b = torch.cuda.mem_get_info(dev)[0]
+    if free_b < need + (8 << 30):
+        return {"skipped": "not enough free memory for an unplaced copy of the sample pool (%.0f GiB free)" % (free_b / 2 ** 30)}
+    S = next(iter(samples.values())).shape[0]
+    bpp = accumulate_bytes_per_px(S, types)
+
+    def b2b(f, smp):
+        f.accumulate(smp)
+        torch.cuda.synchronize()
+        runs = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                f.accumulate(smp)
+            e1.record()
+            torch.cuda.synchronize()
+            runs.append(e0.elapsed_time(e1) / reps)
+        return sorted(runs)[1]
+    placed_ms = b2b(fs, samples)
+    smp_u = {t: torch.empty(v.shape, dtype=torch.float32, device=dev) for t, v in samples.items()}
+    for t in types:
+        smp_u[t].copy_(samples[t])
+    fs_u = film.FilmStats(W, H, dev, types=types)
+    unplaced_ms = b2b(fs_u, smp_u)
+    del smp_u, fs_u
+    torch.cuda.empty_cache()
+    frac = lambda ms: round(bpp * W * H / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return {"spp": S, "placed_ms": round(placed_ms, 4), "placed_frac_hbm": frac(placed_ms), "unplaced_ms": round(unplaced_ms, 4),
+            "unplaced_frac_hbm": frac(unplaced_ms), "what": "the step's accumulation launch back to back (%d launches, median of 3): statmc_malloc_placed "
+            "buffers against torch-allocated copies of the same bytes, same process" % reps}
 
 
 def bind_to_gpu_numa(dev_index):
@@ -1030,6 +1186,14 @@ def main():
     for _ in range(args.warmup):
         step(False)
     barrier()
+    # every buffer of the step is dealt by now (the library's workspaces came with the warm-up's first filter): the slots of the
+    # classes nobody asked for go back to the driver, so that the line's `placement` is what the step holds, not what the search met
+    if PLACED["on"] and not os.environ.get("STATMC_BENCH_NO_TRIM"):
+        try:
+            PLACED["trimmed"] = api.placement_trim()
+        except api.StatmcError as e:
+            PLACED["trim_error"] = str(e)[-200:]
+        barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
@@ -1206,10 +1370,22 @@ def main():
                     return fn(*a)
                 except Exception as e:      # noqa: BLE001
                     return {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
+            ab = leg(accumulate_unplaced_ab, fs, samples, types)
+            result["accumulate_placement_ab"] = ab
+            if isinstance(ab, dict) and "unplaced_ms" in ab:      # the keys VERDICT r5 item 3 names
+                result["kernels"]["accumulate"]["unplaced_ms"] = ab["unplaced_ms"]
+                result["kernels"]["accumulate"]["unplaced_frac_hbm"] = ab["unplaced_frac_hbm"]
+                result["kernels"]["accumulate"]["placed_back_to_back_ms"] = ab["placed_ms"]
+            if args.schedule == "single" and not fed_by_tiles:
+                result["reference_schedule"] = leg(reference_schedule_leg, fs, samples, types, args)
+            if (args.width, args.height) == (1920, 1080):
+                result["config1_1280x720_64spp"] = leg(config_step_leg, 1280, 720, 64, dev, types, args, "configs[1] 1280x720, 64 spp", 10)
             result["cuda_time_bracket"] = leg(host_bracket, fs, args)
             result["tile_fed_accumulate"] = leg(tile_fed_accumulate, fs, samples, types)
             result["accumulate_by_batch"] = leg(accumulate_by_batch, fs, samples, types)
             result["accumulate_by_batch_3840x2160"] = leg(accumulate_by_batch_4k, args, dev, types)
+            if isinstance(result["accumulate_by_batch_3840x2160"], dict) and "config4_step" in result["accumulate_by_batch_3840x2160"]:
+                result["config4_3840x2160_64spp_one_gpu"] = result["accumulate_by_batch_3840x2160"].pop("config4_step")
             result["host_copies"] = leg(host_copy_times, fs, dev)
             result["filter_8_feature_channels"] = leg(eight_channel_filter, fs, args)
             result["pcie_inclusive"] = leg(pcie_inclusive, fs, samples, types, args)
@@ -1284,6 +1460,8 @@ def placement_report():
                        slots_c=info["slots_c"], slots_unclear=info["slots_unclear"], slots_idle=info["slots_idle"],
                        slots_as_they_came=info["slots_as_they_came"], probe_ms=[round(info["fast_probe_ms"], 4), round(info["slow_probe_ms"], 4)],
                        state_GiB=round(info["slab_bytes"][0] / 2 ** 30, 1), stream_GiB=round(info["slab_bytes"][1] / 2 ** 30, 1), map=info["map"],
+                       slots_released=info["slots_released"], trimmed_before_timing=PLACED.get("trimmed"), trim_error=PLACED.get("trim_error"),
+                       budget="1.5 x the bytes asked for + 6 GiB (STATMC_PLACEMENT_MAX_GIB=%s)" % os.environ.get("STATMC_PLACEMENT_MAX_GIB", "unset"),
                        what="running moments in GiB slots of class A, sample arenas in ONE of the other two classes -- the one the card has at hand -- (a stream read beside writes into its own "
                             "class runs ~ 9 % slower on MI355X; the class travels with the physical memory -- most likely its HBM rank -- and is measured per GiB, 0.2 ms each)")
         except Exception as e:      # noqa: BLE001
@@ -1382,14 +1560,18 @@ def build_result(c):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "n_ranks_seen": c["n_ranks_seen"], "backend": c["backend"] if world > 1 else "single",
         "config": {
-            "workload": "StatMC accumulate+prepass+filter, %dx%d film in %d block(s) of %dx%d, %d spp, %d-channel samples, "
-                        "filterradius %d, filtersd %g, G-buffers normal(sd 0.1)+albedo(sd 0.02) "
-                        "[BASELINE.json %s shape, synthetic stream]%s"
-                        % (fw, fh, world, W, H, S, args.channels, r, args.filtersd,
-                           "configs[4]" if (fw, fh, S) == (3840, 2160, 1024) else "configs[2]",
-                           "" if args.schedule == "single" else
-                           "; reference schedule: %d iterations of %s samples, pre-pass + filter after each, statistics reset per step"
-                           % (n_iter, ",".join(str(b) for b in batches))),
+            # (the driver keeps 120 characters of this string: the facts that must survive come first and are keys of their own below)
+            "workload": "StatMC acc+prepass+filter %dx%d %dspp %dch r=%d sd=%g %s%s"
+                        % (fw, fh, S, args.channels, r, args.filtersd,
+                           "configs[4]" if (fw, fh, S) == (3840, 2160, 1024) else "configs[1]" if (fw, fh, S) == (1280, 720, 64) else "configs[2]",
+                           "" if args.schedule == "single" else " ref-schedule %dit" % n_iter),
+            "workload_long": "StatMC accumulate+prepass+filter, %dx%d film in %d block(s) of %dx%d, %d spp, %d-channel samples, "
+                             "filterradius %d, filtersd %g, G-buffers normal(sd 0.1)+albedo(sd 0.02) [synthetic stream]%s"
+                             % (fw, fh, world, W, H, S, args.channels, r, args.filtersd,
+                                "" if args.schedule == "single" else
+                                "; reference schedule: %d iterations of %s samples, pre-pass + filter after each, statistics reset per step"
+                                % (n_iter, ",".join(str(b) for b in batches))),
+            "radius": r, "filter_sd": args.filtersd, "g_buffers": ["normal", "albedo"], "g_sds": [0.1, 0.02],
             "film": "%dx%d" % (fw, fh), "block_grid": "%dx%d" % (c["gx"], c["gy"]),
             "spp": S, "sample_channels": args.channels, "filter_variant": variant,
             "schedule": args.schedule, "iterations_per_step": n_iter,

@@ -457,7 +457,11 @@ int statmc_malloc(void **dev_ptr, size_t bytes) {
     return STATMC_OK;
 }
 int statmc_free(void *dev_ptr) {
-    if (dev_ptr && statmc::placement_free(dev_ptr)) return STATMC_OK;   // a statmc_malloc_placed block goes back to its slab
+    if (dev_ptr) {      // a statmc_malloc_placed block goes back to its slab
+        const int placed = statmc::placement_free(dev_ptr);
+        if (placed > 0) return STATMC_OK;
+        if (placed < 0) return statmc::abi_fail(STATMC_ERR_INVALID, "statmc_free: %p lies inside the placed allocator's range but is not the start of a live block", dev_ptr);
+    }
     HIP_TRY(hipFree(dev_ptr));
     return STATMC_OK;
 }

@@ -227,7 +227,7 @@ int choose_parts(int tiles, int n_rows, int n_cus);
 // statmc_placement.hip (device memory placed by HBM rank)
 int abi_fail(int code, const char *fmt, ...);   // records the calling thread's statmc_last_error() text, returns `code` (statmc_abi.hip)
 int placement_role_of(const void *ptr);         // STATMC_MEM_STATE / _STREAM when `ptr` lies in a block dealt with the wanted class, else -1
-bool placement_free(void *ptr);                 // true: `ptr` was a statmc_malloc_placed block and is free now
+int placement_free(void *ptr);                  // 1: `ptr` was a statmc_malloc_placed block and is free now; 0: not the placed allocator's; -1: inside its ranges, not a live block's start
 hipError_t workspace_alloc(void **p, size_t bytes);   // the library's own read-and-written workspaces: STATE role where the device's caller uses placed memory, hipMalloc otherwise
 hipError_t workspace_free(void *p);
 // parts per tile the LDS kernel would use for this ROI on a device with n_cus compute units

@@ -32,9 +32,11 @@
 // time side by side in a second reserved range (one physical allocation may be mapped at several addresses, and the class is
 // the memory's, not the address's; blocks above 2 GiB) -- so a 6-GiB arena needs six class-B slots, not six in a row: on a card whose classes come
 // in short runs the first version backed 170 GiB to find three runs of six and still put an arena into class C.  Slots are
-// backed until there are enough (up to 60 % of the card; after that the third class, then both up to 75 % of the card, then
-// anything); smaller blocks are carved out of whole slots dealt to their role.  What no role uses stays mapped and idle (about twice what the
-// arenas take, on a 288 GB card) until statmc_placement_trim gives it back to the driver.  No contrast between the probes, no
+// backed until there are enough OF THE WANTED CLASS or the search's byte budget is spent: 1.5 x what the device's callers have asked
+// for so far (+ 6 GiB), or STATMC_PLACEMENT_MAX_GIB; never more than 60 % / 75 % of the card (round 6; until then the two card
+// fractions were the only bounds: 101 GiB backed to place 23).  After that the third class, then both, then anything.  Smaller blocks
+// are carved out of whole slots dealt to their role.  What no role uses stays mapped and idle until statmc_placement_trim gives it
+// back to the driver (a host calls it once its buffers are dealt: bench.py, statmc::Estimator::AllocateBuffers).  No contrast between the probes, no
 // virtual-memory support, too little memory: the call degrades to slots as they come -- placement is an optimisation, never
 // a requirement -- and statmc_placement_info says so.  STATMC_PLACEMENT=0 turns the call into hipMalloc.
 
@@ -115,7 +117,8 @@ struct Window {               // a block of whole slots mapped side by side in t
 struct Placement {
     bool init_tried = false, vmm = false, calibrated = false, no_contrast = false;
     hipMemAllocationProp prop;
-    hipMemAccessDesc access;
+    std::vector<hipMemAccessDesc> access;    // the owning device first, then every device that can reach it as a peer
+    bool peers_granted = false;              // false: only the owner (hipMemSetAccess refused the peers, or there are none)
     char *base = nullptr;                    // GiB-aligned start of the slots (inside the reservation)
     float *sink = nullptr;
     hipStream_t stream = nullptr;
@@ -151,6 +154,45 @@ int classify(const Placement &P, const Slot &s) {
     if (s.probe_ms[1] > kSameAbove * P.fastest_ms) return kClassB;
     if (s.probe_ms[1] < kApartBelow * P.fastest_ms) return kClassC;
     return kMixed;
+}
+
+// slots that hold memory (the range's holes -- statmc_placement_trim -- do not count against a search's cap)
+size_t backed_count(const Placement &P) {
+    size_t n = 0;
+    for (const Slot &s : P.slots) n += s.role != kReleased ? 1 : 0;
+    return n;
+}
+// bytes in live blocks of both roles
+size_t live_total(const Placement &P) {
+    size_t b = 0;
+    for (const auto &kv : P.live) b += kv.second.first;
+    for (const auto &kv : P.windows) b += kv.second.n * kSlot;
+    return b;
+}
+// How many slots the search for a CLASS may have backed, for a device whose callers hold `live_total` and now ask for `need` more:
+// STATMC_PLACEMENT_MAX_GIB if set (> 0), else 1.5 x the bytes asked for + 6 slots (the allocator's own two and what the calibration
+// needs to see both levels).  A third of a card's slots is of any one class, so 1.5 x usually yields "state in A, arenas in B and C"
+// rather than "arenas in B alone" (0.82 against 0.84 of the HBM peak at 1080p / 256 spp; everything in one class: 0.76) -- the price of
+// not backing three times the request.
+size_t budget_slots(const Placement &P, size_t need) {
+    static const double env_gib = [] { const char *e = getenv("STATMC_PLACEMENT_MAX_GIB"); return e ? atof(e) : 0.0; }();
+    if (env_gib > 0.0) return (size_t)env_gib;
+    return (size_t)(1.5 * (double)(live_total(P) + need) / (double)kSlot + 0.999) + 6;
+}
+
+// grants the mapping at `at` to the owner and, where the runtime accepts it, to the peers (a block of this allocator is then a
+// valid operand of statmc_copy_rect / statmc_halo_exchange between devices, like a hipMalloc block under hipDeviceEnablePeerAccess)
+hipError_t set_access(Placement &P, void *at) {
+    if (P.access.size() > 1) {
+        if (hipMemSetAccess(at, kSlot, P.access.data(), P.access.size()) == hipSuccess) {
+            P.peers_granted = true;
+            return hipSuccess;
+        }
+        (void)hipGetLastError();
+        P.access.resize(1);            // this runtime takes no peer descriptors: owner only from here on (statmc_placement_info says so)
+        P.peers_granted = false;
+    }
+    return hipMemSetAccess(at, kSlot, P.access.data(), 1);
 }
 
 hipError_t probe_slot(Placement &P, size_t index, int which = 0) {
@@ -219,7 +261,7 @@ bool back_next_slot(Placement &P, hipError_t *err, size_t leave_free = 512ull <<
     char *at = P.base + index * kSlot;
     hipError_t e = hipMemMap(at, kSlot, 0, s.handle, 0);
     if (e == hipSuccess) {
-        e = hipMemSetAccess(at, kSlot, &P.access, 1);
+        e = set_access(P, at);
         if (e != hipSuccess) (void)hipMemUnmap(at, kSlot);
     }
     if (e != hipSuccess) {
@@ -253,9 +295,22 @@ bool init(Placement &P, int dev) {
     P.prop.type = hipMemAllocationTypePinned;
     P.prop.location.type = hipMemLocationTypeDevice;
     P.prop.location.id = dev;
-    memset(&P.access, 0, sizeof(P.access));
-    P.access.location = P.prop.location;
-    P.access.flags = hipMemAccessFlagsProtReadWrite;
+    hipMemAccessDesc own;
+    memset(&own, 0, sizeof(own));
+    own.location = P.prop.location;
+    own.flags = hipMemAccessFlagsProtReadWrite;
+    P.access.assign(1, own);
+    // every device that can reach this one as a peer gets the mapping too: hipDeviceEnablePeerAccess -- all that statmc_copy_rect's
+    // enable_peer does -- does not cover memory made by hipMemCreate / hipMemMap
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess) { (void)hipGetLastError(); n_dev = 0; }
+    for (int d = 0; d < n_dev; d++) {
+        int can = 0;
+        if (d == dev || hipDeviceCanAccessPeer(&can, d, dev) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
+        hipMemAccessDesc peer = own;
+        peer.location.id = d;
+        P.access.push_back(peer);
+    }
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 4 * kSlot) return false;
     P.total_bytes = total_b;
@@ -293,7 +348,16 @@ void add_free(std::map<size_t, size_t> &fl, size_t off, size_t len);
 hipError_t calibrate(Placement &P) {
     hipError_t err = hipSuccess;
     while (!P.calibrated) {
-        if (P.n_probes >= 2 && P.slowest_ms > kContrast * P.fastest_ms) {
+        // both levels on at least two slots each (one noisy probe -- a clock ramp, somebody else's kernel -- must not
+        // invent a class)
+        int n_fast = 0, n_slow = 0;
+        for (size_t i = 1; i < P.slots.size(); i++) {
+            const float t = P.slots[i].probe_ms[0];
+            if (t <= 0.f) continue;
+            n_fast += t < kApartBelow * P.fastest_ms ? 1 : 0;
+            n_slow += t > kContrast * P.fastest_ms ? 1 : 0;
+        }
+        if (n_fast >= 2 && n_slow >= 2) {
             P.calibrated = true;
         } else if (P.n_probes >= kCalibrationCap || !back_next_slot(P, &err, 8ull << 30)) {
             P.calibrated = true;
@@ -384,7 +448,7 @@ int find_run(Placement &P, int role, size_t want_slots, unsigned mask, size_t ca
                 return STATMC_OK;
             }
         }
-        if (P.slots.size() >= cap_slots) return STATMC_ERR_UNSUPPORTED;
+        if (backed_count(P) >= cap_slots) return STATMC_ERR_UNSUPPORTED;
         hipError_t err = hipSuccess;
         if (!back_next_slot(P, &err, leave_free)) {
             if (err != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "placement: %s", hipGetErrorString(err));
@@ -402,7 +466,7 @@ int window_alloc(Placement &P, int role, size_t bytes, size_t want, unsigned mas
         for (size_t i = 1; i < P.slots.size() && chosen.size() < want; i++)
             if (suits(P, P.slots[i], mask)) chosen.push_back(i);
         if (chosen.size() == want) break;
-        if (P.slots.size() >= cap_slots) return STATMC_ERR_UNSUPPORTED;
+        if (backed_count(P) >= cap_slots) return STATMC_ERR_UNSUPPORTED;
         hipError_t err = hipSuccess;
         if (!back_next_slot(P, &err, leave_free)) {
             if (err != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "placement: %s", hipGetErrorString(err));
@@ -427,7 +491,7 @@ int window_alloc(Placement &P, int role, size_t bytes, size_t want, unsigned mas
         char *at = P.win_base + (first + k) * kSlot;
         hipError_t e = hipMemMap(at, kSlot, 0, P.slots[chosen[k]].handle, 0);
         if (e == hipSuccess) {
-            e = hipMemSetAccess(at, kSlot, &P.access, 1);
+            e = set_access(P, at);
             if (e != hipSuccess) (void)hipMemUnmap(at, kSlot);
         }
         if (e != hipSuccess) {
@@ -473,7 +537,7 @@ int pick_stream_class(Placement &P, size_t want, size_t cap_slots, size_t leave_
         }
         if (n[0] >= want || n[1] >= want) return n[0] >= want && n[0] >= n[1] ? kClassB : n[1] >= want ? kClassC : kClassB;
         hipError_t err = hipSuccess;
-        if (P.slots.size() >= cap_slots || !back_next_slot(P, &err, leave_free)) return n[1] > n[0] ? kClassC : kClassB;
+        if (backed_count(P) >= cap_slots || !back_next_slot(P, &err, leave_free)) return n[1] > n[0] ? kClassC : kClassB;
     }
 }
 
@@ -491,17 +555,24 @@ int take_block(Placement &P, int role, size_t need, void **out) {
     return STATMC_ERR_UNSUPPORTED;
 }
 
-int placed_alloc(Placement &P, int role, size_t bytes, void **out) {
+// may_back = false (the library's own workspaces, asked for from inside a filter call while the caller's kernels are in flight):
+// only what is backed already -- no new slot, hence no probe beside somebody's kernel and no search under the lock
+int placed_alloc(Placement &P, int role, size_t bytes, void **out, bool may_back = true) {
     const size_t need = (bytes + kBlock - 1) / kBlock * kBlock;
     if (take_block(P, role, need, out) == STATMC_OK) return STATMC_OK;
-    if (hipError_t e = calibrate(P); e != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "placement probe: %s", hipGetErrorString(e));
-    if (take_block(P, role, need, out) == STATMC_OK) return STATMC_OK;   // (the calibration deals slot 0's tail to the state role)
+    if (may_back) {
+        if (hipError_t e = calibrate(P); e != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "placement probe: %s", hipGetErrorString(e));
+        if (take_block(P, role, need, out) == STATMC_OK) return STATMC_OK;   // (the calibration deals slot 0's tail to the state role)
+    }
     // whole slots are dealt; the free list joins them with what the role already holds next to them
     const size_t want_slots = (need + kSlot - 1) / kSlot;
-    // how much of the card the search for the right class may back: 60 % for the first choice, 75 % at all (the rest of the
-    // process -- the caller's other allocations, the runtime's -- needs room too; beyond that: what is backed already, any class)
-    const size_t soft_cap = std::min<size_t>(kReserveSlots, (size_t)(0.60 * (double)P.total_bytes / (double)kSlot));
-    const size_t hard_cap = std::min<size_t>(kReserveSlots, (size_t)(0.75 * (double)P.total_bytes / (double)kSlot));
+    // how many slots the search for the right class may have backed: the byte budget (1.5 x what has been asked for, or
+    // STATMC_PLACEMENT_MAX_GIB), and never more than 60 % of the card for the first choice, 75 % at all (the rest of the process --
+    // the caller's other allocations, the runtime's -- needs room too; beyond that: what is backed already, any class)
+    const size_t budget = may_back ? budget_slots(P, need) : 0;
+    const size_t soft_cap = std::min<size_t>({kReserveSlots, (size_t)(0.60 * (double)P.total_bytes / (double)kSlot), budget});
+    const size_t hard_cap = std::min<size_t>({kReserveSlots, (size_t)(0.75 * (double)P.total_bytes / (double)kSlot), budget});
+    const size_t last_cap = may_back ? kReserveSlots : 0;
     struct Search { unsigned mask; size_t cap; bool wanted; };
     // which class serves which role: the state takes slot 0's class (A), the arenas ONE of the other two (pick_stream_class), then the third.
     // STATMC_PLACEMENT_ROLES=BCA etc. (experiment: are the classes interchangeable?) permutes that.
@@ -520,11 +591,11 @@ int placed_alloc(Placement &P, int role, size_t bytes, void **out) {
     }
     const unsigned not_state = bit(cT) | bit(cU) | (cS == kClassA ? bit(kNotA) : 0u);
     const Search state_order[] = {{bit(cS) | (cS == kClassA ? kWellInsideA : 0u), soft_cap, true}, {bit(cS), 0, true}, {bit(cS) | bit(kMixed), 0, false},
-                                  {kAnyClass, hard_cap, false}, {kAnyClass, kReserveSlots, false}};   // (last resort: until the card is full)
+                                  {kAnyClass, hard_cap, false}, {kAnyClass, last_cap, false}};   // (last resort: until the card is full)
     const Search stream_order[] = {{bit(cT), soft_cap, true},                            // one class for all arenas
                                    {bit(cU), 0, true},                                   // ... or the other one
                                    {not_state, hard_cap, true},                          // both (still apart from the state)
-                                   {kAnyClass, hard_cap, false}, {kAnyClass, kReserveSlots, false}};
+                                   {kAnyClass, hard_cap, false}, {kAnyClass, last_cap, false}};
     int rc = STATMC_ERR_UNSUPPORTED;
     const Search *order = role == STATMC_MEM_STATE ? state_order : stream_order;
     const int n_order = 5;
@@ -537,6 +608,7 @@ int placed_alloc(Placement &P, int role, size_t bytes, void **out) {
         for (int k = 0; k < n_order && rc == STATMC_ERR_UNSUPPORTED; k++)
             rc = window_alloc(P, role, bytes, want_slots, order[k].mask, order[k].cap, order[k].wanted, k + 1 < n_order ? (8ull << 30) : (512ull << 20), out);
         if (rc == STATMC_OK || rc == STATMC_ERR_HIP) return rc;
+        if (!may_back) return STATMC_ERR_UNSUPPORTED;
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         return statmc::abi_fail(STATMC_ERR_HIP, "statmc_malloc_placed: out of device memory (%zu slots backed, %d probes %.3f .. %.3f ms, %.1f GiB free, last: %s)",
@@ -545,6 +617,7 @@ int placed_alloc(Placement &P, int role, size_t bytes, void **out) {
     for (int k = 0; k < n_order && rc == STATMC_ERR_UNSUPPORTED; k++)
         rc = find_run(P, role, want_slots, order[k].mask, order[k].cap, order[k].wanted, k + 1 < n_order ? (8ull << 30) : (512ull << 20));
     if (rc == STATMC_ERR_HIP) return rc;
+    if (rc != STATMC_OK && !may_back) return STATMC_ERR_UNSUPPORTED;
     if (rc != STATMC_OK) {
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
@@ -570,13 +643,13 @@ hipError_t workspace_alloc(void **p, size_t bytes) {
         std::lock_guard<std::mutex> lk(g_place_mu);
         auto it = g_place.find(dev);
         if (it != g_place.end() && it->second.vmm && it->second.calibrated && !it->second.no_contrast &&
-            placed_alloc(it->second, STATMC_MEM_STATE, bytes ? bytes : 1, p) == STATMC_OK)
+            placed_alloc(it->second, STATMC_MEM_STATE, bytes ? bytes : 1, p, /*may_back=*/false) == STATMC_OK)
             return hipSuccess;
     }
     return hipMalloc(p, bytes);
 }
 hipError_t workspace_free(void *p) {
-    if (p && placement_free(p)) return hipSuccess;
+    if (p && placement_free(p) != 0) return hipSuccess;
     return hipFree(p);
 }
 
@@ -591,20 +664,36 @@ int placement_role_of(const void *ptr) {
         if (auto w = window_of(P, ptr); w != P.windows.end()) return w->second.wanted ? w->second.role : -1;
         if ((const char *)ptr < P.base || (const char *)ptr >= P.base + P.slots.size() * kSlot) continue;
         const size_t off = (size_t)((const char *)ptr - P.base);
-        if (off < kSlot) return P.slot0_dealt && off >= kProbeWindow ? STATMC_MEM_STATE : -1;   // slot 0: the allocator's own, and the state's first home
-        const Slot &s = P.slots[off / kSlot];
-        return s.role >= 0 && !s.as_it_came ? s.role : -1;
+        // every slot the live block around `ptr` covers must have been dealt to its role with the wanted class (free ranges of
+        // neighbouring slots coalesce whatever their class: a block may span a wanted slot and one taken as it came -- ADVICE r5)
+        size_t b0 = off, b1 = off + 1;
+        int role = -1;
+        if (auto it = P.live.upper_bound(off); it != P.live.begin()) {
+            --it;
+            if (off < it->first + it->second.first) { b0 = it->first; b1 = it->first + it->second.first; role = it->second.second; }
+        }
+        if (role < 0) return -1;                  // not inside a live block
+        for (size_t i = b0 / kSlot; i <= (b1 - 1) / kSlot; i++) {
+            if (i == 0) {                         // slot 0: the allocator's own, and -- behind the probe window -- the state's first home
+                if (!(P.slot0_dealt && role == STATMC_MEM_STATE && b0 >= kProbeWindow)) return -1;
+                continue;
+            }
+            const Slot &s = P.slots[i];
+            if (s.role != role || s.as_it_came) return -1;
+        }
+        return role;
     }
     return -1;
 }
 
-// statmc_free's question: is this pointer one of the placed allocator's?  Frees it if so.
-bool placement_free(void *ptr) {
+// statmc_free's question: is this pointer one of the placed allocator's?  1: it was a live block and is free now; 0: not this
+// allocator's; -1: inside its ranges but not the start of a live block (an interior pointer, a block freed twice)
+int placement_free(void *ptr) {
     std::lock_guard<std::mutex> lk(g_place_mu);
     for (auto &kv : g_place) {
         Placement &P = kv.second;
         if (auto w = window_of(P, ptr); w != P.windows.end()) {
-            if (P.win_base + w->first != (char *)ptr) return true;   // inside a window, not its start: nothing to do (and not hipFree's either)
+            if (P.win_base + w->first != (char *)ptr) return -1;   // inside a window, not its start: nothing to do (and not hipFree's either)
             int cur = 0;
             if (hipGetDevice(&cur) == hipSuccess) {
                 if (cur != kv.first) (void)hipSetDevice(kv.first);
@@ -621,11 +710,11 @@ bool placement_free(void *ptr) {
                 P.win_slot[ws] = -1;
             }
             P.windows.erase(w);
-            return true;
+            return 1;
         }
         if (!P.base || (char *)ptr < P.base || (char *)ptr >= P.base + P.slots.size() * kSlot) continue;
         auto it = P.live.find((size_t)((char *)ptr - P.base));
-        if (it == P.live.end()) return true;            // inside the range, not a live block: nothing to do (and not hipFree's either)
+        if (it == P.live.end()) return -1;            // inside the range, not a live block: nothing to do (and not hipFree's either)
         // like hipFree: work that may still use the block has finished before its memory can be handed out again
         int cur = 0;
         if (hipGetDevice(&cur) == hipSuccess) {
@@ -637,9 +726,9 @@ bool placement_free(void *ptr) {
         add_free(P.free_blocks[role], it->first, it->second.first);
         P.live.erase(it);
         undeal_free_slots(P, role);
-        return true;
+        return 1;
     }
-    return false;
+    return 0;
 }
 
 }  // namespace statmc
@@ -674,7 +763,9 @@ int statmc_placement_info(statmc_placement_info_t *out) {
     const Placement &P = it->second;
     out->active = P.vmm && P.calibrated && !P.no_contrast ? 1 : 0;
     out->virtual_memory = P.vmm ? 1 : 0;
-    out->slots = (int)P.slots.size();
+    out->slots = (int)backed_count(P);
+    out->slots_released = (int)(P.slots.size() - backed_count(P));
+    out->peer_devices = P.peers_granted ? (int)P.access.size() - 1 : 0;
     out->probes = P.n_probes;
     out->fast_probe_ms = P.fastest_ms;
     out->slow_probe_ms = P.slowest_ms;

@@ -37,6 +37,23 @@
 #define STATMC_SYM_PRIO 0
 #endif
 
+// round 6 (get the sweep off the per-step barrier), each measured and written up in HISTORY.md 4.3d:
+// GSPLIT = G > 0: the two waves of a row split the window at a read-group boundary instead of at dx = 0 -- half 0 sweeps
+// groups [0, G), half 1 groups [G, 11): no group is evaluated twice (84 instead of 86 (tap pair, pixel) units per lane and row)
+#ifndef STATMC_SYM_GSPLIT
+#define STATMC_SYM_GSPLIT 0
+#endif
+// which wave of a SIMD pair does the per-step housekeeping (flush, staging, LDS-DMA): 0 = the half-0 wave (the older one; the
+// product), 1 = the half-1 wave, 2 = alternating by step
+#ifndef STATMC_SYM_HK_HALF
+#define STATMC_SYM_HK_HALF 0
+#endif
+// per-wave progress words in LDS instead of the per-step s_barrier: a wave waits only for the wave that last touched the rows it
+// is about to sweep (and, trow 7, for the staged row), housekeeping after the sweep; the whole spatial table lives in LDS
+#ifndef STATMC_SYM_FLAGS
+#define STATMC_SYM_FLAGS 0
+#endif
+
 // timing-only ablations of the Welch gate (round 4): 1 = no table gather (a constant quantile), 2 = no NaN select on the
 // quotient, 4 = no quotient at all (nu = s^2): results are wrong with any bit set
 #ifndef STATMC_SYM_WELCH_ABLATE
@@ -45,8 +62,9 @@
 
 #define STATMC_SYM_DIAGNOSTIC_BITS                                                                                        \
     ((STATMC_SYM_ABLATE ? 1 : 0) | (STATMC_SYM_HK_END ? 2 : 0) | (STATMC_SYM_PIPE ? 4 : 0) | (STATMC_SYM_STAMPS ? 8 : 0) | \
-     (STATMC_SYM_SPLIT ? 16 : 0) | (STATMC_SYM_COUNT ? 32 : 0) | (STATMC_SYM_PRIO ? 64 : 0) | (STATMC_SYM_WELCH_ABLATE ? 256 : 0))
+     (STATMC_SYM_SPLIT ? 16 : 0) | (STATMC_SYM_COUNT ? 32 : 0) | (STATMC_SYM_PRIO ? 64 : 0) | (STATMC_SYM_WELCH_ABLATE ? 256 : 0) | \
+     (STATMC_SYM_GSPLIT ? 512 : 0) | (STATMC_SYM_HK_HALF ? 1024 : 0) | (STATMC_SYM_FLAGS ? 2048 : 0))
 
-#if defined(STATMC_PRODUCT_BUILD) && STATMC_SYM_ABLATE + STATMC_SYM_HK_END + STATMC_SYM_PIPE + STATMC_SYM_STAMPS + STATMC_SYM_SPLIT * STATMC_SYM_SPLIT + STATMC_SYM_COUNT + STATMC_SYM_PRIO + STATMC_SYM_WELCH_ABLATE != 0
+#if defined(STATMC_PRODUCT_BUILD) && STATMC_SYM_ABLATE + STATMC_SYM_HK_END + STATMC_SYM_PIPE + STATMC_SYM_STAMPS + STATMC_SYM_SPLIT * STATMC_SYM_SPLIT + STATMC_SYM_COUNT + STATMC_SYM_PRIO + STATMC_SYM_WELCH_ABLATE + STATMC_SYM_GSPLIT + STATMC_SYM_HK_HALF + STATMC_SYM_FLAGS != 0
 #error "a STATMC_SYM_* diagnostic switch is set in the product build (statmc_amd/build.py): it would ship a wrong or slower filter"
 #endif

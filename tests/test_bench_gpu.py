@@ -45,6 +45,18 @@ def test_single_gpu_line(gpu):
     assert r["host_copies"]["upload_bytes_per_px"] == 76 and r["host_copies"]["download_bytes_per_px"] == 12
     assert r["filter_8_feature_channels"]["filter_variant"] == "sym_r20_g8" and r["filter_8_feature_channels"]["avg_ms"] > 0
     assert r["pcie_inclusive"]["GBs"] > 0 and r["pcie_inclusive"]["mpixels_per_s_if_samples_cross_pcie"] < r["value"]
+    # round 6: the filter parameters as keys of their own (the driver keeps 120 characters of `workload`), the placed allocator trimmed
+    # before the timed region and A/B'd against torch's allocator in the same process, the reference's progressive schedule as a leg
+    cfg = r["config"]
+    assert len(cfg["workload"]) <= 120 and cfg["radius"] == 20 and cfg["filter_sd"] == 10.0 and cfg["g_sds"] == [0.1, 0.02]
+    pl = r["placement"]
+    if pl.get("active"):
+        assert pl["slots_idle"] == 0 and pl["trimmed_before_timing"] is not None and pl["slots"] <= 12, pl
+    ab = r["accumulate_placement_ab"]
+    assert ab["placed_ms"] > 0 and ab["unplaced_ms"] > 0 and r["kernels"]["accumulate"]["unplaced_frac_hbm"] == ab["unplaced_frac_hbm"]
+    rs = r["reference_schedule"]
+    assert rs["batches"] == [4, 4] and rs["iterations"] == 2 and rs["ms_per_step"] > 0 and 0 < rs["filter_share"] < 1
+    assert abs(rs["accumulate_ms"] + rs["prepass_ms"] + rs["filter_ms"] - rs["ms_per_step"]) < 0.5 * rs["ms_per_step"]
 
 
 def test_step_fed_by_tile_blocks(gpu, tmp_path):

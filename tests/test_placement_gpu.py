@@ -26,7 +26,7 @@ def test_placed_blocks_are_ordinary_memory(gpu):
     info = gpu.placement_info()
     assert info["virtual_memory"] == 1 and info["slots"] >= 3
     assert info["live_bytes"][gpu.MEM_STATE] >= a.numel() * 4 and info["live_bytes"][gpu.MEM_STREAM] >= b.numel() * 4
-    assert len(info["map"]) == info["slots"] and info["map"][0] == "#"
+    assert len(info["map"]) == info["slots"] + info["slots_released"] and info["map"][0] == "#"
     if info["active"]:
         # the state block sits in slot 0 itself, behind the probe's window (what every other slot is measured against), the stream
         # block in a slot of one of the other two classes
@@ -161,6 +161,53 @@ def test_trim_releases_the_idle_slots_and_the_allocator_goes_on(gpu):
     if after["map"].count("_"):
         assert again["map"].count("_") < after["map"].count("_"), (after["map"], again["map"])
     assert float(keep.sum().item()) == 3.0 * (1 << 20)
+
+
+def test_free_of_an_interior_pointer_is_an_error_and_role_needs_a_live_block(gpu):
+    """statmc_free must not report OK for a pointer inside the allocator's range that is not a live block's start, and
+    the role statmc_accumulate learns about a buffer is that of the LIVE block around the address (every slot it covers)."""
+    dev = torch.device("cuda:0")
+    lib = gpu.load()
+    lib.statmc_debug_placement_role.restype = C.c_int
+    lib.statmc_debug_placement_role.argtypes = [C.c_void_p]
+    p = C.c_void_p()
+    assert lib.statmc_malloc_placed(C.byref(p), 8 << 20, gpu.MEM_STREAM) == 0
+    inside = C.c_void_p(p.value + (4 << 20))
+    assert lib.statmc_free(inside) == gpu.ERR_INVALID            # an interior pointer
+    if gpu.placement_info()["active"]:
+        assert lib.statmc_debug_placement_role(inside) == gpu.MEM_STREAM
+    assert lib.statmc_free(p) == 0
+    assert lib.statmc_free(p) == gpu.ERR_INVALID                 # freed twice
+    assert lib.statmc_debug_placement_role(inside) == -1         # no live block there any more
+    info = gpu.placement_info()
+    assert info["peer_devices"] >= 0 and info["peer_devices"] <= torch.cuda.device_count() - 1
+
+
+def test_the_search_for_a_class_stays_inside_its_byte_budget():
+    """the class search backs at most 1.5 x the bytes asked for (+ 6 GiB) -- not 60 % of the card --, an explicit
+    STATMC_PLACEMENT_MAX_GIB is honoured, and trimming leaves no idle slot."""
+    code = ("import torch, sys; sys.path.insert(0, %r)\n"
+            "from statmc_amd import api\n"
+            "api.setup(0)\n"
+            "dev = torch.device('cuda:0')\n"
+            "st = api.zeros_placed((1 << 24,), torch.float32, dev, api.MEM_STATE)\n"
+            "c0 = api.placement_info()['slots']      # what the calibration had to back to see both probe levels (runs of one class can be long)\n"
+            "blocks = [api.empty_placed((6 << 28,), torch.float32, dev, api.MEM_STREAM) for _ in range(3)]\n"
+            "i = api.placement_info()\n"
+            "cap = max(int(sys.argv[1]), c0)\n"
+            "assert i['slots'] <= cap, (i['slots'], cap, i['map'])\n"
+            "assert i['live_bytes'][1] >= 3 * (6 << 30)\n"
+            "n = api.placement_trim(); j = api.placement_info()\n"
+            "assert j['slots_idle'] == 0 and j['slots'] == i['slots'] - n and j['slots_released'] == n, (i, j)\n"
+            "for b in blocks: b[-1:].fill_(1.0)\n"
+            "assert all(float(b[-1].item()) == 1.0 for b in blocks)\n"
+            "print('ok', i['slots'], n, i['map'])\n" % ROOT)
+    # default budget: 1.5 x (18 GiB + 64 MiB) + 6 = 34 slots (the calibration may have backed a few more before any class was known)
+    out = subprocess.run([sys.executable, "-c", code, "40"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr[-2000:]
+    # an explicit budget below the request: the class search backs nothing beyond it, the last resort still serves the request
+    out = subprocess.run([sys.executable, "-c", code, "26"], capture_output=True, text=True, timeout=300, env=dict(os.environ, STATMC_PLACEMENT_MAX_GIB="20"))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr[-2000:]
 
 
 def test_switch_off_is_plain_hipmalloc():
