@@ -118,6 +118,9 @@ def parse():
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: assemble film-f on rank 0 inside every step (default: measured after the timed region as gather_ms)")
     ap.add_argument("--no-bind", action="store_true", help="do not bind the rank to the CPUs of its GPU's NUMA node")
+    ap.add_argument("--separate-prepass", dest="fused_prepass", action="store_false",
+                    help="N = 1: run the pre-pass as a launch of its own (rounds 1 - 5; default: the accumulation's epilogue writes mean-corr and "
+                         "discriminator from the registers that hold the new moments -- statmc_stat_type::mean_corr, the same bits)")
     ap.add_argument("--no-placement", dest="placement", action="store_false",
                     help="running moments and sample arenas from torch's allocator (default: statmc_malloc_placed -- the moments in one "
                          "interference class of the card's memory, the arenas in another: include/statmc.h)")
@@ -603,8 +606,8 @@ def reference_schedule_leg(fs, samples, types, args, reps=4):
     batches = synthetic.sample_schedule(min(args.spp, S))
     wall_ms, st = _step_legs(fs, samples, types, batches, reps, reset_per_step=True)
     W, H = fs.width, fs.height
-    acc_bytes = sum(accumulate_bytes_per_px(b, types) for b in batches) * W * H
-    return {"film": "%dx%d" % (W, H), "spp": sum(batches), "iterations": len(batches), "batches": batches,
+    acc_bytes = sum(accumulate_bytes_per_px(b, types) + (24 if fs.fused_prepass else 0) for b in batches) * W * H
+    return {"film": "%dx%d" % (W, H), "spp": sum(batches), "iterations": len(batches), "batches": batches, "prepass_fused": bool(fs.fused_prepass),
             "ms_per_step": round(wall_ms, 4), "mpixels_per_s": round(W * H / wall_ms / 1e3, 2),
             "accumulate_ms": round(st["accumulate"], 4), "prepass_ms": round(st["prepass"], 4), "filter_ms": round(st["filter"], 4),
             "filter_share": round(st["filter"] / max(wall_ms, 1e-9), 4),
@@ -631,13 +634,13 @@ def config_step_leg(W, H, S, dev, types, args, name, reps, smp=None):
             for t in types:
                 smp[t][s0:s0 + part[t].shape[0]] = part[t]
             del part
-    fsx = new_film_stats(W, H, dev, types, filter_sd=args.filtersd, radius=args.radius)
+    fsx = new_film_stats(W, H, dev, types, filter_sd=args.filtersd, radius=args.radius, fused_prepass=args.fused_prepass)
     wall_ms, st = _step_legs(fsx, smp, types, [S], reps, reset_per_step=False)
-    bpp = accumulate_bytes_per_px(S, types)
+    bpp = accumulate_bytes_per_px(S, types) + (24 if args.fused_prepass else 0)
     out = {"config": name, "film": "%dx%d" % (W, H), "spp": S, "ms_per_step": round(wall_ms, 4), "mpixels_per_s": round(W * H / wall_ms / 1e3, 2),
            "accumulate_ms": round(st["accumulate"], 4), "accumulate_frac_hbm": round(bpp * W * H / (st["accumulate"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-           "prepass_ms": round(st["prepass"], 4), "filter_ms": round(st["filter"], 4), "filter_variant": api.last_filter_variant(),
-           "filter_parts": api.load().statmc_debug_last_filter_parts(), "steps": reps}
+           "prepass_ms": round(st["prepass"], 4), "prepass_fused": bool(args.fused_prepass), "filter_ms": round(st["filter"], 4),
+           "filter_variant": api.last_filter_variant(), "filter_parts": api.load().statmc_debug_last_filter_parts(), "steps": reps}
     del fsx
     if own:
         del smp
@@ -1081,10 +1084,11 @@ def main():
         _ballast = torch.empty(int(float(os.environ["STATMC_BENCH_BALLAST_GB"]) * 2 ** 28), dtype=torch.float32, device=dev)
     try:
         pipe = pipeline.BlockPipeline(layout, dev, types, filter_sd=args.filtersd, radius=r,
-                                      via_host=args.backend == "gloo", placed=PLACED["on"])
+                                      via_host=args.backend == "gloo", placed=PLACED["on"], fused_prepass=args.fused_prepass)
     except api.StatmcError as e:
         PLACED.update(on=False, error=str(e)[-300:])
-        pipe = pipeline.BlockPipeline(layout, dev, types, filter_sd=args.filtersd, radius=r, via_host=args.backend == "gloo")
+        pipe = pipeline.BlockPipeline(layout, dev, types, filter_sd=args.filtersd, radius=r, via_host=args.backend == "gloo",
+                                      fused_prepass=args.fused_prepass)
     fs = pipe.fs
     samples, pool = block_samples(args, layout, dev, types, rank, world, share=world if args.share_device else 1)
     batches = synthetic.sample_schedule(S) if args.schedule == "reference" else [S]
@@ -1130,10 +1134,12 @@ def main():
                 arena[at:at + band.numel()] = band
                 at += band.numel()
             t_keep.append(arena)
-            t_sts.append(api.make_stat_type_arena(arena, c, fs.state[t], _film.STAT_TYPES[t]["transform"], _film.STAT_TYPES[t]["max_moment"]))
+            t_sts.append(api.make_stat_type_arena(arena, c, fs.state[t], _film.STAT_TYPES[t]["transform"], _film.STAT_TYPES[t]["max_moment"],
+                                                  prepass_into=(fs.mean_corr, fs.disc) if (fs.fused_prepass and t == "radiance") else None))
 
         def accumulate_range(start, count, rows=None):      # noqa: F811
             api.accumulate_tiles(W, H, t_sts, t_bounds, t_offs, t_cnt)
+            fs._prepass_current = fs._prepass_key() if fs.fused_prepass else None
 
     # Row-strip grids: the rows a neighbour needs are accumulated, pre-passed and sent first, the rest of the block is
     # accumulated while they travel (BlockPipeline.border_rows; same bits).  On one GPU the split costs 0.04 - 0.06 ms per
@@ -1350,6 +1356,7 @@ def main():
                    batches=batches, pool=pool, n_acc_launches=n_acc_launches, ms=ms, elapsed=elapsed, variant=variant,
                    binding=binding, n_ranks_seen=n_ranks_seen, clocks=clocks, overlapped=bool(border), gather_ms=gather_ms,
                    backend=args.backend, border_rows=sum(y1 - y0 for y0, y1 in border), self_check=self_check, fed_by_tiles=fed_by_tiles,
+                   fused_prepass=bool(fs.fused_prepass),
                    parallelism="film blocks x%d, one process per GPU, halo exchange over torch.distributed (%s%s)"
                                % (world, args.backend, " = RCCL" if args.backend == "nccl" else ", halos via the host") if world > 1 else "single GPU")
         result = build_result(ctx)
@@ -1479,8 +1486,10 @@ def build_result(c):
     value = fw * fh * args.steps / c["elapsed"] / 1e6       # whole job: every block's pixels per step time
     n_flt = n_iter
     flt_gbs = FILTER_BYTES_PER_PX * px_block * n_flt / (ms["filter"] * 1e-3) / 1e9
-    acc_bytes_px = sum(accumulate_bytes_per_px(b, types) for b in batches)     # every launch re-reads and re-writes the state
-    acc_bpp = accumulate_bytes_per_px(S, types)
+    # (fused pre-pass: every launch also writes the radiance type's mean-corr and discriminator, 24 B/px)
+    fused = bool(c.get("fused_prepass"))
+    acc_bytes_px = sum(accumulate_bytes_per_px(b, types) + (24 if fused else 0) for b in batches)     # every launch re-reads and re-writes the state
+    acc_bpp = accumulate_bytes_per_px(S, types) + (24 if fused else 0)
     # the launch the roofline line describes: the whole block's accumulation, or -- in the overlapped order -- the
     # interior's (the rows that need no neighbour; the two border strips run beside its first moments)
     acc_px = W * (H - c["border_rows"]) if overlapped else px_block
@@ -1549,8 +1558,13 @@ def build_result(c):
     else:
         kernels["accumulate"] = {"ms_per_step": round(ms["accumulate"], 4), "bytes_per_px": acc_bytes_px,
                                  "achieved_GBs": round(acc_gbs, 1), "frac_hbm": round(acc_gbs / HBM_PEAK_GBS, 4)}
-        kernels["prepass"] = {"ms_per_step": round(ms["prepass"], 4), "bytes_per_px": 160 if world > 1 else PREPASS_BYTES_PER_PX,
-                              "achieved_GBs": round(pre_gbs, 1), "frac_hbm": round(pre_gbs / HBM_PEAK_GBS, 4)}
+        if fused:
+            kernels["prepass"] = {"ms_per_step": 0.0, "launches_per_step": 0, "fused_into": "accumulate_kernel's epilogue (statmc_stat_type::mean_corr / "
+                                  "discriminator: + 24 B/px written, counted in the accumulation's bytes; the same bits as statmc_prepass)",
+                                  "host_call_ms_per_step": round(ms["prepass"], 4)}
+        else:
+            kernels["prepass"] = {"ms_per_step": round(ms["prepass"], 4), "bytes_per_px": 160 if world > 1 else PREPASS_BYTES_PER_PX,
+                                  "achieved_GBs": round(pre_gbs, 1), "frac_hbm": round(pre_gbs / HBM_PEAK_GBS, 4)}
         if world > 1:
             kernels["halo_exchange"] = {"ms_per_step": round(ms["halo"], 4), "order": "after the whole block's accumulation and pre-pass"}
     result = {
@@ -1579,7 +1593,8 @@ def build_result(c):
             "gather_in_step": bool(args.gather and world > 1),
             "parallelism": c["parallelism"],
             "step_order": ("border rows first, exchange behind the interior's accumulation" if overlapped else
-                           "accumulate, pre-pass, exchange, filter" if world > 1 else "accumulate, pre-pass, filter"),
+                           "accumulate, pre-pass, exchange, filter" if world > 1 else
+                           "accumulate (+ pre-pass in its epilogue), filter" if fused else "accumulate, pre-pass, filter"),
             "rank0_binding": c["binding"],
             "feed": "16 x 16 tile blocks (statmc_accumulate_tiles)" if c.get("fed_by_tiles") else "film-major planes (statmc_accumulate)",
         },

@@ -324,6 +324,22 @@ typedef struct statmc_block {
  * out of it itself (an event recorded on each neighbour's stream after this call, awaited before the next pack:
  * statmc_amd/peer.py does). */
 int statmc_halo_exchange(const statmc_block *blocks, int gx, int gy, int block_w, int block_h, int radius);
+/* ---- ... and between PROCESSES, one per GPU, over RCCL (north_star: "RCCL halo exchange over xGMI ... via a thin C-ABI HIP shim").
+ * Every rank owns block (bx, by) = (rank % gx, rank / gx) of the gx x gy grid, packs it (statmc_prepass_pack) on block->stream and
+ * calls statmc_halo_exchange_rccl with a communicator of gx * gy ranks whose rank numbers are the block numbers: point-to-point
+ * sends and receives with the (at most four) neighbours, columns first, then rows over the widened block so that the corners ride
+ * along -- every neighbour one hop over xGMI, no ring, no collective; a row halo is one contiguous message straight out of / into the
+ * image, a column halo passes through a staging buffer.  Asynchronous on block->stream (the next statmc_window_filter on that stream
+ * sees the halo); only `packed`, `device` and `stream` of *block are used.  `nccl_comm` is an ncclComm_t: the caller's own
+ * (ncclCommInitRank of the RCCL the process links) or one made by statmc_rccl_comm_create.  RCCL is bound at run time (dlsym /
+ * dlopen of librccl.so.1); STATMC_ERR_UNSUPPORTED where it cannot be found.  Python ranks do the same exchange through
+ * torch.distributed (statmc_amd/sharding.py). */
+int statmc_halo_exchange_rccl(const statmc_block *block, int gx, int gy, int block_w, int block_h, int radius, void *nccl_comm, int rank);
+int statmc_rccl_available(void);                        /* 1: an RCCL library was found and bound */
+int statmc_rccl_unique_id(void *id128);                 /* ncclGetUniqueId: 128 bytes, made by one rank, handed to the others by the host's own means */
+int statmc_rccl_comm_create(void **nccl_comm, int n_ranks, int rank, const void *id128);   /* ncclCommInitRank on the current device (collective) */
+int statmc_rccl_comm_destroy(void *nccl_comm);
+
 /* Rectangle copy between device images of any two devices of the process (block cut / block paste of the sharded
  * path).  elem_bytes = bytes per pixel; runs on `stream`, a stream of either device (peer access is enabled in both
  * directions on first use). */
@@ -351,6 +367,12 @@ typedef struct statmc_stat_type {
     float *mean, *m2, *m3;
     float *film_mean, *film_m2; /* transform types only; non-transform types alias mean/m2
                                    (estimator.cpp:127-137) and may pass NULL here */
+    /* Optional (both or neither; max_moment 3): the accumulation's epilogue also writes the Johnson-corrected mean and the
+     * discriminator of the UPDATED moments -- exactly what statmc_prepass computes from n / mean / m2 / m3 under the current device's
+     * filter spec and significance level, the same bits, from the registers that hold the new moments -- so that a host whose
+     * statistics live on one device goes from statmc_accumulate straight to statmc_window_filter: one launch and a 40 B/px read
+     * fewer per iteration.  NULL (zero-initialised descriptors): off.  Spec or significance level changed since: call statmc_prepass. */
+    float *mean_corr, *discriminator;
 } statmc_stat_type;
 
 int statmc_accumulate(uint16_t width, uint16_t height, const statmc_stat_type *types, int n_types,

@@ -830,7 +830,21 @@ class Estimator {
         }
         pipe.downloading = true;
     }
+    // Placed memory (usePlacedMemory()): hands the GiB slots of the classes nobody asked for back to the driver
+    // (statmc_placement_trim; synchronises the device).  Denoise() calls it once, after the first iteration's images and sample
+    // arenas have been dealt; a host whose arenas keep growing (the progressive schedule doubles them) may call it again later.
+    int TrimPlacedMemory() {
+        if (!usePlacedMemory()) return 0;
+        check(statmc_set_device(device));
+        const int n = statmc_placement_trim();
+        if (n < 0) check(n);
+        placementTrimmed = true;
+        return n;
+    }
+    bool placementTrimmed = false;
+
     void Denoise() {  // estimator.cpp:427-489
+        if (usePlacedMemory() && !placementTrimmed) TrimPlacedMemory();   // (the trim synchronises the device itself)
         stat_denoiser::FilterCall calls[2];
         int nCalls = 0;
         if (floatBufferCounts[DenoiseGroup] > 0) {
@@ -1112,7 +1126,8 @@ class Estimator {
     // The CU count is the Estimator's own device's, read once in the constructor -- not the calling thread's current device
     // (a render worker that never called statmc_set_device would plan for the 256-CU default) -- and part of the key; the
     // cache is guarded: Upload / Denoise / Download may be driven from different host threads.
-    const bands::Plan &bandPlan() const {
+    // (by value: a reference to the cache would outlive the lock that guards it -- ADVICE r5; a plan is a few dozen ints)
+    bands::Plan bandPlan() const {
         std::lock_guard<std::mutex> lk(planMutex);
         const auto key = std::make_tuple(width, height, (int)filterRadius, bandsRequested, deviceCUs);
         if (planCache.height != height || planCacheKey != key) {

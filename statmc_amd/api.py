@@ -70,6 +70,7 @@ class StatType(C.Structure):
         ("n_samples", C.c_int32), ("samples", C.c_void_p), ("n", C.c_void_p),
         ("mean", C.c_void_p), ("m2", C.c_void_p), ("m3", C.c_void_p),
         ("film_mean", C.c_void_p), ("film_m2", C.c_void_p),
+        ("mean_corr", C.c_void_p), ("discriminator", C.c_void_p),
     ]
 
 
@@ -81,7 +82,7 @@ EXPORTS = [
     "statmc_stream_create", "statmc_stream_create_with_priority", "statmc_stream_destroy", "statmc_synchronize",
     "statmc_event_create", "statmc_event_destroy", "statmc_event_record", "statmc_stream_wait_event",
     "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs", "statmc_prepass_pack", "statmc_prepass_pack_rows",
-    "statmc_halo_exchange", "statmc_copy_rect", "statmc_calculate_mean_vars", "statmc_accumulate", "statmc_accumulate_rows", "statmc_accumulate_row_ranges", "statmc_accumulate_tiles", "statmc_merge_tiles", "statmc_tile_moments", "statmc_film_update",
+    "statmc_halo_exchange", "statmc_halo_exchange_rccl", "statmc_rccl_available", "statmc_rccl_unique_id", "statmc_rccl_comm_create", "statmc_rccl_comm_destroy", "statmc_copy_rect", "statmc_calculate_mean_vars", "statmc_accumulate", "statmc_accumulate_rows", "statmc_accumulate_row_ranges", "statmc_accumulate_tiles", "statmc_merge_tiles", "statmc_tile_moments", "statmc_film_update",
     "statmc_last_filter_variant", "statmc_version", "statmc_clock_probe",
 ]
 
@@ -141,6 +142,10 @@ def load():
     lib.statmc_prepass_pack.argtypes = [C.POINTER(FilterArgs), C.POINTER(Image), C.c_int, C.c_int]
     lib.statmc_prepass_pack_rows.argtypes = [C.POINTER(FilterArgs), C.POINTER(Image), C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int]
     lib.statmc_halo_exchange.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.statmc_halo_exchange_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    lib.statmc_rccl_unique_id.argtypes = [C.c_void_p]
+    lib.statmc_rccl_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]
+    lib.statmc_rccl_comm_destroy.argtypes = [C.c_void_p]
     lib.statmc_copy_rect.argtypes = [C.POINTER(Image), C.c_int, C.c_int, C.c_int, C.POINTER(Image), C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.statmc_set_device.argtypes = [C.c_int]
@@ -194,6 +199,11 @@ def set_filter_spec(spec=None, **fields):
         return
     spec = spec if spec is not None else FilterSpec(**fields)
     check(load().statmc_set_filter_spec(C.byref(spec)))
+
+
+def get_significance():
+    """The current device's significance-level index (statmc_get_significance: 0 = 0.005, 1 = 0.002, 2 = 0.05)."""
+    return int(load().statmc_get_significance())
 
 
 def get_filter_spec():
@@ -416,6 +426,39 @@ def placement_info():
     return out
 
 
+class RcclComm:
+    """An RCCL communicator made through the C ABI (statmc_rccl_unique_id / statmc_rccl_comm_create): what a multi-process C++
+    host uses for statmc_halo_exchange_rccl.  rank 0 makes the id (RcclComm.unique_id()), the host hands its 128 bytes to the
+    other ranks by its own means, every rank constructs RcclComm(n_ranks, rank, id) on its device (collective)."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(load().statmc_rccl_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, n_ranks, rank, id128):
+        assert len(id128) == 128
+        self.n_ranks, self.rank = n_ranks, rank
+        self.handle = C.c_void_p()
+        check(load().statmc_rccl_comm_create(C.byref(self.handle), n_ranks, rank, C.c_char_p(id128)))
+
+    def destroy(self):
+        if self.handle:
+            check(load().statmc_rccl_comm_destroy(self.handle))
+            self.handle = C.c_void_p()
+
+
+def halo_exchange_rccl(packed, device_index, gx, gy, block_w, block_h, radius, comm, stream=None):
+    """statmc_halo_exchange_rccl on this rank's block + halo image `packed` ([rows, cols, channels] device tensor)."""
+    from .peer import Block
+    blk = Block()
+    blk.device = device_index
+    blk.packed = image_of(packed)
+    blk.stream = stream if stream is not None else current_stream_handle()
+    check(load().statmc_halo_exchange_rccl(C.byref(blk), gx, gy, block_w, block_h, radius, comm.handle, comm.rank))
+
+
 def placement_trim():
     """Releases the idle slots of the current device's placed allocator (statmc_placement_trim); returns how many."""
     n = load().statmc_placement_trim()
@@ -424,8 +467,10 @@ def placement_trim():
     return n
 
 
-def make_stat_type(samples, state, transform, max_moment):
-    """samples: [S, H, W, C] device tensor; state: dict of device tensors n/mean/m2/m3/film_mean/film_m2."""
+def make_stat_type(samples, state, transform, max_moment, prepass_into=None):
+    """samples: [S, H, W, C] device tensor; state: dict of device tensors n/mean/m2/m3/film_mean/film_m2.
+    prepass_into = (mean_corr, discriminator): the accumulation's epilogue also writes the pre-pass of the updated moments there
+    (statmc_stat_type::mean_corr / discriminator; max_moment 3)."""
     t = StatType()
     c = samples.shape[3] if samples.dim() == 4 else 1
     t.channels, t.transform, t.max_moment = c, int(bool(transform)), int(max_moment)
@@ -437,12 +482,14 @@ def make_stat_type(samples, state, transform, max_moment):
     t.m3 = state["m3"].data_ptr() if state.get("m3") is not None else None
     t.film_mean = state["film_mean"].data_ptr() if state.get("film_mean") is not None else None
     t.film_m2 = state["film_m2"].data_ptr() if state.get("film_m2") is not None else None
+    if prepass_into is not None:
+        t.mean_corr, t.discriminator = prepass_into[0].data_ptr(), prepass_into[1].data_ptr()
     return t
 
 
-def make_stat_type_arena(arena, channels, state, transform, max_moment):
+def make_stat_type_arena(arena, channels, state, transform, max_moment, prepass_into=None):
     """Stat type whose samples arrive tile by tile (accumulate_tiles): `arena` is a flat fp32 device tensor."""
-    t = make_stat_type(arena.view(1, 1, -1, 1), state, transform, max_moment)
+    t = make_stat_type(arena.view(1, 1, -1, 1), state, transform, max_moment, prepass_into=prepass_into)
     t.channels, t.n_samples = int(channels), 0
     return t
 

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libstatmc_hip.so")
 DEFAULT_SO = SO
-SOURCES = ["statmc_pointwise.hip", "statmc_filter.hip", "statmc_filter_sym.hip", "statmc_placement.hip", "statmc_abi.hip"]
+SOURCES = ["statmc_pointwise.hip", "statmc_filter.hip", "statmc_filter_sym.hip", "statmc_placement.hip", "statmc_abi.hip", "statmc_rccl.hip"]
 HEADERS = ["statmc_device.h", "statmc_filter_common.h", "statmc_sym_experiments.h", "t_quantiles.h", os.path.join("..", "..", "include", "statmc.h"),
            os.path.join("..", "..", "include", "statmc_pinned_spec.h")]
 # -ffp-contract=off: every fp32 op rounds once, in source order, like the CPU oracle build.
@@ -67,7 +67,7 @@ def build(force=False, verbose=False):
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
-        extra = KERNEL_FLAGS if src not in ("statmc_abi.hip", "statmc_placement.hip") else []
+        extra = KERNEL_FLAGS if src not in ("statmc_abi.hip", "statmc_placement.hip", "statmc_rccl.hip") else []
         cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -1220,7 +1220,7 @@ int statmc_calculate_mean_vars(uint8_t n_buffers, uint16_t width, uint16_t heigh
 }
 
 // validates one statmc_stat_type and translates it for the kernels (shared by both accumulate entries)
-static int fill_stat_type(const statmc_stat_type &t, int i, uint16_t width, uint16_t height, bool batch,
+static int fill_stat_type(const DeviceState &ds, const statmc_stat_type &t, int i, uint16_t width, uint16_t height, bool batch,
                           statmc::AccumulateType &d) {
     if (t.channels != 1 && t.channels != 3) return fail(STATMC_ERR_INVALID, "types[%d]: channels must be 1 or 3", i);
     if (t.max_moment < 1 || t.max_moment > 3) return fail(STATMC_ERR_INVALID, "types[%d]: max_moment must be 1..3", i);
@@ -1243,6 +1243,20 @@ static int fill_stat_type(const statmc_stat_type &t, int i, uint16_t width, uint
     d.n_samples = t.n_samples;
     d.transform = t.transform ? 1 : 0;
     d.max_moment = t.max_moment;
+    // optional epilogue: the pre-pass of the updated moments under the device's current spec and significance level
+    // (statmc_prepass's own PrepassArgs, prepass_impl above)
+    d.mean_corr = nullptr;
+    d.disc = nullptr;
+    d.pre_table = 0;
+    d.pre_flags = 0;
+    if (t.mean_corr || t.discriminator) {
+        if (!t.mean_corr || !t.discriminator) return fail(STATMC_ERR_INVALID, "types[%d]: mean_corr and discriminator come together", i);
+        if (t.max_moment < 3) return fail(STATMC_ERR_INVALID, "types[%d]: the pre-pass epilogue needs max_moment 3 (it reads m2 and m3)", i);
+        d.mean_corr = t.mean_corr;
+        d.disc = t.discriminator;
+        d.pre_table = prepass_table(ds);
+        d.pre_flags = (ds.spec.dof == STATMC_DOF_WELCH ? 1 : 0) | (ds.spec.small_n == STATMC_SMALL_N_EXCLUDE ? 2 : 0);
+    }
     return STATMC_OK;
 }
 
@@ -1277,7 +1291,7 @@ int statmc_accumulate_row_ranges(uint16_t width, uint16_t height, const statmc_s
         if (y0 == y1) continue;
         for (int i = 0; i < n_types; i++) {
             statmc::AccumulateType &d = k.t[k.n_types];
-            if (int rc = fill_stat_type(types[i], i, width, height, true, d)) return rc;
+            if (int rc = fill_stat_type(dstate, types[i], i, width, height, true, d)) return rc;
             const long long px0 = (long long)y0 * width, e0 = px0 * d.channels;
             if (d.samples) d.samples += e0;
             d.n += px0;
@@ -1286,6 +1300,7 @@ int statmc_accumulate_row_ranges(uint16_t width, uint16_t height, const statmc_s
             if (d.m3) d.m3 += e0;
             if (d.film_mean) d.film_mean += e0;
             if (d.film_m2) d.film_m2 += e0;
+            if (d.mean_corr) { d.mean_corr += e0; d.disc += e0; }
             d.n_elems = (long long)(y1 - y0) * width * d.channels;   // d.stride stays the whole film's plane
             k.n_types++;
         }
@@ -1319,7 +1334,7 @@ int statmc_accumulate_tiles(uint16_t width, uint16_t height, const statmc_stat_t
     memset(&k, 0, sizeof(k));
     k.n_types = n_types;
     for (int i = 0; i < n_types; i++)
-        if (int rc = fill_stat_type(types[i], i, width, height, false, k.t[i])) return rc;
+        if (int rc = fill_stat_type(dstate, types[i], i, width, height, false, k.t[i])) return rc;
     k.tile_bounds = tile_bounds;
     k.tile_offsets = reinterpret_cast<const long long *>(tile_offsets);
     k.tile_samples = tile_samples;

@@ -36,6 +36,11 @@ struct AccumulateType {
     long long n_elems;  // elements this launch updates: width * rows * channels
     long long stride;   // floats between consecutive samples of an element: width * height * channels (> n_elems when the launch covers a range of rows)
     int channels, n_samples, transform, max_moment;
+    // optional epilogue (max_moment 3): the pre-pass of the updated moments -- Johnson-corrected mean and discriminator, what
+    // prepass_kernel computes from n / mean / m2 / m3 -- written while the state is still in registers (NULL: off)
+    float *mean_corr, *disc;
+    int pre_table;      // Student-t table of the device's significance level and sides (t_quantile)
+    int pre_flags;      // 1: Welch degrees of freedom (t = 1: the pair looks its quantile up), 2: n < 2 excludes the pixel
 };
 constexpr int kMaxSlots = 64;
 struct AccumulateArgs {

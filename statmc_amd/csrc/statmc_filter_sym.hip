@@ -19,16 +19,18 @@
 //   * Tile = 128 x 8 pixels on a grid fixed in FILM coordinates (so that block-decomposed multi-GPU runs
 //     form every sum in the same order as a whole-film run: bit-identical results).  A 512-thread workgroup
 //     = 8 waves; wave (t, h), t = 0..3, h = 0..1, owns tile rows t (lanes 0-31) and t + 4 (lanes 32-63) and
-//     half h of the window columns (h = 0: dx in [-20, 0], h = 1: dx in [1, 20]); a lane owns 4 adjacent
-//     pixels.  Both halves of a row keep the pixels' own data in registers; their partial sums meet in the
-//     epilogue.
+//     share h of the window columns; a lane owns 4 adjacent pixels.  Both waves of a row keep the pixels' own
+//     data in registers; their partial sums meet in the epilogue.  The shares (round 6): whole READ GROUPS --
+//     half 0 the groups [0, G), half 1 the rest, G = 7 or 6 of the 11 by build (gsplit_of) -- so that no group's
+//     operands are read by both waves and the older wave of every SIMD pair, which the issue arbitration
+//     prefers, has the larger share (rounds 2 - 5: h = 0 dx in [-20, 0], h = 1 dx in [1, 20]).
 //   * Step s = window row dy = s, s = 0..20.  At step s tile row t sweeps image row y0 + t + s: 8 live rows
 //     + 1 being staged = a ring of 9 LDS slots.  A slot holds the 15 input planes of a row (168 columns =
 //     tile + 2 x 20 halo) AND its 2 x 4 accumulator planes (Sigma w*colour, Sigma w; one copy per window
 //     half, because the two waves of a row hit the same columns at the same time).  Everything a row needs
 //     lives exactly as long as the row: 9 x 168 x 23 floats = 139 KB, + the spatial table and the LDS-DMA
 //     landing area = 151 KB of the CU's 160 KB.
-//   * dy = 0: the pairs inside a row are the taps dx in [1, 20] of half 1 (the accumulator row is the wave's own
+//   * dy = 0: the pairs inside a row are the taps dx in [1, 20], all with half 1 (the accumulator row is the wave's own
 //     row); half 0 only adds the pixel's own tap.
 //   * q-side scatter: per read group a lane reads the 4 x 2 accumulator values of its two taps, adds its four
 //     pixels' w * colour_p with the same packed FMAs that serve the p side, and writes them back.  Plain
@@ -67,12 +69,14 @@
 namespace statmc {
 namespace sym {
 
-constexpr bool kHkAtEnd = STATMC_SYM_HK_END;   // experiment: per-step housekeeping after the sweep instead of before
+constexpr int kHkAtEndForced = STATMC_SYM_HK_END;   // -1: per build (hk_at_end below); 0 / 1: every build (A/B)
 constexpr bool kStamps = STATMC_SYM_STAMPS;    // diagnostic: per-wave clock sums per step (tools/experiments/stamps_sym.py)
 constexpr bool kPipe = STATMC_SYM_PIPE;        // experiment: hand-placed LDS reads one phase ahead of the arithmetic
 constexpr int kPrio = STATMC_SYM_PRIO;         // experiment (s_setprio)
 constexpr int kSplit = STATMC_SYM_SPLIT;       // window half 0 sweeps dx <= kSplit, half 1 the rest
-constexpr int kGSplit = STATMC_SYM_GSPLIT;     // experiment: the two waves of a row split the window at read group kGSplit (0: at dx = kSplit)
+constexpr int kGSplitForced = STATMC_SYM_GSPLIT;    // -1: per build (gsplit_of below); 0: the window split at dx = kSplit (rounds 2 - 5); G > 0: every build
+constexpr bool kGroupSplitRT = STATMC_SYM_GSPLIT_RT != 0;   // the runtime-radius builds: split at a read-group boundary too
+constexpr unsigned kGMask = STATMC_SYM_GSPLIT_MASK;   // ... and the (tap pair, pixel) units of group kGSplit itself that half 0 takes (bit i * 4 + k: tap i, pixel k)
 constexpr int kHkHalf = STATMC_SYM_HK_HALF;    // experiment: the wave of a SIMD pair that does the housekeeping: 0 half 0, 1 half 1, 2 alternating
 constexpr bool kFlags = STATMC_SYM_FLAGS;      // experiment: per-wave progress words in LDS instead of the per-step barrier
 constexpr int kAblate = STATMC_SYM_ABLATE;     // timing only: 1 no q side, 2 no row staging, 4 no flush, 8 no sweep arithmetic, 16 no barrier
@@ -104,6 +108,25 @@ constexpr bool mode_welch(int m) { return m >= kModeWelch && m <= kModeWelchPair
 constexpr bool mode_welch_joint(int m) { return m == kModeWelchJoint || m == kModeWelchJointFar; }
 constexpr bool mode_welch_far(int m) { return m == kModeWelchFar || m == kModeWelchJointFar || m == kModeWelchPairFar; }
 constexpr bool mode_pair(int m) { return m == 1 /* kModePair */ || m == kModeWelchPair || m == kModeWelchPairFar; }
+// How the two waves of a row share the window, and when the staging waves keep house -- per build, measured (round 6; 1080p, r = 20,
+// back to back, one box, ms: profiles/r06_modes.log; HISTORY.md 4.3d):
+//                     RGB     pooled   one-sided  Moon    8 planes  2 float buffers
+//   dx = 0, hk first  1.446   1.452    1.863      1.812   1.602     1.430      (rounds 2 - 5)
+//   G = 6,  hk first  1.388   1.383    1.783      1.732   1.592     1.394
+//   G = 6,  hk last   1.344   1.342    1.749      1.715   1.631     1.455
+//   G = 7,  hk first  1.339   1.352    1.833      1.871   1.670     1.470
+//   G = 7,  hk last   1.331   1.319    1.859      1.867   1.727     1.534
+// G: half 0 sweeps read groups [0, G), half 1 the rest -- no group is evaluated by both waves, and the OLDER wave of a SIMD pair
+// (half 0: it wins the issue arbitration and would otherwise wait at the barrier) takes the larger share.  hk last: flush, staging
+// and LDS-DMA after the wave's sweep instead of before it.
+constexpr int gsplit_of(int mode, int ng) {
+    if (kGSplitForced >= 0) return kGSplitForced;
+    return (ng == 8 || mode_pair(mode) || mode_asym(mode)) ? 6 : 7;
+}
+constexpr bool hk_at_end(int mode, int ng) {
+    if (kHkAtEndForced >= 0) return kHkAtEndForced != 0;
+    return ng == 6 && !mode_pair(mode);
+}
 constexpr int kR = 20;
 constexpr int kPx = 4;                    // pixels per lane
 constexpr int kW = 32 * kPx;              // 128 tile columns: half a wave per row
@@ -756,6 +779,30 @@ __device__ __forceinline__ void eval_half_row(LaneT &st, const float *row, const
     constexpr bool kPipe = sym::kPipe && !mode_welch(MODE);
     if constexpr (RT) {
         static_assert(kSplit == 0, "the runtime-radius build splits the window in the middle");
+        // From nine read groups up (r >= 16) and in the builds whose r = 20 relatives gain from it (six feature planes, one
+        // buffer): whole read groups [j_lo, g) to half 0, [g, j_hi] to half 1, g = j_lo + 9/14 of the groups -- the share the
+        // r = 20 build measured best (gsplit_of); taps beyond the radius carry -inf in the table, so no group needs a mask.
+        // 1080p: r = 19 1.380 -> 1.340 ms, Welch r = 20 3.48 -> 3.39 (pooled 3.47 -> 3.34); below nine groups the middle split
+        // is as good or better (r = 10 0.58 | 0.60, Welch r = 6 0.70 | 0.72; profiles/r06_rt.log).
+        if (kGroupSplitRT && NG == 6 && !mode_pair(MODE) && j_hi - j_lo + 1 >= 9) {
+            const int g = j_lo + ((j_hi - j_lo + 1) * 9 + 7) / 14;
+            if (dy0) {
+                if constexpr (HF == 0) {
+                    sweep_range<0, 0, false, MODE, NG>(st, row, tab, qrow, tq2);
+                } else {
+                    chunk<Range<1, kR>::m(kMid), true, kPipe, MODE, NG>(st, row, tab, qrow, kMid, tq2);
+#pragma unroll 1
+                    for (int j = kMid + 1; j <= j_hi; j++) chunk<0xFFFFu, true, kPipe, MODE, NG>(st, row, tab, qrow, j, tq2);
+                }
+            } else if constexpr (HF == 0) {
+#pragma unroll 1
+                for (int j = j_lo; j < g; j++) chunk<0xFFFFu, true, kPipe, MODE, NG>(st, row, tab, qrow, j, tq2);
+            } else {
+#pragma unroll 1
+                for (int j = g; j <= j_hi; j++) chunk<0xFFFFu, true, kPipe, MODE, NG>(st, row, tab, qrow, j, tq2);
+            }
+            return;
+        }
         if constexpr (HF == 0) {
             if (dy0) {
                 sweep_range<0, 0, false, MODE, NG>(st, row, tab, qrow, tq2);
@@ -771,14 +818,21 @@ __device__ __forceinline__ void eval_half_row(LaneT &st, const float *row, const
         }
         return;
     }
-    if constexpr (kGSplit > 0) {   // experiment: split at a read-group boundary (dy = 0 as in the product)
-        static_assert(kSplit == 0 && kGSplit < kChunks, "one split experiment at a time");
+    constexpr int kGSplit = gsplit_of(MODE, NG);
+    if constexpr (kGSplit > 0) {   // the split at a read-group boundary (dy = 0: the pairs inside the row stay with half 1)
+        static_assert(kSplit == 0 && kGSplit < kChunks - 1 && (kGMask == 0 || (kGSplit >= 1 && kGMask < 0xFFFFu)), "one split experiment at a time; a shared group is a whole one");
         if (dy0) {
             if constexpr (HF == 0) sweep_range<0, 0, false, MODE, NG>(st, row, tab, qrow, tq2);
             else sweep_range<1, kR, true, MODE, NG>(st, row, tab, qrow, tq2);
         } else {
-            if constexpr (HF == 0) sweep_groups<0, kGSplit - 1, true, MODE, NG>(st, row, tab, qrow, tq2);
-            else sweep_groups<kGSplit, kChunks - 1, true, MODE, NG>(st, row, tab, qrow, tq2);
+            constexpr bool pipe = sym::kPipe && !mode_welch(MODE);
+            if constexpr (HF == 0) {
+                sweep_groups<0, kGSplit - 1, true, MODE, NG>(st, row, tab, qrow, tq2);
+                if constexpr (kGMask != 0) chunk<kGMask & 0xFFFFu, true, pipe, MODE, NG>(st, row, tab, qrow, kGSplit, tq2);
+            } else {
+                if constexpr (kGMask != 0) chunk<0xFFFFu & ~kGMask, true, pipe, MODE, NG>(st, row, tab, qrow, kGSplit, tq2);
+                sweep_groups<kGSplit + (kGMask != 0 ? 1 : 0), kChunks - 1, true, MODE, NG>(st, row, tab, qrow, tq2);
+            }
         }
         return;
     }
@@ -1113,7 +1167,8 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     // wave-local staging geometry (DMA): this wave's columns of every staged row
     // (experiments: FL = progress words instead of the barrier; kHkHalf: which wave of a SIMD pair keeps house)
     constexpr bool FL = Planes<NG, W>::kFl && DMA && !RT;
-    static_assert(!(FL && (kHkHalf != 0 || kHkAtEnd)), "the progress-word build keeps house on the half-0 waves, after the sweep");
+    constexpr bool kHkAtEnd = hk_at_end(MODE, NG) && !FL;   // (the progress-word experiment places its housekeeping itself)
+    static_assert(!(FL && kHkHalf != 0), "the progress-word build keeps house on the half-0 waves, after the sweep");
     float *raw_w = tab_lds + Planes<NG, W>::kTabFloats + Planes<NG, W>::raw_off(wave);
     const int wcol0 = wave_col0(kHkHalf ? (wave & 3) : wave);          // first staged column (0..167) of the wave
     const int ncols = wave_cols(kHkHalf ? (wave & 3) : wave);          // 44, 44, 40, 40, then none

@@ -593,6 +593,29 @@ __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long lo
     const vint4 n_out = {n0[0] + S, n0[1] + S, n0[2] + S, n0[3] + S};
     if (STATMC_ACC_NT_STORES) __builtin_nontemporal_store(n_out, reinterpret_cast<vint4 *>(t.n + p0));
     else *reinterpret_cast<vint4 *>(t.n + p0) = n_out;
+    // Optional epilogue (round 6): the pre-pass of the moments just written, from the registers that hold them -- the same
+    // prepass_elem as prepass_kernel, hence the same bits -- instead of a launch that reads 40 B per pixel back.
+    if constexpr (MAXM >= 3) {
+        if (t.mean_corr != nullptr) {
+            float tq[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) tq[p] = (t.pre_flags & 1) ? 1.f : t_quantile(t.pre_table, n_out[p] - 1);
+#pragma unroll
+            for (int k = 0; k < C; k++) {
+                vfloat4 mc, dc;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int e = 4 * k + j, px = e / C;
+                    float m, d;
+                    prepass_elem(n_out[px], tq[px], st[e >> 1].mean[e & 1], st[e >> 1].m2[e & 1], st[e >> 1].m3[e & 1], m, d, (t.pre_flags & 2) != 0);
+                    mc[j] = m;
+                    dc[j] = d;
+                }
+                *reinterpret_cast<vfloat4 *>(t.mean_corr + e0 + 4 * k) = mc;
+                *reinterpret_cast<vfloat4 *>(t.disc + e0 + 4 * k) = dc;
+            }
+        }
+    }
 }
 
 // One pixel, scalar accesses: unaligned images, ragged ends, tiles whose rows do not split into
@@ -615,6 +638,13 @@ __device__ __forceinline__ void accumulate_pixel(const AccumulateType &t, long l
         if (TRANSFORM) {
             t.film_mean[e] = st.fmean;
             t.film_m2[e] = st.fm2;
+        }
+        if (MAXM >= 3 && t.mean_corr != nullptr) {   // (the optional pre-pass epilogue, as in accumulate_lane)
+            const int ni = n0 + S;
+            float m, d;
+            prepass_elem(ni, (t.pre_flags & 1) ? 1.f : t_quantile(t.pre_table, ni - 1), st.mean, st.m2, st.m3, m, d, (t.pre_flags & 2) != 0);
+            t.mean_corr[e] = m;
+            t.disc[e] = d;
         }
     }
     t.n[p] = n0 + S;

@@ -11,9 +11,11 @@
 #ifndef STATMC_SYM_ABLATE
 #define STATMC_SYM_ABLATE 0
 #endif
-// per-step housekeeping after the sweep instead of before (measured slower)
+// per-step housekeeping after the sweep (1) or before it (0) in EVERY build; -1 (the product): per build, as measured --
+// hk_at_end() in statmc_filter_sym.hip (after the sweep in the one-buffer six-plane builds, before it with eight planes / two float buffers)
+#define STATMC_SYM_HK_END_DEFAULT (-1)
 #ifndef STATMC_SYM_HK_END
-#define STATMC_SYM_HK_END 0
+#define STATMC_SYM_HK_END STATMC_SYM_HK_END_DEFAULT
 #endif
 // hand-placed ds_read_b128 one phase ahead of the arithmetic (1.57 ms against 1.43)
 #ifndef STATMC_SYM_PIPE
@@ -40,8 +42,24 @@
 // round 6 (get the sweep off the per-step barrier), each measured and written up in HISTORY.md 4.3d:
 // GSPLIT = G > 0: the two waves of a row split the window at a read-group boundary instead of at dx = 0 -- half 0 sweeps
 // groups [0, G), half 1 groups [G, 11): no group is evaluated twice (84 instead of 86 (tap pair, pixel) units per lane and row)
+// -1 (the product since round 6): per build, gsplit_of() in statmc_filter_sym.hip -- G = 7 for one RGB buffer under the symmetric
+// gates (half 0, the older wave of its SIMD pair, which also keeps house, takes 54 of the 84 units, half 1 30), 6 for the one-sided /
+// Moon gates, eight feature planes and two float buffers.  1080p RGB, back to back, one box: dx = 0 split 1.440 ms | G = 5 1.42 |
+// 6 1.383 | 7 1.340 | 8 1.442 (profiles/r06_ab*.log); per build: profiles/r06_modes.log.
+// 0 = the window split at dx = STATMC_SYM_SPLIT (rounds 2 - 5); G > 0 = that G in every build.
+#define STATMC_SYM_GSPLIT_DEFAULT (-1)
 #ifndef STATMC_SYM_GSPLIT
-#define STATMC_SYM_GSPLIT 0
+#define STATMC_SYM_GSPLIT STATMC_SYM_GSPLIT_DEFAULT
+#endif
+// ... and the units of group G itself that half 0 takes besides (bit i * 4 + k = tap i against pixel k; a unit = a tap PAIR against
+// a pixel: 0x0033 two units, 0x00FF four, 0x33FF six): the split to a quarter of a group
+#ifndef STATMC_SYM_GSPLIT_MASK
+#define STATMC_SYM_GSPLIT_MASK 0
+#endif
+// the same group-aligned split in the runtime-radius builds (r < 20, Welch)
+#define STATMC_SYM_GSPLIT_RT_DEFAULT 1
+#ifndef STATMC_SYM_GSPLIT_RT
+#define STATMC_SYM_GSPLIT_RT STATMC_SYM_GSPLIT_RT_DEFAULT
 #endif
 // which wave of a SIMD pair does the per-step housekeeping (flush, staging, LDS-DMA): 0 = the half-0 wave (the older one; the
 // product), 1 = the half-1 wave, 2 = alternating by step
@@ -61,10 +79,11 @@
 #endif
 
 #define STATMC_SYM_DIAGNOSTIC_BITS                                                                                        \
-    ((STATMC_SYM_ABLATE ? 1 : 0) | (STATMC_SYM_HK_END ? 2 : 0) | (STATMC_SYM_PIPE ? 4 : 0) | (STATMC_SYM_STAMPS ? 8 : 0) | \
+    ((STATMC_SYM_ABLATE ? 1 : 0) | (STATMC_SYM_HK_END != STATMC_SYM_HK_END_DEFAULT ? 2 : 0) | (STATMC_SYM_PIPE ? 4 : 0) | (STATMC_SYM_STAMPS ? 8 : 0) | \
      (STATMC_SYM_SPLIT ? 16 : 0) | (STATMC_SYM_COUNT ? 32 : 0) | (STATMC_SYM_PRIO ? 64 : 0) | (STATMC_SYM_WELCH_ABLATE ? 256 : 0) | \
-     (STATMC_SYM_GSPLIT ? 512 : 0) | (STATMC_SYM_HK_HALF ? 1024 : 0) | (STATMC_SYM_FLAGS ? 2048 : 0))
+     (STATMC_SYM_GSPLIT != STATMC_SYM_GSPLIT_DEFAULT ? 512 : 0) | (STATMC_SYM_HK_HALF ? 1024 : 0) | (STATMC_SYM_FLAGS ? 2048 : 0) | \
+     (STATMC_SYM_GSPLIT_MASK ? 4096 : 0) | (STATMC_SYM_GSPLIT_RT != STATMC_SYM_GSPLIT_RT_DEFAULT ? 8192 : 0))
 
-#if defined(STATMC_PRODUCT_BUILD) && STATMC_SYM_ABLATE + STATMC_SYM_HK_END + STATMC_SYM_PIPE + STATMC_SYM_STAMPS + STATMC_SYM_SPLIT * STATMC_SYM_SPLIT + STATMC_SYM_COUNT + STATMC_SYM_PRIO + STATMC_SYM_WELCH_ABLATE + STATMC_SYM_GSPLIT + STATMC_SYM_HK_HALF + STATMC_SYM_FLAGS != 0
+#if defined(STATMC_PRODUCT_BUILD) && STATMC_SYM_DIAGNOSTIC_BITS != 0
 #error "a STATMC_SYM_* diagnostic switch is set in the product build (statmc_amd/build.py): it would ship a wrong or slower filter"
 #endif

@@ -40,7 +40,10 @@ class FilmStats:
     """One GPU's block of the film: per-type running moments and the filter's work images."""
 
     def __init__(self, width, height, device, types=("radiance", "normal", "albedo"),
-                 filter_sd=10.0, radius=20, g_buffers=("normal", "albedo"), g_sds=None, placed=False):
+                 filter_sd=10.0, radius=20, g_buffers=("normal", "albedo"), g_sds=None, placed=False, fused_prepass=False):
+        """fused_prepass: whole-film accumulations also write the radiance type's mean-corr / discriminator in their epilogue
+        (statmc_stat_type::mean_corr / discriminator: the bits of statmc_prepass), and prepass() has nothing left to do while
+        that result is current -- same filter spec and significance level, no row-range accumulation, no reset since."""
         api.setup(device.index if device.index is not None else 0)
         self.width, self.height, self.device = width, height, device
         self.types = list(types)
@@ -54,8 +57,11 @@ class FilmStats:
         z3 = (lambda: api.zeros_placed((height, width, 3), torch.float32, device, api.MEM_STATE)) if placed else \
              (lambda: torch.zeros(height, width, 3, dtype=torch.float32, device=device))
         self.mean_corr, self.disc, self.film, self.film_f = z3(), z3(), z3(), z3()
+        self.fused_prepass = bool(fused_prepass)
+        self._prepass_current = None      # (filter spec, significance) under which the epilogue's result was written
 
     def reset(self):
+        self._prepass_current = None
         for st in self.state.values():
             for v in st.values():
                 if v is not None:
@@ -63,9 +69,15 @@ class FilmStats:
 
     def accumulate(self, samples, rows=None):
         """samples: {type: [S, H, W, C]}; one kernel launch covers every stat type.  rows = (y0, y1): only those rows."""
-        sts = [api.make_stat_type(samples[t], self.state[t], STAT_TYPES[t]["transform"],
-                                  STAT_TYPES[t]["max_moment"]) for t in self.types if t in samples]
+        fuse = self.fused_prepass and rows is None and "radiance" in samples
+        sts = [api.make_stat_type(samples[t], self.state[t], STAT_TYPES[t]["transform"], STAT_TYPES[t]["max_moment"],
+                                  prepass_into=(self.mean_corr, self.disc) if (fuse and t == "radiance") else None)
+               for t in self.types if t in samples]
         api.accumulate(self.width, self.height, sts, rows=rows)
+        self._prepass_current = self._prepass_key() if fuse else None
+
+    def _prepass_key(self):
+        return (api.get_filter_spec().as_tuple(), api.get_significance())
 
     def g_buffer(self, name):
         return self.state[name]["mean"]  # film-mean == mean for non-transform types
@@ -84,6 +96,9 @@ class FilmStats:
         return args, keep
 
     def prepass(self):
+        if self._prepass_current is not None and self._prepass_current == self._prepass_key():
+            return          # the last accumulation's epilogue wrote mean-corr / discriminator already (same bits)
+        self._prepass_current = None
         args, keep = self.filter_args()
         api.prepass(args, 3)
 

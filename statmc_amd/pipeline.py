@@ -10,7 +10,7 @@ from . import api, film, sharding
 
 class BlockPipeline:
     def __init__(self, layout, device, types, filter_sd=10.0, radius=20, via_host=False, reproducible=False,
-                 g_buffers=("normal", "albedo"), g_sds=None, placed=False):
+                 g_buffers=("normal", "albedo"), g_sds=None, placed=False, fused_prepass=False):
         """placed: the running moments come from statmc_malloc_placed(STATMC_MEM_STATE) (include/statmc.h; the caller
         allocates its sample arenas with api.empty_placed(..., api.MEM_STREAM)).
         reproducible: pin the window-sweep split of this device to the uniform split a single device would choose for the
@@ -20,8 +20,10 @@ class BlockPipeline:
         statmc_filter_split_auto does not report (include/statmc.h, "window-sweep split").  Default: the split fitted to the
         block (faster on strips, <= 1e-6 from the one-device result)."""
         self.layout, self.device, self.via_host = layout, device, via_host
+        # fused_prepass (one block = the whole film only): the accumulation's epilogue writes mean-corr / discriminator, prepass()
+        # has nothing left to launch (film.FilmStats); blocks of a sharded film pre-pass and pack in one pass of their own
         self.fs = film.FilmStats(layout.bw, layout.bh, device, types=types, filter_sd=filter_sd, radius=radius,
-                                 g_buffers=g_buffers, g_sds=g_sds, placed=placed)
+                                 g_buffers=g_buffers, g_sds=g_sds, placed=placed, fused_prepass=fused_prepass and layout.world == 1)
         self.g_channels = [film.STAT_TYPES[g]["channels"] for g in self.fs.g_names]
         if reproducible:
             fw, fh = layout.film_size
@@ -57,6 +59,13 @@ class BlockPipeline:
     def exchange(self):
         """Fetch the r-pixel border of the block + halo image from the neighbours (RCCL send/recv)."""
         sharding.exchange_halo(self.layout, self.packed, via_host=self.via_host)
+
+    def exchange_rccl(self, comm):
+        """The same exchange through the C ABI's RCCL entry point (statmc_halo_exchange_rccl; comm: api.RcclComm): what a
+        multi-process C++ host calls.  Asynchronous on the current stream."""
+        L = self.layout
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        api.halo_exchange_rccl(self.packed, idx, L.gx, L.gy, L.bw, L.bh, self.radius, comm)
 
     # ---- the halo exchange behind the accumulation (row-strip grids): the rows a neighbour needs are accumulated,
     # pre-passed and sent first; the rest of the block is accumulated while they travel.  Per-pixel stages, so the bits are

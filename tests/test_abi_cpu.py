@@ -79,6 +79,25 @@ def test_no_device_means_error_not_fallback(lib):
         api.setup(0)
 
 
+def test_rccl_entry_points_check_their_arguments_without_a_device(lib):
+    """statmc_halo_exchange_rccl and the communicator helpers (include/statmc.h): exported, RCCL bound at run time (no link-time
+    dependency), argument errors reported before anything touches a device."""
+    import subprocess
+    from statmc_amd import api, build
+    needed = subprocess.check_output(["readelf", "-d", build.SO], text=True)
+    assert "rccl" not in needed.lower(), "libstatmc_hip.so must not link RCCL: it is bound by dlsym / dlopen on first use"
+    assert lib.statmc_rccl_available() in (0, 1)
+    assert lib.statmc_halo_exchange_rccl(None, 1, 2, 64, 64, 20, None, 0) == api.ERR_INVALID
+    from statmc_amd.peer import Block
+    blk = Block()
+    assert lib.statmc_halo_exchange_rccl(C.byref(blk), 1, 2, 64, 8, 20, None, 0) == api.ERR_INVALID      # block smaller than the radius
+    assert lib.statmc_halo_exchange_rccl(C.byref(blk), 1, 2, 64, 64, 20, None, 5) == api.ERR_INVALID     # rank outside the grid
+    assert lib.statmc_halo_exchange_rccl(C.byref(blk), 1, 1, 64, 64, 20, None, 0) == 0                   # one block: nothing to exchange
+    assert lib.statmc_halo_exchange_rccl(C.byref(blk), 1, 2, 64, 64, 20, None, 0) == api.ERR_INVALID     # no communicator
+    assert lib.statmc_rccl_unique_id(None) == api.ERR_INVALID
+    assert lib.statmc_rccl_comm_create(None, 2, 0, None) == api.ERR_INVALID
+
+
 def test_product_does_not_import_oracle():
     """The product path may not import, include or load the checker (oracle/) in any form."""
     offenders = []

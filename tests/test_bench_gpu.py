@@ -54,6 +54,10 @@ def test_single_gpu_line(gpu):
         assert pl["slots_idle"] == 0 and pl["trimmed_before_timing"] is not None and pl["slots"] <= 12, pl
     ab = r["accumulate_placement_ab"]
     assert ab["placed_ms"] > 0 and ab["unplaced_ms"] > 0 and r["kernels"]["accumulate"]["unplaced_frac_hbm"] == ab["unplaced_frac_hbm"]
+    # ... and the pre-pass in the accumulation's epilogue: no launch of its own in the step, the same bits (the CPU leg's
+    # `prepass_bit_exact` above compared mean-corr / discriminator of the timed step with the oracle's)
+    assert r["kernels"]["prepass"]["launches_per_step"] == 0 and r["kernels"]["prepass"]["ms_per_step"] == 0.0
+    assert "epilogue" in r["config"]["step_order"]
     rs = r["reference_schedule"]
     assert rs["batches"] == [4, 4] and rs["iterations"] == 2 and rs["ms_per_step"] > 0 and 0 < rs["filter_share"] < 1
     assert abs(rs["accumulate_ms"] + rs["prepass_ms"] + rs["filter_ms"] - rs["ms_per_step"]) < 0.5 * rs["ms_per_step"]

@@ -457,6 +457,98 @@ def test_prepass_bit_exact(gpu, oracle, channels):
     assert np.array_equal(d.cpu().numpy(), d_ref, equal_nan=True)
 
 
+@pytest.mark.parametrize("W,H,S,spec", [(64, 20, 5, {}), (272, 24, 1, {}), (50, 37, 3, {}), (128, 32, 9, dict(sides=1, small_n=1)), (128, 16, 4, dict(dof=1))],
+                         ids=["vector", "one-sample", "scalar-path", "two-sided-exclude", "welch"])
+def test_prepass_fused_into_the_accumulation_is_bit_exact(gpu, oracle, W, H, S, spec):
+    """statmc_stat_type::mean_corr / discriminator (round 6): the accumulation's epilogue writes the pre-pass of the moments it has just
+    updated -- from the registers that hold them, the same prepass_elem -- so the images must equal, bit for bit, what statmc_prepass
+    computes afterwards from the stored moments, and the oracle's pre-pass; film-major launches, a second batch on top, row ranges,
+    the tile-fed entry, under the spec options that change the pre-pass (quantile sides, n < 2, Welch)."""
+    from statmc_amd import film, synthetic
+    types = ("radiance", "normal", "albedo")
+    scene = synthetic.Scene(W, H, seed=21)
+    gpu.set_filter_spec(**spec)
+    try:
+        fs_f = film.FilmStats(W, H, DEV, types=types, radius=3, fused_prepass=True)
+        fs_u = film.FilmStats(W, H, DEV, types=types, radius=3)
+        for b, seed in enumerate((5, 6)):
+            smp = {k: v.to(DEV) for k, v in scene.samples(S, seed=seed, features=types).items()}
+            if b == 1:                      # a pixel with a negative sample (NaN through the Box-Cox root), one far above the rest
+                smp["radiance"][0, 1, 2, 0] = -1.0
+                smp["radiance"][0, 2, 3, 1] = 1e6
+            fs_f.accumulate(smp)
+            fs_u.accumulate(smp)
+            assert fs_f._prepass_current is not None
+            mc_f, d_f = fs_f.mean_corr.clone(), fs_f.disc.clone()
+            fs_u.prepass()
+            torch.cuda.synchronize()
+            for k in ("n", "mean", "m2", "m3", "film_mean", "film_m2"):      # the epilogue leaves the moments alone
+                assert torch.equal(fs_f.state["radiance"][k].view(torch.int32), fs_u.state["radiance"][k].view(torch.int32)), k
+            assert np.array_equal(mc_f.cpu().numpy().view(np.int32), fs_u.mean_corr.cpu().numpy().view(np.int32))
+            assert np.array_equal(d_f.cpu().numpy().view(np.int32), fs_u.disc.cpu().numpy().view(np.int32))
+            rad = {k: v.cpu().numpy() for k, v in fs_u.state["radiance"].items() if v is not None}
+            ospec = oracle.default_spec()
+            for k, v in spec.items():
+                setattr(ospec, k, v)
+            mc_ref, d_ref = oracle.prepass(rad["n"], rad["mean"], rad["m2"], rad["m3"], spec=ospec)
+            assert np.array_equal(mc_f.cpu().numpy(), mc_ref, equal_nan=True) and np.array_equal(d_f.cpu().numpy(), d_ref, equal_nan=True)
+        # prepass() has nothing to launch while the epilogue's result is current ... and launches again once the spec changes
+        before = fs_f.mean_corr.clone()
+        fs_f.mean_corr.fill_(7.0)
+        fs_f.prepass()
+        assert float(fs_f.mean_corr[0, 0, 0].item()) == 7.0
+        gpu.set_filter_spec(**dict(spec, small_n=0 if spec.get("small_n") else 1))
+        fs_f.prepass()
+        torch.cuda.synchronize()
+        assert float(fs_f.mean_corr[0, 0, 0].item()) != 7.0 and fs_f._prepass_current is None
+        gpu.set_filter_spec(**spec)
+        # row ranges through the C ABI: the epilogue writes exactly the rows of the launch
+        if H >= 16:
+            rad = fs_u.state["radiance"]
+            mc2, d2 = torch.full_like(fs_u.mean_corr, 3.0), torch.full_like(fs_u.disc, 3.0)
+            smp = {k: v.to(DEV) for k, v in scene.samples(2, seed=9, features=types).items()}
+            st = gpu.make_stat_type(smp["radiance"], rad, True, 3, prepass_into=(mc2, d2))
+            gpu.accumulate(W, H, [st], rows=[(2, 5), (H - 4, H - 1)])
+            fs_u.prepass()
+            torch.cuda.synchronize()
+            for y0, y1 in ((2, 5), (H - 4, H - 1)):
+                assert torch.equal(mc2[y0:y1].view(torch.int32), fs_u.mean_corr[y0:y1].view(torch.int32))
+                assert torch.equal(d2[y0:y1].view(torch.int32), fs_u.disc[y0:y1].view(torch.int32))
+            assert float(mc2[0].min().item()) == 3.0 and float(mc2[6:H - 4].max().item()) == 3.0 and float(d2[H - 1].min().item()) == 3.0
+        # the tile-fed entry (16 x 16 tiles, ragged at the film's edges)
+        fs_t = film.FilmStats(W, H, DEV, types=("radiance",), radius=3)
+        fs_v = film.FilmStats(W, H, DEV, types=("radiance",), radius=3)
+        smp = scene.samples(S, seed=11, features=("radiance",))["radiance"]
+        tiles = [(x, y, min(x + 16, W), min(y + 16, H)) for y in range(0, H, 16) for x in range(0, W, 16)]
+        blocks, offs, pos = [], [], 0
+        for x0, y0, x1, y1 in tiles:
+            blocks.append(smp[:, y0:y1, x0:x1].contiguous().reshape(-1))
+            offs.append(pos)
+            pos += (x1 - x0) * (y1 - y0) * S
+            pos = (pos + 3) // 4 * 4
+        arena = torch.zeros(pos * 3, dtype=torch.float32)
+        for blk, o in zip(blocks, offs):
+            arena[o * 3:o * 3 + blk.numel()] = blk
+        arena = arena.to(DEV)
+        st = gpu.make_stat_type_arena(arena, 3, fs_t.state["radiance"], True, 3, prepass_into=(fs_t.mean_corr, fs_t.disc))
+        gpu.accumulate_tiles(W, H, [st], torch.tensor(tiles, dtype=torch.int32, device=DEV), torch.tensor(offs, dtype=torch.int64, device=DEV),
+                             torch.full((len(tiles),), S, dtype=torch.int32, device=DEV))
+        fs_v.accumulate({"radiance": smp.to(DEV)})
+        fs_v.prepass()
+        torch.cuda.synchronize()
+        assert torch.equal(fs_t.state["radiance"]["m3"].view(torch.int32), fs_v.state["radiance"]["m3"].view(torch.int32))
+        assert torch.equal(fs_t.mean_corr.view(torch.int32), fs_v.mean_corr.view(torch.int32)) and torch.equal(fs_t.disc.view(torch.int32), fs_v.disc.view(torch.int32))
+        # both or neither, and only with three moments
+        lib = gpu.load()
+        bad = gpu.make_stat_type(smp.to(DEV), fs_v.state["radiance"], True, 3)
+        bad.mean_corr = fs_v.mean_corr.data_ptr()
+        assert lib.statmc_accumulate(W, H, C.byref(bad), 1, None) == gpu.ERR_INVALID
+        bad = gpu.make_stat_type(smp.to(DEV), fs_v.state["radiance"], True, 2, prepass_into=(fs_v.mean_corr, fs_v.disc))
+        assert lib.statmc_accumulate(W, H, C.byref(bad), 1, None) == gpu.ERR_INVALID
+    finally:
+        gpu.set_filter_spec()
+
+
 def test_significance_levels(gpu, oracle):
     n = np.full((4, 8), 12, np.int32)
     rng = np.random.default_rng(0)

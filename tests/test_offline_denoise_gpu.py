@@ -179,6 +179,11 @@ def test_sharded_denoise_through_the_cpp_host(gpu, tmp_path, grid):
         outs[g] = pfm.read_pfm("%s-%d-film-f.pfm" % (stem, spp))
     assert np.isfinite(outs[None]).all() and np.abs(outs[None] - rad["film_mean"]).max() > 0
     assert np.array_equal(outs[grid], outs[None])
+    # ... and with every device image a block of the placed allocator (statmc::usePlacedMemory(): the Estimator's tables and the
+    # blocks' images; the cross-DEVICE case is tests/test_multidevice_gpu.py)
+    out = subprocess.run([exe, "--stem", stem, "--spp", str(spp), "--output", "film-f", "--parts", "2", "--grid", grid, "--placed"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert np.array_equal(pfm.read_pfm("%s-%d-film-f.pfm" % (stem, spp)), outs[None])
     if grid == "2x2":     # Welch degrees of freedom: the sample count rides in the block + halo image's 16th channel
         for g in (None, grid):
             cmd = [exe, "--stem", stem, "--spp", str(spp), "--output", "film-f", "--parts", "2", "--spec", "dof=welch"] + (["--grid", g] if g else [])

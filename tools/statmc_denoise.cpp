@@ -8,6 +8,7 @@
 //                  [--significance 0|1|2] [--tquantiles table.txt] [--compare other/stem] [--no-write]
 //                  [--spec gate=sym|asym,channels=and|joint,sides=two|one,dof=pixel|welch,border=clip|clamp,small_n=accept|exclude]
 //                  [--grid GXxGY [--devices 0,1,..]]   the denoise pass over film blocks with a halo exchange (C++ only)
+//                  [--placed]                          device images from statmc_malloc_placed (statmc::usePlacedMemory())
 //   statmc_denoise --catalogue [--config denoise|acrr|smis|proden|ours] [--width W --height H]
 //
 // Per iteration it reads "<stem>-<spp>-film.pfm" and every "<stem>-<spp>-t<i>-b<j>-<suffix>.pfm"
@@ -149,6 +150,7 @@ int main(int argc, char **argv) {
             else if (a == "--sweep-significance") sweepSignificance = next();
             else if (a == "--grid") gridText = next();          // GXxGY: the denoise pass sharded over film blocks
             else if (a == "--devices") devicesText = next();    // devices the blocks go to, round robin (default: one)
+            else if (a == "--placed") statmc::usePlacedMemory() = true;   // device images from statmc_malloc_placed (the blocks of --grid too)
             else if (a == "--parts") forceParts = std::stoi(next());
             else if (a == "--kernel") kernel = next();   // "general": window_filter_generic for every call (one arithmetic for every spec)
             else if (a == "--bands") bands = std::stoi(next());  // Upload / Denoise / Download as a pipeline of row bands (0 = automatic, 1 = off)
