@@ -431,6 +431,11 @@ __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long lo
     }
     constexpr int NE = 4 * C;  // elements per lane
     const long long e0 = p0 * C;
+    // (the epilogue's descriptor fields, read BEFORE the first store: read behind the stores they keep the by-value kernel argument
+    // in a private copy -- 2 KB of scratch per lane and 17 more VGPRs, accumulation 3.67 -> 4.60 ms; measured, round 6)
+    float *const pre_mc = MAXM >= 3 ? t.mean_corr : nullptr;
+    float *const pre_dc = MAXM >= 3 ? t.disc : nullptr;
+    const int pre_table = t.pre_table, pre_flags = t.pre_flags;
     PairState st[NE / 2];   // element pairs (2 i, 2 i + 1) of the lane's 4 C consecutive elements
     float tmp[NE];
     const int4 n4 = *reinterpret_cast<const int4 *>(t.n + p0);
@@ -596,10 +601,10 @@ __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long lo
     // Optional epilogue (round 6): the pre-pass of the moments just written, from the registers that hold them -- the same
     // prepass_elem as prepass_kernel, hence the same bits -- instead of a launch that reads 40 B per pixel back.
     if constexpr (MAXM >= 3) {
-        if (t.mean_corr != nullptr) {
+        if (pre_mc != nullptr) {
             float tq[4];
 #pragma unroll
-            for (int p = 0; p < 4; p++) tq[p] = (t.pre_flags & 1) ? 1.f : t_quantile(t.pre_table, n_out[p] - 1);
+            for (int p = 0; p < 4; p++) tq[p] = (pre_flags & 1) ? 1.f : t_quantile(pre_table, n_out[p] - 1);
 #pragma unroll
             for (int k = 0; k < C; k++) {
                 vfloat4 mc, dc;
@@ -607,12 +612,12 @@ __device__ __forceinline__ void accumulate_lane(const AccumulateType &t, long lo
                 for (int j = 0; j < 4; j++) {
                     const int e = 4 * k + j, px = e / C;
                     float m, d;
-                    prepass_elem(n_out[px], tq[px], st[e >> 1].mean[e & 1], st[e >> 1].m2[e & 1], st[e >> 1].m3[e & 1], m, d, (t.pre_flags & 2) != 0);
+                    prepass_elem(n_out[px], tq[px], st[e >> 1].mean[e & 1], st[e >> 1].m2[e & 1], st[e >> 1].m3[e & 1], m, d, (pre_flags & 2) != 0);
                     mc[j] = m;
                     dc[j] = d;
                 }
-                *reinterpret_cast<vfloat4 *>(t.mean_corr + e0 + 4 * k) = mc;
-                *reinterpret_cast<vfloat4 *>(t.disc + e0 + 4 * k) = dc;
+                *reinterpret_cast<vfloat4 *>(pre_mc + e0 + 4 * k) = mc;
+                *reinterpret_cast<vfloat4 *>(pre_dc + e0 + 4 * k) = dc;
             }
         }
     }
@@ -624,6 +629,9 @@ template <int C, int MAXM, bool TRANSFORM>
 __device__ __forceinline__ void accumulate_pixel(const AccumulateType &t, long long p, const float *sp,
                                                  long long stride, int S) {
     const int n0 = t.n[p];
+    float *const pre_mc = MAXM >= 3 ? t.mean_corr : nullptr;      // (read before the first store: see accumulate_lane)
+    float *const pre_dc = MAXM >= 3 ? t.disc : nullptr;
+    const int pre_table = t.pre_table, pre_flags = t.pre_flags;
     for (int c = 0; c < C; c++) {
         const long long e = p * C + c;
         ElemState st = {t.mean[e], MAXM >= 2 ? t.m2[e] : 0.f, MAXM >= 3 ? t.m3[e] : 0.f,
@@ -639,12 +647,12 @@ __device__ __forceinline__ void accumulate_pixel(const AccumulateType &t, long l
             t.film_mean[e] = st.fmean;
             t.film_m2[e] = st.fm2;
         }
-        if (MAXM >= 3 && t.mean_corr != nullptr) {   // (the optional pre-pass epilogue, as in accumulate_lane)
+        if (MAXM >= 3 && pre_mc != nullptr) {   // (the optional pre-pass epilogue, as in accumulate_lane)
             const int ni = n0 + S;
             float m, d;
-            prepass_elem(ni, (t.pre_flags & 1) ? 1.f : t_quantile(t.pre_table, ni - 1), st.mean, st.m2, st.m3, m, d, (t.pre_flags & 2) != 0);
-            t.mean_corr[e] = m;
-            t.disc[e] = d;
+            prepass_elem(ni, (pre_flags & 1) ? 1.f : t_quantile(pre_table, ni - 1), st.mean, st.m2, st.m3, m, d, (pre_flags & 2) != 0);
+            pre_mc[e] = m;
+            pre_dc[e] = d;
         }
     }
     t.n[p] = n0 + S;
@@ -703,7 +711,7 @@ __global__ __launch_bounds__(kBlock, OCC) void accumulate_kernel(AccumulateArgs 
     float *ring = DMA ? acc_lds + (threadIdx.x >> 6) * acc_ring_floats(DMA) : nullptr;
     if (a.resident_blocks > 0) {
         for (int i = 0; i < a.n_types; i++) {
-            const AccumulateType &t = a.t[(blockIdx.x + i) % a.n_types];
+            const AccumulateType t = a.t[(blockIdx.x + i) % a.n_types];   // (by value: see below)
             if (t.channels == 3) accumulate_dispatch<3, VEC, UMUL, DMA>(t, blockIdx.x, gridDim.x, ring, a.dma_first != 0);
             else accumulate_dispatch<1, VEC, UMUL, DMA>(t, blockIdx.x, gridDim.x, ring, a.dma_first != 0);
         }
@@ -714,7 +722,10 @@ __global__ __launch_bounds__(kBlock, OCC) void accumulate_kernel(AccumulateArgs 
         // workgroup of a type does the same amount of work, none walks a second, ragged stride.  The dispatcher hands the
         // blocks out in order, so the resident mix always holds every type and the launch ends within one workgroup's time.
         const int ti = blockIdx.x % a.n_types;
-        const AccumulateType &t = a.t[ti];
+        // (a COPY of the descriptor, not a reference into the by-value kernel argument: with the pre-pass epilogue's fields in use a
+        // reference made the compiler keep the whole 2-KB argument in a private copy -- scratch 2032 B per lane, + 17 VGPRs, the
+        // accumulation 3.67 -> 4.60 ms; round 6)
+        const AccumulateType t = a.t[ti];
         const long long blk = blockIdx.x / a.n_types, nblk = gridDim.x / a.n_types;
         if (t.channels == 3) accumulate_dispatch<3, VEC, UMUL, DMA>(t, blk, nblk, ring, a.dma_first != 0);
         else accumulate_dispatch<1, VEC, UMUL, DMA>(t, blk, nblk, ring, a.dma_first != 0);
@@ -725,7 +736,7 @@ __global__ __launch_bounds__(kBlock, OCC) void accumulate_kernel(AccumulateArgs 
     // that all types finish together instead of leaving the expensive one to run on alone.
     const int slot = blockIdx.x % a.n_slots, round = blockIdx.x / a.n_slots, n_rounds = gridDim.x / a.n_slots;
     const int ti = a.slot_type[slot];
-    const AccumulateType &t = a.t[ti];
+    const AccumulateType t = a.t[ti];
     const long long blk = (long long)round * a.type_slots[ti] + a.slot_rank[slot];
     const long long nblk = (long long)n_rounds * a.type_slots[ti];
     if (t.channels == 3) accumulate_dispatch<3, VEC, UMUL, DMA>(t, blk, nblk, ring, a.dma_first != 0);
@@ -877,22 +888,41 @@ __global__ __launch_bounds__(kBlock) void accumulate_tiles_kernel(AccumulateTile
     // a.order = 0 (rounds 2 - 4; A/B): item = (tile, type), types innermost: the waves of a workgroup work on the types of one
     // tile, so ALU-heavy radiance items and bandwidth-only feature items share every CU
     // (a.order = 1, experiment: tiles innermost -- neighbouring waves read neighbouring blocks of one type's arena)
-    for (long long item = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); item < n_items; item += n_waves) {
-        int tile = __builtin_amdgcn_readfirstlane(a.order ? (int)(item % a.n_tiles) : (int)(item / a.n_types));
-        int ti = __builtin_amdgcn_readfirstlane(a.order ? (int)(item / a.n_tiles) : (int)(item % a.n_types));
+    // An item's state loads hang on its tile's bounds, which hang on a load of their own: at short batches (4 - 16 samples) that extra
+    // latency per item is what separated this walk from the film-major kernel (same bytes, same L2 hits and misses, 1.2 - 1.3 x the
+    // wave cycles: profiles/r06_tiles_pmc_S4.log).  Round 6: a wave fetches the NEXT item's tile record (bounds, sample count, arena
+    // offset: scalar loads, wave-uniform) before it starts on the current one.
+    struct Rec { int tile, ti, x0, y0, x1, y1, S; long long off; };
+    auto decode = [&](long long item, int &tile, int &ti) {
+        tile = __builtin_amdgcn_readfirstlane(a.order ? (int)(item % a.n_tiles) : (int)(item / a.n_types));
+        ti = __builtin_amdgcn_readfirstlane(a.order ? (int)(item / a.n_tiles) : (int)(item % a.n_types));
         if (a.order == 2) {
             const long long q = item >> 2;
             ti = __builtin_amdgcn_readfirstlane((int)(q % a.n_types));
             tile = __builtin_amdgcn_readfirstlane((int)(q / a.n_types) * 4 + (int)(item & 3));
-            if (tile >= a.n_tiles) continue;
         }
-        const int x0 = a.tile_bounds[4 * tile], y0 = a.tile_bounds[4 * tile + 1];
-        const int x1 = a.tile_bounds[4 * tile + 2], y1 = a.tile_bounds[4 * tile + 3];
-        const int S = a.tile_samples[tile];
-        if (S <= 0 || x1 <= x0 || y1 <= y0) continue;
-        const AccumulateType &t = a.t[ti];
-        if (t.channels == 3) accumulate_tile_dispatch<3, UMUL, DMA>(t, a, x0, y0, x1 - x0, y1 - y0, a.tile_offsets[tile], S, ring);
-        else accumulate_tile_dispatch<1, UMUL, DMA>(t, a, x0, y0, x1 - x0, y1 - y0, a.tile_offsets[tile], S, ring);
+    };
+    auto fetch = [&](long long item) {
+        Rec r;
+        r.S = 0; r.x0 = r.y0 = r.x1 = r.y1 = 0; r.off = 0;
+        decode(item, r.tile, r.ti);
+        if (item < n_items && r.tile < a.n_tiles) {
+            r.x0 = a.tile_bounds[4 * r.tile]; r.y0 = a.tile_bounds[4 * r.tile + 1];
+            r.x1 = a.tile_bounds[4 * r.tile + 2]; r.y1 = a.tile_bounds[4 * r.tile + 3];
+            r.S = a.tile_samples[r.tile];
+            r.off = a.tile_offsets[r.tile];
+        }
+        return r;
+    };
+    long long item = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    Rec cur = fetch(item);
+    for (; item < n_items; item += n_waves) {
+        const Rec r = a.prefetch ? cur : fetch(item);       // (a.prefetch = 0: A/B, statmc_debug_accumulate_tiles_variant)
+        if (a.prefetch) cur = fetch(item + n_waves);
+        if (r.tile >= a.n_tiles || r.S <= 0 || r.x1 <= r.x0 || r.y1 <= r.y0) continue;
+        const AccumulateType &t = a.t[r.ti];
+        if (t.channels == 3) accumulate_tile_dispatch<3, UMUL, DMA>(t, a, r.x0, r.y0, r.x1 - r.x0, r.y1 - r.y0, r.off, r.S, ring);
+        else accumulate_tile_dispatch<1, UMUL, DMA>(t, a, r.x0, r.y0, r.x1 - r.x0, r.y1 - r.y0, r.off, r.S, ring);
     }
 }
 

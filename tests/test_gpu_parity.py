@@ -516,8 +516,8 @@ def test_prepass_fused_into_the_accumulation_is_bit_exact(gpu, oracle, W, H, S, 
                 assert torch.equal(d2[y0:y1].view(torch.int32), fs_u.disc[y0:y1].view(torch.int32))
             assert float(mc2[0].min().item()) == 3.0 and float(mc2[6:H - 4].max().item()) == 3.0 and float(d2[H - 1].min().item()) == 3.0
         # the tile-fed entry (16 x 16 tiles, ragged at the film's edges)
-        fs_t = film.FilmStats(W, H, DEV, types=("radiance",), radius=3)
-        fs_v = film.FilmStats(W, H, DEV, types=("radiance",), radius=3)
+        fs_t = film.FilmStats(W, H, DEV, types=("radiance",), radius=3, g_buffers=())
+        fs_v = film.FilmStats(W, H, DEV, types=("radiance",), radius=3, g_buffers=())
         smp = scene.samples(S, seed=11, features=("radiance",))["radiance"]
         tiles = [(x, y, min(x + 16, W), min(y + 16, H)) for y in range(0, H, 16) for x in range(0, W, 16)]
         blocks, offs, pos = [], [], 0
