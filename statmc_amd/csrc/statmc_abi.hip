@@ -1343,8 +1343,7 @@ int statmc_accumulate_tiles(uint16_t width, uint16_t height, const statmc_stat_t
     k.height = height;
     k.dma = dstate.acc_dma;
     k.umul = dstate.tiles_umul;
-    k.order = dstate.tiles_order & 15;
-    k.prefetch = (dstate.tiles_order & 16) ? 0 : 1;
+    k.order = dstate.tiles_order;
     k.wg_per_cu = dstate.tiles_wg_per_cu;
     k.dma_first = dstate.acc_dma_first;
     HIP_TRY(statmc::launch_accumulate_tiles(k, S(stream)));
@@ -1455,8 +1454,7 @@ int statmc_debug_accumulate_umul(int umul) {   // film-major kernel: 2 = the mea
     STATMC_DEBUG_SET(d.acc_umul = umul == 2 ? 2 : 1);
 }
 int statmc_debug_accumulate_tiles_variant(int umul, int order, int wg_per_cu) {  // experiments (time_accumulate_tiles.py)
-    // (order + 16: the same item order without the prefetch of the next item's tile record -- round 6's A/B)
-    STATMC_DEBUG_SET(d.tiles_umul = umul == 2 ? 2 : 1; d.tiles_order = order < 0 || (order & 15) > 2 || order > 18 ? 0 : order; d.tiles_wg_per_cu = wg_per_cu < 0 ? 0 : wg_per_cu);
+    STATMC_DEBUG_SET(d.tiles_umul = umul == 2 ? 2 : 1; d.tiles_order = order < 0 || order > 2 ? 0 : order; d.tiles_wg_per_cu = wg_per_cu < 0 ? 0 : wg_per_cu);
 }
 int statmc_debug_force_filter_parts(int k) { return statmc_set_filter_split(k < 0 ? 0 : k); }   // the older name of the pin
 // non-zero: the library was built with an experiment switch of statmc_sym_experiments.h (never the product build)

@@ -72,7 +72,6 @@ struct AccumulateTilesArgs {
     int dma;                         // RGB sample planes arrive by LDS-DMA (default 1)
     int umul, order, wg_per_cu;      // experiment knobs (statmc_debug_accumulate_tiles_variant): prefetch depth x2, item order, grid size
     int dma_first;                   // A/B (statmc_debug_accumulate_launch): the first rows of the LDS-DMA ring requested before the state loads
-    int prefetch;                    // 1 (default): a wave fetches the next item's tile record before it starts on the current one
 };
 
 struct MergeTilesArgs {

@@ -119,10 +119,11 @@ constexpr bool mode_pair(int m) { return m == 1 /* kModePair */ || m == kModeWel
 // G: half 0 sweeps read groups [0, G), half 1 the rest -- no group is evaluated by both waves, and the OLDER wave of a SIMD pair
 // (half 0: it wins the issue arbitration and would otherwise wait at the barrier) takes the larger share.  hk last: flush, staging
 // and LDS-DMA after the wave's sweep instead of before it.
-constexpr int gsplit_of(int mode, int ng) {
-    if (kGSplitForced >= 0) return kGSplitForced;
-    return (ng == 8 || mode_pair(mode) || mode_asym(mode)) ? 6 : 7;
-}
+// The split decides the ORDER of every pixel's sums, and the builds must agree on it: a block + halo image with 17 channels runs the
+// eight-plane build where the whole film with the same G-buffers runs the six-plane one, and the two must leave the same bits
+// (tests/test_peer_gpu.py caught a per-build G).  So ONE G for every build -- 6: best or within 1 % of the best everywhere -- and
+// only the housekeeping's place, which changes no sum, is chosen per build.
+constexpr int gsplit_of(int, int) { return kGSplitForced >= 0 ? kGSplitForced : 6; }
 constexpr bool hk_at_end(int mode, int ng) {
     if (kHkAtEndForced >= 0) return kHkAtEndForced != 0;
     return ng == 6 && !mode_pair(mode);
@@ -779,13 +780,13 @@ __device__ __forceinline__ void eval_half_row(LaneT &st, const float *row, const
     constexpr bool kPipe = sym::kPipe && !mode_welch(MODE);
     if constexpr (RT) {
         static_assert(kSplit == 0, "the runtime-radius build splits the window in the middle");
-        // From nine read groups up (r >= 16) and in the builds whose r = 20 relatives gain from it (six feature planes, one
-        // buffer): whole read groups [j_lo, g) to half 0, [g, j_hi] to half 1, g = j_lo + 9/14 of the groups -- the share the
-        // r = 20 build measured best (gsplit_of); taps beyond the radius carry -inf in the table, so no group needs a mask.
-        // 1080p: r = 19 1.380 -> 1.340 ms, Welch r = 20 3.48 -> 3.39 (pooled 3.47 -> 3.34); below nine groups the middle split
-        // is as good or better (r = 10 0.58 | 0.60, Welch r = 6 0.70 | 0.72; profiles/r06_rt.log).
-        if (kGroupSplitRT && NG == 6 && !mode_pair(MODE) && j_hi - j_lo + 1 >= 9) {
-            const int g = j_lo + ((j_hi - j_lo + 1) * 9 + 7) / 14;
+        // From nine read groups up (r >= 16), in every build (the same rule for all of them: see gsplit_of): whole read groups
+        // [j_lo, g) to half 0, [g, j_hi] to half 1, g = j_lo + 6/11 of the groups -- the r = 20 builds' share; taps beyond the radius
+        // carry -inf in the table, so no group needs a mask.  Below nine groups the middle split is as good or better (measured with
+        // a 9/14 share: r = 10 0.58 | 0.60 ms, Welch r = 6 0.70 | 0.72; r = 19 1.380 -> 1.340, Welch r = 20 3.48 -> 3.39;
+        // profiles/r06_rt.log).
+        if (kGroupSplitRT && j_hi - j_lo + 1 >= 9) {
+            const int g = j_lo + ((j_hi - j_lo + 1) * 6 + 5) / 11;
             if (dy0) {
                 if constexpr (HF == 0) {
                     sweep_range<0, 0, false, MODE, NG>(st, row, tab, qrow, tq2);

@@ -127,6 +127,7 @@ struct Placement {
     int target2 = -1;                        // the second probe target: the first slot found apart from slot 0 (private too)
     size_t total_bytes = 0;                  // of the card
     float fastest_ms = 0.f, slowest_ms = 0.f;
+    float level = 0.f;                       // fast_level(): what the class thresholds are multiples of
     int n_probes = 0;
     const char *last_note = "-";             // why the last attempt to back a slot ended (diagnostics)
     std::map<size_t, size_t> free_blocks[2]; // per role: offset from base -> bytes (coalesced; never across slots of another role)
@@ -146,13 +147,31 @@ bool placement_disabled() {
     return e && e[0] == '0';
 }
 
+// The level every threshold is a multiple of: the THIRD-smallest probe against slot 0, not the smallest (round 6).  One probe that
+// comes out a few per cent too fast -- a clock still ramping, the first launches of a process -- used to drag the minimum down, push the
+// genuine fast cluster (1.00 - 1.03 x) into the "between the levels" band and leave the allocator with slots it could not classify
+// (arenas dealt as they came, or no contrast seen within 96 slots: three processes in a row on one box, 0.81 | 0.74 | 0.77 of the
+// HBM peak, profiles/r06_bench_d_*.json).  With fewer than three probes: the smallest.
+float fast_level(const Placement &P) {
+    float a = 1e30f, b = 1e30f, c = 1e30f;   // the three smallest, ascending
+    for (size_t i = 1; i < P.slots.size(); i++) {
+        const float t = P.slots[i].probe_ms[0];
+        if (t <= 0.f) continue;
+        if (t < a) { c = b; b = a; a = t; }
+        else if (t < b) { c = b; b = t; }
+        else if (t < c) c = t;
+    }
+    return c < 1e30f ? c : a < 1e30f ? a : 0.f;
+}
+
 int classify(const Placement &P, const Slot &s) {
     if (P.no_contrast || !P.calibrated || s.probe_ms[0] <= 0.f) return kUnknown;
-    if (s.probe_ms[0] > kSameAbove * P.fastest_ms) return kClassA;
-    if (s.probe_ms[0] >= kApartBelow * P.fastest_ms) return kMixed;
+    const float level = P.level;
+    if (s.probe_ms[0] > kSameAbove * level) return kClassA;
+    if (s.probe_ms[0] >= kApartBelow * level) return kMixed;
     if (s.probe_ms[1] <= 0.f) return kNotA;
-    if (s.probe_ms[1] > kSameAbove * P.fastest_ms) return kClassB;
-    if (s.probe_ms[1] < kApartBelow * P.fastest_ms) return kClassC;
+    if (s.probe_ms[1] > kSameAbove * level) return kClassB;
+    if (s.probe_ms[1] < kApartBelow * level) return kClassC;
     return kMixed;
 }
 
@@ -216,6 +235,7 @@ hipError_t probe_slot(Placement &P, size_t index, int which = 0) {
     if (getenv("STATMC_PLACEMENT_DEBUG")) fprintf(stderr, "statmc placement: slot %zu against target %d: %.4f ms\n", index, which, best);
     if (P.fastest_ms == 0.f || best < P.fastest_ms) P.fastest_ms = best;
     if (best > P.slowest_ms) P.slowest_ms = best;
+    if (which == 0) P.level = fast_level(P);
     return hipSuccess;
 }
 
@@ -354,8 +374,8 @@ hipError_t calibrate(Placement &P) {
         for (size_t i = 1; i < P.slots.size(); i++) {
             const float t = P.slots[i].probe_ms[0];
             if (t <= 0.f) continue;
-            n_fast += t < kApartBelow * P.fastest_ms ? 1 : 0;
-            n_slow += t > kContrast * P.fastest_ms ? 1 : 0;
+            n_fast += t < kApartBelow * P.level ? 1 : 0;
+            n_slow += t > kContrast * P.level ? 1 : 0;
         }
         if (n_fast >= 2 && n_slow >= 2) {
             P.calibrated = true;
@@ -384,7 +404,7 @@ bool suits(const Placement &P, const Slot &s, unsigned mask) {
     if (s.role != -1) return false;      // dealt, private or released
     if (P.no_contrast || mask == kAnyClass) return true;
     const int c = classify(P, s);
-    if (c == kClassA && (mask & kWellInsideA) && !(s.probe_ms[0] > state_above() * P.fastest_ms)) return false;
+    if (c == kClassA && (mask & kWellInsideA) && !(s.probe_ms[0] > state_above() * P.level)) return false;
     return c >= 0 && (mask & bit(c));
 }
 

@@ -888,41 +888,25 @@ __global__ __launch_bounds__(kBlock) void accumulate_tiles_kernel(AccumulateTile
     // a.order = 0 (rounds 2 - 4; A/B): item = (tile, type), types innermost: the waves of a workgroup work on the types of one
     // tile, so ALU-heavy radiance items and bandwidth-only feature items share every CU
     // (a.order = 1, experiment: tiles innermost -- neighbouring waves read neighbouring blocks of one type's arena)
-    // An item's state loads hang on its tile's bounds, which hang on a load of their own: at short batches (4 - 16 samples) that extra
-    // latency per item is what separated this walk from the film-major kernel (same bytes, same L2 hits and misses, 1.2 - 1.3 x the
-    // wave cycles: profiles/r06_tiles_pmc_S4.log).  Round 6: a wave fetches the NEXT item's tile record (bounds, sample count, arena
-    // offset: scalar loads, wave-uniform) before it starts on the current one.
-    struct Rec { int tile, ti, x0, y0, x1, y1, S; long long off; };
-    auto decode = [&](long long item, int &tile, int &ti) {
-        tile = __builtin_amdgcn_readfirstlane(a.order ? (int)(item % a.n_tiles) : (int)(item / a.n_types));
-        ti = __builtin_amdgcn_readfirstlane(a.order ? (int)(item / a.n_tiles) : (int)(item % a.n_types));
+    // (Round 6 tried fetching the NEXT item's tile record -- bounds, sample count, arena offset -- before starting on the current one:
+    // 0.627 -> 0.632 of the HBM peak at 4 samples per tile, nothing at 8 .. 64; profiles/r06_tiles_prefetch.log.  Not the latency of
+    // that load, then; removed.)
+    for (long long item = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); item < n_items; item += n_waves) {
+        int tile = __builtin_amdgcn_readfirstlane(a.order ? (int)(item % a.n_tiles) : (int)(item / a.n_types));
+        int ti = __builtin_amdgcn_readfirstlane(a.order ? (int)(item / a.n_tiles) : (int)(item % a.n_types));
         if (a.order == 2) {
             const long long q = item >> 2;
             ti = __builtin_amdgcn_readfirstlane((int)(q % a.n_types));
             tile = __builtin_amdgcn_readfirstlane((int)(q / a.n_types) * 4 + (int)(item & 3));
+            if (tile >= a.n_tiles) continue;
         }
-    };
-    auto fetch = [&](long long item) {
-        Rec r;
-        r.S = 0; r.x0 = r.y0 = r.x1 = r.y1 = 0; r.off = 0;
-        decode(item, r.tile, r.ti);
-        if (item < n_items && r.tile < a.n_tiles) {
-            r.x0 = a.tile_bounds[4 * r.tile]; r.y0 = a.tile_bounds[4 * r.tile + 1];
-            r.x1 = a.tile_bounds[4 * r.tile + 2]; r.y1 = a.tile_bounds[4 * r.tile + 3];
-            r.S = a.tile_samples[r.tile];
-            r.off = a.tile_offsets[r.tile];
-        }
-        return r;
-    };
-    long long item = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    Rec cur = fetch(item);
-    for (; item < n_items; item += n_waves) {
-        const Rec r = a.prefetch ? cur : fetch(item);       // (a.prefetch = 0: A/B, statmc_debug_accumulate_tiles_variant)
-        if (a.prefetch) cur = fetch(item + n_waves);
-        if (r.tile >= a.n_tiles || r.S <= 0 || r.x1 <= r.x0 || r.y1 <= r.y0) continue;
-        const AccumulateType &t = a.t[r.ti];
-        if (t.channels == 3) accumulate_tile_dispatch<3, UMUL, DMA>(t, a, r.x0, r.y0, r.x1 - r.x0, r.y1 - r.y0, r.off, r.S, ring);
-        else accumulate_tile_dispatch<1, UMUL, DMA>(t, a, r.x0, r.y0, r.x1 - r.x0, r.y1 - r.y0, r.off, r.S, ring);
+        const int x0 = a.tile_bounds[4 * tile], y0 = a.tile_bounds[4 * tile + 1];
+        const int x1 = a.tile_bounds[4 * tile + 2], y1 = a.tile_bounds[4 * tile + 3];
+        const int S = a.tile_samples[tile];
+        if (S <= 0 || x1 <= x0 || y1 <= y0) continue;
+        const AccumulateType &t = a.t[ti];
+        if (t.channels == 3) accumulate_tile_dispatch<3, UMUL, DMA>(t, a, x0, y0, x1 - x0, y1 - y0, a.tile_offsets[tile], S, ring);
+        else accumulate_tile_dispatch<1, UMUL, DMA>(t, a, x0, y0, x1 - x0, y1 - y0, a.tile_offsets[tile], S, ring);
     }
 }
 

@@ -42,10 +42,10 @@
 // round 6 (get the sweep off the per-step barrier), each measured and written up in HISTORY.md 4.3d:
 // GSPLIT = G > 0: the two waves of a row split the window at a read-group boundary instead of at dx = 0 -- half 0 sweeps
 // groups [0, G), half 1 groups [G, 11): no group is evaluated twice (84 instead of 86 (tap pair, pixel) units per lane and row)
-// -1 (the product since round 6): per build, gsplit_of() in statmc_filter_sym.hip -- G = 7 for one RGB buffer under the symmetric
-// gates (half 0, the older wave of its SIMD pair, which also keeps house, takes 54 of the 84 units, half 1 30), 6 for the one-sided /
-// Moon gates, eight feature planes and two float buffers.  1080p RGB, back to back, one box: dx = 0 split 1.440 ms | G = 5 1.42 |
-// 6 1.383 | 7 1.340 | 8 1.442 (profiles/r06_ab*.log); per build: profiles/r06_modes.log.
+// -1 (the product since round 6): G = 6 in every build, gsplit_of() in statmc_filter_sym.hip (half 0, the older wave of its SIMD pair,
+// which also keeps house, takes 46 of the 84 units, half 1 38; one G for all builds because the split decides the order of the sums and
+// blocks of a sharded film may run another build than the whole film).  1080p RGB, back to back, one box: dx = 0 split 1.440 ms |
+// G = 5 1.42 | 6 1.383 | 7 1.340 | 8 1.442 (profiles/r06_ab*.log); per build: profiles/r06_modes.log.
 // 0 = the window split at dx = STATMC_SYM_SPLIT (rounds 2 - 5); G > 0 = that G in every build.
 #define STATMC_SYM_GSPLIT_DEFAULT (-1)
 #ifndef STATMC_SYM_GSPLIT
