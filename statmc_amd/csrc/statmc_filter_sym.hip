@@ -780,13 +780,13 @@ __device__ __forceinline__ void eval_half_row(LaneT &st, const float *row, const
     constexpr bool kPipe = sym::kPipe && !mode_welch(MODE);
     if constexpr (RT) {
         static_assert(kSplit == 0, "the runtime-radius build splits the window in the middle");
-        // From nine read groups up (r >= 16), in every build (the same rule for all of them: see gsplit_of): whole read groups
-        // [j_lo, g) to half 0, [g, j_hi] to half 1, g = j_lo + 6/11 of the groups -- the r = 20 builds' share; taps beyond the radius
-        // carry -inf in the table, so no group needs a mask.  Below nine groups the middle split is as good or better (measured with
-        // a 9/14 share: r = 10 0.58 | 0.60 ms, Welch r = 6 0.70 | 0.72; r = 19 1.380 -> 1.340, Welch r = 20 3.48 -> 3.39;
-        // profiles/r06_rt.log).
+        // From nine read groups up (r >= 16), in every build (ONE rule for all of them: see gsplit_of): whole read groups
+        // [j_lo, g) to half 0, [g, j_hi] to half 1, g = j_lo + 9/14 of the groups; taps beyond the radius carry -inf in the table, so
+        // no group needs a mask.  1080p, r = 19: 1.436 ms with the middle split and the housekeeping first, 1.377 with it last, 1.322
+        // with this share on top (a 6/11 share: 1.372); Welch r = 20 3.48 -> 3.39 (pooled 3.47 -> 3.30).  Below nine groups the middle
+        // split is as good or better (r = 10 0.58 | 0.60 ms, Welch r = 6 0.70 | 0.72; profiles/r06_rt.log, r06_modes_product*.log).
         if (kGroupSplitRT && j_hi - j_lo + 1 >= 9) {
-            const int g = j_lo + ((j_hi - j_lo + 1) * 6 + 5) / 11;
+            const int g = j_lo + ((j_hi - j_lo + 1) * 9 + 7) / 14;
             if (dy0) {
                 if constexpr (HF == 0) {
                     sweep_range<0, 0, false, MODE, NG>(st, row, tab, qrow, tq2);

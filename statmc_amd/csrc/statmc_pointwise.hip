@@ -888,9 +888,12 @@ __global__ __launch_bounds__(kBlock) void accumulate_tiles_kernel(AccumulateTile
     // a.order = 0 (rounds 2 - 4; A/B): item = (tile, type), types innermost: the waves of a workgroup work on the types of one
     // tile, so ALU-heavy radiance items and bandwidth-only feature items share every CU
     // (a.order = 1, experiment: tiles innermost -- neighbouring waves read neighbouring blocks of one type's arena)
-    // (Round 6 tried fetching the NEXT item's tile record -- bounds, sample count, arena offset -- before starting on the current one:
-    // 0.627 -> 0.632 of the HBM peak at 4 samples per tile, nothing at 8 .. 64; profiles/r06_tiles_prefetch.log.  Not the latency of
-    // that load, then; removed.)
+    // Round 6, two experiments on why this walk trails the film-major kernel at 4 - 16 samples per tile (same HBM
+    // bytes, same L2 hits and misses, 1.28 x the wave cycles: profiles/r06_tiles_pmc_S4.log), both measured and removed:
+    // the NEXT item's tile record (bounds, sample count, arena offset) fetched before the current item starts -- 0.627 -> 0.632 of the
+    // HBM peak at 4 samples, nothing above (profiles/r06_tiles_prefetch.log); the four waves of a workgroup TOGETHER on four adjacent
+    // tiles, a band of four rows each (moments in 768-byte runs instead of 192-byte ones) -- 0.675 -> 0.648 at 4 samples, 0.720 -> 0.685
+    // at 8, slower at every length (profiles/r06_tiles_quad.log).  Neither the latency of the record nor the shape of the accesses, then.
     for (long long item = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); item < n_items; item += n_waves) {
         int tile = __builtin_amdgcn_readfirstlane(a.order ? (int)(item % a.n_tiles) : (int)(item / a.n_types));
         int ti = __builtin_amdgcn_readfirstlane(a.order ? (int)(item / a.n_tiles) : (int)(item % a.n_types));
