@@ -159,7 +159,7 @@ int statmc_free(void *dev_ptr);   /* blocks of statmc_malloc and of statmc_mallo
  * card, mapped side by side a second time), freed with statmc_free, and otherwise ordinary device memory.  The first call on
  * a device reserves address space and probes GiB slots until both probe levels have been seen (tens of ms); a GiB slot that
  * holds no live block is idle again (either role may take it), slots of the classes a request cannot use stay backed and idle until
- * statmc_placement_trim.  The search for a class backs at most 1.5 x the bytes asked for on the device so far (+ 6 GiB;
+ * statmc_placement_trim.  The search for a class backs at most 2 x the bytes asked for on the device so far (+ 6 GiB;
  * STATMC_PLACEMENT_MAX_GIB=<GiB> sets another budget, never above 60 % of the card) and settles for the other classes after that.
  * Blocks are mapped for every device that can reach the owner as a peer (they are valid operands of statmc_copy_rect and
  * statmc_halo_exchange across devices; not IPC-shareable).  Where the probes show no contrast, the device has no virtual-memory management or memory runs short
@@ -179,6 +179,9 @@ typedef struct statmc_placement_info_t {
     uint64_t slab_bytes[2], live_bytes[2];   /* per role: bytes of the slots dealt to it / bytes in live blocks */
     int32_t slots_released;  /* holes statmc_placement_trim left in the range (not counted in `slots`) */
     int32_t peer_devices;    /* devices besides the owner that the blocks are mapped for (statmc_copy_rect / statmc_halo_exchange operands) */
+    int32_t peak_slots;      /* most GiB slots backed at any one time (what the class searches held before statmc_placement_trim) */
+    int32_t rebased;         /* 1: the allocator's reference slot traded places with a slot of another class, because the card's first
+                                slots were mostly of the first one's (the moments' home should be the class the card has least of) */
 } statmc_placement_info_t;
 int statmc_placement_info(statmc_placement_info_t *out);   /* current device */
 /* Gives the memory of the idle slots of the current device (backed and probed, dealt to no role: the classes nobody asked for)

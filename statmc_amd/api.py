@@ -58,7 +58,8 @@ class PlacementInfo(C.Structure):
     _fields_ = [("active", C.c_int32), ("virtual_memory", C.c_int32), ("slots", C.c_int32), ("probes", C.c_int32),
                 ("slots_a", C.c_int32), ("slots_b", C.c_int32), ("slots_c", C.c_int32), ("slots_unclear", C.c_int32), ("slots_idle", C.c_int32),
                 ("slots_as_they_came", C.c_int32 * 2), ("fast_probe_ms", C.c_float), ("slow_probe_ms", C.c_float),
-                ("slab_bytes", C.c_uint64 * 2), ("live_bytes", C.c_uint64 * 2), ("slots_released", C.c_int32), ("peer_devices", C.c_int32)]
+                ("slab_bytes", C.c_uint64 * 2), ("live_bytes", C.c_uint64 * 2), ("slots_released", C.c_int32), ("peer_devices", C.c_int32),
+                ("peak_slots", C.c_int32), ("rebased", C.c_int32)]
 
 
 MEM_STATE, MEM_STREAM = 0, 1

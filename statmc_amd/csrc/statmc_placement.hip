@@ -32,7 +32,7 @@
 // time side by side in a second reserved range (one physical allocation may be mapped at several addresses, and the class is
 // the memory's, not the address's; blocks above 2 GiB) -- so a 6-GiB arena needs six class-B slots, not six in a row: on a card whose classes come
 // in short runs the first version backed 170 GiB to find three runs of six and still put an arena into class C.  Slots are
-// backed until there are enough OF THE WANTED CLASS or the search's byte budget is spent: 1.5 x what the device's callers have asked
+// backed until there are enough OF THE WANTED CLASS or the search's byte budget is spent: 2 x what the device's callers have asked
 // for so far (+ 6 GiB), or STATMC_PLACEMENT_MAX_GIB; never more than 60 % / 75 % of the card (round 6; until then the two card
 // fractions were the only bounds: 101 GiB backed to place 23).  After that the third class, then both, then anything.  Smaller blocks
 // are carved out of whole slots dealt to their role.  What no role uses stays mapped and idle until statmc_placement_trim gives it
@@ -128,6 +128,8 @@ struct Placement {
     size_t total_bytes = 0;                  // of the card
     float fastest_ms = 0.f, slowest_ms = 0.f;
     float level = 0.f;                       // fast_level(): what the class thresholds are multiples of
+    size_t peak_backed = 0;                  // most slots backed at any one time (what a search held before statmc_placement_trim)
+    bool rebase_tried = false, rebased = false;   // the reference slot moved out of the locally dominant class (calibrate)
     int n_probes = 0;
     const char *last_note = "-";             // why the last attempt to back a slot ended (diagnostics)
     std::map<size_t, size_t> free_blocks[2]; // per role: offset from base -> bytes (coalesced; never across slots of another role)
@@ -189,14 +191,15 @@ size_t live_total(const Placement &P) {
     return b;
 }
 // How many slots the search for a CLASS may have backed, for a device whose callers hold `live_total` and now ask for `need` more:
-// STATMC_PLACEMENT_MAX_GIB if set (> 0), else 1.5 x the bytes asked for + 6 slots (the allocator's own two and what the calibration
-// needs to see both levels).  A third of a card's slots is of any one class, so 1.5 x usually yields "state in A, arenas in B and C"
-// rather than "arenas in B alone" (0.82 against 0.84 of the HBM peak at 1080p / 256 spp; everything in one class: 0.76) -- the price of
-// not backing three times the request.
+// STATMC_PLACEMENT_MAX_GIB if set (> 0), else 2 x the bytes asked for + 6 slots (the allocator's own two and what the calibration
+// needs to see both levels).  A third of a card's slots is of any one class, in runs of 4 .. 64: 2 x usually yields "state in A, arenas
+// in B and C" rather than "arenas in B alone" (0.82 against 0.84 of the HBM peak at 1080p / 256 spp; everything in one class: 0.76) --
+// the price of not backing three times the request -- and falls back to slots as they come only on a card whose first slots are
+// nearly all of the state's class (1.5 x did on one box of five: tests/test_placement_gpu.py).
 size_t budget_slots(const Placement &P, size_t need) {
     static const double env_gib = [] { const char *e = getenv("STATMC_PLACEMENT_MAX_GIB"); return e ? atof(e) : 0.0; }();
     if (env_gib > 0.0) return (size_t)env_gib;
-    return (size_t)(1.5 * (double)(live_total(P) + need) / (double)kSlot + 0.999) + 6;
+    return (size_t)(2.0 * (double)(live_total(P) + need) / (double)kSlot + 0.999) + 6;
 }
 
 // grants the mapping at `at` to the owner and, where the runtime accepts it, to the peers (a block of this allocator is then a
@@ -291,6 +294,7 @@ bool back_next_slot(Placement &P, hipError_t *err, size_t leave_free = 512ull <<
     }
     if (index == P.slots.size()) P.slots.push_back(s);
     else P.slots[index] = s;            // (a hole filled: undealt, unprobed, like a new slot)
+    P.peak_backed = std::max(P.peak_backed, backed_count(P));
     if (index > 0) {
         hipError_t pe = probe_slot(P, index);
         if (pe == hipSuccess) pe = split_not_a(P);
@@ -365,6 +369,33 @@ bool init(Placement &P, int dev) {
 // tell apart on this device.
 void add_free(std::map<size_t, size_t> &fl, size_t off, size_t len);
 
+// Slot k's memory becomes the reference: the two physical allocations trade addresses, every probe is taken again (calibrate)
+hipError_t rebase(Placement &P, size_t k) {
+    if (hipError_t e = hipStreamSynchronize(P.stream); e != hipSuccess) return e;
+    char *a0 = P.base, *ak = P.base + k * kSlot;
+    if (hipError_t e = hipMemUnmap(a0, kSlot); e != hipSuccess) return e;
+    if (hipError_t e = hipMemUnmap(ak, kSlot); e != hipSuccess) return e;
+    std::swap(P.slots[0].handle, P.slots[k].handle);
+    for (char *at : {a0, ak}) {
+        const size_t i = at == a0 ? 0 : k;
+        if (hipError_t e = hipMemMap(at, kSlot, 0, P.slots[i].handle, 0); e != hipSuccess) return e;
+        if (hipError_t e = set_access(P, at); e != hipSuccess) return e;
+    }
+    if (hipError_t e = hipMemsetAsync(P.base, 0, kProbeWindow, P.stream); e != hipSuccess) return e;
+    if (P.target2 >= 0) {                       // (not chosen yet at this point; for completeness)
+        P.slots[P.target2].role = -1;
+        P.target2 = -1;
+    }
+    P.fastest_ms = P.slowest_ms = P.level = 0.f;
+    for (size_t i = 1; i < P.slots.size(); i++) P.slots[i].probe_ms[0] = P.slots[i].probe_ms[1] = 0.f;
+    for (size_t i = 1; i < P.slots.size(); i++)
+        if (P.slots[i].role != kReleased)
+            if (hipError_t e = probe_slot(P, i); e != hipSuccess) return e;
+    P.rebased = true;
+    if (getenv("STATMC_PLACEMENT_DEBUG")) fprintf(stderr, "statmc placement: slot %zu's memory is the reference now\n", k);
+    return hipSuccess;
+}
+
 hipError_t calibrate(Placement &P) {
     hipError_t err = hipSuccess;
     while (!P.calibrated) {
@@ -383,6 +414,25 @@ hipError_t calibrate(Placement &P) {
             P.calibrated = true;
             P.no_contrast = true;
         }
+    }
+    // Round 6: the reference should not sit in the class the card has most of HERE.  Slot 0 is whatever the driver handed out first,
+    // and everything placed afterwards is classified against it: the moments live in its class, the arenas must avoid it.  On a card
+    // whose first dozens of GiB are one long run of slot 0's class a search on a byte budget never finds the arenas' 22 slots apart
+    // from it and deals them as they come -- INTO the moments' class: 0.72 of the HBM peak where torch's allocator gets 0.79
+    // (profiles/r06f_bench.json).  When the calibration has seen a long run of slot 0's class (eight slots or more, three times what it saw apart from it),
+    // the first slot apart from it trades places with slot 0 -- the two physical allocations are mapped at each other's addresses --
+    // and every slot is probed again against the new reference: the long run is now the arenas' class.  Once, before any block
+    // exists.
+    if (err == hipSuccess && !P.no_contrast && !P.rebase_tried && P.live.empty() && P.windows.empty() && !P.slot0_dealt && !getenv("STATMC_PLACEMENT_NO_REBASE")) {
+        P.rebase_tried = true;
+        size_t n_same = 0, n_apart = 0, first_apart = 0;
+        for (size_t i = 1; i < P.slots.size(); i++) {
+            const float t = P.slots[i].probe_ms[0];
+            if (t <= 0.f || P.slots[i].role == kReleased) continue;
+            if (t > kSameAbove * P.level) n_same++;
+            else if (t < kApartBelow * P.level) { n_apart++; if (!first_apart) first_apart = i; }
+        }
+        if (first_apart && n_same >= 8 && n_same >= 3 * n_apart) err = rebase(P, first_apart);   // a clear long run, not a coin toss on four probes
     }
     if (err == hipSuccess) err = split_not_a(P);
     // The state's first home is slot 0 itself, behind the probe's 64-MiB window: every other slot is classified by what a stream of
@@ -586,7 +636,7 @@ int placed_alloc(Placement &P, int role, size_t bytes, void **out, bool may_back
     }
     // whole slots are dealt; the free list joins them with what the role already holds next to them
     const size_t want_slots = (need + kSlot - 1) / kSlot;
-    // how many slots the search for the right class may have backed: the byte budget (1.5 x what has been asked for, or
+    // how many slots the search for the right class may have backed: the byte budget (2 x what has been asked for, or
     // STATMC_PLACEMENT_MAX_GIB), and never more than 60 % of the card for the first choice, 75 % at all (the rest of the process --
     // the caller's other allocations, the runtime's -- needs room too; beyond that: what is backed already, any class)
     const size_t budget = may_back ? budget_slots(P, need) : 0;
@@ -786,6 +836,8 @@ int statmc_placement_info(statmc_placement_info_t *out) {
     out->slots = (int)backed_count(P);
     out->slots_released = (int)(P.slots.size() - backed_count(P));
     out->peer_devices = P.peers_granted ? (int)P.access.size() - 1 : 0;
+    out->peak_slots = (int)P.peak_backed;
+    out->rebased = P.rebased ? 1 : 0;
     out->probes = P.n_probes;
     out->fast_probe_ms = P.fastest_ms;
     out->slow_probe_ms = P.slowest_ms;
