@@ -811,6 +811,40 @@ def eight_channel_filter(fs, args, reps=20):
             "what": "back-to-back launches of the window filter (pre-pass not included) with normal, albedo, depth and material id as G-buffers"}
 
 
+def float_buffer_filter(fs, args, reps=6):
+    """filter<float> as ACRR and SMIS call it on every render iteration (estimator.cpp:434-460: 5 luminance / 12 win-rate buffers in
+    ONE call sharing the G-buffers; statpath.cpp:306-313 reads the result back): the window filter over 1, 2, 5 and 12 one-channel
+    buffers cut from the radiance statistics the timed loop left (two buffers per launch share the range weight).  Secondary."""
+    from statmc_amd import api
+    rad = fs.state["radiance"]
+    gbs = [fs.g_buffer(g) for g in fs.g_names]
+    W, H, dev = fs.width, fs.height, fs.device
+    out = {}
+    for nb in (1, 2, 5, 12):
+        mc = [(fs.mean_corr[..., b % 3:b % 3 + 1] * (1.0 / (1 + b))).contiguous() for b in range(nb)]
+        dc = [(fs.disc[..., b % 3:b % 3 + 1] * (1.0 / (1 + b)) ** 2).contiguous() for b in range(nb)]
+        col = [(rad["film_mean"][..., b % 3:b % 3 + 1] * (1.0 / (1 + b))).contiguous() for b in range(nb)]
+        outs = [torch.zeros(H, W, 1, device=dev) for _ in range(nb)]
+        a, keep = api.make_filter_args(n=[], mean=[], m2=[], m3=[], film=col, mean_corr=mc, disc=dc, film_filtered=outs,
+                                       g_buffers=gbs, g_sds=fs.g_sds, filter_sd=args.filtersd, radius=args.radius)
+        for _ in range(2):
+            api.window_filter(a, 1)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            api.window_filter(a, 1)
+        e1.record()
+        torch.cuda.synchronize()
+        out["%d_buffers_ms" % nb] = round(e0.elapsed_time(e1) / reps, 4)
+        variant = api.last_filter_variant()
+        del mc, dc, col, outs
+    return dict(out, filter_variant=variant, acrr_5_buffers_ms=out["5_buffers_ms"], smis_12_buffers_ms=out["12_buffers_ms"],
+                per_buffer_ms_at_12=round(out["12_buffers_ms"] / 12, 4),
+                what="window filter of n one-channel buffers in one call, back to back (pre-pass not included): the pair-symmetric kernel takes two "
+                     "buffers per launch; more behind one range weight do not fit the CU's LDS (DESIGN.md section 9 item 2)")
+
+
 def _relay_child(cmd, env, timeout_s):
     """Runs a child to its end (or to the time limit: its whole process group is then ended), relays everything but the
     JSON line to stderr; returns (rc, line, last stderr lines, timed_out).  Nothing is exec'ed in this process."""
@@ -1395,6 +1429,7 @@ def main():
                 result["config4_3840x2160_64spp_one_gpu"] = result["accumulate_by_batch_3840x2160"].pop("config4_step")
             result["host_copies"] = leg(host_copy_times, fs, dev)
             result["filter_8_feature_channels"] = leg(eight_channel_filter, fs, args)
+            result["filter_float_buffers"] = leg(float_buffer_filter, fs, args)
             result["pcie_inclusive"] = leg(pcie_inclusive, fs, samples, types, args)
     if run_done is not None:
         run_done.set()

@@ -45,6 +45,8 @@ def test_single_gpu_line(gpu):
     assert r["host_copies"]["upload_bytes_per_px"] == 76 and r["host_copies"]["download_bytes_per_px"] == 12
     assert r["filter_8_feature_channels"]["filter_variant"] == "sym_r20_g8" and r["filter_8_feature_channels"]["avg_ms"] > 0
     assert r["pcie_inclusive"]["GBs"] > 0 and r["pcie_inclusive"]["mpixels_per_s_if_samples_cross_pcie"] < r["value"]
+    ff = r["filter_float_buffers"]
+    assert ff["filter_variant"] == "sym_r20_f" and 0 < ff["1_buffers_ms"] <= ff["2_buffers_ms"] * 1.3 and ff["smis_12_buffers_ms"] > ff["acrr_5_buffers_ms"] > ff["2_buffers_ms"]
     # round 6: the filter parameters as keys of their own (the driver keeps 120 characters of `workload`), the placed allocator trimmed
     # before the timed region and A/B'd against torch's allocator in the same process, the reference's progressive schedule as a leg
     cfg = r["config"]

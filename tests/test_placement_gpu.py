@@ -214,6 +214,44 @@ def test_the_search_for_a_class_stays_inside_its_byte_budget():
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr[-2000:]
 
 
+def test_the_reference_slot_can_trade_places_with_a_slot_of_another_class():
+    """Round 6: on a card whose first GiB are a long run of the reference slot's class the allocator maps the first slot apart from it at
+    the reference's address (and vice versa) and probes everything again, so that the moments' home is the class the card has least of
+    there.  Forced here (STATMC_PLACEMENT_FORCE_REBASE=1: the box at hand may not call for it): the report says so, classes are still
+    told apart, a stream block and a state block land in different classes, and accumulation + filter on such memory leave the bits
+    they leave on torch's allocator."""
+    code = ("import torch, sys, ctypes as C; sys.path.insert(0, %r)\n"
+            "from statmc_amd import api, film, synthetic\n"
+            "api.setup(0)\n"
+            "dev = torch.device('cuda:0')\n"
+            "W, H, S = 256, 96, 6\n"
+            "types = list(synthetic.FEATURES)\n"
+            "smp = synthetic.Scene(W, H, seed=3, device=dev).samples(S, seed=11)\n"
+            "fs_p = film.FilmStats(W, H, dev, types=types, radius=6, placed=True)\n"
+            "psmp = {t: api.empty_placed(tuple(v.shape), torch.float32, dev, api.MEM_STREAM) for t, v in smp.items()}\n"
+            "[psmp[t].copy_(smp[t]) for t in types]\n"
+            "big = api.empty_placed((3 << 28,), torch.float32, dev, api.MEM_STREAM)\n"
+            "big[-1:].fill_(2.0)\n"
+            "i = api.placement_info()\n"
+            "fs_t = film.FilmStats(W, H, dev, types=types, radius=6)\n"
+            "fs_t.accumulate(smp); fs_p.accumulate(psmp)\n"
+            "a, b = fs_t.denoise().clone(), fs_p.denoise().clone()\n"
+            "torch.cuda.synchronize()\n"
+            "assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and float(big[-1].item()) == 2.0\n"
+            "for t in types:\n"
+            "    for k, v in fs_t.state[t].items():\n"
+            "        assert v is None or torch.equal(v.view(torch.int32), fs_p.state[t][k].view(torch.int32)), (t, k)\n"
+            "lib = api.load(); lib.statmc_debug_placement_role.restype = C.c_int; lib.statmc_debug_placement_role.argtypes = [C.c_void_p]\n"
+            "if i['active']:\n"
+            "    assert i['rebased'] == 1 and i['map'][0] == '#', i\n"
+            "    assert lib.statmc_debug_placement_role(C.c_void_p(fs_p.state['radiance']['mean'].data_ptr())) == api.MEM_STATE\n"
+            "    if i['slots_as_they_came'][1] == 0:\n"
+            "        assert lib.statmc_debug_placement_role(C.c_void_p(big.data_ptr())) == api.MEM_STREAM\n"
+            "print('ok', i['active'], i['rebased'], i['map'])\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, STATMC_PLACEMENT_FORCE_REBASE="1"))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr[-2000:]
+
+
 def test_switch_off_is_plain_hipmalloc():
     code = ("import torch, sys; sys.path.insert(0, %r)\n"
             "from statmc_amd import api\n"
