@@ -1504,7 +1504,7 @@ def placement_report():
                        state_GiB=round(info["slab_bytes"][0] / 2 ** 30, 1), stream_GiB=round(info["slab_bytes"][1] / 2 ** 30, 1), map=info["map"],
                        slots_released=info["slots_released"], trimmed_before_timing=PLACED.get("trimmed"), trim_error=PLACED.get("trim_error"),
                        peak_slots=info["peak_slots"], rebased=bool(info["rebased"]),
-                       budget="2 x the bytes asked for + 6 GiB (STATMC_PLACEMENT_MAX_GIB=%s)" % os.environ.get("STATMC_PLACEMENT_MAX_GIB", "unset"),
+                       budget="3 x the bytes asked for + 6 GiB (STATMC_PLACEMENT_MAX_GIB=%s)" % os.environ.get("STATMC_PLACEMENT_MAX_GIB", "unset"),
                        what="running moments in GiB slots of class A, sample arenas in ONE of the other two classes -- the one the card has at hand -- (a stream read beside writes into its own "
                             "class runs ~ 9 % slower on MI355X; the class travels with the physical memory -- most likely its HBM rank -- and is measured per GiB, 0.2 ms each)")
         except Exception as e:      # noqa: BLE001

@@ -159,7 +159,7 @@ int statmc_free(void *dev_ptr);   /* blocks of statmc_malloc and of statmc_mallo
  * card, mapped side by side a second time), freed with statmc_free, and otherwise ordinary device memory.  The first call on
  * a device reserves address space and probes GiB slots until both probe levels have been seen (tens of ms); a GiB slot that
  * holds no live block is idle again (either role may take it), slots of the classes a request cannot use stay backed and idle until
- * statmc_placement_trim.  The search for a class backs at most 2 x the bytes asked for on the device so far (+ 6 GiB;
+ * statmc_placement_trim.  The search for a class backs at most 3 x the bytes asked for on the device so far (+ 6 GiB;
  * STATMC_PLACEMENT_MAX_GIB=<GiB> sets another budget, never above 60 % of the card) and settles for the other classes after that.
  * Blocks are mapped for every device that can reach the owner as a peer (they are valid operands of statmc_copy_rect and
  * statmc_halo_exchange across devices; not IPC-shareable).  Where the probes show no contrast, the device has no virtual-memory management or memory runs short

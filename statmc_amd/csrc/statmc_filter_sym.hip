@@ -76,9 +76,6 @@ constexpr int kPrio = STATMC_SYM_PRIO;         // experiment (s_setprio)
 constexpr int kSplit = STATMC_SYM_SPLIT;       // window half 0 sweeps dx <= kSplit, half 1 the rest
 constexpr int kGSplitForced = STATMC_SYM_GSPLIT;    // -1: per build (gsplit_of below); 0: the window split at dx = kSplit (rounds 2 - 5); G > 0: every build
 constexpr bool kGroupSplitRT = STATMC_SYM_GSPLIT_RT != 0;   // the runtime-radius builds: split at a read-group boundary too
-constexpr unsigned kGMask = STATMC_SYM_GSPLIT_MASK;   // ... and the (tap pair, pixel) units of group kGSplit itself that half 0 takes (bit i * 4 + k: tap i, pixel k)
-constexpr int kHkHalf = STATMC_SYM_HK_HALF;    // experiment: the wave of a SIMD pair that does the housekeeping: 0 half 0, 1 half 1, 2 alternating
-constexpr bool kFlags = STATMC_SYM_FLAGS;      // experiment: per-wave progress words in LDS instead of the per-step barrier
 constexpr int kAblate = STATMC_SYM_ABLATE;     // timing only: 1 no q side, 2 no row staging, 4 no flush, 8 no sweep arithmetic, 16 no barrier
 // membership / buffer mode of a launch: one RGB buffer, every channel passes (default spec) | two float buffers
 // (filter<float>) | one RGB buffer, channels pooled (STATMC_CHANNELS_JOINT: sum_c fma(d_c, d_c, -(D_p,c + D_q,c)) <= 0,
@@ -175,10 +172,7 @@ struct Planes {
     static constexpr int kSlotFloats = (kIn + kQ) * kP;
     static constexpr int kRawTotal = W ? 0 : NG == 6 ? 4 * kWaveCols * 15 : kP * kIn;
     static constexpr int kBandTotal = W ? kWelchBand + 16 : 0;   // Welch: a band of the squared-quantile table + the item's {min n, max n}
-    // the spatial table in LDS: two rows (this step's and the next one's); the progress-word experiment (kFlags, six-plane builds
-    // only: the others have no room) holds all 21 rows + 16 progress words, since no barrier orders a refill
-    static constexpr bool kFl = kFlags && !W && NG == 6;
-    static constexpr int kTabFloats = kFl ? kSteps * kTabPad + 16 : 2 * kTabPad;
+    static constexpr int kTabFloats = 2 * kTabPad;   // the spatial table in LDS: two rows (this step's and the next one's)
     static constexpr size_t kLdsBytes = (size_t)(kSlots * kSlotFloats + kTabFloats + kRawTotal + kBandTotal) * sizeof(float);
     __host__ __device__ static inline int raw_off(int wave) { return W ? 0 : NG == 6 ? (wave & 3) * kWaveCols * 15 : wave_col0(wave & 3) * kIn; }
 };
@@ -821,19 +815,13 @@ __device__ __forceinline__ void eval_half_row(LaneT &st, const float *row, const
     }
     constexpr int kGSplit = gsplit_of(MODE, NG);
     if constexpr (kGSplit > 0) {   // the split at a read-group boundary (dy = 0: the pairs inside the row stay with half 1)
-        static_assert(kSplit == 0 && kGSplit < kChunks - 1 && (kGMask == 0 || (kGSplit >= 1 && kGMask < 0xFFFFu)), "one split experiment at a time; a shared group is a whole one");
+        static_assert(kSplit == 0 && kGSplit < kChunks - 1, "one split at a time");
         if (dy0) {
             if constexpr (HF == 0) sweep_range<0, 0, false, MODE, NG>(st, row, tab, qrow, tq2);
             else sweep_range<1, kR, true, MODE, NG>(st, row, tab, qrow, tq2);
         } else {
-            constexpr bool pipe = sym::kPipe && !mode_welch(MODE);
-            if constexpr (HF == 0) {
-                sweep_groups<0, kGSplit - 1, true, MODE, NG>(st, row, tab, qrow, tq2);
-                if constexpr (kGMask != 0) chunk<kGMask & 0xFFFFu, true, pipe, MODE, NG>(st, row, tab, qrow, kGSplit, tq2);
-            } else {
-                if constexpr (kGMask != 0) chunk<0xFFFFu & ~kGMask, true, pipe, MODE, NG>(st, row, tab, qrow, kGSplit, tq2);
-                sweep_groups<kGSplit + (kGMask != 0 ? 1 : 0), kChunks - 1, true, MODE, NG>(st, row, tab, qrow, tq2);
-            }
+            if constexpr (HF == 0) sweep_groups<0, kGSplit - 1, true, MODE, NG>(st, row, tab, qrow, tq2);
+            else sweep_groups<kGSplit, kChunks - 1, true, MODE, NG>(st, row, tab, qrow, tq2);
         }
         return;
     }
@@ -1166,27 +1154,10 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
     if constexpr (W) st.far = 0u;
 
     // wave-local staging geometry (DMA): this wave's columns of every staged row
-    // (experiments: FL = progress words instead of the barrier; kHkHalf: which wave of a SIMD pair keeps house)
-    constexpr bool FL = Planes<NG, W>::kFl && DMA && !RT;
-    constexpr bool kHkAtEnd = hk_at_end(MODE, NG) && !FL;   // (the progress-word experiment places its housekeeping itself)
-    static_assert(!(FL && kHkHalf != 0), "the progress-word build keeps house on the half-0 waves, after the sweep");
+    constexpr bool kHkAtEnd = hk_at_end(MODE, NG);
     float *raw_w = tab_lds + Planes<NG, W>::kTabFloats + Planes<NG, W>::raw_off(wave);
-    const int wcol0 = wave_col0(kHkHalf ? (wave & 3) : wave);          // first staged column (0..167) of the wave
-    const int ncols = wave_cols(kHkHalf ? (wave & 3) : wave);          // 44, 44, 40, 40, then none
-    auto hk_half = [&](int step) { return kHkHalf == 2 ? ((step - s_a) & 1) : kHkHalf; };   // the half that keeps house at a step
-    volatile int *const flg = reinterpret_cast<volatile int *>(tab_lds + kSteps * kTabPad);  // FL: [0..7] steps done per wave, [8..11] rows staged per staging wave
-    auto wait_for = [&](int word, int need) {   // (bounded: an experiment must not hang the card)
-        for (int spin = 0; spin < (1 << 13); spin++) {
-            if (flg[word] >= need) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-        asm volatile("" ::: "memory");
-    };
-    auto publish = [&](int word, int value) {   // after everything this wave has written to LDS so far
-        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
-        asm volatile("" ::: "memory");
-        if (lane == 0) flg[word] = value;
-    };
+    const int wcol0 = wave_col0(wave);                                 // first staged column (0..167) of the wave
+    const int ncols = wave_cols(wave);                                 // 44, 44, 40, 40, then none
     if (s_a < s_b) {
         if constexpr (W && mode_welch_far(MODE)) tq2 = WelchTab{a.tq2, nullptr, 0u, ~0u};
         if constexpr (W && !mode_welch_far(MODE)) {
@@ -1224,7 +1195,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             // (the barrier after the prologue's staging comes before the first look-up)
         }
         if constexpr (DMA) {   // the first row the sweep will need beyond the prologue: on its way during the prologue
-            if (s_a + 1 < s_b && !(kAblate & 2) && half == hk_half(s_a)) dma_row<NG>(a, F, raw_w, lane, x0 - kR + wcol0, y0 + s_a + kRows, ncols);
+            if (s_a + 1 < s_b && !(kAblate & 2)) dma_row<NG>(a, F, raw_w, lane, x0 - kR + wcol0, y0 + s_a + kRows, ncols);
         }
         // ---- prologue: rows rel = s_a .. s_a+7 (image rows y0 + rel) into slots rel % 9.  All of a thread's fetches
         // are issued before the first is staged: one memory latency per item instead of three.
@@ -1247,14 +1218,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
                 stage_store<NG, W>(lds + ((s_a + rr) % kSlots) * kSlotFloats, i, pro[it], F, !PAIR);
             }
         }
-        if constexpr (FL) {   // every row of the spatial table the item will use, and the progress words
-            for (int idx2 = threadIdx.x; idx2 < (s_b - s_a) * tw; idx2 += kThreads) {
-                const int rr = idx2 / tw, c = idx2 - rr * tw;
-                const float *t = stab + (s_a + rr) * tw + c;
-                *reinterpret_cast<v2f *>(tab_lds + rr * kTabPad + 2 * c) = v2f{t[0], c + 1 < tw ? t[1] : 0.f};
-            }
-            if (threadIdx.x < 16) flg[threadIdx.x] = 0;
-        } else if ((int)threadIdx.x < tw) {
+        if ((int)threadIdx.x < tw) {
             const float *t = stab + s_a * tw + threadIdx.x;
             *reinterpret_cast<v2f *>(tab_lds + 2 * threadIdx.x) = v2f{t[0], (int)threadIdx.x + 1 < tw ? t[1] : 0.f};
         }
@@ -1275,8 +1239,8 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             }
             // Once per step every wave (a) hands the accumulators of the row that went dead at the last barrier to the
             // patch, (b) turns the row fetched during the last step into a ring slot (the dead row's), and (c) starts
-            // the fetch of the row after it.  (Measured: doing it before the sweep in every wave beats both staggering
-            // the two waves of a SIMD -- 1.58 vs 1.51 ms -- and doing it after the sweep.)
+            // the fetch of the row after it -- before its sweep or after it, per build (hk_at_end: measured, round 6; staggering
+            // the two waves of a SIMD, the other wave of the pair, or both waves in turn were all slower: HISTORY.md 4.3 / 4.3d).
             auto housekeeping = [&]() {
                 const int dead = s - 1;
                 if (mine && dead >= q_first && y0 + dead >= 0 && !(kAblate & 4))
@@ -1296,21 +1260,11 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
                 }
             };
             if constexpr (kPrio == 2) { if (half == 0) __builtin_amdgcn_s_setprio(3); }
-            if constexpr (FL) {
-                // what this wave's step needs: the rows it sweeps were last touched, a step ago, by the wave that owns the next
-                // tile row (trow + 1: wave + 1 of the same window half; for wave 3, wave 0's upper half-wave), and trow 7's row
-                // was staged during the last step by the four staging waves
-                const int k = s - s_a;
-                wait_for(((wave + 1) & 3) + 4 * half, k);
-                if ((wave & 3) == 3) { wait_for(8, k); wait_for(9, k); wait_for(10, k); wait_for(11, k); }
-                if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_bar += t - tk0; tk0 = t; }
-            } else {
-                if (!DMA || (!kHkAtEnd && half == hk_half(s))) housekeeping();
-            }
+            if (!DMA || (!kHkAtEnd && half == 0)) housekeeping();
             if constexpr (kPrio == 2) { if (half == 0) __builtin_amdgcn_s_setprio(0); }
             if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_hk += t - tk0; tk0 = t; }
             const int ti = (int)threadIdx.x - (kThreads - 64);
-            const bool tstage = !FL && s + 1 < s_b && ti >= 0 && ti < tw;
+            const bool tstage = s + 1 < s_b && ti >= 0 && ti < tw;
             v2f tnext = v2f{0.f, 0.f};
             if (tstage) {
                 const float *t = stab + (s + 1) * tw + ti;
@@ -1320,7 +1274,7 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             float *slot = lds + ((s + trow) % kSlots) * kSlotFloats;   // per lane: the two halves of a wave differ
             const float *row = slot + kPx * lane32;
             float *qrow = slot + (kIn + 4 * half) * kP + kPx * lane32;
-            const float *tab = tab_lds + (FL ? s - s_a : (s - s_a) & 1) * kTabPad;
+            const float *tab = tab_lds + ((s - s_a) & 1) * kTabPad;
             if (kAblate & 8) {
             } else if (half == 0) {
                 eval_half_row<0, MODE, NG, RT>(st, row, tab, qrow, s == 0, j_lo, j_hi, tq2);
@@ -1329,29 +1283,14 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             }
 
             if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_ev += t - tk0; tk0 = t; }
-            if (DMA && kHkAtEnd && half == hk_half(s)) housekeeping();
+            if (DMA && kHkAtEnd && half == 0) housekeeping();
             if (tstage) *reinterpret_cast<v2f *>(tab_lds + ((s - s_a + 1) & 1) * kTabPad + 2 * ti) = tnext;
             if constexpr (!DMA) {
                 if (stage) stage_store<NG, W>(lds + ((s + kRows) % kSlots) * kSlotFloats, i, nxt, F, !PAIR);
             }
-            if constexpr (FL) {
-                const int k = s - s_a;
-                if (half == 0) {
-                    // the dead row (tile row 0 of the last step) must have been left by both waves that swept it
-                    if (k >= 1) { wait_for(0, k); wait_for(4, k); }
-                    housekeeping();
-                    publish(8 + wave, k + 1);
-                    if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_hk += t - tk0; tk0 = t; }
-                }
-                publish(wave, k + 1);
-            } else {
-                // (alternating housekeeping: the transfers this wave started are awaited by the OTHER wave of the pair next step)
-                if constexpr (DMA && kHkHalf == 2) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-                if (!(kAblate & 16)) __syncthreads();
-            }
+            if (!(kAblate & 16)) __syncthreads();
             if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_bar += t - tk0; tk0 = t; }
         }
-        if constexpr (FL) __syncthreads();   // (the product's last in-loop barrier: every sweep done before the ring is flushed)
         if constexpr (kStamps) {
             t_swept = __builtin_amdgcn_s_memtime();
             s_hk = c_hk; s_ev = c_ev; s_bar = c_bar;

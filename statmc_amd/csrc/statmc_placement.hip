@@ -32,7 +32,7 @@
 // time side by side in a second reserved range (one physical allocation may be mapped at several addresses, and the class is
 // the memory's, not the address's; blocks above 2 GiB) -- so a 6-GiB arena needs six class-B slots, not six in a row: on a card whose classes come
 // in short runs the first version backed 170 GiB to find three runs of six and still put an arena into class C.  Slots are
-// backed until there are enough OF THE WANTED CLASS or the search's byte budget is spent: 2 x what the device's callers have asked
+// backed until there are enough OF THE WANTED CLASS or the search's byte budget is spent: 3 x what the device's callers have asked
 // for so far (+ 6 GiB), or STATMC_PLACEMENT_MAX_GIB; never more than 60 % / 75 % of the card (round 6; until then the two card
 // fractions were the only bounds: 101 GiB backed to place 23).  After that the third class, then both, then anything.  Smaller blocks
 // are carved out of whole slots dealt to their role.  What no role uses stays mapped and idle until statmc_placement_trim gives it
@@ -191,15 +191,16 @@ size_t live_total(const Placement &P) {
     return b;
 }
 // How many slots the search for a CLASS may have backed, for a device whose callers hold `live_total` and now ask for `need` more:
-// STATMC_PLACEMENT_MAX_GIB if set (> 0), else 2 x the bytes asked for + 6 slots (the allocator's own two and what the calibration
-// needs to see both levels).  A third of a card's slots is of any one class, in runs of 4 .. 64: 2 x usually yields "state in A, arenas
-// in B and C" rather than "arenas in B alone" (0.82 against 0.84 of the HBM peak at 1080p / 256 spp; everything in one class: 0.76) --
-// the price of not backing three times the request -- and falls back to slots as they come only on a card whose first slots are
-// nearly all of the state's class (1.5 x did on one box of five: tests/test_placement_gpu.py).
+// STATMC_PLACEMENT_MAX_GIB if set (> 0), else 3 x the bytes asked for + 6 slots (the allocator's own two and what the calibration
+// needs to see both levels).  A third of a card's slots is of any one class, in runs of 4 .. 64, so 3 x is what ONE class for all the
+// arenas takes on average; what the search backs beyond the request is idle only until statmc_placement_trim.  Measured, 1080p /
+// 256 spp in the step: arenas in one class 0.805 of the HBM peak, spread over both classes apart from the moments' 0.77 (what budgets
+// of 1.5 x and 2 x gave on three boxes of five), in the moments' own class 0.72 (profiles/r06h_bench.json, r06w_bench_under_rocprof.json,
+// r06f_bench.json).
 size_t budget_slots(const Placement &P, size_t need) {
     static const double env_gib = [] { const char *e = getenv("STATMC_PLACEMENT_MAX_GIB"); return e ? atof(e) : 0.0; }();
     if (env_gib > 0.0) return (size_t)env_gib;
-    return (size_t)(2.0 * (double)(live_total(P) + need) / (double)kSlot + 0.999) + 6;
+    return (size_t)(3.0 * (double)(live_total(P) + need) / (double)kSlot + 0.999) + 6;
 }
 
 // grants the mapping at `at` to the owner and, where the runtime accepts it, to the peers (a block of this allocator is then a
@@ -637,7 +638,7 @@ int placed_alloc(Placement &P, int role, size_t bytes, void **out, bool may_back
     }
     // whole slots are dealt; the free list joins them with what the role already holds next to them
     const size_t want_slots = (need + kSlot - 1) / kSlot;
-    // how many slots the search for the right class may have backed: the byte budget (2 x what has been asked for, or
+    // how many slots the search for the right class may have backed: the byte budget (3 x what has been asked for, or
     // STATMC_PLACEMENT_MAX_GIB), and never more than 60 % of the card for the first choice, 75 % at all (the rest of the process --
     // the caller's other allocations, the runtime's -- needs room too; beyond that: what is backed already, any class)
     const size_t budget = may_back ? budget_slots(P, need) : 0;

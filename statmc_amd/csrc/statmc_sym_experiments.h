@@ -51,26 +51,14 @@
 #ifndef STATMC_SYM_GSPLIT
 #define STATMC_SYM_GSPLIT STATMC_SYM_GSPLIT_DEFAULT
 #endif
-// ... and the units of group G itself that half 0 takes besides (bit i * 4 + k = tap i against pixel k; a unit = a tap PAIR against
-// a pixel: 0x0033 two units, 0x00FF four, 0x33FF six): the split to a quarter of a group
-#ifndef STATMC_SYM_GSPLIT_MASK
-#define STATMC_SYM_GSPLIT_MASK 0
-#endif
 // the same group-aligned split in the runtime-radius builds (r < 20, Welch)
 #define STATMC_SYM_GSPLIT_RT_DEFAULT 1
 #ifndef STATMC_SYM_GSPLIT_RT
 #define STATMC_SYM_GSPLIT_RT STATMC_SYM_GSPLIT_RT_DEFAULT
 #endif
-// which wave of a SIMD pair does the per-step housekeeping (flush, staging, LDS-DMA): 0 = the half-0 wave (the older one; the
-// product), 1 = the half-1 wave, 2 = alternating by step
-#ifndef STATMC_SYM_HK_HALF
-#define STATMC_SYM_HK_HALF 0
-#endif
-// per-wave progress words in LDS instead of the per-step s_barrier: a wave waits only for the wave that last touched the rows it
-// is about to sweep (and, trow 7, for the staged row), housekeeping after the sweep; the whole spatial table lives in LDS
-#ifndef STATMC_SYM_FLAGS
-#define STATMC_SYM_FLAGS 0
-#endif
+// (Round 6 also built, measured and removed again -- source at commit e762ea4, logs profiles/r06_ab1.log .. r06_ab3.log, HISTORY.md 4.3d:
+// STATMC_SYM_HK_HALF, the housekeeping on the other / on alternating waves of a SIMD pair (slower); STATMC_SYM_FLAGS, per-wave progress
+// words in LDS instead of the per-step barrier (no change); STATMC_SYM_GSPLIT_MASK, a split finer than a read group (slower).)
 
 // timing-only ablations of the Welch gate (round 4): 1 = no table gather (a constant quantile), 2 = no NaN select on the
 // quotient, 4 = no quotient at all (nu = s^2): results are wrong with any bit set
@@ -81,8 +69,8 @@
 #define STATMC_SYM_DIAGNOSTIC_BITS                                                                                        \
     ((STATMC_SYM_ABLATE ? 1 : 0) | (STATMC_SYM_HK_END != STATMC_SYM_HK_END_DEFAULT ? 2 : 0) | (STATMC_SYM_PIPE ? 4 : 0) | (STATMC_SYM_STAMPS ? 8 : 0) | \
      (STATMC_SYM_SPLIT ? 16 : 0) | (STATMC_SYM_COUNT ? 32 : 0) | (STATMC_SYM_PRIO ? 64 : 0) | (STATMC_SYM_WELCH_ABLATE ? 256 : 0) | \
-     (STATMC_SYM_GSPLIT != STATMC_SYM_GSPLIT_DEFAULT ? 512 : 0) | (STATMC_SYM_HK_HALF ? 1024 : 0) | (STATMC_SYM_FLAGS ? 2048 : 0) | \
-     (STATMC_SYM_GSPLIT_MASK ? 4096 : 0) | (STATMC_SYM_GSPLIT_RT != STATMC_SYM_GSPLIT_RT_DEFAULT ? 8192 : 0))
+     (STATMC_SYM_GSPLIT != STATMC_SYM_GSPLIT_DEFAULT ? 512 : 0) | \
+     (STATMC_SYM_GSPLIT_RT != STATMC_SYM_GSPLIT_RT_DEFAULT ? 8192 : 0))
 
 #if defined(STATMC_PRODUCT_BUILD) && STATMC_SYM_DIAGNOSTIC_BITS != 0
 #error "a STATMC_SYM_* diagnostic switch is set in the product build (statmc_amd/build.py): it would ship a wrong or slower filter"
