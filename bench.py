@@ -1014,6 +1014,7 @@ def bring_up(args, rank, world, dev):
 
 def main():
     global torch, dist
+    t_process = time.perf_counter()
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -1437,6 +1438,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        result["bench_wall_s"] = round(time.perf_counter() - t_process, 1)      # this process, imports and every secondary leg included
         print(json.dumps(result), flush=True)
 
 
