@@ -464,7 +464,12 @@ hipError_t calibrate(Placement &P) {
             else if (t < kApartBelow * P.level) { n_apart++; if (!first_apart) first_apart = i; }
         }
         // (STATMC_PLACEMENT_FORCE_REBASE=1: tests -- the trade on a card that does not call for it)
-        if (first_apart && ((n_same >= 8 && n_same >= 3 * n_apart) || getenv("STATMC_PLACEMENT_FORCE_REBASE"))) err = rebase(P, first_apart);   // a clear long run, not a coin toss on four probes
+        if (first_apart && ((n_same >= 8 && n_same >= 3 * n_apart) || getenv("STATMC_PLACEMENT_FORCE_REBASE"))) {   // a clear long run, not a coin toss on four probes
+            err = rebase(P, first_apart);
+            // a trade that failed half-way may have left slot 0 without memory: no block exists yet, so the allocator simply retires
+            // on this device -- every later statmc_malloc_placed is a hipMalloc (init() answers with P.vmm)
+            if (err != hipSuccess) P.vmm = false;
+        }
     }
     if (err == hipSuccess) err = split_not_a(P);
     // The state's first home is slot 0 itself, behind the probe's 64-MiB window: every other slot is classified by what a stream of

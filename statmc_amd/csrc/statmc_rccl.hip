@@ -142,6 +142,24 @@ int statmc_rccl_comm_create(void **comm, int n_ranks, int rank, const void *id12
 }
 
 int statmc_rccl_comm_destroy(void *comm) {
+    {   // the column-halo staging buffers of the current device go with the communicator (they are per (device, stream), grown on demand)
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(g_stage_mu);
+            for (auto it = g_stage.begin(); it != g_stage.end();) {
+                if (it->first.first == dev) {
+                    if (it->second.ptr) {
+                        (void)hipStreamSynchronize(static_cast<hipStream_t>(it->first.second));
+                        (void)hipFree(it->second.ptr);
+                    }
+                    it = g_stage.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+        }
+        (void)hipGetLastError();
+    }
     if (!comm) return STATMC_OK;
     const Rccl &R = rccl();
     if (!R.ok) return statmc::abi_fail(STATMC_ERR_UNSUPPORTED, "RCCL: %s", R.why);

@@ -79,3 +79,25 @@ def test_peer_film_equals_whole_film(gpu, grid, bw, bh, g8, radius):
     finally:
         gpu.set_filter_split(0)
         gpu.set_filter_spec()
+
+
+def test_rccl_binds_at_run_time_and_makes_a_communicator(gpu):
+    """The C ABI's RCCL entry points on ONE device: the library has no link-time dependency on RCCL, binds the copy the process
+    already has (torch's) or librccl.so.1 on first use, and a one-rank communicator made through statmc_rccl_unique_id /
+    statmc_rccl_comm_create exists and goes away again; with one block there is nothing to exchange.  (Two ranks need two
+    devices: tests/test_multidevice_gpu.py::test_rccl_halo_exchange_through_the_c_abi.)"""
+    import ctypes as C
+    from statmc_amd.peer import Block
+    lib = gpu.load()
+    assert lib.statmc_rccl_available() == 1, gpu.load().statmc_last_error()
+    comm = gpu.RcclComm(1, 0, gpu.RcclComm.unique_id())
+    assert comm.handle.value
+    packed = torch.zeros(32, 48, 15, device=DEV)
+    gpu.halo_exchange_rccl(packed, 0, 1, 1, 48, 32, 20, comm)                 # 1 x 1 grid: returns at once
+    blk = Block()
+    blk.device, blk.packed, blk.stream = 0, gpu.image_of(packed), gpu.current_stream_handle()
+    # a grid the communicator does not match is refused before anything is sent
+    assert lib.statmc_halo_exchange_rccl(C.byref(blk), 1, 2, 48, 32, 20, comm.handle, 0) == gpu.ERR_INVALID
+    assert b"communicator" in lib.statmc_last_error()
+    torch.cuda.synchronize()
+    comm.destroy()
