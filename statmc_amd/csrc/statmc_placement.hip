@@ -36,7 +36,7 @@
 // for so far (+ 6 GiB), or STATMC_PLACEMENT_MAX_GIB; never more than 60 % / 75 % of the card (round 6; until then the two card
 // fractions were the only bounds: 101 GiB backed to place 23).  After that the third class, then both, then anything.  Smaller blocks
 // are carved out of whole slots dealt to their role.  What no role uses stays mapped and idle until statmc_placement_trim gives it
-// back to the driver (a host calls it once its buffers are dealt: bench.py, statmc::Estimator::AllocateBuffers).  No contrast between the probes, no
+// back to the driver (a host calls it once its buffers are dealt: bench.py after the warm-up, statmc::Estimator at its first Denoise).  No contrast between the probes, no
 // virtual-memory support, too little memory: the call degrades to slots as they come -- placement is an optimisation, never
 // a requirement -- and statmc_placement_info says so.  STATMC_PLACEMENT=0 turns the call into hipMalloc.
 

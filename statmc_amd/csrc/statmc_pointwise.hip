@@ -776,6 +776,7 @@ hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
         vec = vec && aligned16(t.samples) && aligned16(t.n) && aligned16(t.mean) &&
               (t.max_moment < 2 || aligned16(t.m2)) && (t.max_moment < 3 || aligned16(t.m3)) &&
               (!t.transform || (aligned16(t.film_mean) && aligned16(t.film_m2))) &&
+              (!t.mean_corr || (aligned16(t.mean_corr) && aligned16(t.disc))) &&      // the pre-pass epilogue's images
               (t.n_elems % 4 == 0) && (t.stride % 4 == 0);  // sample planes stay 16-B aligned
         const long long groups = (t.n_elems / t.channels + 3) / 4;
         if (groups > max_groups) max_groups = groups;
@@ -920,7 +921,8 @@ hipError_t launch_accumulate_tiles(const AccumulateTilesArgs &a_in, hipStream_t 
         const AccumulateType &t = a.t[i];
         vec = vec && aligned16(t.samples) && aligned16(t.n) && aligned16(t.mean) &&
               (t.max_moment < 2 || aligned16(t.m2)) && (t.max_moment < 3 || aligned16(t.m3)) &&
-              (!t.transform || (aligned16(t.film_mean) && aligned16(t.film_m2)));
+              (!t.transform || (aligned16(t.film_mean) && aligned16(t.film_m2))) &&
+              (!t.mean_corr || (aligned16(t.mean_corr) && aligned16(t.disc)));
     }
     a.vec = vec ? 1 : 0;
     const long long items = a.order == 2 ? (((long long)a.n_tiles + 3) >> 2) * 4 * a.n_types : (long long)a.n_tiles * a.n_types;
