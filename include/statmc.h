@@ -161,8 +161,8 @@ int statmc_free(void *dev_ptr);   /* blocks of statmc_malloc and of statmc_mallo
  * holds no live block is idle again (either role may take it), slots of the classes a request cannot use stay backed and idle until
  * statmc_placement_trim.  The search for a class backs at most 3 x the bytes asked for on the device so far (+ 6 GiB;
  * STATMC_PLACEMENT_MAX_GIB=<GiB> sets another budget, never above 60 % of the card) and settles for the other classes after that.
- * Blocks are mapped for every device that can reach the owner as a peer (they are valid operands of statmc_copy_rect and
- * statmc_halo_exchange across devices; not IPC-shareable).  Where the probes show no contrast, the device has no virtual-memory management or memory runs short
+ * Blocks are valid operands of statmc_copy_rect and statmc_halo_exchange across devices: the first copy between two devices grants the
+ * owner's blocks to the other device (hipMemSetAccess: hipDeviceEnablePeerAccess does not cover such memory); not IPC-shareable.  Where the probes show no contrast, the device has no virtual-memory management or memory runs short
  * the call still succeeds with memory as it comes (statmc_placement_info says so); STATMC_PLACEMENT=0 in the environment
  * makes it hipMalloc.  Not to be called while a kernel of the caller's runs (the probe competes for the memory system). */
 #define STATMC_MEM_STATE 0

@@ -897,6 +897,9 @@ static int enable_peer(int dst_device, int src_device) {
     (void)hipSetDevice(cur);
     if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(STATMC_ERR_HIP, "hipDeviceEnablePeerAccess: %s", hipGetErrorString(e));
     (void)hipGetLastError();
+    // ... and the blocks of src's placed allocator (hipMemCreate / hipMemMap memory, which the call above does not cover)
+    if (hipError_t pe = statmc::placement_grant_peer(src_device, dst_device); pe != hipSuccess)
+        return fail(STATMC_ERR_HIP, "hipMemSetAccess (placed blocks of device %d for device %d): %s", src_device, dst_device, hipGetErrorString(pe));
     done.emplace_back(dst_device, src_device);
     return STATMC_OK;
 }

@@ -235,6 +235,7 @@ int placement_role_of(const void *ptr);         // STATMC_MEM_STATE / _STREAM wh
 int placement_free(void *ptr);                  // 1: `ptr` was a statmc_malloc_placed block and is free now; 0: not the placed allocator's; -1: inside its ranges, not a live block's start
 hipError_t workspace_alloc(void **p, size_t bytes);   // the library's own read-and-written workspaces: STATE role where the device's caller uses placed memory, hipMalloc otherwise
 hipError_t workspace_free(void *p);
+hipError_t placement_grant_peer(int owner_device, int peer_device);   // blocks of `owner`'s placed allocator become valid operands of copies device `peer` executes
 // parts per tile the LDS kernel would use for this ROI on a device with n_cus compute units
 int lds_filter_parts(const FilterArgs &a, int n_cus);
 

@@ -117,8 +117,8 @@ struct Window {               // a block of whole slots mapped side by side in t
 struct Placement {
     bool init_tried = false, vmm = false, calibrated = false, no_contrast = false;
     hipMemAllocationProp prop;
-    std::vector<hipMemAccessDesc> access;    // the owning device first, then every device that can reach it as a peer
-    bool peers_granted = false;              // false: only the owner (hipMemSetAccess refused the peers, or there are none)
+    std::vector<hipMemAccessDesc> access;    // the owning device first, then the peers granted so far (placement_grant_peer)
+    bool peers_granted = false;              // false: only the owner (no cross-device copy yet, or hipMemSetAccess refused the peers)
     char *base = nullptr;                    // GiB-aligned start of the slots (inside the reservation)
     float *sink = nullptr;
     hipStream_t stream = nullptr;
@@ -326,17 +326,8 @@ bool init(Placement &P, int dev) {
     own.location = P.prop.location;
     own.flags = hipMemAccessFlagsProtReadWrite;
     P.access.assign(1, own);
-    // every device that can reach this one as a peer gets the mapping too: hipDeviceEnablePeerAccess -- all that statmc_copy_rect's
-    // enable_peer does -- does not cover memory made by hipMemCreate / hipMemMap
-    int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess) { (void)hipGetLastError(); n_dev = 0; }
-    for (int d = 0; d < n_dev; d++) {
-        int can = 0;
-        if (d == dev || hipDeviceCanAccessPeer(&can, d, dev) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
-        hipMemAccessDesc peer = own;
-        peer.location.id = d;
-        P.access.push_back(peer);
-    }
+    // (peers are added when a cross-device copy first needs them: placement_grant_peer.  Mapping every slot for every device of the
+    // node up front would put eight sets of page tables behind each GiB of every rank of a one-process-per-GPU run, for nothing.)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 4 * kSlot) return false;
     P.total_bytes = total_b;
@@ -738,6 +729,32 @@ int placed_alloc(Placement &P, int role, size_t bytes, void **out, bool may_back
 }  // namespace
 
 namespace statmc {
+
+// Blocks of `owner`'s placed allocator become operands of copies that device `peer` executes (statmc_copy_rect / statmc_halo_exchange
+// between two devices of one process: enable_peer in statmc_abi.hip calls this once per ordered pair).  hipDeviceEnablePeerAccess does
+// not cover memory made by hipMemCreate / hipMemMap: every backed slot and every window mapping is granted to `peer` here, and slots
+// backed later are mapped for the peers granted so far (set_access).  No allocator on `owner`, or no VMM: nothing to do.
+hipError_t placement_grant_peer(int owner, int peer) {
+    std::lock_guard<std::mutex> lk(g_place_mu);
+    auto it = g_place.find(owner);
+    if (it == g_place.end() || !it->second.vmm || owner == peer) return hipSuccess;
+    Placement &P = it->second;
+    for (const hipMemAccessDesc &d : P.access)
+        if (d.location.id == peer) return hipSuccess;
+    hipMemAccessDesc desc = P.access[0];
+    desc.location.id = peer;
+    for (size_t i = 0; i < P.slots.size(); i++) {
+        if (P.slots[i].role == kReleased) continue;
+        if (hipError_t e = hipMemSetAccess(P.base + i * kSlot, kSlot, &desc, 1); e != hipSuccess) return e;
+    }
+    for (size_t w = 0; w < P.win_slot.size(); w++) {
+        if (P.win_slot[w] < 0) continue;
+        if (hipError_t e = hipMemSetAccess(P.win_base + w * kSlot, kSlot, &desc, 1); e != hipSuccess) return e;
+    }
+    P.access.push_back(desc);
+    P.peers_granted = true;
+    return hipSuccess;
+}
 
 // The library's own workspaces (patch sums of the window filter, packed twins of pitched images) are written and read by
 // every launch: on a device whose caller uses placed memory they live with the STATE role, so that what the filter leaves
