@@ -714,6 +714,9 @@ static int window_filter_impl(const statmc_filter_args *a, int channels) {
     } else {
         k.n_parts = 1;
     }
+    // (the one-sided kernel's view of the call, before the pair-symmetric preparation below changes parts and workspace: an odd number
+    // of float buffers ends with three of them on that kernel -- see the loop)
+    const statmc::FilterArgs k_lds = k;
     // the pair-symmetric kernel (r = 20) also takes G-buffer sets the one-sided kernel has no slots for: two RGB + two
     // 1-channel images (normal, albedo, depth, material id)
     const bool sym = statmc::sym_path_selected(k, channels);
@@ -729,9 +732,21 @@ static int window_filter_impl(const statmc_filter_args *a, int channels) {
     }
     // float buffers share the range weight of a launch: two per launch on the pair-symmetric kernel, three on the
     // one-sided LDS kernel
-    const int group = (fast && channels == 1) ? (sym ? 2 : 3) : 1;
-    for (int b0 = 0; b0 < a->n_buffers; b0 += group) {
+    const int pair_group = (fast && channels == 1) ? (sym ? 2 : 3) : 1;
+    // An ODD number of float buffers (ACRR's five: estimator.cpp:434-460) would end with a launch of the pair-symmetric kernel that
+    // carries one buffer at the price of two (1.39 ms at 1080p).  Where the one-sided kernel can take the call as well -- it shares the
+    // range weight over THREE buffers, 2.47 ms -- the last three go to it: 5 buffers 1.40 + 2.47 instead of 1.40 + 1.40 + 1.39 ms
+    // (round 6).  Only with the whole window sweep in one part there (no partial-sum workspace to share with the patches) and no forced
+    // variant; the two kernels agree to 5e-7, each within 1e-5 of the oracle.
+    const bool mix = sym && channels == 1 && lds_ok && dstate.force_variant == 0 && (a->n_buffers & 1) && a->n_buffers >= 3 && k_lds.n_parts == 1 &&
+                     statmc::lds_path_selected(k_lds, channels);
+    statmc::FilterArgs k_tail = k_lds;
+    statmc::FilterArgs &k_pairs = k;
+    for (int b0 = 0, group = pair_group; b0 < a->n_buffers; b0 += group) {
         const char *variant = "none";
+        const bool tail = mix && a->n_buffers - b0 == 3;
+        if (tail) group = 3;
+        statmc::FilterArgs &k = tail ? k_tail : k_pairs;
         if (group > 1) {
             k.f_active = a->n_buffers - b0 < group ? a->n_buffers - b0 : group;
             if (!a->film || !a->film_filtered) return fail(STATMC_ERR_INVALID, "null film table");
@@ -753,6 +768,12 @@ static int window_filter_impl(const statmc_filter_args *a, int channels) {
                 if (k.f_out[j] == k.f_colour[j]) return fail(STATMC_ERR_INVALID, "filter cannot run in place (buffer %d)", b);
             }
             HIP_TRY(statmc::launch_window_filter(k, channels, S(a->stream), &variant));
+            // (a call that ran both kernels names both: "sym_r20_f+lds_r20_f")
+            if (tail && b0 > 0) {
+                static thread_local char both[96];
+                snprintf(both, sizeof(both), "%s+%s", g_variant, variant);
+                variant = both;
+            }
             g_variant = variant;
             g_last_parts = k.n_parts;
             continue;

@@ -1010,6 +1010,40 @@ def test_filter_float_multibuffer_fast_path(gpu, oracle, n_buffers, radius, vari
             assert rel_l2(args["film_filtered"][b].cpu().numpy(), refs[b]) <= TOL, (name, b)
 
 
+@pytest.mark.parametrize("n_buffers,variant", [(5, "sym_r20_f+lds_r20_f"), (3, "lds_r20_f"), (7, "sym_r20_f+lds_r20_f"), (4, "sym_r20_f"), (1, "sym_r20_f")])
+def test_filter_float_odd_buffer_counts_end_on_the_one_sided_kernel(gpu, oracle, n_buffers, variant):
+    """ACRR's five float buffers (estimator.cpp:434-460): an odd count would end with a pair-symmetric launch that carries one
+    buffer at the price of two; where the one-sided kernel sweeps the window in one part (films of 720p and up; here: the split
+    pinned to 1) the last THREE buffers go to it -- it shares the range weight over three.  Every buffer within TOL of the oracle
+    whichever kernel took it; an even count and a single buffer stay on the pair-symmetric kernel."""
+    W, H = 300, 31
+    _, smp, st = make_case(W, H, 8, seed=70 + n_buffers)
+    rng = np.random.default_rng(700 + n_buffers)
+    gbs = [st["normal"]["mean"], st["albedo"]["mean"]]
+    lum = smp["radiance"].mean(axis=3, keepdims=True)
+    refs, args = [], dict(n=[], mean=[], m2=[], m3=[], film=[], mean_corr=[], disc=[], film_filtered=[])
+    for b in range(n_buffers):
+        s = oracle.new_state(H, W, 1)
+        oracle.accumulate(s, np.ascontiguousarray(lum * np.float32(1.0 / (1 + b)) + rng.random(lum.shape, dtype=np.float32) * 0.01), True, 3)
+        mc, dc = oracle.prepass(s["n"], s["mean"], s["m2"], s["m3"])
+        refs.append(oracle.filter_image(mc, dc, s["film_mean"], gbs, G_DR, -0.5 / FILTER_SD ** 2, 20))
+        for k, v in (("n", s["n"]), ("mean", s["mean"]), ("m2", s["m2"]), ("m3", s["m3"]), ("film", s["film_mean"])):
+            args[k].append(to_dev(v))
+        for k in ("mean_corr", "disc", "film_filtered"):
+            args[k].append(torch.zeros(H, W, 1, device=DEV))
+    a, keep = gpu.make_filter_args(g_buffers=[to_dev(g) for g in gbs], g_sds=[SD_NORMAL, SD_ALBEDO], filter_sd=FILTER_SD, radius=20, **args)
+    gpu.set_filter_split(1)
+    try:
+        gpu.filter_f32(a)
+        torch.cuda.synchronize()
+        v = gpu.last_filter_variant()
+    finally:
+        gpu.set_filter_split(0)
+    assert v == variant
+    for b in range(n_buffers):
+        assert rel_l2(args["film_filtered"][b].cpu().numpy(), refs[b]) <= TOL, b
+
+
 @pytest.mark.parametrize("radius,border,g8", [(20, 0, False), (6, 1, False), (20, 0, True), (9, 1, True)], ids=["r20", "r6-clamp", "r20-eight-planes", "r9-clamp-eight-planes"])
 def test_filter_float_multibuffer_welch(gpu, oracle, radius, border, g8):
     """filter<float> under Welch degrees of freedom: three buffers with DIFFERENT sample counts (5, 9 and 2 400 samples; two

@@ -15,7 +15,7 @@ fs.accumulate(scene.samples(32, seed=2, features=("radiance", "normal", "albedo"
 fs.prepass()
 torch.cuda.synchronize()
 gbs = [fs.g_buffer("normal"), fs.g_buffer("albedo")]
-for nb in (1, 2, 5, 12):
+for nb in (1, 2, 3, 5, 7, 12):
     mc = [(fs.mean_corr[..., b % 3:b % 3 + 1] * (1.0 / (1 + b))).contiguous() for b in range(nb)]
     dc = [(fs.disc[..., b % 3:b % 3 + 1] * (1.0 / (1 + b)) ** 2).contiguous() for b in range(nb)]
     col = [(fs.state["radiance"]["film_mean"][..., b % 3:b % 3 + 1] * (1.0 / (1 + b))).contiguous() for b in range(nb)]
@@ -36,4 +36,4 @@ for nb in (1, 2, 5, 12):
         res[force] = (api.last_filter_variant(), e0.elapsed_time(e1) / 10, [o.clone() for o in out])
         api.force_filter_variant(0)
     err = max(float(((x - y).double().pow(2).sum() / y.double().pow(2).sum()).sqrt()) for x, y in zip(res[0][2], res[3][2]))
-    print("%2d buffers: %-10s %.3f ms   %-10s %.3f ms   max rel L2 between them %.2e" % (nb, res[0][0], res[0][1], res[3][0], res[3][1], err), flush=True)
+    print("%2d buffers: %-20s %.3f ms   %-10s %.3f ms   max rel L2 between them %.2e" % (nb, res[0][0], res[0][1], res[3][0], res[3][1], err), flush=True)
