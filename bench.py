@@ -819,7 +819,7 @@ def float_buffer_filter(fs, args, reps=6):
     rad = fs.state["radiance"]
     gbs = [fs.g_buffer(g) for g in fs.g_names]
     W, H, dev = fs.width, fs.height, fs.device
-    out = {}
+    out, variants = {}, {}
     for nb in (1, 2, 5, 12):
         mc = [(fs.mean_corr[..., b % 3:b % 3 + 1] * (1.0 / (1 + b))).contiguous() for b in range(nb)]
         dc = [(fs.disc[..., b % 3:b % 3 + 1] * (1.0 / (1 + b)) ** 2).contiguous() for b in range(nb)]
@@ -837,12 +837,13 @@ def float_buffer_filter(fs, args, reps=6):
         e1.record()
         torch.cuda.synchronize()
         out["%d_buffers_ms" % nb] = round(e0.elapsed_time(e1) / reps, 4)
-        variant = api.last_filter_variant()
+        variants["%d" % nb] = api.last_filter_variant()
         del mc, dc, col, outs
-    return dict(out, filter_variant=variant, acrr_5_buffers_ms=out["5_buffers_ms"], smis_12_buffers_ms=out["12_buffers_ms"],
+    return dict(out, filter_variant=variants["12"], filter_variant_by_count=variants, acrr_5_buffers_ms=out["5_buffers_ms"], smis_12_buffers_ms=out["12_buffers_ms"],
                 per_buffer_ms_at_12=round(out["12_buffers_ms"] / 12, 4),
                 what="window filter of n one-channel buffers in one call, back to back (pre-pass not included): the pair-symmetric kernel takes two "
-                     "buffers per launch; more behind one range weight do not fit the CU's LDS (DESIGN.md section 9 item 2)")
+                     "buffers per launch (more behind one range weight do not fit the CU's LDS: DESIGN.md section 9 item 2); an odd count ends with three "
+                     "buffers on the one-sided kernel, which shares the weight over three")
 
 
 def _relay_child(cmd, env, timeout_s):

@@ -85,6 +85,8 @@ int statmc_copy_device_settings(int src_device, int dst_device);
  * times: one 1080p RGB buffer, r = 20):
  *   every gate x channel rule x border, per-pixel dof, <= 2 RGB + <= 2 one-channel G-buffers   pair-symmetric LDS kernel   1.4 - 1.9 ms
  *   ... float buffers under the asymmetric / centre gate                                       one-sided LDS kernel        2.1 ms per 3 buffers
+ *   ... float buffers under the symmetric gate: two per launch (1.4 ms); an odd count >= 3     pair-symmetric + one-sided  ACRR's 5: 3.9 ms
+ *       ends with its last three on the one-sided kernel ("sym_r20_f+lds_r20_f", 2.5 ms)
  *   Welch dof (dof = 1), <= 2 RGB G-buffers, any channel rule / border, RGB or float buffers   pair-symmetric Welch build  3.5 ms (1.5 per float buffer)
  *   Welch dof x one-channel G-buffers (depth, material id), RGB or float buffers               eight-plane Welch build     4.2 ms (1.85 per float buffer); block +
  *                                                                                              halo images: the 18-channel layout
