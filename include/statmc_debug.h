@@ -47,6 +47,9 @@ int statmc_debug_interference_probe(const void *stream_ptr, size_t stream_bytes,
 /* The role of the statmc_malloc_placed block that holds `ptr` (any address inside it; window blocks included), -1 when `ptr` is
  * in none, the block was dealt without the wanted class, or the device tells no classes apart: what statmc_accumulate asks. */
 int statmc_debug_placement_role(const void *ptr);
+/* The placed allocator's fast level for a list of probe times against slot 0 (ms; <= 0 = not probed) and slot 0's probe against
+ * itself (0 = unknown): what its class thresholds are multiples of.  Pure arithmetic, no device call (tests/test_abi_cpu.py). */
+float statmc_debug_placement_fast_level(const float *probes_ms, int n, float self_ms);
 
 /* Non-zero: the library was built with a timing-only / diagnostic switch (statmc_sym_experiments.h); its results are
  * not the product's and statmc_amd.api refuses to load it. */

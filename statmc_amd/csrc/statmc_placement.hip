@@ -155,16 +155,33 @@ bool placement_disabled() {
 // genuine fast cluster (1.00 - 1.03 x) into the "between the levels" band and leave the allocator with slots it could not classify
 // (arenas dealt as they came, or no contrast seen within 96 slots: three processes in a row on one box, 0.81 | 0.74 | 0.77 of the
 // HBM peak, profiles/r06_bench_d_*.json).  With fewer than three probes: the smallest.
-float fast_level(const Placement &P) {
+// ... of the probes of the FAST cluster, where slot 0 against itself (self_ms: the level of "same class" by construction) tells which
+// those are: the calibration may end on two slots clearly faster than self_ms, and with one fast slot followed by a run of slot 0's
+// class (a card that hands out 0.177 | 0.195 x 6 | ... | 0.177) the third-smallest probe of ALL is a slow one -- against that level
+// every slot probes "apart from slot 0", the run of slot 0's class is dealt to the first arena, and once more fast probes have
+// arrived the same slots read class A: six of the arenas' 22 GiB in the moments' class, 0.746 of the HBM peak where torch's
+// allocator got 0.764 (profiles/r06_bench_x.json: map "##AAAAAA___CCCCCCCCCC___CCCCCC").
+float fast_level_of(const float *probes, size_t n, float self_ms) {
     float a = 1e30f, b = 1e30f, c = 1e30f;   // the three smallest, ascending
-    for (size_t i = 1; i < P.slots.size(); i++) {
-        const float t = P.slots[i].probe_ms[0];
-        if (t <= 0.f) continue;
-        if (t < a) { c = b; b = a; a = t; }
-        else if (t < b) { c = b; b = t; }
-        else if (t < c) c = t;
+    for (int pass = 0; pass < 2; pass++) {
+        a = b = c = 1e30f;
+        for (size_t i = 0; i < n; i++) {
+            const float t = probes[i];
+            if (t <= 0.f) continue;
+            if (pass == 0 && !(self_ms > 0.f && t * kContrast < self_ms)) continue;   // first: the probes clearly below "same class"
+            if (t < a) { c = b; b = a; a = t; }
+            else if (t < b) { c = b; b = t; }
+            else if (t < c) c = t;
+        }
+        if (a < 1e30f) break;               // (no probe below self_ms -- or no self_ms: every probe counts, as before)
     }
-    return c < 1e30f ? c : a < 1e30f ? a : 0.f;
+    return c < 1e30f ? c : a < 1e30f ? a : 0.f;   // (fewer than three: the smallest -- the calibration waits for the third)
+}
+float fast_level(const Placement &P) {
+    std::vector<float> t;
+    t.reserve(P.slots.size());
+    for (size_t i = 1; i < P.slots.size(); i++) t.push_back(P.slots[i].probe_ms[0]);
+    return fast_level_of(t.data(), t.size(), P.self_ms);
 }
 
 int classify(const Placement &P, const Slot &s) {
@@ -202,6 +219,21 @@ size_t budget_slots(const Placement &P, size_t need) {
     static const double env_gib = [] { const char *e = getenv("STATMC_PLACEMENT_MAX_GIB"); return e ? atof(e) : 0.0; }();
     if (env_gib > 0.0) return (size_t)env_gib;
     return (size_t)(3.0 * (double)(live_total(P) + need) / (double)kSlot + 0.999) + 6;
+}
+
+// hipMemUnmap leaves the shaders' translation of the range in place on this runtime (ROCm 7.2, gfx950): a different allocation mapped
+// at an address another one has just left is NOT what kernels see there -- they go on reading and writing the memory that left, even
+// after it has gone back to the driver -- until something makes the driver rewrite the process's page tables the ordinary way.  An
+// allocation made and freed with hipMalloc / hipFree between the unmap and the next map does (tools/microbench/vmm_remap.hip,
+// profiles/r06_vmm_remap.log: scenarios 0 - 8; a synchronisation, a kernel or giving the address range back and reserving it again do
+// not).  Called after every batch of unmaps, before any of the addresses can be mapped again: the reference slot's trade (which had
+// never taken effect: profiles/r06_rebase_check.log), statmc_placement_trim (holes are filled again), windows (their slots of the
+// window range are used again).
+hipError_t flush_translations() {
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, 2u << 20);
+    if (e == hipSuccess) e = hipFree(p);
+    return e;
 }
 
 // grants the mapping at `at` to the owner and, where the runtime accepts it, to the peers (a block of this allocator is then a
@@ -363,17 +395,35 @@ bool init(Placement &P, int dev) {
 void add_free(std::map<size_t, size_t> &fl, size_t off, size_t len);
 
 hipError_t probe_self(Placement &P);
+// (diagnostic, STATMC_PLACEMENT_DEBUG: do the shaders see the traded memory at the old addresses?)
+__global__ void poke_pair_kernel(unsigned *a, unsigned va, unsigned *b, unsigned vb) { a[0] = va; b[0] = vb; }
+__global__ void peek_pair_kernel(const unsigned *a, const unsigned *b, unsigned *out) { out[0] = a[0]; out[1] = b[0]; }
 // Slot k's memory becomes the reference: the two physical allocations trade addresses, every probe is taken again (calibrate)
 hipError_t rebase(Placement &P, size_t k) {
     if (hipError_t e = hipStreamSynchronize(P.stream); e != hipSuccess) return e;
     char *a0 = P.base, *ak = P.base + k * kSlot;
+    // (a word poked into both slots before the trade and read back through both addresses after it: the trade is checked, not assumed)
+    hipLaunchKernelGGL(poke_pair_kernel, dim3(1), dim3(1), 0, P.stream, reinterpret_cast<unsigned *>(a0 + kSlot - 64), 0xA0A0u,
+                       reinterpret_cast<unsigned *>(ak + kSlot - 64), 0xB0B0u);
+    if (hipError_t e = hipStreamSynchronize(P.stream); e != hipSuccess) return e;
     if (hipError_t e = hipMemUnmap(a0, kSlot); e != hipSuccess) return e;
     if (hipError_t e = hipMemUnmap(ak, kSlot); e != hipSuccess) return e;
+    if (hipError_t e = flush_translations(); e != hipSuccess) return e;
     std::swap(P.slots[0].handle, P.slots[k].handle);
     for (char *at : {a0, ak}) {
         const size_t i = at == a0 ? 0 : k;
         if (hipError_t e = hipMemMap(at, kSlot, 0, P.slots[i].handle, 0); e != hipSuccess) return e;
         if (hipError_t e = set_access(P, at); e != hipSuccess) return e;
+    }
+    {
+        unsigned host[2] = {0u, 0u};
+        hipLaunchKernelGGL(peek_pair_kernel, dim3(1), dim3(1), 0, P.stream, reinterpret_cast<const unsigned *>(a0 + kSlot - 64),
+                           reinterpret_cast<const unsigned *>(ak + kSlot - 64), reinterpret_cast<unsigned *>(P.sink));
+        if (hipError_t e = hipStreamSynchronize(P.stream); e != hipSuccess) return e;
+        if (hipError_t e = hipMemcpy(host, P.sink, 8, hipMemcpyDeviceToHost); e != hipSuccess) return e;
+        if (getenv("STATMC_PLACEMENT_DEBUG"))
+            fprintf(stderr, "statmc placement: after the trade slot 0 reads %#x (0xb0b0 = slot %zu's memory), slot %zu reads %#x\n", host[0], k, k, host[1]);
+        if (host[0] != 0xB0B0u || host[1] != 0xA0A0u) return hipErrorUnknown;   // the shaders still see the old memory: no trade (the caller retires the allocator)
     }
     if (hipError_t e = hipMemsetAsync(P.base, 0, kProbeWindow, P.stream); e != hipSuccess) return e;
     if (P.target2 >= 0) {                       // (not chosen yet at this point; for completeness)
@@ -421,7 +471,7 @@ hipError_t calibrate(Placement &P) {
     while (!P.calibrated) {
         // both levels on at least two slots each (one noisy probe -- a clock ramp, somebody else's kernel -- must not
         // invent a class)
-        // ... or two slots clearly faster than slot 0 against itself (probe_self)
+        // ... or three slots clearly faster than slot 0 against itself (probe_self)
         int n_fast = 0, n_slow = 0, n_below_self = 0;
         for (size_t i = 1; i < P.slots.size(); i++) {
             const float t = P.slots[i].probe_ms[0];
@@ -430,7 +480,8 @@ hipError_t calibrate(Placement &P) {
             n_slow += t > kContrast * P.level ? 1 : 0;
             n_below_self += t * kContrast < P.self_ms ? 1 : 0;
         }
-        if ((n_fast >= 2 && n_slow >= 2) || n_below_self >= 2) {
+        // (three of the fast level, so that its third-smallest probe -- fast_level -- IS one of them)
+        if ((n_fast >= 3 && n_slow >= 2) || n_below_self >= 3) {
             P.calibrated = true;
         } else if (P.n_probes >= kCalibrationCap || !back_next_slot(P, &err, 8ull << 30)) {
             P.calibrated = true;
@@ -594,6 +645,7 @@ int window_alloc(Placement &P, int role, size_t bytes, size_t want, unsigned mas
         }
         if (e != hipSuccess) {
             for (size_t j = 0; j < k; j++) (void)hipMemUnmap(P.win_base + (first + j) * kSlot, kSlot);
+            if (k > 0) (void)flush_translations();
             (void)hipGetLastError();
             return statmc::abi_fail(STATMC_ERR_HIP, "placement: mapping a slot into a window: %s", hipGetErrorString(e));
         }
@@ -818,11 +870,10 @@ int placement_free(void *ptr) {
         Placement &P = kv.second;
         if (auto w = window_of(P, ptr); w != P.windows.end()) {
             if (P.win_base + w->first != (char *)ptr) return -1;   // inside a window, not its start: nothing to do (and not hipFree's either)
-            int cur = 0;
+            int cur = -1;
             if (hipGetDevice(&cur) == hipSuccess) {
                 if (cur != kv.first) (void)hipSetDevice(kv.first);
                 (void)hipDeviceSynchronize();
-                if (cur != kv.first) (void)hipSetDevice(cur);
             }
             for (size_t k = 0; k < w->second.n; k++) {                // the slots keep their memory and their class: undealt again
                 const size_t ws = w->second.first + k;
@@ -833,6 +884,8 @@ int placement_free(void *ptr) {
                 s.window = -1;
                 P.win_slot[ws] = -1;
             }
+            (void)flush_translations();        // before these slots of the window range serve another block (on the block's own device)
+            if (cur >= 0 && cur != kv.first) (void)hipSetDevice(cur);
             P.windows.erase(w);
             return 1;
         }
@@ -873,7 +926,14 @@ int statmc_malloc_placed(void **dev_ptr, size_t bytes, int role) {
         *dev_ptr = p;
         return STATMC_OK;
     }
-    return placed_alloc(P, role, bytes, dev_ptr);
+    const int rc = placed_alloc(P, role, bytes, dev_ptr);
+    if (rc != STATMC_OK && !P.vmm) {                       // the allocator retired during this very call (a trade that did not take): plain memory
+        void *p = nullptr;
+        if (hipError_t e = hipMalloc(&p, bytes); e != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
+        *dev_ptr = p;
+        return STATMC_OK;
+    }
+    return rc;
 }
 
 int statmc_placement_info(statmc_placement_info_t *out) {
@@ -916,6 +976,9 @@ int statmc_placement_info(statmc_placement_info_t *out) {
 // Test hook: what statmc_accumulate learns about a buffer -- the role of the placed block `ptr` lies in (any address inside it),
 // -1 when it is not one, was dealt without the wanted class, or the device tells no classes apart
 int statmc_debug_placement_role(const void *ptr) { return statmc::placement_role_of(ptr); }
+float statmc_debug_placement_fast_level(const float *probes_ms, int n, float self_ms) {
+    return probes_ms && n > 0 ? fast_level_of(probes_ms, (size_t)n, self_ms) : 0.f;
+}
 
 // Test / experiment hook (include/statmc_debug.h): the allocator's probe on memory of the caller's -- streams `stream_bytes` at
 // `stream_ptr` while every fourth step read-modify-writes 16 bytes inside [rmw_ptr, rmw_ptr + rmw_bytes) (their values change: + 1 in
@@ -968,6 +1031,7 @@ int statmc_placement_trim(void) {
         s.role = kReleased;
         n++;
     }
+    if (n > 0) (void)flush_translations();     // before a hole can be filled again
     return n;
 }
 

@@ -263,3 +263,41 @@ def test_switch_off_is_plain_hipmalloc():
             "print('ok')\n" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, STATMC_PLACEMENT="0"))
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-800:]
+
+
+def test_a_window_at_addresses_another_window_left_reaches_its_own_memory():
+    """ROCm 7.2 / gfx950: after hipMemUnmap the shaders keep the old translation of the range until the driver rewrites the page tables
+    the ordinary way (tools/microbench/vmm_remap.hip) -- a window block mapped at the addresses a freed window left used to read and
+    write the FREED window's slots, which by then belong to somebody else.  The allocator now forces that rewrite after every batch of
+    unmaps.  Here: a three-slot window over slots that do not lie side by side is freed, a one-slot block takes its first slot, a second
+    window lands at the first one's addresses over other slots -- and the two live blocks must not share a byte
+    (tools/experiments/window_reuse_check.py, profiles/r06_window_reuse.log: the library before the fix leaves 268 M wrong values)."""
+    code = ("import torch, sys; sys.path.insert(0, %r)\n"
+            "from statmc_amd import api\n"
+            "api.setup(0)\n"
+            "dev = torch.device('cuda:0')\n"
+            "G = 1 << 28\n"
+            "x = [api.empty_placed((G,), torch.float32, dev, api.MEM_STREAM) for _ in range(6)]\n"
+            "for k in (0, 2, 4): x[k] = None\n"
+            "a = api.empty_placed((3 * G,), torch.float32, dev, api.MEM_STREAM)\n"
+            "a.fill_(1.0); pa = a.data_ptr()\n"
+            "torch.cuda.synchronize()\n"
+            "del a\n"
+            "b = api.empty_placed((G,), torch.float32, dev, api.MEM_STREAM)\n"
+            "c = api.empty_placed((3 * G,), torch.float32, dev, api.MEM_STREAM)\n"
+            "same_addresses = c.data_ptr() == pa\n"
+            "b.fill_(2.0); c.fill_(3.0)\n"
+            "torch.cuda.synchronize()\n"
+            "for t, v in ((b, 2.0), (c, 3.0)):\n"
+            "    for k in range(0, t.numel(), G // 2):\n"
+            "        part = t[k:k + G // 2]\n"
+            "        assert float(part.min().item()) == v and float(part.max().item()) == v, (v, k, float(part.min().item()), float(part.max().item()))\n"
+            "n = api.load().statmc_placement_trim()\n"
+            "d = api.empty_placed((3 * G,), torch.float32, dev, api.MEM_STREAM)\n"
+            "d.fill_(4.0)\n"
+            "torch.cuda.synchronize()\n"
+            "for t, v in ((b, 2.0), (c, 3.0), (d, 4.0)):\n"
+            "    assert float(t[::4099].min().item()) == v and float(t[::4099].max().item()) == v, v\n"
+            "print('ok', same_addresses, n, api.placement_info()['map'])\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr[-2000:]
