@@ -165,26 +165,27 @@ def test_stale_library_is_refused(lib, tmp_path, monkeypatch):
         api.load()
 
 
-def test_placement_fast_level_is_taken_from_the_fast_cluster(lib):
+def test_placement_fast_level_is_the_bottom_of_a_tight_cluster(lib):
     """The level the placed allocator's class thresholds are multiples of (statmc_placement.hip: fast_level_of; pure arithmetic, no
-    device).  The card of profiles/r06_bench_x.json handed out one slot apart from slot 0, then six of slot 0's class, then the rest:
-    the third-smallest probe of ALL slots was a slow one at the moment the first arena was dealt, every slot read "apart from slot 0"
-    and the arena took the six slots of the moments' class.  With slot 0's probe against itself as the witness of "same class" the
-    level comes from the probes clearly below it."""
+    device): the smallest probe with two companions within 2 %.  Three cards this round broke simpler rules -- one probe a few per
+    cent too fast (the smallest alone), one fast slot followed by six of slot 0's class (the third-smallest of all: a slow one, every
+    slot read "apart from slot 0": profiles/r06_bench_x.json), slots that straddle two classes at 1.045 x the fast level (the
+    third-smallest of the probes below slot 0's own)."""
     import ctypes as C
     f = lib.statmc_debug_placement_fast_level
     f.restype = C.c_float
     f.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_float]
 
-    def level(probes, self_ms):
-        arr = (C.c_float * len(probes))(*probes)
+    def level(probes, self_ms=0.2):
+        arr = (C.c_float * max(1, len(probes)))(*probes)
         return round(float(f(arr, len(probes), C.c_float(self_ms))), 4)
 
-    slow, fast, self_ms = 0.195, 0.177, 0.196
-    assert level([fast] + [slow] * 6, self_ms) == fast                      # one fast slot so far: that one
-    assert level([fast] + [slow] * 6 + [0.178], self_ms) == fast            # two: the smaller (the calibration waits for a third)
-    assert level([fast] + [slow] * 6 + [0.178, 0.179], self_ms) == 0.179    # three: the third-smallest OF THE FAST ONES
-    assert level([0.170, fast, 0.178, 0.179] + [slow] * 9, self_ms) == 0.178   # one probe a few per cent too fast does not set the level
-    assert level([slow, 0.194, 0.196], self_ms) == 0.196                    # nothing below "same class" yet: every probe counts
-    assert level([fast, slow, 0.0, slow], 0.0) == 0.195                     # no witness: the third-smallest of all, as before (0 = not probed)
-    assert level([], self_ms) == 0.0
+    slow, fast = 0.195, 0.177
+    assert level([fast] + [slow, 0.194, 0.1955]) == 0.194                   # no fast cluster yet: the tight cluster is the slow one (no contrast to it: the calibration goes on)
+    assert level([fast, 0.178] + [slow] * 2) == 0.0                          # two fast slots, two slow: no three within 2 % anywhere
+    assert level([fast, 0.178, 0.179] + [slow] * 6) == fast                  # three: the bottom of the cluster
+    assert level([0.170, fast, 0.178, 0.179] + [slow] * 9) == fast           # one probe a few per cent too fast has no companions
+    assert level([0.1927, 0.1962, 0.1949, 0.1943, 0.1914, 0.1886, 0.1909, 0.1890, 0.1805]) == 0.1886   # (gpurun_out r06_bench_z3, slots 1 - 14: straddling slots ...)
+    assert level([0.1927, 0.1962, 0.1949, 0.1886, 0.1890, 0.1805, 0.1886, 0.1815, 0.1800, 0.1808]) == 0.18   # ... until the fast cluster is there)
+    assert level([fast, slow, 0.0, slow]) == 0.0                             # (0 = not probed)
+    assert level([]) == 0.0

@@ -11,4 +11,4 @@ p=d["placement"]; ab=d.get("accumulate_placement_ab",{})
 print("$tag", d["value"], d["roofline"]["frac"], "ab placed/unplaced", ab.get("placed_frac_hbm"), ab.get("unplaced_frac_hbm"), p["map"], p["probes"], p["peak_slots"], p["rebased"], flush=True)
 PY
 }
-run z1 A=1 && run z2 STATMC_PLACEMENT_NO_REBASE=1 && run z3 A=1
+run ${TAG:-z}1 A=1 && run ${TAG:-z}2 A=1 && run ${TAG:-z}3 A=1
