@@ -124,6 +124,10 @@ def parse():
     ap.add_argument("--no-placement", dest="placement", action="store_false",
                     help="running moments and sample arenas from torch's allocator (default: statmc_malloc_placed -- the moments in one "
                          "interference class of the card's memory, the arenas in another: include/statmc.h)")
+    ap.add_argument("--no-placement-check", dest="placement_check", action="store_false",
+                    help="N = 1: keep the placed buffers whatever they measure (default: before the warm-up the step is run a few times on the "
+                         "placed buffers and on copies from torch's allocator, and the timed region uses the faster set -- a card whose GiB slots "
+                         "mostly straddle interference classes gives the allocator nothing to choose from; the line says which set ran and both times)")
     args = ap.parse_args()
     if args.film:
         args.width, args.height = (int(v) for v in args.film.lower().split("x"))
@@ -689,6 +693,47 @@ def accumulate_unplaced_ab(fs, samples, types, reps=6):
             "buffers against torch-allocated copies of the same bytes, same process" % reps}
 
 
+def placement_check(args, pipe, samples, types, layout, dev, make_pipe, reps=4):
+    """Placement is an optimisation that can come out behind (a card whose slots mostly straddle classes): before the
+    warm-up the step -- accumulate, pre-pass, filter, as in the timed region -- runs `reps` times on the placed buffers and on copies that
+    come from torch's allocator, and the faster set (by the accumulation's median, > 1 %) goes on.  Returns (pipe, samples, report)."""
+    need = sum(v.numel() * 4 for v in samples.values())
+    free_b = torch.cuda.mem_get_info(dev)[0]
+    if free_b < need + (12 << 30):
+        return pipe, samples, {"skipped": "not enough free memory for an unplaced copy of the sample pool (%.0f GiB free)" % (free_b / 2 ** 30)}
+
+    def acc_ms(p, smp):
+        p.fs.reset()
+        runs = []
+        for i in range(reps + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            p.accumulate(smp)
+            e1.record()
+            p.prepass()
+            p.window_filter()
+            torch.cuda.synchronize()
+            if i:
+                runs.append(e0.elapsed_time(e1))
+        p.fs.reset()
+        return sorted(runs)[len(runs) // 2]
+    placed_ms = acc_ms(pipe, samples)
+    pipe_u = make_pipe(False)
+    smp_u = {t: torch.empty(v.shape, dtype=torch.float32, device=dev) for t, v in samples.items()}
+    for t in types:
+        smp_u[t].copy_(samples[t])
+    unplaced_ms = acc_ms(pipe_u, smp_u)
+    report = {"placed_ms": round(placed_ms, 4), "allocator_ms": round(unplaced_ms, 4),
+              "what": "the step (accumulate, pre-pass, filter) %d times on each set before the warm-up, median of the accumulation; the faster set (> 1 %%) runs the timed region" % reps}
+    if unplaced_ms < 0.99 * placed_ms:
+        report["chosen"] = "torch's allocator"
+        return pipe_u, smp_u, report
+    report["chosen"] = "placed"
+    del pipe_u, smp_u
+    torch.cuda.empty_cache()
+    return pipe, samples, report
+
+
 def bind_to_gpu_numa(dev_index):
     """Keep the rank on the CPUs of the NUMA node its GPU hangs off (host-side issue latency, pinned staging buffers)."""
     try:
@@ -1125,8 +1170,20 @@ def main():
         PLACED.update(on=False, error=str(e)[-300:])
         pipe = pipeline.BlockPipeline(layout, dev, types, filter_sd=args.filtersd, radius=r, via_host=args.backend == "gloo",
                                       fused_prepass=args.fused_prepass)
-    fs = pipe.fs
     samples, pool = block_samples(args, layout, dev, types, rank, world, share=world if args.share_device else 1)
+    if PLACED["on"] and world == 1 and args.placement_check and pool == S:
+        make_pipe = lambda placed: pipeline.BlockPipeline(layout, dev, types, filter_sd=args.filtersd, radius=r, via_host=False,
+                                                          placed=placed, fused_prepass=args.fused_prepass)
+        pipe_c, samples_c, PLACED["check"] = placement_check(args, pipe, samples, types, layout, dev, make_pipe)
+        if pipe_c is not pipe:          # the allocator's memory measured faster here: the placed blocks go, and their slots with them
+            pipe, samples = pipe_c, samples_c
+            PLACED.update(on=False, error=None)
+            try:
+                PLACED["trimmed"] = api.placement_trim()
+            except api.StatmcError as e:
+                PLACED["trim_error"] = str(e)[-200:]
+        del pipe_c, samples_c
+    fs = pipe.fs
     batches = synthetic.sample_schedule(S) if args.schedule == "reference" else [S]
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -1446,7 +1503,7 @@ def main():
 def block_samples(args, layout, dev, types, rank, world, share=1):
     """The resident sample pool of block `rank` on `dev`, generated in place (seeded: the same stream whichever backend
     drives the block).  share = blocks that share the device's memory."""
-    from statmc_amd import synthetic
+    from statmc_amd import api, synthetic
     W, H = layout.bw, layout.bh
     fw, fh = layout.film_size
     ox, oy = layout.origin
@@ -1464,6 +1521,8 @@ def block_samples(args, layout, dev, types, rank, world, share=1):
     samples = None
     if PLACED["on"]:
         try:
+            # (the arenas' total, announced: ONE class is then searched for all of them, not arena by arena)
+            api.placement_expect(api.MEM_STREAM, sum(4 * pool * H * W * synthetic.CHANNELS[t] for t in types), dev)
             samples = {t: new_arena((pool, H, W, synthetic.CHANNELS[t]), dev) for t in types}
         except Exception as e:      # noqa: BLE001  (placement is an optimisation: report and go on without)
             PLACED.update(on=False, error="%s: %s" % (type(e).__name__, str(e)[-300:]))
@@ -1496,7 +1555,17 @@ def read_clock_slots(slots, idx):
 
 def placement_report():
     """Where the timed step's buffers came from (include/statmc.h: statmc_malloc_placed)."""
-    out = {"requested": PLACED["on"] or PLACED["error"] is not None, "error": PLACED["error"]}
+    out = {"requested": PLACED["on"] or PLACED["error"] is not None or "check" in PLACED, "error": PLACED["error"]}
+    if "check" in PLACED:
+        out["check"] = PLACED["check"]
+        out["timed_region_ran_on"] = "placed blocks" if PLACED["on"] else "torch's allocator"
+        if not PLACED["on"]:
+            out["map_after_release"] = None
+            try:
+                from statmc_amd import api
+                out["map_after_release"] = api.placement_info()["map"]
+            except Exception:      # noqa: BLE001
+                pass
     if PLACED["on"]:
         try:
             from statmc_amd import api

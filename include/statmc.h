@@ -166,10 +166,18 @@ int statmc_free(void *dev_ptr);   /* blocks of statmc_malloc and of statmc_mallo
  * Blocks are valid operands of statmc_copy_rect and statmc_halo_exchange across devices: the first copy between two devices grants the
  * owner's blocks to the other device (hipMemSetAccess: hipDeviceEnablePeerAccess does not cover such memory); not IPC-shareable.  Where the probes show no contrast, the device has no virtual-memory management or memory runs short
  * the call still succeeds with memory as it comes (statmc_placement_info says so); STATMC_PLACEMENT=0 in the environment
- * makes it hipMalloc.  Not to be called while a kernel of the caller's runs (the probe competes for the memory system). */
+ * makes it hipMalloc.  Not to be called while a kernel of the caller's runs (the probe competes for the memory system).
+ * (ROCm 7.2 / gfx950: hipMemUnmap leaves the shaders' address translation in place -- memory mapped at an address that was mapped
+ * before is not what kernels see until the driver rewrites the page tables; the allocator forces that after every unmap, so addresses
+ * it uses again -- windows, filled holes -- reach their own memory: tools/microbench/vmm_remap.hip) */
 #define STATMC_MEM_STATE 0
 #define STATMC_MEM_STREAM 1
 int statmc_malloc_placed(void **dev_ptr, size_t bytes, int role);
+/* Announces how many bytes the caller is about to ask for in `role` on the current device, in however many blocks: the class search of
+ * those calls is budgeted -- and, for STATMC_MEM_STREAM, the arenas' class chosen -- for all of them at once (arena by arena the first
+ * 6-GiB arena settles for whichever class has six slots at hand and the later ones for what is left: arenas spread over two classes,
+ * 0.77 of the HBM peak instead of 0.805).  Every statmc_malloc_placed of the role counts against it; 0 withdraws it.  Optional. */
+int statmc_placement_expect(int role, size_t bytes);
 typedef struct statmc_placement_info_t {
     int32_t active;          /* 1: slots are told apart and dealt by class */
     int32_t virtual_memory;  /* 1: the device maps physical allocations into reserved ranges (hipMemCreate / hipMemMap) */

@@ -79,7 +79,7 @@ EXPORTS = [
     "statmc_last_error", "statmc_setup", "statmc_device_cus", "statmc_set_device", "statmc_set_significance", "statmc_get_significance", "statmc_set_t_quantiles",
     "statmc_set_filter_spec", "statmc_get_filter_spec", "statmc_reset_filter_spec", "statmc_pinned_from", "statmc_copy_device_settings",
     "statmc_set_filter_split", "statmc_get_filter_split", "statmc_filter_split_auto",
-    "statmc_malloc", "statmc_free", "statmc_malloc_placed", "statmc_placement_info", "statmc_placement_map", "statmc_placement_trim", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_download",
+    "statmc_malloc", "statmc_free", "statmc_malloc_placed", "statmc_placement_expect", "statmc_placement_info", "statmc_placement_map", "statmc_placement_trim", "statmc_malloc_host", "statmc_free_host", "statmc_memset", "statmc_upload", "statmc_download",
     "statmc_stream_create", "statmc_stream_create_with_priority", "statmc_stream_destroy", "statmc_synchronize",
     "statmc_event_create", "statmc_event_destroy", "statmc_event_record", "statmc_stream_wait_event",
     "statmc_filter_f32", "statmc_filter_f32x3", "statmc_prepass", "statmc_window_filter", "statmc_pack_filter_inputs", "statmc_prepass_pack", "statmc_prepass_pack_rows",
@@ -121,6 +121,7 @@ def load():
     lib.statmc_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     lib.statmc_free.argtypes = [C.c_void_p]
     lib.statmc_malloc_placed.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_int]
+    lib.statmc_placement_expect.argtypes = [C.c_int, C.c_size_t]
     lib.statmc_placement_info.argtypes = [C.POINTER(PlacementInfo)]
     lib.statmc_malloc_host.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     lib.statmc_free_host.argtypes = [C.c_void_p]
@@ -411,6 +412,15 @@ def empty_placed(shape, dtype, device, role):
         if n == 0:
             return torch.empty(shape, dtype=dtype, device=device)
         return torch.as_tensor(blk, device=device)
+
+
+def placement_expect(role, nbytes, device=None):
+    """Announces the bytes about to be asked for in `role` (include/statmc.h: the class search is budgeted, and the arenas' class chosen, for all
+    of them at once)."""
+    import torch
+    idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+    with torch.cuda.device(idx):
+        check(load().statmc_placement_expect(int(role), int(nbytes)))
 
 
 def zeros_placed(shape, dtype, device, role):

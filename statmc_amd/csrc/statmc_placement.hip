@@ -138,6 +138,7 @@ struct Placement {
     std::map<size_t, std::pair<size_t, int>> live;   // offset -> (bytes, role)
     bool slot0_dealt = false;                // slot 0 behind its probe window belongs to the STATE role's free list
     int stream_class = -1;                   // kClassB or kClassC once the first STREAM block has chosen: the arenas' class on this device
+    size_t expect[2] = {0, 0};               // per role: bytes the caller has announced and not asked for yet (statmc_placement_expect)
     char *win_base = nullptr;                // the window range (GiB-aligned; nullptr: no second range, blocks need runs of slots)
     std::vector<int> win_slot;               // per window slot: the slot mapped there, -1 = free
     std::map<size_t, Window> windows;        // offset from win_base -> block
@@ -714,7 +715,11 @@ int placed_alloc(Placement &P, int role, size_t bytes, void **out, bool may_back
     // how many slots the search for the right class may have backed: the byte budget (3 x what has been asked for, or
     // STATMC_PLACEMENT_MAX_GIB), and never more than 60 % of the card for the first choice, 75 % at all (the rest of the process --
     // the caller's other allocations, the runtime's -- needs room too; beyond that: what is backed already, any class)
-    const size_t budget = may_back ? budget_slots(P, need) : 0;
+    // (what the caller has announced for this role counts as asked for: the class is then searched, and chosen, for ALL the arenas at
+    // once -- arena by arena the first one's budget of 3 x 6 + 6 GiB settles for the class that has six slots at hand, and the later ones
+    // for whatever is left: 16 slots of one class + 6 of the other, 0.77 of the HBM peak where one class for all gets 0.805)
+    const size_t outlook = std::max(need, P.expect[role]);
+    const size_t budget = may_back ? budget_slots(P, outlook) : 0;
     const size_t soft_cap = std::min<size_t>({kReserveSlots, (size_t)(0.60 * (double)P.total_bytes / (double)kSlot), budget});
     const size_t hard_cap = std::min<size_t>({kReserveSlots, (size_t)(0.75 * (double)P.total_bytes / (double)kSlot), budget});
     const size_t last_cap = may_back ? kReserveSlots : 0;
@@ -729,7 +734,7 @@ int placed_alloc(Placement &P, int role, size_t bytes, void **out, bool may_back
     if (role == STATMC_MEM_STREAM && !P.no_contrast && !getenv("STATMC_PLACEMENT_ROLES")) {
         int c = P.stream_class;
         if (c < 0) {
-            c = pick_stream_class(P, want_slots, soft_cap, 8ull << 30);
+            c = pick_stream_class(P, (outlook + kSlot - 1) / kSlot, soft_cap, 8ull << 30);
             if (want_slots >= 3) P.stream_class = c;       // an arena decides for the device; a small block takes what is at hand
         }
         if (c == kClassC) std::swap(cT, cU);
@@ -740,10 +745,15 @@ int placed_alloc(Placement &P, int role, size_t bytes, void **out, bool may_back
     const Search stream_order[] = {{bit(cT), soft_cap, true},                            // one class for all arenas
                                    {bit(cU), 0, true},                                   // ... or the other one
                                    {not_state, hard_cap, true},                          // both (still apart from the state)
+                                   // ... then slots that straddle classes -- at worst half of such a slot is the moments' class -- before
+                                   // anything of the moments' class itself (a card whose slots 34 .. 72 all read 1.03 - 1.06 x: the arenas
+                                   // went "as they came" into slots 1 - 6, slot 0's own run: 0.718 where torch's allocator got 0.77,
+                                   // profiles/r06_place_t2.json)
+                                   {not_state | bit(kMixed), 0, false},
                                    {kAnyClass, hard_cap, false}, {kAnyClass, last_cap, false}};
     int rc = STATMC_ERR_UNSUPPORTED;
     const Search *order = role == STATMC_MEM_STATE ? state_order : stream_order;
-    const int n_order = 5;
+    const int n_order = role == STATMC_MEM_STATE ? 5 : 6;
     // searching for a CLASS never takes the card's last 8 GiB (other allocators of the process need room); only the last resort --
     // any class, the request would fail otherwise -- goes down to half a GiB
     if (want_slots >= 3 && P.win_base) {                   // (a window takes whole slots: below 2 GiB a run of two is the better deal)
@@ -922,6 +932,7 @@ int statmc_malloc_placed(void **dev_ptr, size_t bytes, int role) {
         return STATMC_OK;
     }
     const int rc = placed_alloc(P, role, bytes, dev_ptr);
+    if (rc == STATMC_OK) P.expect[role] -= std::min(P.expect[role], bytes);
     if (rc != STATMC_OK && !P.vmm) {                       // the allocator retired during this very call (a trade that did not take): plain memory
         void *p = nullptr;
         if (hipError_t e = hipMalloc(&p, bytes); e != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
@@ -929,6 +940,15 @@ int statmc_malloc_placed(void **dev_ptr, size_t bytes, int role) {
         return STATMC_OK;
     }
     return rc;
+}
+
+int statmc_placement_expect(int role, size_t bytes) {
+    if (role != STATMC_MEM_STATE && role != STATMC_MEM_STREAM) return statmc::abi_fail(STATMC_ERR_INVALID, "role must be STATMC_MEM_STATE or STATMC_MEM_STREAM");
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return statmc::abi_fail(STATMC_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lk(g_place_mu);
+    g_place[dev].expect[role] = bytes;
+    return STATMC_OK;
 }
 
 int statmc_placement_info(statmc_placement_info_t *out) {
