@@ -1527,6 +1527,11 @@ def block_samples(args, layout, dev, types, rank, world, share=1):
         except Exception as e:      # noqa: BLE001  (placement is an optimisation: report and go on without)
             PLACED.update(on=False, error="%s: %s" % (type(e).__name__, str(e)[-300:]))
             samples = None
+        finally:
+            try:
+                api.placement_expect(api.MEM_STREAM, 0, dev)      # (what was announced and not asked for is withdrawn)
+            except Exception:      # noqa: BLE001
+                pass
     if samples is None:
         samples = {t: torch.empty((pool, H, W, synthetic.CHANNELS[t]), dtype=torch.float32, device=dev) for t in types}
     for s0 in range(0, pool, chunk):
