@@ -301,3 +301,21 @@ def test_a_window_at_addresses_another_window_left_reaches_its_own_memory():
             "print('ok', same_addresses, n, api.placement_info()['map'])\n" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr[-2000:]
+
+
+def test_placement_expect_announces_a_total(gpu):
+    """statmc_placement_expect (include/statmc.h): argument checks; an announced total is counted down by the role's allocations and
+    changes nothing about the blocks themselves."""
+    lib = gpu.load()
+    assert lib.statmc_placement_expect(7, 1 << 30) == gpu.ERR_INVALID
+    dev = torch.device("cuda:0")
+    gpu.placement_expect(gpu.MEM_STREAM, 3 << 30, dev)
+    a = gpu.empty_placed((1 << 28,), torch.float32, dev, gpu.MEM_STREAM)
+    b = gpu.empty_placed((1 << 28,), torch.float32, dev, gpu.MEM_STREAM)
+    a.fill_(1.0)
+    b.fill_(2.0)
+    torch.cuda.synchronize()
+    assert float(a[::4097].sum().item()) == float(a[::4097].numel()) and float(b[::4097].min().item()) == 2.0
+    gpu.placement_expect(gpu.MEM_STREAM, 0, dev)
+    info = gpu.placement_info()
+    assert info["live_bytes"][gpu.MEM_STREAM] >= 2 << 30
