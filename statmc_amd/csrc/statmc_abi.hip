@@ -738,7 +738,8 @@ static int window_filter_impl(const statmc_filter_args *a, int channels) {
     // range weight over THREE buffers, 2.47 ms -- the last three go to it: 5 buffers 1.40 + 2.47 instead of 1.40 + 1.40 + 1.39 ms
     // (round 6).  Only with the whole window sweep in one part there (no partial-sum workspace to share with the patches) and no forced
     // variant; the two kernels agree to 5e-7, each within 1e-5 of the oracle.
-    const bool mix = sym && channels == 1 && lds_ok && dstate.force_variant == 0 && (a->n_buffers & 1) && a->n_buffers >= 3 && k_lds.n_parts == 1 &&
+    static const bool mix_allowed = [] { const char *e = getenv("STATMC_FLOAT_MIX"); return !(e && e[0] == '0'); }();   // (A/B: tools/experiments/time_float.py)
+    const bool mix = mix_allowed && sym && channels == 1 && lds_ok && dstate.force_variant == 0 && (a->n_buffers & 1) && a->n_buffers >= 3 && k_lds.n_parts == 1 &&
                      statmc::lds_path_selected(k_lds, channels);
     statmc::FilterArgs k_tail = k_lds;
     statmc::FilterArgs &k_pairs = k;
