@@ -62,6 +62,24 @@ def new_film_stats(W, H, dev, types, **kw):
     return film.FilmStats(W, H, dev, types=types, placed=PLACED["on"], **kw)
 
 
+def new_arenas(S, H, W, dev, types):
+    """One sample arena per stat type, their total announced first (statmc_placement_expect: ONE class is searched for all of them)."""
+    from statmc_amd import api, synthetic
+    if PLACED["on"]:
+        try:
+            api.placement_expect(api.MEM_STREAM, sum(4 * S * H * W * synthetic.CHANNELS[t] for t in types), dev)
+        except Exception:      # noqa: BLE001
+            pass
+    try:
+        return {t: new_arena((S, H, W, synthetic.CHANNELS[t]), dev) for t in types}
+    finally:
+        if PLACED["on"]:
+            try:
+                api.placement_expect(api.MEM_STREAM, 0, dev)
+            except Exception:      # noqa: BLE001
+                pass
+
+
 def new_arena(shape, dev):
     """A sample arena (float32), placed like the timed step's."""
     from statmc_amd import api
@@ -540,7 +558,7 @@ def accumulate_by_batch_4k(args, dev, types):
     if free_b < 3 * 4 * args.channels * W * H * S:
         return {"skipped": "not enough free memory for a 4K / 64-spp pool (%.0f GiB free)" % (free_b / 2 ** 30)}
     scene = synthetic.Scene(W, H, n_regions=12, seed=1, device=dev)
-    smp = {t: new_arena((S, H, W, synthetic.CHANNELS[t]), dev) for t in types}
+    smp = new_arenas(S, H, W, dev, types)
     for s0 in range(0, S, 16):
         part = scene.samples(16, seed=77 + s0, features=types)
         for t in types:
@@ -632,7 +650,7 @@ def config_step_leg(W, H, S, dev, types, args, name, reps, smp=None):
     own = smp is None
     if own:
         scene = synthetic.Scene(W, H, n_regions=12, seed=1, device=dev)
-        smp = {t: new_arena((S, H, W, synthetic.CHANNELS[t]), dev) for t in types}
+        smp = new_arenas(S, H, W, dev, types)
         for s0 in range(0, S, 16):
             part = scene.samples(min(16, S - s0), seed=77 + s0, features=types)
             for t in types:
