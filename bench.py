@@ -1599,9 +1599,19 @@ def placement_report():
                        state_GiB=round(info["slab_bytes"][0] / 2 ** 30, 1), stream_GiB=round(info["slab_bytes"][1] / 2 ** 30, 1), map=info["map"],
                        slots_released=info["slots_released"], trimmed_before_timing=PLACED.get("trimmed"), trim_error=PLACED.get("trim_error"),
                        peak_slots=info["peak_slots"], rebased=bool(info["rebased"]),
+                       state_live_GiB=round(info["live_bytes"][0] / 2 ** 30, 2), stream_live_GiB=round(info["live_bytes"][1] / 2 ** 30, 2),
                        budget="3 x the bytes asked for + 6 GiB (STATMC_PLACEMENT_MAX_GIB=%s)" % os.environ.get("STATMC_PLACEMENT_MAX_GIB", "unset"),
                        what="running moments in GiB slots of class A, sample arenas in ONE of the other two classes -- the one the card has at hand -- (a stream read beside writes into its own "
                             "class runs ~ 9 % slower on MI355X; the class travels with the physical memory -- most likely its HBM rank -- and is measured per GiB, 0.2 ms each)")
+            # where the window filter's workspace (patch sums) lives: a block of the state role, or plain hipMalloc memory (role -1)
+            import ctypes as C
+            lib = api.load()
+            wp, wb = C.c_void_p(), C.c_size_t()
+            lib.statmc_debug_last_workspace.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+            lib.statmc_debug_placement_role.restype = C.c_int
+            lib.statmc_debug_placement_role.argtypes = [C.c_void_p]
+            if lib.statmc_debug_last_workspace(C.byref(wp), C.byref(wb)) == 0 and wp.value:
+                out["filter_workspace"] = {"MiB": round(wb.value / 2 ** 20, 1), "role": int(lib.statmc_debug_placement_role(wp))}
         except Exception as e:      # noqa: BLE001
             out["info_error"] = repr(e)[:200]
     return out
