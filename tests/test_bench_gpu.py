@@ -54,6 +54,7 @@ def test_single_gpu_line(gpu):
     pl = r["placement"]
     if pl.get("active"):
         assert pl["slots_idle"] == 0 and pl["trimmed_before_timing"] is not None and pl["slots"] <= 12, pl
+        assert "skipped" in pl["check"]       # (a test-sized pool: too short to tell two sets of buffers apart)
     ab = r["accumulate_placement_ab"]
     assert ab["placed_ms"] > 0 and ab["unplaced_ms"] > 0 and r["kernels"]["accumulate"]["unplaced_frac_hbm"] == ab["unplaced_frac_hbm"]
     # ... and the pre-pass in the accumulation's epilogue: no launch of its own in the step, the same bits (the CPU leg's
@@ -63,6 +64,23 @@ def test_single_gpu_line(gpu):
     rs = r["reference_schedule"]
     assert rs["batches"] == [4, 4] and rs["iterations"] == 2 and rs["ms_per_step"] > 0 and 0 < rs["filter_share"] < 1
     assert abs(rs["accumulate_ms"] + rs["prepass_ms"] + rs["filter_ms"] - rs["ms_per_step"]) < 0.5 * rs["ms_per_step"]
+
+
+def test_placement_check_can_hand_the_step_to_the_allocators_memory(gpu):
+    """bench.py runs the step on the placed buffers and on copies from torch's allocator before it times, and the faster set goes on
+    (one card in six gives the placed allocator little to choose from).  The other branch, forced: the line says
+    which set ran, the placed blocks are gone, every later leg runs on plain memory."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + COMMON + ["--no-cpu-baseline"], capture_output=True, text=True,
+                         timeout=360, env=dict(os.environ, STATMC_BENCH_CHECK_PICKS="allocator"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = _line(out)
+    pl = r["placement"]
+    if "check" in pl and "skipped" not in pl["check"]:      # (a device without virtual-memory management has nothing to check)
+        assert pl["check"]["chosen"] == "torch's allocator" and pl["check"]["forced"] and pl["timed_region_ran_on"] == "torch's allocator"
+        assert pl["check"]["placed_ms"] > 0 and pl["check"]["allocator_ms"] > 0
+        assert set(pl["map_after_release"]) <= set("#_")          # only the allocator's own slots are still backed
+        assert "skipped" in r["accumulate_placement_ab"]
+    assert r["value"] > 0 and r["reference_schedule"]["ms_per_step"] > 0
 
 
 def test_step_fed_by_tile_blocks(gpu, tmp_path):
