@@ -24,8 +24,11 @@ int statmc_debug_last_filter_parts(void);
 /* ... and its tail split: the last *tail_rows tile rows of the image swept with *parts_hi parts (0, 0: uniform). */
 int statmc_debug_last_filter_tail(int *parts_hi, int *tail_rows);
 
-/* Film-major accumulation: n > 0 runs it as n resident workgroups (0 = the large interleaved grid, default). */
+/* Film-major accumulation: n > 0 runs it as n resident workgroups; 0 = by shape (default: the large interleaved grid, or one
+ * workgroup per compute unit on 1080p-sized films of placed buffers from 256 samples per launch up); -1 = never a resident grid. */
 int statmc_debug_accumulate_resident_blocks(int n);
+/* Workgroups of the calling thread's last statmc_accumulate launch (which launch shape the sizes chose: DESIGN.md 4.1). */
+int statmc_debug_last_accumulate_grid(void);
 /* 1 (default): RGB sample planes stream through LDS-DMA; 0: loads into registers (same bits). */
 int statmc_debug_accumulate_dma(int on);
 /* Film-major launch shape: grid_mode -1 = chosen by the batch length (default); 1 = one pass per workgroup, stat types

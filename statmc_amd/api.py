@@ -225,7 +225,7 @@ def force_filter_variant(v):
 
 
 def accumulate_resident_blocks(n):
-    """0: default large grid; n > 0: the accumulate kernel runs as n resident workgroups."""
+    """0: by shape (default); n > 0: the accumulate kernel runs as n resident workgroups; -1: never a resident grid."""
     check(load().statmc_debug_accumulate_resident_blocks(int(n)))
 
 

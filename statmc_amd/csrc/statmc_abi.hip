@@ -1332,6 +1332,7 @@ int statmc_accumulate_row_ranges(uint16_t width, uint16_t height, const statmc_s
     }
     if (k.n_types == 0) return STATMC_OK;
     k.resident_blocks = dstate.acc_resident_blocks;
+    k.cus = dstate.cus;
     k.umul = dstate.acc_umul;
     k.dma = dstate.acc_dma;
     k.grid_mode = dstate.acc_grid_mode;
@@ -1463,9 +1464,10 @@ int statmc_filter_split_auto(int width, int height, int radius) {
 int statmc_debug_force_filter_variant(int v) {  // 0 auto, 1 generic, 2 runtime-radius one-sided LDS, 3 one-sided r = 20
     STATMC_DEBUG_SET(d.force_variant = v);
 }
-int statmc_debug_accumulate_resident_blocks(int n) {  // 0 large grid (default), n > 0: n resident workgroups
-    STATMC_DEBUG_SET(d.acc_resident_blocks = n < 0 ? 0 : n);
+int statmc_debug_accumulate_resident_blocks(int n) {  // 0 by shape (default), n > 0: n resident workgroups, -1: never a resident grid
+    STATMC_DEBUG_SET(d.acc_resident_blocks = n < 0 ? -1 : n);
 }
+int statmc_debug_last_accumulate_grid(void) { return (int)statmc::last_accumulate_grid(); }
 int statmc_debug_accumulate_dma(int on) {   // 1 (default): RGB sample planes stream through LDS-DMA; 0: loads into registers; 3 .. 6: that ring depth (experiment builds)
     STATMC_DEBUG_SET(d.acc_dma = on < 0 ? 1 : on > 6 ? 6 : on == 2 ? 1 : on);
 }

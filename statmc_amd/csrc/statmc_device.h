@@ -46,7 +46,8 @@ constexpr int kMaxSlots = 64;
 struct AccumulateArgs {
     AccumulateType t[kMaxStatTypes];
     int n_types;
-    int resident_blocks;  // 0: large interleaved grid; > 0: that many workgroups walk all types
+    int resident_blocks;  // 0: by shape (launch_accumulate); > 0: that many workgroups walk all types; -1: never (A/B)
+    int cus;              // compute units of the device (the resident grid's size where the shape calls for one)
     int umul;             // 2: the mean-only feature types prefetch twice as deep (statmc_debug_accumulate_umul; A/B)
     int dma;              // RGB sample planes arrive by LDS-DMA (default 1; 0: loads into registers, A/B)
     int grid_mode;        // -1: by batch length (default); 0: capped grid, slots per type in proportion to cost, grid-stride; 1: one pass per workgroup, types round-robin
@@ -195,6 +196,7 @@ const float *t_table_sq_device_ptr(int table);  // ... of its squares (fl(t * t)
 hipError_t launch_prepass(const PrepassArgs &a, hipStream_t s);
 hipError_t launch_mean_vars(const MeanVarsArgs &a, hipStream_t s);
 hipError_t launch_accumulate(const AccumulateArgs &a, hipStream_t s);
+unsigned last_accumulate_grid();
 hipError_t launch_accumulate_tiles(const AccumulateTilesArgs &a, hipStream_t s);
 hipError_t launch_merge_tiles(const MergeTilesArgs &a, int n_tiles, int max_tile_pixels, hipStream_t s);
 hipError_t launch_tile_moments(const TileMomentsArgs &a, hipStream_t s);

@@ -745,6 +745,9 @@ __global__ __launch_bounds__(kBlock, OCC) void accumulate_kernel(AccumulateArgs 
 
 int acc_diagnostic_bits() { return STATMC_ACC_SKIP_STORES ? 128 : 0; }
 
+static thread_local unsigned g_last_acc_grid = 0;
+unsigned last_accumulate_grid() { return g_last_acc_grid; }   // workgroups of the calling thread's last film-major launch (tests)
+
 hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
     AccumulateArgs a = a_in;
     // slots per type ~ relative cost: 4 B x channels per sample, x1.3 for transform types
@@ -794,12 +797,21 @@ hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
     // Round 5: with the samples and the moments in different interference classes (a.apart: statmc_malloc_placed blocks) the one-pass
     // shape also wins on 4K films at every batch length (+ 1 - 5 %) and on long batches at 1080p (256 spp: 3.61 against 3.67 - 3.70
     // ms); 32 - 64 samples on films up to 1080p keep the capped grid (+ 1.5 - 2.5 %).  Three processes, profiles/r05_acc_launch_placed.log.
+    // Round 6, last session: ONE workgroup per CU walking every type (four waves per CU, half the occupancy) on 1080p-sized films from
+    // 256 samples per launch up, placed buffers: the accumulation 3.72 - 3.73 against 3.77 - 3.78 ms in the step, three rounds on each of
+    // two boxes with the same placement (profiles/r06_ab_resident.log, r06_ab_resident2.log; round 5 had seen 3.57 / 3.62 and 3.74 / 3.76
+    // back to back and left it an experiment hook: it loses at 720p -- 900 units on 256 workgroups -- and at 4K).  Fewer CUs than all
+    // starve the stream (192 workgroups: 4.17 ms) though the filter behind it then holds 2.15 instead of 1.98 GHz (1.49 against 1.61 ms).
+    if (a.resident_blocks == 0 && a.grid_mode < 0 && a.apart && a.cus > 0 && max_s >= 256 && max_groups >= (1 << 18) && max_groups < (1 << 20))
+        a.resident_blocks = a.cus;
+    if (a.resident_blocks < 0) a.resident_blocks = 0;
     if (a.grid_mode < 0) {
         const bool big = max_groups >= (1 << 20);
         if (a.apart) a.grid_mode = (max_s <= 16 || big || max_s >= 128) ? 1 : 0;
         else a.grid_mode = (max_s <= 8 || (max_s <= 16 && !big)) ? 1 : 0;
     }
     const dim3 grid(a.resident_blocks > 0 ? a.resident_blocks : a.grid_mode == 1 ? (unsigned)(units * a.n_types) : rounds * a.n_slots);
+    g_last_acc_grid = grid.x;
     // a.dma: 0 = loads into registers (A/B), 1 = the default ring depth, 3 .. 6 = that depth where the build holds it
     // (STATMC_ACC_DMA_DEPTHS: experiment builds instantiate every depth, the product build the default one)
     const int depth = a.dma == 1 ? kAccDmaD : a.dma;

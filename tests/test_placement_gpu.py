@@ -327,3 +327,36 @@ def test_random_allocations_and_frees_never_share_memory():
     (tools/experiments/alloc_soak.py; 200 steps, 44 windows: profiles/r06_alloc_soak.log)."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "experiments", "alloc_soak.py"), "48"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok 48" in out.stdout, out.stdout + out.stderr[-2000:]
+
+
+def test_headline_shape_takes_the_resident_grid_and_leaves_the_same_bits(gpu):
+    """1080p, 256 samples per launch, samples in a STREAM block and moments in STATE blocks: the accumulation runs as one workgroup per
+    compute unit (launch_accumulate, round 6) -- the same bits as the large grid, which every other shape keeps."""
+    from statmc_amd import film, synthetic
+    lib = gpu.load()
+    dev = torch.device("cuda:0")
+    W, H, S = 1920, 1080, 256
+    types = ["radiance"]
+    smp = {"radiance": gpu.empty_placed((S, H, W, 3), torch.float32, dev, gpu.MEM_STREAM)}
+    scene = synthetic.Scene(W, H, seed=5, device=dev)
+    for s0 in range(0, S, 32):
+        smp["radiance"][s0:s0 + 32] = scene.samples(32, seed=100 + s0, features=types)["radiance"]
+    fs_a = film.FilmStats(W, H, dev, types=types, placed=True)
+    fs_b = film.FilmStats(W, H, dev, types=types, placed=True)
+    fs_a.accumulate(smp)
+    grid_auto = lib.statmc_debug_last_accumulate_grid()
+    gpu.accumulate_resident_blocks(-1)
+    try:
+        fs_b.accumulate(smp)
+        grid_large = lib.statmc_debug_last_accumulate_grid()
+    finally:
+        gpu.accumulate_resident_blocks(0)
+    fs_a.accumulate({"radiance": smp["radiance"][:64]})      # a shorter batch keeps the large grid
+    grid_short = lib.statmc_debug_last_accumulate_grid()
+    fs_b.accumulate({"radiance": smp["radiance"][:64]})
+    torch.cuda.synchronize()
+    if gpu.placement_info()["active"] and lib.statmc_debug_placement_role(C.c_void_p(smp["radiance"].data_ptr())) == gpu.MEM_STREAM:
+        assert grid_auto == lib.statmc_device_cus() and grid_large > 4 * grid_auto and grid_short > 4 * grid_auto, (grid_auto, grid_large, grid_short)
+    for k, v in fs_a.state["radiance"].items():
+        if v is not None:
+            assert torch.equal(v.view(torch.int32), fs_b.state["radiance"][k].view(torch.int32)), k
