@@ -802,8 +802,13 @@ hipError_t launch_accumulate(const AccumulateArgs &a_in, hipStream_t s) {
     // two boxes with the same placement (profiles/r06_ab_resident.log, r06_ab_resident2.log; round 5 had seen 3.57 / 3.62 and 3.74 / 3.76
     // back to back and left it an experiment hook: it loses at 720p -- 900 units on 256 workgroups -- and at 4K).  Fewer CUs than all
     // starve the stream (192 workgroups: 4.17 ms) though the filter behind it then holds 2.15 instead of 1.98 GHz (1.49 against 1.61 ms).
-    if (a.resident_blocks == 0 && a.grid_mode < 0 && a.apart && a.cus > 0 && max_s >= 256 && max_groups >= (1 << 18) && max_groups < (1 << 20))
-        a.resident_blocks = a.cus;
+    // Only there: at 128 samples a tie, at 64 slower (1.044 against 1.016 ms); 1280 x 720, 2560 x 1440 (14.06 walks per workgroup: the
+    // fifteenth is nearly empty) and 3840 x 2160 slower by 2 - 6 % (profiles/r06_ab_resident_spp.log).  So: the film's groups must fill the
+    // workgroups' last walk (>= 97 %), and the film must be of about that size.
+    if (a.resident_blocks == 0 && a.grid_mode < 0 && a.apart && a.cus > 0 && max_s >= 256 && max_groups >= (1 << 18) && max_groups < 3 * (1 << 18)) {
+        const double walks = (double)max_groups / ((double)a.cus * kBlock);
+        if (walks / ceil(walks) >= 0.97) a.resident_blocks = a.cus;
+    }
     if (a.resident_blocks < 0) a.resident_blocks = 0;
     if (a.grid_mode < 0) {
         const bool big = max_groups >= (1 << 20);
