@@ -120,7 +120,11 @@ constexpr bool mode_pair(int m) { return m == 1 /* kModePair */ || m == kModeWel
 // eight-plane build where the whole film with the same G-buffers runs the six-plane one, and the two must leave the same bits
 // (tests/test_peer_gpu.py caught a per-build G).  So ONE G for every build -- 6: best or within 1 % of the best everywhere -- and
 // only the housekeeping's place, which changes no sum, is chosen per build.
-constexpr int gsplit_of(int, int) { return kGSplitForced >= 0 ? kGSplitForced : 6; }
+// ... with ONE exception, decided by the G-buffer SET and not by the build (the last session of round 6): a call whose G-buffers are
+// exactly two RGB images -- the shipped normal + albedo -- runs a six-plane build whether it filters the whole film or a 15-channel block +
+// halo image, so those calls may have a G of their own: 7 under the default and the pooled test (G7 builds; 1.603 - 1.611 against 1.641 -
+// 1.650 ms in the step at 1080p, three A/B pairs, profiles/r06_ab_g7_step.log).  Every other set keeps 6 in every build.
+constexpr int gsplit_of(int, int, bool g7 = false) { return kGSplitForced >= 0 ? kGSplitForced : g7 ? 7 : 6; }
 constexpr bool hk_at_end(int mode, int ng) {
     if (kHkAtEndForced >= 0) return kHkAtEndForced != 0;
     return ng == 6 && !mode_pair(mode);
@@ -769,7 +773,7 @@ __device__ __forceinline__ void sweep_groups(LaneT &st, const float *row, const 
 // read groups a half sweeps are groups [j_lo, 4] + the cut group 5 (half 0) and the cut group 5 + groups [6, j_hi] (half 1),
 // where j_lo / j_hi are the outermost groups that hold a tap with |dx| <= r; taps of those groups beyond r carry a
 // spatial exponent of -inf in the table (weight 0).
-template <int HF, int MODE, int NG, bool RT, class LaneT>
+template <int HF, int MODE, int NG, bool RT, bool G7, class LaneT>
 __device__ __forceinline__ void eval_half_row(LaneT &st, const float *row, const float *tab, float *qrow, bool dy0, int j_lo, int j_hi, const WelchTab &tq2) {
     constexpr bool kPipe = sym::kPipe && !mode_welch(MODE);
     if constexpr (RT) {
@@ -813,7 +817,7 @@ __device__ __forceinline__ void eval_half_row(LaneT &st, const float *row, const
         }
         return;
     }
-    constexpr int kGSplit = gsplit_of(MODE, NG);
+    constexpr int kGSplit = gsplit_of(MODE, NG, G7);
     if constexpr (kGSplit > 0) {   // the split at a read-group boundary (dy = 0: the pairs inside the row stay with half 1)
         static_assert(kSplit == 0 && kGSplit < kChunks - 1, "one split at a time");
         if (dy0) {
@@ -1022,8 +1026,10 @@ __device__ __forceinline__ Staged raw_pixel(const FilterArgs &a, const Feat &F, 
 // PAIR = filter<float>, two 1-channel buffers per launch: the (x, y) channels of the three statistics / colour images
 // hold buffer 0 and buffer 1 (pack_pair_kernel), the third channel is empty; the buffers share the range weight, gate
 // and normalise separately.
-template <bool DMA, int MODE, int NG, bool RT>
+// G7: the call's G-buffers are exactly two RGB images (see gsplit_of): the window is shared after read group 7, not 6
+template <bool DMA, int MODE, int NG, bool RT, bool G7 = false>
 __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
+    static_assert(!G7 || (!RT && NG == 6 && (MODE == kModeRgb || MODE == kModeJoint)), "G7 builds: r = 20, six planes, the symmetric gate on one RGB buffer");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // Welch (band build): the quantile band sits at LDS address 0 -- a look-up's byte offset is its address -- and the
     // ring behind it
@@ -1277,9 +1283,9 @@ __global__ __launch_bounds__(kThreads, 2) void window_filter_sym(FilterArgs a) {
             const float *tab = tab_lds + ((s - s_a) & 1) * kTabPad;
             if (kAblate & 8) {
             } else if (half == 0) {
-                eval_half_row<0, MODE, NG, RT>(st, row, tab, qrow, s == 0, j_lo, j_hi, tq2);
+                eval_half_row<0, MODE, NG, RT, G7>(st, row, tab, qrow, s == 0, j_lo, j_hi, tq2);
             } else {
-                eval_half_row<1, MODE, NG, RT>(st, row, tab, qrow, s == 0, j_lo, j_hi, tq2);
+                eval_half_row<1, MODE, NG, RT, G7>(st, row, tab, qrow, s == 0, j_lo, j_hi, tq2);
             }
 
             if constexpr (kStamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_ev += t - tk0; tk0 = t; }
@@ -1644,6 +1650,11 @@ hipError_t launch_sym(FilterArgs a, hipStream_t s) {
 #undef STATMC_SYM_ROW
 #undef STATMC_SYM_K
     const void *kernel = kernels[rt ? 1 : 0][g8 ? 1 : 0][dma ? 1 : 0][mode];
+    // exactly two RGB G-buffers (whole film, or its 15-channel block + halo image), r = 20, the symmetric gate on one RGB buffer: the G7 builds
+    if (!rt && !g8 && !welch && a.n_g == 2 && a.g[0].channels == 3 && a.g[1].channels == 3 && (mode == kModeRgb || mode == kModeJoint)) {
+        if (mode == kModeRgb) kernel = dma ? reinterpret_cast<const void *>(&window_filter_sym<true, kModeRgb, 6, false, true>) : reinterpret_cast<const void *>(&window_filter_sym<false, kModeRgb, 6, false, true>);
+        else kernel = dma ? reinterpret_cast<const void *>(&window_filter_sym<true, kModeJoint, 6, false, true>) : reinterpret_cast<const void *>(&window_filter_sym<false, kModeJoint, 6, false, true>);
+    }
     const void *kernel_far = nullptr;
     if (welch) {   // (the gate field has no meaning under Welch: there is one test, symmetric in the pair)
         if (a.sym.redo == nullptr) return hipErrorInvalidValue;
