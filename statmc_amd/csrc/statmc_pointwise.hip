@@ -711,7 +711,14 @@ __global__ __launch_bounds__(kBlock, OCC) void accumulate_kernel(AccumulateArgs 
     float *ring = DMA ? acc_lds + (threadIdx.x >> 6) * acc_ring_floats(DMA) : nullptr;
     if (a.resident_blocks > 0) {
         for (int i = 0; i < a.n_types; i++) {
-            const AccumulateType t = a.t[(blockIdx.x + i) % a.n_types];   // (by value: see below)
+#ifndef STATMC_ACC_RESIDENT_START
+#define STATMC_ACC_RESIDENT_START 0
+#endif
+            // (which type a workgroup starts with: 0 = its index, so that every type is walked by a fifth of the grid at any time; experiment
+            // builds: 1 = every workgroup the same type -- 3.92 against 3.75 ms --, 2 = the eight workgroups of a dispatch round -- one per
+            // XCD -- the same type: no difference; profiles/r06_ab_resident_start.log)
+            const int first = STATMC_ACC_RESIDENT_START == 1 ? 0 : STATMC_ACC_RESIDENT_START == 2 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+            const AccumulateType t = a.t[(first + i) % a.n_types];   // (by value: see below)
             if (t.channels == 3) accumulate_dispatch<3, VEC, UMUL, DMA>(t, blockIdx.x, gridDim.x, ring, a.dma_first != 0);
             else accumulate_dispatch<1, VEC, UMUL, DMA>(t, blockIdx.x, gridDim.x, ring, a.dma_first != 0);
         }
