@@ -385,8 +385,8 @@ bool init(Placement &P, int dev) {
 
 // Nothing is classified before BOTH levels of the probe have been seen: the classes come in runs of 4 .. 64 slots, so the
 // first dozen slots may well all be of one class -- slot 0's or not -- and one level alone does not say which.  Slots are
-// backed until a probe differs from the fastest by the distance of the two levels; none after kCalibrationCap: no classes to
-// tell apart on this device.
+// backed until there is a tight cluster of fast probes (fast_level) and the other level has been seen beside it (calibrate); none
+// after kCalibrationCap: no classes to tell apart on this device.
 void add_free(std::map<size_t, size_t> &fl, size_t off, size_t len);
 
 hipError_t probe_self(Placement &P);
@@ -440,7 +440,8 @@ hipError_t rebase(Placement &P, size_t k) {
 // processes in a row on one box declared "no contrast" after 96 probes -- slot 0 sat in a class of which the card's first 96 GiB held
 // one more slot or none (probe_ms 0.178 .. 0.194 and 0.176 .. 0.181), and the rule "both levels on two slots each" never fired;
 // everything came unclassified and the accumulation ran at 0.73 of the HBM peak (profiles/r06_bench_j1.json, _j2).  A reference in a
-// RARE class is the best case, not a failure: with this probe two slots clearly faster than it are proof enough of contrast.
+// RARE class is the best case, not a failure: with this probe a tight cluster of three slots 8 % faster than it is proof enough of
+// contrast (calibrate).
 hipError_t probe_self(Placement &P) {
     float best = 1e30f;
     hipError_t err = hipSuccess;
